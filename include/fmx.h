@@ -1,0 +1,155 @@
+/*
+ * fmx.h -- C ABI of libfmx: the MI355X (gfx950) implementation of sdr-j-fm's FM processing
+ * chain (reference: /root/reference/src/fm/fm-processor.cpp:373-759 and the leaf classes in
+ * src/various).  One fmx handle owns N independent FM channels ("fmProcessor" instances) that
+ * are demodulated as one batch on one GPU.
+ *
+ * Each entry point names the reference interface it replaces (file:line relative to the
+ * reference tree).  No C++, Qt or torch types cross this boundary: plain pointers and sizes.
+ *
+ * Threading: exactly one processing thread per handle (the adapter's QThread replacing
+ * fmProcessor::run()).  fmx_set_param may be called from any thread; values take effect at the
+ * next fmx_process_* call, mirroring the settings mailbox of fm-processor.cpp:396-413.
+ * Ownership: the caller owns every in/out buffer; the handle owns all device memory and state.
+ * Errors: 0 = FMX_OK, negative = error; text via fmx_last_error().  There is NO CPU fallback:
+ * every call fails with FMX_E_NO_DEVICE / FMX_E_HIP when the GPU path is unavailable.
+ */
+#ifndef FMX_H
+#define FMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMX_ABI_VERSION 1
+
+typedef struct fmx_handle_s *fmx_handle;
+
+enum {
+    FMX_OK = 0,
+    FMX_E_INVALID = -1,        /* bad argument / unknown parameter id / out-of-range value */
+    FMX_E_UNSUPPORTED = -2,    /* a setting of the reference this build does not implement */
+    FMX_E_NO_DEVICE = -3,      /* no HIP device: the product path never falls back to the CPU */
+    FMX_E_HIP = -4,            /* HIP runtime error (text in fmx_last_error) */
+    FMX_E_NOMEM = -5,
+    FMX_E_TOO_LARGE = -6,      /* n > max_block, or pcm capacity too small */
+};
+
+/* Construction arguments: replaces the fmProcessor constructor
+ * (fm-processor.cpp:48-63; GUI values radio.cpp:231-252,915-930).  Only the DSP-relevant
+ * arguments exist here; the scope ring buffers / Qt objects stay in the adapter. */
+typedef struct {
+    int32_t struct_size;       /* sizeof(fmx_config), for ABI growth */
+    int32_t device;            /* HIP device ordinal */
+    int32_t channels;          /* number of FM channels in this batch (>=1) */
+    int32_t streams;           /* number of distinct IQ input streams; 0 => one per channel */
+    const int32_t *stream_of_channel; /* [channels] or NULL (identity); several channels may share a
+                                  wide-band stream and differ in set_localOscillator (BASELINE config 3) */
+    int32_t inputRate;         /* 2304000 (fm-constants.h:35); the only rate this build accepts */
+    int32_t fmRate;            /* 192000 */
+    int32_t workingRate;       /* 48000 */
+    int32_t audioRate;         /* 48000 (== workingRate: sendSampletoOutput's direct path, :826-829) */
+    int32_t max_block;         /* max complex samples per stream per call (reference block = 16384, :374) */
+} fmx_config;
+
+/* One id per fmProcessor setter (fm-processor.h:104-156).  Values are passed as double. */
+typedef enum {
+    FMX_P_FM_MODE = 1,         /* setfmMode: 0 Stereo, 1 StereoPano, 2 Mono          (:241-243)  */
+    FMX_P_FM_DECODER = 2,      /* fm_Demodulator::setDecoder: 1 AM 2 PLL 3 Mixed 4 ComplexBB 5 RealBB 6 Diff
+                                  (fm-demodulator.cpp:27-44,93-103); AM is FMX_E_UNSUPPORTED */
+    FMX_P_SOUND_MODE = 3,      /* setSoundMode: Channels enum 0..6                   (:273-275)  */
+    FMX_P_STEREO_PANORAMA = 4, /* setStereoPanorama 0..200                           (:277-280)  */
+    FMX_P_SOUND_BALANCE = 5,   /* setSoundBalance -100..100                          (:282-286)  */
+    FMX_P_DEEMPHASIS = 6,      /* setDeemphasis, microseconds >= 1                   (:291-297)  */
+    FMX_P_VOLUME_DB = 7,       /* setVolume, dB                                      (:299-301)  */
+    FMX_P_LF_CUTOFF = 8,       /* setlfcutoff, Hz; <= 0 switches the audio filter off (:762-770) */
+    FMX_P_BANDWIDTH = 9,       /* setBandwidth, Hz (the GUI's "165kHz" -> 165000); 0 = "Off" (:232-239) */
+    FMX_P_ATTENUATION_L = 10,  /* setAttenuation (Lgain)                             (:351-359)  */
+    FMX_P_ATTENUATION_R = 11,  /* setAttenuation (Rgain)                                         */
+    FMX_P_RDS_MODE = 12,       /* setfmRdsSelector: 0 off, 1..3                      (:840-847)  */
+    FMX_P_LOCAL_OSCILLATOR = 13,/* set_localOscillator, Hz                           (:866-868)  */
+    FMX_P_AUTO_MONO = 14,      /* setAutoMonoMode                                    (:914-916)  */
+    FMX_P_PSS = 15,            /* setPSSMode                                         (:918-920)  */
+    FMX_P_DC_REMOVE = 16,      /* setDCRemove (also zeroes RfDC)                     (:922-925)  */
+    FMX_P_SQUELCH_MODE = 17,   /* set_squelchMode: only 0 (OFF) accepted, else FMX_E_UNSUPPORTED */
+    FMX_P_TEST_TONE = 18,      /* setTestTone: only 0 accepted                                   */
+    /* actions (value ignored) */
+    FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
+    FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */
+    FMX_A_RESET_RDS = 102,                /* resetRds               (:862-864) */
+} fmx_param_id;
+
+/* What fmProcessor reports upward: SMetaData (fm-processor.h:91-101, emitted :662-684) */
+typedef struct {
+    float   DcValRf, DcValIf, PssPhaseShiftDegree, PssPhaseChange;
+    int32_t PssState;          /* 0 OFF, 1 ANALYZING, 2 ESTABLISHED */
+    float   PilotPllLockStrength;
+    int32_t PilotPllLocked;
+    int64_t fm_samples;        /* fm-rate samples processed so far */
+    int64_t pcm_frames;        /* PCM frames produced so far */
+} fmx_meta;
+
+typedef enum {
+    FMX_TAP_FM_IQ = 0,         /* complex @fmRate after fmBand_2 (IF_FILTERED scope, :601-604)   */
+    FMX_TAP_DEMOD = 1,         /* float   @fmRate after demodulate (DEMODULATOR scope, :605-607) */
+    FMX_TAP_LR_RAW = 2,        /* complex @fmRate (sum,diff) (AF_SUM/AF_DIFF scopes, :608-613)   */
+    FMX_TAP_PRE_RESAMPLER = 3, /* complex @fmRate after de-emphasis + gain (:594-595,630); this
+                                  build applies the audio low-pass AFTER this point */
+} fmx_tap_id;
+
+/* per-kernel timing collected with HIP events on the processing stream */
+typedef struct {
+    int64_t launches[4];       /* 0 front-end (input FIR), 1 demod/pilot/PSS, 2 audio FIR+resample, 3 reserved */
+    double  ms[4];             /* accumulated GPU time of each kernel */
+    int64_t input_samples;     /* complex input samples (summed over streams) covered by the timings */
+    int64_t channel_samples;   /* complex input samples summed over channels */
+} fmx_profile;
+
+int  fmx_abi_version(void);
+const char *fmx_last_error(void);
+
+/* replaces `new fmProcessor(...)` (radio.cpp:915-930) */
+int  fmx_create(const fmx_config *cfg, fmx_handle *out);
+/* replaces fmProcessor::stop() + delete (fm-processor.cpp:200-211) */
+int  fmx_destroy(fmx_handle h);
+
+/* replaces the ~25 setters; channel = -1 addresses every channel */
+int  fmx_set_param(fmx_handle h, int32_t channel, int32_t param_id, double value);
+
+/* number of PCM frames the next call with n complex samples will produce per channel */
+int64_t fmx_frames_for(fmx_handle h, int64_t n_complex);
+
+/* Replaces one iteration of the loop in fmProcessor::run() (fm-processor.cpp:387-686) for every
+ * channel: `iq` = what deviceHandler::getSamples (device-handler.h:71-74) delivered, interleaved
+ * (I,Q) float32, stream s at iq + 2*s*stream_stride; `pcm` = what is handed to
+ * audioSink::putSamples (audiosink.h:45), interleaved (L,R) float32, channel c at
+ * pcm + 2*c*pcm_stride.  Host buffers; synchronous. */
+int  fmx_process_host(fmx_handle h, const float *iq, int64_t stream_stride, int64_t n_complex,
+                      float *pcm, int64_t pcm_stride, int64_t *n_frames);
+/* Same with DEVICE pointers (IQ already resident in HBM); asynchronous on `hip_stream`
+ * (a hipStream_t, NULL = the handle's own stream).  *n_frames is known on return. */
+int  fmx_process_device(fmx_handle h, const float *d_iq, int64_t stream_stride, int64_t n_complex,
+                        float *d_pcm, int64_t pcm_stride, int64_t *n_frames, void *hip_stream);
+int  fmx_synchronize(fmx_handle h);
+
+/* replaces the showMetaData signal payload / isPilotLocked / get_demodDcComponent */
+int  fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *meta);
+/* replaces the hf/lf/iq scope ring feeds: copies the most recent n samples of a tap
+ * (n * 1 or 2 floats) to host memory; n <= samples produced by the last call */
+int  fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap_id, float *dst, int64_t n);
+/* replaces rdsDecoder::doDecode's bit output (rds-decoder.cpp:69-104): pending RDS bits */
+int  fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity, int32_t *n_bits);
+
+/* introspection used by the parity tests: the filter taps the kernels run with.
+ * which: 0 front-end polyphase taps, 1 PSS low-pass, 2 audio+resampler FIR, 3 resampler alone */
+int  fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32_t capacity, int32_t *n);
+
+int  fmx_profile_enable(fmx_handle h, int32_t on);
+int  fmx_profile_read(fmx_handle h, fmx_profile *out, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,604 @@
+// fmx_api.hip -- the C ABI of libfmx (include/fmx.h): handle, settings mailbox, table/tap
+// design + upload, per-call geometry and the three kernel launches.  No CPU fallback exists:
+// every entry point fails when HIP is unavailable.
+#include "../../include/fmx.h"
+#include "fmx_internal.h"
+#include "fmx_design.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace fmx;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(FMX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+int next_pow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return (int)p; }
+
+// per-channel user-level settings (what the fmProcessor setters store)
+struct ChanUser {
+    int32_t bandwidth = 0;       // 0 = Off.  NB ctor default: inputFilterOn=false (fm-processor.cpp:149)
+    int32_t lf_cutoff = 0;       // <=0 = off. ctor default fmAudioFilterActive=false (:164)
+    int32_t deemph_us = 0;       // 0 = ctor default alpha (:174)
+    bool    ctor_volume = true;  // volumeFactor = 0.5f (:127) until setVolume
+    float   volume_db = 0.f;
+    int32_t balance = 0, panorama = 100;
+};
+
+struct ProfRec { hipEvent_t e[4]; int64_t in_samples, ch_samples; int n; };
+
+}  // namespace
+
+struct fmx_handle_s {
+    fmx_config cfg{};
+    int channels = 0, streams = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mtx;                          // guards the mailbox (set_param from any thread)
+    std::vector<ChanUser> user;
+    std::vector<ChanParams> params;          // host mirror
+    bool params_dirty = true, sets_dirty = true;
+    // unique tap sets
+    std::vector<int32_t> front_keys, audio_keys;
+    int front_cap = 0, audio_cap = 0;
+    std::vector<float> h_front_taps, h_audio_taps, h_pss_taps, h_rs_taps;
+    std::vector<FrontSet> h_front_sets; std::vector<AudioSet> h_audio_sets;
+    // device
+    float *d_front_taps = nullptr, *d_audio_taps = nullptr, *d_pss_taps = nullptr;
+    FrontSet *d_front_sets = nullptr; AudioSet *d_audio_sets = nullptr;
+    float2 *d_sincos = nullptr, *d_lo = nullptr; float *d_atan = nullptr, *d_arcsine = nullptr;
+    ChanParams *d_params = nullptr;
+    DeviceTables T{}; DeviceBuffers B{};
+    int ring = 0, dring = 0, sring = 0;
+    int64_t g_total = 0;                     // input samples consumed per stream
+    // staging for the host-pointer entry point
+    float2 *d_iq = nullptr, *d_pcm = nullptr; int64_t pcm_cap = 0;
+    // profiling
+    bool prof_on = false; std::vector<ProfRec> prof; fmx_profile prof_acc{};
+    int64_t last_J0 = 0, last_J1 = 0;
+};
+
+namespace {
+
+// ---- tap-set construction -----------------------------------------------------------------
+// Front end = inputFilter (optional) * fmBand_1 * fmBand_2 folded into one real /12 polyphase FIR.
+void build_front_set(int32_t bw, int32_t inputRate, int32_t fmRate, float *taps /*A_TAPS_STRIDE*/, FrontSet *fs) {
+    const int32_t IRate = inputRate / 6;                                       // fm-processor.cpp:36
+    design::DecimKernel k1 = design::decim(4 * inputRate / IRate + 1, fmRate / 2, inputRate);   // :68-71
+    design::DecimKernel k2 = design::decim(IRate / fmRate + 1, fmRate / 2, IRate);              // :72-75
+    const int D1 = inputRate / IRate;                                          // 6
+    // y[m] = sum k1[l] x[6m+5-l]; z[j] = sum k2[i] y[2j+1-i]  (fir-filters.cpp:397-424)
+    //  => z[j] = sum_k g[k] x[12j+11-k],  g[k] = sum_{D1*i+l=k} h2[i] h1[l]
+    std::vector<double> g((size_t)(D1 * (k2.hn.size() - 1) + k1.hn.size()), 0.0);
+    for (size_t i = 0; i < k2.hn.size(); i++)
+        for (size_t l = 0; l < k1.hn.size(); l++) g[D1 * i + l] += (double)k2.hn[i] * (double)k1.hn[l];
+    int L = 0;                                                                 // overlap-add latency in input samples
+    if (bw > 0) {
+        // inputFilter.setLowPass(fmBandwidth / 2, inputRate), fftFilter(2*32768, 251) (:77,398)
+        std::vector<float> hin = design::lowpass(251, bw / 2, inputRate);
+        g = design::convolve(g, design::to_double(hin));
+        L = 2 * 32768 - 251;                                                   // NumofSamples fft-filters.cpp:34
+    }
+    const int NT = (int)g.size();
+    // z[j] = sum_k g[k] x'[12 j + 11 - L - k]  ->  off = 11 - (L mod 12), delay = L div 12 (+ carry)
+    int off = 11 - (L % 12), delay = L / 12;
+    if (off < 0) { off += 12; delay += 1; }
+    fs->off = off; fs->delay_fm = delay;
+    int nd = 0;
+    std::fill(taps, taps + A_TAPS_STRIDE, 0.f);
+    for (int d = 0; d < A_MAX_ND; d++)
+        for (int r = 0; r < DECIM; r++) {
+            const int k = 12 * d + off - r;
+            if (k >= 0 && k < NT) { taps[d * DECIM + r] = (float)g[k]; nd = d + 1; }
+        }
+    fs->nd = nd;
+    // complex gain of the (h/sum, h) kernels: (1 + j S1)(1 + j S2)  (fir-filters.cpp:345-346)
+    const double S1 = k1.sum, S2 = k2.sum;
+    fs->gain_re = (float)(1.0 - S1 * S2); fs->gain_im = (float)(S1 + S2);
+}
+
+void build_audio_set(int32_t lf, int32_t fmRate, const std::vector<float> &rs, float *taps /*C_TAPS_STRIDE*/, AudioSet *as) {
+    std::vector<double> g = design::to_double(rs);
+    as->delay = 0;
+    if (lf > 0) {
+        // fmAudioFilter.setLowPass(lowPassFrequency, fmRate), fftFilter(2*4096, 756) (:76,404)
+        std::vector<float> ha = design::lowpass(AUDIO_TAPS, lf, fmRate);
+        g = design::convolve(design::to_double(ha), g);
+        as->delay = AUDIO_DELAY;
+    }
+    as->ntaps = (int)g.size();
+    std::fill(taps, taps + C_TAPS_STRIDE, 0.f);
+    for (int kk = 0; kk < as->ntaps; kk++) taps[kk] = (float)g[as->ntaps - 1 - kk];   // reversed
+}
+
+int ensure_sets(fmx_handle h) {
+    // deduplicate bandwidth / lf-cutoff values into tap sets, upload when changed
+    std::vector<int32_t> fk, ak;
+    for (int c = 0; c < h->channels; c++) {
+        int32_t b = h->user[c].bandwidth, l = h->user[c].lf_cutoff > 0 ? h->user[c].lf_cutoff : 0;
+        auto it = std::find(fk.begin(), fk.end(), b);
+        if (it == fk.end()) { fk.push_back(b); it = fk.end() - 1; }
+        h->params[c].front_set = (int)(it - fk.begin());
+        auto ia = std::find(ak.begin(), ak.end(), l);
+        if (ia == ak.end()) { ak.push_back(l); ia = ak.end() - 1; }
+        h->params[c].audio_set = (int)(ia - ak.begin());
+    }
+    if (fk != h->front_keys) {
+        h->front_keys = fk;
+        h->h_front_taps.assign(fk.size() * A_TAPS_STRIDE, 0.f);
+        h->h_front_sets.resize(fk.size());
+        for (size_t i = 0; i < fk.size(); i++)
+            build_front_set(fk[i], h->cfg.inputRate, h->cfg.fmRate, &h->h_front_taps[i * A_TAPS_STRIDE], &h->h_front_sets[i]);
+        if ((int)fk.size() > h->front_cap) {
+            if (h->d_front_taps) { (void)hipFree(h->d_front_taps); (void)hipFree(h->d_front_sets); }
+            h->front_cap = std::max<int>((int)fk.size(), 4);
+            HIPCHK(hipMalloc(&h->d_front_taps, sizeof(float) * A_TAPS_STRIDE * h->front_cap));
+            HIPCHK(hipMalloc(&h->d_front_sets, sizeof(FrontSet) * h->front_cap));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->d_front_taps, h->h_front_taps.data(), sizeof(float) * h->h_front_taps.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_front_sets, h->h_front_sets.data(), sizeof(FrontSet) * fk.size(), hipMemcpyHostToDevice));
+        h->T.front_taps = h->d_front_taps; h->T.front_sets = h->d_front_sets;
+    }
+    if (ak != h->audio_keys) {
+        h->audio_keys = ak;
+        h->h_audio_taps.assign(ak.size() * C_TAPS_STRIDE, 0.f);
+        h->h_audio_sets.resize(ak.size());
+        for (size_t i = 0; i < ak.size(); i++)
+            build_audio_set(ak[i], h->cfg.fmRate, h->h_rs_taps, &h->h_audio_taps[i * C_TAPS_STRIDE], &h->h_audio_sets[i]);
+        if ((int)ak.size() > h->audio_cap) {
+            if (h->d_audio_taps) { (void)hipFree(h->d_audio_taps); (void)hipFree(h->d_audio_sets); }
+            h->audio_cap = std::max<int>((int)ak.size(), 4);
+            HIPCHK(hipMalloc(&h->d_audio_taps, sizeof(float) * C_TAPS_STRIDE * h->audio_cap));
+            HIPCHK(hipMalloc(&h->d_audio_sets, sizeof(AudioSet) * h->audio_cap));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->d_audio_taps, h->h_audio_taps.data(), sizeof(float) * h->h_audio_taps.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_audio_sets, h->h_audio_sets.data(), sizeof(AudioSet) * ak.size(), hipMemcpyHostToDevice));
+        h->T.audio_taps = h->d_audio_taps; h->T.audio_sets = h->d_audio_sets;
+    }
+    h->sets_dirty = false;
+    return FMX_OK;
+}
+
+void refresh_derived(fmx_handle h, int c) {
+    // the arithmetic of the setters themselves
+    const ChanUser &u = h->user[c];
+    ChanParams &p = h->params[c];
+    const int32_t fmRate = h->cfg.fmRate;
+    if (u.deemph_us >= 1) {                     // setDeemphasis fm-processor.cpp:291-297 (Tau is float)
+        const float Tau = (float)(1000000.0 / u.deemph_us);
+        p.deemph_alpha = (float)(1.0 / ((double)((float)fmRate / Tau) + 1.0));
+    } else {                                    // ctor :174
+        p.deemph_alpha = (float)(1.0 / (fmRate / (1000000.0 / 50.0 + 1)));
+    }
+    p.volume = u.ctor_volume ? 0.5f : std::pow(10.0f, u.volume_db / 20.0f);        // :127, :299-301
+    p.left_ch = (u.balance > 0 ? (float)((100 - u.balance) / 100.0) : 1.0f);       // :282-286
+    p.right_ch = (u.balance < 0 ? (float)((100 + u.balance) / 100.0) : 1.0f);
+    p.panorama = (float)(int16_t)u.panorama / 100.0f;                               // :277-280
+}
+
+int ensure_lo_table(fmx_handle h) {
+    if (h->d_lo) return FMX_OK;
+    const int32_t R = h->cfg.inputRate;
+    std::vector<float2> tab((size_t)R);
+    for (int32_t i = 0; i < R; i++)             // Oscillator ctor oscillator.cpp:26-35
+        tab[i] = make_float2((float)std::cos(2.0 * design::kPi * i / R), (float)std::sin(2.0 * design::kPi * i / R));
+    HIPCHK(hipMalloc(&h->d_lo, sizeof(float2) * (size_t)R));
+    HIPCHK(hipMemcpy(h->d_lo, tab.data(), sizeof(float2) * (size_t)R, hipMemcpyHostToDevice));
+    h->T.lo_table = h->d_lo;
+    return FMX_OK;
+}
+
+int flush_mailbox(fmx_handle h) {
+    std::lock_guard<std::mutex> lk(h->mtx);
+    if (h->sets_dirty) { int rc = ensure_sets(h); if (rc) return rc; h->params_dirty = true; }
+    bool any_lo = false;
+    for (auto &p : h->params) any_lo |= (p.lo_freq != 0);
+    if (any_lo) { int rc = ensure_lo_table(h); if (rc) return rc; }
+    if (h->params_dirty) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->d_params, h->params.data(), sizeof(ChanParams) * h->channels, hipMemcpyHostToDevice));
+        bool had_actions = false;
+        for (auto &p : h->params) { had_actions |= (p.actions != 0); p.actions = 0; }
+        h->params_dirty = had_actions;          // re-upload cleared action bits before the following call
+    }
+    return FMX_OK;
+}
+
+void frames_geom(const fmx_handle h, int64_t n, CallGeom *G) {
+    G->g0 = h->g_total; G->n = n;
+    G->J0 = h->g_total / DECIM; G->J1 = (h->g_total + n) / DECIM;
+    // newConverter: 192 frames in -> 48 out (newconverter.cpp:55-80, inputLimit = fmRate/1000)
+    G->M0 = 48 * (G->J0 / 192); G->M1 = 48 * (G->J1 / 192);
+}
+
+int run_call(fmx_handle h, const float2 *d_iq, int64_t stream_stride, int64_t n, float2 *d_pcm,
+             int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
+    if (n <= 0 || n > h->cfg.max_block) return fail(FMX_E_TOO_LARGE, "n_complex must be in [1, max_block]");
+    int rc = flush_mailbox(h);
+    if (rc) return rc;
+    CallGeom G{};
+    frames_geom(h, n, &G);
+    G.ring_mask = h->ring - 1; G.dring_mask = h->dring - 1; G.sring_mask = h->sring - 1;
+    G.input_rate = h->cfg.inputRate; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
+    const int64_t frames = G.M1 - G.M0;
+    if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
+    ProfRec pr{}; const bool prof = h->prof_on;
+    if (prof) {
+        for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&pr.e[i]));
+        pr.in_samples = n * h->streams; pr.ch_samples = n * h->channels;
+        HIPCHK(hipEventRecord(pr.e[0], s));
+    }
+    launch_front(h->T, h->B, G, d_iq, h->channels, s);
+    if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
+    launch_demod(h->T, h->B, G, h->channels, s);
+    if (prof) HIPCHK(hipEventRecord(pr.e[2], s));
+    launch_audio(h->T, h->B, G, d_pcm, h->channels, s);
+    if (prof) { HIPCHK(hipEventRecord(pr.e[3], s)); h->prof.push_back(pr); }
+    HIPCHK(hipGetLastError());
+    h->last_J0 = G.J0; h->last_J1 = G.J1;
+    h->g_total += n;
+    if (n_frames) *n_frames = frames;
+    return FMX_OK;
+}
+
+int prof_drain(fmx_handle h) {
+    for (auto &pr : h->prof) {
+        HIPCHK(hipEventSynchronize(pr.e[3]));
+        for (int k = 0; k < 3; k++) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, pr.e[k], pr.e[k + 1]));
+            h->prof_acc.ms[k] += ms; h->prof_acc.launches[k] += 1;
+        }
+        h->prof_acc.input_samples += pr.in_samples; h->prof_acc.channel_samples += pr.ch_samples;
+        for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
+    }
+    h->prof.clear();
+    return FMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fmx_abi_version(void) { return FMX_ABI_VERSION; }
+const char *fmx_last_error(void) { return g_err.c_str(); }
+
+int fmx_create(const fmx_config *cfg, fmx_handle *out) {
+    if (!cfg || !out) return fail(FMX_E_INVALID, "null argument");
+    if (cfg->struct_size != (int32_t)sizeof(fmx_config)) return fail(FMX_E_INVALID, "fmx_config.struct_size mismatch");
+    if (cfg->channels < 1) return fail(FMX_E_INVALID, "channels must be >= 1");
+    if (cfg->inputRate != 2304000 || cfg->fmRate != 192000 || cfg->workingRate != 48000 || cfg->audioRate != 48000)
+        return fail(FMX_E_UNSUPPORTED, "this build implements inputRate 2304000 / fmRate 192000 / workingRate = audioRate 48000");
+    if (cfg->max_block < 12 || cfg->max_block > (1 << 20)) return fail(FMX_E_INVALID, "max_block must be in [12, 1048576]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(FMX_E_NO_DEVICE, "no HIP device visible: libfmx has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(FMX_E_INVALID, "device ordinal out of range");
+    HIPCHK(hipSetDevice(cfg->device));
+
+    fmx_handle h = new (std::nothrow) fmx_handle_s();
+    if (!h) return fail(FMX_E_NOMEM, "out of host memory");
+    h->cfg = *cfg; h->cfg.stream_of_channel = nullptr;
+    h->channels = cfg->channels;
+    h->streams = cfg->streams > 0 ? cfg->streams : cfg->channels;
+    h->user.assign(h->channels, ChanUser());
+    h->params.assign(h->channels, ChanParams());
+    for (int c = 0; c < h->channels; c++) {
+        ChanParams &p = h->params[c];
+        std::memset(&p, 0, sizeof(p));
+        int s = cfg->stream_of_channel ? cfg->stream_of_channel[c] : (cfg->streams > 0 ? c % h->streams : c);
+        if (s < 0 || s >= h->streams) { delete h; return fail(FMX_E_INVALID, "stream_of_channel entry out of range"); }
+        p.stream = s;
+        // constructor defaults fm-processor.cpp:110-160 / fm-demodulator.cpp:66
+        p.fm_mode = 0; p.sound_sel = 0; p.decoder = 3; p.auto_mono = 1; p.pss_active = 1; p.dc_remove = 1;
+        p.rds_mode = 0; p.lo_freq = 0; p.att_l = 1.f; p.att_r = 1.f;
+        refresh_derived(h, c);
+    }
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+
+    // ---- tables -------------------------------------------------------------------------
+    const int32_t fmRate = cfg->fmRate;
+    {
+        std::vector<float2> sc((size_t)SINCOS_N);                       // SinCos ctor sincos.cpp:45-54
+        for (int i = 0; i < SINCOS_N; i++)
+            sc[i] = make_float2((float)std::cos(2 * design::kPi * i / fmRate), (float)std::sin(2 * design::kPi * i / fmRate));
+        HIPCHK(hipMalloc(&h->d_sincos, sizeof(float2) * SINCOS_N));
+        HIPCHK(hipMemcpy(h->d_sincos, sc.data(), sizeof(float2) * SINCOS_N, hipMemcpyHostToDevice));
+        std::vector<float> at((size_t)ATAN_N + 1);                      // compAtan ctor Xtan2.cpp:28-31
+        const float St = (float)design::kPi;
+        for (int i = 0; i <= ATAN_N; i++) { float f = (float)i / ATAN_N; at[i] = (float)((double)(std::atan(f) * St) / design::kPi); }
+        HIPCHK(hipMalloc(&h->d_atan, sizeof(float) * (ATAN_N + 1)));
+        HIPCHK(hipMemcpy(h->d_atan, at.data(), sizeof(float) * (ATAN_N + 1), hipMemcpyHostToDevice));
+        std::vector<float> as((size_t)ARCSINE_N + 1);                   // fm-demodulator.cpp:74-77
+        for (int i = 0; i <= ARCSINE_N; i++) as[i] = (float)(std::asin(2.0 * i / ARCSINE_N - 1.0) / 2.0);
+        HIPCHK(hipMalloc(&h->d_arcsine, sizeof(float) * (ARCSINE_N + 1)));
+        HIPCHK(hipMemcpy(h->d_arcsine, as.data(), sizeof(float) * (ARCSINE_N + 1), hipMemcpyHostToDevice));
+        h->h_pss_taps = design::lowpass(PSS_TAPS, 15000, fmRate);      // stereo-separation.cpp:31,39
+        HIPCHK(hipMalloc(&h->d_pss_taps, sizeof(float) * PSS_TAPS));
+        HIPCHK(hipMemcpy(h->d_pss_taps, h->h_pss_taps.data(), sizeof(float) * PSS_TAPS, hipMemcpyHostToDevice));
+        h->h_rs_taps = design::resampler(RS_TAPS);
+    }
+    h->T.sincos = h->d_sincos; h->T.atan_ppy = h->d_atan; h->T.arcsine = h->d_arcsine; h->T.lo_table = nullptr;
+    h->T.pss_taps = h->d_pss_taps;
+    h->T.sincos_C = fmRate / (2 * design::kPi);
+    {   // fm_Demodulator ctor fm-demodulator.cpp:57-72
+        const float F_G = (float)(0.65 * fmRate / 2), Delta_F = (float)(0.95 * fmRate / 2);
+        const float B_FM = 2 * (Delta_F + F_G);
+        h->T.K_FM = (float)((double)(2 * B_FM) * design::kPi / (double)F_G);
+        const float max_dev = (float)(0.95 * (0.5 * fmRate));
+        const float fac = (float)(2.0 * design::kPi / fmRate);         // pllC ctor pllC.cpp:42-53
+        h->T.pll_beta = (float)std::exp(-2.0 * design::kPi * (double)(float)(0.85 * fmRate) / 2 / fmRate);
+        h->T.pll_lo = -max_dev * fac; h->T.pll_hi = max_dev * fac; h->T.pll_center = (float)(0 * 2 * design::kPi / fmRate);
+    }
+    // pilotRecovery / PSS ctor args fm-processor.cpp:78-82, stereo-separation.cpp:32
+    h->T.pil_omega = (float)((double)((float)19000 / (float)fmRate) * (2 * design::kPi));
+    h->T.pil_gain = (float)(10 * (2 * design::kPi) / fmRate);
+    h->T.pss_alpha = 10.0f / (float)fmRate;
+    h->T.pss_lock_alpha = 1.0f / fmRate;
+
+    // ---- per-channel buffers ------------------------------------------------------------
+    const int64_t fm_per_call = cfg->max_block / DECIM + 2;
+    h->ring = next_pow2(5440 + fm_per_call + 2 * B_CHUNK);
+    h->dring = next_pow2(AUDIO_DELAY + C_MAX_TAPS + fm_per_call + 192 + 4 * C_TILE);
+    h->sring = 4096;
+    const size_t C = (size_t)h->channels;
+    HIPCHK(hipMalloc(&h->B.hist, sizeof(float2) * C * DECIM * A_HIST_COLS));
+    HIPCHK(hipMalloc(&h->B.zring, sizeof(float2) * C * h->ring));
+    HIPCHK(hipMalloc(&h->B.demod_ring, sizeof(float) * C * h->ring));
+    HIPCHK(hipMalloc(&h->B.lr_ring, sizeof(float2) * C * h->ring));
+    HIPCHK(hipMalloc(&h->B.sring, sizeof(float2) * C * h->sring));
+    HIPCHK(hipMalloc(&h->B.dring, sizeof(float2) * C * h->dring));
+    HIPCHK(hipMalloc(&h->B.state, sizeof(ChanState) * C));
+    HIPCHK(hipMalloc(&h->d_params, sizeof(ChanParams) * C));
+    HIPCHK(hipMemset(h->B.hist, 0, sizeof(float2) * C * DECIM * A_HIST_COLS));
+    HIPCHK(hipMemset(h->B.zring, 0, sizeof(float2) * C * h->ring));
+    HIPCHK(hipMemset(h->B.demod_ring, 0, sizeof(float) * C * h->ring));
+    HIPCHK(hipMemset(h->B.lr_ring, 0, sizeof(float2) * C * h->ring));
+    HIPCHK(hipMemset(h->B.sring, 0, sizeof(float2) * C * h->sring));
+    HIPCHK(hipMemset(h->B.dring, 0, sizeof(float2) * C * h->dring));
+    {
+        ChanState s0; std::memset(&s0, 0, sizeof(s0));
+        s0.Imin1 = s0.Qmin1 = s0.Imin2 = s0.Qmin2 = (float)0.01;        // fm-demodulator.cpp:79-82
+        std::vector<ChanState> init(C, s0);
+        HIPCHK(hipMemcpy(h->B.state, init.data(), sizeof(ChanState) * C, hipMemcpyHostToDevice));
+    }
+    h->B.params = h->d_params;
+    int rc = ensure_sets(h);
+    if (rc) { fmx_destroy(h); return rc; }
+    *out = h;
+    return FMX_OK;
+}
+
+int fmx_destroy(fmx_handle h) {
+    if (!h) return FMX_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &pr : h->prof) for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
+    void *ptrs[] = { h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
+                     h->d_lo, h->d_atan, h->d_arcsine, h->d_params, h->B.hist, h->B.zring, h->B.demod_ring,
+                     h->B.lr_ring, h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return FMX_OK;
+}
+
+int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
+    if (!h) return fail(FMX_E_INVALID, "null handle");
+    if (channel < -1 || channel >= h->channels) return fail(FMX_E_INVALID, "channel out of range");
+    const int iv = (int)std::llround(value);
+    // validate once
+    switch (id) {
+    case FMX_P_FM_MODE: if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "fm mode must be 0..2"); break;
+    case FMX_P_FM_DECODER:
+        if (iv == 1) return fail(FMX_E_UNSUPPORTED, "AM decoder is not part of the FM hot path");
+        if (iv < 2 || iv > 6) return fail(FMX_E_INVALID, "decoder must be 2..6"); break;
+    case FMX_P_SOUND_MODE: if (iv < 0 || iv > 6) return fail(FMX_E_INVALID, "sound mode must be 0..6"); break;
+    case FMX_P_STEREO_PANORAMA: if (iv < 0 || iv > 200) return fail(FMX_E_INVALID, "panorama must be 0..200"); break;
+    case FMX_P_SOUND_BALANCE: if (iv < -100 || iv > 100) return fail(FMX_E_INVALID, "balance must be -100..100"); break;
+    case FMX_P_DEEMPHASIS: if (iv < 1) return fail(FMX_E_INVALID, "de-emphasis must be >= 1 us (Q_ASSERT fm-processor.cpp:293)"); break;
+    case FMX_P_BANDWIDTH: if (iv < 0 || iv > h->cfg.inputRate) return fail(FMX_E_INVALID, "bandwidth out of range"); break;
+    case FMX_P_RDS_MODE:
+        if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "rds mode must be 0..3");
+        if (iv != 0) return fail(FMX_E_UNSUPPORTED, "the RDS path is not built in this round"); break;
+    case FMX_P_LOCAL_OSCILLATOR:
+        if (std::abs(iv) > h->cfg.inputRate) return fail(FMX_E_INVALID, "|lo| must be <= inputRate (oscillator.cpp:49-58)"); break;
+    case FMX_P_SQUELCH_MODE: if (iv != 0) return fail(FMX_E_UNSUPPORTED, "squelch is outside the hot path (SURVEY 8f)"); break;
+    case FMX_P_TEST_TONE: if (iv != 0) return fail(FMX_E_UNSUPPORTED, "test tone is a GUI aid, not built"); break;
+    case FMX_P_VOLUME_DB: case FMX_P_LF_CUTOFF: case FMX_P_ATTENUATION_L: case FMX_P_ATTENUATION_R:
+    case FMX_P_AUTO_MONO: case FMX_P_PSS: case FMX_P_DC_REMOVE:
+    case FMX_A_TRIGGER_FREQUENCY_CHANGE: case FMX_A_RESTART_PSS: case FMX_A_RESET_RDS: break;
+    default: return fail(FMX_E_INVALID, "unknown parameter id");
+    }
+    std::lock_guard<std::mutex> lk(h->mtx);
+    const int c0 = channel < 0 ? 0 : channel, c1 = channel < 0 ? h->channels : channel + 1;
+    for (int c = c0; c < c1; c++) {
+        ChanUser &u = h->user[c]; ChanParams &p = h->params[c];
+        switch (id) {
+        case FMX_P_FM_MODE: p.fm_mode = iv; break;
+        case FMX_P_FM_DECODER: p.decoder = iv; break;
+        case FMX_P_SOUND_MODE: p.sound_sel = iv; break;
+        case FMX_P_STEREO_PANORAMA: u.panorama = iv; break;
+        case FMX_P_SOUND_BALANCE: u.balance = iv; break;
+        case FMX_P_DEEMPHASIS: u.deemph_us = iv; break;
+        case FMX_P_VOLUME_DB: u.volume_db = (float)value; u.ctor_volume = false; break;
+        case FMX_P_LF_CUTOFF: u.lf_cutoff = iv > 0 ? iv : 0; h->sets_dirty = true; break;
+        case FMX_P_BANDWIDTH: u.bandwidth = iv; h->sets_dirty = true; break;
+        case FMX_P_ATTENUATION_L: p.att_l = (float)value; break;
+        case FMX_P_ATTENUATION_R: p.att_r = (float)value; break;
+        case FMX_P_RDS_MODE: p.rds_mode = iv; break;
+        case FMX_P_LOCAL_OSCILLATOR: p.lo_freq = iv; break;
+        case FMX_P_AUTO_MONO: p.auto_mono = iv != 0; break;
+        case FMX_P_PSS: p.pss_active = iv != 0; break;
+        case FMX_P_DC_REMOVE: p.dc_remove = iv != 0; p.actions |= ACT_DC_RESET; break;
+        case FMX_A_TRIGGER_FREQUENCY_CHANGE: p.actions |= ACT_TRIGGER_FREQ; break;
+        case FMX_A_RESTART_PSS: p.actions |= ACT_RESTART_PSS; break;
+        default: break;
+        }
+        refresh_derived(h, c);
+    }
+    h->params_dirty = true;
+    return FMX_OK;
+}
+
+int64_t fmx_frames_for(fmx_handle h, int64_t n) {
+    if (!h || n < 0) return -1;
+    CallGeom G{}; frames_geom(h, n, &G);
+    return G.M1 - G.M0;
+}
+
+int fmx_process_device(fmx_handle h, const float *d_iq, int64_t stream_stride, int64_t n, float *d_pcm,
+                       int64_t pcm_stride, int64_t *n_frames, void *hip_stream) {
+    if (!h || !d_iq || !d_pcm) return fail(FMX_E_INVALID, "null argument");
+    if (stream_stride < n) return fail(FMX_E_INVALID, "stream_stride < n_complex");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    return run_call(h, reinterpret_cast<const float2 *>(d_iq), stream_stride, n, reinterpret_cast<float2 *>(d_pcm),
+                    pcm_stride, n_frames, s);
+}
+
+int fmx_process_host(fmx_handle h, const float *iq, int64_t stream_stride, int64_t n, float *pcm,
+                     int64_t pcm_stride, int64_t *n_frames) {
+    if (!h || !iq || !pcm) return fail(FMX_E_INVALID, "null argument");
+    if (stream_stride < n) return fail(FMX_E_INVALID, "stream_stride < n_complex");
+    if (n <= 0 || n > h->cfg.max_block) return fail(FMX_E_TOO_LARGE, "n_complex must be in [1, max_block]");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int64_t cap = h->cfg.max_block / 48 + 96;
+    if (!h->d_iq) {
+        HIPCHK(hipMalloc(&h->d_iq, sizeof(float2) * (size_t)h->streams * h->cfg.max_block));
+        HIPCHK(hipMalloc(&h->d_pcm, sizeof(float2) * (size_t)h->channels * cap));
+        h->pcm_cap = cap;
+    }
+    const int64_t frames = fmx_frames_for(h, n);
+    if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
+    HIPCHK(hipMemcpy2DAsync(h->d_iq, sizeof(float2) * h->cfg.max_block, iq, sizeof(float2) * stream_stride,
+                            sizeof(float2) * n, h->streams, hipMemcpyHostToDevice, h->stream));
+    int64_t got = 0;
+    int rc = run_call(h, h->d_iq, h->cfg.max_block, n, h->d_pcm, cap, &got, h->stream);
+    if (rc) return rc;
+    if (got > 0)
+        HIPCHK(hipMemcpy2DAsync(pcm, sizeof(float2) * pcm_stride, h->d_pcm, sizeof(float2) * cap, sizeof(float2) * got,
+                                h->channels, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_frames) *n_frames = got;
+    return FMX_OK;
+}
+
+int fmx_synchronize(fmx_handle h) {
+    if (!h) return fail(FMX_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    return FMX_OK;
+}
+
+int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
+    if (!h || !m || channel < 0 || channel >= h->channels) return fail(FMX_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    ChanState st;
+    HIPCHK(hipMemcpy(&st, h->B.state + channel, sizeof(st), hipMemcpyDeviceToHost));
+    m->DcValRf = st.meta_dc_rf; m->DcValIf = st.meta_dc_if; m->PssPhaseShiftDegree = st.meta_pss_deg;
+    m->PssPhaseChange = st.meta_pss_change; m->PssState = st.meta_pss_state;
+    m->PilotPllLockStrength = st.meta_lock_strength; m->PilotPllLocked = st.meta_locked;
+    m->fm_samples = h->g_total / DECIM; m->pcm_frames = 48 * ((h->g_total / DECIM) / 192);
+    return FMX_OK;
+}
+
+int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t n) {
+    if (!h || !dst || channel < 0 || channel >= h->channels || n < 0) return fail(FMX_E_INVALID, "bad argument");
+    const int64_t J1 = h->g_total / DECIM;
+    if (n > J1 || n > (h->last_J1 - h->last_J0)) return fail(FMX_E_INVALID, "n exceeds the samples produced by the last call");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    const char *base; int64_t cap, elem, delay = 0;
+    switch (tap) {
+    case FMX_TAP_FM_IQ: base = (const char *)(h->B.zring + (size_t)channel * h->ring); cap = h->ring; elem = sizeof(float2);
+        delay = h->h_front_sets[h->params[channel].front_set].delay_fm; break;
+    case FMX_TAP_DEMOD: base = (const char *)(h->B.demod_ring + (size_t)channel * h->ring); cap = h->ring; elem = sizeof(float); break;
+    case FMX_TAP_LR_RAW: base = (const char *)(h->B.lr_ring + (size_t)channel * h->ring); cap = h->ring; elem = sizeof(float2); break;
+    case FMX_TAP_PRE_RESAMPLER: base = (const char *)(h->B.dring + (size_t)channel * h->dring); cap = h->dring; elem = sizeof(float2); break;
+    default: return fail(FMX_E_INVALID, "unknown tap id");
+    }
+    // samples j in [J1-n, J1) live at ring index (j - delay) & (cap-1); before the stream start they are 0
+    char *out = (char *)dst;
+    for (int64_t j = J1 - n; j < J1;) {
+        const int64_t jv = j - delay;
+        if (jv < 0) { std::memset(out, 0, elem); out += elem; j++; continue; }
+        const int64_t pos = jv & (cap - 1);
+        const int64_t run = std::min<int64_t>(cap - pos, J1 - j);
+        HIPCHK(hipMemcpy(out, base + pos * elem, (size_t)(run * elem), hipMemcpyDeviceToHost));
+        out += run * elem; j += run;
+    }
+    return FMX_OK;
+}
+
+int fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity, int32_t *n_bits) {
+    (void)bits; (void)capacity;
+    if (!h || channel < 0 || channel >= h->channels || !n_bits) return fail(FMX_E_INVALID, "bad argument");
+    *n_bits = 0;
+    return fail(FMX_E_UNSUPPORTED, "the RDS path is not built in this round");
+}
+
+int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32_t capacity, int32_t *n) {
+    if (!h || !dst || !n || channel < 0 || channel >= h->channels) return fail(FMX_E_INVALID, "bad argument");
+    { int rc = flush_mailbox(h); if (rc) return rc; }
+    const float *src = nullptr; int cnt = 0;
+    std::vector<float> tmp;
+    switch (which) {
+    case 0: {   // front-end taps back in FIR order G[k], k = 12 d + off - r
+        const FrontSet &fs = h->h_front_sets[h->params[channel].front_set];
+        const float *t = &h->h_front_taps[(size_t)h->params[channel].front_set * A_TAPS_STRIDE];
+        int NT = 0;
+        tmp.assign(A_TAPS_STRIDE, 0.f);
+        for (int d = 0; d < fs.nd; d++) for (int r = 0; r < DECIM; r++) {
+            int k = 12 * d + fs.off - r;
+            if (k >= 0 && k < A_TAPS_STRIDE) { tmp[k] = t[d * DECIM + r]; if (t[d * DECIM + r] != 0.f) NT = std::max(NT, k + 1); }
+        }
+        src = tmp.data(); cnt = NT; break; }
+    case 1: src = h->h_pss_taps.data(); cnt = PSS_TAPS; break;
+    case 2: {
+        const AudioSet &as = h->h_audio_sets[h->params[channel].audio_set];
+        const float *t = &h->h_audio_taps[(size_t)h->params[channel].audio_set * C_TAPS_STRIDE];
+        tmp.resize(as.ntaps);
+        for (int k = 0; k < as.ntaps; k++) tmp[k] = t[as.ntaps - 1 - k];
+        src = tmp.data(); cnt = as.ntaps; break; }
+    case 3: src = h->h_rs_taps.data(); cnt = RS_TAPS; break;
+    default: return fail(FMX_E_INVALID, "unknown tap-set id");
+    }
+    if (cnt > capacity) return fail(FMX_E_TOO_LARGE, "capacity too small");
+    std::memcpy(dst, src, sizeof(float) * cnt);
+    *n = cnt;
+    return FMX_OK;
+}
+
+int fmx_profile_enable(fmx_handle h, int32_t on) {
+    if (!h) return fail(FMX_E_INVALID, "null handle");
+    h->prof_on = on != 0;
+    return FMX_OK;
+}
+int fmx_profile_read(fmx_handle h, fmx_profile *out, int32_t reset) {
+    if (!h || !out) return fail(FMX_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = prof_drain(h);
+    if (rc) return rc;
+    *out = h->prof_acc;
+    if (reset) std::memset(&h->prof_acc, 0, sizeof(h->prof_acc));
+    return FMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// fmx_design.h -- host-side filter / table design for libfmx (product code, no oracle dependency).
+//
+// The reference designs its filters at run time with mixed f32/f64 arithmetic
+// (src/various/fir-filters.cpp); the kernels here run FOLDED versions of those filters, so the
+// host first reproduces the reference taps in the reference's own arithmetic and then convolves
+// them in double precision.  Every function cites the lines it follows.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace fmx {
+namespace design {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// windowed-sinc prototype shared by LowPassFIR / DecimatingFIR::newKernel
+// (fir-filters.cpp:45-59, 331-343): f32 taps, f64 sin/cos, Blackman window on i/N, f32 running sum.
+inline float sinc_blackman(int N, float f, std::vector<float> &tmp) {
+    tmp.assign((size_t)N, 0.f);
+    float sum = 0.0f;
+    for (int i = 0; i < N; i++) {
+        if (i == N / 2)
+            tmp[i] = (float)(2 * kPi * (double)f);
+        else
+            tmp[i] = (float)(std::sin(2 * kPi * (double)f * (double)(i - N / 2)) / (double)(i - N / 2));
+        tmp[i] = (float)((double)tmp[i] *
+                         (0.42 - 0.50 * std::cos(2 * kPi * (double)(float)i / (double)(float)N) +
+                          0.08 * std::cos(4 * kPi * (double)(float)i / (double)(float)N)));
+        sum += tmp[i];
+    }
+    return sum;
+}
+
+// LowPassFIR::newKernel fir-filters.cpp:41-62 -> real taps
+inline std::vector<float> lowpass(int N, int32_t Fc, int32_t fs) {
+    std::vector<float> tmp;
+    const float f = (float)Fc / (float)fs;
+    const float sum = sinc_blackman(N, f, tmp);
+    for (auto &v : tmp) v = v / sum;
+    return tmp;
+}
+
+// DecimatingFIR::newKernel fir-filters.cpp:327-347: kernel = (tmp/sum, tmp).  Returned as the
+// normalised real taps plus the f32 `sum`, i.e. kernel[i] ~= hn[i] * (1 + j*sum).
+struct DecimKernel { std::vector<float> hn; float sum; };
+inline DecimKernel decim(int N, int32_t low, int32_t fs) {
+    DecimKernel k;
+    std::vector<float> tmp;
+    const float f = (float)low / (float)fs;
+    k.sum = sinc_blackman(N, f, tmp);
+    k.hn.resize((size_t)N);
+    for (int i = 0; i < N; i++) k.hn[i] = tmp[i] / k.sum;
+    return k;
+}
+
+// fmx resampler: 128-tap Kaiser(beta=9) windowed sinc, fc = 24 kHz @ 192 kHz, unity DC gain
+// (replaces libsamplerate, which is third-party and absent; see DESIGN.md "Resampler").
+inline double bessel_i0(double x) {
+    double s = 1, t = 1;
+    for (int k = 1; k < 64; k++) { t *= (x / (2.0 * k)) * (x / (2.0 * k)); s += t; if (t < 1e-20 * s) break; }
+    return s;
+}
+inline std::vector<float> resampler(int N = 128) {
+    const double beta = 9.0, fc = 0.125;
+    std::vector<double> tmp((size_t)N);
+    double sum = 0;
+    for (int k = 0; k < N; k++) {
+        const double t = k - (N - 1) / 2.0;
+        const double x = 2.0 * k / (N - 1) - 1.0;
+        const double w = bessel_i0(beta * std::sqrt(1.0 - x * x)) / bessel_i0(beta);
+        const double s = (t == 0.0) ? 2 * fc : std::sin(2 * kPi * fc * t) / (kPi * t);
+        tmp[k] = s * w; sum += tmp[k];
+    }
+    std::vector<float> h((size_t)N);
+    for (int k = 0; k < N; k++) h[k] = (float)(tmp[k] / sum);
+    return h;
+}
+
+inline std::vector<double> convolve(const std::vector<double> &a, const std::vector<double> &b) {
+    std::vector<double> c(a.size() + b.size() - 1, 0.0);
+    for (size_t i = 0; i < a.size(); i++)
+        for (size_t j = 0; j < b.size(); j++) c[i + j] += a[i] * b[j];
+    return c;
+}
+inline std::vector<double> to_double(const std::vector<float> &a) { return std::vector<double>(a.begin(), a.end()); }
+
+}  // namespace design
+}  // namespace fmx

@@ -1,0 +1,123 @@
+// fmx_internal.h -- structures shared by the host side (fmx_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fmx {
+
+constexpr int DECIM = 12;              // inputRate / fmRate (2304000 / 192000)
+constexpr int A_TILE_COLS = 256;       // front-end tile: 256 fm-rate outputs = 3072 input samples
+constexpr int A_HIST_COLS = 25;        // history columns kept per channel (>= max taps/12 + 1)
+constexpr int A_MAX_ND = 25;           // tap columns: 287 taps at off=6 -> 25 columns of 12
+constexpr int A_TAPS_STRIDE = A_MAX_ND * DECIM;   // 300 floats per front-end tap set
+constexpr int PSS_TAPS = 295;          // stereo-separation.cpp:31
+constexpr int PSS_DELAY = 2048 - 295;  // overlap-add latency fftSize - degree (fft-filters.cpp:34)
+constexpr int B_CHUNK = 256;           // fm samples per sequential chunk of the demod kernel
+constexpr int RS_TAPS = 128;           // fmx resampler (oracle/fm_oracle.c fmo_resampler_taps)
+constexpr int AUDIO_TAPS = 756;        // fm-processor.cpp:76
+constexpr int AUDIO_DELAY = 8192 - 756;
+constexpr int C_MAX_TAPS = AUDIO_TAPS + RS_TAPS - 1;   // 883
+constexpr int C_TAPS_STRIDE = 896;     // padded
+constexpr int C_TILE = 256;            // PCM frames per audio-FIR tile
+constexpr int SINCOS_N = 192000;
+constexpr int ATAN_N = 8192;
+constexpr int ARCSINE_N = 4 * 8192;
+
+// front-end filter description of one tap set
+struct FrontSet {
+    int32_t nd;          // tap columns used
+    int32_t off;         // newest input sample of output j is 12*j + off
+    int32_t delay_fm;    // pure delay in fm samples applied after the FIR (overlap-add latency)
+    float   gain_re, gain_im;   // complex gain (1 + j*S1)(1 + j*S2) of the two DecimatingFIRs
+};
+
+struct AudioSet {
+    int32_t ntaps;       // 883 (audio filter on) or 128
+    int32_t delay;       // AUDIO_DELAY or 0
+};
+
+// per-channel settings (host mirror uploaded before each call when dirty)
+struct ChanParams {
+    int32_t stream;
+    int32_t front_set, audio_set;
+    int32_t fm_mode, sound_sel, decoder, auto_mono, pss_active, dc_remove, rds_mode;
+    int32_t lo_freq;
+    float   att_l, att_r;
+    float   deemph_alpha, volume, left_ch, right_ch, panorama;
+    int32_t actions;     // one-shot ACT_* bits consumed by the kernels of the next call
+};
+enum { ACT_TRIGGER_FREQ = 1, ACT_RESTART_PSS = 2, ACT_DC_RESET = 4 };
+
+// per-channel DSP state carried between calls
+struct ChanState {
+    // front end
+    float   dc_re, dc_im;
+    int32_t lo_phase;
+    // discriminator (fm-demodulator.cpp:79-86)
+    float   Imin1, Qmin1, Imin2, Qmin2, fm_afc, am_carr;
+    // pllC (pllC.cpp:37-60)
+    float   nco_phase, phase_incr;
+    // pilot PLL (pilot-recover.cpp:28-47)
+    float   pil_phase, pil_old, pil_lock;
+    int32_t pil_stable, pil_locked;
+    // PSS (stereo-separation.cpp:46-54)
+    float   pss_acc, pss_mean;
+    int32_t pss_lock_cnt, pss_unlock_cnt, pss_minimized;
+    float   pilot_delay_pss;
+    int64_t pss_count;           // number of process_sample calls so far (filter time base)
+    // de-emphasis (fm-processor.cpp:594-595)
+    float   de_l, de_r;
+    // fade-in (fm-processor.cpp:130-131,638-642)
+    int64_t fade_start_frame;    // PCM frame index at which suppressAudioSampleCnt was (re)armed
+    // meta snapshot (fm-processor.cpp:662-684)
+    int32_t my_count;
+    float   meta_dc_rf, meta_dc_if, meta_pss_deg, meta_pss_change, meta_lock_strength;
+    int32_t meta_pss_state, meta_locked;
+};
+
+struct DeviceTables {
+    const float2 *sincos;        // [SINCOS_N] (cos, sin)
+    const float  *atan_ppy;      // [ATAN_N + 1]
+    const float  *arcsine;       // [ARCSINE_N + 1]
+    const float2 *lo_table;      // [inputRate] or null when every lo == 0
+    const float  *front_taps;    // [sets][A_TAPS_STRIDE]  T[d*12 + r] = G[12 d + off - r]
+    const FrontSet *front_sets;
+    const float  *pss_taps;      // [PSS_TAPS]
+    const float  *audio_taps;    // [sets][C_TAPS_STRIDE]
+    const AudioSet *audio_sets;
+    double  sincos_C;            // Rate / (2*M_PI)  (sincos.cpp:42)
+    float   K_FM;
+    float   pil_omega, pil_gain, pss_alpha, pss_lock_alpha;
+    float   pll_beta, pll_lo, pll_hi, pll_center;
+};
+
+struct CallGeom {
+    int64_t g0;          // global index of the first input sample of this call
+    int64_t n;           // input samples per stream
+    int64_t J0, J1;      // fm samples [J0, J1) are demodulated in this call
+    int64_t M0, M1;      // PCM frames [M0, M1) are produced in this call
+    int32_t ring_mask;   // fm-rate ring capacity - 1
+    int32_t dring_mask;  // d ring capacity - 1
+    int32_t sring_mask;  // s ring capacity - 1
+    int32_t input_rate;
+    int64_t stream_stride, pcm_stride;   // in complex samples / frames
+};
+
+struct DeviceBuffers {
+    float2 *hist;        // [channels][DECIM][A_HIST_COLS]   mixed input history (column layout)
+    float2 *zring;       // [channels][ring]  front-end output v[j]
+    float  *demod_ring;  // [channels][ring]
+    float2 *lr_ring;     // [channels][ring]  (sum, diff)
+    float2 *sring;       // [channels][sring] PSS filter input history
+    float2 *dring;       // [channels][dring] de-emphasised, gained stereo @ fmRate
+    ChanState *state;
+    const ChanParams *params;
+};
+
+void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const float2 *iq,
+                  int channels, hipStream_t s);
+void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
+void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,
+                  int channels, hipStream_t s);
+
+}  // namespace fmx

@@ -1,0 +1,276 @@
+"""ctypes binding of libfmx (include/fmx.h) plus a host-side mirror of the reference's
+``fmProcessor`` interface (includes/fm/fm-processor.h:104-156) for the FM hot path.
+
+This module never computes DSP itself and has no CPU fallback: if libfmx.so or a HIP device
+is missing every call raises ``FmxError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libfmx.so")
+
+# error codes (include/fmx.h)
+FMX_OK, FMX_E_INVALID, FMX_E_UNSUPPORTED, FMX_E_NO_DEVICE, FMX_E_HIP, FMX_E_NOMEM, FMX_E_TOO_LARGE = 0, -1, -2, -3, -4, -5, -6
+
+# parameter ids (include/fmx.h fmx_param_id)
+P_FM_MODE, P_FM_DECODER, P_SOUND_MODE, P_STEREO_PANORAMA, P_SOUND_BALANCE, P_DEEMPHASIS = 1, 2, 3, 4, 5, 6
+P_VOLUME_DB, P_LF_CUTOFF, P_BANDWIDTH, P_ATTENUATION_L, P_ATTENUATION_R, P_RDS_MODE = 7, 8, 9, 10, 11, 12
+P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE = 13, 14, 15, 16, 17, 18
+A_TRIGGER_FREQUENCY_CHANGE, A_RESTART_PSS, A_RESET_RDS = 100, 101, 102
+
+TAP_FM_IQ, TAP_DEMOD, TAP_LR_RAW, TAP_PRE_RESAMPLER = 0, 1, 2, 3
+
+EXPORTS = [
+    "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
+    "fmx_process_host", "fmx_process_device", "fmx_synchronize", "fmx_get_meta", "fmx_get_tap",
+    "fmx_rds_bits", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
+]
+
+
+class FmxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libfmx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class FmxConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("channels", C.c_int32), ("streams", C.c_int32),
+        ("stream_of_channel", C.POINTER(C.c_int32)),
+        ("inputRate", C.c_int32), ("fmRate", C.c_int32), ("workingRate", C.c_int32), ("audioRate", C.c_int32),
+        ("max_block", C.c_int32),
+    ]
+
+
+class FmxMeta(C.Structure):
+    _fields_ = [
+        ("DcValRf", C.c_float), ("DcValIf", C.c_float), ("PssPhaseShiftDegree", C.c_float),
+        ("PssPhaseChange", C.c_float), ("PssState", C.c_int32), ("PilotPllLockStrength", C.c_float),
+        ("PilotPllLocked", C.c_int32), ("fm_samples", C.c_int64), ("pcm_frames", C.c_int64),
+    ]
+
+
+class FmxProfile(C.Structure):
+    _fields_ = [("launches", C.c_int64 * 4), ("ms", C.c_double * 4), ("input_samples", C.c_int64),
+                ("channel_samples", C.c_int64)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libfmx.so and declare every symbol of include/fmx.h.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FmxError(FMX_E_NO_DEVICE, "%s not built (run `python sdr-j-fm_amd/build.py`); there is no CPU fallback" % p)
+    L = C.CDLL(p)
+    vp, i32, i64, f32p = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_float)
+    L.fmx_abi_version.restype = C.c_int
+    L.fmx_abi_version.argtypes = []
+    L.fmx_last_error.restype = C.c_char_p
+    L.fmx_last_error.argtypes = []
+    L.fmx_create.restype = C.c_int
+    L.fmx_create.argtypes = [C.POINTER(FmxConfig), C.POINTER(vp)]
+    L.fmx_destroy.restype = C.c_int
+    L.fmx_destroy.argtypes = [vp]
+    L.fmx_set_param.restype = C.c_int
+    L.fmx_set_param.argtypes = [vp, i32, i32, C.c_double]
+    L.fmx_frames_for.restype = i64
+    L.fmx_frames_for.argtypes = [vp, i64]
+    L.fmx_process_host.restype = C.c_int
+    L.fmx_process_host.argtypes = [vp, f32p, i64, i64, f32p, i64, C.POINTER(i64)]
+    L.fmx_process_device.restype = C.c_int
+    L.fmx_process_device.argtypes = [vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp]
+    L.fmx_synchronize.restype = C.c_int
+    L.fmx_synchronize.argtypes = [vp]
+    L.fmx_get_meta.restype = C.c_int
+    L.fmx_get_meta.argtypes = [vp, i32, C.POINTER(FmxMeta)]
+    L.fmx_get_tap.restype = C.c_int
+    L.fmx_get_tap.argtypes = [vp, i32, i32, f32p, i64]
+    L.fmx_rds_bits.restype = C.c_int
+    L.fmx_rds_bits.argtypes = [vp, i32, C.POINTER(C.c_uint8), i32, C.POINTER(i32)]
+    L.fmx_get_taps.restype = C.c_int
+    L.fmx_get_taps.argtypes = [vp, i32, i32, f32p, i32, C.POINTER(i32)]
+    L.fmx_profile_enable.restype = C.c_int
+    L.fmx_profile_enable.argtypes = [vp, i32]
+    L.fmx_profile_read.restype = C.c_int
+    L.fmx_profile_read.argtypes = [vp, C.POINTER(FmxProfile), i32]
+    if path is None:
+        _lib = L
+    return L
+
+
+class Fmx:
+    """Thin object wrapper over an fmx_handle (a batch of FM channels on one GPU)."""
+
+    def __init__(self, channels=1, streams=0, stream_of_channel=None, device=0, max_block=16384,
+                 inputRate=2304000, fmRate=192000, workingRate=48000, audioRate=48000):
+        self.L = load_library()
+        cfg = FmxConfig()
+        cfg.struct_size = C.sizeof(FmxConfig)
+        cfg.device, cfg.channels, cfg.streams = device, channels, streams
+        self._map = None
+        if stream_of_channel is not None:
+            self._map = (C.c_int32 * channels)(*[int(x) for x in stream_of_channel])
+            cfg.stream_of_channel = C.cast(self._map, C.POINTER(C.c_int32))
+        cfg.inputRate, cfg.fmRate, cfg.workingRate, cfg.audioRate = inputRate, fmRate, workingRate, audioRate
+        cfg.max_block = max_block
+        self.channels = channels
+        self.streams = streams if streams > 0 else channels
+        self.max_block = max_block
+        self.h = C.c_void_p()
+        self._check(self.L.fmx_create(C.byref(cfg), C.byref(self.h)))
+
+    def _check(self, rc):
+        if rc != FMX_OK:
+            raise FmxError(rc, self.L.fmx_last_error().decode("utf-8", "replace"))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.fmx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_param(self, pid, value, channel=-1):
+        self._check(self.L.fmx_set_param(self.h, channel, pid, float(value)))
+
+    def frames_for(self, n):
+        return int(self.L.fmx_frames_for(self.h, n))
+
+    def process_host(self, iq):
+        """iq: float32 [streams, n, 2] (or [n, 2] for one stream) -> pcm float32 [channels, frames, 2]."""
+        iq = np.ascontiguousarray(iq, np.float32)
+        if iq.ndim == 2:
+            iq = iq[None]
+        assert iq.shape[0] == self.streams and iq.shape[2] == 2
+        n = iq.shape[1]
+        frames = self.frames_for(n)
+        cap = max(frames, 1)
+        pcm = np.zeros((self.channels, cap, 2), np.float32)
+        got = C.c_int64()
+        self._check(self.L.fmx_process_host(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), n, n,
+                                            pcm.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(got)))
+        return pcm[:, :got.value]
+
+    def process_device(self, d_iq_ptr, stream_stride, n, d_pcm_ptr, pcm_stride, hip_stream=None):
+        got = C.c_int64()
+        self._check(self.L.fmx_process_device(self.h, C.c_void_p(d_iq_ptr), stream_stride, n, C.c_void_p(d_pcm_ptr),
+                                              pcm_stride, C.byref(got), C.c_void_p(hip_stream or 0)))
+        return got.value
+
+    def synchronize(self):
+        self._check(self.L.fmx_synchronize(self.h))
+
+    def meta(self, channel=0):
+        m = FmxMeta()
+        self._check(self.L.fmx_get_meta(self.h, channel, C.byref(m)))
+        return m
+
+    def tap(self, tap_id, n, channel=0):
+        width = 1 if tap_id == TAP_DEMOD else 2
+        out = np.zeros((n, width), np.float32)
+        self._check(self.L.fmx_get_tap(self.h, channel, tap_id, out.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return out[:, 0] if width == 1 else out
+
+    def taps(self, which, channel=0):
+        buf = np.zeros(1024, np.float32)
+        n = C.c_int32()
+        self._check(self.L.fmx_get_taps(self.h, channel, which, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size, C.byref(n)))
+        return buf[:n.value].copy()
+
+    def profile_enable(self, on=True):
+        self._check(self.L.fmx_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        p = FmxProfile()
+        self._check(self.L.fmx_profile_read(self.h, C.byref(p), 1 if reset else 0))
+        return {"launches": list(p.launches), "ms": list(p.ms), "input_samples": p.input_samples,
+                "channel_samples": p.channel_samples}
+
+
+class FmProcessor:
+    """Host-side mirror of the reference's ``fmProcessor`` (fm-processor.h:79-156) for ONE channel
+    of an :class:`Fmx` batch: same method names and argument meaning as the reference setters, so a
+    test written against the reference class reads the same here.  ``run_block`` is one iteration
+    of ``fmProcessor::run()`` (fm-processor.cpp:387-686): pull a block from a deviceHandler-shaped
+    source (``Samples()``/``getSamples(n)``) and push PCM into an audioSink-shaped sink
+    (``putSamples(array)``)."""
+
+    FM_Mode = {"Stereo": 0, "StereoPano": 1, "Mono": 2}
+    DECODERS = {"AM": 1, "FM PLL Decoder": 2, "FM Mixed Demod": 3, "FM Complex Baseband Delay": 4,
+                "FM Real Baseband Delay": 5, "FM Difference Based": 6}      # fm-demodulator.cpp:36-43
+
+    def __init__(self, theDevice=None, mySink=None, inputRate=2304000, fmRate=192000, workingRate=48000,
+                 audioRate=48000, fmx=None, channel=0, blockSize=16384):
+        self.myRig, self.theSink = theDevice, mySink
+        self.fmx = fmx if fmx is not None else Fmx(1, max_block=blockSize, inputRate=inputRate, fmRate=fmRate,
+                                                   workingRate=workingRate, audioRate=audioRate)
+        self.channel = channel
+        self.bufferSize = blockSize                       # fm-processor.cpp:374
+
+    def _set(self, pid, v):
+        self.fmx.set_param(pid, v, self.channel)
+
+    # --- the reference's setters (same names) ---
+    def setfmMode(self, m): self._set(P_FM_MODE, self.FM_Mode[m] if isinstance(m, str) else m)
+
+    def setFMdecoder(self, name):
+        # fm_Demodulator::setDecoder: an unknown name selects -1, which falls into `default:` = PLL
+        self._set(P_FM_DECODER, self.DECODERS.get(name, 2) if isinstance(name, str) else name)
+
+    def setSoundMode(self, selector): self._set(P_SOUND_MODE, selector)
+    def setStereoPanorama(self, pan): self._set(P_STEREO_PANORAMA, pan)
+    def setSoundBalance(self, balance): self._set(P_SOUND_BALANCE, balance)
+    def setDeemphasis(self, us): self._set(P_DEEMPHASIS, us)
+    def setVolume(self, gain_db): self._set(P_VOLUME_DB, gain_db)
+    def setlfcutoff(self, hz): self._set(P_LF_CUTOFF, hz)
+
+    def setBandwidth(self, s):
+        # the reference takes the GUI string "165kHz" or "Off" (fm-processor.cpp:232-239)
+        if isinstance(s, str):
+            v = 0 if s == "Off" else int("".join(ch for ch in s if ch.isdigit() or ch == "-") or "0") * 1000
+        else:
+            v = int(s)
+        self._set(P_BANDWIDTH, v)
+
+    def setAttenuation(self, l, r):
+        self._set(P_ATTENUATION_L, l)
+        self._set(P_ATTENUATION_R, r)
+
+    def setfmRdsSelector(self, m): self._set(P_RDS_MODE, m)
+    def triggerFrequencyChange(self): self._set(A_TRIGGER_FREQUENCY_CHANGE, 0)
+    def restartPssAnalyzer(self): self._set(A_RESTART_PSS, 0)
+    def resetRds(self): self._set(A_RESET_RDS, 0)
+    def set_localOscillator(self, lo): self._set(P_LOCAL_OSCILLATOR, lo)
+    def set_squelchMode(self, m): self._set(P_SQUELCH_MODE, m)
+    def setAutoMonoMode(self, b): self._set(P_AUTO_MONO, 1 if b else 0)
+    def setPSSMode(self, b): self._set(P_PSS, 1 if b else 0)
+    def setDCRemove(self, b): self._set(P_DC_REMOVE, 1 if b else 0)
+    def setTestTone(self, b): self._set(P_TEST_TONE, 1 if b else 0)
+
+    def isPilotLocked(self):
+        m = self.fmx.meta(self.channel)
+        return bool(m.PilotPllLocked), m.PilotPllLockStrength
+
+    def get_demodDcComponent(self): return self.fmx.meta(self.channel).DcValIf
+
+    def run_block(self):
+        """One loop iteration of fmProcessor::run(): returns False when the device has < bufferSize samples."""
+        if self.myRig.Samples() < self.bufferSize:
+            return False
+        iq = self.myRig.getSamples(self.bufferSize)
+        pcm = self.fmx.process_host(iq)
+        if self.theSink is not None and pcm.shape[1] > 0:
+            self.theSink.putSamples(pcm[self.channel])
+        return True

@@ -1,0 +1,27 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def fmx_amd():
+    """The product package (name contains '-', hence importlib)."""
+    return importlib.import_module("sdr-j-fm_amd")
+
+
+@pytest.fixture(scope="session")
+def ol():
+    import oracle_lib
+    oracle_lib.oracle()
+    return oracle_lib
