@@ -102,7 +102,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="shard512", choices=sorted(WORKLOADS))
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
     ap.add_argument("--block", type=int, default=BLOCK)

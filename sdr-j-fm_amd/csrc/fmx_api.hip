@@ -59,11 +59,13 @@ struct fmx_handle_s {
     // device
     float *d_front_taps = nullptr, *d_audio_taps = nullptr, *d_pss_taps = nullptr;
     FrontSet *d_front_sets = nullptr; AudioSet *d_audio_sets = nullptr;
-    float2 *d_sincos = nullptr, *d_lo = nullptr; float *d_atan = nullptr, *d_arcsine = nullptr;
+    float2 *d_sincos = nullptr, *d_lo = nullptr; float *d_atan = nullptr, *d_arcsine = nullptr; double2 *d_trig3 = nullptr;
     ChanParams *d_params = nullptr;
     DeviceTables T{}; DeviceBuffers B{};
     int ring = 0, dring = 0, sring = 0;
     int64_t g_total = 0;                     // input samples consumed per stream
+    int64_t work_nj = 0;                     // rows of the sample-major work arrays
+    int pitch = 0;                           // their row pitch in elements
     // staging for the host-pointer entry point
     float2 *d_iq = nullptr, *d_pcm = nullptr; int64_t pcm_cap = 0;
     // profiling
@@ -209,6 +211,12 @@ int flush_mailbox(fmx_handle h) {
     bool any_lo = false;
     for (auto &p : h->params) any_lo |= (p.lo_freq != 0);
     if (any_lo) { int rc = ensure_lo_table(h); if (rc) return rc; }
+    bool any_pll = false;
+    for (auto &p : h->params) any_pll |= (p.decoder == 2);
+    if (any_pll && !h->B.w_iq) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMalloc(&h->B.w_iq, sizeof(float2) * (size_t)h->work_nj * h->pitch));
+    }
     if (h->params_dirty) {
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemcpy(h->d_params, h->params.data(), sizeof(ChanParams) * h->channels, hipMemcpyHostToDevice));
@@ -234,7 +242,7 @@ int run_call(fmx_handle h, const float2 *d_iq, int64_t stream_stride, int64_t n,
     CallGeom G{};
     frames_geom(h, n, &G);
     G.ring_mask = h->ring - 1; G.dring_mask = h->dring - 1; G.sring_mask = h->sring - 1;
-    G.input_rate = h->cfg.inputRate; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
+    G.input_rate = h->cfg.inputRate; G.pitch = h->pitch; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
     const int64_t frames = G.M1 - G.M0;
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
     ProfRec pr{}; const bool prof = h->prof_on;
@@ -319,6 +327,24 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
             sc[i] = make_float2((float)std::cos(2 * design::kPi * i / fmRate), (float)std::sin(2 * design::kPi * i / fmRate));
         HIPCHK(hipMalloc(&h->d_sincos, sizeof(float2) * SINCOS_N));
         HIPCHK(hipMemcpy(h->d_sincos, sc.data(), sizeof(float2) * SINCOS_N, hipMemcpyHostToDevice));
+        {   // 2-level factorisation of the sine column for the sequential pilot PLL (LDS resident):
+            // sin(2 pi idx/N) = Im(EA[a] EB[b]), idx = 256 a + b.  Used only if the f64 expression rounds to
+            // exactly the reference's f32 table entry for EVERY idx (checked here with the same unfused
+            // multiply/add sequence the kernel runs); otherwise the kernel reads the global table.
+            std::vector<double2> tr((size_t)TRIG2_N);
+            for (int a = 0; a < TRIG2_A; a++) { double t = 2 * design::kPi * (256.0 * a) / fmRate; tr[a] = make_double2(std::cos(t), std::sin(t)); }
+            for (int b = 0; b < TRIG2_B; b++) { double t = 2 * design::kPi * (double)b / fmRate; tr[TRIG2_A + b] = make_double2(std::cos(t), std::sin(t)); }
+            bool exact = (fmRate == TRIG2_A * TRIG2_B);
+            for (int i = 0; exact && i < SINCOS_N; i++) {
+                const double2 ea = tr[i >> 8], eb = tr[TRIG2_A + (i & 255)];
+                const float sn = (float)(ea.y * eb.x + ea.x * eb.y);
+                if (std::memcmp(&sn, &sc[i].y, 4) != 0) exact = false;
+            }
+            if (exact) {
+                HIPCHK(hipMalloc(&h->d_trig3, sizeof(double2) * TRIG2_N));
+                HIPCHK(hipMemcpy(h->d_trig3, tr.data(), sizeof(double2) * TRIG2_N, hipMemcpyHostToDevice));
+            }
+        }
         std::vector<float> at((size_t)ATAN_N + 1);                      // compAtan ctor Xtan2.cpp:28-31
         const float St = (float)design::kPi;
         for (int i = 0; i <= ATAN_N; i++) { float f = (float)i / ATAN_N; at[i] = (float)((double)(std::atan(f) * St) / design::kPi); }
@@ -333,7 +359,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMemcpy(h->d_pss_taps, h->h_pss_taps.data(), sizeof(float) * PSS_TAPS, hipMemcpyHostToDevice));
         h->h_rs_taps = design::resampler(RS_TAPS);
     }
-    h->T.sincos = h->d_sincos; h->T.atan_ppy = h->d_atan; h->T.arcsine = h->d_arcsine; h->T.lo_table = nullptr;
+    h->T.sincos = h->d_sincos; h->T.atan_ppy = h->d_atan; h->T.arcsine = h->d_arcsine; h->T.lo_table = nullptr; h->T.trig2 = h->d_trig3;
     h->T.pss_taps = h->d_pss_taps;
     h->T.sincos_C = fmRate / (2 * design::kPi);
     {   // fm_Demodulator ctor fm-demodulator.cpp:57-72
@@ -348,12 +374,13 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     // pilotRecovery / PSS ctor args fm-processor.cpp:78-82, stereo-separation.cpp:32
     h->T.pil_omega = (float)((double)((float)19000 / (float)fmRate) * (2 * design::kPi));
     h->T.pil_gain = (float)(10 * (2 * design::kPi) / fmRate);
+    h->T.K_FM_rcp = 1.0f / h->T.K_FM; h->T.pil_omega_rcp = 1.0f / h->T.pil_omega;
     h->T.pss_alpha = 10.0f / (float)fmRate;
     h->T.pss_lock_alpha = 1.0f / fmRate;
 
     // ---- per-channel buffers ------------------------------------------------------------
     const int64_t fm_per_call = cfg->max_block / DECIM + 2;
-    h->ring = next_pow2(5440 + fm_per_call + 2 * B_CHUNK);
+    h->ring = next_pow2(5440 + fm_per_call + 512);
     h->dring = next_pow2(AUDIO_DELAY + C_MAX_TAPS + fm_per_call + 192 + 4 * C_TILE);
     h->sring = 4096;
     const size_t C = (size_t)h->channels;
@@ -363,6 +390,21 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     HIPCHK(hipMalloc(&h->B.lr_ring, sizeof(float2) * C * h->ring));
     HIPCHK(hipMalloc(&h->B.sring, sizeof(float2) * C * h->sring));
     HIPCHK(hipMalloc(&h->B.dring, sizeof(float2) * C * h->dring));
+    {
+        const size_t NJ = (size_t)fm_per_call + 1;
+        h->work_nj = (int64_t)NJ;
+        h->pitch = ((h->channels + 63) / 64) * 64 + 64;
+        const size_t C = (size_t)h->pitch;   // rows are padded (see CallGeom.pitch)
+        HIPCHK(hipMalloc(&h->B.w_dem, sizeof(float) * NJ * C));
+        HIPCHK(hipMalloc(&h->B.w_cur, sizeof(float) * NJ * C));
+        HIPCHK(hipMalloc(&h->B.w_osc, sizeof(float) * NJ * C));
+        HIPCHK(hipMalloc(&h->B.w_lock, sizeof(uint8_t) * NJ * C));
+        HIPCHK(hipMalloc(&h->B.w_err, sizeof(float) * (size_t)PSS_CHUNK * C));
+        HIPCHK(hipMalloc(&h->B.w_pdp, sizeof(float) * NJ * C));
+        HIPCHK(hipMalloc(&h->B.w_tag, sizeof(int32_t) * NJ * C));
+        HIPCHK(hipMalloc(&h->B.w_x, sizeof(float2) * NJ * C));
+        h->B.w_iq = nullptr;
+    }
     HIPCHK(hipMalloc(&h->B.state, sizeof(ChanState) * C));
     HIPCHK(hipMalloc(&h->d_params, sizeof(ChanParams) * C));
     HIPCHK(hipMemset(h->B.hist, 0, sizeof(float2) * C * DECIM * A_HIST_COLS));
@@ -390,8 +432,9 @@ int fmx_destroy(fmx_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &pr : h->prof) for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
     void *ptrs[] = { h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
-                     h->d_lo, h->d_atan, h->d_arcsine, h->d_params, h->B.hist, h->B.zring, h->B.demod_ring,
-                     h->B.lr_ring, h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm };
+                     h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.zring, h->B.demod_ring,
+                     h->B.lr_ring, h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
+                     h->B.w_osc, h->B.w_lock, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

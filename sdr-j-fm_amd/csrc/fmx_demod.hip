@@ -12,11 +12,16 @@
 //   L/R matrix, selector              fm-processor.cpp:517-549
 //   de-emphasis, gain                 fm-processor.cpp:594-595, 303-306
 //
-// MI355X design: one wavefront per channel, persistent over the call.  The work is cut into
-// chunks of 256 fm samples; inside a chunk the time-parallel parts (limiter + atan2 LUT
-// discriminator, the PSS low-pass, the 38 kHz mix and the matrix) use all 64 lanes, while the
-// genuinely sequential feedback loops (AFC, pilot PLL, PSS integrator, lock state machines,
-// de-emphasis) run in lane 0 from LDS.  Parallelism across the chip comes from the channels.
+// MI355X design.  The stage is a chain of small kernels over a call's fm-rate samples, of two kinds:
+//   * time-parallel kernels (one thread per (channel, sample)): limiter + LUT discriminator,
+//     the PSS low-pass, the 38 kHz mix + matrix, the ring transposes;
+//   * recurrence kernels (AFC, pilot PLL, lock detector, PSS integrator, de-emphasis): ONE LANE PER
+//     CHANNEL, 64 channels per wavefront, all lanes stepping through time together.  These loops
+//     cannot be parallelised in time (non-linear feedback through LUT indices); their parallelism
+//     is the channel count, and every lane is busy.  Work arrays between the kernels are
+//     sample-major [sample][channel] so both kinds of kernel access them coalesced.
+// The only feedback path with a lag is the PSS loop (error -> integrator -> 38 kHz phase -> mix ->
+// 1753-sample low-pass -> error), so only its kernels are iterated in chunks of <= 1753 samples.
 #include "fmx_internal.h"
 
 namespace fmx {
@@ -24,13 +29,40 @@ namespace fmx {
 #define FMX_2PI 6.283185307179586476925286766559   /* 2 * M_PI as the double the reference uses */
 #define FMX_PI_4 0.78539816339744830962
 
-// ---- PI_Constrain fm-constants.h:148-158
+// exact fmod(x, 2*pi) for |x| < 8*pi by Sterbenz-exact subtractions (the generic ocml fmod is a
+// long loop; every use here is within a few turns).  Falls back to fmod outside that range.
+__device__ __attribute__((noinline)) double fmod_2pi_slow(double x) { return fmod(x, FMX_2PI); }
+__device__ __forceinline__ double fmod_2pi(double x) {
+    double ax = fabs(x);
+    if (__builtin_expect(!(ax < 4 * FMX_2PI), 0)) return fmod_2pi_slow(x);   // also NaN/inf
+    ax = (ax >= 2 * FMX_2PI) ? ax - 2 * FMX_2PI : ax;
+    ax = (ax >= FMX_2PI) ? ax - FMX_2PI : ax;
+    return copysign(ax, x);
+}
+// ---- PI_Constrain fm-constants.h:148-158; the in-range test is done in f32:
+//      val < 2*M_PI (double)  <=>  val < 6.2831855f (the float just above 2*pi)
 __device__ __forceinline__ float pi_constrain(float val) {
+    if (val >= 0.f && val < 6.2831855f) return val;
     const double v = (double)val;
-    if (0.0 <= v && v < FMX_2PI) return val;
-    if (v >= FMX_2PI) return (float)fmod(v, FMX_2PI);
+    if (v >= FMX_2PI) return (float)fmod_2pi(v);
     if (v > -FMX_2PI) return (float)(v + FMX_2PI);
-    return (float)(FMX_2PI - fmod(-v, FMX_2PI));
+    return (float)(FMX_2PI - fmod_2pi(-v));
+}
+// PI_Constrain for arguments known to lie in (-2*pi, 4*pi) (the pilot phase after one update):
+// branch-free selects; v - 2*pi is exact for v in [2*pi, 4*pi) (Sterbenz), as is fmod there.
+__device__ __forceinline__ float pi_constrain_near(float val) {
+    // (the pilot phase is [0, 2pi) +- 5*|demod|*gain + omega: |5*demod*gain| < 0.01 since |demod| < 4.1)
+    const double v = (double)val;
+    const float hi = (float)(v - FMX_2PI), lo = (float)(v + FMX_2PI);
+    return (val < 0.f) ? lo : ((val < 6.2831855f) ? val : hi);
+}
+// x / c for a CONSTANT c with rc = RN(1/c): q0 = x*rc; r = fma(-q0, c, x); q = fma(r, rc, q0).
+// Markstein's correction step gives the correctly rounded IEEE quotient; verified exhaustively on the
+// host for K_FM and the pilot omega over |x| in [2^-60, 2^60] (DESIGN.md "exact division by constants").
+__device__ __forceinline__ float fdiv_const(float x, float c, float rc) {
+    const float q0 = x * rc;
+    const float r = __fmaf_rn(-q0, c, x);
+    return __fmaf_rn(r, rc, q0);
 }
 // ---- SinCos sincos.cpp:63-97
 __device__ __forceinline__ int sc_index(float phase, double C) {    // phase >= 0
@@ -42,7 +74,7 @@ __device__ __forceinline__ float sc_sin(const float2 *__restrict__ tab, double C
 }
 __device__ __forceinline__ float sc_wrap(float phase) {
     while (phase < 0) phase = (float)((double)phase + FMX_2PI);
-    return (float)fmod((double)phase, FMX_2PI);
+    return (float)fmod_2pi((double)phase);
 }
 __device__ __forceinline__ float2 sc_complex(const float2 *__restrict__ tab, double C, float phase) {
     return tab[sc_index(sc_wrap(phase), C)];
@@ -76,212 +108,387 @@ __device__ __forceinline__ float lut_atan2(const float *__restrict__ ppy, float 
     if (x <= y) return ppy[at_idx(S, y, x)] - St;                        // NNY
     return -St * 0.5f - ppy[at_idx(S, x, y)];                            // NNX
 }
+// ---- limiter fm-demodulator.cpp:119-126 (std::abs(complex<float>) == hypotf == f64 sqrt of f64 sum)
+__device__ __forceinline__ float2 limiter(float2 z) {
+    const float zAbs = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
+    if ((double)zAbs <= 0.001) return make_float2((float)0.001, (float)0.001);
+    return make_float2(z.x / zAbs, z.y / zAbs);
+}
 
-constexpr int WIN = B_CHUNK + PSS_TAPS - 1;      // 550 PSS low-pass window entries
-
-__global__ __launch_bounds__(64) void demod_kernel(DeviceTables T, DeviceBuffers B, CallGeom G) {
-    __shared__ float2 sIQ[B_CHUNK + 2];          // limiter outputs; [0],[1] = two previous samples
-    __shared__ float  sRES[B_CHUNK];             // discriminator output before AFC
-    __shared__ float  sERR[B_CHUNK];             // PSS error Re*Im for call index i0 + r
-    __shared__ float  sDEM[B_CHUNK];
-    __shared__ float  sPH[B_CHUNK];              // 38 kHz mixing phase (phaseforLRDiff)
-    __shared__ int    sIDX[B_CHUNK];             // -2 mono branch, -1 stereo without PSS, >=0 s-ring index offset
-    __shared__ float2 sWIN[WIN];                 // PSS window, later reused for the matrix output
-    __shared__ float2 sY[B_CHUNK];               // de-emphasised stereo
-
-    const int ch = blockIdx.x;
-    const int lane = threadIdx.x;
-    const ChanParams P = B.params[ch];
-    const FrontSet FS = T.front_sets[P.front_set];
-    ChanState *stp = B.state + ch;
+// =================================================================================================
+// B1  limiter + memoryless discriminator   (time-parallel; 64 samples x 64 channels per block)
+// =================================================================================================
+__global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
+    const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
+    __shared__ float tile[64][65];
+    __shared__ float2 tileIQ[64][65];
+    const int tid = threadIdx.x;
+    const int64_t nj = G.J1 - G.J0;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
     const int ring = G.ring_mask + 1;
-    const float2 *__restrict__ zring = B.zring + (size_t)ch * ring;
-    float *demod_ring = B.demod_ring + (size_t)ch * ring;
-    float2 *lr_ring = B.lr_ring + (size_t)ch * ring;
-    float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
-    float2 *dring = B.dring + (size_t)ch * (G.dring_mask + 1);
+    const bool want_iq = B.w_iq != nullptr;
+    for (int i = 0; i < 16; i++) {
+        const int cl = (tid >> 6) + 4 * i, rl = tid & 63;
+        const int ch = c0 + cl;
+        const int64_t r = r0 + rl;
+        float res = 0.f; float2 cur = make_float2(0.f, 0.f);
+        if (ch < C && r < nj) {
+            const ChanParams &P = B.params[ch];
+            const int delay = T.front_sets[P.front_set].delay_fm;
+            const float2 *zr = B.zring + (size_t)ch * ring;
+            const int64_t j = G.J0 + r;
+            // z[j'] is 0 before the filter latency has elapsed; the demodulator's initial
+            // Imin/Qmin is 0.01 (fm-demodulator.cpp:79-82)
+            auto lim_at = [&](int64_t jj) -> float2 {
+                if (jj < 0) return make_float2((float)0.01, (float)0.01);
+                const int64_t v = jj - delay;
+                return limiter(v >= 0 ? zr[v & G.ring_mask] : make_float2(0.f, 0.f));
+            };
+            cur = lim_at(j);
+            const float2 p1 = lim_at(j - 1);
+            const float I = cur.x, Q = cur.y, I1 = p1.x, Q1 = p1.y;
+            const int decoder = P.decoder;
+            if (decoder == 5) {            // REAL_BB fm-demodulator.cpp:174-182
+                res = (float)((double)(I1 * Q - Q1 * I + 1) / 2.0);
+                int index = (int)floorf(res * (float)ARCSINE_N);
+                if (index < 0) index = 0;
+                if (index >= ARCSINE_N) index = ARCSINE_N;
+                res = T.arcsine[index];
+            } else if (decoder == 6) {     // DIFF :184-189
+                const float2 p2 = lim_at(j - 2);
+                const float Scaler = (float)1.4142135623730951;
+                res = (I1 * (Q - p2.y) - Q1 * (I - p2.x));
+                res /= (I1 * I1 + Q1 * Q1) * Scaler;
+            } else if (decoder != 2) {     // MIXED :168-172 (COMPLEX_BB :174-177 is bitwise the same)
+                res = lut_atan2(T.atan_ppy, Q * I1 - I * Q1, I * I1 + Q * Q1);
+            }
+        }
+        tile[cl][rl] = res;
+        if (want_iq) tileIQ[cl][rl] = cur;
+    }
+    __syncthreads();
+    for (int i = 0; i < 16; i++) {
+        const int rl = (tid >> 6) + 4 * i, cl = tid & 63;
+        const int ch = c0 + cl;
+        const int64_t r = r0 + rl;
+        if (ch < C && r < nj) {
+            B.w_dem[r * CP + ch] = tile[cl][rl];
+            if (want_iq) B.w_iq[r * CP + ch] = tileIQ[cl][rl];
+        }
+    }
+}
+
+// =================================================================================================
+// B2  the per-sample recurrences up to the pilot lock   [lane per channel, 64 channels per wave]
+//       AFC + scaling            fm-demodulator.cpp:197-198   (pllC.cpp:67-90 when decoder == PLL)
+//       pilot PLL                pilot-recover.cpp:54-61
+//       lock detector            pilot-recover.cpp:62-80
+//       PSS call index (tag)     fm-processor.cpp:704-705,716-718 (which samples call process_sample)
+//     Work arrays are read a batch ahead into registers (global latency off the dependent chain);
+//     the NCO sine (float)sin(2*pi*idx/192000) is rebuilt from two f64 factor tables held in LDS
+//     (idx = 256 a + b); the host proved the expression rounds to the reference's f32 table entry
+//     for every idx (fmx_api.hip), else T.trig2 is null and the global table is used.
+// =================================================================================================
+constexpr int SEQ_UB = 8;
+struct Seq1State {
+    float afc, nco_phase, incr, phase, lock, old;
+    int stable, locked, tagn;
+};
+struct Seq1Const {
+    float c1, fmDcAlpha, K, rK, gain, omega, romega, lockA;
+    double keep, SC;
+    bool stereo_possible, auto_mono, pss_active, use_pll, t2;
+};
+template <bool PLLDEC>
+__device__ __forceinline__ void seq1_step(Seq1State &s, const Seq1Const &c, const DeviceTables &T,
+                                          const double2 *sA, const double2 *sB, float res, float2 sig,
+                                          float &o_dem, float &o_cur, int &o_lk, int &o_tag) {
+    if (PLLDEC) {
+        if (c.use_pll) {                         // pllC::do_pll pllC.cpp:67-90
+            const float2 nco = sc_complex(T.sincos, c.SC, s.nco_phase);
+            const float dre = nco.x * sig.x - (-nco.y) * sig.y;      // conj(nco) * signal
+            const float dim = nco.x * sig.y + (-nco.y) * sig.x;
+            const float perr = lut_atan2(T.atan_ppy, dim, dre);
+            s.incr = (1 - T.pll_beta) * perr + T.pll_beta * s.incr;
+            if (s.incr < T.pll_lo || s.incr > T.pll_hi) s.incr = T.pll_center;
+            s.nco_phase += s.incr;
+            if ((double)s.nco_phase >= FMX_2PI) s.nco_phase = (float)fmod_2pi((double)s.nco_phase);
+            else while (s.nco_phase < 0) s.nco_phase = (float)((double)s.nco_phase + FMX_2PI);
+            res = s.incr;
+        }
+    }
+    // AFC + scaling fm-demodulator.cpp:197-198
+    s.afc = c.c1 * s.afc + c.fmDcAlpha * res;
+    const float demod = fdiv_const(20.0f * (res - s.afc) * 1.0f, c.K, c.rK);
+    o_dem = demod;
+    // pilot PLL: SinCos::getSin sincos.cpp:81-85 (phase stays within (-2pi, 4pi))
+    const float pilot = 5 * demod;
+    const bool neg = s.phase < 0.f;
+    const float p = neg ? -s.phase : s.phase;
+    int idx = (int)((double)p * c.SC);
+    idx = (idx >= SINCOS_N) ? idx - SINCOS_N : idx;          // p <= 2pi + 0.01 -> idx <= N + 306
+    float osc;
+    if (c.t2) {
+        const double2 ea = sA[idx >> 8], eb = sB[idx & 255];
+        osc = (float)(ea.y * eb.x + ea.x * eb.y);
+    } else osc = T.sincos[idx].y;
+    osc = neg ? -osc : osc;
+    const float perr = pilot * osc;
+    s.phase += perr * c.gain;
+    o_cur = s.phase;                                         // PI_Constrain of it is applied in pss_mix_kernel
+    s.phase = pi_constrain_near(s.phase + c.omega);
+    // lock detector pilot-recover.cpp:62-80
+    const float quadRef = fdiv_const(osc - s.old, c.omega, c.romega);
+    s.old = osc;
+    s.lock = (float)((double)(c.lockA * (-quadRef * pilot)) + (double)s.lock * c.keep);
+    const bool tmp = s.lock > 0.07f;
+    // if (tmp) { if (locked || ++stable > N/2) locked = 1; } else { locked = 0; stable = 0; }
+    const int stable_inc = s.stable + ((tmp && !s.locked) ? 1 : 0);
+    s.locked = tmp ? ((s.locked || stable_inc > (SINCOS_N >> 1)) ? 1 : 0) : 0;
+    s.stable = tmp ? stable_inc : 0;
+    o_lk = s.locked;
+    // which samples call PerfectStereoSeparation::process_sample (fm-processor.cpp:704-705,716-718)
+    const bool branch = c.stereo_possible && (s.locked || !c.auto_mono);
+    o_tag = branch ? (c.pss_active ? s.tagn : -1) : -2;
+    s.tagn += (branch && c.pss_active) ? 1 : 0;
+}
+
+template <bool PLLDEC>
+__global__ __launch_bounds__(64) void seq1_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
+    const int CP = G.pitch;       // padded row pitch of the sample-major work arrays
+    __shared__ double2 sA[TRIG2_A];
+    __shared__ double2 sB[TRIG2_B];
+    Seq1Const c;
+    c.t2 = T.trig2 != nullptr;
+    if (c.t2) {
+        for (int i = threadIdx.x; i < TRIG2_A; i += 64) sA[i] = T.trig2[i];
+        for (int i = threadIdx.x; i < TRIG2_B; i += 64) sB[i] = T.trig2[TRIG2_A + i];
+    }
+    __syncthreads();
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C) return;
+    const int64_t nj = G.J1 - G.J0;
+    ChanState *st = B.state + ch;
+    const ChanParams &P = B.params[ch];
+    c.use_pll = PLLDEC && (P.decoder == 2);
+    c.stereo_possible = P.fm_mode != 2; c.auto_mono = P.auto_mono != 0; c.pss_active = P.pss_active != 0;
+    c.fmDcAlpha = 0.0001f; c.c1 = 1 - c.fmDcAlpha; c.K = T.K_FM; c.rK = T.K_FM_rcp;
+    c.gain = T.pil_gain; c.omega = T.pil_omega; c.romega = T.pil_omega_rcp;
+    c.lockA = 1.0f / 3000.0f; c.keep = 1.0 - (double)c.lockA; c.SC = T.sincos_C;
+    Seq1State s;
+    s.afc = st->fm_afc; s.nco_phase = st->nco_phase; s.incr = st->phase_incr;
+    s.phase = st->pil_phase; s.lock = st->pil_lock; s.old = st->pil_old;
+    s.stable = st->pil_stable; s.locked = st->pil_locked; s.tagn = 0;
+    float *wd = B.w_dem + ch; float *wc = B.w_cur + ch; uint8_t *wl = B.w_lock + ch; int *wt = B.w_tag + ch;
+    const float2 *wiq = PLLDEC ? B.w_iq + ch : nullptr;
+
+    // main loop: full batches, no guards; the next batch's inputs are loaded while this one computes
+    const int64_t nfull = nj / SEQ_UB;
+    float nx[SEQ_UB]; float2 nq[SEQ_UB];
+    if (nfull > 0) {
+#pragma unroll
+        for (int k = 0; k < SEQ_UB; k++) { nx[k] = wd[k * CP]; if (PLLDEC) nq[k] = wiq[k * CP]; }
+    }
+    for (int64_t b = 0; b < nfull; b++) {
+        float x[SEQ_UB]; float2 xq[SEQ_UB];
+#pragma unroll
+        for (int k = 0; k < SEQ_UB; k++) { x[k] = nx[k]; xq[k] = PLLDEC ? nq[k] : make_float2(0.f, 0.f); }
+        const int nb = (b + 1 < nfull) ? SEQ_UB * CP : 0;       // the last prefetch re-reads this batch
+#pragma unroll
+        for (int k = 0; k < SEQ_UB; k++) { nx[k] = wd[nb + k * CP]; if (PLLDEC) nq[k] = wiq[nb + k * CP]; }
+        float o_dem[SEQ_UB], o_cur[SEQ_UB]; int o_lk[SEQ_UB], o_tag[SEQ_UB];
+#pragma unroll
+        for (int k = 0; k < SEQ_UB; k++)
+            seq1_step<PLLDEC>(s, c, T, sA, sB, x[k], xq[k], o_dem[k], o_cur[k], o_lk[k], o_tag[k]);
+#pragma unroll
+        for (int k = 0; k < SEQ_UB; k++) {
+            wd[k * CP] = o_dem[k]; wc[k * CP] = o_cur[k]; wl[k * CP] = (uint8_t)o_lk[k]; wt[k * CP] = o_tag[k];
+        }
+        wd += SEQ_UB * CP; wc += SEQ_UB * CP; wl += SEQ_UB * CP; wt += SEQ_UB * CP;
+        if (PLLDEC) wiq += SEQ_UB * CP;
+    }
+    for (int64_t r = nfull * SEQ_UB; r < nj; r++) {                 // tail (< SEQ_UB samples)
+        float od, oc; int ol, ot;
+        seq1_step<PLLDEC>(s, c, T, sA, sB, wd[0], PLLDEC ? wiq[0] : make_float2(0.f, 0.f), od, oc, ol, ot);
+        wd[0] = od; wc[0] = oc; wl[0] = (uint8_t)ol; wt[0] = ot;
+        wd += CP; wc += CP; wl += CP; wt += CP;
+        if (PLLDEC) wiq += CP;
+    }
+    st->fm_afc = s.afc; st->nco_phase = s.nco_phase; st->phase_incr = s.incr;
+    st->pil_phase = s.phase; st->pil_lock = s.lock; st->pil_old = s.old; st->pil_stable = s.stable; st->pil_locked = s.locked;
+    st->pss_call_total = s.tagn;
+}
+
+// =================================================================================================
+// B5  PSS low-pass + error for every sample of the chunk   (time-parallel)
+//     stereo-separation.cpp:60-83 : err = Re(y)*Im(y), y = sum_k h[k] s[i - 1753 - k], i = PSS call index
+// =================================================================================================
+constexpr int PSS_TILE = 256;
+constexpr int PSS_WIN = PSS_TILE + PSS_TAPS - 1;
+__global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
+                                                     int64_t rc0, int chunk_len) {
+    const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
+    __shared__ float2 sWIN[PSS_WIN];
+    __shared__ int sTag[PSS_TILE];
+    const int ch = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int q0 = blockIdx.x * PSS_TILE;
+    const ChanParams &P = B.params[ch];
+    if (P.fm_mode == 2 || !P.pss_active) return;
+    const int64_t ic = B.state[ch].pss_count;            // PSS call index at the start of this CALL
+    int tmin = 0x7fffffff;
+    for (int m = 0; m < 4; m++) {
+        const int q = q0 + lane + 64 * m;
+        const int tg = (q < chunk_len) ? B.w_tag[(rc0 + q) * CP + ch] : -2;
+        sTag[lane + 64 * m] = tg;
+        if (tg >= 0) tmin = tg < tmin ? tg : tmin;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(tmin, d, 64); tmin = o < tmin ? o : tmin; }
+    if (tmin == 0x7fffffff) return;                      // no PSS call in this tile
+    const float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
+    // window entry w <-> s index (ic + tmin) - (1753 + 294) + w ; tags in a tile span < PSS_TILE
+    for (int w = lane; w < PSS_WIN; w += 64) {
+        const int64_t idx = ic + tmin - (PSS_DELAY + PSS_TAPS - 1) + w;
+        sWIN[w] = (idx >= 0) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    int off[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) { const int tg = sTag[lane + 64 * m]; off[m] = tg >= 0 ? tg - tmin : 0; }
+    float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < PSS_TAPS; k++) {
+        const float h = T.pss_taps[k];
+        const int w = (PSS_TAPS - 1) - k;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const float2 v = sWIN[w + off[m]];
+            ar[m] = fmaf(h, v.x, ar[m]); ai[m] = fmaf(h, v.y, ai[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int q = q0 + lane + 64 * m;
+        if (q < chunk_len) B.w_err[(size_t)q * CP + ch] = ar[m] * ai[m];
+    }
+}
+
+// =================================================================================================
+// B6  PSS integrator + state machines   [lane per channel]
+//     fm-processor.cpp:699-718, stereo-separation.cpp:84-109
+// =================================================================================================
+constexpr int ACC_UB = 16;
+struct AccState { float acc, mean, pdp; int lock_cnt, unlock_cnt, minimized; };
+__device__ __forceinline__ float pss_acc_step(AccState &s, float alpha, float la, int locked, int tag, float err) {
+    // branch-free: every lane (channel) may be in a different state
+    const bool rst = !locked;                      // unlocked: pilotDelayPSS = 0; pPSS.reset() (fm-processor.cpp:699-702)
+    s.pdp = rst ? 0.f : s.pdp; s.acc = rst ? 0.f : s.acc; s.mean = rst ? 0.f : s.mean;
+    s.minimized = rst ? 0 : s.minimized; s.lock_cnt = rst ? 0 : s.lock_cnt; s.unlock_cnt = rst ? 0 : s.unlock_cnt;
+    const float used = s.pdp;                      // the value phaseforLRDiff is built from (:707-709)
+    const bool call = tag >= 0;                    // PerfectStereoSeparation::process_sample :60-109
+    const float error = s.minimized ? err : err * 10.0f;
+    float nacc = s.acc + alpha * error;
+    const float nmean = la * error + s.mean * (1.0f - la);
+    const bool small = fabsf(nmean) < 0.001f;
+    // small: if (minimized || ++lock_cnt > 3N) minimized = 1; unlock_cnt = 0;
+    // else : if (!minimized || ++unlock_cnt > 3N) minimized = 0; lock_cnt = 0;
+    const int lc1 = s.lock_cnt + ((small && !s.minimized) ? 1 : 0);
+    const int uc1 = s.unlock_cnt + ((!small && s.minimized) ? 1 : 0);
+    const int nmin = small ? ((s.minimized || lc1 > 3 * SINCOS_N) ? 1 : 0)
+                           : ((!s.minimized || uc1 > 3 * SINCOS_N) ? 0 : 1);
+    const int nlc = small ? lc1 : 0, nuc = small ? 0 : uc1;
+    nacc = ((double)nacc < -FMX_PI_4) ? (float)-FMX_PI_4 : (((double)nacc > FMX_PI_4) ? (float)FMX_PI_4 : nacc);
+    s.acc = call ? nacc : s.acc; s.mean = call ? nmean : s.mean; s.minimized = call ? nmin : s.minimized;
+    s.lock_cnt = call ? nlc : s.lock_cnt; s.unlock_cnt = call ? nuc : s.unlock_cnt;
+    s.pdp = call ? nacc : ((tag == -1) ? 0.f : s.pdp);
+    return used;
+}
+__global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
+                                                     int64_t rc0, int chunk_len) {
+    const int CP = G.pitch;       // padded row pitch of the sample-major work arrays
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C) return;
+    ChanState *st = B.state + ch;
+    const ChanParams &P = B.params[ch];
+    AccState s;
+    s.acc = st->pss_acc; s.mean = st->pss_mean; s.pdp = st->pilot_delay_pss;
+    s.lock_cnt = st->pss_lock_cnt; s.unlock_cnt = st->pss_unlock_cnt; s.minimized = st->pss_minimized;
+    if ((P.actions & (ACT_TRIGGER_FREQ | ACT_RESTART_PSS)) && rc0 == 0) {
+        // triggerFrequencyChange / restartPssAnalyzer fm-processor.cpp:849-860
+        s.pdp = 0.f; s.acc = 0.f; s.minimized = 0; s.mean = 0.f; s.lock_cnt = 0; s.unlock_cnt = 0;
+        if (P.actions & ACT_TRIGGER_FREQ) st->fade_start_frame = G.M0;
+    }
+    const uint8_t *lk = B.w_lock + ch + rc0 * (int64_t)CP;
+    const int *tg = B.w_tag + ch + rc0 * (int64_t)CP;
+    const float *err = B.w_err + ch;
+    float *pdpw = B.w_pdp + ch + rc0 * (int64_t)CP;
+    const float alpha = T.pss_alpha, la = T.pss_lock_alpha;
+    const bool pss_on = (P.fm_mode != 2) && (P.pss_active != 0);
+    const int nfull = chunk_len / ACC_UB;
+    uint8_t nl[ACC_UB]; int nt[ACC_UB]; float ne[ACC_UB];
+    if (nfull > 0) {
+#pragma unroll
+        for (int k = 0; k < ACC_UB; k++) { nl[k] = lk[k * CP]; nt[k] = tg[k * CP]; ne[k] = err[k * CP]; }
+    }
+    for (int b = 0; b < nfull; b++) {
+        uint8_t l[ACC_UB]; int t[ACC_UB]; float e[ACC_UB]; float o[ACC_UB];
+#pragma unroll
+        for (int k = 0; k < ACC_UB; k++) { l[k] = nl[k]; t[k] = nt[k]; e[k] = pss_on ? ne[k] : 0.f; }
+        const int nb = (b + 1 < nfull) ? ACC_UB * CP : 0;
+#pragma unroll
+        for (int k = 0; k < ACC_UB; k++) { nl[k] = lk[nb + k * CP]; nt[k] = tg[nb + k * CP]; ne[k] = err[nb + k * CP]; }
+#pragma unroll
+        for (int k = 0; k < ACC_UB; k++) o[k] = pss_acc_step(s, alpha, la, l[k], t[k], e[k]);
+#pragma unroll
+        for (int k = 0; k < ACC_UB; k++) pdpw[k * CP] = o[k];
+        lk += ACC_UB * CP; tg += ACC_UB * CP; err += ACC_UB * CP; pdpw += ACC_UB * CP;
+    }
+    for (int q = nfull * ACC_UB; q < chunk_len; q++) {
+        pdpw[0] = pss_acc_step(s, alpha, la, lk[0], tg[0], pss_on ? err[0] : 0.f);
+        lk += CP; tg += CP; err += CP; pdpw += CP;
+    }
+    st->pss_acc = s.acc; st->pss_mean = s.mean; st->pilot_delay_pss = s.pdp;
+    st->pss_lock_cnt = s.lock_cnt; st->pss_unlock_cnt = s.unlock_cnt; st->pss_minimized = s.minimized;
+}
+
+// =================================================================================================
+// B7  38 kHz mix, PSS input, stereo matrix   (time-parallel; transposing like B1)
+//     fm-processor.cpp:707-730, 517-549
+// =================================================================================================
+__global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
+                                                      int64_t rc0, int chunk_len) {
+    const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
+    __shared__ float2 tLR[64][65];
+    __shared__ float tDEM[64][65];
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int ring = G.ring_mask + 1;
     const float2 *__restrict__ sct = T.sincos;
     const double SC = T.sincos_C;
-    const int decoder = P.decoder;
-    const bool stereo_possible = (P.fm_mode != 2);
-    const bool want_pss = stereo_possible && (P.pss_active != 0);
-
-    ChanState st = *stp;                         // every lane holds a copy; lane 0 is authoritative
-    int64_t fade_start = st.fade_start_frame;
-    if (P.actions & (ACT_TRIGGER_FREQ | ACT_RESTART_PSS)) {
-        // triggerFrequencyChange / restartPssAnalyzer fm-processor.cpp:849-860
-        st.pilot_delay_pss = 0.f;
-        st.pss_acc = 0.f; st.pss_minimized = 0; st.pss_mean = 0.f; st.pss_lock_cnt = 0; st.pss_unlock_cnt = 0;
-        if (P.actions & ACT_TRIGGER_FREQ) fade_start = G.M0;
-    }
-
-    for (int64_t jc = G.J0; jc < G.J1; jc += B_CHUNK) {
-        const int cnt = (int)((G.J1 - jc) < B_CHUNK ? (G.J1 - jc) : B_CHUNK);
-        // ================= phase 1: limiter (fm-demodulator.cpp:119-126) =================
-        if (lane == 0) { sIQ[0] = make_float2(st.Imin2, st.Qmin2); sIQ[1] = make_float2(st.Imin1, st.Qmin1); }
-        for (int r = lane; r < cnt; r += 64) {
-            const int64_t j = jc + r;
-            const int64_t jv = j - FS.delay_fm;                // overlap-add latency of the input filter
-            float2 z = make_float2(0.f, 0.f);
-            if (jv >= 0) z = zring[jv & G.ring_mask];
-            const float zAbs = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);  // hypotf
-            float I, Q;
-            if ((double)zAbs <= 0.001) { I = Q = (float)0.001; }
-            else { I = z.x / zAbs; Q = z.y / zAbs; }
-            sIQ[r + 2] = make_float2(I, Q);
-        }
-        __syncthreads();
-        // ================= phase 1b: memoryless discriminators =================
-        if (decoder != 2) {
-            for (int r = lane; r < cnt; r += 64) {
-                const float2 c = sIQ[r + 2], p1 = sIQ[r + 1], p2 = sIQ[r];
-                const float I = c.x, Q = c.y, I1 = p1.x, Q1 = p1.y;
-                float res;
-                if (decoder == 5) {            // REAL_BB :174-182
-                    res = (float)((double)(I1 * Q - Q1 * I + 1) / 2.0);
-                    int index = (int)floorf(res * (float)ARCSINE_N);
-                    if (index < 0) index = 0;
-                    if (index >= ARCSINE_N) index = ARCSINE_N;
-                    res = T.arcsine[index];
-                } else if (decoder == 6) {     // DIFF :184-189
-                    const float Scaler = (float)1.4142135623730951;
-                    res = (I1 * (Q - p2.y) - Q1 * (I - p2.x));
-                    res /= (I1 * I1 + Q1 * Q1) * Scaler;
-                } else {                       // MIXED :168-172 (COMPLEX_BB :174-177 is bitwise the same)
-                    res = lut_atan2(T.atan_ppy, Q * I1 - I * Q1, I * I1 + Q * Q1);
-                }
-                sRES[r] = res;
-            }
-        }
-        // ================= phase 1c: PSS low-pass -> error for this chunk's call indices ==========
-        const int64_t i0 = st.pss_count;
-        if (want_pss) {
-            for (int w = lane; w < WIN; w += 64) {
-                const int64_t idx = i0 - (PSS_DELAY + PSS_TAPS - 1) + w;
-                sWIN[w] = (idx >= 0) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
-            }
-            __syncthreads();
-            float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < PSS_TAPS; k++) {
-                const float h = T.pss_taps[k];
-                const int w = lane + (PSS_TAPS - 1) - k;
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const float2 v = sWIN[w + 64 * m];
-                    ar[m] = fmaf(h, v.x, ar[m]); ai[m] = fmaf(h, v.y, ai[m]);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < 4; m++) sERR[lane + 64 * m] = ar[m] * ai[m];
-        }
-        __syncthreads();
-        // ================= phase 2: the sequential loops (lane 0) =================
-        if (lane == 0) {
-            const float fmDcAlpha = 0.0001f;
-            const float lockA = 1.0f / 3000.0f;
-            int64_t ipss = i0;
-            for (int r = 0; r < cnt; r++) {
-                float res;
-                if (decoder == 2) {            // pllC::do_pll pllC.cpp:67-90
-                    const float2 sig = sIQ[r + 2];
-                    const float2 nco = sc_complex(sct, SC, st.nco_phase);
-                    // conj(nco) * signal
-                    const float dre = nco.x * sig.x - (-nco.y) * sig.y;
-                    const float dim = nco.x * sig.y + (-nco.y) * sig.x;
-                    const float perr = lut_atan2(T.atan_ppy, dim, dre);
-                    st.phase_incr = (1 - T.pll_beta) * perr + T.pll_beta * st.phase_incr;
-                    if (st.phase_incr < T.pll_lo || st.phase_incr > T.pll_hi) st.phase_incr = T.pll_center;
-                    st.nco_phase += st.phase_incr;
-                    if ((double)st.nco_phase >= FMX_2PI) st.nco_phase = (float)fmod((double)st.nco_phase, FMX_2PI);
-                    else while (st.nco_phase < 0) st.nco_phase = (float)((double)st.nco_phase + FMX_2PI);
-                    res = st.phase_incr;
-                } else res = sRES[r];
-                // AFC + scaling fm-demodulator.cpp:197-198
-                st.fm_afc = (1 - fmDcAlpha) * st.fm_afc + fmDcAlpha * res;
-                const float demod = 20.0f * (res - st.fm_afc) * 1.0f / T.K_FM;
-                sDEM[r] = demod;
-                // pilot PLL pilot-recover.cpp:54-83
-                const float pilot = 5 * demod;
-                const float osc = sc_sin(sct, SC, st.pil_phase);
-                const float perr = pilot * osc;
-                st.pil_phase += perr * T.pil_gain;
-                const float cur = pi_constrain(st.pil_phase);
-                st.pil_phase = pi_constrain(st.pil_phase + T.pil_omega);
-                const float quadRef = (osc - st.pil_old) / T.pil_omega;
-                st.pil_old = osc;
-                st.pil_lock = (float)((double)(lockA * (-quadRef * pilot)) + (double)st.pil_lock * (1.0 - (double)lockA));
-                if (st.pil_lock > 0.07f) {
-                    if (st.pil_locked || ++st.pil_stable > (SINCOS_N >> 1)) st.pil_locked = 1;
-                } else { st.pil_locked = 0; st.pil_stable = 0; }
-                // process_signal_with_rds fm-processor.cpp:699-730
-                if (!st.pil_locked) {
-                    st.pilot_delay_pss = 0.f;
-                    st.pss_acc = 0.f; st.pss_minimized = 0; st.pss_mean = 0.f; st.pss_lock_cnt = 0; st.pss_unlock_cnt = 0;
-                }
-                int tag = -2;
-                float ph = 0.f;
-                if (stereo_possible && (st.pil_locked || !P.auto_mono)) {
-                    ph = (float)(2 * ((double)cur + FMX_PI_4 + 0) - (double)st.pilot_delay_pss);
-                    if ((double)ph < -FMX_2PI) ph = (float)((double)ph + 2 * FMX_2PI);
-                    ph = (float)fmod((double)ph, FMX_2PI);
-                    if (P.pss_active) {        // PerfectStereoSeparation::process_sample :60-109
-                        tag = (int)(ipss - i0);
-                        float error = sERR[tag];
-                        ipss++;
-                        if (!st.pss_minimized) error *= 10.0f;
-                        st.pss_acc += T.pss_alpha * error;
-                        st.pss_mean = T.pss_lock_alpha * error + st.pss_mean * (1.0f - T.pss_lock_alpha);
-                        if (fabsf(st.pss_mean) < 0.001f) {
-                            if (st.pss_minimized || (++st.pss_lock_cnt > 3 * SINCOS_N)) st.pss_minimized = 1;
-                            st.pss_unlock_cnt = 0;
-                        } else {
-                            if (!st.pss_minimized || (++st.pss_unlock_cnt > 3 * SINCOS_N)) st.pss_minimized = 0;
-                            st.pss_lock_cnt = 0;
-                        }
-                        if ((double)st.pss_acc < -FMX_PI_4) st.pss_acc = (float)-FMX_PI_4;
-                        else if ((double)st.pss_acc > FMX_PI_4) st.pss_acc = (float)FMX_PI_4;
-                        st.pilot_delay_pss = st.pss_acc;
-                    } else { tag = -1; st.pilot_delay_pss = 0.f; }
-                }
-                sPH[r] = ph; sIDX[r] = tag;
-                // meta snapshot fm-processor.cpp:662-684
-                if (++st.my_count > (SINCOS_N >> 1)) {
-                    const bool lk = stereo_possible && st.pil_locked;
-                    st.meta_locked = lk ? 1 : 0;
-                    st.meta_lock_strength = stereo_possible ? st.pil_lock : 0.f;
-                    const float dcabs = (float)sqrt((double)st.dc_re * (double)st.dc_re + (double)st.dc_im * (double)st.dc_im);
-                    st.meta_dc_rf = P.dc_remove ? 20 * log10f(dcabs + 1.0f / 32768) : (float)-99.99;
-                    st.meta_dc_if = st.fm_afc;
-                    st.meta_pss_deg = (float)((double)st.pilot_delay_pss / 3.14159265358979323846 * 180.0f);
-                    st.meta_pss_change = st.pss_mean * 1000;
-                    st.meta_pss_state = (P.pss_active && lk) ? (st.pss_minimized ? 2 : 1) : 0;
-                    st.my_count = 0;
-                }
-            }
-            st.pss_count = ipss;
-            const float2 l1 = sIQ[cnt + 1], l2 = sIQ[cnt];
-            st.Imin1 = l1.x; st.Qmin1 = l1.y; st.Imin2 = l2.x; st.Qmin2 = l2.y;
-        }
-        __syncthreads();
-        // ================= phase 3: 38 kHz mix, PSS input, matrix (all lanes) =================
-        for (int r = lane; r < cnt; r += 64) {
-            const int64_t j = jc + r;
-            const float demod = sDEM[r];
-            const int tag = sIDX[r];
+    // pass 1: threads along channels (coalesced reads of the sample-major work arrays)
+    for (int i = 0; i < 16; i++) {
+        const int ql = (tid >> 6) + 4 * i, cl = tid & 63;
+        const int ch = c0 + cl, q = q0 + ql;
+        if (ch < C && q < chunk_len) {
+            const int64_t r = rc0 + q;
+            const ChanParams &P = B.params[ch];
+            const float demod = B.w_dem[r * CP + ch];
+            const int tag = B.w_tag[r * CP + ch];
             float2 audio = make_float2(demod, 0.f);
             if (tag != -2) {
-                const float ph = sPH[r];
+                // phaseforLRDiff fm-processor.cpp:707-714
+                float ph = (float)(2 * ((double)pi_constrain(B.w_cur[r * CP + ch]) + FMX_PI_4 + 0) - (double)B.w_pdp[r * CP + ch]);
+                if ((double)ph < -FMX_2PI) ph = (float)((double)ph + 2 * FMX_2PI);
+                ph = (float)fmod_2pi((double)ph);
+                const float2 e = sct[sc_index(sc_wrap(ph), SC)];
                 if (tag >= 0) {
-                    const float2 e = sc_complex(sct, SC, ph);
-                    sring[(i0 + tag) & G.sring_mask] = make_float2(e.x * demod, e.y * demod);
+                    const int64_t ic = B.state[ch].pss_count;
+                    B.sring[(size_t)ch * (G.sring_mask + 1) + ((ic + tag) & G.sring_mask)] = make_float2(e.x * demod, e.y * demod);
                 }
-                float lut;
-                if (P.sound_sel == 6) lut = sc_sin(sct, SC, ph);
-                else lut = sct[sc_index(sc_wrap(ph), SC)].x;
+                const float lut = (P.sound_sel == 6) ? sc_sin(sct, SC, ph) : e.x;
                 audio.y = (float)(2.0 * (double)lut * (double)demod);
             }
-            demod_ring[j & G.ring_mask] = demod;
-            lr_ring[j & G.ring_mask] = audio;
             const float sumLR = audio.x, diffLR = audio.y;
             const float dw = diffLR * (P.fm_mode == 1 ? P.panorama : 1.0f);
             const float left = sumLR + dw, right = sumLR - dw;
@@ -295,53 +502,130 @@ __global__ __launch_bounds__(64) void demod_kernel(DeviceTables T, DeviceBuffers
             case 4: o = make_float2(sumLR, sumLR); break;
             case 5: case 6: o = make_float2(dw, dw); break;
             }
-            sWIN[r] = o;
+            B.w_x[r * CP + ch] = o;
+            tLR[cl][ql] = audio; tDEM[cl][ql] = demod;
         }
-        __syncthreads();
-        // ================= phase 4: de-emphasis (lanes 0/1 = L/R), fm-processor.cpp:594-595 =======
-        if (lane < 2) {
-            const float a = P.deemph_alpha;
-            float y = lane == 0 ? st.de_l : st.de_r;
-            const float *xin = reinterpret_cast<const float *>(sWIN) + lane;
-            float *yout = reinterpret_cast<float *>(sY) + lane;
-            for (int r = 0; r < cnt; r++) {
-                y = (xin[2 * r] - y) * a + y;
-                yout[2 * r] = y;
-            }
-            if (lane == 0) st.de_l = y; else st.de_r = y;
-        }
-        // lane 1's de_r -> lane 0 (the authoritative copy)
-        {
-            const float der = __shfl(st.de_r, 1, 64);
-            if (lane == 0) st.de_r = der;
-        }
-        __syncthreads();
-        // ================= phase 5: gain (audioGainCorrection :303-306) -> d ring =================
-        for (int r = lane; r < cnt; r += 64) {
-            const int64_t j = jc + r;
-            const float2 y = sY[r];
-            dring[j & G.dring_mask] = make_float2(P.volume * P.left_ch * y.x, P.volume * P.right_ch * y.y);
-        }
-        // broadcast lane 0's state so every lane starts the next chunk consistently
-        {
-            int *w = reinterpret_cast<int *>(&st);
-#pragma unroll
-            for (unsigned i = 0; i < sizeof(ChanState) / 4; i++) w[i] = __shfl(w[i], 0, 64);
-        }
-        __syncthreads();
     }
-    if (lane == 0) {
-        // the front end owns dc/lo state: do not overwrite what it stored this call
-        ChanState out = st;
-        out.dc_re = stp->dc_re; out.dc_im = stp->dc_im; out.lo_phase = stp->lo_phase;
-        out.fade_start_frame = fade_start;
-        *stp = out;
+    __syncthreads();
+    // pass 2: threads along time -> channel-major tap rings (GUI scope feeds / tests)
+    for (int i = 0; i < 16; i++) {
+        const int cl = (tid >> 6) + 4 * i, ql = tid & 63;
+        const int ch = c0 + cl, q = q0 + ql;
+        if (ch < C && q < chunk_len) {
+            const int64_t j = G.J0 + rc0 + q;
+            B.demod_ring[(size_t)ch * ring + (j & G.ring_mask)] = tDEM[cl][ql];
+            B.lr_ring[(size_t)ch * ring + (j & G.ring_mask)] = tLR[cl][ql];
+        }
+    }
+}
+// =================================================================================================
+// B8  de-emphasis + gain   [lane per channel]   fm-processor.cpp:594-595, 303-306
+//     plus the 0.5 s meta snapshot (:662-684)
+// =================================================================================================
+__global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
+    const int CP = G.pitch;       // padded row pitch of the sample-major work arrays
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C) return;
+    const int64_t nj = G.J1 - G.J0;
+    ChanState *st = B.state + ch;
+    const ChanParams &P = B.params[ch];
+    const float a = P.deemph_alpha;
+    const float gl = P.volume * P.left_ch, gr = P.volume * P.right_ch;
+    float yl = st->de_l, yr = st->de_r;
+    float2 *x = B.w_x + ch;
+    constexpr int UB = 16;
+    const int64_t nfull = nj / UB;
+    float2 nx[UB];
+    if (nfull > 0) {
+#pragma unroll
+        for (int k = 0; k < UB; k++) nx[k] = x[k * CP];
+    }
+    for (int64_t b = 0; b < nfull; b++) {
+        float2 v[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) v[k] = nx[k];
+        const int nb = (b + 1 < nfull) ? UB * CP : 0;
+#pragma unroll
+        for (int k = 0; k < UB; k++) nx[k] = x[nb + k * CP];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            yl = (v[k].x - yl) * a + yl;
+            yr = (v[k].y - yr) * a + yr;
+            v[k] = make_float2(gl * yl, gr * yr);
+        }
+#pragma unroll
+        for (int k = 0; k < UB; k++) x[k * CP] = v[k];
+        x += UB * CP;
+    }
+    for (int64_t r = nfull * UB; r < nj; r++) {
+        const float2 v = x[0];
+        yl = (v.x - yl) * a + yl;
+        yr = (v.y - yr) * a + yr;
+        x[0] = make_float2(gl * yl, gr * yr);
+        x += CP;
+    }
+    st->de_l = yl; st->de_r = yr;
+    // meta snapshot: emitted by the reference every fmRate/2 samples; taken at the end of the call
+    // in which that count is crossed (values of the call end)
+    int cnt = st->my_count + (int)nj;
+    if (cnt > (SINCOS_N >> 1)) {
+        const bool stereo_possible = P.fm_mode != 2;
+        const bool lk = stereo_possible && st->pil_locked;
+        st->meta_locked = lk ? 1 : 0;
+        st->meta_lock_strength = stereo_possible ? st->pil_lock : 0.f;
+        const float dcabs = (float)sqrt((double)st->dc_re * (double)st->dc_re + (double)st->dc_im * (double)st->dc_im);
+        st->meta_dc_rf = P.dc_remove ? 20 * log10f(dcabs + 1.0f / 32768) : (float)-99.99;
+        st->meta_dc_if = st->fm_afc;
+        st->meta_pss_deg = (float)((double)st->pilot_delay_pss / 3.14159265358979323846 * 180.0f);
+        st->meta_pss_change = st->pss_mean * 1000;
+        st->meta_pss_state = (P.pss_active && lk) ? (st->pss_minimized ? 2 : 1) : 0;
+        cnt -= (SINCOS_N >> 1) + 1;
+    }
+    st->my_count = cnt;
+    st->pss_count += st->pss_call_total;           // advance the PSS filter time base by this call's process_sample calls
+    st->pss_call_total = 0;
+}
+
+// =================================================================================================
+// B9  work array -> channel-major d ring   (transpose)
+// =================================================================================================
+__global__ __launch_bounds__(256) void dring_kernel(DeviceBuffers B, CallGeom G, int C) {
+    const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
+    __shared__ float2 tile[64][65];
+    const int tid = threadIdx.x;
+    const int64_t nj = G.J1 - G.J0;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    for (int i = 0; i < 16; i++) {
+        const int rl = (tid >> 6) + 4 * i, cl = tid & 63;
+        const int ch = c0 + cl; const int64_t r = r0 + rl;
+        if (ch < C && r < nj) tile[cl][rl] = B.w_x[r * CP + ch];
+    }
+    __syncthreads();
+    const int dcap = G.dring_mask + 1;
+    for (int i = 0; i < 16; i++) {
+        const int cl = (tid >> 6) + 4 * i, rl = tid & 63;
+        const int ch = c0 + cl; const int64_t r = r0 + rl;
+        if (ch < C && r < nj) B.dring[(size_t)ch * dcap + ((G.J0 + r) & G.dring_mask)] = tile[cl][rl];
     }
 }
 
-void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s) {
-    if (G.J1 <= G.J0) return;
-    hipLaunchKernelGGL(demod_kernel, dim3(channels), dim3(64), 0, s, T, B, G);
+void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s) {
+    const int64_t nj = G.J1 - G.J0;
+    if (nj <= 0) return;
+    const dim3 tiles((unsigned)((nj + 63) / 64), (unsigned)((C + 63) / 64));
+    const dim3 lanes((unsigned)((C + 63) / 64));
+    hipLaunchKernelGGL(disc_kernel, tiles, dim3(256), 0, s, T, B, G, C);
+    if (B.w_iq) hipLaunchKernelGGL(seq1_kernel<true>, lanes, dim3(64), 0, s, T, B, G, C);
+    else hipLaunchKernelGGL(seq1_kernel<false>, lanes, dim3(64), 0, s, T, B, G, C);
+    for (int64_t rc0 = 0; rc0 < nj; rc0 += PSS_CHUNK) {
+        const int len = (int)((nj - rc0) < PSS_CHUNK ? (nj - rc0) : PSS_CHUNK);
+        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, s, T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, s, T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, s, T, B, G, C, rc0, len);
+    }
+    hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, s, T, B, G, C);
+    hipLaunchKernelGGL(dring_kernel, tiles, dim3(256), 0, s, B, G, C);
 }
 
 }  // namespace fmx

@@ -12,7 +12,7 @@ constexpr int A_MAX_ND = 25;           // tap columns: 287 taps at off=6 -> 25 c
 constexpr int A_TAPS_STRIDE = A_MAX_ND * DECIM;   // 300 floats per front-end tap set
 constexpr int PSS_TAPS = 295;          // stereo-separation.cpp:31
 constexpr int PSS_DELAY = 2048 - 295;  // overlap-add latency fftSize - degree (fft-filters.cpp:34)
-constexpr int B_CHUNK = 256;           // fm samples per sequential chunk of the demod kernel
+constexpr int PSS_CHUNK = 1753;        // PSS feedback lag: the only chunked part of stage B (<= PSS_DELAY)
 constexpr int RS_TAPS = 128;           // fmx resampler (oracle/fm_oracle.c fmo_resampler_taps)
 constexpr int AUDIO_TAPS = 756;        // fm-processor.cpp:76
 constexpr int AUDIO_DELAY = 8192 - 756;
@@ -22,6 +22,8 @@ constexpr int C_TILE = 256;            // PCM frames per audio-FIR tile
 constexpr int SINCOS_N = 192000;
 constexpr int ATAN_N = 8192;
 constexpr int ARCSINE_N = 4 * 8192;
+constexpr int TRIG2_A = 750, TRIG2_B = 256;   // 192000 = 750 * 256: idx = 256 a + b
+constexpr int TRIG2_N = TRIG2_A + TRIG2_B;
 
 // front-end filter description of one tap set
 struct FrontSet {
@@ -65,6 +67,8 @@ struct ChanState {
     int32_t pss_lock_cnt, pss_unlock_cnt, pss_minimized;
     float   pilot_delay_pss;
     int64_t pss_count;           // number of process_sample calls so far (filter time base)
+    int32_t pss_call_total;      // process_sample calls made by the current call (seq1 -> deemph advances pss_count)
+    int32_t pad0;
     // de-emphasis (fm-processor.cpp:594-595)
     float   de_l, de_r;
     // fade-in (fm-processor.cpp:130-131,638-642)
@@ -80,13 +84,14 @@ struct DeviceTables {
     const float  *atan_ppy;      // [ATAN_N + 1]
     const float  *arcsine;       // [ARCSINE_N + 1]
     const float2 *lo_table;      // [inputRate] or null when every lo == 0
+    const double2 *trig2;        // [TRIG2_N] f64 (cos,sin) factors exp(j2pi 256a/N), exp(j2pi b/N); null if the host check failed
     const float  *front_taps;    // [sets][A_TAPS_STRIDE]  T[d*12 + r] = G[12 d + off - r]
     const FrontSet *front_sets;
     const float  *pss_taps;      // [PSS_TAPS]
     const float  *audio_taps;    // [sets][C_TAPS_STRIDE]
     const AudioSet *audio_sets;
     double  sincos_C;            // Rate / (2*M_PI)  (sincos.cpp:42)
-    float   K_FM;
+    float   K_FM, K_FM_rcp, pil_omega_rcp;   // rcp = RN(1/c) for fdiv_const
     float   pil_omega, pil_gain, pss_alpha, pss_lock_alpha;
     float   pll_beta, pll_lo, pll_hi, pll_center;
 };
@@ -100,6 +105,9 @@ struct CallGeom {
     int32_t dring_mask;  // d ring capacity - 1
     int32_t sring_mask;  // s ring capacity - 1
     int32_t input_rate;
+    int32_t pitch;       // row pitch (elements) of the sample-major work arrays: channels + pad, so that
+                         // consecutive rows do not land on the same HBM channel/bank (power-of-two strides do)
+    int32_t pad_;
     int64_t stream_stride, pcm_stride;   // in complex samples / frames
 };
 
@@ -112,6 +120,16 @@ struct DeviceBuffers {
     float2 *dring;       // [channels][dring] de-emphasised, gained stereo @ fmRate
     ChanState *state;
     const ChanParams *params;
+    // sample-major [fm sample of this call][channel] work arrays of stage B
+    float   *w_dem;      // discriminator output, then demod (in place)
+    float2  *w_iq;       // limiter output (only allocated when a channel uses the PLL decoder)
+    float   *w_cur;      // pilot phase (currentPilotPhase)
+    float   *w_osc;      // pilot NCO sine
+    uint8_t *w_lock;     // pilot lock flag per sample
+    float   *w_err;      // [PSS_CHUNK][channel] PSS error for the chunk's call indices
+    float   *w_pdp;      // pilotDelayPSS as used by each sample
+    int32_t *w_tag;      // -2 mono branch, -1 stereo without PSS, >= 0 PSS call index within the chunk
+    float2  *w_x;        // matrix output, then de-emphasised + gained stereo (in place)
 };
 
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const float2 *iq,
