@@ -95,7 +95,7 @@ typedef enum {
     FMX_TAP_FM_IQ = 0,         /* complex @fmRate after fmBand_2 (IF_FILTERED scope, :601-604)   */
     FMX_TAP_DEMOD = 1,         /* float   @fmRate after demodulate (DEMODULATOR scope, :605-607) */
     FMX_TAP_LR_RAW = 2,        /* complex @fmRate (sum,diff) (AF_SUM/AF_DIFF scopes, :608-613)   */
-    FMX_TAP_PRE_RESAMPLER = 3, /* complex @fmRate after de-emphasis + gain (:594-595,630); this
+    FMX_TAP_PRE_RESAMPLER = 3, /* complex @fmRate after de-emphasis (:594-595), before gain; this
                                   build applies the audio low-pass AFTER this point */
 } fmx_tap_id;
 

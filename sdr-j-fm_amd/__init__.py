@@ -5,4 +5,4 @@ The package holds only what the path needs: ``csrc/`` (HIP kernels + the C ABI o
 fmProcessor interface).  Import with ``importlib.import_module("sdr-j-fm_amd")``.
 """
 from .fmx import (Fmx, FmProcessor, FmxError, load_library, EXPORTS, LIB_PATH)  # noqa: F401
-from . import fmx  # noqa: F401
+from . import fmx, shard  # noqa: F401

@@ -59,6 +59,10 @@ __global__ __launch_bounds__(256) void audio_kernel(DeviceTables T, DeviceBuffer
         const float2 v = X[kk & 3][t + (kk >> 2)];
         al = fmaf(w, v.x, al); ar = fmaf(w, v.y, ar);
     }
+    // audioGainCorrection fm-processor.cpp:303-306: (volumeFactor * leftChannel) * sample.  Applied here, at
+    // the output of the folded FIR, so that a volume/balance change takes effect at the call boundary as in
+    // the reference (it sits behind the audio low-pass there) rather than one filter latency late.
+    al *= P.volume * P.left_ch; ar *= P.volume * P.right_ch;
     // start-up fade fm-processor.cpp:638-642: factor = (Max - cnt)/Max with cnt = Max - (m - F)
     const int64_t F = B.state[ch].fade_start_frame;
     const int64_t since = m - F;

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuff
     }
 }
 // =================================================================================================
-// B8  de-emphasis + gain   [lane per channel]   fm-processor.cpp:594-595, 303-306
+// B8  de-emphasis   [lane per channel]   fm-processor.cpp:594-595 (the gain of :303-306 is applied by the audio kernel)
 //     plus the 0.5 s meta snapshot (:662-684)
 // =================================================================================================
 __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
@@ -530,7 +530,6 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
     ChanState *st = B.state + ch;
     const ChanParams &P = B.params[ch];
     const float a = P.deemph_alpha;
-    const float gl = P.volume * P.left_ch, gr = P.volume * P.right_ch;
     float yl = st->de_l, yr = st->de_r;
     float2 *x = B.w_x + ch;
     constexpr int UB = 16;
@@ -551,7 +550,7 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
         for (int k = 0; k < UB; k++) {
             yl = (v[k].x - yl) * a + yl;
             yr = (v[k].y - yr) * a + yr;
-            v[k] = make_float2(gl * yl, gr * yr);
+            v[k] = make_float2(yl, yr);
         }
 #pragma unroll
         for (int k = 0; k < UB; k++) x[k * CP] = v[k];
@@ -561,7 +560,7 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
         const float2 v = x[0];
         yl = (v.x - yl) * a + yl;
         yr = (v.y - yr) * a + yr;
-        x[0] = make_float2(gl * yl, gr * yr);
+        x[0] = make_float2(yl, yr);
         x += CP;
     }
     st->de_l = yl; st->de_r = yr;

@@ -1,0 +1,61 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/fmx.h declares; without a
+HIP device the product path fails loudly (no CPU fallback).  No compute is attempted here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "fmx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fmx_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree(fmx_amd):
+    names = header_functions()
+    assert len(names) >= 15
+    assert sorted(fmx_amd.EXPORTS) == names
+
+
+def test_library_exports_every_declared_symbol(fmx_amd):
+    L = fmx_amd.load_library()
+    for n in header_functions():
+        assert hasattr(L, n), n
+    assert L.fmx_abi_version() == 1
+
+
+def test_no_oracle_dependency_in_product():
+    """The shipped library must not link, load or reference anything under oracle/."""
+    lib = os.path.join(ROOT, "sdr-j-fm_amd", "lib", "libfmx.so")
+    blob = open(lib, "rb").read()
+    assert b"fmoracle" not in blob and b"fmo_chain" not in blob and b"libfmref" not in blob
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sdr-j-fm_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle_lib" not in src and "fm_oracle.h" not in src, os.path.join(dirpath, f)
+
+
+def test_fails_loudly_without_gpu(fmx_amd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(fmx_amd.FmxError) as e:
+        fmx_amd.Fmx(1)
+    assert e.value.code == fmx_amd.fmx.FMX_E_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_null_handle_errors(fmx_amd):
+    L = fmx_amd.load_library()
+    assert L.fmx_set_param(None, 0, 1, 0.0) == fmx_amd.fmx.FMX_E_INVALID
+    assert L.fmx_destroy(None) == 0
+    assert L.fmx_frames_for(None, 10) == -1
+    bad = fmx_amd.fmx.FmxConfig()
+    h = C.c_void_p()
+    assert L.fmx_create(C.byref(bad), C.byref(h)) == fmx_amd.fmx.FMX_E_INVALID      # struct_size mismatch
+    assert b"struct_size" in L.fmx_last_error()

@@ -1,0 +1,92 @@
+"""Host-side logic that needs no GPU: the fmProcessor-shaped mirror (setter names/argument parsing as in
+includes/fm/fm-processor.h:104-156), the block loop of fmProcessor::run(), and the frame-count rule."""
+import numpy as np
+import pytest
+
+
+class FakeFmx:
+    def __init__(self):
+        self.calls = []
+        self.blocks = []
+
+    def set_param(self, pid, value, channel=-1):
+        self.calls.append((pid, value, channel))
+
+    def process_host(self, iq):
+        self.blocks.append(np.asarray(iq).shape)
+        return np.zeros((1, 341, 2), np.float32)
+
+    def meta(self, channel=0):
+        class M:
+            PilotPllLocked, PilotPllLockStrength, DcValIf = 1, 0.35, 0.01
+        return M()
+
+
+class FakeDevice:
+    """deviceHandler-shaped source (devices/device-handler.h:71-74): Samples() / getSamples(n)."""
+    def __init__(self, n):
+        self.left = n
+
+    def Samples(self):
+        return self.left
+
+    def getSamples(self, n):
+        self.left -= n
+        return np.zeros((n, 2), np.float32)
+
+
+class FakeSink:
+    """audioSink-shaped (includes/output/audiosink.h:45)."""
+    def __init__(self):
+        self.frames = 0
+
+    def putSamples(self, pcm):
+        self.frames += pcm.shape[0]
+
+
+def test_setters_map_to_parameter_ids(fmx_amd):
+    m = fmx_amd.fmx
+    f = FakeFmx()
+    p = fmx_amd.FmProcessor(fmx=f, channel=3)
+    p.setBandwidth("165kHz"); p.setBandwidth("Off"); p.setBandwidth("82kHz")
+    assert [c[1] for c in f.calls] == [165000, 0, 82000] and all(c[0] == m.P_BANDWIDTH and c[2] == 3 for c in f.calls)
+    f.calls.clear()
+    p.setfmMode("Mono"); p.setFMdecoder("FM PLL Decoder"); p.setFMdecoder("PLL Decoder")   # unknown name -> default: PLL
+    p.setDeemphasis(50); p.setVolume(-6.0); p.setlfcutoff(15000); p.setSoundBalance(-20); p.setStereoPanorama(150)
+    p.setAttenuation(0.9, 1.1); p.set_localOscillator(-200000); p.setAutoMonoMode(False); p.setPSSMode(True)
+    p.setDCRemove(True); p.triggerFrequencyChange(); p.restartPssAnalyzer(); p.setSoundMode(4)
+    got = [(c[0], c[1]) for c in f.calls]
+    assert got == [(m.P_FM_MODE, 2), (m.P_FM_DECODER, 2), (m.P_FM_DECODER, 2), (m.P_DEEMPHASIS, 50), (m.P_VOLUME_DB, -6.0),
+                   (m.P_LF_CUTOFF, 15000), (m.P_SOUND_BALANCE, -20), (m.P_STEREO_PANORAMA, 150),
+                   (m.P_ATTENUATION_L, 0.9), (m.P_ATTENUATION_R, 1.1), (m.P_LOCAL_OSCILLATOR, -200000),
+                   (m.P_AUTO_MONO, 0), (m.P_PSS, 1), (m.P_DC_REMOVE, 1), (m.A_TRIGGER_FREQUENCY_CHANGE, 0),
+                   (m.A_RESTART_PSS, 0), (m.P_SOUND_MODE, 4)]
+    assert p.isPilotLocked() == (True, 0.35)
+
+
+def test_run_block_pulls_whole_blocks_only(fmx_amd):
+    """fm-processor.cpp:388: the loop waits until Samples() >= 16384 and never consumes a partial block."""
+    f, dev, sink = FakeFmx(), FakeDevice(16384 * 3 + 100), FakeSink()
+    p = fmx_amd.FmProcessor(theDevice=dev, mySink=sink, fmx=f)
+    n = 0
+    while p.run_block():
+        n += 1
+    assert n == 3 and dev.left == 100 and sink.frames == 3 * 341
+    assert f.blocks == [(16384, 2)] * 3
+
+
+def frames_model(g, n):
+    j0, j1 = g // 12, (g + n) // 12
+    return 48 * (j1 // 192) - 48 * (j0 // 192)
+
+
+def test_frame_count_rule_matches_oracle(ol):
+    """192 fm samples in -> 48 PCM frames out (newconverter.cpp:55-80); the oracle only consumes whole 16384 blocks."""
+    ch = ol.OracleChain(inputFilterBw=0)
+    g = 0
+    for k in (1, 3, 2, 7):
+        n = 16384 * k
+        got = ch.process(np.zeros((n, 2), np.float32)).shape[0]
+        assert got == frames_model(g, n)
+        g += n
+    assert frames_model(0, 16384) == 336 and frames_model(16384, 16384) == 336 and frames_model(0, 230400) == 4800
