@@ -59,3 +59,12 @@ def test_null_handle_errors(fmx_amd):
     h = C.c_void_p()
     assert L.fmx_create(C.byref(bad), C.byref(h)) == fmx_amd.fmx.FMX_E_INVALID      # struct_size mismatch
     assert b"struct_size" in L.fmx_last_error()
+
+
+def test_cpp_adapter_compiles_and_links(fmx_amd, tmp_path):
+    """The Qt-free fmProcessor-shaped C++ adapter builds against include/fmx.h and links libfmx.so."""
+    import subprocess
+    host = os.path.join(ROOT, "sdr-j-fm_amd", "host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(host, "adapter_demo.cpp"),
+                           "-L" + os.path.dirname(fmx_amd.LIB_PATH), "-lfmx",
+                           "-Wl,-rpath," + os.path.dirname(fmx_amd.LIB_PATH), "-o", str(tmp_path / "adapter_demo")])

@@ -384,3 +384,23 @@ def test_many_channels_spot_check(fmx_amd, ol):
         want = ol.OracleChain(inputFilterBw=165000).process(base[c % 4])
         assert rms(pcm[c] - want) <= PCM_RMS_TOL, c
         assert np.array_equal(pcm[c], pcm[c % 4])
+
+
+def test_cpp_adapter_drop_in(fmx_amd, ol, tmp_path):
+    """The C++ fmProcessor-shaped adapter (sdr-j-fm_amd/host) driven like RadioInterface drives fmProcessor:
+    deviceHandler-shaped source -> FmProcessor -> audioSink-shaped sink, 16384-sample blocks."""
+    import subprocess
+    host = os.path.join(os.path.dirname(fmx_amd.__file__), "host")
+    exe = str(tmp_path / "adapter_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(host, "adapter_demo.cpp"),
+                           "-L" + os.path.dirname(fmx_amd.LIB_PATH), "-lfmx",
+                           "-Wl,-rpath," + os.path.dirname(fmx_amd.LIB_PATH), "-o", exe])
+    n = 16384 * 80 + 1000                                  # the tail < 16384 is never pulled (fm-processor.cpp:388)
+    iq = ol.synth_iq(n)
+    iq.tofile(str(tmp_path / "iq.f32"))
+    out = subprocess.check_output([exe, str(tmp_path / "iq.f32"), str(tmp_path / "pcm.f32")]).decode()
+    pcm = np.fromfile(str(tmp_path / "pcm.f32"), np.float32).reshape(-1, 2)
+    want = ol.OracleChain(inputFilterBw=165000).process(iq)
+    assert pcm.shape == want.shape, out
+    assert rms(pcm - want) <= PCM_RMS_TOL
+    assert "locked 1" in out
