@@ -89,6 +89,11 @@ typedef struct {
     int32_t PilotPllLocked;
     int64_t fm_samples;        /* fm-rate samples processed so far */
     int64_t pcm_frames;        /* PCM frames produced so far */
+    /* live values (not the 0.5 s snapshot): what isPilotLocked() (:870-880) / get_demodDcComponent() (:221-226) read */
+    int32_t live_pilot_locked;
+    float   live_lock_strength;
+    float   live_dc_if;
+    int32_t reserved;
 } fmx_meta;
 
 typedef enum {

@@ -104,7 +104,7 @@ void build_front_set(int32_t bw, int32_t inputRate, int32_t fmRate, float *taps 
     for (int d = 0; d < A_MAX_ND; d++)
         for (int r = 0; r < DECIM; r++) {
             const int k = 12 * d + off - r;
-            if (k >= 0 && k < NT) { taps[d * DECIM + r] = (float)g[k]; nd = d + 1; }
+            if (k >= 0 && k < NT) { taps[(d + 1) * DECIM + r] = (float)g[k]; nd = d + 1; }
         }
     fs->nd = nd;
     // complex gain of the (h/sum, h) kernels: (1 + j S1)(1 + j S2)  (fir-filters.cpp:345-346)
@@ -558,6 +558,9 @@ int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
     m->DcValRf = st.meta_dc_rf; m->DcValIf = st.meta_dc_if; m->PssPhaseShiftDegree = st.meta_pss_deg;
     m->PssPhaseChange = st.meta_pss_change; m->PssState = st.meta_pss_state;
     m->PilotPllLockStrength = st.meta_lock_strength; m->PilotPllLocked = st.meta_locked;
+    m->live_pilot_locked = (h->params[channel].fm_mode != 2) ? st.pil_locked : 0;
+    m->live_lock_strength = (h->params[channel].fm_mode != 2) ? st.pil_lock : 0.f;
+    m->live_dc_if = st.fm_afc; m->reserved = 0;
     m->fm_samples = h->g_total / DECIM; m->pcm_frames = 48 * ((h->g_total / DECIM) / 192);
     return FMX_OK;
 }
@@ -610,7 +613,7 @@ int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32
         tmp.assign(A_TAPS_STRIDE, 0.f);
         for (int d = 0; d < fs.nd; d++) for (int r = 0; r < DECIM; r++) {
             int k = 12 * d + fs.off - r;
-            if (k >= 0 && k < A_TAPS_STRIDE) { tmp[k] = t[d * DECIM + r]; if (t[d * DECIM + r] != 0.f) NT = std::max(NT, k + 1); }
+            if (k >= 0 && k < A_TAPS_STRIDE) { tmp[k] = t[(d + 1) * DECIM + r]; if (t[(d + 1) * DECIM + r] != 0.f) NT = std::max(NT, k + 1); }
         }
         src = tmp.data(); cnt = NT; break; }
     case 1: src = h->h_pss_taps.data(); cnt = PSS_TAPS; break;
@@ -626,6 +629,23 @@ int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32
     if (cnt > capacity) return fail(FMX_E_TOO_LARGE, "capacity too small");
     std::memcpy(dst, src, sizeof(float) * cnt);
     *n = cnt;
+    return FMX_OK;
+}
+
+// diagnostics (not part of include/fmx.h): per-phase shader-cycle counters of front_kernel, summed over channels
+int fmx_debug_phase_cycles(fmx_handle h, int32_t enable, unsigned long long *out /*[16], may be null*/) {
+    if (!h) return fail(FMX_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t nb = sizeof(unsigned long long) * 16 * (size_t)h->channels;
+    if (out && h->B.dbg) {
+        std::vector<unsigned long long> tmp(16 * (size_t)h->channels);
+        HIPCHK(hipMemcpy(tmp.data(), h->B.dbg, nb, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 16; k++) { out[k] = 0; for (int c = 0; c < h->channels; c++) out[k] += tmp[(size_t)c * 16 + k]; }
+    }
+    if (enable && !h->B.dbg) { HIPCHK(hipMalloc(&h->B.dbg, nb)); }
+    if (h->B.dbg) HIPCHK(hipMemset(h->B.dbg, 0, nb));
+    if (!enable && h->B.dbg) { (void)hipFree(h->B.dbg); h->B.dbg = nullptr; }
     return FMX_OK;
 }
 

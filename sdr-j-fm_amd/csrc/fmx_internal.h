@@ -9,7 +9,7 @@ constexpr int DECIM = 12;              // inputRate / fmRate (2304000 / 192000)
 constexpr int A_TILE_COLS = 256;       // front-end tile: 256 fm-rate outputs = 3072 input samples
 constexpr int A_HIST_COLS = 25;        // history columns kept per channel (>= max taps/12 + 1)
 constexpr int A_MAX_ND = 25;           // tap columns: 287 taps at off=6 -> 25 columns of 12
-constexpr int A_TAPS_STRIDE = A_MAX_ND * DECIM;   // 300 floats per front-end tap set
+constexpr int A_TAPS_STRIDE = (A_MAX_ND + 2) * DECIM;   // 324: Tz[(d+1)*12 + r], d = -1..25, zero rows at both ends
 constexpr int PSS_TAPS = 295;          // stereo-separation.cpp:31
 constexpr int PSS_DELAY = 2048 - 295;  // overlap-add latency fftSize - degree (fft-filters.cpp:34)
 constexpr int PSS_CHUNK = 1753;        // PSS feedback lag: the only chunked part of stage B (<= PSS_DELAY)
@@ -85,7 +85,7 @@ struct DeviceTables {
     const float  *arcsine;       // [ARCSINE_N + 1]
     const float2 *lo_table;      // [inputRate] or null when every lo == 0
     const double2 *trig2;        // [TRIG2_N] f64 (cos,sin) factors exp(j2pi 256a/N), exp(j2pi b/N); null if the host check failed
-    const float  *front_taps;    // [sets][A_TAPS_STRIDE]  T[d*12 + r] = G[12 d + off - r]
+    const float  *front_taps;    // [sets][A_TAPS_STRIDE]  Tz[(d+1)*12 + r] = G[12 d + off - r] (0 outside)
     const FrontSet *front_sets;
     const float  *pss_taps;      // [PSS_TAPS]
     const float  *audio_taps;    // [sets][C_TAPS_STRIDE]
@@ -120,6 +120,7 @@ struct DeviceBuffers {
     float2 *dring;       // [channels][dring] de-emphasised, gained stereo @ fmRate
     ChanState *state;
     const ChanParams *params;
+    unsigned long long *dbg;   // optional [channels][16] per-phase cycle counters of front_kernel (null = off; diagnostics)
     // sample-major [fm sample of this call][channel] work arrays of stage B
     float   *w_dem;      // discriminator output, then demod (in place)
     float2  *w_iq;       // limiter output (only allocated when a channel uses the PLL decoder)

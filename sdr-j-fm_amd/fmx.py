@@ -50,6 +50,8 @@ class FmxMeta(C.Structure):
         ("DcValRf", C.c_float), ("DcValIf", C.c_float), ("PssPhaseShiftDegree", C.c_float),
         ("PssPhaseChange", C.c_float), ("PssState", C.c_int32), ("PilotPllLockStrength", C.c_float),
         ("PilotPllLocked", C.c_int32), ("fm_samples", C.c_int64), ("pcm_frames", C.c_int64),
+        ("live_pilot_locked", C.c_int32), ("live_lock_strength", C.c_float), ("live_dc_if", C.c_float),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -261,9 +263,9 @@ class FmProcessor:
 
     def isPilotLocked(self):
         m = self.fmx.meta(self.channel)
-        return bool(m.PilotPllLocked), m.PilotPllLockStrength
+        return bool(m.live_pilot_locked), m.live_lock_strength
 
-    def get_demodDcComponent(self): return self.fmx.meta(self.channel).DcValIf
+    def get_demodDcComponent(self): return self.fmx.meta(self.channel).live_dc_if
 
     def run_block(self):
         """One loop iteration of fmProcessor::run(): returns False when the device has < bufferSize samples."""

@@ -100,10 +100,10 @@ public:
     bool isPilotLocked(float &oLockStrength) {                             // fm-processor.cpp:870-880
         fmx_meta m{};
         if (fmx_get_meta(h, 0, &m) != FMX_OK) { oLockStrength = 0; return false; }
-        oLockStrength = m.PilotPllLockStrength;
-        return m.PilotPllLocked != 0;
+        oLockStrength = m.live_lock_strength;
+        return m.live_pilot_locked != 0;
     }
-    float get_demodDcComponent() { fmx_meta m{}; return fmx_get_meta(h, 0, &m) == FMX_OK ? m.DcValIf : 0.0f; }
+    float get_demodDcComponent() { fmx_meta m{}; return fmx_get_meta(h, 0, &m) == FMX_OK ? m.live_dc_if : 0.0f; }
 
     // ---- the processing loop ----
     // One iteration of the while loop of fmProcessor::run() (fm-processor.cpp:387-686).  Returns false

@@ -19,6 +19,7 @@ class FakeFmx:
     def meta(self, channel=0):
         class M:
             PilotPllLocked, PilotPllLockStrength, DcValIf = 1, 0.35, 0.01
+            live_pilot_locked, live_lock_strength, live_dc_if = 1, 0.35, 0.01
         return M()
 
 
