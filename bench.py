@@ -191,6 +191,16 @@ def main():
         # algorithmic bytes of ONE front-end launch: every channel reads its n samples (8 B) and writes n/12 (8 B)
         alg_bytes = ALG_BYTES_STAGE_A * channels * n
         achieved = alg_bytes / (ms_a * 1e-3) / 1e9 if ms_a > 0 else 0.0
+        # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE),
+        # committed under profiles/; only valid for the configuration it was collected on.
+        traffic = None
+        try:
+            pmcs = sorted(x for x in os.listdir(os.path.join(ROOT, "profiles")) if x.endswith("_front_pmc.json"))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
+            if pmc.get("channels") == channels and pmc.get("block") == n:
+                traffic = pmc["front_kernel_hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "IQ MSamples/s demodulated to 48 kHz stereo",
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -202,7 +212,7 @@ def main():
                        "pcm_frames_per_channel_per_step": frames // max(args.steps, 1), "parallelism": "channels sharded, 1 rank/GPU"},
             "roofline": {"bound": "hbm", "kernel": "fmx::front_kernel (input FIR stage)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": None, "avg_launch_ms": round(ms_a, 4),
+                         "traffic": traffic, "avg_launch_ms": round(ms_a, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "kernels_ms_per_step": {"front_fir": round(prof["ms"][0] / launches, 4),
                                     "demod_pilot_pss": round(prof["ms"][1] / launches, 4),
