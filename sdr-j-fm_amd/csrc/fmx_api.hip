@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -47,6 +48,8 @@ struct fmx_handle_s {
     fmx_config cfg{};
     int channels = 0, streams = 0;
     hipStream_t stream = nullptr;
+    hipStream_t s_pss = nullptr, s_post = nullptr;      // side streams of the stage-B chunk pipeline
+    std::vector<hipEvent_t> evs; hipEvent_t ev_join = nullptr;
     std::mutex mtx;                          // guards the mailbox (set_param from any thread)
     std::vector<ChanUser> user;
     std::vector<ChanParams> params;          // host mirror
@@ -150,7 +153,7 @@ int ensure_sets(fmx_handle h) {
             HIPCHK(hipMalloc(&h->d_front_taps, sizeof(float) * A_TAPS_STRIDE * h->front_cap));
             HIPCHK(hipMalloc(&h->d_front_sets, sizeof(FrontSet) * h->front_cap));
         }
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(h->d_front_taps, h->h_front_taps.data(), sizeof(float) * h->h_front_taps.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_front_sets, h->h_front_sets.data(), sizeof(FrontSet) * fk.size(), hipMemcpyHostToDevice));
         h->T.front_taps = h->d_front_taps; h->T.front_sets = h->d_front_sets;
@@ -167,7 +170,7 @@ int ensure_sets(fmx_handle h) {
             HIPCHK(hipMalloc(&h->d_audio_taps, sizeof(float) * C_TAPS_STRIDE * h->audio_cap));
             HIPCHK(hipMalloc(&h->d_audio_sets, sizeof(AudioSet) * h->audio_cap));
         }
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(h->d_audio_taps, h->h_audio_taps.data(), sizeof(float) * h->h_audio_taps.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_audio_sets, h->h_audio_sets.data(), sizeof(AudioSet) * ak.size(), hipMemcpyHostToDevice));
         h->T.audio_taps = h->d_audio_taps; h->T.audio_sets = h->d_audio_sets;
@@ -214,11 +217,11 @@ int flush_mailbox(fmx_handle h) {
     bool any_pll = false;
     for (auto &p : h->params) any_pll |= (p.decoder == 2);
     if (any_pll && !h->B.w_iq) {
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMalloc(&h->B.w_iq, sizeof(float2) * (size_t)h->work_nj * h->pitch));
     }
     if (h->params_dirty) {
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipDeviceSynchronize());   // the previous call may still run on the caller's stream and the side streams
         HIPCHK(hipMemcpy(h->d_params, h->params.data(), sizeof(ChanParams) * h->channels, hipMemcpyHostToDevice));
         bool had_actions = false;
         for (auto &p : h->params) { had_actions |= (p.actions != 0); p.actions = 0; }
@@ -253,7 +256,11 @@ int run_call(fmx_handle h, const float2 *d_iq, int64_t stream_stride, int64_t n,
     }
     launch_front(h->T, h->B, G, d_iq, h->channels, s);
     if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
-    launch_demod(h->T, h->B, G, h->channels, s);
+    {
+        static const bool serial = getenv("FMX_SERIAL_STAGE_B") != nullptr;     // diagnostics: no side streams
+        DemodStreams DS{serial ? nullptr : h->s_pss, serial ? nullptr : h->s_post, h->evs.data(), (int)h->evs.size(), h->ev_join};
+        launch_demod(h->T, h->B, G, h->channels, s, DS);
+    }
     if (prof) HIPCHK(hipEventRecord(pr.e[2], s));
     launch_audio(h->T, h->B, G, d_pcm, h->channels, s);
     if (prof) { HIPCHK(hipEventRecord(pr.e[3], s)); h->prof.push_back(pr); }
@@ -318,6 +325,11 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         refresh_derived(h, c);
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->s_pss, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->s_post, hipStreamNonBlocking));
+    h->evs.resize(64);
+    for (auto &e : h->evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
 
     // ---- tables -------------------------------------------------------------------------
     const int32_t fmRate = cfg->fmRate;
@@ -436,6 +448,10 @@ int fmx_destroy(fmx_handle h) {
                      h->B.lr_ring, h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
                      h->B.w_osc, h->B.w_lock, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : h->evs) (void)hipEventDestroy(e);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->s_pss) (void)hipStreamDestroy(h->s_pss);
+    if (h->s_post) (void)hipStreamDestroy(h->s_post);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FMX_OK;

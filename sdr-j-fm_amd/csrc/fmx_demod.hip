@@ -255,7 +255,8 @@ __device__ __forceinline__ void seq1_step(Seq1State &s, const Seq1Const &c, cons
 }
 
 template <bool PLLDEC>
-__global__ __launch_bounds__(64) void seq1_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
+__global__ __launch_bounds__(64) void seq1_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
+                                                  int64_t rc0, int chunk_len) {
     const int CP = G.pitch;       // padded row pitch of the sample-major work arrays
     __shared__ double2 sA[TRIG2_A];
     __shared__ double2 sB[TRIG2_B];
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(64) void seq1_kernel(DeviceTables T, DeviceBuffers 
     __syncthreads();
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= C) return;
-    const int64_t nj = G.J1 - G.J0;
+    const int64_t nj = chunk_len;                   // this launch handles rows [rc0, rc0 + chunk_len) of the call
     ChanState *st = B.state + ch;
     const ChanParams &P = B.params[ch];
     c.use_pll = PLLDEC && (P.decoder == 2);
@@ -279,9 +280,10 @@ __global__ __launch_bounds__(64) void seq1_kernel(DeviceTables T, DeviceBuffers 
     Seq1State s;
     s.afc = st->fm_afc; s.nco_phase = st->nco_phase; s.incr = st->phase_incr;
     s.phase = st->pil_phase; s.lock = st->pil_lock; s.old = st->pil_old;
-    s.stable = st->pil_stable; s.locked = st->pil_locked; s.tagn = 0;
-    float *wd = B.w_dem + ch; float *wc = B.w_cur + ch; uint8_t *wl = B.w_lock + ch; int *wt = B.w_tag + ch;
-    const float2 *wiq = PLLDEC ? B.w_iq + ch : nullptr;
+    s.stable = st->pil_stable; s.locked = st->pil_locked; s.tagn = (rc0 == 0) ? 0 : st->pss_call_total;
+    const int64_t ro = rc0 * (int64_t)CP + ch;
+    float *wd = B.w_dem + ro; float *wc = B.w_cur + ro; uint8_t *wl = B.w_lock + ro; int *wt = B.w_tag + ro;
+    const float2 *wiq = PLLDEC ? B.w_iq + ro : nullptr;
 
     // main loop: full batches, no guards; the next batch's inputs are loaded while this one computes
     const int64_t nfull = nj / SEQ_UB;
@@ -522,16 +524,17 @@ __global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuff
 // B8  de-emphasis   [lane per channel]   fm-processor.cpp:594-595 (the gain of :303-306 is applied by the audio kernel)
 //     plus the 0.5 s meta snapshot (:662-684)
 // =================================================================================================
-__global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
+__global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
+                                                    int64_t rc0, int chunk_len, int last_chunk) {
     const int CP = G.pitch;       // padded row pitch of the sample-major work arrays
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= C) return;
-    const int64_t nj = G.J1 - G.J0;
+    const int64_t nj = chunk_len;
     ChanState *st = B.state + ch;
     const ChanParams &P = B.params[ch];
     const float a = P.deemph_alpha;
     float yl = st->de_l, yr = st->de_r;
-    float2 *x = B.w_x + ch;
+    float2 *x = B.w_x + rc0 * (int64_t)CP + ch;
     constexpr int UB = 16;
     const int64_t nfull = nj / UB;
     float2 nx[UB];
@@ -564,9 +567,10 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
         x += CP;
     }
     st->de_l = yl; st->de_r = yr;
+    if (!last_chunk) return;
     // meta snapshot: emitted by the reference every fmRate/2 samples; taken at the end of the call
     // in which that count is crossed (values of the call end)
-    int cnt = st->my_count + (int)nj;
+    int cnt = st->my_count + (int)(G.J1 - G.J0);
     if (cnt > (SINCOS_N >> 1)) {
         const bool stereo_possible = P.fm_mode != 2;
         const bool lk = stereo_possible && st->pil_locked;
@@ -609,22 +613,33 @@ __global__ __launch_bounds__(256) void dring_kernel(DeviceBuffers B, CallGeom G,
     }
 }
 
-void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s) {
+void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s,
+                  const DemodStreams &DS) {
     const int64_t nj = G.J1 - G.J0;
     if (nj <= 0) return;
     const dim3 tiles((unsigned)((nj + 63) / 64), (unsigned)((C + 63) / 64));
     const dim3 lanes((unsigned)((C + 63) / 64));
     hipLaunchKernelGGL(disc_kernel, tiles, dim3(256), 0, s, T, B, G, C);
-    if (B.w_iq) hipLaunchKernelGGL(seq1_kernel<true>, lanes, dim3(64), 0, s, T, B, G, C);
-    else hipLaunchKernelGGL(seq1_kernel<false>, lanes, dim3(64), 0, s, T, B, G, C);
-    for (int64_t rc0 = 0; rc0 < nj; rc0 += PSS_CHUNK) {
+    // The recurrences are latency-bound and use a handful of wavefronts, so the three chunked stages run as a
+    // software pipeline on three streams: seq1(chunk c+1) || PSS loop(chunk c) || de-emphasis(chunk c-1).
+    // Chunks are rows of the same work arrays, so nothing is double-buffered.
+    hipStream_t s2 = DS.pss ? DS.pss : s, s3 = DS.post ? DS.post : s;
+    int c = 0;
+    for (int64_t rc0 = 0; rc0 < nj; rc0 += PSS_CHUNK, c++) {
         const int len = (int)((nj - rc0) < PSS_CHUNK ? (nj - rc0) : PSS_CHUNK);
-        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, s, T, B, G, C, rc0, len);
-        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, s, T, B, G, C, rc0, len);
-        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, s, T, B, G, C, rc0, len);
+        const int last = (rc0 + len >= nj) ? 1 : 0;
+        if (B.w_iq) hipLaunchKernelGGL(seq1_kernel<true>, lanes, dim3(64), 0, s, T, B, G, C, rc0, len);
+        else hipLaunchKernelGGL(seq1_kernel<false>, lanes, dim3(64), 0, s, T, B, G, C, rc0, len);
+        hipEvent_t e1 = DS.ev ? DS.ev[(2 * c) % DS.nev] : nullptr, e2 = DS.ev ? DS.ev[(2 * c + 1) % DS.nev] : nullptr;
+        if (s2 != s) { (void)hipEventRecord(e1, s); (void)hipStreamWaitEvent(s2, e1, 0); }
+        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, s2, T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, s2, T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, s2, T, B, G, C, rc0, len);
+        if (s3 != s2) { (void)hipEventRecord(e2, s2); (void)hipStreamWaitEvent(s3, e2, 0); }
+        hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, s3, T, B, G, C, rc0, len, last);
     }
-    hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, s, T, B, G, C);
-    hipLaunchKernelGGL(dring_kernel, tiles, dim3(256), 0, s, B, G, C);
+    hipLaunchKernelGGL(dring_kernel, tiles, dim3(256), 0, s3, B, G, C);
+    if (s3 != s) { (void)hipEventRecord(DS.join, s3); (void)hipStreamWaitEvent(s, DS.join, 0); }
 }
 
 }  // namespace fmx

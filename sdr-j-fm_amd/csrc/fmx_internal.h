@@ -135,7 +135,10 @@ struct DeviceBuffers {
 
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const float2 *iq,
                   int channels, hipStream_t s);
-void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
+// side streams + events for the chunk pipeline of stage B (null streams = run everything on the caller's stream)
+struct DemodStreams { hipStream_t pss, post; hipEvent_t *ev; int nev; hipEvent_t join; };
+void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s,
+                  const DemodStreams &DS);
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,
                   int channels, hipStream_t s);
 
