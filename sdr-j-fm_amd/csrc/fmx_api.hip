@@ -48,7 +48,7 @@ struct fmx_handle_s {
     fmx_config cfg{};
     int channels = 0, streams = 0;
     hipStream_t stream = nullptr;
-    hipStream_t s_pss = nullptr, s_post = nullptr;      // side streams of the stage-B chunk pipeline
+    hipStream_t s_side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the stage-B chunk pipeline
     std::vector<hipEvent_t> evs; hipEvent_t ev_join = nullptr;
     std::mutex mtx;                          // guards the mailbox (set_param from any thread)
     std::vector<ChanUser> user;
@@ -245,7 +245,7 @@ int run_call(fmx_handle h, const float2 *d_iq, int64_t stream_stride, int64_t n,
     CallGeom G{};
     frames_geom(h, n, &G);
     G.ring_mask = h->ring - 1; G.dring_mask = h->dring - 1; G.sring_mask = h->sring - 1;
-    G.input_rate = h->cfg.inputRate; G.pitch = h->pitch; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
+    G.input_rate = h->cfg.inputRate; G.pitch = h->pitch; G.pad_ = 0; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
     const int64_t frames = G.M1 - G.M0;
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
     ProfRec pr{}; const bool prof = h->prof_on;
@@ -258,7 +258,9 @@ int run_call(fmx_handle h, const float2 *d_iq, int64_t stream_stride, int64_t n,
     if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
     {
         static const bool serial = getenv("FMX_SERIAL_STAGE_B") != nullptr;     // diagnostics: no side streams
-        DemodStreams DS{serial ? nullptr : h->s_pss, serial ? nullptr : h->s_post, h->evs.data(), (int)h->evs.size(), h->ev_join};
+        DemodStreams DS{};
+        for (int i = 0; i < 4; i++) DS.side[i] = serial ? nullptr : h->s_side[i];
+        DS.ev = h->evs.data(); DS.nev = (int)h->evs.size(); DS.join = h->ev_join;
         launch_demod(h->T, h->B, G, h->channels, s, DS);
     }
     if (prof) HIPCHK(hipEventRecord(pr.e[2], s));
@@ -325,9 +327,8 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         refresh_derived(h, c);
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&h->s_pss, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&h->s_post, hipStreamNonBlocking));
-    h->evs.resize(64);
+    for (auto &ss : h->s_side) HIPCHK(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
+    h->evs.resize(128);
     for (auto &e : h->evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
 
@@ -450,8 +451,7 @@ int fmx_destroy(fmx_handle h) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->evs) (void)hipEventDestroy(e);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->s_pss) (void)hipStreamDestroy(h->s_pss);
-    if (h->s_post) (void)hipStreamDestroy(h->s_post);
+    for (auto &ss : h->s_side) if (ss) (void)hipStreamDestroy(ss);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FMX_OK;

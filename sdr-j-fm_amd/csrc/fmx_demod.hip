@@ -180,146 +180,210 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
 }
 
 // =================================================================================================
-// B2  the per-sample recurrences up to the pilot lock   [lane per channel, 64 channels per wave]
-//       AFC + scaling            fm-demodulator.cpp:197-198   (pllC.cpp:67-90 when decoder == PLL)
-//       pilot PLL                pilot-recover.cpp:54-61
-//       lock detector            pilot-recover.cpp:62-80
-//       PSS call index (tag)     fm-processor.cpp:704-705,716-718 (which samples call process_sample)
-//     Work arrays are read a batch ahead into registers (global latency off the dependent chain);
-//     the NCO sine (float)sin(2*pi*idx/192000) is rebuilt from two f64 factor tables held in LDS
-//     (idx = 256 a + b); the host proved the expression rounds to the reference's f32 table entry
-//     for every idx (fmx_api.hip), else T.trig2 is null and the global table is used.
+// B2..B4  the per-sample recurrences up to the pilot lock   [lane per channel, 64 channels per wave]
+//   B2 afc_kernel   AFC + scaling            fm-demodulator.cpp:197-198  (pllC.cpp:67-90 when decoder == PLL)
+//   B3 pll_kernel   pilot PLL                pilot-recover.cpp:54-61
+//   B4 lock_kernel  lock detector            pilot-recover.cpp:62-80
+//                   PSS call index (tag)     fm-processor.cpp:704-705,716-718 (which samples call process_sample)
+// Three kernels rather than one: each is a dependent chain whose time is set by instruction latency, and as
+// separate stages of the chunk pipeline (launch_demod) they run concurrently on different wavefronts.
+// Work arrays are read a batch ahead into registers (global latency off the dependent chain).
 // =================================================================================================
-constexpr int SEQ_UB = 8;
-struct Seq1State {
-    float afc, nco_phase, incr, phase, lock, old;
-    int stable, locked, tagn;
-};
-struct Seq1Const {
-    float c1, fmDcAlpha, K, rK, gain, omega, romega, lockA;
-    double keep, SC;
-    bool stereo_possible, auto_mono, pss_active, use_pll, t2;
-};
+constexpr int SEQ_UB = 16;
+
+// ---- B2
 template <bool PLLDEC>
-__device__ __forceinline__ void seq1_step(Seq1State &s, const Seq1Const &c, const DeviceTables &T,
-                                          const double2 *sA, const double2 *sB, float res, float2 sig,
-                                          float &o_dem, float &o_cur, int &o_lk, int &o_tag) {
-    if (PLLDEC) {
-        if (c.use_pll) {                         // pllC::do_pll pllC.cpp:67-90
-            const float2 nco = sc_complex(T.sincos, c.SC, s.nco_phase);
-            const float dre = nco.x * sig.x - (-nco.y) * sig.y;      // conj(nco) * signal
-            const float dim = nco.x * sig.y + (-nco.y) * sig.x;
-            const float perr = lut_atan2(T.atan_ppy, dim, dre);
-            s.incr = (1 - T.pll_beta) * perr + T.pll_beta * s.incr;
-            if (s.incr < T.pll_lo || s.incr > T.pll_hi) s.incr = T.pll_center;
-            s.nco_phase += s.incr;
-            if ((double)s.nco_phase >= FMX_2PI) s.nco_phase = (float)fmod_2pi((double)s.nco_phase);
-            else while (s.nco_phase < 0) s.nco_phase = (float)((double)s.nco_phase + FMX_2PI);
-            res = s.incr;
+__global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
+                                                 int64_t rc0, int chunk_len) {
+    const int CP = G.pitch;
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C) return;
+    ChanState *st = B.state + ch;
+    const bool use_pll = PLLDEC && (B.params[ch].decoder == 2);
+    const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha, K = T.K_FM, rK = T.K_FM_rcp;
+    const double SC = T.sincos_C;
+    float afc = st->fm_afc, nco_phase = st->nco_phase, incr = st->phase_incr;
+    const int64_t ro = rc0 * (int64_t)CP + ch;
+    float *wd = B.w_dem + ro;
+    const float2 *wiq = PLLDEC ? B.w_iq + ro : nullptr;
+    auto step = [&](float res, float2 sig) -> float {
+        if (PLLDEC) {
+            if (use_pll) {                           // pllC::do_pll pllC.cpp:67-90
+                const float2 nco = sc_complex(T.sincos, SC, nco_phase);
+                const float dre = nco.x * sig.x - (-nco.y) * sig.y;      // conj(nco) * signal
+                const float dim = nco.x * sig.y + (-nco.y) * sig.x;
+                const float perr = lut_atan2(T.atan_ppy, dim, dre);
+                incr = (1 - T.pll_beta) * perr + T.pll_beta * incr;
+                if (incr < T.pll_lo || incr > T.pll_hi) incr = T.pll_center;
+                nco_phase += incr;
+                if ((double)nco_phase >= FMX_2PI) nco_phase = (float)fmod_2pi((double)nco_phase);
+                else while (nco_phase < 0) nco_phase = (float)((double)nco_phase + FMX_2PI);
+                res = incr;
+            }
         }
+        afc = c1 * afc + fmDcAlpha * res;            // fm-demodulator.cpp:197
+        return fdiv_const(20.0f * (res - afc) * 1.0f, K, rK);      // :198
+    };
+    constexpr int UB = 32;
+    const int nfull = chunk_len / UB;
+    float nx[UB]; float2 nq[UB];
+    if (nfull > 0) {
+#pragma unroll
+        for (int k = 0; k < UB; k++) { nx[k] = wd[k * CP]; if (PLLDEC) nq[k] = wiq[k * CP]; }
     }
-    // AFC + scaling fm-demodulator.cpp:197-198
-    s.afc = c.c1 * s.afc + c.fmDcAlpha * res;
-    const float demod = fdiv_const(20.0f * (res - s.afc) * 1.0f, c.K, c.rK);
-    o_dem = demod;
-    // pilot PLL: SinCos::getSin sincos.cpp:81-85 (phase stays within (-2pi, 4pi))
-    const float pilot = 5 * demod;
-    const bool neg = s.phase < 0.f;
-    const float p = neg ? -s.phase : s.phase;
-    int idx = (int)((double)p * c.SC);
-    idx = (idx >= SINCOS_N) ? idx - SINCOS_N : idx;          // p <= 2pi + 0.01 -> idx <= N + 306
-    float osc;
-    if (c.t2) {
-        const double2 ea = sA[idx >> 8], eb = sB[idx & 255];
-        osc = (float)(ea.y * eb.x + ea.x * eb.y);
-    } else osc = T.sincos[idx].y;
-    osc = neg ? -osc : osc;
-    const float perr = pilot * osc;
-    s.phase += perr * c.gain;
-    o_cur = s.phase;                                         // PI_Constrain of it is applied in pss_mix_kernel
-    s.phase = pi_constrain_near(s.phase + c.omega);
-    // lock detector pilot-recover.cpp:62-80
-    const float quadRef = fdiv_const(osc - s.old, c.omega, c.romega);
-    s.old = osc;
-    s.lock = (float)((double)(c.lockA * (-quadRef * pilot)) + (double)s.lock * c.keep);
-    const bool tmp = s.lock > 0.07f;
-    // if (tmp) { if (locked || ++stable > N/2) locked = 1; } else { locked = 0; stable = 0; }
-    const int stable_inc = s.stable + ((tmp && !s.locked) ? 1 : 0);
-    s.locked = tmp ? ((s.locked || stable_inc > (SINCOS_N >> 1)) ? 1 : 0) : 0;
-    s.stable = tmp ? stable_inc : 0;
-    o_lk = s.locked;
-    // which samples call PerfectStereoSeparation::process_sample (fm-processor.cpp:704-705,716-718)
-    const bool branch = c.stereo_possible && (s.locked || !c.auto_mono);
-    o_tag = branch ? (c.pss_active ? s.tagn : -1) : -2;
-    s.tagn += (branch && c.pss_active) ? 1 : 0;
+    for (int b = 0; b < nfull; b++) {
+        float x[UB]; float2 xq[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) { x[k] = nx[k]; xq[k] = PLLDEC ? nq[k] : make_float2(0.f, 0.f); }
+        const int nb = (b + 1 < nfull) ? UB * CP : 0;             // the last prefetch re-reads this batch
+#pragma unroll
+        for (int k = 0; k < UB; k++) { nx[k] = wd[nb + k * CP]; if (PLLDEC) nq[k] = wiq[nb + k * CP]; }
+#pragma unroll
+        for (int k = 0; k < UB; k++) x[k] = step(x[k], xq[k]);
+#pragma unroll
+        for (int k = 0; k < UB; k++) wd[k * CP] = x[k];
+        wd += UB * CP;
+        if (PLLDEC) wiq += UB * CP;
+    }
+    for (int r = nfull * UB; r < chunk_len; r++) {
+        wd[0] = step(wd[0], PLLDEC ? wiq[0] : make_float2(0.f, 0.f));
+        wd += CP;
+        if (PLLDEC) wiq += CP;
+    }
+    st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr;
 }
 
-template <bool PLLDEC>
-__global__ __launch_bounds__(64) void seq1_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
-                                                  int64_t rc0, int chunk_len) {
-    const int CP = G.pitch;       // padded row pitch of the sample-major work arrays
+// ---- B3.  The NCO sine (float)sin(2*pi*idx/192000) is rebuilt from two f64 factor tables held in LDS
+// (idx = 256 a + b); the host proved the expression rounds to the reference's f32 table entry for every idx
+// (fmx_api.hip), else T.trig2 is null and the global table is used.
+__global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
+                                                 int64_t rc0, int chunk_len) {
+    const int CP = G.pitch;
     __shared__ double2 sA[TRIG2_A];
     __shared__ double2 sB[TRIG2_B];
-    Seq1Const c;
-    c.t2 = T.trig2 != nullptr;
-    if (c.t2) {
+    const bool t2 = T.trig2 != nullptr;
+    if (t2) {
         for (int i = threadIdx.x; i < TRIG2_A; i += 64) sA[i] = T.trig2[i];
         for (int i = threadIdx.x; i < TRIG2_B; i += 64) sB[i] = T.trig2[TRIG2_A + i];
     }
     __syncthreads();
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= C) return;
-    const int64_t nj = chunk_len;                   // this launch handles rows [rc0, rc0 + chunk_len) of the call
     ChanState *st = B.state + ch;
-    const ChanParams &P = B.params[ch];
-    c.use_pll = PLLDEC && (P.decoder == 2);
-    c.stereo_possible = P.fm_mode != 2; c.auto_mono = P.auto_mono != 0; c.pss_active = P.pss_active != 0;
-    c.fmDcAlpha = 0.0001f; c.c1 = 1 - c.fmDcAlpha; c.K = T.K_FM; c.rK = T.K_FM_rcp;
-    c.gain = T.pil_gain; c.omega = T.pil_omega; c.romega = T.pil_omega_rcp;
-    c.lockA = 1.0f / 3000.0f; c.keep = 1.0 - (double)c.lockA; c.SC = T.sincos_C;
-    Seq1State s;
-    s.afc = st->fm_afc; s.nco_phase = st->nco_phase; s.incr = st->phase_incr;
-    s.phase = st->pil_phase; s.lock = st->pil_lock; s.old = st->pil_old;
-    s.stable = st->pil_stable; s.locked = st->pil_locked; s.tagn = (rc0 == 0) ? 0 : st->pss_call_total;
+    const float gain = T.pil_gain, omega = T.pil_omega;
+    const double SC = T.sincos_C;
+    float phase = st->pil_phase;
     const int64_t ro = rc0 * (int64_t)CP + ch;
-    float *wd = B.w_dem + ro; float *wc = B.w_cur + ro; uint8_t *wl = B.w_lock + ro; int *wt = B.w_tag + ro;
-    const float2 *wiq = PLLDEC ? B.w_iq + ro : nullptr;
-
-    // main loop: full batches, no guards; the next batch's inputs are loaded while this one computes
-    const int64_t nfull = nj / SEQ_UB;
-    float nx[SEQ_UB]; float2 nq[SEQ_UB];
+    const float *wd = B.w_dem + ro; float *wc = B.w_cur + ro; float *wo = B.w_osc + ro;
+    auto step = [&](float demod, float &o_cur, float &o_osc) {
+        // SinCos::getSin sincos.cpp:81-85.  phase is in [0, 2pi] here (PI_Constrain output) except possibly the
+        // very first sample of a stream, hence the sign handling stays.
+        const float pilot = 5 * demod;
+        const bool neg = phase < 0.f;
+        const float p = neg ? -phase : phase;
+        int idx = (int)((double)p * SC);
+        idx = (idx >= SINCOS_N) ? idx - SINCOS_N : idx;          // p <= 2pi + 0.01 -> idx <= N + 306
+        float osc;
+        if (t2) {
+            const double2 ea = sA[idx >> 8], eb = sB[idx & 255];
+            osc = (float)(ea.y * eb.x + ea.x * eb.y);
+        } else osc = T.sincos[idx].y;
+        osc = neg ? -osc : osc;
+        const float perr = pilot * osc;
+        phase += perr * gain;
+        o_cur = phase;                                           // PI_Constrain of it is applied in pss_mix_kernel
+        phase = pi_constrain_near(phase + omega);
+        o_osc = osc;
+    };
+    const int nfull = chunk_len / SEQ_UB;
+    float nx[SEQ_UB];
     if (nfull > 0) {
 #pragma unroll
-        for (int k = 0; k < SEQ_UB; k++) { nx[k] = wd[k * CP]; if (PLLDEC) nq[k] = wiq[k * CP]; }
+        for (int k = 0; k < SEQ_UB; k++) nx[k] = wd[k * CP];
     }
-    for (int64_t b = 0; b < nfull; b++) {
-        float x[SEQ_UB]; float2 xq[SEQ_UB];
+    for (int b = 0; b < nfull; b++) {
+        float x[SEQ_UB], oc[SEQ_UB], oo[SEQ_UB];
 #pragma unroll
-        for (int k = 0; k < SEQ_UB; k++) { x[k] = nx[k]; xq[k] = PLLDEC ? nq[k] : make_float2(0.f, 0.f); }
-        const int nb = (b + 1 < nfull) ? SEQ_UB * CP : 0;       // the last prefetch re-reads this batch
+        for (int k = 0; k < SEQ_UB; k++) x[k] = nx[k];
+        const int nb = (b + 1 < nfull) ? SEQ_UB * CP : 0;
 #pragma unroll
-        for (int k = 0; k < SEQ_UB; k++) { nx[k] = wd[nb + k * CP]; if (PLLDEC) nq[k] = wiq[nb + k * CP]; }
-        float o_dem[SEQ_UB], o_cur[SEQ_UB]; int o_lk[SEQ_UB], o_tag[SEQ_UB];
+        for (int k = 0; k < SEQ_UB; k++) nx[k] = wd[nb + k * CP];
 #pragma unroll
-        for (int k = 0; k < SEQ_UB; k++)
-            seq1_step<PLLDEC>(s, c, T, sA, sB, x[k], xq[k], o_dem[k], o_cur[k], o_lk[k], o_tag[k]);
+        for (int k = 0; k < SEQ_UB; k++) step(x[k], oc[k], oo[k]);
 #pragma unroll
-        for (int k = 0; k < SEQ_UB; k++) {
-            wd[k * CP] = o_dem[k]; wc[k * CP] = o_cur[k]; wl[k * CP] = (uint8_t)o_lk[k]; wt[k * CP] = o_tag[k];
-        }
-        wd += SEQ_UB * CP; wc += SEQ_UB * CP; wl += SEQ_UB * CP; wt += SEQ_UB * CP;
-        if (PLLDEC) wiq += SEQ_UB * CP;
+        for (int k = 0; k < SEQ_UB; k++) { wc[k * CP] = oc[k]; wo[k * CP] = oo[k]; }
+        wd += SEQ_UB * CP; wc += SEQ_UB * CP; wo += SEQ_UB * CP;
     }
-    for (int64_t r = nfull * SEQ_UB; r < nj; r++) {                 // tail (< SEQ_UB samples)
-        float od, oc; int ol, ot;
-        seq1_step<PLLDEC>(s, c, T, sA, sB, wd[0], PLLDEC ? wiq[0] : make_float2(0.f, 0.f), od, oc, ol, ot);
-        wd[0] = od; wc[0] = oc; wl[0] = (uint8_t)ol; wt[0] = ot;
-        wd += CP; wc += CP; wl += CP; wt += CP;
-        if (PLLDEC) wiq += CP;
+    for (int r = nfull * SEQ_UB; r < chunk_len; r++) {
+        float oc, oo;
+        step(wd[0], oc, oo);
+        wc[0] = oc; wo[0] = oo;
+        wd += CP; wc += CP; wo += CP;
     }
-    st->fm_afc = s.afc; st->nco_phase = s.nco_phase; st->phase_incr = s.incr;
-    st->pil_phase = s.phase; st->pil_lock = s.lock; st->pil_old = s.old; st->pil_stable = s.stable; st->pil_locked = s.locked;
-    st->pss_call_total = s.tagn;
+    st->pil_phase = phase;
+}
+
+// ---- B4
+__global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
+                                                  int64_t rc0, int chunk_len) {
+    const int CP = G.pitch;
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C) return;
+    ChanState *st = B.state + ch;
+    const ChanParams &P = B.params[ch];
+    const bool stereo_possible = P.fm_mode != 2, auto_mono = P.auto_mono != 0, pss_active = P.pss_active != 0;
+    const float lockA = 1.0f / 3000.0f;
+    const double keep = 1.0 - (double)lockA;
+    const float omega = T.pil_omega, romega = T.pil_omega_rcp;
+    float lock = st->pil_lock, old = st->pil_old;
+    int stable = st->pil_stable, locked = st->pil_locked;
+    int tagn = (rc0 == 0) ? 0 : st->pss_call_total;
+    const int64_t ro = rc0 * (int64_t)CP + ch;
+    const float *wd = B.w_dem + ro, *wo = B.w_osc + ro;
+    int *wt = B.w_tag + ro;                        // packed: ((tag + 2) << 1) | locked
+    auto step = [&](float demod, float osc, int &o_lk, int &o_tag) {
+        const float pilot = 5 * demod;
+        const float quadRef = fdiv_const(osc - old, omega, romega);
+        old = osc;
+        lock = (float)((double)(lockA * (-quadRef * pilot)) + (double)lock * keep);
+        const bool tmp = lock > 0.07f;
+        // if (tmp) { if (locked || ++stable > N/2) locked = 1; } else { locked = 0; stable = 0; }
+        const int stable_inc = stable + ((tmp && !locked) ? 1 : 0);
+        locked = tmp ? ((locked || stable_inc > (SINCOS_N >> 1)) ? 1 : 0) : 0;
+        stable = tmp ? stable_inc : 0;
+        o_lk = locked;
+        const bool branch = stereo_possible && (locked || !auto_mono);
+        o_tag = branch ? (pss_active ? tagn : -1) : -2;
+        tagn += (branch && pss_active) ? 1 : 0;
+    };
+    constexpr int UB = 32;
+    const int nfull = chunk_len / UB;
+    float nd[UB], no[UB];
+    if (nfull > 0) {
+#pragma unroll
+        for (int k = 0; k < UB; k++) { nd[k] = wd[k * CP]; no[k] = wo[k * CP]; }
+    }
+    for (int b = 0; b < nfull; b++) {
+        float d[UB], o[UB]; int lk[UB], tg[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) { d[k] = nd[k]; o[k] = no[k]; }
+        const int nb = (b + 1 < nfull) ? UB * CP : 0;
+#pragma unroll
+        for (int k = 0; k < UB; k++) { nd[k] = wd[nb + k * CP]; no[k] = wo[nb + k * CP]; }
+#pragma unroll
+        for (int k = 0; k < UB; k++) step(d[k], o[k], lk[k], tg[k]);
+#pragma unroll
+        for (int k = 0; k < UB; k++) wt[k * CP] = ((tg[k] + 2) << 1) | lk[k];
+        wd += UB * CP; wo += UB * CP; wt += UB * CP;
+    }
+    for (int r = nfull * UB; r < chunk_len; r++) {
+        int lk, tg;
+        step(wd[0], wo[0], lk, tg);
+        wt[0] = ((tg + 2) << 1) | lk;
+        wd += CP; wo += CP; wt += CP;
+    }
+    st->pil_lock = lock; st->pil_old = old; st->pil_stable = stable; st->pil_locked = locked;
+    st->pss_call_total = tagn;
 }
 
 // =================================================================================================
@@ -342,7 +406,7 @@ __global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffe
     int tmin = 0x7fffffff;
     for (int m = 0; m < 4; m++) {
         const int q = q0 + lane + 64 * m;
-        const int tg = (q < chunk_len) ? B.w_tag[(rc0 + q) * CP + ch] : -2;
+        const int tg = (q < chunk_len) ? (B.w_tag[(rc0 + q) * CP + ch] >> 1) - 2 : -2;
         sTag[lane + 64 * m] = tg;
         if (tg >= 0) tmin = tg < tmin ? tg : tmin;
     }
@@ -379,29 +443,28 @@ __global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffe
 // B6  PSS integrator + state machines   [lane per channel]
 //     fm-processor.cpp:699-718, stereo-separation.cpp:84-109
 // =================================================================================================
-constexpr int ACC_UB = 16;
-struct AccState { float acc, mean, pdp; int lock_cnt, unlock_cnt, minimized; };
-__device__ __forceinline__ float pss_acc_step(AccState &s, float alpha, float la, int locked, int tag, float err) {
+constexpr int ACC_UB = 32;
+struct AccState { float acc, mean, pdp; int lock_cnt, unlock_cnt; bool minimized; };
+__device__ __forceinline__ float pss_acc_step(AccState &s, float alpha, float la, float keep, bool locked, int tag, float err) {
     // branch-free: every lane (channel) may be in a different state
     const bool rst = !locked;                      // unlocked: pilotDelayPSS = 0; pPSS.reset() (fm-processor.cpp:699-702)
     s.pdp = rst ? 0.f : s.pdp; s.acc = rst ? 0.f : s.acc; s.mean = rst ? 0.f : s.mean;
-    s.minimized = rst ? 0 : s.minimized; s.lock_cnt = rst ? 0 : s.lock_cnt; s.unlock_cnt = rst ? 0 : s.unlock_cnt;
+    s.minimized = s.minimized && !rst; s.lock_cnt = rst ? 0 : s.lock_cnt; s.unlock_cnt = rst ? 0 : s.unlock_cnt;
     const float used = s.pdp;                      // the value phaseforLRDiff is built from (:707-709)
     const bool call = tag >= 0;                    // PerfectStereoSeparation::process_sample :60-109
     const float error = s.minimized ? err : err * 10.0f;
-    float nacc = s.acc + alpha * error;
-    const float nmean = la * error + s.mean * (1.0f - la);
+    // clamp to +-M_PI_4: `acc < -M_PI_4` (f64 compare) <=> acc <= -fl32(pi/4), and the assigned value is fl32(pi/4)
+    const float c4 = 0.785398185253143310546875f;
+    const float nacc = fminf(fmaxf(s.acc + alpha * error, -c4), c4);
+    const float nmean = la * error + s.mean * keep;
     const bool small = fabsf(nmean) < 0.001f;
     // small: if (minimized || ++lock_cnt > 3N) minimized = 1; unlock_cnt = 0;
     // else : if (!minimized || ++unlock_cnt > 3N) minimized = 0; lock_cnt = 0;
     const int lc1 = s.lock_cnt + ((small && !s.minimized) ? 1 : 0);
     const int uc1 = s.unlock_cnt + ((!small && s.minimized) ? 1 : 0);
-    const int nmin = small ? ((s.minimized || lc1 > 3 * SINCOS_N) ? 1 : 0)
-                           : ((!s.minimized || uc1 > 3 * SINCOS_N) ? 0 : 1);
-    const int nlc = small ? lc1 : 0, nuc = small ? 0 : uc1;
-    nacc = ((double)nacc < -FMX_PI_4) ? (float)-FMX_PI_4 : (((double)nacc > FMX_PI_4) ? (float)FMX_PI_4 : nacc);
+    const bool nmin = small ? (s.minimized || lc1 > 3 * SINCOS_N) : (s.minimized && !(uc1 > 3 * SINCOS_N));
     s.acc = call ? nacc : s.acc; s.mean = call ? nmean : s.mean; s.minimized = call ? nmin : s.minimized;
-    s.lock_cnt = call ? nlc : s.lock_cnt; s.unlock_cnt = call ? nuc : s.unlock_cnt;
+    s.lock_cnt = call ? (small ? lc1 : 0) : s.lock_cnt; s.unlock_cnt = call ? (small ? 0 : uc1) : s.unlock_cnt;
     s.pdp = call ? nacc : ((tag == -1) ? 0.f : s.pdp);
     return used;
 }
@@ -414,43 +477,64 @@ __global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffe
     const ChanParams &P = B.params[ch];
     AccState s;
     s.acc = st->pss_acc; s.mean = st->pss_mean; s.pdp = st->pilot_delay_pss;
-    s.lock_cnt = st->pss_lock_cnt; s.unlock_cnt = st->pss_unlock_cnt; s.minimized = st->pss_minimized;
+    s.lock_cnt = st->pss_lock_cnt; s.unlock_cnt = st->pss_unlock_cnt; s.minimized = st->pss_minimized != 0;
     if ((P.actions & (ACT_TRIGGER_FREQ | ACT_RESTART_PSS)) && rc0 == 0) {
         // triggerFrequencyChange / restartPssAnalyzer fm-processor.cpp:849-860
-        s.pdp = 0.f; s.acc = 0.f; s.minimized = 0; s.mean = 0.f; s.lock_cnt = 0; s.unlock_cnt = 0;
+        s.pdp = 0.f; s.acc = 0.f; s.minimized = false; s.mean = 0.f; s.lock_cnt = 0; s.unlock_cnt = 0;
         if (P.actions & ACT_TRIGGER_FREQ) st->fade_start_frame = G.M0;
     }
-    const uint8_t *lk = B.w_lock + ch + rc0 * (int64_t)CP;
-    const int *tg = B.w_tag + ch + rc0 * (int64_t)CP;
+    const int *tg = B.w_tag + ch + rc0 * (int64_t)CP;         // packed ((tag + 2) << 1) | locked
     const float *err = B.w_err + ch;
     float *pdpw = B.w_pdp + ch + rc0 * (int64_t)CP;
-    const float alpha = T.pss_alpha, la = T.pss_lock_alpha;
+    const float alpha = T.pss_alpha, la = T.pss_lock_alpha, keep = 1.0f - la;
     const bool pss_on = (P.fm_mode != 2) && (P.pss_active != 0);
     const int nfull = chunk_len / ACC_UB;
-    uint8_t nl[ACC_UB]; int nt[ACC_UB]; float ne[ACC_UB];
+    int nt[ACC_UB]; float ne[ACC_UB];
     if (nfull > 0) {
 #pragma unroll
-        for (int k = 0; k < ACC_UB; k++) { nl[k] = lk[k * CP]; nt[k] = tg[k * CP]; ne[k] = err[k * CP]; }
+        for (int k = 0; k < ACC_UB; k++) { nt[k] = tg[k * CP]; ne[k] = err[k * CP]; }
     }
     for (int b = 0; b < nfull; b++) {
-        uint8_t l[ACC_UB]; int t[ACC_UB]; float e[ACC_UB]; float o[ACC_UB];
+        int l[ACC_UB]; int t[ACC_UB]; float e[ACC_UB]; float o[ACC_UB];
 #pragma unroll
-        for (int k = 0; k < ACC_UB; k++) { l[k] = nl[k]; t[k] = nt[k]; e[k] = pss_on ? ne[k] : 0.f; }
+        for (int k = 0; k < ACC_UB; k++) { l[k] = nt[k] & 1; t[k] = (nt[k] >> 1) - 2; e[k] = pss_on ? ne[k] : 0.f; }
         const int nb = (b + 1 < nfull) ? ACC_UB * CP : 0;
 #pragma unroll
-        for (int k = 0; k < ACC_UB; k++) { nl[k] = lk[nb + k * CP]; nt[k] = tg[nb + k * CP]; ne[k] = err[nb + k * CP]; }
+        for (int k = 0; k < ACC_UB; k++) { nt[k] = tg[nb + k * CP]; ne[k] = err[nb + k * CP]; }
+        // steady state (every channel of the wave locked and calling process_sample for the whole batch): the
+        // reset / no-call selects drop out.  Wave-uniform test, identical arithmetic.
+        bool steady = true;
 #pragma unroll
-        for (int k = 0; k < ACC_UB; k++) o[k] = pss_acc_step(s, alpha, la, l[k], t[k], e[k]);
+        for (int k = 0; k < ACC_UB; k++) steady = steady && (l[k] != 0) && (t[k] >= 0);
+        if (__all(steady)) {
+            const float c4 = 0.785398185253143310546875f;
+#pragma unroll
+            for (int k = 0; k < ACC_UB; k++) {
+                o[k] = s.pdp;
+                const float error = s.minimized ? e[k] : e[k] * 10.0f;
+                s.acc = fminf(fmaxf(s.acc + alpha * error, -c4), c4);
+                s.mean = la * error + s.mean * keep;
+                const bool small = fabsf(s.mean) < 0.001f;
+                const int lc1 = s.lock_cnt + ((small && !s.minimized) ? 1 : 0);
+                const int uc1 = s.unlock_cnt + ((!small && s.minimized) ? 1 : 0);
+                s.minimized = small ? (s.minimized || lc1 > 3 * SINCOS_N) : (s.minimized && !(uc1 > 3 * SINCOS_N));
+                s.lock_cnt = small ? lc1 : 0; s.unlock_cnt = small ? 0 : uc1;
+                s.pdp = s.acc;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ACC_UB; k++) o[k] = pss_acc_step(s, alpha, la, keep, l[k] != 0, t[k], e[k]);
+        }
 #pragma unroll
         for (int k = 0; k < ACC_UB; k++) pdpw[k * CP] = o[k];
-        lk += ACC_UB * CP; tg += ACC_UB * CP; err += ACC_UB * CP; pdpw += ACC_UB * CP;
+        tg += ACC_UB * CP; err += ACC_UB * CP; pdpw += ACC_UB * CP;
     }
     for (int q = nfull * ACC_UB; q < chunk_len; q++) {
-        pdpw[0] = pss_acc_step(s, alpha, la, lk[0], tg[0], pss_on ? err[0] : 0.f);
-        lk += CP; tg += CP; err += CP; pdpw += CP;
+        pdpw[0] = pss_acc_step(s, alpha, la, keep, (tg[0] & 1) != 0, (tg[0] >> 1) - 2, pss_on ? err[0] : 0.f);
+        tg += CP; err += CP; pdpw += CP;
     }
     st->pss_acc = s.acc; st->pss_mean = s.mean; st->pilot_delay_pss = s.pdp;
-    st->pss_lock_cnt = s.lock_cnt; st->pss_unlock_cnt = s.unlock_cnt; st->pss_minimized = s.minimized;
+    st->pss_lock_cnt = s.lock_cnt; st->pss_unlock_cnt = s.unlock_cnt; st->pss_minimized = s.minimized ? 1 : 0;
 }
 
 // =================================================================================================
@@ -476,7 +560,7 @@ __global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuff
             const int64_t r = rc0 + q;
             const ChanParams &P = B.params[ch];
             const float demod = B.w_dem[r * CP + ch];
-            const int tag = B.w_tag[r * CP + ch];
+            const int tag = (B.w_tag[r * CP + ch] >> 1) - 2;
             float2 audio = make_float2(demod, 0.f);
             if (tag != -2) {
                 // phaseforLRDiff fm-processor.cpp:707-714
@@ -535,7 +619,7 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
     const float a = P.deemph_alpha;
     float yl = st->de_l, yr = st->de_r;
     float2 *x = B.w_x + rc0 * (int64_t)CP + ch;
-    constexpr int UB = 16;
+    constexpr int UB = 32;
     const int64_t nfull = nj / UB;
     float2 nx[UB];
     if (nfull > 0) {
@@ -620,23 +704,34 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
     const dim3 tiles((unsigned)((nj + 63) / 64), (unsigned)((C + 63) / 64));
     const dim3 lanes((unsigned)((C + 63) / 64));
     hipLaunchKernelGGL(disc_kernel, tiles, dim3(256), 0, s, T, B, G, C);
-    // The recurrences are latency-bound and use a handful of wavefronts, so the three chunked stages run as a
-    // software pipeline on three streams: seq1(chunk c+1) || PSS loop(chunk c) || de-emphasis(chunk c-1).
+    // The recurrences are latency-bound and use a handful of wavefronts each, so the chunked stages run as a
+    // software pipeline on five streams:  AFC(c+3) || PLL(c+2) || lock(c+1) || PSS loop(c) || de-emphasis(c-1).
     // Chunks are rows of the same work arrays, so nothing is double-buffered.
-    hipStream_t s2 = DS.pss ? DS.pss : s, s3 = DS.post ? DS.post : s;
+    hipStream_t st[5] = { s, DS.side[0] ? DS.side[0] : s, DS.side[1] ? DS.side[1] : s, DS.side[2] ? DS.side[2] : s,
+                          DS.side[3] ? DS.side[3] : s };
+    hipStream_t s3 = st[4];
+    auto hand_over = [&](int from, int to, int c) {
+        if (st[from] == st[to]) return;
+        hipEvent_t e = DS.ev[(4 * c + from) % DS.nev];
+        (void)hipEventRecord(e, st[from]);
+        (void)hipStreamWaitEvent(st[to], e, 0);
+    };
     int c = 0;
     for (int64_t rc0 = 0; rc0 < nj; rc0 += PSS_CHUNK, c++) {
         const int len = (int)((nj - rc0) < PSS_CHUNK ? (nj - rc0) : PSS_CHUNK);
         const int last = (rc0 + len >= nj) ? 1 : 0;
-        if (B.w_iq) hipLaunchKernelGGL(seq1_kernel<true>, lanes, dim3(64), 0, s, T, B, G, C, rc0, len);
-        else hipLaunchKernelGGL(seq1_kernel<false>, lanes, dim3(64), 0, s, T, B, G, C, rc0, len);
-        hipEvent_t e1 = DS.ev ? DS.ev[(2 * c) % DS.nev] : nullptr, e2 = DS.ev ? DS.ev[(2 * c + 1) % DS.nev] : nullptr;
-        if (s2 != s) { (void)hipEventRecord(e1, s); (void)hipStreamWaitEvent(s2, e1, 0); }
-        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, s2, T, B, G, C, rc0, len);
-        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, s2, T, B, G, C, rc0, len);
-        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, s2, T, B, G, C, rc0, len);
-        if (s3 != s2) { (void)hipEventRecord(e2, s2); (void)hipStreamWaitEvent(s3, e2, 0); }
-        hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, s3, T, B, G, C, rc0, len, last);
+        if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
+        else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
+        hand_over(0, 1, c);
+        hipLaunchKernelGGL(pll_kernel, lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
+        hand_over(1, 2, c);
+        hipLaunchKernelGGL(lock_kernel, lanes, dim3(64), 0, st[2], T, B, G, C, rc0, len);
+        hand_over(2, 3, c);
+        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, st[3], T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, st[3], T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len);
+        hand_over(3, 4, c);
+        hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last);
     }
     hipLaunchKernelGGL(dring_kernel, tiles, dim3(256), 0, s3, B, G, C);
     if (s3 != s) { (void)hipEventRecord(DS.join, s3); (void)hipStreamWaitEvent(s, DS.join, 0); }

@@ -136,7 +136,7 @@ struct DeviceBuffers {
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const float2 *iq,
                   int channels, hipStream_t s);
 // side streams + events for the chunk pipeline of stage B (null streams = run everything on the caller's stream)
-struct DemodStreams { hipStream_t pss, post; hipEvent_t *ev; int nev; hipEvent_t join; };
+struct DemodStreams { hipStream_t side[4]; hipEvent_t *ev; int nev; hipEvent_t join; };
 void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s,
                   const DemodStreams &DS);
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,
