@@ -68,7 +68,8 @@ typedef enum {
     FMX_P_BANDWIDTH = 9,       /* setBandwidth, Hz (the GUI's "165kHz" -> 165000); 0 = "Off" (:232-239) */
     FMX_P_ATTENUATION_L = 10,  /* setAttenuation (Lgain)                             (:351-359)  */
     FMX_P_ATTENUATION_R = 11,  /* setAttenuation (Rgain)                                         */
-    FMX_P_RDS_MODE = 12,       /* setfmRdsSelector: 0 off, 1..3                      (:840-847)  */
+    FMX_P_RDS_MODE = 12,       /* setfmRdsSelector: 0 off, 2 = RDS_2 (rds-decoder-2.cpp); 1 and 3 are
+                                  FMX_E_UNSUPPORTED                                  (:840-847)  */
     FMX_P_LOCAL_OSCILLATOR = 13,/* set_localOscillator, Hz                           (:866-868)  */
     FMX_P_AUTO_MONO = 14,      /* setAutoMonoMode                                    (:914-916)  */
     FMX_P_PSS = 15,            /* setPSSMode                                         (:918-920)  */
@@ -102,6 +103,7 @@ typedef enum {
     FMX_TAP_LR_RAW = 2,        /* complex @fmRate (sum,diff) (AF_SUM/AF_DIFF scopes, :608-613)   */
     FMX_TAP_PRE_RESAMPLER = 3, /* complex @fmRate after de-emphasis (:594-595), before gain; this
                                   build applies the audio low-pass AFTER this point */
+    FMX_TAP_RDS_IQ = 4,        /* complex @24 kS/s after rdsDecimator (RDS_INPUT scope, :566-569)        */
 } fmx_tap_id;
 
 /* per-kernel timing collected with HIP events on the processing stream */

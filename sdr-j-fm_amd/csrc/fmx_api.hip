@@ -74,6 +74,11 @@ struct fmx_handle_s {
     // profiling
     bool prof_on = false; std::vector<ProfRec> prof; fmx_profile prof_acc{};
     int64_t last_J0 = 0, last_J1 = 0;
+    // RDS path (allocated when a channel first switches RDS on)
+    bool rds_alloc = false; RdsBuffers R{}; int64_t rds_start = -1;   // fm sample index at which RDS was switched on
+    std::vector<int32_t> rds_read;          // per channel: bits already handed out by fmx_rds_bits
+    int64_t last_m0 = 0, last_m1 = 0;       // 24 kS/s outputs of the last call
+    std::vector<void *> rds_ptrs;
 };
 
 namespace {
@@ -208,12 +213,87 @@ int ensure_lo_table(fmx_handle h) {
     return FMX_OK;
 }
 
+int ensure_rds(fmx_handle h) {
+    if (h->rds_alloc) return FMX_OK;
+    const size_t C = (size_t)h->channels;
+    const int32_t fmRate = h->cfg.fmRate;
+    auto dalloc = [&](void **p, size_t bytes, bool zero) -> int {
+        HIPCHK(hipMalloc(p, bytes));
+        if (zero) HIPCHK(hipMemset(*p, 0, bytes));
+        h->rds_ptrs.push_back(*p);
+        return FMX_OK;
+    };
+    RdsBuffers &R = h->R;
+    int rc;
+    if ((rc = dalloc((void **)&R.in_blk, sizeof(float) * C * RDS_BLK, true))) return rc;
+    if ((rc = dalloc((void **)&R.bpreal, sizeof(float) * C * 2 * RDS_BLK, true))) return rc;
+    if ((rc = dalloc((void **)&R.bp_over, sizeof(float2) * C * 768, true))) return rc;
+    if ((rc = dalloc((void **)&R.hil, sizeof(float2) * C * 2 * RDS_BLK, true))) return rc;
+    if ((rc = dalloc((void **)&R.hil_over, sizeof(float2) * C * 768, true))) return rc;
+    if ((rc = dalloc((void **)&R.phase_ring, sizeof(float) * C * RDS_PHASE_RING, true))) return rc;
+    if ((rc = dalloc((void **)&R.U, sizeof(float2) * C * 32768, false))) return rc;
+    if ((rc = dalloc((void **)&R.V, sizeof(float2) * C * 32768, false))) return rc;
+    if ((rc = dalloc((void **)&R.rds24, sizeof(float2) * C * RDS24_RING, true))) return rc;
+    R.pitch = h->pitch;
+    if ((rc = dalloc((void **)&R.mf, sizeof(float2) * (size_t)(h->work_nj / 8 + 8) * h->pitch, false))) return rc;
+    if ((rc = dalloc((void **)&R.bits, C * RDS_BITS_CAP, true))) return rc;
+    {   // rdsDecoder_2 / AGC / Costas constructor state (rds-decoder-2.cpp:44-78, rds-decoder.cpp:41-43)
+        RdsState s0; std::memset(&s0, 0, sizeof(s0));
+        s0.gain = 9.0f; s0.mu = 0.f; s0.skip = 3; s0.sample_count = 0;
+        s0.c_limit = (float)(2 * design::kPi * (double)10.0f / (double)(float)24000);
+        std::vector<RdsState> init(C, s0);
+        if ((rc = dalloc((void **)&R.state, sizeof(RdsState) * C, false))) return rc;
+        HIPCHK(hipMemcpy(R.state, init.data(), sizeof(RdsState) * C, hipMemcpyHostToDevice));
+    }
+    {   // spectra: the DFT of the zero-padded band-pass kernel (fft-filters.cpp:71-82, setBand(57000 -+ 2400)), and the
+        // analytic-signal mask of fftFilterHilbert::setHilbert (:177-190)
+        const int N = 32768, D = 768;
+        std::vector<float> k = design::bandpass(D, 3 * 19000 - 4800 / 2, 3 * 19000 + 4800 / 2, fmRate);
+        std::vector<float2> S((size_t)N), M((size_t)N);
+        std::vector<double> cs((size_t)N), sn((size_t)N);
+        for (int i = 0; i < N; i++) { cs[i] = std::cos(-2 * design::kPi * i / N); sn[i] = std::sin(-2 * design::kPi * i / N); }
+        for (int f = 0; f < N; f++) {
+            double re = 0, im = 0;
+            for (int i = 0; i < D; i++) {
+                const int a = (int)(((int64_t)f * i) & (N - 1));
+                re += (double)k[2 * i] * cs[a] - (double)k[2 * i + 1] * sn[a];
+                im += (double)k[2 * i] * sn[a] + (double)k[2 * i + 1] * cs[a];
+            }
+            S[f] = make_float2((float)re, (float)im);
+            M[f] = make_float2(f == 0 || f == N / 2 ? 1.0f : (f < N / 2 ? 2.0f : 0.0f), 0.f);
+        }
+        float2 *dS, *dM;
+        if ((rc = dalloc((void **)&dS, sizeof(float2) * N, false))) return rc;
+        if ((rc = dalloc((void **)&dM, sizeof(float2) * N, false))) return rc;
+        HIPCHK(hipMemcpy(dS, S.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dM, M.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
+        R.S_bp = dS; R.S_hil = dM;
+        std::vector<float> dk = design::decim_complex(11, 24000 / 2, fmRate);      // rdsDecimator fm-processor.cpp:382
+        std::vector<float> rr = design::rrc(1.0, 24000, 2 * 1187.5f, 1.0, 45);       // rds-decoder-2.cpp:67-71
+        float2 *dd; float *dr;
+        if ((rc = dalloc((void **)&dd, sizeof(float2) * 11, false))) return rc;
+        if ((rc = dalloc((void **)&dr, sizeof(float) * 45, false))) return rc;
+        HIPCHK(hipMemcpy(dd, dk.data(), sizeof(float2) * 11, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dr, rr.data(), sizeof(float) * 45, hipMemcpyHostToDevice));
+        R.dec_taps = dd; R.rrc = dr;
+    }
+    h->rds_read.assign(C, 0);
+    h->rds_alloc = true;
+    return FMX_OK;
+}
+
 int flush_mailbox(fmx_handle h) {
     std::lock_guard<std::mutex> lk(h->mtx);
     if (h->sets_dirty) { int rc = ensure_sets(h); if (rc) return rc; h->params_dirty = true; }
     bool any_lo = false;
     for (auto &p : h->params) any_lo |= (p.lo_freq != 0);
     if (any_lo) { int rc = ensure_lo_table(h); if (rc) return rc; }
+    bool any_rds = false;
+    for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
+    if (any_rds) {
+        int rc = ensure_rds(h); if (rc) return rc;
+        if (h->rds_start < 0) h->rds_start = h->g_total / DECIM;       // the RDS filters start counting here (all channels)
+    }
     bool any_pll = false;
     for (auto &p : h->params) any_pll |= (p.decoder == 2);
     if (any_pll && !h->B.w_iq) {
@@ -262,6 +342,16 @@ int run_call(fmx_handle h, const float2 *d_iq, int64_t stream_stride, int64_t n,
         for (int i = 0; i < 4; i++) DS.side[i] = serial ? nullptr : h->s_side[i];
         DS.ev = h->evs.data(); DS.nev = (int)h->evs.size(); DS.join = h->ev_join;
         launch_demod(h->T, h->B, G, h->channels, s, DS);
+    }
+    if (h->rds_alloc && h->rds_start >= 0) {
+        bool any_rds = false;
+        for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
+        if (any_rds) {
+            if (G.J1 - G.J0 > RDS_BLK) return fail(FMX_E_TOO_LARGE, "with RDS on, a call may cover at most 32000 fm samples (384000 input samples)");
+            const int64_t n0 = G.J0 - h->rds_start;
+            launch_rds(h->B, h->R, G, h->channels, n0, s);
+            h->last_m0 = n0 / 8; h->last_m1 = (n0 + (G.J1 - G.J0)) / 8;
+        }
     }
     if (prof) HIPCHK(hipEventRecord(pr.e[2], s));
     launch_audio(h->T, h->B, G, d_pcm, h->channels, s);
@@ -449,6 +539,7 @@ int fmx_destroy(fmx_handle h) {
                      h->B.lr_ring, h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
                      h->B.w_osc, h->B.w_lock, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->evs) (void)hipEventDestroy(e);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto &ss : h->s_side) if (ss) (void)hipStreamDestroy(ss);
@@ -474,7 +565,10 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_BANDWIDTH: if (iv < 0 || iv > h->cfg.inputRate) return fail(FMX_E_INVALID, "bandwidth out of range"); break;
     case FMX_P_RDS_MODE:
         if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "rds mode must be 0..3");
-        if (iv != 0) return fail(FMX_E_UNSUPPORTED, "the RDS path is not built in this round"); break;
+        if (iv == 1 || iv == 3) return fail(FMX_E_UNSUPPORTED, "only the RDS_2 decoder (rds-decoder-2.cpp) is built");
+        if (iv == 2 && h->rds_start >= 0 && h->rds_start != h->g_total / DECIM && h->params[channel < 0 ? 0 : channel].rds_mode == 0)
+            return fail(FMX_E_UNSUPPORTED, "switch RDS on for all channels in the same call (shared overlap-add block phase)");
+        break;
     case FMX_P_LOCAL_OSCILLATOR:
         if (std::abs(iv) > h->cfg.inputRate) return fail(FMX_E_INVALID, "|lo| must be <= inputRate (oscillator.cpp:49-58)"); break;
     case FMX_P_SQUELCH_MODE: if (iv != 0) return fail(FMX_E_UNSUPPORTED, "squelch is outside the hot path (SURVEY 8f)"); break;
@@ -584,7 +678,7 @@ int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
 int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t n) {
     if (!h || !dst || channel < 0 || channel >= h->channels || n < 0) return fail(FMX_E_INVALID, "bad argument");
     const int64_t J1 = h->g_total / DECIM;
-    if (n > J1 || n > (h->last_J1 - h->last_J0)) return fail(FMX_E_INVALID, "n exceeds the samples produced by the last call");
+    if (tap != 4 && (n > J1 || n > (h->last_J1 - h->last_J0))) return fail(FMX_E_INVALID, "n exceeds the samples produced by the last call");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
     const char *base; int64_t cap, elem, delay = 0;
@@ -594,6 +688,17 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
     case FMX_TAP_DEMOD: base = (const char *)(h->B.demod_ring + (size_t)channel * h->ring); cap = h->ring; elem = sizeof(float); break;
     case FMX_TAP_LR_RAW: base = (const char *)(h->B.lr_ring + (size_t)channel * h->ring); cap = h->ring; elem = sizeof(float2); break;
     case FMX_TAP_PRE_RESAMPLER: base = (const char *)(h->B.dring + (size_t)channel * h->dring); cap = h->dring; elem = sizeof(float2); break;
+    case 4: {   // FMX_TAP_RDS_IQ: complex @24 kS/s after rdsDecimator (:553): the last n outputs of the last call
+        if (!h->rds_alloc) return fail(FMX_E_INVALID, "RDS is off");
+        if (n > h->last_m1 - h->last_m0) return fail(FMX_E_INVALID, "n exceeds the RDS samples produced by the last call");
+        char *o = (char *)dst;
+        for (int64_t m = h->last_m1 - n; m < h->last_m1;) {
+            const int64_t pos = m & (RDS24_RING - 1);
+            const int64_t run = std::min<int64_t>(RDS24_RING - pos, h->last_m1 - m);
+            HIPCHK(hipMemcpy(o, (const char *)(h->R.rds24 + (size_t)channel * RDS24_RING) + pos * sizeof(float2), (size_t)run * sizeof(float2), hipMemcpyDeviceToHost));
+            o += run * sizeof(float2); m += run;
+        }
+        return FMX_OK; }
     default: return fail(FMX_E_INVALID, "unknown tap id");
     }
     // samples j in [J1-n, J1) live at ring index (j - delay) & (cap-1); before the stream start they are 0
@@ -610,10 +715,24 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
 }
 
 int fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity, int32_t *n_bits) {
-    (void)bits; (void)capacity;
-    if (!h || channel < 0 || channel >= h->channels || !n_bits) return fail(FMX_E_INVALID, "bad argument");
+    if (!h || channel < 0 || channel >= h->channels || !n_bits || capacity < 0) return fail(FMX_E_INVALID, "bad argument");
     *n_bits = 0;
-    return fail(FMX_E_UNSUPPORTED, "the RDS path is not built in this round");
+    if (!h->rds_alloc) return FMX_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    RdsState st;
+    HIPCHK(hipMemcpy(&st, h->R.state + channel, sizeof(st), hipMemcpyDeviceToHost));
+    int32_t have = st.nbits - h->rds_read[channel];
+    if (have > RDS_BITS_CAP) { h->rds_read[channel] = st.nbits - RDS_BITS_CAP; have = RDS_BITS_CAP; }   // ring overrun: oldest bits lost
+    const int32_t take = have < capacity ? have : capacity;
+    std::vector<uint8_t> ring((size_t)RDS_BITS_CAP);
+    if (take > 0 && bits) {
+        HIPCHK(hipMemcpy(ring.data(), h->R.bits + (size_t)channel * RDS_BITS_CAP, RDS_BITS_CAP, hipMemcpyDeviceToHost));
+        for (int32_t i = 0; i < take; i++) bits[i] = ring[(size_t)((h->rds_read[channel] + i) & (RDS_BITS_CAP - 1))];
+        h->rds_read[channel] += take;
+    }
+    *n_bits = (take > 0 && bits) ? take : 0;
+    return FMX_OK;
 }
 
 int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32_t capacity, int32_t *n) {

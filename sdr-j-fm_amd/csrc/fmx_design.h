@@ -77,6 +77,60 @@ inline std::vector<float> resampler(int N = 128) {
     return h;
 }
 
+// BandPassFIR::newKernel fir-filters.cpp:197-222: integer halving first, f32 divisions; `v` is DSPFLOAT so the
+// cos/sin are the FLOAT overloads and tmp*cosf(v)/sum is evaluated in f32.  Returns interleaved (re, im).
+inline std::vector<float> bandpass(int N, int32_t low, int32_t high, int32_t fs) {
+    std::vector<float> tmp;
+    const float lo = (float)((high - low) / 2) / (float)fs;
+    const float shift = (float)((high + low) / 2) / (float)fs;
+    const float sum = sinc_blackman(N, lo, tmp);
+    std::vector<float> k((size_t)2 * N);
+    for (int i = 0; i < N; i++) {
+        const float v = (float)((double)(i - N / 2) * (2 * kPi * (double)shift));
+        k[2 * i] = tmp[i] * std::cos(v) / sum;
+        k[2 * i + 1] = tmp[i] * std::sin(v) / sum;
+    }
+    return k;
+}
+// DecimatingFIR complex kernel (tmp/sum, tmp) fir-filters.cpp:345-346, interleaved
+inline std::vector<float> decim_complex(int N, int32_t low, int32_t fs) {
+    std::vector<float> tmp;
+    const float f = (float)low / (float)fs;
+    const float sum = sinc_blackman(N, f, tmp);
+    std::vector<float> k((size_t)2 * N);
+    for (int i = 0; i < N; i++) { k[2 * i] = tmp[i] / sum; k[2 * i + 1] = tmp[i]; }
+    return k;
+}
+// ShapingFilter::root_raised_cosine shaping_filter.cpp:4-54 (all f64, taps stored f32)
+inline std::vector<float> rrc(double gain, double sampling_freq, double symbol_rate, double alpha, int ntaps) {
+    ntaps |= 1;
+    const double spb = sampling_freq / symbol_rate;
+    std::vector<float> taps((size_t)ntaps);
+    double scale = 0;
+    for (int i = 0; i < ntaps; i++) {
+        double x1, x2, x3, num, den;
+        const double xindx = i - ntaps / 2;
+        x1 = kPi * xindx / spb;
+        x2 = 4 * alpha * xindx / spb;
+        x3 = x2 * x2 - 1;
+        if (std::fabs(x3) >= 0.000001) {
+            if (i != ntaps / 2) num = std::cos((1 + alpha) * x1) + std::sin((1 - alpha) * x1) / (4 * alpha * xindx / spb);
+            else num = std::cos((1 + alpha) * x1) + (1 - alpha) * kPi / (4 * alpha);
+            den = x3 * kPi;
+        } else {
+            if (alpha == 1) { taps[i] = -1; scale += taps[i]; continue; }
+            x3 = (1 - alpha) * x1; x2 = (1 + alpha) * x1;
+            num = (std::sin(x2) * (1 + alpha) * kPi - std::cos(x3) * ((1 - alpha) * kPi * spb) / (4 * alpha * xindx)
+                   + std::sin(x3) * spb * spb / (4 * alpha * xindx * xindx));
+            den = -32 * kPi * alpha * alpha * xindx / spb;
+        }
+        taps[i] = (float)(4 * alpha * num / den);
+        scale += taps[i];
+    }
+    for (int i = 0; i < ntaps; i++) taps[i] = (float)((double)taps[i] * gain / scale);
+    return taps;
+}
+
 inline std::vector<double> convolve(const std::vector<double> &a, const std::vector<double> &b) {
     std::vector<double> c(a.size() + b.size() - 1, 0.0);
     for (size_t i = 0; i < a.size(); i++)

@@ -133,6 +133,36 @@ struct DeviceBuffers {
     float2  *w_x;        // matrix output, then de-emphasised + gained stereo (in place)
 };
 
+// ---- RDS path (fmx_rds.hip) -------------------------------------------------------------------
+constexpr int RDS_BLK = 32000;              // overlap-add block of the two 32768-pt filters (fft-filters.cpp:34)
+constexpr int RDS_PHASE_RING = 131072;      // pilot-phase delay line (>= 64000 + one block + one call)
+constexpr int RDS24_RING = 8192;            // 24 kS/s decimator output ring
+constexpr int RDS_BITS_CAP = 8192;          // per-channel bit ring (>= 6 s of bits)
+struct RdsState {                           // rdsDecoder_2 + AGC + Costas state (rds-decoder-2.cpp:44-78)
+    float gain, mu, c_freq, c_phase, c_limit;
+    int32_t sample_count, skip, prev_bit, nbits;
+    float2 sb0, sb1, sb2;
+};
+struct RdsBuffers {
+    float  *in_blk;      // [ch][32000]     demod samples of the block being filled
+    float  *bpreal;      // [ch][2][32000]  real part of the band-pass block results (parity = block index & 1)
+    float2 *bp_over;     // [ch][768]       band-pass Overloop
+    float2 *hil;         // [ch][2][32000]  Hilbert block results
+    float2 *hil_over;    // [ch][768]
+    float  *phase_ring;  // [ch][RDS_PHASE_RING]
+    float2 *U, *V;       // [ch][32768]     FFT scratch
+    float2 *rds24;       // [ch][RDS24_RING]
+    float2 *mf;          // [rows][pitch]   matched-filter output of the call (sample-major)
+    RdsState *state;
+    uint8_t *bits;       // [ch][RDS_BITS_CAP]
+    const float2 *S_bp, *S_hil;   // [32768] filter spectra
+    const float2 *dec_taps;       // [11] rdsDecimator kernel (h/sum, h)
+    const float *rrc;             // [45] matched filter
+    int32_t pitch;
+};
+#define C_RDS_PITCH(Rb) ((Rb).pitch)
+void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, int64_t n0, hipStream_t s);
+
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const float2 *iq,
                   int channels, hipStream_t s);
 // side streams + events for the chunk pipeline of stage B (null streams = run everything on the caller's stream)

@@ -1,0 +1,316 @@
+// fmx_rds.hip -- the RDS path, run after stage B when a channel has RDS on.
+//
+// Replaces per channel:
+//   rdsBandPassFilter.Pass(float)   fm-processor.cpp:741, fft-filters.cpp:97-130  (32768-pt overlap-add, x3, real part)
+//   rdsHilbertFilter.Pass(float)    fm-processor.cpp:742-743, fft-filters.cpp:165-201 (spectrum mask 1,2..2,1,0..0)
+//   57 kHz mix with 3 x the pilot phase of 64000 samples ago   fm-processor.cpp:744-754
+//   rdsDecimator (11 taps, /8)      fm-processor.cpp:382,553, fir-filters.cpp:397-424
+//   rdsDecoder_2::doDecode          rds-decoder-2.cpp:83-157 (RRC matched filter, AGC agc.h, Mueller&Mueller
+//                                   timing, Costas costas.h, differential decode)
+//
+// The two overlap-add filters are NOT equivalent to short FIRs: the Hilbert mask is applied to the
+// zero-padded 32768-point block CIRCULARLY, so each output depends on the whole 32000-sample block.  They are
+// therefore reproduced as what they are -- block FFT filters with the reference's block phase, latency
+// (32000 samples each) and overlap buffers -- on a hand-written four-step FFT (32768 = 128 x 256) in LDS.
+// Everything downstream of them is cheap: the mix + decimator is time-parallel (each 24 kS/s output recomputes its
+// 11 inputs), the matched filter is time-parallel, and only AGC / M&M / Costas run as a lane-per-channel recurrence.
+#include "fmx_internal.h"
+
+namespace fmx {
+
+constexpr int RN = 32768, RN1 = 128, RN2 = 256;      // FFT size and its four-step factorisation
+constexpr int RBLK = RDS_BLK;                         // NumofSamples = fftSize - degree (fft-filters.cpp:34)
+constexpr int RDEG = 768;
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// ---- four-step FFT, step 1: 256 column FFTs of length 128 (+ twiddle), 16 columns per workgroup.
+//      in  : x[n], n = 256*n1 + n2          out : a[k1*256 + n2] = W_N^(n2 k1) * sum_n1 x[256 n1 + n2] W_128^(n1 k1)
+__global__ __launch_bounds__(256) void rds_fft_step1(const float2 *__restrict__ in, float2 *__restrict__ out, int nch,
+                                                     const int *__restrict__ chlist) {
+    __shared__ float2 s[16][RN1 + 1];
+    __shared__ float2 tw[RN1 / 2];
+    const int tid = threadIdx.x;
+    const int ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
+    const int c0 = blockIdx.x * 16;
+    const float2 *x = in + (size_t)ch * RN;
+    float2 *a = out + (size_t)ch * RN;
+    if (tid < RN1 / 2) { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN1, &sn, &cs); tw[tid] = make_float2(cs, sn); }
+    for (int i = tid; i < RN1 * 16; i += 256) { const int n1 = i >> 4, c = i & 15; s[c][n1] = x[n1 * RN2 + c0 + c]; }
+    __syncthreads();
+    // 16 independent FFT-128, 16 threads each
+    {
+        const int f = tid >> 4, lt = tid & 15;
+        float2 *v = s[f];
+        for (int i = lt; i < RN1; i += 16) {
+            const int j = (int)(__brev((unsigned)i) >> 25);
+            if (j > i) { const float2 t = v[i]; v[i] = v[j]; v[j] = t; }
+        }
+        __syncthreads();
+        for (int size = 2, step = RN1 / 2; size <= RN1; size <<= 1, step >>= 1) {
+            const int half = size >> 1;
+            for (int b = lt; b < RN1 / 2; b += 16) {
+                const int grp = b / half, k = b - grp * half;
+                const int j = grp * size + k, l = j + half;
+                const float2 t = cmulf(v[l], tw[k * step]);
+                const float2 u = v[j];
+                v[l] = make_float2(u.x - t.x, u.y - t.y);
+                v[j] = make_float2(u.x + t.x, u.y + t.y);
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < RN1 * 16; i += 256) {
+        const int k1 = i >> 4, c = i & 15, n2 = c0 + c;
+        float sn, cs;
+        sincospif(-2.0f * (float)((k1 * n2) & (RN - 1)) / (float)RN, &sn, &cs);
+        a[k1 * RN2 + n2] = cmulf(s[c][k1], make_float2(cs, sn));
+    }
+}
+// ---- step 2: 128 row FFTs of length 256, 16 rows per workgroup; X[k1 + 128 k2] = sum_n2 a[k1][n2] W_256^(n2 k2)
+__global__ __launch_bounds__(256) void rds_fft_step2(const float2 *__restrict__ in, float2 *__restrict__ out, int nch,
+                                                     const int *__restrict__ chlist) {
+    __shared__ float2 s[16][RN2 + 1];
+    __shared__ float2 tw[RN2 / 2];
+    const int tid = threadIdx.x;
+    const int ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
+    const int k10 = blockIdx.x * 16;
+    const float2 *a = in + (size_t)ch * RN;
+    float2 *X = out + (size_t)ch * RN;
+    if (tid < RN2 / 2) { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN2, &sn, &cs); tw[tid] = make_float2(cs, sn); }
+    for (int i = tid; i < RN2 * 16; i += 256) { const int r = i >> 8, n2 = i & 255; s[r][n2] = a[(k10 + r) * RN2 + n2]; }
+    __syncthreads();
+    {
+        const int f = tid >> 4, lt = tid & 15;
+        float2 *v = s[f];
+        for (int i = lt; i < RN2; i += 16) {
+            const int j = (int)(__brev((unsigned)i) >> 24);
+            if (j > i) { const float2 t = v[i]; v[i] = v[j]; v[j] = t; }
+        }
+        __syncthreads();
+        for (int size = 2, step = RN2 / 2; size <= RN2; size <<= 1, step >>= 1) {
+            const int half = size >> 1;
+            for (int b = lt; b < RN2 / 2; b += 16) {
+                const int grp = b / half, k = b - grp * half;
+                const int j = grp * size + k, l = j + half;
+                const float2 t = cmulf(v[l], tw[k * step]);
+                const float2 u = v[j];
+                v[l] = make_float2(u.x - t.x, u.y - t.y);
+                v[j] = make_float2(u.x + t.x, u.y + t.y);
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < RN2 * 16; i += 256) { const int k2 = i >> 4, r = i & 15; X[(k10 + r) + RN1 * k2] = s[r][k2]; }
+}
+
+// ---- load a 32000-sample real block, zero padded (fft-filters.cpp:104-107)
+__global__ void rds_load_real(const float *__restrict__ src, size_t src_stride, float2 *__restrict__ U, const int *chlist) {
+    const int ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < RN) U[(size_t)ch * RN + i] = make_float2(i < RBLK ? src[(size_t)ch * src_stride + i] : 0.f, 0.f);
+}
+// ---- FFT_C = conj(FFT_A * filterVector [* 3])   (fft-filters.cpp:111-118 / 145-150)
+__global__ void rds_spectrum(float2 *__restrict__ U, const float2 *__restrict__ S, float scale, const int *chlist) {
+    const int ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < RN) {
+        float2 v = cmulf(U[(size_t)ch * RN + i], S[i]);
+        v.x *= scale; v.y *= scale;
+        U[(size_t)ch * RN + i] = make_float2(v.x, -v.y);
+    }
+}
+// ---- FFT_C = conj(FFT_C)/N; overlap add; keep the tail   (fft-filters.cpp:120-125 / 152-157)
+//      writes the 32000 outputs either as real parts (band-pass) or complex (Hilbert)
+__global__ void rds_finish(const float2 *__restrict__ U, float2 *__restrict__ over, float *__restrict__ out_real,
+                           float2 *__restrict__ out_cplx, size_t out_stride, const int *chlist) {
+    const int ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= RN) return;
+    const float f = 1.0f / (float)RN;
+    float2 v = U[(size_t)ch * RN + i];
+    v = make_float2(v.x * f, -v.y * f);
+    if (i < RDEG) { const float2 o = over[(size_t)ch * RDEG + i]; v.x += o.x; v.y += o.y; }
+    if (i < RBLK) {
+        if (out_real) out_real[(size_t)ch * out_stride + i] = v.x;
+        if (out_cplx) out_cplx[(size_t)ch * out_stride + i] = v;
+    }
+}
+__global__ void rds_save_tail(const float2 *__restrict__ U, float2 *__restrict__ over, const int *chlist) {
+    // Overloop[j] = FFT_C[NumofSamples + j] AFTER the scaling (and before the overlap is added: j >= 32000 > 768)
+    const int ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < RDEG) {
+        const float f = 1.0f / (float)RN;
+        const float2 v = U[(size_t)ch * RN + RBLK + j];
+        over[(size_t)ch * RDEG + j] = make_float2(v.x * f, -v.y * f);
+    }
+}
+
+// ---- append this call's demod samples to the block being filled and the pilot phases to the delay ring
+__global__ void rds_collect(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, int64_t row0, int nrows, int64_t n0 /* rds index of row0 */) {
+    const int ch = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nrows || B.params[ch].rds_mode == 0) return;
+    const int64_t r = row0 + q, n = n0 + q;
+    const float demod = B.w_dem[r * G.pitch + ch];
+    const float cur = B.w_cur[r * G.pitch + ch];             // unconstrained pilot phase; PI_Constrain gives currentPilotPhase
+    Rb.in_blk[(size_t)ch * RBLK + (int)(n % RBLK)] = demod;
+    float c = cur;
+    {   // PI_Constrain fm-constants.h:148-158 (arguments are within (-2pi, 4pi))
+        const double v = (double)c;
+        if (!(c >= 0.f && c < 6.2831855f)) c = (v >= 6.283185307179586) ? (float)(v - 6.283185307179586) : (float)(v + 6.283185307179586);
+    }
+    Rb.phase_ring[(size_t)ch * RDS_PHASE_RING + (int)(n & (RDS_PHASE_RING - 1))] = c;
+}
+
+// ---- 57 kHz mix + decimate by 8: one thread per 24 kS/s output m (rds sample index 8m+7)
+__global__ void rds_mix_decim(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, int64_t m0, int nout) {
+    const int ch = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nout || B.params[ch].rds_mode == 0) return;
+    const int64_t m = m0 + q;
+    float2 acc = make_float2(0.f, 0.f);
+    for (int i = 0; i < 11; i++) {                           // newest -> oldest, kernel[0] * newest (fir-filters.cpp:409-418)
+        const int64_t n = 8 * m + 7 - i;
+        float2 x = make_float2(0.f, 0.f);
+        if (n >= 0) {
+            const int64_t blk = n / RBLK; const int inp = (int)(n - blk * RBLK);
+            // during block blk the Hilbert filter returns the result of block blk-1 (zeros for the first block)
+            float2 hv = make_float2(0.f, 0.f);
+            if (blk >= 1) hv = Rb.hil[((size_t)ch * 2 + ((blk - 1) & 1)) * RBLK + inp];
+            float th = 0.f;
+            if (n >= 2 * RBLK) th = Rb.phase_ring[(size_t)ch * RDS_PHASE_RING + (int)((n - 2 * RBLK) & (RDS_PHASE_RING - 1))];
+            th = 3 * th;                                     // thePhase = 3 * rdsPhaseBuffer[idx]  (:744)
+            const float2 osc = make_float2(cosf(th), -sinf(th));
+            x = cmulf(osc, hv);                              // *rdsValueCmpl = oscValue * rdsBaseHilb  (:754)
+        }
+        const float2 k = Rb.dec_taps[i];
+        const float2 p = cmulf(x, k);
+        acc.x += p.x; acc.y += p.y;
+    }
+    Rb.rds24[(size_t)ch * RDS24_RING + (int)(m & (RDS24_RING - 1))] = acc;
+}
+
+// ---- RRC matched filter (rds-decoder-2.cpp:83-98), time-parallel
+__global__ void rds_matched(DeviceBuffers B, RdsBuffers Rb, int64_t m0, int nout) {
+    const int ch = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nout || B.params[ch].rds_mode == 0) return;
+    const int64_t m = m0 + q;
+    float2 acc = make_float2(0.f, 0.f);
+    for (int i = 0; i < 45; i++) {
+        const int64_t j = m - i;
+        if (j < 0) continue;
+        const float2 v = Rb.rds24[(size_t)ch * RDS24_RING + (int)(j & (RDS24_RING - 1))];
+        const float w = Rb.rrc[i];
+        acc.x += v.x * w; acc.y += v.y * w;
+    }
+    Rb.mf[(size_t)q * C_RDS_PITCH(Rb) + ch] = acc;
+}
+
+// ---- AGC -> Mueller&Mueller timing -> Costas -> slicer -> differential decode   [lane per channel]
+//      agc.h:14-18, rds-decoder-2.cpp:101-157, costas.h:21-33
+__global__ __launch_bounds__(64) void rds_slicer(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C || B.params[ch].rds_mode == 0) return;
+    RdsState st = Rb.state[ch];
+    const int pitch = C_RDS_PITCH(Rb);
+    const float sps = 24000.0f / 1187.5f;                   // samplesPerSymbol = rate / (float)RDS_BITCLK_HZ
+    const float mm_alpha = (float)0.01;
+    uint8_t *bits = Rb.bits + (size_t)ch * RDS_BITS_CAP;
+    for (int q = 0; q < nout; q++) {
+        float2 v = Rb.mf[(size_t)q * pitch + ch];
+        // AGC (2e-3, 0.38, start 9)
+        v = make_float2(v.x * st.gain, v.y * st.gain);
+        const float mag = (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);   // std::abs(complex) = hypotf
+        st.gain += 2e-3f * (0.38f - mag);
+        // process_sample rds-decoder-2.cpp:120-157
+        st.sb0 = st.sb1; st.sb1 = st.sb2; st.sb2 = v;
+        if (++st.sample_count >= st.skip) {
+            const float2 r0 = make_float2(st.sb0.x > 0.f ? 1.f : -1.f, st.sb0.y > 0.f ? 1.f : -1.f);
+            const float2 r1 = make_float2(st.sb1.x > 0.f ? 1.f : -1.f, st.sb1.y > 0.f ? 1.f : -1.f);
+            const float2 r2 = make_float2(st.sb2.x > 0.f ? 1.f : -1.f, st.sb2.y > 0.f ? 1.f : -1.f);
+            const float x = (r2.x - r0.x) * st.sb1.x + (r2.y - r0.y) * st.sb1.y;
+            const float y = (st.sb2.x - st.sb0.x) * r1.x + (st.sb2.y - st.sb0.y) * r1.y;
+            const float mm = y - x;
+            st.mu += sps + mm_alpha * mm;
+            st.skip = (int)st.mu;
+            st.mu -= (float)st.skip;
+            st.sample_count = 0;
+            // Costas (alpha 1, beta 0.02, limit 2*pi*10/24000)
+            const float2 e = make_float2(cosf(-st.c_phase), sinf(-st.c_phase));       // std::exp(complex(0, -phase))
+            const float2 r = cmulf(st.sb2, e);
+            const float err = r.x * r.y;
+            st.c_freq += 0.02f * err;
+            if (fabsf(st.c_freq) > st.c_limit) st.c_freq = 0.f;
+            st.c_phase += st.c_freq + 1.0f * err;
+            {   // PI_Constrain, generic form
+                const double pv = (double)st.c_phase;
+                if (!(0.0 <= pv && pv < 6.283185307179586)) {
+                    if (pv >= 6.283185307179586) st.c_phase = (float)fmod(pv, 6.283185307179586);
+                    else if (pv > -6.283185307179586) st.c_phase = (float)(pv + 6.283185307179586);
+                    else st.c_phase = (float)(6.283185307179586 - fmod(-pv, 6.283185307179586));
+                }
+            }
+            const int bit = r.x >= 0.f ? 1 : 0;
+            bits[st.nbits & (RDS_BITS_CAP - 1)] = (uint8_t)(bit ^ st.prev_bit);
+            st.prev_bit = bit;
+            st.nbits++;
+        }
+    }
+    Rb.state[ch] = st;
+}
+
+static void fft_fwd(const RdsBuffers &Rb, int nch, const int *chlist, hipStream_t s) {
+    hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nch), dim3(256), 0, s, Rb.U, Rb.V, nch, chlist);
+    hipLaunchKernelGGL(rds_fft_step2, dim3(RN1 / 16, nch), dim3(256), 0, s, Rb.V, Rb.U, nch, chlist);
+}
+
+// one block boundary: BP filter of the demod block just completed (block index blk), Hilbert of the previous BP result
+void launch_rds_block(const RdsBuffers &Rb, int C, int64_t blk, hipStream_t s) {
+    const dim3 g(RN / 256, C);
+    // Hilbert first: its input is bpreal[(blk-1)&1] (zeros when blk == 0), output hil[blk & 1]
+    hipLaunchKernelGGL(rds_load_real, g, dim3(256), 0, s, Rb.bpreal + (size_t)((blk + 1) & 1) * RBLK, (size_t)2 * RBLK, Rb.U, nullptr);
+    fft_fwd(Rb, C, nullptr, s);
+    hipLaunchKernelGGL(rds_spectrum, g, dim3(256), 0, s, Rb.U, Rb.S_hil, 1.0f, nullptr);
+    fft_fwd(Rb, C, nullptr, s);
+    hipLaunchKernelGGL(rds_finish, g, dim3(256), 0, s, Rb.U, Rb.hil_over, (float *)nullptr, Rb.hil + (size_t)(blk & 1) * RBLK, (size_t)2 * RBLK, nullptr);
+    hipLaunchKernelGGL(rds_save_tail, dim3(3, C), dim3(256), 0, s, Rb.U, Rb.hil_over, nullptr);
+    // band-pass: input in_blk, output bpreal[blk & 1]
+    hipLaunchKernelGGL(rds_load_real, g, dim3(256), 0, s, Rb.in_blk, (size_t)RBLK, Rb.U, nullptr);
+    fft_fwd(Rb, C, nullptr, s);
+    hipLaunchKernelGGL(rds_spectrum, g, dim3(256), 0, s, Rb.U, Rb.S_bp, 3.0f, nullptr);
+    fft_fwd(Rb, C, nullptr, s);
+    hipLaunchKernelGGL(rds_finish, g, dim3(256), 0, s, Rb.U, Rb.bp_over, Rb.bpreal + (size_t)(blk & 1) * RBLK, (float2 *)nullptr, (size_t)2 * RBLK, nullptr);
+    hipLaunchKernelGGL(rds_save_tail, dim3(3, C), dim3(256), 0, s, Rb.U, Rb.bp_over, nullptr);
+}
+
+// the RDS work of one call: rows [0, nj) of the work arrays are rds samples [n0, n0 + nj)
+void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, int64_t n0, hipStream_t s) {
+    const int64_t nj = G.J1 - G.J0;
+    if (nj <= 0) return;
+    int64_t row = 0;
+    while (row < nj) {
+        const int64_t n = n0 + row;
+        const int64_t blk = n / RBLK;
+        const int64_t to_end = (blk + 1) * RBLK - n;              // samples until this block completes
+        const int64_t take = to_end < (nj - row) ? to_end : (nj - row);
+        hipLaunchKernelGGL(rds_collect, dim3((unsigned)((take + 255) / 256), C), dim3(256), 0, s, B, Rb, G, C, row, (int)take, n);
+        // the 24 kS/s outputs whose newest input 8m+7 lies in this segment: mixed BEFORE the block transform below
+        // replaces the Hilbert result of two blocks ago, which the 10-sample look-back may still need
+        const int64_t ma = n / 8, mb = (n + take) / 8;
+        if (mb > ma)
+            hipLaunchKernelGGL(rds_mix_decim, dim3((unsigned)((mb - ma + 255) / 256), C), dim3(256), 0, s, B, Rb, G, C, ma, (int)(mb - ma));
+        row += take;
+        if (take == to_end) launch_rds_block(Rb, C, blk, s);      // block `blk` is complete
+    }
+    const int64_t mfirst = n0 / 8;                 // smallest m with 8m+7 >= n0
+    const int64_t mend = (n0 + nj) / 8;            // one past the largest m with 8m+7 < n0+nj
+    const int nout = (int)(mend - mfirst);
+    if (nout <= 0) return;
+    hipLaunchKernelGGL(rds_matched, dim3((unsigned)((nout + 255) / 256), C), dim3(256), 0, s, B, Rb, mfirst, nout);
+    hipLaunchKernelGGL(rds_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
+}
+
+}  // namespace fmx

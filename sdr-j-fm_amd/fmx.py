@@ -21,7 +21,7 @@ P_VOLUME_DB, P_LF_CUTOFF, P_BANDWIDTH, P_ATTENUATION_L, P_ATTENUATION_R, P_RDS_M
 P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE = 13, 14, 15, 16, 17, 18
 A_TRIGGER_FREQUENCY_CHANGE, A_RESTART_PSS, A_RESET_RDS = 100, 101, 102
 
-TAP_FM_IQ, TAP_DEMOD, TAP_LR_RAW, TAP_PRE_RESAMPLER = 0, 1, 2, 3
+TAP_FM_IQ, TAP_DEMOD, TAP_LR_RAW, TAP_PRE_RESAMPLER, TAP_RDS_IQ = 0, 1, 2, 3, 4
 
 EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
@@ -184,6 +184,12 @@ class Fmx:
         out = np.zeros((n, width), np.float32)
         self._check(self.L.fmx_get_tap(self.h, channel, tap_id, out.ctypes.data_as(C.POINTER(C.c_float)), n))
         return out[:, 0] if width == 1 else out
+
+    def rds_bits(self, channel=0, capacity=8192):
+        buf = (C.c_uint8 * capacity)()
+        n = C.c_int32()
+        self._check(self.L.fmx_rds_bits(self.h, channel, buf, capacity, C.byref(n)))
+        return np.frombuffer(buf, np.uint8, n.value).copy()
 
     def taps(self, which, channel=0):
         buf = np.zeros(1024, np.float32)

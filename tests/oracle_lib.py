@@ -256,15 +256,22 @@ def siggen_config(**kw):
     return c
 
 
-def synth_iq(n, **kw):
-    """n complex samples of synthetic FM IQ as float32 [n,2] (oracle's deterministic generator)."""
+def synth_iq(n, return_rds_bits=False, **kw):
+    """n complex samples of synthetic FM IQ as float32 [n,2] (oracle's deterministic generator); with
+    return_rds_bits also the (pre differential-encoding) RDS data bits the generator sent."""
     L = oracle()
     cfg = siggen_config(**kw)
     g = L.fmo_siggen_new(C.byref(cfg))
     out = np.empty((n, 2), np.float32)
     L.fmo_siggen_run(g, fptr(out), n)
+    bits = None
+    if return_rds_bits:
+        nb = L.fmo_siggen_rds_bits(g, None, 0)
+        bits = np.zeros(max(nb, 1), np.uint8)
+        L.fmo_siggen_rds_bits(g, u8ptr(bits), nb)
+        bits = bits[:nb]
     L.fmo_siggen_free(g)
-    return out
+    return (out, bits) if return_rds_bits else out
 
 
 class OracleChain:
