@@ -155,11 +155,16 @@ int ensure_sets(fmx_handle h) {
         if ((int)fk.size() > h->front_cap) {
             if (h->d_front_taps) { (void)hipFree(h->d_front_taps); (void)hipFree(h->d_front_sets); }
             h->front_cap = std::max<int>((int)fk.size(), 4);
-            HIPCHK(hipMalloc(&h->d_front_taps, sizeof(float) * A_TAPS_STRIDE * h->front_cap));
+            HIPCHK(hipMalloc(&h->d_front_taps, sizeof(float) * A_TAPS_DEV * h->front_cap));
             HIPCHK(hipMalloc(&h->d_front_sets, sizeof(FrontSet) * h->front_cap));
         }
         HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipMemcpy(h->d_front_taps, h->h_front_taps.data(), sizeof(float) * h->h_front_taps.size(), hipMemcpyHostToDevice));
+        std::vector<float> dev(fk.size() * A_TAPS_DEV, 0.f);             // device image: [set][r][d]
+        for (size_t i = 0; i < fk.size(); i++)
+            for (int d = 0; d < A_MAX_ND; d++)
+                for (int r = 0; r < DECIM; r++)
+                    dev[i * A_TAPS_DEV + r * A_TAPS_ROW + d] = h->h_front_taps[i * A_TAPS_STRIDE + (d + 1) * DECIM + r];
+        HIPCHK(hipMemcpy(h->d_front_taps, dev.data(), sizeof(float) * dev.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_front_sets, h->h_front_sets.data(), sizeof(FrontSet) * fk.size(), hipMemcpyHostToDevice));
         h->T.front_taps = h->d_front_taps; h->T.front_sets = h->d_front_sets;
     }
@@ -299,6 +304,7 @@ int flush_mailbox(fmx_handle h) {
     if (any_pll && !h->B.w_iq) {
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMalloc(&h->B.w_iq, sizeof(float2) * (size_t)h->work_nj * h->pitch));
+        HIPCHK(hipMemset(h->B.w_iq, 0, sizeof(float2) * (size_t)h->work_nj * h->pitch));
     }
     if (h->params_dirty) {
         HIPCHK(hipDeviceSynchronize());   // the previous call may still run on the caller's stream and the side streams
@@ -507,6 +513,15 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMalloc(&h->B.w_tag, sizeof(int32_t) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_x, sizeof(float2) * NJ * C));
         h->B.w_iq = nullptr;
+        // the recurrence kernels move whole 64-channel row blocks, pad columns included: keep those finite
+        HIPCHK(hipMemset(h->B.w_dem, 0, sizeof(float) * NJ * C));
+        HIPCHK(hipMemset(h->B.w_cur, 0, sizeof(float) * NJ * C));
+        HIPCHK(hipMemset(h->B.w_osc, 0, sizeof(float) * NJ * C));
+        HIPCHK(hipMemset(h->B.w_lock, 0, sizeof(uint8_t) * NJ * C));
+        HIPCHK(hipMemset(h->B.w_err, 0, sizeof(float) * (size_t)PSS_CHUNK * C));
+        HIPCHK(hipMemset(h->B.w_pdp, 0, sizeof(float) * NJ * C));
+        HIPCHK(hipMemset(h->B.w_tag, 0, sizeof(int32_t) * NJ * C));
+        HIPCHK(hipMemset(h->B.w_x, 0, sizeof(float2) * NJ * C));
     }
     HIPCHK(hipMalloc(&h->B.state, sizeof(ChanState) * C));
     HIPCHK(hipMalloc(&h->d_params, sizeof(ChanParams) * C));

@@ -9,7 +9,9 @@ constexpr int DECIM = 12;              // inputRate / fmRate (2304000 / 192000)
 constexpr int A_TILE_COLS = 256;       // front-end tile: 256 fm-rate outputs = 3072 input samples
 constexpr int A_HIST_COLS = 25;        // history columns kept per channel (>= max taps/12 + 1)
 constexpr int A_MAX_ND = 25;           // tap columns: 287 taps at off=6 -> 25 columns of 12
-constexpr int A_TAPS_STRIDE = (A_MAX_ND + 2) * DECIM;   // 324: Tz[(d+1)*12 + r], d = -1..25, zero rows at both ends
+constexpr int A_TAPS_STRIDE = (A_MAX_ND + 2) * DECIM;   // 324: host image Tz[(d+1)*12 + r], d = -1..25, zero rows at both ends
+constexpr int A_TAPS_ROW = 32;         // device image Trd[r][d] (d contiguous, zero padded): one row = the taps of phase r
+constexpr int A_TAPS_DEV = DECIM * A_TAPS_ROW;
 constexpr int PSS_TAPS = 295;          // stereo-separation.cpp:31
 constexpr int PSS_DELAY = 2048 - 295;  // overlap-add latency fftSize - degree (fft-filters.cpp:34)
 constexpr int PSS_CHUNK = 1753;        // PSS feedback lag: the only chunked part of stage B (<= PSS_DELAY)
@@ -85,7 +87,7 @@ struct DeviceTables {
     const float  *arcsine;       // [ARCSINE_N + 1]
     const float2 *lo_table;      // [inputRate] or null when every lo == 0
     const double2 *trig2;        // [TRIG2_N] f64 (cos,sin) factors exp(j2pi 256a/N), exp(j2pi b/N); null if the host check failed
-    const float  *front_taps;    // [sets][A_TAPS_STRIDE]  Tz[(d+1)*12 + r] = G[12 d + off - r] (0 outside)
+    const float  *front_taps;    // [sets][DECIM][A_TAPS_ROW]  Trd[r][d] = G[12 d + off - r] (0 outside)
     const FrontSet *front_sets;
     const float  *pss_taps;      // [PSS_TAPS]
     const float  *audio_taps;    // [sets][C_TAPS_STRIDE]
@@ -126,7 +128,7 @@ struct DeviceBuffers {
     float2  *w_iq;       // limiter output (only allocated when a channel uses the PLL decoder)
     float   *w_cur;      // pilot phase (currentPilotPhase)
     float   *w_osc;      // pilot NCO sine
-    uint8_t *w_lock;     // pilot lock flag per sample
+    uint8_t *w_lock;     // (spare byte-per-sample array; the lock flag travels packed in w_tag)
     float   *w_err;      // [PSS_CHUNK][channel] PSS error for the chunk's call indices
     float   *w_pdp;      // pilotDelayPSS as used by each sample
     int32_t *w_tag;      // -2 mono branch, -1 stereo without PSS, >= 0 PSS call index within the chunk

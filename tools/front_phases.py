@@ -20,7 +20,7 @@ K = 3
 for _ in range(K): f.process_device(iq.data_ptr(), n, n, pcm.data_ptr(), n // 48 + 96, hip_stream=s)
 out = (C.c_ulonglong * 16)()
 L.fmx_debug_phase_cycles(f.h, 0, out)
-names = ["prologue+first load", "DC scan", "mix+LDS write+sync", "prefetch issue", "FIR", "store+sync", "slide/hist"]
+names = ["prologue+first load", "slide+scatter to LDS", "DC removal (scan) + mix + barriers", "prefetch issue", "FIR + partial sums + barrier", "reduce + store", "history save"]
 tiles = ch * K * (n / 6144.0)
 tot = sum(out[:8])
 for k, nm in enumerate(names):
