@@ -442,10 +442,11 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
             // multiply/add sequence the kernel runs); otherwise the kernel reads the global table.
             std::vector<double2> tr((size_t)TRIG2_N);
             for (int a = 0; a < TRIG2_A; a++) { double t = 2 * design::kPi * (256.0 * a) / fmRate; tr[a] = make_double2(std::cos(t), std::sin(t)); }
-            for (int b = 0; b < TRIG2_B; b++) { double t = 2 * design::kPi * (double)b / fmRate; tr[TRIG2_A + b] = make_double2(std::cos(t), std::sin(t)); }
+            for (int a = 0; a < TRIG2_APAD; a++) tr[TRIG2_A + a] = tr[a];          // idx in [N, N + 512) wraps to idx - N
+            for (int b = 0; b < TRIG2_B; b++) { double t = 2 * design::kPi * (double)b / fmRate; tr[TRIG2_A + TRIG2_APAD + b] = make_double2(std::cos(t), std::sin(t)); }
             bool exact = (fmRate == TRIG2_A * TRIG2_B);
             for (int i = 0; exact && i < SINCOS_N; i++) {
-                const double2 ea = tr[i >> 8], eb = tr[TRIG2_A + (i & 255)];
+                const double2 ea = tr[i >> 8], eb = tr[TRIG2_A + TRIG2_APAD + (i & 255)];
                 const float sn = (float)(ea.y * eb.x + ea.x * eb.y);
                 if (std::memcmp(&sn, &sc[i].y, 4) != 0) exact = false;
             }
@@ -453,6 +454,19 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
                 HIPCHK(hipMalloc(&h->d_trig3, sizeof(double2) * TRIG2_N));
                 HIPCHK(hipMemcpy(h->d_trig3, tr.data(), sizeof(double2) * TRIG2_N, hipMemcpyHostToDevice));
             }
+        }
+        {   // the pilot-phase wrap: (float)((double)v - 2 pi) == (v - P32) + C32 in f32 for every float v the PLL can
+            // produce there, v in [P32, P32 + 0.7)?  (P32 = the float just above 2 pi.)  Checked bit for bit.
+            const float P32 = 6.2831855f;
+            const float C32 = (float)((double)P32 - 2 * design::kPi);
+            bool ok = true;
+            for (float v = P32; ok && v < P32 + 0.7f; v = std::nextafterf(v, 100.f)) {
+                const float want = (float)((double)v - 2 * design::kPi);
+                volatile float d = v - P32;
+                const float got = d + C32;
+                if (std::memcmp(&want, &got, 4) != 0) ok = false;
+            }
+            h->T.wrap32_c = C32; h->T.wrap32_ok = ok ? 1 : 0;
         }
         std::vector<float> at((size_t)ATAN_N + 1);                      // compAtan ctor Xtan2.cpp:28-31
         const float St = (float)design::kPi;

@@ -189,6 +189,9 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
 // separate stages of the chunk pipeline (launch_demod) they run concurrently on different wavefronts.
 // Work arrays are read a batch ahead into registers (global latency off the dependent chain).
 // =================================================================================================
+// Batch size of the register-prefetched work-array rows.  A wave can have at most 63 vector-memory operations in flight
+// (6-bit vmcnt) and on gfx9 stores count too: the loads of the next batch are issued right behind the stores of the
+// last one, so (loads + stores) per batch must stay below that or every batch stalls for a store round trip.
 constexpr int SEQ_UB = 16;
 
 // ---- B2
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
         afc = c1 * afc + fmDcAlpha * res;            // fm-demodulator.cpp:197
         return fdiv_const(20.0f * (res - afc) * 1.0f, K, rK);      // :198
     };
-    constexpr int UB = 32;
+    constexpr int UB = SEQ_UB;
     const int nfull = chunk_len / UB;
     float nx[UB]; float2 nq[UB];
     if (nfull > 0) {
@@ -253,18 +256,27 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
     st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr;
 }
 
-// ---- B3.  The NCO sine (float)sin(2*pi*idx/192000) is rebuilt from two f64 factor tables held in LDS
-// (idx = 256 a + b); the host proved the expression rounds to the reference's f32 table entry for every idx
-// (fmx_api.hip), else T.trig2 is null and the global table is used.
+// ---- B3.  The pilot PLL: the longest dependent chain of the path (phase -> LUT index -> sine -> phase).  One wave
+// issues a dependent VALU operation every ~8.5 cycles and an LDS read returns after ~52, so the kernel is written for
+// a SHORT CHAIN rather than for few instructions:
+//   * the NCO sine (float)sin(2*pi*idx/192000) is rebuilt from two f64 factor tables held in LDS (idx = 256 a + b);
+//     the host proved the expression rounds to the reference's f32 table entry for every idx (fmx_api.hip), else
+//     T.trig2 is null and the global table is used.  The A table carries two wrap-around entries, so idx needs no
+//     reduction modulo N (phase < fl32(2 pi) gives idx <= N);
+//   * the phase never goes negative (it is PI_Constrain'ed, the correction 5*demod*gain is < 0.01 < omega), so the
+//     odd-symmetry branch of SinCos::getSin and the negative branch of PI_Constrain drop out;
+//   * the wrap itself, (float)fmod((double)val, 2 pi) for val in [2 pi, 2 pi + 0.7), is two exact-by-construction f32
+//     operations (val - P32 is exact by Sterbenz, P32 - 2 pi is added as a constant) when the host verified that
+//     identity for every float in the interval (T.wrap32_ok), else the f64 form.
+template <bool T2, bool W32>
 __global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
                                                  int64_t rc0, int chunk_len) {
     const int CP = G.pitch;
-    __shared__ double2 sA[TRIG2_A];
-    __shared__ double2 sB[TRIG2_B];
-    const bool t2 = T.trig2 != nullptr;
-    if (t2) {
-        for (int i = threadIdx.x; i < TRIG2_A; i += 64) sA[i] = T.trig2[i];
-        for (int i = threadIdx.x; i < TRIG2_B; i += 64) sB[i] = T.trig2[TRIG2_A + i];
+    __shared__ double2 sA[T2 ? TRIG2_A + TRIG2_APAD : 1];
+    __shared__ double2 sB[T2 ? TRIG2_B : 1];
+    if (T2) {
+        for (int i = threadIdx.x; i < TRIG2_A + TRIG2_APAD; i += 64) sA[i] = T.trig2[i];
+        for (int i = threadIdx.x; i < TRIG2_B; i += 64) sB[i] = T.trig2[TRIG2_A + TRIG2_APAD + i];
     }
     __syncthreads();
     const int ch = blockIdx.x * 64 + threadIdx.x;
@@ -272,27 +284,28 @@ __global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B
     ChanState *st = B.state + ch;
     const float gain = T.pil_gain, omega = T.pil_omega;
     const double SC = T.sincos_C;
+    const float P32 = 6.2831855f, C32 = T.wrap32_c;              // fl32 just above 2 pi; fl32(P32 - 2 pi)
     float phase = st->pil_phase;
+    if (!(phase >= 0.f)) phase = pi_constrain(phase);             // cannot happen (see above); keeps the invariant anyway
     const int64_t ro = rc0 * (int64_t)CP + ch;
     const float *wd = B.w_dem + ro; float *wc = B.w_cur + ro; float *wo = B.w_osc + ro;
     auto step = [&](float demod, float &o_cur, float &o_osc) {
-        // SinCos::getSin sincos.cpp:81-85.  phase is in [0, 2pi] here (PI_Constrain output) except possibly the
-        // very first sample of a stream, hence the sign handling stays.
-        const float pilot = 5 * demod;
-        const bool neg = phase < 0.f;
-        const float p = neg ? -phase : phase;
-        int idx = (int)((double)p * SC);
-        idx = (idx >= SINCOS_N) ? idx - SINCOS_N : idx;          // p <= 2pi + 0.01 -> idx <= N + 306
+        // SinCos::getSin sincos.cpp:81-85 with phase >= 0
+        int idx = (int)((double)phase * SC);
         float osc;
-        if (t2) {
+        if (T2) {
             const double2 ea = sA[idx >> 8], eb = sB[idx & 255];
             osc = (float)(ea.y * eb.x + ea.x * eb.y);
-        } else osc = T.sincos[idx].y;
-        osc = neg ? -osc : osc;
-        const float perr = pilot * osc;
-        phase += perr * gain;
-        o_cur = phase;                                           // PI_Constrain of it is applied in pss_mix_kernel
-        phase = pi_constrain_near(phase + omega);
+        } else {
+            idx = (idx >= SINCOS_N) ? idx - SINCOS_N : idx;
+            osc = T.sincos[idx].y;
+        }
+        const float perr = (5 * demod) * osc;                    // pilot-recover.cpp:56-58
+        const float t = phase + perr * gain;
+        o_cur = t;                                               // PI_Constrain of it is applied in pss_mix_kernel
+        const float val = t + omega;                             // in (0.6, 2 pi + 0.64)
+        const float wrapped = W32 ? (val - P32) + C32 : (float)((double)val - FMX_2PI);
+        phase = (val < P32) ? val : wrapped;                     // PI_Constrain fm-constants.h:148-158
         o_osc = osc;
     };
     const int nfull = chunk_len / SEQ_UB;
@@ -356,7 +369,11 @@ __global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers 
         o_tag = branch ? (pss_active ? tagn : -1) : -2;
         tagn += (branch && pss_active) ? 1 : 0;
     };
-    constexpr int UB = 32;
+    // The lock VALUE is a linear recurrence of the inputs; only the flags and counters derived from it feed the
+    // outputs.  Fast path per block of UB samples: run the value chain alone, note whether `lock > 0.07` held for
+    // all / none of the block's samples; if so (and no counter threshold can be crossed inside the block) the state
+    // machine has a closed form.  Anything else (a wave-uniform decision) replays the block sample by sample.
+    constexpr int UB = SEQ_UB;
     const int nfull = chunk_len / UB;
     float nd[UB], no[UB];
     if (nfull > 0) {
@@ -364,16 +381,50 @@ __global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers 
         for (int k = 0; k < UB; k++) { nd[k] = wd[k * CP]; no[k] = wo[k * CP]; }
     }
     for (int b = 0; b < nfull; b++) {
-        float d[UB], o[UB]; int lk[UB], tg[UB];
+        float d[UB], o[UB]; int pk[UB];
 #pragma unroll
         for (int k = 0; k < UB; k++) { d[k] = nd[k]; o[k] = no[k]; }
         const int nb = (b + 1 < nfull) ? UB * CP : 0;
 #pragma unroll
         for (int k = 0; k < UB; k++) { nd[k] = wd[nb + k * CP]; no[k] = wo[nb + k * CP]; }
+        const float lock0 = lock, old0 = old;
+        bool all_hi = true, all_lo = true;
 #pragma unroll
-        for (int k = 0; k < UB; k++) step(d[k], o[k], lk[k], tg[k]);
+        for (int k = 0; k < UB; k++) {
+            const float quadRef = fdiv_const(o[k] - old, omega, romega);
+            old = o[k];
+            lock = (float)((double)(lockA * (-quadRef * (5 * d[k]))) + (double)lock * keep);
+            const bool tmp = lock > 0.07f;
+            all_hi = all_hi && tmp; all_lo = all_lo && !tmp;
+        }
+        // closed forms:  all_hi & locked -> unchanged;  all_hi & !locked & stable + UB <= N/2 -> stable += UB;
+        //                all_lo -> locked = 0, stable = 0
+        const bool easy = all_lo || (all_hi && (locked != 0 || stable + UB <= (SINCOS_N >> 1)));
+        const bool fast = __all(easy) != 0;
+        if (B.dbg && threadIdx.x == 0) B.dbg[(size_t)ch * 16 + (fast ? 11 : 12)] += 1;
+        if (fast) {
+            if (all_lo) { locked = 0; stable = 0; }
+            else if (!locked) stable += UB;
+            const bool branch = stereo_possible && (locked || !auto_mono);
+            const bool counts = branch && pss_active;
+            const int base = branch ? (pss_active ? tagn : -1) : -2;
+            const int inc = counts ? 1 : 0;
 #pragma unroll
-        for (int k = 0; k < UB; k++) wt[k * CP] = ((tg[k] + 2) << 1) | lk[k];
+            for (int k = 0; k < UB; k++) pk[k] = ((base + inc * k + 2) << 1) | locked;
+            tagn += inc * UB;
+#pragma unroll
+            for (int k = 0; k < UB; k++) wt[k * CP] = pk[k];
+        } else {
+            // rare (lock acquisition / loss): replay the block from memory in a rolled loop, so that the fast path's
+            // register arrays are never indexed dynamically
+            lock = lock0; old = old0;
+#pragma unroll 1
+            for (int k = 0; k < UB; k++) {
+                int lk, tg;
+                step(wd[k * CP], wo[k * CP], lk, tg);
+                wt[k * CP] = ((tg + 2) << 1) | lk;
+            }
+        }
         wd += UB * CP; wo += UB * CP; wt += UB * CP;
     }
     for (int r = nfull * UB; r < chunk_len; r++) {
@@ -443,7 +494,7 @@ __global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffe
 // B6  PSS integrator + state machines   [lane per channel]
 //     fm-processor.cpp:699-718, stereo-separation.cpp:84-109
 // =================================================================================================
-constexpr int ACC_UB = 32;
+constexpr int ACC_UB = SEQ_UB;
 struct AccState { float acc, mean, pdp; int lock_cnt, unlock_cnt; bool minimized; };
 __device__ __forceinline__ float pss_acc_step(AccState &s, float alpha, float la, float keep, bool locked, int tag, float err) {
     // branch-free: every lane (channel) may be in a different state
@@ -488,42 +539,70 @@ __global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffe
     float *pdpw = B.w_pdp + ch + rc0 * (int64_t)CP;
     const float alpha = T.pss_alpha, la = T.pss_lock_alpha, keep = 1.0f - la;
     const bool pss_on = (P.fm_mode != 2) && (P.pss_active != 0);
+    // Fast paths per block of ACC_UB samples (wave-uniform decisions, identical arithmetic):
+    //  * steady: every channel of the wave locked and calling process_sample for the whole block, and no lock /
+    //    unlock counter within a block of its 3 s threshold, so `minimized` cannot change inside the block: the float
+    //    recurrences run alone (`small` is collected as a bit per sample) and the counters follow in closed form;
+    //  * idle: nobody locked, nobody calling (mono or no pilot with autoMono): the state is all zeros.
     const int nfull = chunk_len / ACC_UB;
     int nt[ACC_UB]; float ne[ACC_UB];
     if (nfull > 0) {
 #pragma unroll
         for (int k = 0; k < ACC_UB; k++) { nt[k] = tg[k * CP]; ne[k] = err[k * CP]; }
     }
+    const float c4 = 0.785398185253143310546875f;
     for (int b = 0; b < nfull; b++) {
-        int l[ACC_UB]; int t[ACC_UB]; float e[ACC_UB]; float o[ACC_UB];
+        float e[ACC_UB]; float o[ACC_UB];
+        unsigned andv = ~0u, orv = 0u; int minv = 0x7fffffff;
 #pragma unroll
-        for (int k = 0; k < ACC_UB; k++) { l[k] = nt[k] & 1; t[k] = (nt[k] >> 1) - 2; e[k] = pss_on ? ne[k] : 0.f; }
+        for (int k = 0; k < ACC_UB; k++) {
+            e[k] = pss_on ? ne[k] : 0.f;
+            andv &= (unsigned)nt[k]; orv |= (unsigned)nt[k]; minv = nt[k] < minv ? nt[k] : minv;
+        }
         const int nb = (b + 1 < nfull) ? ACC_UB * CP : 0;
 #pragma unroll
         for (int k = 0; k < ACC_UB; k++) { nt[k] = tg[nb + k * CP]; ne[k] = err[nb + k * CP]; }
-        // steady state (every channel of the wave locked and calling process_sample for the whole batch): the
-        // reset / no-call selects drop out.  Wave-uniform test, identical arithmetic.
-        bool steady = true;
-#pragma unroll
-        for (int k = 0; k < ACC_UB; k++) steady = steady && (l[k] != 0) && (t[k] >= 0);
-        if (__all(steady)) {
-            const float c4 = 0.785398185253143310546875f;
+        // (only the counter that can flip `minimized` matters: lock_cnt while it is 0, unlock_cnt while it is 1)
+        const bool steady = ((andv & 1u) != 0) && (minv >= 4) &&                 // locked, tag >= 0 throughout
+                            ((s.minimized ? s.unlock_cnt : s.lock_cnt) + ACC_UB <= 3 * SINCOS_N);
+        const bool idle = (orv & ~2u) == 0;                                      // unlocked, tag < 0 throughout
+        const bool f_steady = __all(steady) != 0, f_idle = __all(idle) != 0;
+        if (B.dbg && threadIdx.x == 0) B.dbg[(size_t)ch * 16 + (f_steady ? 8 : (f_idle ? 9 : 10))] += 1;
+        if (f_steady) {
+            const float scale = s.minimized ? 1.0f : 10.0f;                      // error = minimized ? err : err * 10
+            constexpr unsigned ALL = (ACC_UB == 32) ? ~0u : ((1u << (ACC_UB & 31)) - 1u);
+            unsigned bits = 0;
+            float prev = s.pdp;
 #pragma unroll
             for (int k = 0; k < ACC_UB; k++) {
-                o[k] = s.pdp;
-                const float error = s.minimized ? e[k] : e[k] * 10.0f;
-                s.acc = fminf(fmaxf(s.acc + alpha * error, -c4), c4);
+                o[k] = prev;
+                const float error = e[k] * scale;
+                s.acc = __builtin_amdgcn_fmed3f(s.acc + alpha * error, -c4, c4);
                 s.mean = la * error + s.mean * keep;
-                const bool small = fabsf(s.mean) < 0.001f;
-                const int lc1 = s.lock_cnt + ((small && !s.minimized) ? 1 : 0);
-                const int uc1 = s.unlock_cnt + ((!small && s.minimized) ? 1 : 0);
-                s.minimized = small ? (s.minimized || lc1 > 3 * SINCOS_N) : (s.minimized && !(uc1 > 3 * SINCOS_N));
-                s.lock_cnt = small ? lc1 : 0; s.unlock_cnt = small ? 0 : uc1;
-                s.pdp = s.acc;
+                bits = (bits << 1) | (fabsf(s.mean) < 0.001f ? 1u : 0u);
+                prev = s.acc;
             }
-        } else {
+            s.pdp = s.acc;
+            if (s.minimized) {
+                s.lock_cnt = (bits == ALL) ? s.lock_cnt : 0;
+                s.unlock_cnt = (bits == 0u) ? s.unlock_cnt + ACC_UB : __builtin_ctz(bits);
+            } else {
+                s.lock_cnt = (bits == ALL) ? s.lock_cnt + ACC_UB : __builtin_ctz(~bits);
+                s.unlock_cnt = (bits != 0u) ? 0 : s.unlock_cnt;
+            }
+        } else if (f_idle) {
+            s.pdp = 0.f; s.acc = 0.f; s.mean = 0.f; s.minimized = false; s.lock_cnt = 0; s.unlock_cnt = 0;
 #pragma unroll
-            for (int k = 0; k < ACC_UB; k++) o[k] = pss_acc_step(s, alpha, la, keep, l[k] != 0, t[k], e[k]);
+            for (int k = 0; k < ACC_UB; k++) o[k] = 0.f;
+        } else {
+            // rare (lock transitions, a counter near its threshold, mixed modes in one wave): rolled replay from memory
+#pragma unroll 1
+            for (int k = 0; k < ACC_UB; k++) {
+                const int p = tg[k * CP];
+                pdpw[k * CP] = pss_acc_step(s, alpha, la, keep, (p & 1) != 0, (p >> 1) - 2, pss_on ? err[k * CP] : 0.f);
+            }
+            tg += ACC_UB * CP; err += ACC_UB * CP; pdpw += ACC_UB * CP;
+            continue;
         }
 #pragma unroll
         for (int k = 0; k < ACC_UB; k++) pdpw[k * CP] = o[k];
@@ -619,7 +698,7 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
     const float a = P.deemph_alpha;
     float yl = st->de_l, yr = st->de_r;
     float2 *x = B.w_x + rc0 * (int64_t)CP + ch;
-    constexpr int UB = 32;
+    constexpr int UB = SEQ_UB;
     const int64_t nfull = nj / UB;
     float2 nx[UB];
     if (nfull > 0) {
@@ -723,7 +802,9 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
         else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
         hand_over(0, 1, c);
-        hipLaunchKernelGGL(pll_kernel, lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
+        if (T.trig2 && T.wrap32_ok) hipLaunchKernelGGL((pll_kernel<true, true>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
+        else if (T.trig2) hipLaunchKernelGGL((pll_kernel<true, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
+        else hipLaunchKernelGGL((pll_kernel<false, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
         hand_over(1, 2, c);
         hipLaunchKernelGGL(lock_kernel, lanes, dim3(64), 0, st[2], T, B, G, C, rc0, len);
         hand_over(2, 3, c);

@@ -25,7 +25,8 @@ constexpr int SINCOS_N = 192000;
 constexpr int ATAN_N = 8192;
 constexpr int ARCSINE_N = 4 * 8192;
 constexpr int TRIG2_A = 750, TRIG2_B = 256;   // 192000 = 750 * 256: idx = 256 a + b
-constexpr int TRIG2_N = TRIG2_A + TRIG2_B;
+constexpr int TRIG2_APAD = 2;                  // wrap-around entries a = 750, 751 (idx may reach N)
+constexpr int TRIG2_N = TRIG2_A + TRIG2_APAD + TRIG2_B;
 
 // front-end filter description of one tap set
 struct FrontSet {
@@ -96,6 +97,8 @@ struct DeviceTables {
     float   K_FM, K_FM_rcp, pil_omega_rcp;   // rcp = RN(1/c) for fdiv_const
     float   pil_omega, pil_gain, pss_alpha, pss_lock_alpha;
     float   pll_beta, pll_lo, pll_hi, pll_center;
+    float   wrap32_c;            // fl32(fl32_above(2 pi) - 2 pi)
+    int32_t wrap32_ok;           // the f32 form of the pilot-phase wrap was verified on the host for every float it can see
 };
 
 struct CallGeom {

@@ -11,7 +11,7 @@ dev = torch.device('cuda', 0)
 iq = bench.synth_device(torch, ch, n, dev)
 pcm = torch.zeros((ch, n // 48 + 96, 2), dtype=torch.float32, device=dev)
 s = torch.cuda.current_stream().cuda_stream
-for _ in range(3): f.process_device(iq.data_ptr(), n, n, pcm.data_ptr(), n // 48 + 96, hip_stream=s)
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3): f.process_device(iq.data_ptr(), n, n, pcm.data_ptr(), n // 48 + 96, hip_stream=s)
 torch.cuda.synchronize()
 L = pkg.load_library()
 L.fmx_debug_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_ulonglong)]
@@ -26,3 +26,4 @@ tot = sum(out[:8])
 for k, nm in enumerate(names):
     print(f"{nm:24s} {out[k]/tiles:9.0f} cycles/tile  {100*out[k]/tot:5.1f}%")
 print("total cycles/tile", tot / tiles)
+print("stage-B block paths: pss_acc steady/idle/replay =", out[8], out[9], out[10], " lock closed-form/replay =", out[11], out[12])
