@@ -10,36 +10,41 @@
 // MI355X design (not the reference's structure): the three LTI stages are folded on the host into ONE
 // real polyphase decimate-by-12 FIR (37 taps, or 287 with the input filter) evaluated once per
 // 12 inputs; the overlap-add latency is reproduced as a pure delay (5 input samples folded into
-// the tap alignment `off`, 5440 fm-rate samples applied by the consumer of the ring).  One
-// persistent workgroup per channel streams the call's samples tile by tile: each thread owns one
-// 12-sample column (= one output), so the DC-removal recurrence is a per-thread run plus one
-// f64 affine block scan, and the mixed samples sit in LDS in a [12 phases][columns] layout whose
-// FIR reads are conflict-free ds_read_b64 with wave-uniform taps in SGPRs.
+// the tap alignment `off`, 5440 fm-rate samples applied by the consumer of the ring).
+//
+// One persistent 256-thread workgroup per channel streams the call; its four waves take the call's
+// 1536-sample tiles (128 output columns of 12 samples) round-robin and NEVER meet at a workgroup barrier:
+//   * a wave loads its tile with coalesced dwordx4 loads, scatters it into its private LDS image X[r][C],
+//     removes DC / mixes (each lane owns 24 consecutive samples; wave scan of the affine DC maps), runs the
+//     polyphase FIR for its own 128 outputs and stores them;
+//   * the only things a tile needs from its predecessor -- the DC state at its first sample and the 24 newest
+//     processed columns (the FIR history) -- travel through small LDS mailboxes with sequence counters
+//     (decoupled look-back: the DC carry is published before the wave's own second pass).
 #include "fmx_internal.h"
 
 namespace fmx {
 
-constexpr int HL = A_HIST_COLS - 1;            // 24 full history columns in front of a tile
-constexpr int CPT = 2;                         // columns per thread in the load / DC / mix / store phases
-constexpr int TCOLS = 256 * CPT;               // 512 columns = 6144 input samples per tile
-constexpr int XCOLS = HL + TCOLS;              // 536
-constexpr int SPT = DECIM * CPT;               // 24 samples per thread per tile
-constexpr int FCOLS = 8;                       // adjacent columns (= outputs) per lane in the FIR phase
-constexpr int RPW = DECIM / 4;                 // polyphase rows per wave in the FIR phase
+constexpr int HL = A_HIST_COLS - 1;            // 24 history columns in front of a tile
+constexpr int WCOLS = 128;                     // fresh columns (= outputs) per wave tile
+constexpr int WSAMP = WCOLS * DECIM;           // 1536 input samples per wave tile
+constexpr int XCOLS = HL + WCOLS;              // 152 columns in a wave's LDS image
+constexpr int SPT = 2 * DECIM;                 // 24 samples per lane per tile (two adjacent columns)
+constexpr int FCOLS = 8;                       // adjacent outputs per lane in the FIR phase
+constexpr int RPQ = DECIM / 4;                 // polyphase rows per lane quarter in the FIR phase
 
-// LDS image of a tile: X[r][C], r = sample index mod 12, C = column (0..23 history, 24..535 fresh).  The unit of
+// LDS image of a wave tile: X[r][C], r = sample index mod 12, C = column (0..23 history, 24..151 fresh).  The unit of
 // storage is the float4 holding the column pair (C even, C+1); unit index = r*XRS + ((C%8)/2)*XS4 + C/8, i.e. for a
-// fixed row and pair slot the 8-column groups are contiguous.  That makes BOTH access patterns conflict-free
-// ds_read_b128: the FIR phase (lane l reads groups l .. l+3 of one pair slot) and the DC phase (thread t reads the
-// pair slot t%4 of group 3 + t/4; XS4 = 4 mod 16 spreads the four slots over the 16 sixteen-byte bank slots for the
-// lane groups ds_read_b128 is serviced in).
-constexpr int XS4 = 68;                        // >= 67 groups, = 4 (mod 16)
-constexpr int XRS = 4 * XS4 + 1;               // row stride in units
+// fixed row and pair slot the 8-column groups are contiguous.  Both consumers read it with conflict-free
+// ds_read_b128: the DC phase (lane l: pair slot l%4 of group 3 + l/4; XS4 = 4 mod 16 spreads the four slots over the
+// sixteen 16-byte bank slots of the lane groups ds_read_b128 is serviced in) and the FIR phase (each of those
+// 16-lane service groups reads 16 consecutive groups of ONE row, see fir_lane_map).
+constexpr int XS4 = 20;                        // >= 19 groups, = 4 (mod 16)
+constexpr int XRS = 4 * XS4 + 1;               // row stride in units (odd: even rows spread over the banks on scatter)
+constexpr int XUNITS = DECIM * XRS;            // 972 float4 = 15552 B per wave
 __device__ __forceinline__ int xunit(int r, int C) { return r * XRS + ((C & 7) >> 1) * XS4 + (C >> 3); }
 __device__ __forceinline__ int xidx(int r, int C) { return 2 * xunit(r, C) + (C & 1); }   // float2 index
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(4))) const float cfloat;    // constant address space: uniform loads become s_load
 
 // The DC recurrence r <- r + alpha (x - r) over a run of samples is the affine map r -> r (1 - u) + a.
 // (u, a) are kept instead of (m = 1 - u, a): u ~ count * alpha is tiny, so f32 holds it to 1e-7 relative,
@@ -55,17 +60,26 @@ __device__ __forceinline__ Aff aff_then(const Aff &f, const Aff &g) {      // ap
 
 #define FMX_TICK(k) do { if (dbg_on) { unsigned long long now_ = clock64(); dbg_acc[k] += now_ - dbg_t; dbg_t = now_; } } while (0)
 
-// FIR phase of one wave: rows r0 .. r0+2, eight adjacent outputs per lane.  For each row the lane holds the window
-// W[0..31] = X[r][8 l .. 8 l + 31] (tile columns; output column 24 + 8 l + k uses W[24 + k - d]) in registers, the
-// row's taps sit in SGPRs, and every tap feeds eight packed FMAs (re, im): 1 LDS byte per 1.6 flop.
+// mailbox counters between the waves of a workgroup (LDS, workgroup scope)
+__device__ __forceinline__ void seq_wait(int *p, int need) {
+    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void seq_post(int *p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// FIR phase: the lane computes eight adjacent outputs (columns 8 cg .. 8 cg + 7 of the tile) over polyphase rows
+// r0 .. r0+2.  For each row it holds the window W[0..31] = X[r][8 cg .. 8 cg + 31] (image columns; output column
+// 24 + 8 cg + k uses W[24 + k - d]) in registers, the row's taps arrive by wave-uniform-per-quarter LDS reads, and
+// every tap feeds eight packed FMAs (re, im): 1 LDS byte per 1.6 flop.
 template <int ND>
-__device__ __forceinline__ void fir_rows(const float4 *__restrict__ X4, int lane, int r0, const float4 *__restrict__ tp, v2f acc[FCOLS]) {
+__device__ __forceinline__ void fir_rows(const float4 *__restrict__ X4, int cg, int r0, const float4 *__restrict__ tp, v2f acc[FCOLS]) {
     constexpr int JMIN = (HL - (ND - 1)) / 8;                       // first 8-column group the taps reach
 #pragma unroll 1
-    for (int rr = 0; rr < RPW; rr++) {
+    for (int rr = 0; rr < RPQ; rr++) {
         float tw[(ND + 3) / 4 * 4];
 #pragma unroll
-        for (int d4 = 0; d4 < (ND + 3) / 4; d4++) {                  // wave-uniform address: one broadcast LDS cycle each
+        for (int d4 = 0; d4 < (ND + 3) / 4; d4++) {                  // same address for the 16 lanes of a quarter: broadcast
             const float4 v = tp[rr * (A_TAPS_ROW / 4) + d4];
             tw[4 * d4] = v.x; tw[4 * d4 + 1] = v.y; tw[4 * d4 + 2] = v.z; tw[4 * d4 + 3] = v.w;
         }
@@ -74,7 +88,7 @@ __device__ __forceinline__ void fir_rows(const float4 *__restrict__ X4, int lane
         for (int j = 3; j >= JMIN; j--)                              // newest columns first: the taps d = 0.. use them first
 #pragma unroll
             for (int kp = 0; kp < 4; kp++) {
-                const float4 v = X4[(r0 + rr) * XRS + kp * XS4 + lane + j];
+                const float4 v = X4[(r0 + rr) * XRS + kp * XS4 + cg + j];
                 W[8 * j + 2 * kp] = (v2f){v.x, v.y};
                 W[8 * j + 2 * kp + 1] = (v2f){v.z, v.w};
             }
@@ -89,16 +103,17 @@ __device__ __forceinline__ void fir_rows(const float4 *__restrict__ X4, int lane
 
 __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
                                                        const float2 *__restrict__ iq) {
-    __shared__ __attribute__((aligned(16))) float4 X4[DECIM * XRS];
-    __shared__ __attribute__((aligned(16))) float4 red[4][64][FCOLS / 2];   // per-wave partial sums, [wave][lane][pair]
+    __shared__ __attribute__((aligned(16))) float4 Xall[4][XUNITS];       // one image per wave (62208 B)
     __shared__ __attribute__((aligned(16))) float sT[A_TAPS_DEV];          // the channel's tap set Trd[r][d]
-    __shared__ float wave_tot[4][3];
-    __shared__ float carry[2][2];                    // double-buffered by tile parity
-    float2 *X2 = reinterpret_cast<float2 *>(X4);
+    __shared__ float carry[8][2];                                          // DC state after tile ti, slot = ti & 7
+    __shared__ int carry_seq;                                              // tiles whose carry is published
+    __shared__ int hist_seq[4], free_seq[4];                               // per wave image: history of tile (n-1) is in / tile (n-1) is done
 
     const int ch = blockIdx.x;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    float4 *X4 = Xall[wave];
+    float2 *X2 = reinterpret_cast<float2 *>(X4);
     const ChanParams P = B.params[ch];
     const FrontSet FS = T.front_sets[P.front_set];
     const float2 *__restrict__ in = iq + (size_t)P.stream * G.stream_stride;
@@ -110,26 +125,29 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
     // Call-local 32-bit geometry: sample index s = global index - 12 qa, column index = global column - qa.
     const int64_t qa = G.g0 / 12;                     // column holding the first fresh sample
     const int r0 = (int)(G.g0 - qa * 12);             // the call's fresh samples are s in [g0, gend)
-    const int g0 = r0, n = (int)G.n, gend = r0 + n;
+    const int g0 = r0, gend = r0 + (int)G.n;
     const int ja = (int)((G.g0 - off + 11) / 12 - qa);            // first output completed by this call
     const int jb = (int)((G.g0 + G.n - off + 11) / 12 - qa);      // one past the last
     const int qb = (gend - 1) / 12;                   // column holding the last fresh sample
+    const int NT = qb / WCOLS + 1;                    // wave tiles in this call
     const int zr0 = (int)(qa & (int64_t)G.ring_mask);
 
-    // ---- history -> LDS (columns qa-24 .. qa-1 at C 0..23, partial column qa at C 24)
-    for (int i = t; i < DECIM * A_HIST_COLS; i += 256) {
-        int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;
-        float2 v = hist[i];
-        if (c == HL && r >= r0) v = make_float2(0.f, 0.f);
-        X2[xidx(r, c)] = v;
-    }
-    if (t == 0) {
-        const bool rst = (P.actions & ACT_DC_RESET) != 0;        // setDCRemove zeroes RfDC (:922-925)
-        carry[0][0] = rst ? 0.f : st->dc_re; carry[0][1] = rst ? 0.f : st->dc_im;
-    }
     for (int i = t; i < A_TAPS_DEV; i += 256) sT[i] = T.front_taps[(size_t)P.front_set * A_TAPS_DEV + i];
-    // this wave's three tap rows, d-contiguous: Trd[r][d] = G[12 d + off - r]
-    const float4 *tp = reinterpret_cast<const float4 *>(sT + RPW * wave * A_TAPS_ROW);
+    if (t == 0) { carry_seq = 0; for (int i = 0; i < 4; i++) { hist_seq[i] = 0; free_seq[i] = 0; } }
+    // ---- history -> the image of tile 0 (wave 0): columns qa-24 .. qa-1 at C 0..23, partial column qa at C 24
+    if (wave == 0) {
+        for (int i = lane; i < DECIM * A_HIST_COLS; i += 64) {
+            int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;
+            float2 v = hist[i];
+            if (c == HL && r >= r0) v = make_float2(0.f, 0.f);
+            X2[xidx(r, c)] = v;
+        }
+    }
+    // per-channel state is read by every wave BEFORE the barrier (the wave that ends the call rewrites it)
+    const int lo_phase0 = st->lo_phase;
+    const bool dc_rst = (P.actions & ACT_DC_RESET) != 0;          // setDCRemove zeroes RfDC (:922-925)
+    const float dc0r = dc_rst ? 0.f : st->dc_re, dc0i = dc_rst ? 0.f : st->dc_im;
+    __syncthreads();                                  // the only workgroup barrier: tables and counters are set up
 
     const bool dcr = P.dc_remove != 0;
     const int lo = P.lo_freq;
@@ -137,26 +155,51 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
     const int R = G.input_rate;
     const float alpha = 1.0f / (float)R;              // rfDcAlpha fm-processor.cpp:379
     const float Lg = P.att_l, Rg = P.att_r;
+    const bool touch = dcr || mix || Lg != 1.0f || Rg != 1.0f;
     const bool aligned16 = ((g0 & 1) == 0) && ((G.stream_stride & 1) == 0) &&
                            ((reinterpret_cast<uintptr_t>(iq) & 15) == 0);
-    const int lo_phase0 = st->lo_phase;
-    float u_full = 0.f;                               // u of a full 24-sample run (the same for every such thread)
+    float u_full = 0.f;                               // u of a full 24-sample run (the same for every such lane)
     for (int k = 0; k < SPT; k++) u_full = (1.0f - u_full) * alpha + u_full;
+    // Full tiles: every lane's run has the same u, so the scan of u is known in advance -- u_exc = u of `lane` runs,
+    // u_tile = u of 64 runs -- and only the `a` parts are scanned: a <- a + a_earlier * m with m = (1 - u)^(runs the lane's
+    // partial result covers), which is a constant per scan step (m1, m2, m4, m8) or per lane (mA, mB) (DPP scan below).
+    const float m1 = 1.0f - u_full, m2 = m1 * m1, m4 = m2 * m2, m8 = m4 * m4;
+    float u_exc = 0.f, u_tile = 0.f, mA = 1.f, mB = 1.f;
+    for (int i = 0; i < 64; i++) {
+        if (i < lane) u_exc = u_exc + u_full - u_exc * u_full;
+        u_tile = u_tile + u_full - u_tile * u_full;
+        if (i < (lane & 15) + 1) mA *= m1;
+        if (i < (lane & 31) + 1) mB *= m1;
+    }
+    // history hand-off: the 24 newest columns of this image go straight into the next wave's image (144 float4 units)
+    float4 *Xn = Xall[(wave + 1) & 3];
+    int ho_src[3], ho_dst[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = lane + 64 * k, r = (i < DECIM * 12) ? i / 12 : 0, cp = (i < DECIM * 12) ? i - 12 * r : 0;
+        ho_src[k] = xunit(r, WCOLS + 2 * cp); ho_dst[k] = xunit(r, 2 * cp);
+    }
 
-    // Each wave owns a quarter of the tile: 128 columns = 1536 consecutive samples.  It loads them with
-    // fully coalesced float4 loads (lane l, step k -> sample pair l + 64 k of the quarter), scatters them into
-    // its own X columns, and each lane then reads back "its" two columns (24 consecutive samples in time).
-    constexpr int WCOLS = TCOLS / 4, WSAMP = WCOLS * DECIM;      // 128 columns, 1536 samples
+    // FIR lane map: ds_read_b128 is serviced in the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32); each
+    // group takes ONE row quarter and 16 consecutive column groups, so its 16 reads fall on 16 distinct bank slots.
+    const int lg = lane & 31;
+    const bool inA = (lg < 4) || (lg >= 12 && lg < 16) || (lg >= 20 && lg < 28);
+    const int rq = (lane >> 5) * 2 + (inA ? 0 : 1);
+    const int cg = inA ? (lg < 4 ? lg : (lg < 16 ? lg - 8 : lg - 12)) : (lg < 12 ? lg - 4 : (lg < 20 ? lg - 8 : lg - 16));
+    const float4 *tp = reinterpret_cast<const float4 *>(sT + RPQ * rq * A_TAPS_ROW);
+
+    // Coalesced tile load: lane l, step k -> sample pair l + 64 k of the tile; after the scatter each lane reads back
+    // "its" two columns (24 consecutive samples in time).
     float4 raw[SPT / 2];
     int sc_idx[SPT / 2];                                          // float2 index of sample pair k's first sample
 #pragma unroll
     for (int k = 0; k < SPT / 2; k++) {
-        const int e = 2 * (lane + 64 * k);                        // sample index within the wave's quarter (even)
+        const int e = 2 * (lane + 64 * k);                        // sample index within the tile (even)
         const int c = e / 12, r = e - 12 * c;                     // r is even: the pair stays inside one column
-        sc_idx[k] = xidx(r, HL + WCOLS * wave + c);
+        sc_idx[k] = xidx(r, HL + c);
     }
-    auto load_tile = [&](int qt) {
-        const int wbase = (qt + WCOLS * wave) * 12;              // index of the wave's first sample
+    auto load_tile = [&](int ti) {
+        const int wbase = ti * WSAMP;                             // index of the tile's first sample
         if (aligned16 && wbase >= g0 && wbase + WSAMP <= gend) {
             const float4 *p4 = reinterpret_cast<const float4 *>(in + (wbase - g0));
 #pragma unroll
@@ -174,21 +217,15 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
     const bool dbg_on = (B.dbg != nullptr) && (t == 0);
     unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
-    load_tile(0);
-    // history slide: the last 24 columns (groups 64..66) of every row / pair slot move to groups 0..2
-    const int sl_r = t / 12, sl_rem = t - 12 * sl_r;
-    const int sl_unit = sl_r * XRS + (sl_rem / 3) * XS4 + (sl_rem % 3);
-    float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool slide = false;
-    int it = 0;
-    const int dc_unit = (t & 3) * XS4 + 3 + (t >> 2);   // this thread's column pair (24 + 2t, 24 + 2t + 1), row 0
+    if (wave < NT) load_tile(wave);
+    const int dc_unit = (lane & 3) * XS4 + 3 + (lane >> 2);     // this lane's column pair (24 + 2 l, 24 + 2 l + 1), row 0
     FMX_TICK(0);
 
-    for (int qt = 0; qt <= qb; qt += TCOLS, it++) {
-        // ---- finish the slide of the previous tile and scatter the raw samples
-        if (slide && t < DECIM * 12) X4[sl_unit] = m0;
+    for (int ti = wave; ti < NT; ti += 4) {
+        const int qt = ti * WCOLS;                    // first column of the tile
+        const int wbase = qt * 12;
+        // ---- scatter the raw samples into the image
         {
-            const int wbase = (qt + WCOLS * wave) * 12;
             const bool allfresh = (wbase >= g0) && (wbase + WSAMP <= gend);
             if (allfresh) {
 #pragma unroll
@@ -206,28 +243,27 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
                 }
             }
         }
-        // no workgroup barrier here: a wave scatters exactly the columns its own lanes pick up below (wave w: columns
-        // 128 w .. 128 w + 127), LDS operations of one wave complete in order, and the slid history columns are only read
-        // by the FIR phase, two barriers further on
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();              // LDS operations of one wave complete in order
         FMX_TICK(1);
-        const int q = qt + CPT * t;                   // this thread's first column
+        const int q = qt + 2 * lane;                  // this lane's first column
         const int base = q * 12;
-        // fresh samples of this thread are rows [first, lastp1) of its 24
+        // fresh samples of this lane are rows [first, lastp1) of its 24
         int first = (base >= g0) ? 0 : ((g0 - base) < SPT ? (g0 - base) : SPT);
         int lastp1 = (base + SPT <= gend) ? SPT : ((gend - base) > 0 ? (gend - base) : 0);
         if (lastp1 < first) lastp1 = first;
         const bool wave_full = __all(first == 0 && lastp1 == SPT);
+        float c_out_r = 0.f, c_out_i = 0.f;           // DC state after this tile
 
-        if (dcr || mix || Lg != 1.0f || Rg != 1.0f) {
+        if (touch) {
             v2f x[SPT];
 #pragma unroll
             for (int r = 0; r < DECIM; r++) {
                 const float4 v = X4[dc_unit + r * XRS];
                 x[r] = (v2f){v.x, v.y}; x[r + DECIM] = (v2f){v.z, v.w};
             }
-            // ---- RF DC removal (fm-processor.cpp:423-446): per-thread run, block scan of the affine maps, then
-            //      the reference's own f32 recurrence RfDC = (x - RfDC)*alpha + RfDC from the scanned prefix.
+            // ---- RF DC removal (fm-processor.cpp:423-446): per-lane run, wave scan of the affine maps, the carry of
+            //      the previous tile from the mailbox, then the reference's own f32 recurrence
+            //      RfDC = (x - RfDC)*alpha + RfDC from the scanned prefix.
             if (dcr) {
                 Aff a; a.u = 0.f;
                 v2f aa = (v2f){0.f, 0.f};
@@ -245,42 +281,69 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
                         }
                     }
                 }
-                a.ar = aa.x; a.ai = aa.y;
-                Aff inc = a;                              // inclusive scan over the wave
+                Aff pre;                                  // exclusive prefix within the tile
+                float tu, tar, tai;                       // the whole tile's map
+                if (wave_full) {
+                    // inclusive scan of the a parts with DPP: four steps inside the 16-lane rows, then the row totals
+                    // ride row_bcast:15 (into rows 1, 3) and row_bcast:31 (into rows 2, 3)
+                    float sr = aa.x, si = aa.y;
+#define FMX_SCAN_STEP(ctrl, rmask, mm)                                                                                       \
+                    {                                                                                                        \
+                        const float er = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), ctrl, rmask, 0xf, false)); \
+                        const float ei = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), ctrl, rmask, 0xf, false)); \
+                        sr = fmaf(er, mm, sr); si = fmaf(ei, mm, si);                                                        \
+                    }
+                    FMX_SCAN_STEP(0x111, 0xf, m1)
+                    FMX_SCAN_STEP(0x112, 0xf, m2)
+                    FMX_SCAN_STEP(0x114, 0xf, m4)
+                    FMX_SCAN_STEP(0x118, 0xf, m8)
+                    FMX_SCAN_STEP(0x142, 0xa, mA)
+                    FMX_SCAN_STEP(0x143, 0xc, mB)
+#undef FMX_SCAN_STEP
+                    pre.ar = __shfl_up(sr, 1, 64); pre.ai = __shfl_up(si, 1, 64);
+                    if (lane == 0) { pre.ar = 0.f; pre.ai = 0.f; }
+                    pre.u = u_exc;
+                    tu = u_tile;
+                    tar = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sr), 63));
+                    tai = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(si), 63));
+                } else {
+                    a.ar = aa.x; a.ai = aa.y;
+                    Aff inc = a;                          // general inclusive scan (first / last tile of a call)
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    Aff o; o.u = __shfl_up(inc.u, d, 64); o.ar = __shfl_up(inc.ar, d, 64); o.ai = __shfl_up(inc.ai, d, 64);
-                    if (lane >= d) inc = aff_then(o, inc);
+                    for (int d = 1; d < 64; d <<= 1) {
+                        Aff o; o.u = __shfl_up(inc.u, d, 64); o.ar = __shfl_up(inc.ar, d, 64); o.ai = __shfl_up(inc.ai, d, 64);
+                        if (lane >= d) inc = aff_then(o, inc);
+                    }
+                    pre.u = __shfl_up(inc.u, 1, 64); pre.ar = __shfl_up(inc.ar, 1, 64); pre.ai = __shfl_up(inc.ai, 1, 64);
+                    if (lane == 0) { pre.u = 0.f; pre.ar = 0.f; pre.ai = 0.f; }
+                    tu = __shfl(inc.u, 63, 64); tar = __shfl(inc.ar, 63, 64); tai = __shfl(inc.ai, 63, 64);
                 }
-                if (lane == 63) { wave_tot[wave][0] = inc.u; wave_tot[wave][1] = inc.ar; wave_tot[wave][2] = inc.ai; }
-                Aff exc;                                  // exclusive prefix within the wave
-                exc.u = __shfl_up(inc.u, 1, 64); exc.ar = __shfl_up(inc.ar, 1, 64); exc.ai = __shfl_up(inc.ai, 1, 64);
-                if (lane == 0) { exc.u = 0.f; exc.ar = 0.f; exc.ai = 0.f; }
-                __syncthreads();
-                Aff pre; pre.u = 0.f; pre.ar = 0.f; pre.ai = 0.f;
-                for (int w = 0; w < wave; w++) {
-                    Aff wv; wv.u = wave_tot[w][0]; wv.ar = wave_tot[w][1]; wv.ai = wave_tot[w][2];
-                    pre = aff_then(pre, wv);
+                // carry in: the DC state at the tile's first sample
+                float c0 = dc0r, c1 = dc0i;
+                if (ti > 0) {
+                    seq_wait(&carry_seq, ti);
+                    c0 = carry[(ti - 1) & 7][0]; c1 = carry[(ti - 1) & 7][1];
                 }
-                pre = aff_then(pre, exc);
-                const float c0 = carry[it & 1][0], c1 = carry[it & 1][1];
+                c_out_r = c0 - c0 * tu + tar; c_out_i = c1 - c1 * tu + tai;
+                if (lane == 0) { carry[ti & 7][0] = c_out_r; carry[ti & 7][1] = c_out_i; }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) seq_post(&carry_seq, ti + 1);              // look-back hand-off, before this wave's pass 2
                 v2f rr = (v2f){c0 - c0 * pre.u + pre.ar, c1 - c1 * pre.u + pre.ai};
                 if (wave_full) {
 #pragma unroll
                     for (int k = 0; k < SPT; k++) {
                         rr = __builtin_elementwise_fma(x[k] - rr, al, rr);
-                        x[k] -= (v2f){fminf(fmaxf(rr.x, -0.01f), 0.01f), fminf(fmaxf(rr.y, -0.01f), 0.01f)};   // DCRlimit :429-442
+                        x[k] -= (v2f){__builtin_amdgcn_fmed3f(rr.x, -0.01f, 0.01f), __builtin_amdgcn_fmed3f(rr.y, -0.01f, 0.01f)};   // DCRlimit :429-442
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < SPT; k++) {
                         if (k >= first && k < lastp1) {
                             rr = __builtin_elementwise_fma(x[k] - rr, al, rr);
-                            x[k] -= (v2f){fminf(fmaxf(rr.x, -0.01f), 0.01f), fminf(fmaxf(rr.y, -0.01f), 0.01f)};
+                            x[k] -= (v2f){__builtin_amdgcn_fmed3f(rr.x, -0.01f, 0.01f), __builtin_amdgcn_fmed3f(rr.y, -0.01f, 0.01f)};
                         }
                     }
                 }
-                if (t == 255) { carry[(it + 1) & 1][0] = rr.x; carry[(it + 1) & 1][1] = rr.y; }   // new state
             }
             // ---- IQ balance + LO mix (fm-processor.cpp:462-466, oscillator.cpp:49-58)
             if (Lg != 1.0f || Rg != 1.0f) {
@@ -308,35 +371,63 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
 #pragma unroll
             for (int r = 0; r < DECIM; r++)
                 X4[dc_unit + r * XRS] = make_float4(x[r].x, x[r].y, x[r + DECIM].x, x[r + DECIM].y);
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
         FMX_TICK(2);
-        // ---- prefetch the next tile's raw samples; they land while the FIR runs
-        const bool more = (qt + TCOLS <= qb);
-        if (more) load_tile(qt + TCOLS);
+        // ---- hand the 24 newest processed columns to the next tile: written straight into the next wave's image, once
+        //      that wave is done with its previous tile (ti - 3), whose history / partial sums live there
+        if (ti + 1 < NT) {
+            const int nw = (wave + 1) & 3;
+            if (ti >= 3) seq_wait(&free_seq[nw], ti - 2);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (k < 2 || lane < DECIM * 12 - 128) Xn[ho_dst[k]] = X4[ho_src[k]];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) seq_post(&hist_seq[nw], ti + 1);
+        }
+        // ---- and wait for the previous tile's (tile 0 got the call's history from HBM)
+        if (ti > 0) seq_wait(&hist_seq[wave], ti);
         FMX_TICK(3);
+        // ---- prefetch this wave's next tile; the loads land while the FIR runs
+        const bool more = (ti + 4 < NT);
+        if (more) load_tile(ti + 4);
 
-        // ---- polyphase FIR  out[j] = sum_d sum_r Trd[r][d] * X[r][C_j - d]:  wave w sums rows 3w..3w+2 for all
-        //      512 outputs (eight adjacent ones per lane), the four partial sums meet in LDS
+        // ---- polyphase FIR  out[j] = sum_d sum_r Trd[r][d] * X[r][C_j - d]:  lane quarter rq sums rows 3 rq .. 3 rq + 2
+        //      for eight adjacent outputs per lane; the four partial sums meet in LDS (on top of the image, which is
+        //      dead by then)
         {
             v2f acc[FCOLS];
 #pragma unroll
             for (int k = 0; k < FCOLS; k++) acc[k] = (v2f){0.f, 0.f};
-            if (nd <= 4) fir_rows<4>(X4, lane, RPW * wave, tp, acc);
-            else fir_rows<A_MAX_ND>(X4, lane, RPW * wave, tp, acc);
+            if (nd <= 4) fir_rows<4>(X4, cg, RPQ * rq, tp, acc);
+            else fir_rows<A_MAX_ND>(X4, cg, RPQ * rq, tp, acc);
+            __builtin_amdgcn_wave_barrier();
+            // save the columns the call-end history needs before the image is overwritten (last tile only: below)
+            if (ti == NT - 1) {
+                // ---- last tile: save history for the next call (columns qn-24 .. qn of the call, from this image)
+                const int qn = gend / 12;                 // column of the next call's first sample
+                const int cbase = qn - qt;                // image column of history slot 0 (= column qn-24)
+                for (int i = lane; i < DECIM * A_HIST_COLS; i += 64) {
+                    int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;
+                    int lc = cbase + c;
+                    float2 v = make_float2(0.f, 0.f);
+                    if (lc >= 0 && lc < XCOLS) v = X2[xidx(r, lc)];
+                    hist[i] = v;
+                }
+                if (lane == 0 && (dcr || dc_rst)) { st->dc_re = dcr ? c_out_r : dc0r; st->dc_im = dcr ? c_out_i : dc0i; }
+                __builtin_amdgcn_wave_barrier();
+            }
 #pragma unroll
             for (int k = 0; k < FCOLS / 2; k++)
-                red[wave][lane][(k + (lane >> 1)) & 3] = make_float4(acc[2 * k].x, acc[2 * k].y, acc[2 * k + 1].x, acc[2 * k + 1].y);
+                X4[(rq * 16 + cg) * 4 + ((k + (cg >> 1)) & 3)] = make_float4(acc[2 * k].x, acc[2 * k].y, acc[2 * k + 1].x, acc[2 * k + 1].y);
         }
-        // the 24 columns that become the next tile's history (written back at the top of the next iteration)
-        slide = more;
-        if (more && t < DECIM * 12) m0 = X4[sl_unit + 64];
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         FMX_TICK(4);
         {
-            // outputs 2t, 2t+1 = pair (t & 3) of FIR lane t >> 2
-            const int fl = t >> 2, pr = ((t & 3) + (fl >> 1)) & 3;
-            const float4 s0 = red[0][fl][pr], s1 = red[1][fl][pr], s2 = red[2][fl][pr], s3 = red[3][fl][pr];
+            // outputs 2 l, 2 l + 1 = pair (l & 3) of column group l >> 2
+            const int fg = lane >> 2, pr = ((lane & 3) + (fg >> 1)) & 3;
+            const float4 s0 = X4[(0 * 16 + fg) * 4 + pr], s1 = X4[(1 * 16 + fg) * 4 + pr];
+            const float4 s2 = X4[(2 * 16 + fg) * 4 + pr], s3 = X4[(3 * 16 + fg) * 4 + pr];
             const float2 aA = make_float2((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
             const float2 aB = make_float2((s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
             if (q >= ja && q < jb)
@@ -344,30 +435,17 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
             if (q + 1 >= ja && q + 1 < jb)
                 zring[(zr0 + q + 1) & G.ring_mask] = make_float2(aB.x * FS.gain_re - aB.y * FS.gain_im, aB.x * FS.gain_im + aB.y * FS.gain_re);
         }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) seq_post(&free_seq[wave], ti + 1);          // this image may receive the history of tile ti + 3
         FMX_TICK(5);
-        if (!more) {
-            // ---- last tile: save history for the next call
-            const int qn = gend / 12;                 // column of the next call's first sample
-            const int cbase = qn - qt;                // LDS column of history slot 0 (= column qn-24)
-            for (int i = t; i < DECIM * A_HIST_COLS; i += 256) {
-                int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;
-                int lc = cbase + c;
-                float2 v = make_float2(0.f, 0.f);
-                if (lc >= 0 && lc < XCOLS) v = X2[xidx(r, lc)];
-                hist[i] = v;
-            }
-        }
     }
     FMX_TICK(6);
     if (dbg_on) for (int k = 0; k < 8; k++) B.dbg[(size_t)ch * 16 + k] += dbg_acc[k];
-    if (t == 0) {
-        if (dcr || (P.actions & ACT_DC_RESET)) { st->dc_re = carry[it & 1][0]; st->dc_im = carry[it & 1][1]; }
-        if (lo != 0) {
-            long long m = ((long long)G.n * (long long)lo) % (long long)R;
-            int ph = (int)(((long long)lo_phase0 - m) % (long long)R);
-            if (ph < 0) ph += R;
-            st->lo_phase = ph;
-        }
+    if (t == 0 && lo != 0) {
+        long long m = ((long long)G.n * (long long)lo) % (long long)R;
+        int ph = (int)(((long long)lo_phase0 - m) % (long long)R);
+        if (ph < 0) ph += R;
+        st->lo_phase = ph;
     }
 }
 

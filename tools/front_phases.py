@@ -20,8 +20,8 @@ K = 3
 for _ in range(K): f.process_device(iq.data_ptr(), n, n, pcm.data_ptr(), n // 48 + 96, hip_stream=s)
 out = (C.c_ulonglong * 16)()
 L.fmx_debug_phase_cycles(f.h, 0, out)
-names = ["prologue+first load", "slide+scatter to LDS", "DC removal (scan) + mix + barriers", "prefetch issue", "FIR + partial sums + barrier", "reduce + store", "history save"]
-tiles = ch * K * (n / 6144.0)
+names = ["prologue+first load", "scatter to LDS", "DC removal (scan, carry wait) + mix", "history hand-off (waits)", "prefetch + FIR + partial sums", "reduce + store", "epilogue"]
+tiles = ch * K * (n / 1536.0 / 4)     # wave 0 of every workgroup handles a quarter of the 1536-sample tiles
 tot = sum(out[:8])
 for k, nm in enumerate(names):
     print(f"{nm:24s} {out[k]/tiles:9.0f} cycles/tile  {100*out[k]/tot:5.1f}%")
