@@ -514,7 +514,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     HIPCHK(hipMalloc(&h->B.sring, sizeof(float2) * C * h->sring));
     HIPCHK(hipMalloc(&h->B.dring, sizeof(float2) * C * h->dring));
     {
-        const size_t NJ = (size_t)fm_per_call + 1;
+        const size_t NJ = (((size_t)fm_per_call + 1 + WT - 1) / WT) * WT;      // whole work-array tiles (widx)
         h->work_nj = (int64_t)NJ;
         h->pitch = ((h->channels + 63) / 64) * 64 + 64;
         const size_t C = (size_t)h->pitch;   // rows are padded (see CallGeom.pitch)
@@ -522,7 +522,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMalloc(&h->B.w_cur, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_osc, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_lock, sizeof(uint8_t) * NJ * C));
-        HIPCHK(hipMalloc(&h->B.w_err, sizeof(float) * (size_t)PSS_CHUNK * C));
+        HIPCHK(hipMalloc(&h->B.w_err, sizeof(float) * (size_t)(PSS_CHUNK + WT) * C));
         HIPCHK(hipMalloc(&h->B.w_pdp, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_tag, sizeof(int32_t) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_x, sizeof(float2) * NJ * C));
@@ -532,7 +532,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMemset(h->B.w_cur, 0, sizeof(float) * NJ * C));
         HIPCHK(hipMemset(h->B.w_osc, 0, sizeof(float) * NJ * C));
         HIPCHK(hipMemset(h->B.w_lock, 0, sizeof(uint8_t) * NJ * C));
-        HIPCHK(hipMemset(h->B.w_err, 0, sizeof(float) * (size_t)PSS_CHUNK * C));
+        HIPCHK(hipMemset(h->B.w_err, 0, sizeof(float) * (size_t)(PSS_CHUNK + WT) * C));
         HIPCHK(hipMemset(h->B.w_pdp, 0, sizeof(float) * NJ * C));
         HIPCHK(hipMemset(h->B.w_tag, 0, sizeof(int32_t) * NJ * C));
         HIPCHK(hipMemset(h->B.w_x, 0, sizeof(float2) * NJ * C));

@@ -168,13 +168,14 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
         if (want_iq) tileIQ[cl][rl] = cur;
     }
     __syncthreads();
-    for (int i = 0; i < 16; i++) {
-        const int rl = (tid >> 6) + 4 * i, cl = tid & 63;
+    for (int i = 0; i < 16; i++) {                    // threads as (row in work-array tile, channel): contiguous stores
+        const int e = tid + 256 * i;
+        const int rl = (e & 15) + 16 * (e >> 10), cl = (e >> 4) & 63;
         const int ch = c0 + cl;
         const int64_t r = r0 + rl;
         if (ch < C && r < nj) {
-            B.w_dem[r * CP + ch] = tile[cl][rl];
-            if (want_iq) B.w_iq[r * CP + ch] = tileIQ[cl][rl];
+            B.w_dem[widx(r, ch, CP)] = tile[cl][rl];
+            if (want_iq) B.w_iq[widx(r, ch, CP)] = tileIQ[cl][rl];
         }
     }
 }
@@ -192,7 +193,70 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
 // Batch size of the register-prefetched work-array rows.  A wave can have at most 63 vector-memory operations in flight
 // (6-bit vmcnt) and on gfx9 stores count too: the loads of the next batch are issued right behind the stores of the
 // last one, so (loads + stores) per batch must stay below that or every batch stalls for a store round trip.
-constexpr int SEQ_UB = 16;
+constexpr int SEQ_UB = WT;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// one work-array tile of this lane's channel (16 consecutive rows, 64 or 128 contiguous bytes) <-> registers
+__device__ __forceinline__ void wld(float x[WT], const float *tile) {
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(tile);
+#pragma unroll
+    for (int i = 0; i < WT / 4; i++) {
+        const f32x4 v = q[i];
+        x[4 * i] = v[0]; x[4 * i + 1] = v[1]; x[4 * i + 2] = v[2]; x[4 * i + 3] = v[3];
+    }
+}
+__device__ __forceinline__ void wld(int x[WT], const int *tile) {
+    const i32x4 *q = reinterpret_cast<const i32x4 *>(tile);
+#pragma unroll
+    for (int i = 0; i < WT / 4; i++) {
+        const i32x4 v = q[i];
+        x[4 * i] = v[0]; x[4 * i + 1] = v[1]; x[4 * i + 2] = v[2]; x[4 * i + 3] = v[3];
+    }
+}
+__device__ __forceinline__ void wst(float *tile, const float x[WT]) {
+    f32x4 *q = reinterpret_cast<f32x4 *>(tile);
+#pragma unroll
+    for (int i = 0; i < WT / 4; i++) { f32x4 v; v[0] = x[4 * i]; v[1] = x[4 * i + 1]; v[2] = x[4 * i + 2]; v[3] = x[4 * i + 3]; q[i] = v; }
+}
+__device__ __forceinline__ void wst(int *tile, const int x[WT]) {
+    i32x4 *q = reinterpret_cast<i32x4 *>(tile);
+#pragma unroll
+    for (int i = 0; i < WT / 4; i++) { i32x4 v; v[0] = x[4 * i]; v[1] = x[4 * i + 1]; v[2] = x[4 * i + 2]; v[3] = x[4 * i + 3]; q[i] = v; }
+}
+__device__ __forceinline__ void wld2(float2 x[WT], const float2 *tile) {
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(tile);
+#pragma unroll
+    for (int i = 0; i < WT / 2; i++) { const f32x4 v = q[i]; x[2 * i] = make_float2(v[0], v[1]); x[2 * i + 1] = make_float2(v[2], v[3]); }
+}
+__device__ __forceinline__ void wst2(float2 *tile, const float2 x[WT]) {
+    f32x4 *q = reinterpret_cast<f32x4 *>(tile);
+#pragma unroll
+    for (int i = 0; i < WT / 2; i++) { f32x4 v; v[0] = x[2 * i].x; v[1] = x[2 * i].y; v[2] = x[2 * i + 1].x; v[3] = x[2 * i + 1].y; q[i] = v; }
+}
+// Software pipeline over the `nfull` whole tiles of a chunk.  A work-array tile written by the previous kernel comes
+// from HBM / Infinity Cache with ~1.4 us latency and a recurrence wave has nothing else to run meanwhile, so the loads
+// run far ahead of the compute: two register sets of PD tiles each, set B's loads are all issued before set A's 64
+// samples are consumed and vice versa (block form rather than a rotating window: the compiler's s_waitcnt placement
+// then leaves the full distance).  `load(set, u, tile)` fills registers, `body(set, u, tile)` consumes them; set and u
+// are compile-time after unrolling.  Loads are clamped, never conditional.
+constexpr int PD = 4;
+template <typename LoadF, typename BodyF>
+__device__ __forceinline__ void tile_pipeline(int nfull, LoadF load, BodyF body) {
+    if (nfull <= 0) return;
+    const int nlast = nfull - 1;
+#pragma unroll
+    for (int u = 0; u < PD; u++) load(0, u, u < nlast ? u : nlast);
+    for (int b0 = 0; b0 < nfull; b0 += 2 * PD) {
+#pragma unroll
+        for (int u = 0; u < PD; u++) load(1, u, (b0 + PD + u < nlast) ? b0 + PD + u : nlast);
+#pragma unroll
+        for (int u = 0; u < PD; u++) if (b0 + u < nfull) body(0, u, b0 + u);
+#pragma unroll
+        for (int u = 0; u < PD; u++) load(0, u, (b0 + 2 * PD + u < nlast) ? b0 + 2 * PD + u : nlast);
+#pragma unroll
+        for (int u = 0; u < PD; u++) if (b0 + PD + u < nfull) body(1, u, b0 + PD + u);
+    }
+}
 
 // ---- B2
 template <bool PLLDEC>
@@ -206,7 +270,7 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
     const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha, K = T.K_FM, rK = T.K_FM_rcp;
     const double SC = T.sincos_C;
     float afc = st->fm_afc, nco_phase = st->nco_phase, incr = st->phase_incr;
-    const int64_t ro = rc0 * (int64_t)CP + ch;
+    const size_t ro = widx(rc0, ch, CP);              // rc0 is a multiple of the tile height
     float *wd = B.w_dem + ro;
     const float2 *wiq = PLLDEC ? B.w_iq + ro : nullptr;
     auto step = [&](float res, float2 sig) -> float {
@@ -229,29 +293,22 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
     };
     constexpr int UB = SEQ_UB;
     const int nfull = chunk_len / UB;
-    float nx[UB]; float2 nq[UB];
-    if (nfull > 0) {
+    const int TS = UB * CP;                                       // elements from one tile of this channel to the next
+    float nx[2][PD][UB]; float2 nq[PLLDEC ? 2 : 1][PLLDEC ? PD : 1][UB];
+    tile_pipeline(nfull,
+        [&](int s, int u, int tl) { wld(nx[s][u], wd + tl * TS); if (PLLDEC) wld2(nq[PLLDEC ? s : 0][PLLDEC ? u : 0], wiq + tl * TS); },
+        [&](int s, int u, int tb) {
+            float x[UB]; float2 xq[UB];
 #pragma unroll
-        for (int k = 0; k < UB; k++) { nx[k] = wd[k * CP]; if (PLLDEC) nq[k] = wiq[k * CP]; }
-    }
-    for (int b = 0; b < nfull; b++) {
-        float x[UB]; float2 xq[UB];
+            for (int k = 0; k < UB; k++) { x[k] = nx[s][u][k]; xq[k] = PLLDEC ? nq[PLLDEC ? s : 0][PLLDEC ? u : 0][k] : make_float2(0.f, 0.f); }
 #pragma unroll
-        for (int k = 0; k < UB; k++) { x[k] = nx[k]; xq[k] = PLLDEC ? nq[k] : make_float2(0.f, 0.f); }
-        const int nb = (b + 1 < nfull) ? UB * CP : 0;             // the last prefetch re-reads this batch
-#pragma unroll
-        for (int k = 0; k < UB; k++) { nx[k] = wd[nb + k * CP]; if (PLLDEC) nq[k] = wiq[nb + k * CP]; }
-#pragma unroll
-        for (int k = 0; k < UB; k++) x[k] = step(x[k], xq[k]);
-#pragma unroll
-        for (int k = 0; k < UB; k++) wd[k * CP] = x[k];
-        wd += UB * CP;
-        if (PLLDEC) wiq += UB * CP;
-    }
-    for (int r = nfull * UB; r < chunk_len; r++) {
-        wd[0] = step(wd[0], PLLDEC ? wiq[0] : make_float2(0.f, 0.f));
-        wd += CP;
-        if (PLLDEC) wiq += CP;
+            for (int k = 0; k < UB; k++) x[k] = step(x[k], xq[k]);
+            wst(wd + tb * TS, x);
+        });
+    {
+        float *wdt = wd + nfull * TS; const float2 *wiqt = PLLDEC ? wiq + nfull * TS : nullptr;
+        for (int k = 0; k < chunk_len - nfull * UB; k++)          // ragged end of a call: rows of the last, partial tile
+            wdt[k] = step(wdt[k], PLLDEC ? wiqt[k] : make_float2(0.f, 0.f));
     }
     st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr;
 }
@@ -287,7 +344,7 @@ __global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B
     const float P32 = 6.2831855f, C32 = T.wrap32_c;              // fl32 just above 2 pi; fl32(P32 - 2 pi)
     float phase = st->pil_phase;
     if (!(phase >= 0.f)) phase = pi_constrain(phase);             // cannot happen (see above); keeps the invariant anyway
-    const int64_t ro = rc0 * (int64_t)CP + ch;
+    const size_t ro = widx(rc0, ch, CP);
     const float *wd = B.w_dem + ro; float *wc = B.w_cur + ro; float *wo = B.w_osc + ro;
     auto step = [&](float demod, float &o_cur, float &o_osc) {
         // SinCos::getSin sincos.cpp:81-85 with phase >= 0
@@ -309,29 +366,22 @@ __global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B
         o_osc = osc;
     };
     const int nfull = chunk_len / SEQ_UB;
-    float nx[SEQ_UB];
-    if (nfull > 0) {
+    const int TS = SEQ_UB * CP;
+    float nx[2][PD][SEQ_UB];
+    tile_pipeline(nfull,
+        [&](int s, int u, int tl) { wld(nx[s][u], wd + tl * TS); },
+        [&](int s, int u, int tb) {
+            float x[SEQ_UB], oc[SEQ_UB], oo[SEQ_UB];
 #pragma unroll
-        for (int k = 0; k < SEQ_UB; k++) nx[k] = wd[k * CP];
-    }
-    for (int b = 0; b < nfull; b++) {
-        float x[SEQ_UB], oc[SEQ_UB], oo[SEQ_UB];
+            for (int k = 0; k < SEQ_UB; k++) x[k] = nx[s][u][k];
 #pragma unroll
-        for (int k = 0; k < SEQ_UB; k++) x[k] = nx[k];
-        const int nb = (b + 1 < nfull) ? SEQ_UB * CP : 0;
-#pragma unroll
-        for (int k = 0; k < SEQ_UB; k++) nx[k] = wd[nb + k * CP];
-#pragma unroll
-        for (int k = 0; k < SEQ_UB; k++) step(x[k], oc[k], oo[k]);
-#pragma unroll
-        for (int k = 0; k < SEQ_UB; k++) { wc[k * CP] = oc[k]; wo[k * CP] = oo[k]; }
-        wd += SEQ_UB * CP; wc += SEQ_UB * CP; wo += SEQ_UB * CP;
-    }
-    for (int r = nfull * SEQ_UB; r < chunk_len; r++) {
+            for (int k = 0; k < SEQ_UB; k++) step(x[k], oc[k], oo[k]);
+            wst(wc + tb * TS, oc); wst(wo + tb * TS, oo);
+        });
+    for (int k = 0; k < chunk_len - nfull * SEQ_UB; k++) {
         float oc, oo;
-        step(wd[0], oc, oo);
-        wc[0] = oc; wo[0] = oo;
-        wd += CP; wc += CP; wo += CP;
+        step(wd[nfull * TS + k], oc, oo);
+        wc[nfull * TS + k] = oc; wo[nfull * TS + k] = oo;
     }
     st->pil_phase = phase;
 }
@@ -351,7 +401,7 @@ __global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers 
     float lock = st->pil_lock, old = st->pil_old;
     int stable = st->pil_stable, locked = st->pil_locked;
     int tagn = (rc0 == 0) ? 0 : st->pss_call_total;
-    const int64_t ro = rc0 * (int64_t)CP + ch;
+    const size_t ro = widx(rc0, ch, CP);
     const float *wd = B.w_dem + ro, *wo = B.w_osc + ro;
     int *wt = B.w_tag + ro;                        // packed: ((tag + 2) << 1) | locked
     auto step = [&](float demod, float osc, int &o_lk, int &o_tag) {
@@ -375,63 +425,57 @@ __global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers 
     // machine has a closed form.  Anything else (a wave-uniform decision) replays the block sample by sample.
     constexpr int UB = SEQ_UB;
     const int nfull = chunk_len / UB;
-    float nd[UB], no[UB];
-    if (nfull > 0) {
+    const int TS = UB * CP;
+    float nd[2][PD][UB], no[2][PD][UB];
+    tile_pipeline(nfull,
+        [&](int s, int u, int tl) { wld(nd[s][u], wd + tl * TS); wld(no[s][u], wo + tl * TS); },
+        [&](int s, int u, int tb) {
+            float d[UB], o[UB]; int pk[UB];
 #pragma unroll
-        for (int k = 0; k < UB; k++) { nd[k] = wd[k * CP]; no[k] = wo[k * CP]; }
-    }
-    for (int b = 0; b < nfull; b++) {
-        float d[UB], o[UB]; int pk[UB];
+            for (int k = 0; k < UB; k++) { d[k] = nd[s][u][k]; o[k] = no[s][u][k]; }
+            const float lock0 = lock, old0 = old;
+            bool all_hi = true, all_lo = true;
 #pragma unroll
-        for (int k = 0; k < UB; k++) { d[k] = nd[k]; o[k] = no[k]; }
-        const int nb = (b + 1 < nfull) ? UB * CP : 0;
-#pragma unroll
-        for (int k = 0; k < UB; k++) { nd[k] = wd[nb + k * CP]; no[k] = wo[nb + k * CP]; }
-        const float lock0 = lock, old0 = old;
-        bool all_hi = true, all_lo = true;
-#pragma unroll
-        for (int k = 0; k < UB; k++) {
-            const float quadRef = fdiv_const(o[k] - old, omega, romega);
-            old = o[k];
-            lock = (float)((double)(lockA * (-quadRef * (5 * d[k]))) + (double)lock * keep);
-            const bool tmp = lock > 0.07f;
-            all_hi = all_hi && tmp; all_lo = all_lo && !tmp;
-        }
-        // closed forms:  all_hi & locked -> unchanged;  all_hi & !locked & stable + UB <= N/2 -> stable += UB;
-        //                all_lo -> locked = 0, stable = 0
-        const bool easy = all_lo || (all_hi && (locked != 0 || stable + UB <= (SINCOS_N >> 1)));
-        const bool fast = __all(easy) != 0;
-        if (B.dbg && threadIdx.x == 0) B.dbg[(size_t)ch * 16 + (fast ? 11 : 12)] += 1;
-        if (fast) {
-            if (all_lo) { locked = 0; stable = 0; }
-            else if (!locked) stable += UB;
-            const bool branch = stereo_possible && (locked || !auto_mono);
-            const bool counts = branch && pss_active;
-            const int base = branch ? (pss_active ? tagn : -1) : -2;
-            const int inc = counts ? 1 : 0;
-#pragma unroll
-            for (int k = 0; k < UB; k++) pk[k] = ((base + inc * k + 2) << 1) | locked;
-            tagn += inc * UB;
-#pragma unroll
-            for (int k = 0; k < UB; k++) wt[k * CP] = pk[k];
-        } else {
-            // rare (lock acquisition / loss): replay the block from memory in a rolled loop, so that the fast path's
-            // register arrays are never indexed dynamically
-            lock = lock0; old = old0;
-#pragma unroll 1
             for (int k = 0; k < UB; k++) {
-                int lk, tg;
-                step(wd[k * CP], wo[k * CP], lk, tg);
-                wt[k * CP] = ((tg + 2) << 1) | lk;
+                const float quadRef = fdiv_const(o[k] - old, omega, romega);
+                old = o[k];
+                lock = (float)((double)(lockA * (-quadRef * (5 * d[k]))) + (double)lock * keep);
+                const bool tmp = lock > 0.07f;
+                all_hi = all_hi && tmp; all_lo = all_lo && !tmp;
             }
-        }
-        wd += UB * CP; wo += UB * CP; wt += UB * CP;
-    }
-    for (int r = nfull * UB; r < chunk_len; r++) {
+            // closed forms:  all_hi & locked -> unchanged;  all_hi & !locked & stable + UB <= N/2 -> stable += UB;
+            //                all_lo -> locked = 0, stable = 0
+            const bool easy = all_lo || (all_hi && (locked != 0 || stable + UB <= (SINCOS_N >> 1)));
+            const bool fast = __all(easy) != 0;
+            if (B.dbg && threadIdx.x == 0) B.dbg[(size_t)ch * 16 + (fast ? 11 : 12)] += 1;
+            if (fast) {
+                if (all_lo) { locked = 0; stable = 0; }
+                else if (!locked) stable += UB;
+                const bool branch = stereo_possible && (locked || !auto_mono);
+                const bool counts = branch && pss_active;
+                const int base = branch ? (pss_active ? tagn : -1) : -2;
+                const int inc = counts ? 1 : 0;
+#pragma unroll
+                for (int k = 0; k < UB; k++) pk[k] = ((base + inc * k + 2) << 1) | locked;
+                tagn += inc * UB;
+                wst(wt + tb * TS, pk);
+            } else {
+                // rare (lock acquisition / loss): replay the block from memory in a rolled loop, so that the fast path's
+                // register arrays are never indexed dynamically
+                lock = lock0; old = old0;
+                const float *wdr = wd + tb * TS, *wor = wo + tb * TS; int *wtr = wt + tb * TS;
+#pragma unroll 1
+                for (int k = 0; k < UB; k++) {
+                    int lk, tg;
+                    step(wdr[k], wor[k], lk, tg);
+                    wtr[k] = ((tg + 2) << 1) | lk;
+                }
+            }
+        });
+    for (int k = 0; k < chunk_len - nfull * UB; k++) {
         int lk, tg;
-        step(wd[0], wo[0], lk, tg);
-        wt[0] = ((tg + 2) << 1) | lk;
-        wd += CP; wo += CP; wt += CP;
+        step(wd[nfull * TS + k], wo[nfull * TS + k], lk, tg);
+        wt[nfull * TS + k] = ((tg + 2) << 1) | lk;
     }
     st->pil_lock = lock; st->pil_old = old; st->pil_stable = stable; st->pil_locked = locked;
     st->pss_call_total = tagn;
@@ -457,7 +501,7 @@ __global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffe
     int tmin = 0x7fffffff;
     for (int m = 0; m < 4; m++) {
         const int q = q0 + lane + 64 * m;
-        const int tg = (q < chunk_len) ? (B.w_tag[(rc0 + q) * CP + ch] >> 1) - 2 : -2;
+        const int tg = (q < chunk_len) ? (B.w_tag[widx(rc0 + q, ch, (int)CP)] >> 1) - 2 : -2;
         sTag[lane + 64 * m] = tg;
         if (tg >= 0) tmin = tg < tmin ? tg : tmin;
     }
@@ -486,7 +530,7 @@ __global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffe
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         const int q = q0 + lane + 64 * m;
-        if (q < chunk_len) B.w_err[(size_t)q * CP + ch] = ar[m] * ai[m];
+        if (q < chunk_len) B.w_err[widx(q, ch, (int)CP)] = ar[m] * ai[m];
     }
 }
 
@@ -534,9 +578,9 @@ __global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffe
         s.pdp = 0.f; s.acc = 0.f; s.minimized = false; s.mean = 0.f; s.lock_cnt = 0; s.unlock_cnt = 0;
         if (P.actions & ACT_TRIGGER_FREQ) st->fade_start_frame = G.M0;
     }
-    const int *tg = B.w_tag + ch + rc0 * (int64_t)CP;         // packed ((tag + 2) << 1) | locked
-    const float *err = B.w_err + ch;
-    float *pdpw = B.w_pdp + ch + rc0 * (int64_t)CP;
+    const int *tg = B.w_tag + widx(rc0, ch, CP);              // packed ((tag + 2) << 1) | locked
+    const float *err = B.w_err + widx(0, ch, CP);
+    float *pdpw = B.w_pdp + widx(rc0, ch, CP);
     const float alpha = T.pss_alpha, la = T.pss_lock_alpha, keep = 1.0f - la;
     const bool pss_on = (P.fm_mode != 2) && (P.pss_active != 0);
     // Fast paths per block of ACC_UB samples (wave-uniform decisions, identical arithmetic):
@@ -545,72 +589,66 @@ __global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffe
     //    recurrences run alone (`small` is collected as a bit per sample) and the counters follow in closed form;
     //  * idle: nobody locked, nobody calling (mono or no pilot with autoMono): the state is all zeros.
     const int nfull = chunk_len / ACC_UB;
-    int nt[ACC_UB]; float ne[ACC_UB];
-    if (nfull > 0) {
-#pragma unroll
-        for (int k = 0; k < ACC_UB; k++) { nt[k] = tg[k * CP]; ne[k] = err[k * CP]; }
-    }
+    const int TS = ACC_UB * CP;
+    int nt[2][PD][ACC_UB]; float ne[2][PD][ACC_UB];
     const float c4 = 0.785398185253143310546875f;
-    for (int b = 0; b < nfull; b++) {
-        float e[ACC_UB]; float o[ACC_UB];
-        unsigned andv = ~0u, orv = 0u; int minv = 0x7fffffff;
-#pragma unroll
-        for (int k = 0; k < ACC_UB; k++) {
-            e[k] = pss_on ? ne[k] : 0.f;
-            andv &= (unsigned)nt[k]; orv |= (unsigned)nt[k]; minv = nt[k] < minv ? nt[k] : minv;
-        }
-        const int nb = (b + 1 < nfull) ? ACC_UB * CP : 0;
-#pragma unroll
-        for (int k = 0; k < ACC_UB; k++) { nt[k] = tg[nb + k * CP]; ne[k] = err[nb + k * CP]; }
-        // (only the counter that can flip `minimized` matters: lock_cnt while it is 0, unlock_cnt while it is 1)
-        const bool steady = ((andv & 1u) != 0) && (minv >= 4) &&                 // locked, tag >= 0 throughout
-                            ((s.minimized ? s.unlock_cnt : s.lock_cnt) + ACC_UB <= 3 * SINCOS_N);
-        const bool idle = (orv & ~2u) == 0;                                      // unlocked, tag < 0 throughout
-        const bool f_steady = __all(steady) != 0, f_idle = __all(idle) != 0;
-        if (B.dbg && threadIdx.x == 0) B.dbg[(size_t)ch * 16 + (f_steady ? 8 : (f_idle ? 9 : 10))] += 1;
-        if (f_steady) {
-            const float scale = s.minimized ? 1.0f : 10.0f;                      // error = minimized ? err : err * 10
-            constexpr unsigned ALL = (ACC_UB == 32) ? ~0u : ((1u << (ACC_UB & 31)) - 1u);
-            unsigned bits = 0;
-            float prev = s.pdp;
+    tile_pipeline(nfull,
+        [&](int g, int u, int tl) { wld(nt[g][u], tg + tl * TS); wld(ne[g][u], err + tl * TS); },
+        [&](int g, int u, int tb) {
+            float e[ACC_UB]; float o[ACC_UB];
+            unsigned andv = ~0u, orv = 0u; int minv = 0x7fffffff;
 #pragma unroll
             for (int k = 0; k < ACC_UB; k++) {
-                o[k] = prev;
-                const float error = e[k] * scale;
-                s.acc = __builtin_amdgcn_fmed3f(s.acc + alpha * error, -c4, c4);
-                s.mean = la * error + s.mean * keep;
-                bits = (bits << 1) | (fabsf(s.mean) < 0.001f ? 1u : 0u);
-                prev = s.acc;
+                e[k] = pss_on ? ne[g][u][k] : 0.f;
+                andv &= (unsigned)nt[g][u][k]; orv |= (unsigned)nt[g][u][k]; minv = nt[g][u][k] < minv ? nt[g][u][k] : minv;
             }
-            s.pdp = s.acc;
-            if (s.minimized) {
-                s.lock_cnt = (bits == ALL) ? s.lock_cnt : 0;
-                s.unlock_cnt = (bits == 0u) ? s.unlock_cnt + ACC_UB : __builtin_ctz(bits);
+            // (only the counter that can flip `minimized` matters: lock_cnt while it is 0, unlock_cnt while it is 1)
+            const bool steady = ((andv & 1u) != 0) && (minv >= 4) &&                 // locked, tag >= 0 throughout
+                                ((s.minimized ? s.unlock_cnt : s.lock_cnt) + ACC_UB <= 3 * SINCOS_N);
+            const bool idle = (orv & ~2u) == 0;                                      // unlocked, tag < 0 throughout
+            const bool f_steady = __all(steady) != 0, f_idle = __all(idle) != 0;
+            if (B.dbg && threadIdx.x == 0) B.dbg[(size_t)ch * 16 + (f_steady ? 8 : (f_idle ? 9 : 10))] += 1;
+            if (f_steady) {
+                const float scale = s.minimized ? 1.0f : 10.0f;                      // error = minimized ? err : err * 10
+                constexpr unsigned ALL = (ACC_UB == 32) ? ~0u : ((1u << (ACC_UB & 31)) - 1u);
+                unsigned bits = 0;
+                float prev = s.pdp;
+#pragma unroll
+                for (int k = 0; k < ACC_UB; k++) {
+                    o[k] = prev;
+                    const float error = e[k] * scale;
+                    s.acc = __builtin_amdgcn_fmed3f(s.acc + alpha * error, -c4, c4);
+                    s.mean = la * error + s.mean * keep;
+                    bits = (bits << 1) | (fabsf(s.mean) < 0.001f ? 1u : 0u);
+                    prev = s.acc;
+                }
+                s.pdp = s.acc;
+                if (s.minimized) {
+                    s.lock_cnt = (bits == ALL) ? s.lock_cnt : 0;
+                    s.unlock_cnt = (bits == 0u) ? s.unlock_cnt + ACC_UB : __builtin_ctz(bits);
+                } else {
+                    s.lock_cnt = (bits == ALL) ? s.lock_cnt + ACC_UB : __builtin_ctz(~bits);
+                    s.unlock_cnt = (bits != 0u) ? 0 : s.unlock_cnt;
+                }
+                wst(pdpw + tb * TS, o);
+            } else if (f_idle) {
+                s.pdp = 0.f; s.acc = 0.f; s.mean = 0.f; s.minimized = false; s.lock_cnt = 0; s.unlock_cnt = 0;
+#pragma unroll
+                for (int k = 0; k < ACC_UB; k++) o[k] = 0.f;
+                wst(pdpw + tb * TS, o);
             } else {
-                s.lock_cnt = (bits == ALL) ? s.lock_cnt + ACC_UB : __builtin_ctz(~bits);
-                s.unlock_cnt = (bits != 0u) ? 0 : s.unlock_cnt;
-            }
-        } else if (f_idle) {
-            s.pdp = 0.f; s.acc = 0.f; s.mean = 0.f; s.minimized = false; s.lock_cnt = 0; s.unlock_cnt = 0;
-#pragma unroll
-            for (int k = 0; k < ACC_UB; k++) o[k] = 0.f;
-        } else {
-            // rare (lock transitions, a counter near its threshold, mixed modes in one wave): rolled replay from memory
+                // rare (lock transitions, a counter near its threshold, mixed modes in one wave): rolled replay from memory
+                const int *tgr = tg + tb * TS; const float *errr = err + tb * TS; float *pr = pdpw + tb * TS;
 #pragma unroll 1
-            for (int k = 0; k < ACC_UB; k++) {
-                const int p = tg[k * CP];
-                pdpw[k * CP] = pss_acc_step(s, alpha, la, keep, (p & 1) != 0, (p >> 1) - 2, pss_on ? err[k * CP] : 0.f);
+                for (int k = 0; k < ACC_UB; k++) {
+                    const int p = tgr[k];
+                    pr[k] = pss_acc_step(s, alpha, la, keep, (p & 1) != 0, (p >> 1) - 2, pss_on ? errr[k] : 0.f);
+                }
             }
-            tg += ACC_UB * CP; err += ACC_UB * CP; pdpw += ACC_UB * CP;
-            continue;
-        }
-#pragma unroll
-        for (int k = 0; k < ACC_UB; k++) pdpw[k * CP] = o[k];
-        tg += ACC_UB * CP; err += ACC_UB * CP; pdpw += ACC_UB * CP;
-    }
-    for (int q = nfull * ACC_UB; q < chunk_len; q++) {
-        pdpw[0] = pss_acc_step(s, alpha, la, keep, (tg[0] & 1) != 0, (tg[0] >> 1) - 2, pss_on ? err[0] : 0.f);
-        tg += CP; err += CP; pdpw += CP;
+        });
+    for (int k = 0; k < chunk_len - nfull * ACC_UB; k++) {
+        const int p = tg[nfull * TS + k];
+        pdpw[nfull * TS + k] = pss_acc_step(s, alpha, la, keep, (p & 1) != 0, (p >> 1) - 2, pss_on ? err[nfull * TS + k] : 0.f);
     }
     st->pss_acc = s.acc; st->pss_mean = s.mean; st->pilot_delay_pss = s.pdp;
     st->pss_lock_cnt = s.lock_cnt; st->pss_unlock_cnt = s.unlock_cnt; st->pss_minimized = s.minimized ? 1 : 0;
@@ -631,19 +669,21 @@ __global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuff
     const int ring = G.ring_mask + 1;
     const float2 *__restrict__ sct = T.sincos;
     const double SC = T.sincos_C;
-    // pass 1: threads along channels (coalesced reads of the sample-major work arrays)
+    // pass 1: threads as (row in work-array tile, channel): contiguous reads and writes of the tiled work arrays
     for (int i = 0; i < 16; i++) {
-        const int ql = (tid >> 6) + 4 * i, cl = tid & 63;
+        const int e = tid + 256 * i;
+        const int ql = (e & 15) + 16 * (e >> 10), cl = (e >> 4) & 63;
         const int ch = c0 + cl, q = q0 + ql;
         if (ch < C && q < chunk_len) {
             const int64_t r = rc0 + q;
             const ChanParams &P = B.params[ch];
-            const float demod = B.w_dem[r * CP + ch];
-            const int tag = (B.w_tag[r * CP + ch] >> 1) - 2;
+            const size_t wi = widx(r, ch, (int)CP);
+            const float demod = B.w_dem[wi];
+            const int tag = (B.w_tag[wi] >> 1) - 2;
             float2 audio = make_float2(demod, 0.f);
             if (tag != -2) {
                 // phaseforLRDiff fm-processor.cpp:707-714
-                float ph = (float)(2 * ((double)pi_constrain(B.w_cur[r * CP + ch]) + FMX_PI_4 + 0) - (double)B.w_pdp[r * CP + ch]);
+                float ph = (float)(2 * ((double)pi_constrain(B.w_cur[wi]) + FMX_PI_4 + 0) - (double)B.w_pdp[wi]);
                 if ((double)ph < -FMX_2PI) ph = (float)((double)ph + 2 * FMX_2PI);
                 ph = (float)fmod_2pi((double)ph);
                 const float2 e = sct[sc_index(sc_wrap(ph), SC)];
@@ -667,7 +707,7 @@ __global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuff
             case 4: o = make_float2(sumLR, sumLR); break;
             case 5: case 6: o = make_float2(dw, dw); break;
             }
-            B.w_x[r * CP + ch] = o;
+            B.w_x[wi] = o;
             tLR[cl][ql] = audio; tDEM[cl][ql] = demod;
         }
     }
@@ -697,37 +737,30 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
     const ChanParams &P = B.params[ch];
     const float a = P.deemph_alpha;
     float yl = st->de_l, yr = st->de_r;
-    float2 *x = B.w_x + rc0 * (int64_t)CP + ch;
+    float2 *x = B.w_x + widx(rc0, ch, CP);
     constexpr int UB = SEQ_UB;
-    const int64_t nfull = nj / UB;
-    float2 nx[UB];
-    if (nfull > 0) {
+    const int nfull = (int)(nj / UB);
+    const int TS = UB * CP;
+    float2 nx[2][PD][UB];
+    tile_pipeline(nfull,
+        [&](int s, int u, int tl) { wld2(nx[s][u], x + tl * TS); },
+        [&](int s, int u, int tb) {
+            float2 v[UB];
 #pragma unroll
-        for (int k = 0; k < UB; k++) nx[k] = x[k * CP];
-    }
-    for (int64_t b = 0; b < nfull; b++) {
-        float2 v[UB];
+            for (int k = 0; k < UB; k++) v[k] = nx[s][u][k];
 #pragma unroll
-        for (int k = 0; k < UB; k++) v[k] = nx[k];
-        const int nb = (b + 1 < nfull) ? UB * CP : 0;
-#pragma unroll
-        for (int k = 0; k < UB; k++) nx[k] = x[nb + k * CP];
-#pragma unroll
-        for (int k = 0; k < UB; k++) {
-            yl = (v[k].x - yl) * a + yl;
-            yr = (v[k].y - yr) * a + yr;
-            v[k] = make_float2(yl, yr);
-        }
-#pragma unroll
-        for (int k = 0; k < UB; k++) x[k * CP] = v[k];
-        x += UB * CP;
-    }
-    for (int64_t r = nfull * UB; r < nj; r++) {
-        const float2 v = x[0];
+            for (int k = 0; k < UB; k++) {
+                yl = (v[k].x - yl) * a + yl;
+                yr = (v[k].y - yr) * a + yr;
+                v[k] = make_float2(yl, yr);
+            }
+            wst2(x + tb * TS, v);
+        });
+    for (int k = 0; k < (int)(nj - (int64_t)nfull * UB); k++) {
+        const float2 v = x[nfull * TS + k];
         yl = (v.x - yl) * a + yl;
         yr = (v.y - yr) * a + yr;
-        x[0] = make_float2(yl, yr);
-        x += CP;
+        x[nfull * TS + k] = make_float2(yl, yr);
     }
     st->de_l = yl; st->de_r = yr;
     if (!last_chunk) return;
@@ -762,10 +795,11 @@ __global__ __launch_bounds__(256) void dring_kernel(DeviceBuffers B, CallGeom G,
     const int64_t nj = G.J1 - G.J0;
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
-    for (int i = 0; i < 16; i++) {
-        const int rl = (tid >> 6) + 4 * i, cl = tid & 63;
+    for (int i = 0; i < 16; i++) {                    // threads as (row in work-array tile, channel): contiguous reads
+        const int e = tid + 256 * i;
+        const int rl = (e & 15) + 16 * (e >> 10), cl = (e >> 4) & 63;
         const int ch = c0 + cl; const int64_t r = r0 + rl;
-        if (ch < C && r < nj) tile[cl][rl] = B.w_x[r * CP + ch];
+        if (ch < C && r < nj) tile[cl][rl] = B.w_x[widx(r, ch, (int)CP)];
     }
     __syncthreads();
     const int dcap = G.dring_mask + 1;

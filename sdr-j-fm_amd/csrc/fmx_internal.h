@@ -14,7 +14,7 @@ constexpr int A_TAPS_ROW = 32;         // device image Trd[r][d] (d contiguous, 
 constexpr int A_TAPS_DEV = DECIM * A_TAPS_ROW;
 constexpr int PSS_TAPS = 295;          // stereo-separation.cpp:31
 constexpr int PSS_DELAY = 2048 - 295;  // overlap-add latency fftSize - degree (fft-filters.cpp:34)
-constexpr int PSS_CHUNK = 1753;        // PSS feedback lag: the only chunked part of stage B (<= PSS_DELAY)
+constexpr int PSS_CHUNK = 1744;        // <= PSS_DELAY and a multiple of the work-array tile (16 rows)        // PSS feedback lag: the only chunked part of stage B (<= PSS_DELAY)
 constexpr int RS_TAPS = 128;           // fmx resampler (oracle/fm_oracle.c fmo_resampler_taps)
 constexpr int AUDIO_TAPS = 756;        // fm-processor.cpp:76
 constexpr int AUDIO_DELAY = 8192 - 756;
@@ -81,6 +81,15 @@ struct ChanState {
     float   meta_dc_rf, meta_dc_if, meta_pss_deg, meta_pss_change, meta_lock_strength;
     int32_t meta_pss_state, meta_locked;
 };
+
+// Work arrays of stage B (w_*): element (row r, channel ch) lives at ((r / 16) * pitch + ch) * 16 + r % 16 -- tiles of 16
+// consecutive fm samples per channel.  A lane-per-channel recurrence kernel moves its 16 samples with four dwordx4
+// operations (64 contiguous bytes per lane), a time-parallel kernel maps threads as (row-in-tile fastest, channel next)
+// and stays fully coalesced (1 KB contiguous per 64 channels).
+constexpr int WT = 16;
+__host__ __device__ __forceinline__ size_t widx(int64_t r, int ch, int pitch) {
+    return ((size_t)(r >> 4) * (size_t)pitch + (size_t)ch) * WT + (size_t)(r & 15);
+}
 
 struct DeviceTables {
     const float2 *sincos;        // [SINCOS_N] (cos, sin)
