@@ -139,6 +139,20 @@ int  fmx_process_host(fmx_handle h, const float *iq, int64_t stream_stride, int6
  * (a hipStream_t, NULL = the handle's own stream).  *n_frames is known on return. */
 int  fmx_process_device(fmx_handle h, const float *d_iq, int64_t stream_stride, int64_t n_complex,
                         float *d_pcm, int64_t pcm_stride, int64_t *n_frames, void *hip_stream);
+/* The same two calls for RAW device samples (the conversion the device handlers do on the host moves into
+ * the input-FIR kernel, so 2 or 4 bytes per complex sample cross PCIe / HBM instead of 8).  Interleaved (I,Q) pairs of
+ *   FMX_IQ_F32  float32, as above
+ *   FMX_IQ_U8   uint8,  value = (u8 - 127) / 128        rtlsdr-handler.cpp:291-292
+ *   FMX_IQ_S8   int8,   value = s8 / 128                hackrf-handler.cpp:364-365
+ *   FMX_IQ_S16  int16,  value = s16 / s16_denominator   lime-handler.cpp:250, pluto-handler.cpp:578,
+ *                                                       sdrplay-handler-v3.cpp:261 (2048 or 4096); 32768 for PCM16 files
+ * stream_stride stays in COMPLEX SAMPLES; s16_denominator must be a power of two (the division is then exact, as in the
+ * reference) and is ignored for the other formats. */
+typedef enum { FMX_IQ_F32 = 0, FMX_IQ_U8 = 1, FMX_IQ_S8 = 2, FMX_IQ_S16 = 3 } fmx_iq_format;
+int  fmx_process_host_raw(fmx_handle h, const void *iq, int32_t format, float s16_denominator, int64_t stream_stride,
+                          int64_t n_complex, float *pcm, int64_t pcm_stride, int64_t *n_frames);
+int  fmx_process_device_raw(fmx_handle h, const void *d_iq, int32_t format, float s16_denominator, int64_t stream_stride,
+                            int64_t n_complex, float *d_pcm, int64_t pcm_stride, int64_t *n_frames, void *hip_stream);
 int  fmx_synchronize(fmx_handle h);
 
 /* replaces the showMetaData signal payload / isPilotLocked / get_demodDcComponent */

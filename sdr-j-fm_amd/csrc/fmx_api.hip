@@ -323,8 +323,13 @@ void frames_geom(const fmx_handle h, int64_t n, CallGeom *G) {
     G->M0 = 48 * (G->J0 / 192); G->M1 = 48 * (G->J1 / 192);
 }
 
-int run_call(fmx_handle h, const float2 *d_iq, int64_t stream_stride, int64_t n, float2 *d_pcm,
+int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
              int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
+    if (fmt < 0 || fmt > 3) return fail(FMX_E_INVALID, "unknown IQ format");
+    if (fmt == 3) {
+        int ex = 0; const float m = std::frexp(s16_den, &ex);
+        if (!(s16_den >= 1.0f) || m != 0.5f) return fail(FMX_E_INVALID, "s16_denominator must be a power of two >= 1");
+    }
     if (n <= 0 || n > h->cfg.max_block) return fail(FMX_E_TOO_LARGE, "n_complex must be in [1, max_block]");
     int rc = flush_mailbox(h);
     if (rc) return rc;
@@ -332,6 +337,7 @@ int run_call(fmx_handle h, const float2 *d_iq, int64_t stream_stride, int64_t n,
     frames_geom(h, n, &G);
     G.ring_mask = h->ring - 1; G.dring_mask = h->dring - 1; G.sring_mask = h->sring - 1;
     G.input_rate = h->cfg.inputRate; G.pitch = h->pitch; G.pad_ = 0; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
+    G.iq_format = fmt; G.iq_scale = (fmt == 3) ? 1.0f / s16_den : 1.0f / 128.0f;
     const int64_t frames = G.M1 - G.M0;
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
     ProfRec pr{}; const bool prof = h->prof_on;
@@ -644,34 +650,41 @@ int64_t fmx_frames_for(fmx_handle h, int64_t n) {
     return G.M1 - G.M0;
 }
 
-int fmx_process_device(fmx_handle h, const float *d_iq, int64_t stream_stride, int64_t n, float *d_pcm,
-                       int64_t pcm_stride, int64_t *n_frames, void *hip_stream) {
+static int bytes_per_sample(int32_t fmt) { return fmt == FMX_IQ_F32 ? 8 : (fmt == FMX_IQ_S16 ? 4 : 2); }
+
+int fmx_process_device_raw(fmx_handle h, const void *d_iq, int32_t format, float s16_den, int64_t stream_stride, int64_t n,
+                           float *d_pcm, int64_t pcm_stride, int64_t *n_frames, void *hip_stream) {
     if (!h || !d_iq || !d_pcm) return fail(FMX_E_INVALID, "null argument");
     if (stream_stride < n) return fail(FMX_E_INVALID, "stream_stride < n_complex");
     HIPCHK(hipSetDevice(h->cfg.device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
-    return run_call(h, reinterpret_cast<const float2 *>(d_iq), stream_stride, n, reinterpret_cast<float2 *>(d_pcm),
-                    pcm_stride, n_frames, s);
+    return run_call(h, d_iq, format, s16_den, stream_stride, n, reinterpret_cast<float2 *>(d_pcm), pcm_stride, n_frames, s);
+}
+int fmx_process_device(fmx_handle h, const float *d_iq, int64_t stream_stride, int64_t n, float *d_pcm,
+                       int64_t pcm_stride, int64_t *n_frames, void *hip_stream) {
+    return fmx_process_device_raw(h, d_iq, FMX_IQ_F32, 0.f, stream_stride, n, d_pcm, pcm_stride, n_frames, hip_stream);
 }
 
-int fmx_process_host(fmx_handle h, const float *iq, int64_t stream_stride, int64_t n, float *pcm,
-                     int64_t pcm_stride, int64_t *n_frames) {
+int fmx_process_host_raw(fmx_handle h, const void *iq, int32_t format, float s16_den, int64_t stream_stride, int64_t n,
+                         float *pcm, int64_t pcm_stride, int64_t *n_frames) {
     if (!h || !iq || !pcm) return fail(FMX_E_INVALID, "null argument");
+    if (format < 0 || format > 3) return fail(FMX_E_INVALID, "unknown IQ format");
     if (stream_stride < n) return fail(FMX_E_INVALID, "stream_stride < n_complex");
     if (n <= 0 || n > h->cfg.max_block) return fail(FMX_E_TOO_LARGE, "n_complex must be in [1, max_block]");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int64_t cap = h->cfg.max_block / 48 + 96;
     if (!h->d_iq) {
-        HIPCHK(hipMalloc(&h->d_iq, sizeof(float2) * (size_t)h->streams * h->cfg.max_block));
+        HIPCHK(hipMalloc(&h->d_iq, sizeof(float2) * (size_t)h->streams * h->cfg.max_block));    // sized for the widest format
         HIPCHK(hipMalloc(&h->d_pcm, sizeof(float2) * (size_t)h->channels * cap));
         h->pcm_cap = cap;
     }
     const int64_t frames = fmx_frames_for(h, n);
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
-    HIPCHK(hipMemcpy2DAsync(h->d_iq, sizeof(float2) * h->cfg.max_block, iq, sizeof(float2) * stream_stride,
-                            sizeof(float2) * n, h->streams, hipMemcpyHostToDevice, h->stream));
+    const size_t bps = (size_t)bytes_per_sample(format);
+    HIPCHK(hipMemcpy2DAsync(h->d_iq, bps * h->cfg.max_block, iq, bps * stream_stride, bps * n, h->streams,
+                            hipMemcpyHostToDevice, h->stream));
     int64_t got = 0;
-    int rc = run_call(h, h->d_iq, h->cfg.max_block, n, h->d_pcm, cap, &got, h->stream);
+    int rc = run_call(h, h->d_iq, format, s16_den, h->cfg.max_block, n, h->d_pcm, cap, &got, h->stream);
     if (rc) return rc;
     if (got > 0)
         HIPCHK(hipMemcpy2DAsync(pcm, sizeof(float2) * pcm_stride, h->d_pcm, sizeof(float2) * cap, sizeof(float2) * got,
@@ -679,6 +692,10 @@ int fmx_process_host(fmx_handle h, const float *iq, int64_t stream_stride, int64
     HIPCHK(hipStreamSynchronize(h->stream));
     if (n_frames) *n_frames = got;
     return FMX_OK;
+}
+int fmx_process_host(fmx_handle h, const float *iq, int64_t stream_stride, int64_t n, float *pcm,
+                     int64_t pcm_stride, int64_t *n_frames) {
+    return fmx_process_host_raw(h, iq, FMX_IQ_F32, 0.f, stream_stride, n, pcm, pcm_stride, n_frames);
 }
 
 int fmx_synchronize(fmx_handle h) {

@@ -101,8 +101,13 @@ __device__ __forceinline__ void fir_rows(const float4 *__restrict__ X4, int cg, 
     }
 }
 
+// FMT: fmx_iq_format of the input (include/fmx.h).  Raw integer samples are converted while they are loaded --
+// (u8 - 127) / 128, s8 / 128, s16 / denominator, all exact as in the reference's device handlers
+// (rtlsdr-handler.cpp:291, hackrf-handler.cpp:364, lime-handler.cpp:250) -- into the same register layout.
+template <int FMT>
 __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
-                                                       const float2 *__restrict__ iq) {
+                                                       const void *__restrict__ iq_raw) {
+    constexpr int BPS = (FMT == 0) ? 8 : (FMT == 3 ? 4 : 2);          // bytes per complex sample
     __shared__ __attribute__((aligned(16))) float4 Xall[4][XUNITS];       // one image per wave (62208 B)
     __shared__ __attribute__((aligned(16))) float sT[A_TAPS_DEV];          // the channel's tap set Trd[r][d]
     __shared__ float carry[8][2];                                          // DC state after tile ti, slot = ti & 7
@@ -116,7 +121,9 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
     float2 *X2 = reinterpret_cast<float2 *>(X4);
     const ChanParams P = B.params[ch];
     const FrontSet FS = T.front_sets[P.front_set];
-    const float2 *__restrict__ in = iq + (size_t)P.stream * G.stream_stride;
+    const char *__restrict__ inb = reinterpret_cast<const char *>(iq_raw) + (size_t)P.stream * G.stream_stride * BPS;
+    const float2 *__restrict__ in = reinterpret_cast<const float2 *>(inb);       // FMT == 0
+    const float qs = G.iq_scale;
     ChanState *st = B.state + ch;
     float2 *hist = B.hist + (size_t)ch * DECIM * A_HIST_COLS;
     float2 *zring = B.zring + (size_t)ch * (G.ring_mask + 1);
@@ -156,8 +163,18 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
     const float alpha = 1.0f / (float)R;              // rfDcAlpha fm-processor.cpp:379
     const float Lg = P.att_l, Rg = P.att_r;
     const bool touch = dcr || mix || Lg != 1.0f || Rg != 1.0f;
+    // a lane's sample PAIR is one 16 / 4 / 8 byte load when the buffer is aligned that far
     const bool aligned16 = ((g0 & 1) == 0) && ((G.stream_stride & 1) == 0) &&
-                           ((reinterpret_cast<uintptr_t>(iq) & 15) == 0);
+                           ((reinterpret_cast<uintptr_t>(iq_raw) & (2 * BPS - 1)) == 0);
+    auto cvt1 = [&](int i) -> float2 {                            // one sample at buffer index i (call-relative)
+        if (FMT == 0) return in[i];
+        if (FMT == 1) { const uint8_t *p = reinterpret_cast<const uint8_t *>(inb) + 2 * (size_t)i;
+                        return make_float2((float)((int)p[0] - 127) * qs, (float)((int)p[1] - 127) * qs); }
+        if (FMT == 2) { const int8_t *p = reinterpret_cast<const int8_t *>(inb) + 2 * (size_t)i;
+                        return make_float2((float)p[0] * qs, (float)p[1] * qs); }
+        const int16_t *p = reinterpret_cast<const int16_t *>(inb) + 2 * (size_t)i;
+        return make_float2((float)p[0] * qs, (float)p[1] * qs);
+    };
     float u_full = 0.f;                               // u of a full 24-sample run (the same for every such lane)
     for (int k = 0; k < SPT; k++) u_full = (1.0f - u_full) * alpha + u_full;
     // Full tiles: every lane's run has the same u, so the scan of u is known in advance -- u_exc = u of `lane` runs,
@@ -201,15 +218,37 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
     auto load_tile = [&](int ti) {
         const int wbase = ti * WSAMP;                             // index of the tile's first sample
         if (aligned16 && wbase >= g0 && wbase + WSAMP <= gend) {
-            const float4 *p4 = reinterpret_cast<const float4 *>(in + (wbase - g0));
+            if (FMT == 0) {
+                const float4 *p4 = reinterpret_cast<const float4 *>(in + (wbase - g0));
 #pragma unroll
-            for (int k = 0; k < SPT / 2; k++) raw[k] = p4[lane + 64 * k];
+                for (int k = 0; k < SPT / 2; k++) raw[k] = p4[lane + 64 * k];
+            } else if (FMT == 1 || FMT == 2) {
+                const uint32_t *p1 = reinterpret_cast<const uint32_t *>(inb + (size_t)(wbase - g0) * BPS);
+#pragma unroll
+                for (int k = 0; k < SPT / 2; k++) {
+                    const uint32_t w = p1[lane + 64 * k];             // I0 Q0 I1 Q1
+                    if (FMT == 1)
+                        raw[k] = make_float4((float)((int)(w & 255u) - 127) * qs, (float)((int)((w >> 8) & 255u) - 127) * qs,
+                                             (float)((int)((w >> 16) & 255u) - 127) * qs, (float)((int)(w >> 24) - 127) * qs);
+                    else
+                        raw[k] = make_float4((float)(int8_t)(w & 255u) * qs, (float)(int8_t)((w >> 8) & 255u) * qs,
+                                             (float)(int8_t)((w >> 16) & 255u) * qs, (float)(int8_t)(w >> 24) * qs);
+                }
+            } else {
+                const uint2 *p2 = reinterpret_cast<const uint2 *>(inb + (size_t)(wbase - g0) * BPS);
+#pragma unroll
+                for (int k = 0; k < SPT / 2; k++) {
+                    const uint2 w = p2[lane + 64 * k];                // (I0 Q0) (I1 Q1)
+                    raw[k] = make_float4((float)(int16_t)(w.x & 0xffffu) * qs, (float)(int16_t)(w.x >> 16) * qs,
+                                         (float)(int16_t)(w.y & 0xffffu) * qs, (float)(int16_t)(w.y >> 16) * qs);
+                }
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < SPT / 2; k++) {
                 const int i0 = wbase + 2 * (lane + 64 * k);
-                const float2 a = (i0 >= g0 && i0 < gend) ? in[i0 - g0] : make_float2(0.f, 0.f);
-                const float2 b = (i0 + 1 >= g0 && i0 + 1 < gend) ? in[i0 + 1 - g0] : make_float2(0.f, 0.f);
+                const float2 a = (i0 >= g0 && i0 < gend) ? cvt1(i0 - g0) : make_float2(0.f, 0.f);
+                const float2 b = (i0 + 1 >= g0 && i0 + 1 < gend) ? cvt1(i0 + 1 - g0) : make_float2(0.f, 0.f);
                 raw[k] = make_float4(a.x, a.y, b.x, b.y);
             }
         }
@@ -449,9 +488,14 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
     }
 }
 
-void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const float2 *iq,
+void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s) {
-    hipLaunchKernelGGL(front_kernel, dim3(channels), dim3(256), 0, s, T, B, G, iq);
+    switch (G.iq_format) {
+    case 1: hipLaunchKernelGGL(front_kernel<1>, dim3(channels), dim3(256), 0, s, T, B, G, iq); break;
+    case 2: hipLaunchKernelGGL(front_kernel<2>, dim3(channels), dim3(256), 0, s, T, B, G, iq); break;
+    case 3: hipLaunchKernelGGL(front_kernel<3>, dim3(channels), dim3(256), 0, s, T, B, G, iq); break;
+    default: hipLaunchKernelGGL(front_kernel<0>, dim3(channels), dim3(256), 0, s, T, B, G, iq); break;
+    }
 }
 
 }  // namespace fmx

@@ -123,6 +123,8 @@ struct CallGeom {
                          // consecutive rows do not land on the same HBM channel/bank (power-of-two strides do)
     int32_t pad_;
     int64_t stream_stride, pcm_stride;   // in complex samples / frames
+    int32_t iq_format;   // fmx_iq_format of the input buffer
+    float   iq_scale;    // 1/128 (U8, S8) or 1/denominator (S16)
 };
 
 struct DeviceBuffers {
@@ -177,7 +179,7 @@ struct RdsBuffers {
 #define C_RDS_PITCH(Rb) ((Rb).pitch)
 void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, int64_t n0, hipStream_t s);
 
-void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const float2 *iq,
+void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s);
 // side streams + events for the chunk pipeline of stage B (null streams = run everything on the caller's stream)
 struct DemodStreams { hipStream_t side[4]; hipEvent_t *ev; int nev; hipEvent_t join; };

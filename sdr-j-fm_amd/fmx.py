@@ -22,10 +22,12 @@ P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE
 A_TRIGGER_FREQUENCY_CHANGE, A_RESTART_PSS, A_RESET_RDS = 100, 101, 102
 
 TAP_FM_IQ, TAP_DEMOD, TAP_LR_RAW, TAP_PRE_RESAMPLER, TAP_RDS_IQ = 0, 1, 2, 3, 4
+IQ_F32, IQ_U8, IQ_S8, IQ_S16 = 0, 1, 2, 3
 
 EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
-    "fmx_process_host", "fmx_process_device", "fmx_synchronize", "fmx_get_meta", "fmx_get_tap",
+    "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
+    "fmx_get_meta", "fmx_get_tap",
     "fmx_rds_bits", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
@@ -89,6 +91,10 @@ def load_library(path=None):
     L.fmx_process_host.argtypes = [vp, f32p, i64, i64, f32p, i64, C.POINTER(i64)]
     L.fmx_process_device.restype = C.c_int
     L.fmx_process_device.argtypes = [vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp]
+    L.fmx_process_host_raw.restype = C.c_int
+    L.fmx_process_host_raw.argtypes = [vp, vp, i32, C.c_float, i64, i64, f32p, i64, C.POINTER(i64)]
+    L.fmx_process_device_raw.restype = C.c_int
+    L.fmx_process_device_raw.argtypes = [vp, vp, i32, C.c_float, i64, i64, vp, i64, C.POINTER(i64), vp]
     L.fmx_synchronize.restype = C.c_int
     L.fmx_synchronize.argtypes = [vp]
     L.fmx_get_meta.restype = C.c_int
@@ -163,6 +169,22 @@ class Fmx:
         got = C.c_int64()
         self._check(self.L.fmx_process_host(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), n, n,
                                             pcm.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(got)))
+        return pcm[:, :got.value]
+
+    def process_host_raw(self, iq, fmt, s16_denominator=2048.0):
+        """Raw device samples: iq uint8 / int8 / int16 [streams, n, 2] (or [n, 2]), fmt = IQ_U8 / IQ_S8 /
+        IQ_S16; converted on the GPU exactly as the reference's device handlers do on the host."""
+        dt = {IQ_U8: np.uint8, IQ_S8: np.int8, IQ_S16: np.int16, IQ_F32: np.float32}[fmt]
+        iq = np.ascontiguousarray(iq, dt)
+        if iq.ndim == 2:
+            iq = iq[None]
+        assert iq.shape[0] == self.streams and iq.shape[2] == 2
+        n = iq.shape[1]
+        cap = max(self.frames_for(n), 1)
+        pcm = np.zeros((self.channels, cap, 2), np.float32)
+        got = C.c_int64()
+        self._check(self.L.fmx_process_host_raw(self.h, iq.ctypes.data_as(C.c_void_p), fmt, float(s16_denominator), n, n,
+                                                pcm.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(got)))
         return pcm[:, :got.value]
 
     def process_device(self, d_iq_ptr, stream_stride, n, d_pcm_ptr, pcm_stride, hip_stream=None):

@@ -421,6 +421,46 @@ def test_rds_batched_channels_and_second_read(fmx_amd, ol):
     assert np.count_nonzero(chains[0].rds_bits()[600:1400] != chains[1].rds_bits()[600:1400]) > 100
 
 
+# ------------------------------------------------------------------------------------------------
+# raw device samples: the host-side conversion of the device handlers moved into the input-FIR kernel
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt,name", [(1, "u8_rtlsdr"), (2, "s8_hackrf"), (3, "s16_2048")])
+def test_raw_iq_formats(fmx_amd, ol, fmt, name):
+    """Feeding quantised raw samples == feeding the floats the reference's handler makes of them
+    (rtlsdr-handler.cpp:291, hackrf-handler.cpp:364, lime-handler.cpp:250): bit-identical PCM; and the oracle agrees
+    on those floats.  Blocks are odd-sized so that the unaligned load path runs too."""
+    n = 16384 * 40
+    iq = ol.synth_iq(n)
+    if fmt == 1:
+        raw = np.clip(np.round(iq * 128.0 + 127.0), 0, 255).astype(np.uint8)
+        fl = ((raw.astype(np.float32) - 127.0) / 128.0).astype(np.float32)
+    elif fmt == 2:
+        raw = np.clip(np.round(iq * 128.0), -128, 127).astype(np.int8)
+        fl = (raw.astype(np.float32) / 128.0).astype(np.float32)
+    else:
+        raw = np.clip(np.round(iq * 2048.0), -2048, 2047).astype(np.int16)
+        fl = (raw.astype(np.float32) / 2048.0).astype(np.float32)
+    blocks = [16384 * 8, 16384 * 8 + 7, 99991, 16384 * 8]
+    fa = fmx_amd.Fmx(1, max_block=max(blocks)); gui_defaults(fa)
+    fb = fmx_amd.Fmx(1, max_block=max(blocks)); gui_defaults(fb)
+    pa, pb, pos = [], [], 0
+    for b in blocks:
+        pa.append(fa.process_host_raw(raw[pos:pos + b], fmt, 2048.0)[0])
+        pb.append(fb.process_host(fl[pos:pos + b])[0])
+        pos += b
+    pa, pb = np.concatenate(pa), np.concatenate(pb)
+    assert pa.shape == pb.shape and np.array_equal(pa, pb)
+    ch = ol.OracleChain(inputFilterBw=165000)
+    po = ch.process(fl[:pos])
+    m = min(len(po), len(pa))
+    e = rms(pa[:m] - po[:m])
+    print(f"\n[{name}] raw == float path bit for bit; pcm rms vs oracle {e:.3e}")
+    assert e <= PCM_RMS_TOL
+    if fmt == 3:
+        with pytest.raises(fmx_amd.FmxError):
+            fa.process_host_raw(raw[:4096], 3, 1000.0)            # the denominator must be a power of two
+
+
 def test_tap_sets_match_oracle_design(fmx_amd, ol):
     """The folded filters the kernels run are the reference taps convolved in f64: check against the
     oracle's (reference-pinned) designs."""

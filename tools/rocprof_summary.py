@@ -23,7 +23,7 @@ def main():
     print("# per-dispatch resources of the fmx kernels (first dispatch of each)")
     seen = set()
     q = ("select name,grid_x,grid_y,workgroup_x,lds_size,static_lds_size,scratch_size,vgpr_count,accum_vgpr_count,sgpr_count,duration "
-         "from kernels where name like 'fmx::%' order by start")
+         "from kernels where name like 'fmx::%' or name like 'void fmx::%' order by start")
     rows = list(cur.execute(q))
     for r in rows:
         k = r[0].split("(")[0]
