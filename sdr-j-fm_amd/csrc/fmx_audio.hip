@@ -7,8 +7,8 @@
 //
 // MI355X design: the audio low-pass and the decimate-by-4 resampler are both LTI, so they are
 // folded on the host into ONE polyphase FIR (756 + 128 - 1 = 883 taps) that is only evaluated at
-// the 48 kHz output instants (4x fewer MACs than filtering at 192 kS/s); de-emphasis and the
-// volume/balance gains commute with it and were applied upstream (fmx_demod.hip).  The
+// the 48 kHz output instants (4x fewer MACs than filtering at 192 kS/s); de-emphasis commutes with it and is
+// applied upstream (fmx_demod.hip), the volume/balance gain at the FIR output.  The
 // overlap-add latency (7436 samples = 1859 PCM frames) is reproduced by reading further back in
 // the per-channel d ring.  libsamplerate itself is third-party and absent: the resampler is the
 // documented fmx design (oracle/fm_oracle.c fmo_resampler_taps), "parity unpinned" for that stage.
@@ -16,63 +16,101 @@
 
 namespace fmx {
 
-constexpr int CW = C_TILE + (C_MAX_TAPS + 3) / 4 + 1;     // columns of the 4-phase window: 256 + 221 + 1
-constexpr int CWS = CW + 1;
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int CQ = C_TAPS_STRIDE / 4;                     // 224 tap columns per phase (zero padded)
+constexpr int CWC = C_TILE + CQ + 16;                     // window columns per phase
+constexpr int FPT = 4;                                    // adjacent output frames per thread
 
-__global__ __launch_bounds__(256) void audio_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
-                                                    float2 *__restrict__ pcm) {
-    __shared__ float2 X[4][CWS];
+// One wave per (256-frame tile, channel).  The window lives in LDS as four decimation phases X[p][col] (entry w of the
+// window = fm index fbase + w sits at X[w & 3][w >> 2]), so output frame f reads X[p][f + q] for tap 4 q + p.  A thread
+// computes FOUR adjacent frames with a sliding register window: per four taps of a phase it fetches four new (L, R)
+// columns (2 ds_read_b128) and the four taps (one broadcast ds_read_b128) and issues 16 packed FMAs -- (L, R) ride in
+// one v_pk_fma_f32 because the taps are real.
+__global__ __launch_bounds__(64) void audio_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
+                                                   float2 *__restrict__ pcm) {
+    // X[p][half][block] = the column pair (4 block + 2 half, + 1) of phase p: a thread's four new columns are one float4
+    // from each half-plane, both read at a 16-byte lane stride (conflict-free ds_read_b128)
+    __shared__ __attribute__((aligned(16))) float4 X[4][2][CWC / 4];
+    __shared__ __attribute__((aligned(16))) float tp[4][CQ];         // taps by phase: tp[p][q] = taps[4 q + p]
     const int ch = blockIdx.y;
     const int t = threadIdx.x;
     const int64_t m0 = G.M0 + (int64_t)blockIdx.x * C_TILE;
     if (m0 >= G.M1) return;
     const ChanParams P = B.params[ch];
     const AudioSet AS = T.audio_sets[P.audio_set];
-    const float *__restrict__ taps = T.audio_taps + (size_t)P.audio_set * C_TAPS_STRIDE;   // reversed order
+    const float *__restrict__ taps = T.audio_taps + (size_t)P.audio_set * C_TAPS_STRIDE;   // reversed order, zero padded
     const float2 *__restrict__ dring = B.dring + (size_t)ch * (G.dring_mask + 1);
     const int NC = AS.ntaps;
-    // window entry w <-> fm index fbase + w ; output t reads w = 4 t + kk, kk = NC-1-k
+    const int NG = ((NC + 15) / 16 + 1) & ~1;               // groups of four tap columns per phase, even
+    // window entry w <-> fm index fbase + w ; output frame f (0..255) reads w = 4 f + kk, kk = tap index
     const int64_t fbase = 4 * m0 + 3 - AS.delay - (NC - 1);
-    const int nw = 4 * (C_TILE - 1) + NC;
-    for (int w = t; w < nw; w += 256) {
+    const int nw = 4 * (C_TILE + 4 * NG + 4);
+    for (int w = t; w < nw; w += 64) {
         const int64_t f = fbase + w;
         float2 v = make_float2(0.f, 0.f);
-        if (f >= 0) v = dring[f & G.dring_mask];
-        X[w & 3][w >> 2] = v;
+        if (f >= 0 && w < 4 * (C_TILE - 1) + NC) v = dring[f & G.dring_mask];
+        const int col = w >> 2;
+        reinterpret_cast<float2 *>(&X[w & 3][(col >> 1) & 1][col >> 2])[col & 1] = v;
     }
+    for (int i = t; i < C_TAPS_STRIDE; i += 64) tp[i & 3][i >> 2] = taps[i];
     __syncthreads();
-    const int64_t m = m0 + t;
-    if (m >= G.M1) return;
-    float al = 0.f, ar = 0.f;
-    int kk = 0;
-    for (; kk + 4 <= NC; kk += 4) {
-        const int c = t + (kk >> 2);
+    v2f acc[FPT];
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const float w = taps[kk + p];
-            const float2 v = X[p][c];
-            al = fmaf(w, v.x, al); ar = fmaf(w, v.y, ar);
+    for (int j = 0; j < FPT; j++) acc[j] = (v2f){0.f, 0.f};
+    const int c0 = FPT * t;
+    for (int p = 0; p < 4; p++) {
+        const float4 *xa = &X[p][0][t], *xb = &X[p][1][t];               // this thread's blocks t, t+1, ...
+        const float4 *tr = reinterpret_cast<const float4 *>(&tp[p][0]);
+        v2f c[8];
+        { const float4 a = xa[0], b = xb[0]; c[0] = (v2f){a.x, a.y}; c[1] = (v2f){a.z, a.w}; c[2] = (v2f){b.x, b.y}; c[3] = (v2f){b.z, b.w}; }
+        // two tap groups per iteration: the eight-column register window is used as a ring, so nothing is moved
+        for (int g = 0; g < NG; g += 2) {
+            {
+                const float4 a = xa[g + 1], b = xb[g + 1];
+                c[4] = (v2f){a.x, a.y}; c[5] = (v2f){a.z, a.w}; c[6] = (v2f){b.x, b.y}; c[7] = (v2f){b.z, b.w};
+                const float4 w4 = tr[g];
+                const float wq[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const v2f w = (v2f){wq[q], wq[q]};
+#pragma unroll
+                    for (int j = 0; j < FPT; j++) acc[j] = __builtin_elementwise_fma(w, c[q + j], acc[j]);
+                }
+            }
+            {   // (for an odd group count the extra group multiplies zero taps: the tap table is padded, the window too)
+                const float4 a = xa[g + 2], b = xb[g + 2];
+                c[0] = (v2f){a.x, a.y}; c[1] = (v2f){a.z, a.w}; c[2] = (v2f){b.x, b.y}; c[3] = (v2f){b.z, b.w};
+                const float4 w4 = tr[g + 1];
+                const float wq[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const v2f w = (v2f){wq[q], wq[q]};
+#pragma unroll
+                    for (int j = 0; j < FPT; j++) acc[j] = __builtin_elementwise_fma(w, c[(4 + q + j) & 7], acc[j]);
+                }
+            }
         }
-    }
-    for (; kk < NC; kk++) {
-        const float w = taps[kk];
-        const float2 v = X[kk & 3][t + (kk >> 2)];
-        al = fmaf(w, v.x, al); ar = fmaf(w, v.y, ar);
     }
     // audioGainCorrection fm-processor.cpp:303-306: (volumeFactor * leftChannel) * sample.  Applied here, at
     // the output of the folded FIR, so that a volume/balance change takes effect at the call boundary as in
     // the reference (it sits behind the audio low-pass there) rather than one filter latency late.
-    al *= P.volume * P.left_ch; ar *= P.volume * P.right_ch;
-    // start-up fade fm-processor.cpp:638-642: factor = (Max - cnt)/Max with cnt = Max - (m - F)
+    const float gl = P.volume * P.left_ch, gr = P.volume * P.right_ch;
     const int64_t F = B.state[ch].fade_start_frame;
-    const int64_t since = m - F;
     const int Max = 24000;                               // workingRate / 2
-    if (since >= 0 && since < Max) {
-        const float cnt = (float)(Max - (int)since);
-        const float f = ((float)Max - cnt) / (float)Max;
-        al *= f; ar *= f;
+#pragma unroll
+    for (int j = 0; j < FPT; j++) {
+        const int64_t m = m0 + c0 + j;
+        if (m >= G.M1) break;
+        float al = acc[j].x * gl, ar = acc[j].y * gr;
+        // start-up fade fm-processor.cpp:638-642: factor = (Max - cnt)/Max with cnt = Max - (m - F)
+        const int64_t since = m - F;
+        if (since >= 0 && since < Max) {
+            const float cnt = (float)(Max - (int)since);
+            const float f = ((float)Max - cnt) / (float)Max;
+            al *= f; ar *= f;
+        }
+        pcm[(size_t)ch * G.pcm_stride + (m - G.M0)] = make_float2(al, ar);
     }
-    pcm[(size_t)ch * G.pcm_stride + (m - G.M0)] = make_float2(al, ar);
 }
 
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,
@@ -80,7 +118,7 @@ void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
     const int64_t frames = G.M1 - G.M0;
     if (frames <= 0) return;
     const int tiles = (int)((frames + C_TILE - 1) / C_TILE);
-    hipLaunchKernelGGL(audio_kernel, dim3(tiles, channels), dim3(256), 0, s, T, B, G, pcm);
+    hipLaunchKernelGGL(audio_kernel, dim3(tiles, channels), dim3(64), 0, s, T, B, G, pcm);
 }
 
 }  // namespace fmx
