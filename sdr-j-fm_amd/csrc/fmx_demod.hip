@@ -486,51 +486,110 @@ __global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers 
 //     stereo-separation.cpp:60-83 : err = Re(y)*Im(y), y = sum_k h[k] s[i - 1753 - k], i = PSS call index
 // =================================================================================================
 constexpr int PSS_TILE = 256;
-constexpr int PSS_WIN = PSS_TILE + PSS_TAPS - 1;
+constexpr int PSS_TQ = (PSS_TAPS + 3) / 4 + 1;              // tap groups of four (reversed taps, zero padded): 75
+constexpr int PSS_WB = (PSS_TILE + 4 * PSS_TQ) / 4 + 2;     // window blocks of four s samples
+// One wave per (256-sample tile, channel); a thread computes FOUR adjacent samples.  When their PSS call indices are
+// consecutive (the steady case: every sample calls process_sample) the s window slides through an eight-entry register
+// ring -- per four taps two conflict-free ds_read_b128 (half-plane layout as in the audio kernel), one broadcast read
+// of the taps and 16 packed FMAs (the PSS input is complex, the taps real); otherwise each output reads its own window.
 __global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
                                                      int64_t rc0, int chunk_len) {
     const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
-    __shared__ float2 sWIN[PSS_WIN];
-    __shared__ int sTag[PSS_TILE];
+    __shared__ __attribute__((aligned(16))) float4 sW[2][PSS_WB];     // s window: sW[half][block] = entries 4 block + 2 half, +1
+    __shared__ __attribute__((aligned(16))) float sH[4 * PSS_TQ];     // sH[w] = h[PSS_TAPS - 1 - w] (0 beyond)
     const int ch = blockIdx.y;
     const int lane = threadIdx.x;
     const int q0 = blockIdx.x * PSS_TILE;
     const ChanParams &P = B.params[ch];
     if (P.fm_mode == 2 || !P.pss_active) return;
     const int64_t ic = B.state[ch].pss_count;            // PSS call index at the start of this CALL
-    int tmin = 0x7fffffff;
-    for (int m = 0; m < 4; m++) {
-        const int q = q0 + lane + 64 * m;
-        const int tg = (q < chunk_len) ? (B.w_tag[widx(rc0 + q, ch, (int)CP)] >> 1) - 2 : -2;
-        sTag[lane + 64 * m] = tg;
-        if (tg >= 0) tmin = tg < tmin ? tg : tmin;
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    int tg[4];
+    {
+        const int q = q0 + 4 * lane;                     // four adjacent rows of one work-array tile: one dwordx4
+        i32x4_t pk = {0, 0, 0, 0};
+        if (q < chunk_len) pk = *reinterpret_cast<const i32x4_t *>(&B.w_tag[widx(rc0 + q, ch, (int)CP)]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) tg[j] = (q + j < chunk_len) ? (pk[j] >> 1) - 2 : -2;
     }
+    int tmin = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (tg[j] >= 0) tmin = tg[j] < tmin ? tg[j] : tmin;
     for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(tmin, d, 64); tmin = o < tmin ? o : tmin; }
     if (tmin == 0x7fffffff) return;                      // no PSS call in this tile
     const float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
     // window entry w <-> s index (ic + tmin) - (1753 + 294) + w ; tags in a tile span < PSS_TILE
-    for (int w = lane; w < PSS_WIN; w += 64) {
+    for (int w = lane; w < 4 * PSS_WB; w += 64) {
         const int64_t idx = ic + tmin - (PSS_DELAY + PSS_TAPS - 1) + w;
-        sWIN[w] = (idx >= 0) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
+        const float2 v = (idx >= 0 && w < PSS_TILE + PSS_TAPS - 1) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
+        reinterpret_cast<float2 *>(&sW[(w >> 1) & 1][w >> 2])[w & 1] = v;
     }
+    for (int w = lane; w < 4 * PSS_TQ; w += 64) sH[w] = (w < PSS_TAPS) ? T.pss_taps[PSS_TAPS - 1 - w] : 0.f;
     __syncthreads();
-    int off[4];
+    // y(sample) = sum_w sH[w] * s[w + off], off = tag - tmin
+    typedef float v2f_t __attribute__((ext_vector_type(2)));
+    float err4[4];
+    const bool beyond = q0 + 4 * lane >= chunk_len;      // lanes past the end of the chunk compute nothing that is stored
+    const bool consecutive = beyond || ((tg[0] >= 0) && (tg[1] == tg[0] + 1) && (tg[2] == tg[0] + 2) && (tg[3] == tg[0] + 3) &&
+                                        (((tg[0] - tmin) & 3) == 0));
+    if (__all(consecutive)) {
+        const int b0 = beyond ? 0 : (tg[0] - tmin) >> 2; // first window block of this thread
+        const float4 *xa = &sW[0][b0], *xb = &sW[1][b0];
+        const float4 *hr = reinterpret_cast<const float4 *>(sH);
+        v2f_t acc[4], c[8];
 #pragma unroll
-    for (int m = 0; m < 4; m++) { const int tg = sTag[lane + 64 * m]; off[m] = tg >= 0 ? tg - tmin : 0; }
-    float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < PSS_TAPS; k++) {
-        const float h = T.pss_taps[k];
-        const int w = (PSS_TAPS - 1) - k;
+        for (int j = 0; j < 4; j++) acc[j] = (v2f_t){0.f, 0.f};
+        { const float4 a = xa[0], b = xb[0]; c[0] = (v2f_t){a.x, a.y}; c[1] = (v2f_t){a.z, a.w}; c[2] = (v2f_t){b.x, b.y}; c[3] = (v2f_t){b.z, b.w}; }
+        for (int g = 0; g < PSS_TQ - 1; g += 2) {        // PSS_TQ - 1 = 74 groups cover the 295 taps
+            {
+                const float4 a = xa[g + 1], b = xb[g + 1];
+                c[4] = (v2f_t){a.x, a.y}; c[5] = (v2f_t){a.z, a.w}; c[6] = (v2f_t){b.x, b.y}; c[7] = (v2f_t){b.z, b.w};
+                const float4 h4 = hr[g];
+                const float hq[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const float2 v = sWIN[w + off[m]];
-            ar[m] = fmaf(h, v.x, ar[m]); ai[m] = fmaf(h, v.y, ai[m]);
+                for (int q = 0; q < 4; q++) {
+                    const v2f_t w = (v2f_t){hq[q], hq[q]};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[j] = __builtin_elementwise_fma(w, c[q + j], acc[j]);
+                }
+            }
+            {
+                const float4 a = xa[g + 2], b = xb[g + 2];
+                c[0] = (v2f_t){a.x, a.y}; c[1] = (v2f_t){a.z, a.w}; c[2] = (v2f_t){b.x, b.y}; c[3] = (v2f_t){b.z, b.w};
+                const float4 h4 = hr[g + 1];
+                const float hq[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const v2f_t w = (v2f_t){hq[q], hq[q]};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[j] = __builtin_elementwise_fma(w, c[(4 + q + j) & 7], acc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) err4[j] = acc[j].x * acc[j].y;
+    } else {
+        const float2 *s2 = reinterpret_cast<const float2 *>(&sW[0][0]);
+        auto sat = [&](int w) -> float2 {                // entry w of the window in the half-plane layout
+            return reinterpret_cast<const float2 *>(&sW[(w >> 1) & 1][w >> 2])[w & 1];
+        };
+        (void)s2;
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) {
+            float ar = 0.f, ai = 0.f;
+            if (tg[j] >= 0) {
+                const int off = tg[j] - tmin;
+                for (int w = 0; w < PSS_TAPS; w++) { const float2 v = sat(w + off); ar = fmaf(sH[w], v.x, ar); ai = fmaf(sH[w], v.y, ai); }
+            }
+            err4[j] = ar * ai;
         }
     }
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const int q = q0 + lane + 64 * m;
-        if (q < chunk_len) B.w_err[widx(q, ch, (int)CP)] = ar[m] * ai[m];
+    {
+        const int q = q0 + 4 * lane;
+        float *dst = &B.w_err[widx(q, ch, (int)CP)];
+        if (q + 3 < chunk_len) *reinterpret_cast<f32x4_t *>(dst) = (f32x4_t){err4[0], err4[1], err4[2], err4[3]};
+        else for (int j = 0; j < 4; j++) if (q + j < chunk_len) dst[j] = err4[j];
     }
 }
 
