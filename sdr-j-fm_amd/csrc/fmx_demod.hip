@@ -121,34 +121,39 @@ __device__ __forceinline__ float2 limiter(float2 z) {
 __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
     const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
     __shared__ float tile[64][65];
-    __shared__ float2 tileIQ[64][65];
+    __shared__ float2 sLIM[64][67];                   // limited samples of rows r0-2 .. r0+63 (each is used by up to three outputs)
     const int tid = threadIdx.x;
     const int64_t nj = G.J1 - G.J0;
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
     const int ring = G.ring_mask + 1;
     const bool want_iq = B.w_iq != nullptr;
+    // ---- limiter (fm-demodulator.cpp:119-126), once per sample: threads along time (contiguous ring reads)
+    for (int i = tid; i < 64 * 66; i += 256) {
+        const int cl = i / 66, rl = i - 66 * cl;      // rl 0..65 <-> row r0 - 2 + rl
+        const int ch = c0 + cl;
+        float2 v = make_float2(0.f, 0.f);
+        if (ch < C) {
+            const int delay = T.front_sets[B.params[ch].front_set].delay_fm;
+            const float2 *zr = B.zring + (size_t)ch * ring;
+            const int64_t jj = G.J0 + r0 - 2 + rl;
+            // z[j'] is 0 before the filter latency has elapsed; the demodulator's initial Imin/Qmin is 0.01
+            // (fm-demodulator.cpp:79-82)
+            if (jj < 0) v = make_float2((float)0.01, (float)0.01);
+            else { const int64_t s = jj - delay; v = limiter(s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f)); }
+        }
+        sLIM[cl][rl] = v;
+    }
+    __syncthreads();
     for (int i = 0; i < 16; i++) {
         const int cl = (tid >> 6) + 4 * i, rl = tid & 63;
         const int ch = c0 + cl;
         const int64_t r = r0 + rl;
-        float res = 0.f; float2 cur = make_float2(0.f, 0.f);
+        float res = 0.f;
         if (ch < C && r < nj) {
-            const ChanParams &P = B.params[ch];
-            const int delay = T.front_sets[P.front_set].delay_fm;
-            const float2 *zr = B.zring + (size_t)ch * ring;
-            const int64_t j = G.J0 + r;
-            // z[j'] is 0 before the filter latency has elapsed; the demodulator's initial
-            // Imin/Qmin is 0.01 (fm-demodulator.cpp:79-82)
-            auto lim_at = [&](int64_t jj) -> float2 {
-                if (jj < 0) return make_float2((float)0.01, (float)0.01);
-                const int64_t v = jj - delay;
-                return limiter(v >= 0 ? zr[v & G.ring_mask] : make_float2(0.f, 0.f));
-            };
-            cur = lim_at(j);
-            const float2 p1 = lim_at(j - 1);
+            const float2 cur = sLIM[cl][rl + 2], p1 = sLIM[cl][rl + 1];
             const float I = cur.x, Q = cur.y, I1 = p1.x, Q1 = p1.y;
-            const int decoder = P.decoder;
+            const int decoder = B.params[ch].decoder;
             if (decoder == 5) {            // REAL_BB fm-demodulator.cpp:174-182
                 res = (float)((double)(I1 * Q - Q1 * I + 1) / 2.0);
                 int index = (int)floorf(res * (float)ARCSINE_N);
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
                 if (index >= ARCSINE_N) index = ARCSINE_N;
                 res = T.arcsine[index];
             } else if (decoder == 6) {     // DIFF :184-189
-                const float2 p2 = lim_at(j - 2);
+                const float2 p2 = sLIM[cl][rl];
                 const float Scaler = (float)1.4142135623730951;
                 res = (I1 * (Q - p2.y) - Q1 * (I - p2.x));
                 res /= (I1 * I1 + Q1 * Q1) * Scaler;
@@ -165,7 +170,6 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
             }
         }
         tile[cl][rl] = res;
-        if (want_iq) tileIQ[cl][rl] = cur;
     }
     __syncthreads();
     for (int i = 0; i < 16; i++) {                    // threads as (row in work-array tile, channel): contiguous stores
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
         const int64_t r = r0 + rl;
         if (ch < C && r < nj) {
             B.w_dem[widx(r, ch, CP)] = tile[cl][rl];
-            if (want_iq) B.w_iq[widx(r, ch, CP)] = tileIQ[cl][rl];
+            if (want_iq) B.w_iq[widx(r, ch, CP)] = sLIM[cl][rl + 2];
         }
     }
 }
