@@ -892,9 +892,13 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         (void)hipEventRecord(e, st[from]);
         (void)hipStreamWaitEvent(st[to], e, 0);
     };
+    // The first chunk is short: the five-stage pipeline fills in the time of 256 samples instead of 1744 (the call's
+    // first PSS kernel starts ~0.2 ms earlier); any chunk length <= PSS_CHUNK that is a multiple of the tile is valid.
+    constexpr int FIRST_CHUNK = 256;
     int c = 0;
-    for (int64_t rc0 = 0; rc0 < nj; rc0 += PSS_CHUNK, c++) {
-        const int len = (int)((nj - rc0) < PSS_CHUNK ? (nj - rc0) : PSS_CHUNK);
+    for (int64_t rc0 = 0; rc0 < nj; c++) {
+        const int cap = (c == 0 && nj > 2 * FIRST_CHUNK) ? FIRST_CHUNK : PSS_CHUNK;
+        const int len = (int)((nj - rc0) < cap ? (nj - rc0) : cap);
         const int last = (rc0 + len >= nj) ? 1 : 0;
         if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
         else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
@@ -910,6 +914,7 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len);
         hand_over(3, 4, c);
         hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last);
+        rc0 += len;
     }
     hipLaunchKernelGGL(dring_kernel, tiles, dim3(256), 0, s3, B, G, C);
     if (s3 != s) { (void)hipEventRecord(DS.join, s3); (void)hipStreamWaitEvent(s, DS.join, 0); }
