@@ -23,6 +23,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# libfmx pipelines stage B on five HIP streams; ROCm maps streams onto 4 hardware queues by default, so two of them
+# would share one.  Must be set before the HIP runtime starts (i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 INPUT_RATE = 2304000
 BLOCK = 230400            # 0.1 s per channel per step; every synthetic tone is periodic in it
