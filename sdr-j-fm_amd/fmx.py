@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libfmx.so")
+LIB_PATH = os.environ.get("FMX_LIB") or os.path.join(HERE, "lib", "libfmx.so")      # FMX_LIB: A/B runs of two builds
 
 # error codes (include/fmx.h)
 FMX_OK, FMX_E_INVALID, FMX_E_UNSUPPORTED, FMX_E_NO_DEVICE, FMX_E_HIP, FMX_E_NOMEM, FMX_E_TOO_LARGE = 0, -1, -2, -3, -4, -5, -6
