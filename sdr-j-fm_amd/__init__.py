@@ -12,3 +12,4 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .fmx import (Fmx, FmProcessor, FmxError, load_library, EXPORTS, LIB_PATH)  # noqa: F401
 from . import fmx, shard  # noqa: F401
+from .filesource import WavFileSource  # noqa: F401

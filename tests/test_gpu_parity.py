@@ -461,6 +461,46 @@ def test_raw_iq_formats(fmx_amd, ol, fmt, name):
             fa.process_host_raw(raw[:4096], 3, 1000.0)            # the denominator must be a power of two
 
 
+def test_config1_wav_file_reader(fmx_amd, ol, tmp_path):
+    """BASELINE configs[0] literally: a PCM16 stereo .wav at 2.304 MS/s through the file source (fileHulp semantics) and
+    the fmProcessor mirror, mono FM, input filter OFF -- against the oracle fed with the floats libsndfile would deliver;
+    and the raw int16 route gives the same PCM bit for bit."""
+    import struct
+    n = 16384 * 30
+    iq = ol.synth_iq(n, stereo=0)
+    s16 = np.clip(np.round(iq * 32768.0 * 0.9), -32768, 32767).astype(np.int16)
+    body = s16.astype("<i2").tobytes()
+    with open(tmp_path / "c1.wav", "wb") as f:
+        f.write(struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(body), b"WAVE", b"fmt ", 16, 1, 2, 2304000,
+                            2304000 * 4, 4, 16, b"data", len(body)) + body)
+
+    class Sink:
+        def __init__(self): self.chunks = []
+        def putSamples(self, a): self.chunks.append(np.array(a))
+
+    src, sink = fmx_amd.WavFileSource(str(tmp_path / "c1.wav")), Sink()
+    assert src.getRate() == 2304000
+    p = fmx_amd.FmProcessor(src, sink, blockSize=16384)
+    p.setfmMode("Mono"); p.setBandwidth("Off"); p.setDeemphasis(50); p.setlfcutoff(15000); p.setVolume(-6.0)
+    p.setFMdecoder("FM Mixed Demod")
+    for _ in range(n // 16384):
+        assert p.run_block()
+    pcm_g = np.concatenate(sink.chunks)
+    fl = (s16.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    ch = ol.OracleChain(inputFilterBw=0, fmMode=2)
+    pcm_o = ch.process(fl)
+    e = rms(pcm_g - pcm_o)
+    print(f"\n[config1 .wav] {len(pcm_g)} frames, pcm rms vs oracle {e:.3e} (signal {rms(pcm_o):.3f})")
+    assert pcm_g.shape == pcm_o.shape and e <= PCM_RMS_TOL
+    # the file's own int16 pairs straight to the GPU
+    src.currPos = 0
+    f = fmx_amd.Fmx(1, max_block=16384)
+    f.set_param(M.P_FM_MODE, 2); f.set_param(M.P_BANDWIDTH, 0); f.set_param(M.P_DEEMPHASIS, 50)
+    f.set_param(M.P_LF_CUTOFF, 15000); f.set_param(M.P_VOLUME_DB, -6.0); f.set_param(M.P_FM_DECODER, 3)
+    raw = np.concatenate([f.process_host_raw(src.raw(16384), M.IQ_S16, 32768.0)[0] for _ in range(n // 16384)])
+    assert np.array_equal(raw, pcm_g)
+
+
 def test_tap_sets_match_oracle_design(fmx_amd, ol):
     """The folded filters the kernels run are the reference taps convolved in f64: check against the
     oracle's (reference-pinned) designs."""

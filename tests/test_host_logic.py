@@ -91,3 +91,40 @@ def test_frame_count_rule_matches_oracle(ol):
         assert got == frames_model(g, n)
         g += n
     assert frames_model(0, 16384) == 336 and frames_model(16384, 16384) == 336 and frames_model(0, 230400) == 4800
+
+
+def _write_wav(path, x, rate, fmt):
+    import struct
+    ch = x.shape[1]
+    if fmt == "pcm16":
+        body, tag, bits = x.astype("<i2").tobytes(), 1, 16
+    else:
+        body, tag, bits = x.astype("<f4").tobytes(), 3, 32
+    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(body), b"WAVE", b"fmt ", 16, tag, ch, rate,
+                      rate * ch * bits // 8, ch * bits // 8, bits, b"data", len(body))
+    with open(path, "wb") as f:
+        f.write(hdr + body)
+
+
+def test_wav_file_source(tmp_path):
+    """fileHulp semantics (filehulp.cpp:41-147): header rate/channels, PCM16 / 32768, mono -> Q = 0, loop at EOF without
+    padding, attenuation; raw() hands out the file's own int16 pairs."""
+    import importlib
+    pkg = importlib.import_module("sdr-j-fm_amd")
+    rng = np.random.default_rng(5)
+    s = rng.integers(-20000, 20000, size=(1000, 2)).astype(np.int16)
+    _write_wav(tmp_path / "a.wav", s, 2304000, "pcm16")
+    src = pkg.WavFileSource(str(tmp_path / "a.wav"))
+    assert src.getRate() == 2304000 and src.numofChannels == 2 and src.samplesinFile == 1000
+    a = src.getSamples(600)
+    assert np.array_equal(a, s[:600].astype(np.float32) / np.float32(32768.0))
+    b = src.getSamples(600)                                   # wraps: 400 from the end, 200 from the start again
+    assert np.array_equal(b, np.concatenate([s[600:], s[:200]]).astype(np.float32) / np.float32(32768.0))
+    assert np.array_equal(src.raw(300), s[200:500])
+    src2 = pkg.WavFileSource(str(tmp_path / "a.wav"), attenuation=0.5)
+    assert np.array_equal(src2.getSamples(10), (s[:10].astype(np.float32) / np.float32(32768.0)) * np.float32(0.5))
+    m = rng.standard_normal((50, 1)).astype(np.float32)
+    _write_wav(tmp_path / "m.wav", m, 192000, "f32")
+    mono = pkg.WavFileSource(str(tmp_path / "m.wav"))
+    v = mono.getSamples(50)
+    assert mono.getRate() == 192000 and np.array_equal(v[:, 0], m[:, 0]) and not v[:, 1].any()
