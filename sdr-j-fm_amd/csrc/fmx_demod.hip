@@ -738,67 +738,76 @@ __global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffe
 // =================================================================================================
 __global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
                                                       int64_t rc0, int chunk_len) {
-    const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
-    __shared__ float2 tLR[64][65];
-    __shared__ float tDEM[64][65];
+    // One block = one work-array tile row: 16 samples x 64 channels, threads as (sample in tile, channel), four elements
+    // per thread.  With that mapping the tiled work arrays AND the channel-major rings are written in 64-byte runs, so
+    // nothing is transposed.  The loads of all four elements are issued before anything is computed, and the SinCos
+    // gathers of all four before they are used (the kernel sits on the PSS loop's critical path: latency, not bandwidth).
+    const int CP = G.pitch;
     const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * 64;
+    const int q0 = blockIdx.x * WT;
     const int c0 = blockIdx.y * 64;
     const int ring = G.ring_mask + 1;
     const float2 *__restrict__ sct = T.sincos;
     const double SC = T.sincos_C;
-    // pass 1: threads as (row in work-array tile, channel): contiguous reads and writes of the tiled work arrays
-    for (int i = 0; i < 16; i++) {
-        const int e = tid + 256 * i;
-        const int ql = (e & 15) + 16 * (e >> 10), cl = (e >> 4) & 63;
-        const int ch = c0 + cl, q = q0 + ql;
-        if (ch < C && q < chunk_len) {
-            const int64_t r = rc0 + q;
-            const ChanParams &P = B.params[ch];
-            const size_t wi = widx(r, ch, (int)CP);
-            const float demod = B.w_dem[wi];
-            const int tag = (B.w_tag[wi] >> 1) - 2;
-            float2 audio = make_float2(demod, 0.f);
-            if (tag != -2) {
-                // phaseforLRDiff fm-processor.cpp:707-714
-                float ph = (float)(2 * ((double)pi_constrain(B.w_cur[wi]) + FMX_PI_4 + 0) - (double)B.w_pdp[wi]);
-                if ((double)ph < -FMX_2PI) ph = (float)((double)ph + 2 * FMX_2PI);
-                ph = (float)fmod_2pi((double)ph);
-                const float2 e = sct[sc_index(sc_wrap(ph), SC)];
-                if (tag >= 0) {
-                    const int64_t ic = B.state[ch].pss_count;
-                    B.sring[(size_t)ch * (G.sring_mask + 1) + ((ic + tag) & G.sring_mask)] = make_float2(e.x * demod, e.y * demod);
-                }
-                const float lut = (P.sound_sel == 6) ? sc_sin(sct, SC, ph) : e.x;
-                audio.y = (float)(2.0 * (double)lut * (double)demod);
-            }
-            const float sumLR = audio.x, diffLR = audio.y;
-            const float dw = diffLR * (P.fm_mode == 1 ? P.panorama : 1.0f);
-            const float left = sumLR + dw, right = sumLR - dw;
-            float2 o;
-            switch (P.sound_sel) {
-            default:
-            case 0: o = make_float2(left, right); break;
-            case 1: o = make_float2(right, left); break;
-            case 2: o = make_float2(left, left); break;
-            case 3: o = make_float2(right, right); break;
-            case 4: o = make_float2(sumLR, sumLR); break;
-            case 5: case 6: o = make_float2(dw, dw); break;
-            }
-            B.w_x[wi] = o;
-            tLR[cl][ql] = audio; tDEM[cl][ql] = demod;
-        }
+    constexpr int EPT = 4;
+    const int ql = tid & 15, q = q0 + ql;
+    const bool qok = q < chunk_len;
+    const int64_t r = rc0 + (qok ? q : chunk_len - 1);            // clamped: loads stay unconditional
+    int ch[EPT]; bool ok[EPT]; size_t wi[EPT];
+    float demod[EPT], cur[EPT], pdp[EPT]; int tag[EPT];
+    int ssel[EPT], fmode[EPT]; float pano[EPT]; int64_t ic[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int cl = (tid >> 4) + 16 * i;
+        ch[i] = c0 + cl; ok[i] = qok && ch[i] < C;
+        const int chc = ch[i] < C ? ch[i] : C - 1;
+        wi[i] = widx(r, chc, CP);
+        demod[i] = B.w_dem[wi[i]]; tag[i] = (B.w_tag[wi[i]] >> 1) - 2; cur[i] = B.w_cur[wi[i]]; pdp[i] = B.w_pdp[wi[i]];
+        const ChanParams &P = B.params[chc];
+        ssel[i] = P.sound_sel; fmode[i] = P.fm_mode; pano[i] = P.panorama;
+        ic[i] = B.state[chc].pss_count;
     }
-    __syncthreads();
-    // pass 2: threads along time -> channel-major tap rings (GUI scope feeds / tests)
-    for (int i = 0; i < 16; i++) {
-        const int cl = (tid >> 6) + 4 * i, ql = tid & 63;
-        const int ch = c0 + cl, q = q0 + ql;
-        if (ch < C && q < chunk_len) {
-            const int64_t j = G.J0 + rc0 + q;
-            B.demod_ring[(size_t)ch * ring + (j & G.ring_mask)] = tDEM[cl][ql];
-            B.lr_ring[(size_t)ch * ring + (j & G.ring_mask)] = tLR[cl][ql];
+    float ph[EPT]; float2 e[EPT]; float sn[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        // phaseforLRDiff fm-processor.cpp:707-714
+        float p = (float)(2 * ((double)pi_constrain(cur[i]) + FMX_PI_4 + 0) - (double)pdp[i]);
+        if ((double)p < -FMX_2PI) p = (float)((double)p + 2 * FMX_2PI);
+        ph[i] = (tag[i] != -2) ? (float)fmod_2pi((double)p) : 0.f;     // (mono: the LUT entry is not used)
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        e[i] = sct[sc_index(sc_wrap(ph[i]), SC)];
+        sn[i] = (ssel[i] == 6) ? sc_sin(sct, SC, ph[i]) : 0.f;    // S_LEFTminusRIGHT_Test only
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        if (!ok[i]) continue;
+        float2 audio = make_float2(demod[i], 0.f);
+        if (tag[i] != -2) {
+            if (tag[i] >= 0)
+                B.sring[(size_t)ch[i] * (G.sring_mask + 1) + ((ic[i] + tag[i]) & G.sring_mask)] = make_float2(e[i].x * demod[i], e[i].y * demod[i]);
+            const float lut = (ssel[i] == 6) ? sn[i] : e[i].x;
+            audio.y = (float)(2.0 * (double)lut * (double)demod[i]);
         }
+        const float sumLR = audio.x, diffLR = audio.y;
+        const float dw = diffLR * (fmode[i] == 1 ? pano[i] : 1.0f);
+        const float left = sumLR + dw, right = sumLR - dw;
+        float2 o;
+        switch (ssel[i]) {
+        default:
+        case 0: o = make_float2(left, right); break;
+        case 1: o = make_float2(right, left); break;
+        case 2: o = make_float2(left, left); break;
+        case 3: o = make_float2(right, right); break;
+        case 4: o = make_float2(sumLR, sumLR); break;
+        case 5: case 6: o = make_float2(dw, dw); break;
+        }
+        B.w_x[wi[i]] = o;
+        // channel-major tap rings (GUI scope feeds / tests): 16 consecutive entries per channel from 16 lanes
+        const int64_t j = G.J0 + rc0 + q;
+        B.demod_ring[(size_t)ch[i] * ring + (j & G.ring_mask)] = demod[i];
+        B.lr_ring[(size_t)ch[i] * ring + (j & G.ring_mask)] = audio;
     }
 }
 // =================================================================================================
@@ -928,7 +937,7 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         hand_over(2, 3, c);
         hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, st[3], T, B, G, C, rc0, len);
         hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, st[3], T, B, G, C, rc0, len);
-        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len);
         hand_over(3, 4, c);
         hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last);
         rc0 += len;
