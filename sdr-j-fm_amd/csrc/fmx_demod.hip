@@ -120,18 +120,18 @@ __device__ __forceinline__ float2 limiter(float2 z) {
 // =================================================================================================
 __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
                                                    int64_t row0, int nrows) {
-    const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
-    __shared__ float tile[64][65];
-    __shared__ float2 sLIM[64][67];                   // limited samples of rows r0-2 .. r0+63 (each is used by up to three outputs)
+    // One block = one work-array tile row: 16 samples x 64 channels (rows row0 + 16 blockIdx.x ...; row0 is a multiple of 16).
+    const int CP = G.pitch;
+    __shared__ float2 sLIM[64][WT + 3];               // limited samples of rows r0-2 .. r0+15 (each is used by up to three outputs)
     const int tid = threadIdx.x;
-    const int64_t nj = row0 + nrows;                  // rows [row0, row0 + nrows) of the call (row0 a multiple of 64)
-    const int64_t r0 = row0 + (int64_t)blockIdx.x * 64;
+    const int64_t nj = row0 + nrows;
+    const int64_t r0 = row0 + (int64_t)blockIdx.x * WT;
     const int c0 = blockIdx.y * 64;
     const int ring = G.ring_mask + 1;
     const bool want_iq = B.w_iq != nullptr;
-    // ---- limiter (fm-demodulator.cpp:119-126), once per sample: threads along time (contiguous ring reads)
-    for (int i = tid; i < 64 * 66; i += 256) {
-        const int cl = i / 66, rl = i - 66 * cl;      // rl 0..65 <-> row r0 - 2 + rl
+    // ---- limiter (fm-demodulator.cpp:119-126), once per sample: 18 consecutive ring entries per channel
+    for (int i = tid; i < 64 * (WT + 2); i += 256) {
+        const int cl = i / (WT + 2), rl = i - (WT + 2) * cl;      // rl 0..17 <-> row r0 - 2 + rl
         const int ch = c0 + cl;
         float2 v = make_float2(0.f, 0.f);
         if (ch < C) {
@@ -146,12 +146,14 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
         sLIM[cl][rl] = v;
     }
     __syncthreads();
-    for (int i = 0; i < 16; i++) {
-        const int cl = (tid >> 6) + 4 * i, rl = tid & 63;
+    // ---- discriminator; threads as (sample in tile, channel): 64-byte runs in the tiled work arrays
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int rl = tid & 15, cl = (tid >> 4) + 16 * i;
         const int ch = c0 + cl;
         const int64_t r = r0 + rl;
-        float res = 0.f;
         if (ch < C && r < nj) {
+            float res = 0.f;
             const float2 cur = sLIM[cl][rl + 2], p1 = sLIM[cl][rl + 1];
             const float I = cur.x, Q = cur.y, I1 = p1.x, Q1 = p1.y;
             const int decoder = B.params[ch].decoder;
@@ -169,18 +171,8 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
             } else if (decoder != 2) {     // MIXED :168-172 (COMPLEX_BB :174-177 is bitwise the same)
                 res = lut_atan2(T.atan_ppy, Q * I1 - I * Q1, I * I1 + Q * Q1);
             }
-        }
-        tile[cl][rl] = res;
-    }
-    __syncthreads();
-    for (int i = 0; i < 16; i++) {                    // threads as (row in work-array tile, channel): contiguous stores
-        const int e = tid + 256 * i;
-        const int rl = (e & 15) + 16 * (e >> 10), cl = (e >> 4) & 63;
-        const int ch = c0 + cl;
-        const int64_t r = r0 + rl;
-        if (ch < C && r < nj) {
-            B.w_dem[widx(r, ch, CP)] = tile[cl][rl];
-            if (want_iq) B.w_iq[widx(r, ch, CP)] = sLIM[cl][rl + 2];
+            B.w_dem[widx(r, ch, CP)] = res;
+            if (want_iq) B.w_iq[widx(r, ch, CP)] = cur;
         }
     }
 }
@@ -925,7 +917,7 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         const int last = (rc0 + len >= nj) ? 1 : 0;
         // the discriminator runs per chunk in front of the AFC (a stage with time to spare), so the first PSS kernel
         // starts after 256 rows of it instead of after the whole call's
-        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, st[0], T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[0], T, B, G, C, rc0, len);
         if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
         else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
         hand_over(0, 1, c);
