@@ -867,25 +867,19 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
 // =================================================================================================
 // B9  work array -> channel-major d ring   (transpose)
 // =================================================================================================
-__global__ __launch_bounds__(256) void dring_kernel(DeviceBuffers B, CallGeom G, int C) {
-    const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
-    __shared__ float2 tile[64][65];
+__global__ __launch_bounds__(256) void dring_kernel(DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows) {
+    // one block = one work-array tile row (16 samples x 64 channels); threads as (sample in tile, channel): 128-byte runs on
+    // both sides, nothing to transpose
+    const int CP = G.pitch;
     const int tid = threadIdx.x;
-    const int64_t nj = G.J1 - G.J0;
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int64_t r = row0 + (int64_t)blockIdx.x * WT + (tid & 15);
     const int c0 = blockIdx.y * 64;
-    for (int i = 0; i < 16; i++) {                    // threads as (row in work-array tile, channel): contiguous reads
-        const int e = tid + 256 * i;
-        const int rl = (e & 15) + 16 * (e >> 10), cl = (e >> 4) & 63;
-        const int ch = c0 + cl; const int64_t r = r0 + rl;
-        if (ch < C && r < nj) tile[cl][rl] = B.w_x[widx(r, ch, (int)CP)];
-    }
-    __syncthreads();
     const int dcap = G.dring_mask + 1;
-    for (int i = 0; i < 16; i++) {
-        const int cl = (tid >> 6) + 4 * i, rl = tid & 63;
-        const int ch = c0 + cl; const int64_t r = r0 + rl;
-        if (ch < C && r < nj) B.dring[(size_t)ch * dcap + ((G.J0 + r) & G.dring_mask)] = tile[cl][rl];
+    if (r >= row0 + nrows) return;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int ch = c0 + (tid >> 4) + 16 * i;
+        if (ch < C) B.dring[(size_t)ch * dcap + ((G.J0 + r) & G.dring_mask)] = B.w_x[widx(r, ch, CP)];
     }
 }
 
@@ -932,9 +926,9 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len);
         hand_over(3, 4, c);
         hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last);
+        hipLaunchKernelGGL(dring_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[4], B, G, C, rc0, len);
         rc0 += len;
     }
-    hipLaunchKernelGGL(dring_kernel, tiles, dim3(256), 0, s3, B, G, C);
     if (s3 != s) { (void)hipEventRecord(DS.join, s3); (void)hipStreamWaitEvent(s, DS.join, 0); }
 }
 
