@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B
     if (ch >= C) return;
     ChanState *st = B.state + ch;
     const float gain = T.pil_gain, omega = T.pil_omega;
-    const double SC = T.sincos_C;
+    const double SC = T.sincos_C, SC256 = T.sincos_C * (1.0 / 256.0);
     const float P32 = 6.2831855f, C32 = T.wrap32_c;              // fl32 just above 2 pi; fl32(P32 - 2 pi)
     float phase = st->pil_phase;
     if (!(phase >= 0.f)) phase = pi_constrain(phase);             // cannot happen (see above); keeps the invariant anyway
@@ -345,10 +345,14 @@ __global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B
     const float *wd = B.w_dem + ro; float *wc = B.w_cur + ro; float *wo = B.w_osc + ro;
     auto step = [&](float demod, float &o_cur, float &o_osc) {
         // SinCos::getSin sincos.cpp:81-85 with phase >= 0
-        int idx = (int)((double)phase * SC);
+        const double pd = (double)phase;
+        int idx = (int)(pd * SC);
         float osc;
         if (T2) {
-            const double2 ea = sA[idx >> 8], eb = sB[idx & 255];
+            // idx >> 8 straight from the product: p * (SC/256) == (p * SC) / 256 exactly (power-of-two scaling), and
+            // trunc(x / 256) == trunc(x) >> 8 for x >= 0 -- one operation less on the dependent chain than shift + shift
+            const int ia = (int)(pd * SC256);
+            const double2 ea = sA[ia], eb = sB[idx & 255];
             osc = (float)(ea.y * eb.x + ea.x * eb.y);
         } else {
             idx = (idx >= SINCOS_N) ? idx - SINCOS_N : idx;
