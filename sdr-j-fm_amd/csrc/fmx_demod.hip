@@ -291,13 +291,23 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
     constexpr int UB = SEQ_UB;
     const int nfull = chunk_len / UB;
     const int TS = UB * CP;                                       // elements from one tile of this channel to the next
-    float nx[2][PD][UB]; float2 nq[PLLDEC ? 2 : 1][PLLDEC ? PD : 1][UB];
+    // (prefetch registers as plain float arrays: loop-carried arrays of HIP's float2 struct end up in scratch memory)
+    float nx[2][PD][UB]; float nqa[PLLDEC ? 2 : 1][PLLDEC ? PD : 1][UB], nqb[PLLDEC ? 2 : 1][PLLDEC ? PD : 1][UB];
     tile_pipeline(nfull,
-        [&](int s, int u, int tl) { wld(nx[s][u], wd + tl * TS); if (PLLDEC) wld2(nq[PLLDEC ? s : 0][PLLDEC ? u : 0], wiq + tl * TS); },
-        [&](int s, int u, int tb) {
+        [&](int s, int u, int tl) __attribute__((always_inline)) {
+            wld(nx[s][u], wd + tl * TS);
+            if (PLLDEC) { const float *qp = reinterpret_cast<const float *>(wiq + tl * TS); wld(nqa[PLLDEC ? s : 0][PLLDEC ? u : 0], qp); wld(nqb[PLLDEC ? s : 0][PLLDEC ? u : 0], qp + UB); }
+        },
+        [&](int s, int u, int tb) __attribute__((always_inline)) {
             float x[UB]; float2 xq[UB];
 #pragma unroll
-            for (int k = 0; k < UB; k++) { x[k] = nx[s][u][k]; xq[k] = PLLDEC ? nq[PLLDEC ? s : 0][PLLDEC ? u : 0][k] : make_float2(0.f, 0.f); }
+            for (int k = 0; k < UB; k++) {
+                x[k] = nx[s][u][k];
+                const int ss = PLLDEC ? s : 0, uu = PLLDEC ? u : 0;
+                xq[k] = !PLLDEC ? make_float2(0.f, 0.f)
+                        : (k < UB / 2 ? make_float2(nqa[ss][uu][2 * k], nqa[ss][uu][2 * k + 1])
+                                      : make_float2(nqb[ss][uu][(2 * k) % UB], nqb[ss][uu][(2 * k) % UB + 1]));
+            }
 #pragma unroll
             for (int k = 0; k < UB; k++) x[k] = step(x[k], xq[k]);
             wst(wd + tb * TS, x);
@@ -370,8 +380,8 @@ __global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B
     const int TS = SEQ_UB * CP;
     float nx[2][PD][SEQ_UB];
     tile_pipeline(nfull,
-        [&](int s, int u, int tl) { wld(nx[s][u], wd + tl * TS); },
-        [&](int s, int u, int tb) {
+        [&](int s, int u, int tl) __attribute__((always_inline)) { wld(nx[s][u], wd + tl * TS); },
+        [&](int s, int u, int tb) __attribute__((always_inline)) {
             float x[SEQ_UB], oc[SEQ_UB], oo[SEQ_UB];
 #pragma unroll
             for (int k = 0; k < SEQ_UB; k++) x[k] = nx[s][u][k];
@@ -430,8 +440,8 @@ __global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers 
     float nd[2][PD][UB], no[2][PD][UB];
     __shared__ float sLd[UB][64], sLo[UB][64];
     tile_pipeline(nfull,
-        [&](int s, int u, int tl) { wld(nd[s][u], wd + tl * TS); wld(no[s][u], wo + tl * TS); },
-        [&](int s, int u, int tb) {
+        [&](int s, int u, int tl) __attribute__((always_inline)) { wld(nd[s][u], wd + tl * TS); wld(no[s][u], wo + tl * TS); },
+        [&](int s, int u, int tb) __attribute__((always_inline)) {
             float d[UB], o[UB]; int pk[UB];
 #pragma unroll
             for (int k = 0; k < UB; k++) { d[k] = nd[s][u][k]; o[k] = no[s][u][k]; }
@@ -660,8 +670,8 @@ __global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffe
     __shared__ float sEr[ACC_UB][64];
     const float c4 = 0.785398185253143310546875f;
     tile_pipeline(nfull,
-        [&](int g, int u, int tl) { wld(nt[g][u], tg + tl * TS); wld(ne[g][u], err + tl * TS); },
-        [&](int g, int u, int tb) {
+        [&](int g, int u, int tl) __attribute__((always_inline)) { wld(nt[g][u], tg + tl * TS); wld(ne[g][u], err + tl * TS); },
+        [&](int g, int u, int tb) __attribute__((always_inline)) {
             float e[ACC_UB]; float o[ACC_UB];
             unsigned andv = ~0u, orv = 0u; int minv = 0x7fffffff;
 #pragma unroll
@@ -826,8 +836,8 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
     const int TS = UB * CP;
     float2 nx[2][PD][UB];
     tile_pipeline(nfull,
-        [&](int s, int u, int tl) { wld2(nx[s][u], x + tl * TS); },
-        [&](int s, int u, int tb) {
+        [&](int s, int u, int tl) __attribute__((always_inline)) { wld2(nx[s][u], x + tl * TS); },
+        [&](int s, int u, int tb) __attribute__((always_inline)) {
             float2 v[UB];
 #pragma unroll
             for (int k = 0; k < UB; k++) v[k] = nx[s][u][k];
