@@ -425,7 +425,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         p.stream = s;
         // constructor defaults fm-processor.cpp:110-160 / fm-demodulator.cpp:66
         p.fm_mode = 0; p.sound_sel = 0; p.decoder = 3; p.auto_mono = 1; p.pss_active = 1; p.dc_remove = 1;
-        p.rds_mode = 0; p.lo_freq = 0; p.att_l = 1.f; p.att_r = 1.f;
+        p.rds_mode = 0; p.lo_freq = 0; p.lo_period = 0; p.att_l = 1.f; p.att_r = 1.f;
         refresh_derived(h, c);
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -630,7 +630,14 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         case FMX_P_ATTENUATION_L: p.att_l = (float)value; break;
         case FMX_P_ATTENUATION_R: p.att_r = (float)value; break;
         case FMX_P_RDS_MODE: p.rds_mode = iv; break;
-        case FMX_P_LOCAL_OSCILLATOR: p.lo_freq = iv; break;
+        case FMX_P_LOCAL_OSCILLATOR: {
+            p.lo_freq = iv;
+            int64_t a = iv < 0 ? -(int64_t)iv : iv, b = h->cfg.inputRate;
+            while (b) { const int64_t r = a % b; a = b; b = r; }                  // gcd(|lo|, inputRate)
+            const int64_t per = a ? h->cfg.inputRate / a : 0;
+            p.lo_period = (iv != 0 && per <= LO_LDS_MAX) ? (int32_t)per : 0;
+            break;
+        }
         case FMX_P_AUTO_MONO: p.auto_mono = iv != 0; break;
         case FMX_P_PSS: p.pss_active = iv != 0; break;
         case FMX_P_DC_REMOVE: p.dc_remove = iv != 0; p.actions |= ACT_DC_RESET; break;

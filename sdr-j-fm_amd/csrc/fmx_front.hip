@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
     constexpr int BPS = (FMT == 0) ? 8 : (FMT == 3 ? 4 : 2);          // bytes per complex sample
     __shared__ __attribute__((aligned(16))) float4 Xall[4][XUNITS];       // one image per wave (62208 B)
     __shared__ __attribute__((aligned(16))) float sT[A_TAPS_DEV];          // the channel's tap set Trd[r][d]
+    __shared__ float2 sLO[LO_LDS_MAX];                                     // one period of the LO (when the channel's lo has a short one)
     __shared__ float carry[8][2];                                          // DC state after tile ti, slot = ti & 7
     __shared__ int carry_seq;                                              // tiles whose carry is published
     __shared__ int hist_seq[4], free_seq[4];                               // per wave image: history of tile (n-1) is in / tile (n-1) is done
@@ -154,6 +155,16 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
     const int lo_phase0 = st->lo_phase;
     const bool dc_rst = (P.actions & ACT_DC_RESET) != 0;          // setDCRemove zeroes RfDC (:922-925)
     const float dc0r = dc_rst ? 0.f : st->dc_re, dc0i = dc_rst ? 0.f : st->dc_im;
+    // ---- LO mix table: LOPhase after sample i of the call is (P0 - (i+1) lo) mod R; when lo / R has a short period p
+    //      (channels on a raster: 200 kHz at 2.304 MS/s gives p = 288) the p table entries the call will use sit in LDS,
+    //      sLO[m] = T[(P0 - m lo) mod R] with m = (i + 1) mod p, instead of 24 scattered reads of the 18 MB table per lane
+    //      and tile
+    const int lo_per = (P.lo_freq != 0 && T.lo_table != nullptr) ? P.lo_period : 0;
+    for (int m = t; m < lo_per; m += 256) {
+        long long ph = ((long long)lo_phase0 - (long long)m * (long long)P.lo_freq) % (long long)G.input_rate;
+        if (ph < 0) ph += G.input_rate;
+        sLO[m] = T.lo_table[ph];
+    }
     __syncthreads();                                  // the only workgroup barrier: tables and counters are set up
 
     const bool dcr = P.dc_remove != 0;
@@ -391,18 +402,31 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
             }
             if (mix && lastp1 > first) {
                 // LOPhase after sample i (0-based within the call) = (P0 - (i+1)*lo) mod R
-                const long long i1 = (long long)(base + first - g0) + 1;
-                const long long m = (i1 * (long long)lo) % (long long)R;
-                int ph = (int)(((long long)lo_phase0 - m) % (long long)R);
-                if (ph < 0) ph += R;
+                if (lo_per > 0) {
+                    int m = (int)((unsigned)(base + first - g0 + 1) % (unsigned)lo_per);
 #pragma unroll
-                for (int k = 0; k < SPT; k++) {
-                    if (k >= first && k < lastp1) {
-                        const float2 w = T.lo_table[ph];
-                        const v2f v = x[k];
-                        x[k] = (v2f){v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x};
-                        ph -= lo;
-                        if (ph < 0) ph += R; else if (ph >= R) ph -= R;
+                    for (int k = 0; k < SPT; k++) {
+                        if (k >= first && k < lastp1) {
+                            const float2 w = sLO[m];
+                            const v2f v = x[k];
+                            x[k] = (v2f){v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x};
+                            m = (m + 1 == lo_per) ? 0 : m + 1;
+                        }
+                    }
+                } else {
+                    const long long i1 = (long long)(base + first - g0) + 1;
+                    const long long m = (i1 * (long long)lo) % (long long)R;
+                    int ph = (int)(((long long)lo_phase0 - m) % (long long)R);
+                    if (ph < 0) ph += R;
+#pragma unroll
+                    for (int k = 0; k < SPT; k++) {
+                        if (k >= first && k < lastp1) {
+                            const float2 w = T.lo_table[ph];
+                            const v2f v = x[k];
+                            x[k] = (v2f){v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x};
+                            ph -= lo;
+                            if (ph < 0) ph += R; else if (ph >= R) ph -= R;
+                        }
                     }
                 }
             }

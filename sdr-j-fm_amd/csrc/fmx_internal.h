@@ -47,6 +47,7 @@ struct ChanParams {
     int32_t front_set, audio_set;
     int32_t fm_mode, sound_sel, decoder, auto_mono, pss_active, dc_remove, rds_mode;
     int32_t lo_freq;
+    int32_t lo_period;   // inputRate / gcd(|lo_freq|, inputRate) when <= LO_LDS_MAX (the LO phase sequence repeats), else 0
     float   att_l, att_r;
     float   deemph_alpha, volume, left_ch, right_ch, panorama;
     int32_t actions;     // one-shot ACT_* bits consumed by the kernels of the next call
@@ -86,6 +87,7 @@ struct ChanState {
 // consecutive fm samples per channel.  A lane-per-channel recurrence kernel moves its 16 samples with four dwordx4
 // operations (64 contiguous bytes per lane), a time-parallel kernel maps threads as (row-in-tile fastest, channel next)
 // and stays fully coalesced (1 KB contiguous per 64 channels).
+constexpr int LO_LDS_MAX = 1024;       // LO phase periods up to this are tabulated in LDS by the input-FIR kernel
 constexpr int WT = 16;
 __host__ __device__ __forceinline__ size_t widx(int64_t r, int ch, int pitch) {
     return ((size_t)(r >> 4) * (size_t)pitch + (size_t)ch) * WT + (size_t)(r & 15);
