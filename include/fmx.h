@@ -58,7 +58,7 @@ typedef struct {
 typedef enum {
     FMX_P_FM_MODE = 1,         /* setfmMode: 0 Stereo, 1 StereoPano, 2 Mono          (:241-243)  */
     FMX_P_FM_DECODER = 2,      /* fm_Demodulator::setDecoder: 1 AM 2 PLL 3 Mixed 4 ComplexBB 5 RealBB 6 Diff
-                                  (fm-demodulator.cpp:27-44,93-103); AM is FMX_E_UNSUPPORTED */
+                                  (fm-demodulator.cpp:27-44,93-103,215-241) */
     FMX_P_SOUND_MODE = 3,      /* setSoundMode: Channels enum 0..6                   (:273-275)  */
     FMX_P_STEREO_PANORAMA = 4, /* setStereoPanorama 0..200                           (:277-280)  */
     FMX_P_SOUND_BALANCE = 5,   /* setSoundBalance -100..100                          (:282-286)  */

@@ -300,7 +300,7 @@ int flush_mailbox(fmx_handle h) {
         if (h->rds_start < 0) h->rds_start = h->g_total / DECIM;       // the RDS filters start counting here (all channels)
     }
     bool any_pll = false;
-    for (auto &p : h->params) any_pll |= (p.decoder == 2);
+    for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1);     // both run pllC on the fm-rate IQ
     if (any_pll && !h->B.w_iq) {
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMalloc(&h->B.w_iq, sizeof(float2) * (size_t)h->work_nj * h->pitch));
@@ -591,8 +591,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     switch (id) {
     case FMX_P_FM_MODE: if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "fm mode must be 0..2"); break;
     case FMX_P_FM_DECODER:
-        if (iv == 1) return fail(FMX_E_UNSUPPORTED, "AM decoder is not part of the FM hot path");
-        if (iv < 2 || iv > 6) return fail(FMX_E_INVALID, "decoder must be 2..6"); break;
+        if (iv < 1 || iv > 6) return fail(FMX_E_INVALID, "decoder must be 1..6"); break;
     case FMX_P_SOUND_MODE: if (iv < 0 || iv > 6) return fail(FMX_E_INVALID, "sound mode must be 0..6"); break;
     case FMX_P_STEREO_PANORAMA: if (iv < 0 || iv > 200) return fail(FMX_E_INVALID, "panorama must be 0..200"); break;
     case FMX_P_SOUND_BALANCE: if (iv < -100 || iv > 100) return fail(FMX_E_INVALID, "balance must be -100..100"); break;

@@ -140,8 +140,13 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
             const int64_t jj = G.J0 + r0 - 2 + rl;
             // z[j'] is 0 before the filter latency has elapsed; the demodulator's initial Imin/Qmin is 0.01
             // (fm-demodulator.cpp:79-82)
-            if (jj < 0) v = make_float2((float)0.01, (float)0.01);
-            else { const int64_t s = jj - delay; v = limiter(s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f)); }
+            const bool am = B.params[ch].decoder == 1;      // the AM decoder works on the unlimited sample (fm-demodulator.cpp:133-134)
+            if (jj < 0) v = am ? make_float2(0.f, 0.f) : make_float2((float)0.01, (float)0.01);
+            else {
+                const int64_t s = jj - delay;
+                const float2 z = s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f);
+                v = am ? z : limiter(z);
+            }
         }
         sLIM[cl][rl] = v;
     }
@@ -157,7 +162,9 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
             const float2 cur = sLIM[cl][rl + 2], p1 = sLIM[cl][rl + 1];
             const float I = cur.x, Q = cur.y, I1 = p1.x, Q1 = p1.y;
             const int decoder = B.params[ch].decoder;
-            if (decoder == 5) {            // REAL_BB fm-demodulator.cpp:174-182
+            if (decoder == 1) {            // AM: |z| for decodeAM (:215-241); the carrier IIR and the PLL run in afc_kernel
+                res = (float)sqrt((double)cur.x * (double)cur.x + (double)cur.y * (double)cur.y);
+            } else if (decoder == 5) {     // REAL_BB fm-demodulator.cpp:174-182
                 res = (float)((double)(I1 * Q - Q1 * I + 1) / 2.0);
                 int index = (int)floorf(res * (float)ARCSINE_N);
                 if (index < 0) index = 0;
@@ -263,7 +270,8 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= C) return;
     ChanState *st = B.state + ch;
-    const bool use_pll = PLLDEC && (B.params[ch].decoder == 2);
+    const bool use_pll = PLLDEC && (B.params[ch].decoder == 2), use_am = PLLDEC && (B.params[ch].decoder == 1);
+    float am = st->am_carr;
     const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha, K = T.K_FM, rK = T.K_FM_rcp;
     const double SC = T.sincos_C;
     float afc = st->fm_afc, nco_phase = st->nco_phase, incr = st->phase_incr;
@@ -272,7 +280,8 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
     const float2 *wiq = PLLDEC ? B.w_iq + ro : nullptr;
     auto step = [&](float res, float2 sig) -> float {
         if (PLLDEC) {
-            if (use_pll) {                           // pllC::do_pll pllC.cpp:67-90
+            if (use_am) am = (1.0f - 0.0010f) * am + 0.0010f * res;      // am_carr_ampl, carrierAlpha (fm-demodulator.cpp:117,130-131)
+            if (use_pll || use_am) {                 // pllC::do_pll pllC.cpp:67-90 (AM: on the unlimited sample, :222)
                 const float2 nco = sc_complex(T.sincos, SC, nco_phase);
                 const float dre = nco.x * sig.x - (-nco.y) * sig.y;      // conj(nco) * signal
                 const float dim = nco.x * sig.y + (-nco.y) * sig.x;
@@ -282,6 +291,13 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
                 nco_phase += incr;
                 if ((double)nco_phase >= FMX_2PI) nco_phase = (float)fmod_2pi((double)nco_phase);
                 else while (nco_phase < 0) nco_phase = (float)((double)nco_phase + FMX_2PI);
+                if (use_am) {                        // decodeAM fm-demodulator.cpp:215-241
+                    afc = c1 * afc + fmDcAlpha * incr;
+                    const float gainLimit = 0.01f;
+                    float r = (res - am) / (am < gainLimit ? gainLimit : am);
+                    if (r > 1.0f) r = 1.0f; else if (r < -1.0f) r = -1.0f;
+                    return r;
+                }
                 res = incr;
             }
         }
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
         for (int k = 0; k < chunk_len - nfull * UB; k++)          // ragged end of a call: rows of the last, partial tile
             wdt[k] = step(wdt[k], PLLDEC ? wiqt[k] : make_float2(0.f, 0.f));
     }
-    st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr;
+    st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr; st->am_carr = am;
 }
 
 // ---- B3.  The pilot PLL: the longest dependent chain of the path (phase -> LUT index -> sine -> phase).  One wave

@@ -214,6 +214,33 @@ def test_decoders(fmx_amd, ol, decoder):
     assert d <= 5e-5 and rms(pcm_g - pcm_o) <= PCM_RMS_TOL
 
 
+def test_am_decoder(fmx_amd, ol):
+    """setFMdecoder("AM") (fm-demodulator.cpp:215-241): envelope / carrier IIR, with the PLL tracking the
+    unlimited sample for the AFC read-out.  An AM carrier at +15 kHz, 50 % depth 1 kHz tone, plus noise;
+    fed in three blocks so the carrier IIR, the PLL state and fm_afc cross call boundaries."""
+    n = 16384 * 12 * 3
+    t = np.arange(n) / 2304000.0
+    rng = np.random.default_rng(5)
+    env = 0.4 * (1 + 0.5 * np.sin(2 * np.pi * 1000 * t))
+    z = env * np.exp(2j * np.pi * 15000 * t) + 0.003 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    iq = np.stack([z.real, z.imag], 1).astype(np.float32)
+    o = ol.OracleChain(taps=[ol.TAP_DEMOD], inputFilterBw=0, decoder=1, fmMode=2, tap_seconds=0.3)
+    pcm_o = o.process(iq)
+    f = fmx_amd.Fmx(2, max_block=n // 3)
+    gui_defaults(f, bw=0, decoder=1, stereo=False)
+    f.set_param(M.P_FM_DECODER, 3, 1)                 # channel 1 stays an FM channel next to the AM one
+    pcm = run_blocks(f, np.stack([iq, iq]), n // 3)
+    nb = n // 36                                      # fm-rate samples of the last call
+    d_o = o.tap(ol.TAP_DEMOD)[2 * nb:3 * nb]
+    d = rms(f.tap(M.TAP_DEMOD, nb) - d_o)
+    o3 = ol.OracleChain(inputFilterBw=0, decoder=3, fmMode=2)
+    print(f"\n[AM] demod rms {d:.3e} (signal {rms(d_o):.3e}) pcm rms {rms(pcm[0] - pcm_o):.3e}")
+    assert rms(d_o) > 0.1                             # the tone is there
+    assert d <= 5e-5 and rms(pcm[0] - pcm_o) <= PCM_RMS_TOL
+    assert rms(pcm[1] - o3.process(iq)) <= PCM_RMS_TOL
+    assert abs(f.meta(0).DcValIf - o.meta().dcValIf) <= 2e-6          # AFC read-out: the PLL's phase increment, IIR-smoothed
+
+
 @pytest.mark.parametrize("kw,setp", [
     (dict(fmMode=1, panorama=150), [(M.P_FM_MODE, 1), (M.P_STEREO_PANORAMA, 150)]),
     (dict(soundSelector=1), [(M.P_SOUND_MODE, 1)]),
@@ -333,7 +360,7 @@ def test_edge_inputs(fmx_amd, ol):
 
 def test_error_behaviour(fmx_amd):
     f = fmx_amd.Fmx(2, max_block=16384)
-    for pid, v, code in [(M.P_FM_MODE, 3, M.FMX_E_INVALID), (M.P_FM_DECODER, 1, M.FMX_E_UNSUPPORTED),
+    for pid, v, code in [(M.P_FM_MODE, 3, M.FMX_E_INVALID), (M.P_FM_DECODER, 0, M.FMX_E_INVALID),
                          (M.P_FM_DECODER, 9, M.FMX_E_INVALID), (M.P_DEEMPHASIS, 0, M.FMX_E_INVALID),
                          (M.P_SQUELCH_MODE, 1, M.FMX_E_UNSUPPORTED), (M.P_RDS_MODE, 1, M.FMX_E_UNSUPPORTED),
                          (M.P_RDS_MODE, 3, M.FMX_E_UNSUPPORTED), (M.P_RDS_MODE, 4, M.FMX_E_INVALID),
