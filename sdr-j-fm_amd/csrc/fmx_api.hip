@@ -49,6 +49,9 @@ struct fmx_handle_s {
     int channels = 0, streams = 0;
     hipStream_t stream = nullptr;
     hipStream_t s_side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the stage-B chunk pipeline
+    hipStream_t s_r = nullptr, s_t[2] = {nullptr, nullptr};          // persistent layout of stage B: CU-masked streams
+    DemodSync *d_sync = nullptr;
+    bool partitioned = false; int ev_next = 0;
     std::vector<hipEvent_t> evs; hipEvent_t ev_join = nullptr;
     std::mutex mtx;                          // guards the mailbox (set_param from any thread)
     std::vector<ChanUser> user;
@@ -353,6 +356,8 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         DemodStreams DS{};
         for (int i = 0; i < 4; i++) DS.side[i] = serial ? nullptr : h->s_side[i];
         DS.ev = h->evs.data(); DS.nev = (int)h->evs.size(); DS.join = h->ev_join;
+        DS.rs = h->s_r; DS.ts[0] = h->s_t[0]; DS.ts[1] = h->s_t[1]; DS.sync = h->d_sync;
+        DS.partitioned = (h->partitioned && !serial) ? 1 : 0; DS.ev_next = &h->ev_next;
         launch_demod(h->T, h->B, G, h->channels, s, DS);
     }
     if (h->rds_alloc && h->rds_start >= 0) {
@@ -392,6 +397,30 @@ int prof_drain(fmx_handle h) {
 
 }  // namespace
 
+// ---- diagnostics: the practical HBM ceiling (SURVEY 8d asks for the measured device-copy bandwidth next to the nominal 8 TB/s)
+namespace fmx {
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// mode 0: dst[i] = src[i] (float2 copy, 16 B per lane per access);  mode 1: stage A's traffic shape: read 12 float2, write 1.
+template <int MODE>
+__global__ __launch_bounds__(256) void stream_probe_kernel(const f32x4_t *__restrict__ src, f32x4_t *__restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (MODE == 0) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    } else {
+        // each lane reads 6 x 16 B (12 float2) spaced a wave apart (coalesced), sums, and writes one float2 per 12 read
+        const size_t ngroups = n16 / (6 * 64);
+        const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = stride >> 6;
+        const int lane = threadIdx.x & 63;
+        for (size_t g = wave; g < ngroups; g += nwaves) {
+            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 6; k++) a += __builtin_nontemporal_load(src + (g * 6 + k) * 64 + lane);
+            reinterpret_cast<float2 *>(dst)[g * 64 + lane] = make_float2(a.x + a.z, a.y + a.w);
+        }
+    }
+}
+}  // namespace fmx
+
 extern "C" {
 
 int fmx_abi_version(void) { return FMX_ABI_VERSION; }
@@ -430,7 +459,37 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto &ss : h->s_side) HIPCHK(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
-    h->evs.resize(128);
+    {
+        // Persistent layout of stage B (fmx_demod.hip launch_demod_persistent) from FMX_PERSISTENT_MIN_CHANNELS channels on
+        // (default 1; 0 = never): the recurrence kernel gets a CU set of its own, big enough to hold all its wavefronts
+        // at once (they wait for each other), the time-parallel kernels the other CUs.  Mask bit i is CU i / 8 of XCD i % 8.
+        const char *e1 = getenv("FMX_PERSISTENT_MIN_CHANNELS");
+        const int minch = e1 ? atoi(e1) : 1;
+        hipDeviceProp_t prop{};
+        HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+        const int ncu = prop.multiProcessorCount;
+        const int groups = (h->channels + 63) / 64;
+        // every wavefront of the recurrence kernel must be resident at once (they wait for each other): count five per CU
+        // (LDS and VGPRs allow eight; the dispatcher does not pack CUs completely), one spare CU per XCD, and check the runtime's own occupancy figure agrees
+        const int occ = recurrences_blocks_per_cu();
+        const char *e3 = getenv("FMX_RECURRENCE_WAVES_PER_CU");
+        const int per_cu = std::min(occ, e3 ? std::max(1, atoi(e3)) : 5);
+        if (getenv("FMX_DEBUG_LAYOUT")) fprintf(stderr, "[fmx] recurrence kernel occupancy %d blocks/CU, %d groups\n", occ, groups);
+        if (minch > 0 && h->channels >= minch && ncu >= 64 && ncu <= 1024 && per_cu > 0) {
+            int rcus = (PB_ROLES * groups + per_cu - 1) / per_cu;
+            rcus = std::max(16, (rcus + 7) / 8 * 8 + 8);
+            if (rcus <= ncu * 3 / 4) {
+                std::vector<uint32_t> mr((ncu + 31) / 32, 0u), mt((ncu + 31) / 32, 0u);
+                for (int i = 0; i < ncu; i++) (i < rcus ? mr : mt)[i / 32] |= 1u << (i % 32);
+                bool ok = hipExtStreamCreateWithCUMask(&h->s_r, (uint32_t)mr.size(), mr.data()) == hipSuccess;
+                for (auto &ss : h->s_t) ok = ok && hipExtStreamCreateWithCUMask(&ss, (uint32_t)mt.size(), mt.data()) == hipSuccess;
+                ok = ok && hipMalloc(&h->d_sync, sizeof(DemodSync) + sizeof(int) * PB_ROLES * groups) == hipSuccess;
+                (void)hipGetLastError();
+                h->partitioned = ok;             // otherwise the event-driven layout is used
+            }
+        }
+    }
+    h->evs.resize(512);
     for (auto &e : h->evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
 
@@ -578,6 +637,9 @@ int fmx_destroy(fmx_handle h) {
     for (auto &e : h->evs) (void)hipEventDestroy(e);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto &ss : h->s_side) if (ss) (void)hipStreamDestroy(ss);
+    if (h->s_r) (void)hipStreamDestroy(h->s_r);
+    for (auto &ss : h->s_t) if (ss) (void)hipStreamDestroy(ss);
+    if (h->d_sync) (void)hipFree(h->d_sync);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FMX_OK;
@@ -708,6 +770,15 @@ int fmx_synchronize(fmx_handle h) {
     if (!h) return fail(FMX_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
+    if (h->partitioned && h->d_sync) {          // a stalled stage-B pipeline gives up instead of hanging (fmx_demod.hip pb_wait)
+        int ab[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpy(ab, h->d_sync, sizeof(ab), hipMemcpyDeviceToHost));
+        if (ab[0]) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "stage B pipeline stalled (waiter %d needed %d, saw %d): the call's output is invalid", ab[1], ab[2], ab[3]);
+            return fail(FMX_E_HIP, msg);
+        }
+    }
     return FMX_OK;
 }
 
@@ -816,6 +887,49 @@ int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32
     if (cnt > capacity) return fail(FMX_E_TOO_LARGE, "capacity too small");
     std::memcpy(dst, src, sizeof(float) * cnt);
     *n = cnt;
+    return FMX_OK;
+}
+
+// diagnostics (not part of include/fmx.h): streaming bandwidth of this GPU in GB/s over `bytes` of float2 data, the mean of
+// `iters` launches timed with HIP events.  mode 0: copy (counts bytes read + written); mode 1: read 12, write 1 (stage A's shape).
+int fmx_debug_stream_bandwidth(int32_t device, int32_t mode, int64_t bytes, int32_t iters, double *gbps) {
+    if (!gbps || bytes < (1 << 20) || iters < 1 || (mode != 0 && mode != 1)) return fail(FMX_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(device));
+    const size_t n16 = (size_t)bytes / 16 / (6 * 64) * (6 * 64);
+    fmx::f32x4_t *src = nullptr, *dst = nullptr;
+    HIPCHK(hipMalloc(&src, n16 * 16));
+    if (hipMalloc(&dst, mode == 0 ? n16 * 16 : n16 * 16 / 12 + 64) != hipSuccess) { (void)hipFree(src); return fail(FMX_E_HIP, "hipMalloc"); }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemset(src, 0, n16 * 16));
+    const int grid = 256 * 8;
+    for (int it = -2; it < iters; it++) {
+        if (it == 0) HIPCHK(hipEventRecord(e0, 0));
+        if (mode == 0) hipLaunchKernelGGL(fmx::stream_probe_kernel<0>, dim3(grid), dim3(256), 0, 0, src, dst, n16);
+        else hipLaunchKernelGGL(fmx::stream_probe_kernel<1>, dim3(grid), dim3(256), 0, 0, src, dst, n16);
+    }
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    const double moved = mode == 0 ? 2.0 * n16 * 16 : n16 * 16 * (1.0 + 1.0 / 12);
+    *gbps = moved * iters / (ms * 1e-3) * 1e-9;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(src); (void)hipFree(dst);
+    return FMX_OK;
+}
+
+// diagnostics (not part of include/fmx.h): the progress words of the persistent stage-B layout after a device synchronise
+int fmx_debug_sync_dump(fmx_handle h, int32_t *out, int32_t capacity, int32_t *n) {
+    if (!h || !out || !n) return fail(FMX_E_INVALID, "null argument");
+    *n = 0;
+    if (!h->partitioned || !h->d_sync) return FMX_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    const int groups = (h->channels + 63) / 64;
+    const int words = (int)(sizeof(DemodSync) / sizeof(int)) + PB_ROLES * groups;
+    const int m = std::min(words, (int)capacity);
+    HIPCHK(hipMemcpy(out, h->d_sync, sizeof(int) * m, hipMemcpyDeviceToHost));
+    *n = m;
     return FMX_OK;
 }
 

@@ -84,29 +84,28 @@ __device__ __forceinline__ float2 sc_complex(const float2 *__restrict__ tab, dou
 __device__ __forceinline__ int at_idx(float size, float num, float den) {
     return (int)((double)(size * num / den) + 0.5);
 }
+// Branch-free: a wavefront's lanes fall into all eight octants (the FM phase step reaches +-2.4 rad), so the
+// reference's if-tree would execute every arm one after the other.  Octant -> (table sign `size`, numerator /
+// denominator, offset A, sign of the table value); every arm is  A + (+-table[idx])  with one f32 addition, which
+// is the reference's own expression (a - t == a + (-t) etc. in IEEE arithmetic).
 __device__ __forceinline__ float lut_atan2(const float *__restrict__ ppy, float y, float x) {
-    const float St = (float)3.14159265358979323846;
-    if (isinf(x) || isinf(y)) return 0.f;
-    if (isnan(x) || isnan(y)) return 0.f;
-    if (x == 0.f) {
-        if (y == 0.f) return 0.f;
-        return y > 0.f ? (float)(3.14159265358979323846 / 2) : (float)(-3.14159265358979323846 / 2);
+    const float St = (float)3.14159265358979323846, Sh = St * 0.5f;
+    const bool special = isinf(x) || isinf(y) || isnan(x) || isnan(y) || x == 0.f;
+    const bool xpos = x > 0.f, ypos = y >= 0.f;
+    const bool swap = !(fabsf(x) >= fabsf(y));                 // the ..X arms: |y| > |x|
+    const bool same = xpos == ypos;
+    const float size = same ? (float)ATAN_N : -(float)ATAN_N;  // PPY PPX NNY NNX use +Size, the others -Size
+    const float num = swap ? x : y, den = swap ? y : x;
+    int idx = at_idx(size, num, special ? 1.f : den);
+    idx = special ? 0 : idx;
+    const float tv = ppy[idx];
+    const float A = swap ? (ypos ? Sh : -Sh) : (xpos ? 0.f : (ypos ? St : -St));
+    const float r = A + ((same == swap) ? -tv : tv);
+    if (special) {
+        if (x == 0.f && y != 0.f && !isnan(y) && !isinf(y)) return y > 0.f ? (float)(3.14159265358979323846 / 2) : (float)(-3.14159265358979323846 / 2);
+        return 0.f;
     }
-    const float S = (float)ATAN_N, E = -(float)ATAN_N;
-    if (x > 0.f) {
-        if (y >= 0.f) {
-            if (x >= y) return ppy[at_idx(S, y, x)];                     // PPY
-            return St * 0.5f - ppy[at_idx(S, x, y)];                     // PPX
-        }
-        if (x >= -y) return -ppy[at_idx(E, y, x)];                       // PNY
-        return ppy[at_idx(E, x, y)] - St * 0.5f;                         // PNX
-    }
-    if (y >= 0.f) {
-        if (-x >= y) return St - ppy[at_idx(E, y, x)];                   // NPY
-        return ppy[at_idx(E, x, y)] + St * 0.5f;                         // NPX
-    }
-    if (x <= y) return ppy[at_idx(S, y, x)] - St;                        // NNY
-    return -St * 0.5f - ppy[at_idx(S, x, y)];                            // NNX
+    return r;
 }
 // ---- limiter fm-demodulator.cpp:119-126 (std::abs(complex<float>) == hypotf == f64 sqrt of f64 sum)
 __device__ __forceinline__ float2 limiter(float2 z) {
@@ -115,18 +114,25 @@ __device__ __forceinline__ float2 limiter(float2 z) {
     return make_float2(z.x / zAbs, z.y / zAbs);
 }
 
+// Completion count of a time-parallel kernel for the persistent recurrence kernel (launch_demod): every block adds one when
+// its stores are visible device-wide; `done` is null on the event-driven path.
+__device__ __forceinline__ void block_done(int *done) {
+    if (done == nullptr) return;
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence(); atomicAdd(done, 1); }
+}
+
 // =================================================================================================
 // B1  limiter + memoryless discriminator   (time-parallel; 64 samples x 64 channels per block)
 // =================================================================================================
-__global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
-                                                   int64_t row0, int nrows) {
-    // One block = one work-array tile row: 16 samples x 64 channels (rows row0 + 16 blockIdx.x ...; row0 is a multiple of 16).
+__device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, const int bid_x, const int bid_y) {
+    // One block = one work-array tile row: 16 samples x 64 channels (rows row0 + 16 bid_x ...; row0 is a multiple of 16).
     const int CP = G.pitch;
     __shared__ float2 sLIM[64][WT + 3];               // limited samples of rows r0-2 .. r0+15 (each is used by up to three outputs)
     const int tid = threadIdx.x;
     const int64_t nj = row0 + nrows;
-    const int64_t r0 = row0 + (int64_t)blockIdx.x * WT;
-    const int c0 = blockIdx.y * 64;
+    const int64_t r0 = row0 + (int64_t)bid_x * WT;
+    const int c0 = bid_y * 64;
     const int ring = G.ring_mask + 1;
     const bool want_iq = B.w_iq != nullptr;
     // ---- limiter (fm-demodulator.cpp:119-126), once per sample: 18 consecutive ring entries per channel
@@ -183,6 +189,10 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
         }
     }
 }
+__global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, int *done) {
+    disc_body(T, B, G, C, row0, nrows, (int)blockIdx.x, (int)blockIdx.y);
+    block_done(done);
+}
 
 // =================================================================================================
 // B2..B4  the per-sample recurrences up to the pilot lock   [lane per channel, 64 channels per wave]
@@ -198,6 +208,16 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
 // (6-bit vmcnt) and on gfx9 stores count too: the loads of the next batch are issued right behind the stores of the
 // last one, so (loads + stores) per batch must stay below that or every batch stalls for a store round trip.
 constexpr int SEQ_UB = WT;
+// LDS of the recurrence bodies: a workgroup runs exactly one of them (also in the persistent kernel, where the role is
+// fixed per workgroup), so they share one buffer -- the pilot PLL's factor tables, or the replay staging of the lock
+// detector / PSS integrator.
+constexpr int REC_LDS_BYTES = (TRIG2_A + TRIG2_APAD + TRIG2_B) * 16 > 2 * SEQ_UB * 64 * 4 ? (TRIG2_A + TRIG2_APAD + TRIG2_B) * 16 : 2 * SEQ_UB * 64 * 4;
+__shared__ __attribute__((aligned(16))) char g_rec_lds[REC_LDS_BYTES];
+// The recurrence kernels are a few wavefronts whose run time is pure instruction latency; when the time-parallel kernels
+// of the other streams fill the same SIMDs, the issue arbiter must not make them wait: raise their wave priority.
+#ifndef FMX_RECURRENCE_PRIO
+#define FMX_RECURRENCE_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 // one work-array tile of this lane's channel (16 consecutive rows, 64 or 128 contiguous bytes) <-> registers
@@ -243,8 +263,8 @@ __device__ __forceinline__ void wst2(float2 *tile, const float2 x[WT]) {
 // samples are consumed and vice versa (block form rather than a rotating window: the compiler's s_waitcnt placement
 // then leaves the full distance).  `load(set, u, tile)` fills registers, `body(set, u, tile)` consumes them; set and u
 // are compile-time after unrolling.  Loads are clamped, never conditional.
-constexpr int PD = 4;
-template <typename LoadF, typename BodyF>
+constexpr int PD = 4;           // default depth; the two-array recurrences use 3 so that the persistent kernel keeps two waves per SIMD
+template <int PD, typename LoadF, typename BodyF>
 __device__ __forceinline__ void tile_pipeline(int nfull, LoadF load, BodyF body) {
     if (nfull <= 0) return;
     const int nlast = nfull - 1;
@@ -264,10 +284,10 @@ __device__ __forceinline__ void tile_pipeline(int nfull, LoadF load, BodyF body)
 
 // ---- B2
 template <bool PLLDEC>
-__global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
-                                                 int64_t rc0, int chunk_len) {
+__device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y) {
+    constexpr int PDA = PLLDEC ? 2 : 4;
     const int CP = G.pitch;
-    const int ch = blockIdx.x * 64 + threadIdx.x;
+    const int ch = bid_x * 64 + threadIdx.x;
     if (ch >= C) return;
     ChanState *st = B.state + ch;
     const bool use_pll = PLLDEC && (B.params[ch].decoder == 2), use_am = PLLDEC && (B.params[ch].decoder == 1);
@@ -308,8 +328,8 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
     const int nfull = chunk_len / UB;
     const int TS = UB * CP;                                       // elements from one tile of this channel to the next
     // (prefetch registers as plain float arrays: loop-carried arrays of HIP's float2 struct end up in scratch memory)
-    float nx[2][PD][UB]; float nqa[PLLDEC ? 2 : 1][PLLDEC ? PD : 1][UB], nqb[PLLDEC ? 2 : 1][PLLDEC ? PD : 1][UB];
-    tile_pipeline(nfull,
+    float nx[2][PDA][UB]; float nqa[PLLDEC ? 2 : 1][PLLDEC ? PDA : 1][UB], nqb[PLLDEC ? 2 : 1][PLLDEC ? PDA : 1][UB];
+    tile_pipeline<PDA>(nfull,
         [&](int s, int u, int tl) __attribute__((always_inline)) {
             wld(nx[s][u], wd + tl * TS);
             if (PLLDEC) { const float *qp = reinterpret_cast<const float *>(wiq + tl * TS); wld(nqa[PLLDEC ? s : 0][PLLDEC ? u : 0], qp); wld(nqb[PLLDEC ? s : 0][PLLDEC ? u : 0], qp + UB); }
@@ -335,6 +355,12 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
     }
     st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr; st->am_carr = am;
 }
+template <bool PLLDEC>
+__global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+    FMX_RECURRENCE_PRIO();
+    afc_body<PLLDEC>(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
+    block_done(done);
+}
 
 // ---- B3.  The pilot PLL: the longest dependent chain of the path (phase -> LUT index -> sine -> phase).  One wave
 // issues a dependent VALU operation every ~8.5 cycles and an LDS read returns after ~52, so the kernel is written for
@@ -349,17 +375,16 @@ __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B
 //     operations (val - P32 is exact by Sterbenz, P32 - 2 pi is added as a constant) when the host verified that
 //     identity for every float in the interval (T.wrap32_ok), else the f64 form.
 template <bool T2, bool W32>
-__global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
-                                                 int64_t rc0, int chunk_len) {
+__device__ __forceinline__ void pll_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y, const bool load_tables = true) {
+    constexpr int PDP = 4;
     const int CP = G.pitch;
-    __shared__ double2 sA[T2 ? TRIG2_A + TRIG2_APAD : 1];
-    __shared__ double2 sB[T2 ? TRIG2_B : 1];
-    if (T2) {
+    double2 *sA = reinterpret_cast<double2 *>(g_rec_lds), *sB = sA + (TRIG2_A + TRIG2_APAD);
+    if (T2 && load_tables) {                          // (the persistent kernel loads them once per call)
         for (int i = threadIdx.x; i < TRIG2_A + TRIG2_APAD; i += 64) sA[i] = T.trig2[i];
         for (int i = threadIdx.x; i < TRIG2_B; i += 64) sB[i] = T.trig2[TRIG2_A + TRIG2_APAD + i];
     }
     __syncthreads();
-    const int ch = blockIdx.x * 64 + threadIdx.x;
+    const int ch = bid_x * 64 + threadIdx.x;
     if (ch >= C) return;
     ChanState *st = B.state + ch;
     const float gain = T.pil_gain, omega = T.pil_omega;
@@ -394,8 +419,8 @@ __global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B
     };
     const int nfull = chunk_len / SEQ_UB;
     const int TS = SEQ_UB * CP;
-    float nx[2][PD][SEQ_UB];
-    tile_pipeline(nfull,
+    float nx[2][PDP][SEQ_UB];
+    tile_pipeline<PDP>(nfull,
         [&](int s, int u, int tl) __attribute__((always_inline)) { wld(nx[s][u], wd + tl * TS); },
         [&](int s, int u, int tb) __attribute__((always_inline)) {
             float x[SEQ_UB], oc[SEQ_UB], oo[SEQ_UB];
@@ -412,12 +437,18 @@ __global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B
     }
     st->pil_phase = phase;
 }
+template <bool T2, bool W32>
+__global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+    FMX_RECURRENCE_PRIO();
+    pll_body<T2, W32>(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
+    block_done(done);
+}
 
 // ---- B4
-__global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
-                                                  int64_t rc0, int chunk_len) {
+__device__ __forceinline__ void lock_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y) {
+    constexpr int PDL = 3;
     const int CP = G.pitch;
-    const int ch = blockIdx.x * 64 + threadIdx.x;
+    const int ch = bid_x * 64 + threadIdx.x;
     if (ch >= C) return;
     ChanState *st = B.state + ch;
     const ChanParams &P = B.params[ch];
@@ -453,9 +484,9 @@ __global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers 
     constexpr int UB = SEQ_UB;
     const int nfull = chunk_len / UB;
     const int TS = UB * CP;
-    float nd[2][PD][UB], no[2][PD][UB];
-    __shared__ float sLd[UB][64], sLo[UB][64];
-    tile_pipeline(nfull,
+    float nd[2][PDL][UB], no[2][PDL][UB];
+    float (*sLd)[64] = reinterpret_cast<float (*)[64]>(g_rec_lds), (*sLo)[64] = sLd + UB;
+    tile_pipeline<PDL>(nfull,
         [&](int s, int u, int tl) __attribute__((always_inline)) { wld(nd[s][u], wd + tl * TS); wld(no[s][u], wo + tl * TS); },
         [&](int s, int u, int tb) __attribute__((always_inline)) {
             float d[UB], o[UB]; int pk[UB];
@@ -512,6 +543,11 @@ __global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers 
     st->pil_lock = lock; st->pil_old = old; st->pil_stable = stable; st->pil_locked = locked;
     st->pss_call_total = tagn;
 }
+__global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+    FMX_RECURRENCE_PRIO();
+    lock_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
+    block_done(done);
+}
 
 // =================================================================================================
 // B5  PSS low-pass + error for every sample of the chunk   (time-parallel)
@@ -524,14 +560,13 @@ constexpr int PSS_WB = (PSS_TILE + 4 * PSS_TQ) / 4 + 2;     // window blocks of 
 // consecutive (the steady case: every sample calls process_sample) the s window slides through an eight-entry register
 // ring -- per four taps two conflict-free ds_read_b128 (half-plane layout as in the audio kernel), one broadcast read
 // of the taps and 16 packed FMAs (the PSS input is complex, the taps real); otherwise each output reads its own window.
-__global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
-                                                     int64_t rc0, int chunk_len) {
+__device__ __forceinline__ void pss_fir_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y) {
     const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
     __shared__ __attribute__((aligned(16))) float4 sW[2][PSS_WB];     // s window: sW[half][block] = entries 4 block + 2 half, +1
     __shared__ __attribute__((aligned(16))) float sH[4 * PSS_TQ];     // sH[w] = h[PSS_TAPS - 1 - w] (0 beyond)
-    const int ch = blockIdx.y;
+    const int ch = bid_y;
     const int lane = threadIdx.x;
-    const int q0 = blockIdx.x * PSS_TILE;
+    const int q0 = bid_x * PSS_TILE;
     const ChanParams &P = B.params[ch];
     if (P.fm_mode == 2 || !P.pss_active) return;
     const int64_t ic = B.state[ch].pss_count;            // PSS call index at the start of this CALL
@@ -624,6 +659,10 @@ __global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffe
         else for (int j = 0; j < 4; j++) if (q + j < chunk_len) dst[j] = err4[j];
     }
 }
+__global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+    pss_fir_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
+    block_done(done);
+}
 
 // =================================================================================================
 // B6  PSS integrator + state machines   [lane per channel]
@@ -654,10 +693,10 @@ __device__ __forceinline__ float pss_acc_step(AccState &s, float alpha, float la
     s.pdp = call ? nacc : ((tag == -1) ? 0.f : s.pdp);
     return used;
 }
-__global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
-                                                     int64_t rc0, int chunk_len) {
+__device__ __forceinline__ void pss_acc_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y) {
+    constexpr int PDC = 3;
     const int CP = G.pitch;       // padded row pitch of the sample-major work arrays
-    const int ch = blockIdx.x * 64 + threadIdx.x;
+    const int ch = bid_x * 64 + threadIdx.x;
     if (ch >= C) return;
     ChanState *st = B.state + ch;
     const ChanParams &P = B.params[ch];
@@ -681,11 +720,11 @@ __global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffe
     //  * idle: nobody locked, nobody calling (mono or no pilot with autoMono): the state is all zeros.
     const int nfull = chunk_len / ACC_UB;
     const int TS = ACC_UB * CP;
-    int nt[2][PD][ACC_UB]; float ne[2][PD][ACC_UB];
-    __shared__ int sTg[ACC_UB][64];
-    __shared__ float sEr[ACC_UB][64];
+    int nt[2][PDC][ACC_UB]; float ne[2][PDC][ACC_UB];
+    int (*sTg)[64] = reinterpret_cast<int (*)[64]>(g_rec_lds);
+    float (*sEr)[64] = reinterpret_cast<float (*)[64]>(g_rec_lds) + ACC_UB;
     const float c4 = 0.785398185253143310546875f;
-    tile_pipeline(nfull,
+    tile_pipeline<PDC>(nfull,
         [&](int g, int u, int tl) __attribute__((always_inline)) { wld(nt[g][u], tg + tl * TS); wld(ne[g][u], err + tl * TS); },
         [&](int g, int u, int tb) __attribute__((always_inline)) {
             float e[ACC_UB]; float o[ACC_UB];
@@ -753,21 +792,25 @@ __global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffe
     st->pss_acc = s.acc; st->pss_mean = s.mean; st->pilot_delay_pss = s.pdp;
     st->pss_lock_cnt = s.lock_cnt; st->pss_unlock_cnt = s.unlock_cnt; st->pss_minimized = s.minimized ? 1 : 0;
 }
+__global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+    FMX_RECURRENCE_PRIO();
+    pss_acc_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
+    block_done(done);
+}
 
 // =================================================================================================
 // B7  38 kHz mix, PSS input, stereo matrix   (time-parallel; transposing like B1)
 //     fm-processor.cpp:707-730, 517-549
 // =================================================================================================
-__global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
-                                                      int64_t rc0, int chunk_len) {
+__device__ __forceinline__ void pss_mix_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y) {
     // One block = one work-array tile row: 16 samples x 64 channels, threads as (sample in tile, channel), four elements
     // per thread.  With that mapping the tiled work arrays AND the channel-major rings are written in 64-byte runs, so
     // nothing is transposed.  The loads of all four elements are issued before anything is computed, and the SinCos
     // gathers of all four before they are used (the kernel sits on the PSS loop's critical path: latency, not bandwidth).
     const int CP = G.pitch;
     const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * WT;
-    const int c0 = blockIdx.y * 64;
+    const int q0 = bid_x * WT;
+    const int c0 = bid_y * 64;
     const int ring = G.ring_mask + 1;
     const float2 *__restrict__ sct = T.sincos;
     const double SC = T.sincos_C;
@@ -832,14 +875,18 @@ __global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuff
         B.lr_ring[(size_t)ch[i] * ring + (j & G.ring_mask)] = audio;
     }
 }
+__global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+    pss_mix_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
+    block_done(done);
+}
 // =================================================================================================
 // B8  de-emphasis   [lane per channel]   fm-processor.cpp:594-595 (the gain of :303-306 is applied by the audio kernel)
 //     plus the 0.5 s meta snapshot (:662-684)
 // =================================================================================================
-__global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C,
-                                                    int64_t rc0, int chunk_len, int last_chunk) {
+__device__ __forceinline__ void deemph_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int last_chunk, const int bid_x, const int bid_y) {
+    constexpr int PDD = 3;
     const int CP = G.pitch;       // padded row pitch of the sample-major work arrays
-    const int ch = blockIdx.x * 64 + threadIdx.x;
+    const int ch = bid_x * 64 + threadIdx.x;
     if (ch >= C) return;
     const int64_t nj = chunk_len;
     ChanState *st = B.state + ch;
@@ -850,8 +897,8 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
     constexpr int UB = SEQ_UB;
     const int nfull = (int)(nj / UB);
     const int TS = UB * CP;
-    float2 nx[2][PD][UB];
-    tile_pipeline(nfull,
+    float2 nx[2][PDD][UB];
+    tile_pipeline<PDD>(nfull,
         [&](int s, int u, int tl) __attribute__((always_inline)) { wld2(nx[s][u], x + tl * TS); },
         [&](int s, int u, int tb) __attribute__((always_inline)) {
             float2 v[UB];
@@ -893,23 +940,199 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
     st->pss_count += st->pss_call_total;           // advance the PSS filter time base by this call's process_sample calls
     st->pss_call_total = 0;
 }
+__global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int last_chunk, int *done) {
+    FMX_RECURRENCE_PRIO();
+    deemph_body(T, B, G, C, rc0, chunk_len, last_chunk, (int)blockIdx.x, (int)blockIdx.y);
+    block_done(done);
+}
 
 // =================================================================================================
 // B9  work array -> channel-major d ring   (transpose)
 // =================================================================================================
-__global__ __launch_bounds__(256) void dring_kernel(DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows) {
+__device__ __forceinline__ void dring_body(DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, const int bid_x, const int bid_y) {
     // one block = one work-array tile row (16 samples x 64 channels); threads as (sample in tile, channel): 128-byte runs on
     // both sides, nothing to transpose
     const int CP = G.pitch;
     const int tid = threadIdx.x;
-    const int64_t r = row0 + (int64_t)blockIdx.x * WT + (tid & 15);
-    const int c0 = blockIdx.y * 64;
+    const int64_t r = row0 + (int64_t)bid_x * WT + (tid & 15);
+    const int c0 = bid_y * 64;
     const int dcap = G.dring_mask + 1;
     if (r >= row0 + nrows) return;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int ch = c0 + (tid >> 4) + 16 * i;
         if (ch < C) B.dring[(size_t)ch * dcap + ((G.J0 + r) & G.dring_mask)] = B.w_x[widx(r, ch, CP)];
+    }
+}
+__global__ __launch_bounds__(256) void dring_kernel(DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, int *done) {
+    dring_body(B, G, C, row0, nrows, (int)blockIdx.x, (int)blockIdx.y);
+    block_done(done);
+}
+
+// =================================================================================================
+// Persistent layout of stage B (large channel counts, see launch_demod_persistent)
+// =================================================================================================
+struct ChunkPlan { int n; int rc0[PB_MAX_CHUNKS]; int len[PB_MAX_CHUNKS]; int nb_disc[PB_MAX_CHUNKS], nb_fir[PB_MAX_CHUNKS], nb_mix[PB_MAX_CHUNKS]; };
+constexpr int PB_SPIN_LIMIT = 1 << 22;            // x ~0.5 us: a wait longer than ~2 s gives up and raises DemodSync::abort
+
+// wave-uniform wait until *p >= need; false when the pipeline was aborted.  The polls are relaxed loads (an acquire load
+// per poll would invalidate the XCD's L2 every time); one acquire fence follows once the word has arrived.
+__device__ __forceinline__ bool pb_wait(const int *p, int need, int *abort_flag, int who) {
+    int spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > PB_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            if (__hip_atomic_exchange(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                DemodSync *S = reinterpret_cast<DemodSync *>(abort_flag);       // diagnostics: who gave up first, and the state then
+                S->info[0] = who; S->info[1] = need; S->info[2] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int g = S->groups;
+                for (int i = 0; i < 16; i++) {
+                    S->snap[i] = __hip_atomic_load(&S->cnt_disc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    S->snap[16 + i] = __hip_atomic_load(&S->cnt_fir[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    S->snap[32 + i] = __hip_atomic_load(&S->cnt_mix[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                for (int r = 0; r < PB_ROLES; r++) {
+                    S->snap[48 + r] = __hip_atomic_load(&S->prog[0][0] + r * g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    S->snap[56 + r] = __hip_atomic_load(&S->prog[0][0] + r * g + g - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return false;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+// One wave per (64-channel group, role); every role walks the call's chunks in order.  A role waits for the progress word
+// of the role in front of it (same group), or for the completion count of the time-parallel kernel that feeds it, then
+// runs the same chunk body as the event-driven layout and publishes its own progress.
+template <bool PLLDEC, bool T2, bool W32>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void recurrences_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, ChunkPlan P,
+                                                         DemodSync *S, int groups) {
+    FMX_RECURRENCE_PRIO();
+    const int grp = blockIdx.x, role = blockIdx.y;
+    int *prog = &S->prog[0][0];
+    bool first = true;
+    for (int c = 0; c < P.n; c++) {
+        bool ok = true;
+        switch (role) {
+        case 0: ok = pb_wait(&S->cnt_disc[c], P.nb_disc[c], &S->abort, 100 * c + 0); break;
+        case 1: ok = pb_wait(&prog[0 * groups + grp], c + 1, &S->abort, 100 * c + 1); break;
+        case 2: ok = pb_wait(&prog[1 * groups + grp], c + 1, &S->abort, 100 * c + 2); break;
+        case 3: ok = pb_wait(&S->cnt_fir[c], P.nb_fir[c], &S->abort, 100 * c + 3); break;
+        default: ok = pb_wait(&S->cnt_mix[c], P.nb_mix[c], &S->abort, 100 * c + 4); break;
+        }
+        if (!ok) return;
+        const int64_t rc0 = P.rc0[c]; const int len = P.len[c];
+        switch (role) {
+        case 0: afc_body<PLLDEC>(T, B, G, C, rc0, len, grp, 0); break;
+        case 1: pll_body<T2, W32>(T, B, G, C, rc0, len, grp, 0, first); break;
+        case 2: lock_body(T, B, G, C, rc0, len, grp, 0); break;
+        case 3: pss_acc_body(T, B, G, C, rc0, len, grp, 0); break;
+        default: deemph_body(T, B, G, C, rc0, len, (c == P.n - 1) ? 1 : 0, grp, 0); break;
+        }
+        first = false;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence();                                      // this chunk's stores (work arrays, channel state) before the word
+        if (threadIdx.x == 0) __hip_atomic_store(&prog[role * groups + grp], c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Gate in front of a time-parallel kernel on its stream: returns once role `role` has finished chunk `need - 1` in every group.
+__global__ __launch_bounds__(64) void gate_kernel(DemodSync *S, int role, int groups, int need) {
+    const int *prog = &S->prog[0][0] + role * groups;
+    for (int g = threadIdx.x; g < groups; g += 64)
+        if (!pb_wait(&prog[g], need, &S->abort, 100 * need + 10 + role)) return;
+}
+
+// Completion word of a time-parallel kernel: launched right behind it on the same stream, so the kernel boundary has
+// already made that kernel's stores visible device-wide (a release fence per BLOCK would write the XCD's L2 back
+// thousands of times per kernel).
+__global__ __launch_bounds__(64) void signal_kernel(int *p, int v) {
+    if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool PLLDEC, bool T2, bool W32>
+static void launch_recurrences(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, const ChunkPlan &P,
+                               DemodSync *S, int groups, hipStream_t s) {
+    hipLaunchKernelGGL((recurrences_kernel<PLLDEC, T2, W32>), dim3((unsigned)groups, PB_ROLES), dim3(64), 0, s, T, B, G, C, P, S, groups);
+}
+
+// Occupancy of the persistent kernel (blocks per CU), for the co-residency check the host makes before choosing this layout.
+int recurrences_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recurrences_kernel<false, true, true>, 64, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int m = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, recurrences_kernel<true, true, true>, 64, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n < m ? n : m;
+}
+
+// Stage B for large channel counts.  A time-parallel kernel then fills every CU for tens of microseconds; a recurrence wave
+// that shares a CU with it runs 2-3x slower, and stream events between many queues cost 60-160 us each on this GPU (they
+// are cheap only between two or three queues).  So: the recurrences of the WHOLE call are one persistent kernel on a CU set
+// of their own, the time-parallel kernels run on the remaining CUs in two streams, and the two sides meet through progress
+// words in device memory --
+//   ts[1]: disc(0..2) | per chunk c: [gate de-emphasis(c)] d-ring(c), disc(c+3)
+//   ts[0]: per chunk c: [gate lock(c)] PSS low-pass(c), [gate integrator(c)] mix(c)
+//   rs   : AFC(c) <- disc(c) count;  PLL <- AFC;  lock <- PLL;  integrator(c) <- low-pass(c) count;  de-emphasis(c) <- mix(c) count
+// Stream events remain only at the two ends of the call.
+static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s,
+                                    const DemodStreams &DS) {
+    const int64_t nj = G.J1 - G.J0;
+    constexpr int FIRST_CHUNK = 256;
+    const int groups = (C + 63) / 64;
+    ChunkPlan P{};
+    for (int64_t rc0 = 0; rc0 < nj;) {
+        const int c = P.n;
+        const int cap = (c == 0 && nj > 2 * FIRST_CHUNK) ? FIRST_CHUNK : PSS_CHUNK;
+        const int len = (int)((nj - rc0) < cap ? (nj - rc0) : cap);
+        P.rc0[c] = (int)rc0; P.len[c] = len;
+        P.nb_disc[c] = ((len + WT - 1) / WT) * groups; P.nb_mix[c] = P.nb_disc[c];
+        P.nb_fir[c] = ((len + PSS_TILE - 1) / PSS_TILE) * C;
+        P.n++; rc0 += len;
+    }
+    DemodSync *S = DS.sync;
+    (void)hipMemsetAsync(S, 0, sizeof(DemodSync) + sizeof(int) * PB_ROLES * groups, s);
+    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, s, &S->groups, groups);
+    hipEvent_t e0 = DS.ev[(*DS.ev_next)++ % DS.nev];
+    (void)hipEventRecord(e0, s);                                   // the front kernel's output and the cleared words
+    (void)hipStreamWaitEvent(DS.rs, e0, 0); (void)hipStreamWaitEvent(DS.ts[0], e0, 0);
+    const bool plldec = B.w_iq != nullptr;
+    if (T.trig2 && T.wrap32_ok) { if (plldec) launch_recurrences<true, true, true>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, true, true>(T, B, G, C, P, S, groups, DS.rs); }
+    else if (T.trig2) { if (plldec) launch_recurrences<true, true, false>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, true, false>(T, B, G, C, P, S, groups, DS.rs); }
+    else { if (plldec) launch_recurrences<true, false, false>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, false, false>(T, B, G, C, P, S, groups, DS.rs); }
+    auto trow = [&](int c) { return dim3((unsigned)((P.len[c] + WT - 1) / WT), (unsigned)groups); };
+    auto signal = [&](hipStream_t q, int *p, int v) { hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, q, p, v); };
+    auto gate = [&](hipStream_t q, int role, int need) { hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, q, S, role, groups, need); };
+    hipStream_t tq = DS.ts[0];
+    auto disc = [&](int c) {
+        hipLaunchKernelGGL(disc_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
+        signal(tq, &S->cnt_disc[c], P.nb_disc[c]);
+    };
+    auto dring = [&](int c) {
+        gate(tq, 4, c + 1);
+        hipLaunchKernelGGL(dring_kernel, trow(c), dim3(256), 0, tq, B, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
+    };
+    // one stream for all the time-parallel kernels: the discriminator (three chunks ahead) and the d-ring copy of the
+    // previous chunk run while the PSS integrator of this chunk does, between the low-pass and the mix
+    constexpr int LEAD = 3;
+    for (int c = 0; c < LEAD && c < P.n; c++) disc(c);
+    for (int c = 0; c < P.n; c++) {
+        gate(tq, 2, c + 1);
+        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((P.len[c] + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
+        signal(tq, &S->cnt_fir[c], P.nb_fir[c]);
+        if (c + LEAD < P.n) disc(c + LEAD);
+        if (c > 0) dring(c - 1);
+        gate(tq, 3, c + 1);
+        hipLaunchKernelGGL(pss_mix_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
+        signal(tq, &S->cnt_mix[c], P.nb_mix[c]);
+    }
+    dring(P.n - 1);
+    hipStream_t ends[2] = { DS.rs, DS.ts[0] };
+    for (hipStream_t q : ends) {
+        hipEvent_t e = DS.ev[(*DS.ev_next)++ % DS.nev];
+        (void)hipEventRecord(e, q);
+        (void)hipStreamWaitEvent(s, e, 0);
     }
 }
 
@@ -935,28 +1158,29 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
     // first PSS kernel starts ~0.2 ms earlier); any chunk length <= PSS_CHUNK that is a multiple of the tile is valid.
     constexpr int FIRST_CHUNK = 256;
     int c = 0;
+    if (DS.partitioned && nj <= (int64_t)(PB_MAX_CHUNKS - 2) * PSS_CHUNK) { launch_demod_persistent(T, B, G, C, s, DS); return; }
     for (int64_t rc0 = 0; rc0 < nj; c++) {
         const int cap = (c == 0 && nj > 2 * FIRST_CHUNK) ? FIRST_CHUNK : PSS_CHUNK;
         const int len = (int)((nj - rc0) < cap ? (nj - rc0) : cap);
         const int last = (rc0 + len >= nj) ? 1 : 0;
         // the discriminator runs per chunk in front of the AFC (a stage with time to spare), so the first PSS kernel
         // starts after 256 rows of it instead of after the whole call's
-        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[0], T, B, G, C, rc0, len);
-        if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
-        else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[0], T, B, G, C, rc0, len, (int *)nullptr);
+        if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len, (int *)nullptr);
+        else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len, (int *)nullptr);
         hand_over(0, 1, c);
-        if (T.trig2 && T.wrap32_ok) hipLaunchKernelGGL((pll_kernel<true, true>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
-        else if (T.trig2) hipLaunchKernelGGL((pll_kernel<true, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
-        else hipLaunchKernelGGL((pll_kernel<false, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
+        if (T.trig2 && T.wrap32_ok) hipLaunchKernelGGL((pll_kernel<true, true>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len, (int *)nullptr);
+        else if (T.trig2) hipLaunchKernelGGL((pll_kernel<true, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len, (int *)nullptr);
+        else hipLaunchKernelGGL((pll_kernel<false, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len, (int *)nullptr);
         hand_over(1, 2, c);
-        hipLaunchKernelGGL(lock_kernel, lanes, dim3(64), 0, st[2], T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(lock_kernel, lanes, dim3(64), 0, st[2], T, B, G, C, rc0, len, (int *)nullptr);
         hand_over(2, 3, c);
-        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, st[3], T, B, G, C, rc0, len);
-        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, st[3], T, B, G, C, rc0, len);
-        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, st[3], T, B, G, C, rc0, len, (int *)nullptr);
+        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, st[3], T, B, G, C, rc0, len, (int *)nullptr);
+        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len, (int *)nullptr);
         hand_over(3, 4, c);
-        hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last);
-        hipLaunchKernelGGL(dring_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[4], B, G, C, rc0, len);
+        hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last, (int *)nullptr);
+        hipLaunchKernelGGL(dring_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[4], B, G, C, rc0, len, (int *)nullptr);
         rc0 += len;
     }
     if (s3 != s) { (void)hipEventRecord(DS.join, s3); (void)hipStreamWaitEvent(s, DS.join, 0); }

@@ -58,6 +58,12 @@ __device__ __forceinline__ Aff aff_then(const Aff &f, const Aff &g) {      // ap
     return o;
 }
 
+#ifndef FMX_EARLY_PREFETCH
+#define FMX_EARLY_PREFETCH 1
+#endif
+#ifndef FMX_ABL
+#define FMX_ABL 0      /* diagnostic builds only (tools/ablate_front.sh): bit 0 no scatter, 1 no DC/mix pass, 2 no FIR */
+#endif
 #define FMX_TICK(k) do { if (dbg_on) { unsigned long long now_ = clock64(); dbg_acc[k] += now_ - dbg_t; dbg_t = now_; } } while (0)
 
 // mailbox counters between the waves of a workgroup (LDS, workgroup scope)
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
         // ---- scatter the raw samples into the image
         {
             const bool allfresh = (wbase >= g0) && (wbase + WSAMP <= gend);
-            if (allfresh) {
+            if (allfresh && !(FMX_ABL & 1)) {
 #pragma unroll
                 for (int k = 0; k < SPT / 2; k++) {
                     X2[sc_idx[k]] = make_float2(raw[k].x, raw[k].y);
@@ -294,6 +300,12 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
             }
         }
         __builtin_amdgcn_wave_barrier();              // LDS operations of one wave complete in order
+        // ---- prefetch this wave's next tile as soon as the registers are free: the loads are in flight for the whole
+        //      iteration (DC pass, hand-off, FIR), so every wave keeps 12 KB of HBM reads outstanding all the time
+        const bool more = (ti + 4 < NT);
+#if FMX_EARLY_PREFETCH
+        if (more) load_tile(ti + 4);
+#endif
         FMX_TICK(1);
         const int q = qt + 2 * lane;                  // this lane's first column
         const int base = q * 12;
@@ -304,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
         const bool wave_full = __all(first == 0 && lastp1 == SPT);
         float c_out_r = 0.f, c_out_i = 0.f;           // DC state after this tile
 
-        if (touch) {
+        if (touch && !(FMX_ABL & 2)) {
             v2f x[SPT];
 #pragma unroll
             for (int r = 0; r < DECIM; r++) {
@@ -451,9 +463,9 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
         // ---- and wait for the previous tile's (tile 0 got the call's history from HBM)
         if (ti > 0) seq_wait(&hist_seq[wave], ti);
         FMX_TICK(3);
-        // ---- prefetch this wave's next tile; the loads land while the FIR runs
-        const bool more = (ti + 4 < NT);
-        if (more) load_tile(ti + 4);
+#if !FMX_EARLY_PREFETCH
+        if (more) load_tile(ti + 4);                  // (A/B build) prefetch only in front of the FIR
+#endif
 
         // ---- polyphase FIR  out[j] = sum_d sum_r Trd[r][d] * X[r][C_j - d]:  lane quarter rq sums rows 3 rq .. 3 rq + 2
         //      for eight adjacent outputs per lane; the four partial sums meet in LDS (on top of the image, which is
@@ -462,7 +474,8 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
             v2f acc[FCOLS];
 #pragma unroll
             for (int k = 0; k < FCOLS; k++) acc[k] = (v2f){0.f, 0.f};
-            if (nd <= 4) fir_rows<4>(X4, cg, RPQ * rq, tp, acc);
+            if (FMX_ABL & 4) { acc[0] = (v2f){(float)cg, 1.f}; }
+            else if (nd <= 4) fir_rows<4>(X4, cg, RPQ * rq, tp, acc);
             else fir_rows<A_MAX_ND>(X4, cg, RPQ * rq, tp, acc);
             __builtin_amdgcn_wave_barrier();
             // save the columns the call-end history needs before the image is overwritten (last tile only: below)

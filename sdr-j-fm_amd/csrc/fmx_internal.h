@@ -184,7 +184,25 @@ void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G,
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s);
 // side streams + events for the chunk pipeline of stage B (null streams = run everything on the caller's stream)
-struct DemodStreams { hipStream_t side[4]; hipEvent_t *ev; int nev; hipEvent_t join; };
+// Streams of the stage-B chunk pipeline.  side[]: four unmasked side streams of the event-driven layout.
+// Persistent layout (partitioned != 0): rs / ts[] are bound to two disjoint CU sets (hipExtStreamCreateWithCUMask); ONE
+// persistent kernel on rs runs every recurrence of the call (roles AFC, PLL, lock, PSS integrator, de-emphasis), the
+// time-parallel kernels run chunk by chunk on ts[0] (PSS low-pass, mix) and ts[1] (discriminator, d-ring), and the two
+// sides meet through progress words in `sync` (device memory) instead of stream events.
+constexpr int PB_MAX_CHUNKS = 48;      // chunks of one call in the persistent layout
+constexpr int PB_ROLES = 5;
+struct DemodSync {                      // zeroed at the start of every call
+    int abort;                          // set when a wait ran out of patience (a stalled pipeline must not hang the GPU)
+    int info[3];                        // first waiter that gave up: id, value needed, value seen
+    int groups;
+    int pad[11];
+    int snap[64];                       // snapshot of the words below at that moment (diagnostics)
+    int cnt_disc[PB_MAX_CHUNKS], cnt_fir[PB_MAX_CHUNKS], cnt_mix[PB_MAX_CHUNKS];     // finished blocks of chunk c's kernel
+    int prog[PB_ROLES][1];              // [role][group]: chunks finished; really [PB_ROLES][groups] (allocated to size)
+};
+struct DemodStreams { hipStream_t side[4]; hipEvent_t *ev; int nev; hipEvent_t join; hipStream_t rs; hipStream_t ts[2];
+                      int partitioned; int *ev_next; DemodSync *sync; };
+int recurrences_blocks_per_cu();
 void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s,
                   const DemodStreams &DS);
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,
