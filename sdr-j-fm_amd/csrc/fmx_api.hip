@@ -473,7 +473,10 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         // (LDS and VGPRs allow eight; the dispatcher does not pack CUs completely), one spare CU per XCD, and check the runtime's own occupancy figure agrees
         const int occ = recurrences_blocks_per_cu();
         const char *e3 = getenv("FMX_RECURRENCE_WAVES_PER_CU");
-        const int per_cu = std::min(occ, e3 ? std::max(1, atoi(e3)) : 5);
+        // few waves per CU while that costs few CUs (the recurrences then run undisturbed), up to five when the channel
+        // count is large and the time-parallel kernels need the CUs more
+        const int want = std::max(2, std::min(5, (PB_ROLES * groups + 47) / 48));   // (7 of the 8 possible did not all become resident)
+        const int per_cu = std::min(occ, e3 ? std::max(1, atoi(e3)) : want);
         if (getenv("FMX_DEBUG_LAYOUT")) fprintf(stderr, "[fmx] recurrence kernel occupancy %d blocks/CU, %d groups\n", occ, groups);
         if (minch > 0 && h->channels >= minch && ncu >= 64 && ncu <= 1024 && per_cu > 0) {
             int rcus = (PB_ROLES * groups + per_cu - 1) / per_cu;

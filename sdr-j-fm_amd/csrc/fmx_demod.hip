@@ -1028,7 +1028,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         case 0: afc_body<PLLDEC>(T, B, G, C, rc0, len, grp, 0); break;
         case 1: pll_body<T2, W32>(T, B, G, C, rc0, len, grp, 0, first); break;
         case 2: lock_body(T, B, G, C, rc0, len, grp, 0); break;
-        case 3: pss_acc_body(T, B, G, C, rc0, len, grp, 0); break;
+        case 3: {                                            // chunk c's errors sit in half (c & 1) of the error array
+            DeviceBuffers Bc = B;
+            Bc.w_err = B.w_err + (size_t)(c & 1) * (PB_CHUNK / WT) * G.pitch * WT;
+            pss_acc_body(T, Bc, G, C, rc0, len, grp, 0);
+            break; }
         default: deemph_body(T, B, G, C, rc0, len, (c == P.n - 1) ? 1 : 0, grp, 0); break;
         }
         first = false;
@@ -1084,7 +1088,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
     ChunkPlan P{};
     for (int64_t rc0 = 0; rc0 < nj;) {
         const int c = P.n;
-        const int cap = (c == 0 && nj > 2 * FIRST_CHUNK) ? FIRST_CHUNK : PSS_CHUNK;
+        const int cap = (c == 0 && nj > 2 * FIRST_CHUNK) ? FIRST_CHUNK : PB_CHUNK;
         const int len = (int)((nj - rc0) < cap ? (nj - rc0) : cap);
         P.rc0[c] = (int)rc0; P.len[c] = len;
         P.nb_disc[c] = ((len + WT - 1) / WT) * groups; P.nb_mix[c] = P.nb_disc[c];
@@ -1113,21 +1117,30 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         gate(tq, 4, c + 1);
         hipLaunchKernelGGL(dring_kernel, trow(c), dim3(256), 0, tq, B, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
     };
-    // one stream for all the time-parallel kernels: the discriminator (three chunks ahead) and the d-ring copy of the
-    // previous chunk run while the PSS integrator of this chunk does, between the low-pass and the mix
+    // One stream for all the time-parallel kernels.  Chunks are at most HALF the PSS feedback lag long, so the low-pass of
+    // chunk c reads s-ring entries the mix wrote no later than chunk c - 2: it does not wait for the integrator of chunk
+    // c - 1, the integrator runs chunk after chunk without a gap, and the order below only has to keep every kernel behind
+    // its producers:  low-pass(c), disc(c + 3), d-ring(c - 2), mix(c - 1).
     constexpr int LEAD = 3;
-    for (int c = 0; c < LEAD && c < P.n; c++) disc(c);
-    for (int c = 0; c < P.n; c++) {
+    auto fir = [&](int c) {
         gate(tq, 2, c + 1);
-        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((P.len[c] + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
+        DeviceBuffers Bc = B;
+        Bc.w_err = B.w_err + (size_t)(c & 1) * (PB_CHUNK / WT) * G.pitch * WT;
+        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((P.len[c] + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, tq, T, Bc, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
         signal(tq, &S->cnt_fir[c], P.nb_fir[c]);
-        if (c + LEAD < P.n) disc(c + LEAD);
-        if (c > 0) dring(c - 1);
+    };
+    auto mix = [&](int c) {
         gate(tq, 3, c + 1);
         hipLaunchKernelGGL(pss_mix_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
         signal(tq, &S->cnt_mix[c], P.nb_mix[c]);
+    };
+    for (int c = 0; c < LEAD && c < P.n; c++) disc(c);
+    for (int c = 0; c < P.n + 2; c++) {
+        if (c < P.n) fir(c);
+        if (c + LEAD < P.n) disc(c + LEAD);
+        if (c >= 2 && c - 2 < P.n) dring(c - 2);
+        if (c >= 1 && c - 1 < P.n) mix(c - 1);
     }
-    dring(P.n - 1);
     hipStream_t ends[2] = { DS.rs, DS.ts[0] };
     for (hipStream_t q : ends) {
         hipEvent_t e = DS.ev[(*DS.ev_next)++ % DS.nev];
@@ -1158,7 +1171,7 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
     // first PSS kernel starts ~0.2 ms earlier); any chunk length <= PSS_CHUNK that is a multiple of the tile is valid.
     constexpr int FIRST_CHUNK = 256;
     int c = 0;
-    if (DS.partitioned && nj <= (int64_t)(PB_MAX_CHUNKS - 2) * PSS_CHUNK) { launch_demod_persistent(T, B, G, C, s, DS); return; }
+    if (DS.partitioned && nj <= (int64_t)(PB_MAX_CHUNKS - 2) * PB_CHUNK) { launch_demod_persistent(T, B, G, C, s, DS); return; }
     for (int64_t rc0 = 0; rc0 < nj; c++) {
         const int cap = (c == 0 && nj > 2 * FIRST_CHUNK) ? FIRST_CHUNK : PSS_CHUNK;
         const int len = (int)((nj - rc0) < cap ? (nj - rc0) : cap);

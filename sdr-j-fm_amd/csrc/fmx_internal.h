@@ -189,7 +189,8 @@ void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
 // persistent kernel on rs runs every recurrence of the call (roles AFC, PLL, lock, PSS integrator, de-emphasis), the
 // time-parallel kernels run chunk by chunk on ts[0] (PSS low-pass, mix) and ts[1] (discriminator, d-ring), and the two
 // sides meet through progress words in `sync` (device memory) instead of stream events.
-constexpr int PB_MAX_CHUNKS = 48;      // chunks of one call in the persistent layout
+constexpr int PB_MAX_CHUNKS = 64;      // chunks of one call in the persistent layout
+constexpr int PB_CHUNK = 864;          // its chunk length: <= PSS_DELAY / 2 and a multiple of the work-array tile
 constexpr int PB_ROLES = 5;
 struct DemodSync {                      // zeroed at the start of every call
     int abort;                          // set when a wait ran out of patience (a stalled pipeline must not hang the GPU)
