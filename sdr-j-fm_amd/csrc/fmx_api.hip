@@ -476,7 +476,10 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         // few waves per CU while that costs few CUs (the recurrences then run undisturbed), up to five when the channel
         // count is large and the time-parallel kernels need the CUs more
         const int want = std::max(2, std::min(5, (PB_ROLES * groups + 47) / 48));   // (7 of the 8 possible did not all become resident)
-        const int per_cu = std::min(occ, e3 ? std::max(1, atoi(e3)) : want);
+        // From 2048 channels on stage B is bound by the time-parallel kernels' throughput, not by the recurrences' latency:
+        // they then run on every CU (sharing the recurrence CUs), and the recurrence waves are spread three to a CU.
+        const bool t_everywhere = getenv("FMX_T_UNMASKED") ? atoi(getenv("FMX_T_UNMASKED")) != 0 : groups >= 32;
+        const int per_cu = std::min(occ, e3 ? std::max(1, atoi(e3)) : (t_everywhere ? 3 : want));
         if (getenv("FMX_DEBUG_LAYOUT")) fprintf(stderr, "[fmx] recurrence kernel occupancy %d blocks/CU, %d groups\n", occ, groups);
         if (minch > 0 && h->channels >= minch && ncu >= 64 && ncu <= 1024 && per_cu > 0) {
             int rcus = (PB_ROLES * groups + per_cu - 1) / per_cu;
@@ -484,6 +487,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
             if (rcus <= ncu * 3 / 4) {
                 std::vector<uint32_t> mr((ncu + 31) / 32, 0u), mt((ncu + 31) / 32, 0u);
                 for (int i = 0; i < ncu; i++) (i < rcus ? mr : mt)[i / 32] |= 1u << (i % 32);
+                if (t_everywhere) for (int i = 0; i < ncu; i++) mt[i / 32] |= 1u << (i % 32);
                 bool ok = hipExtStreamCreateWithCUMask(&h->s_r, (uint32_t)mr.size(), mr.data()) == hipSuccess;
                 for (auto &ss : h->s_t) ok = ok && hipExtStreamCreateWithCUMask(&ss, (uint32_t)mt.size(), mt.data()) == hipSuccess;
                 ok = ok && hipMalloc(&h->d_sync, sizeof(DemodSync) + sizeof(int) * PB_ROLES * groups) == hipSuccess;

@@ -114,6 +114,32 @@ __device__ __forceinline__ float2 limiter(float2 z) {
     return make_float2(z.x / zAbs, z.y / zAbs);
 }
 
+// How a time-parallel kernel meets the persistent recurrence kernel (launch_demod_persistent); all null / zero on the
+// event-driven path.  `sig`: completion word of the kernel in FRONT of this one on the stream -- stored by this kernel's
+// first block, because the kernel boundary in between has made that kernel's stores visible device-wide (a release
+// fence per block would write the XCD's L2 back thousands of times).  `gate`: progress words [group] of the recurrence
+// role this kernel consumes; a block starts once its own group has reached `need`.
+struct TSync { const int *gate; int need; int *sig; int sigv; int *abort_flag; };
+__device__ __forceinline__ bool tsync_enter(const TSync &Y, int group) {
+    if (Y.sig != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(Y.sig, Y.sigv, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (Y.gate == nullptr) return true;
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        int spins = 0, good = 1;
+        // (the words and the rows behind them were never in this XCD's L2 before the kernel started: no invalidate needed)
+        while (__hip_atomic_load(Y.gate + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < Y.need) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22) || __hip_atomic_load(Y.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(Y.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); good = 0; break;
+            }
+        }
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
 // Completion count of a time-parallel kernel for the persistent recurrence kernel (launch_demod): every block adds one when
 // its stores are visible device-wide; `done` is null on the event-driven path.
 __device__ __forceinline__ void block_done(int *done) {
@@ -189,9 +215,9 @@ __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallG
         }
     }
 }
-__global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, int *done) {
+__global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, TSync Y) {
+    if (!tsync_enter(Y, (int)blockIdx.y)) return;
     disc_body(T, B, G, C, row0, nrows, (int)blockIdx.x, (int)blockIdx.y);
-    block_done(done);
 }
 
 // =================================================================================================
@@ -553,17 +579,20 @@ __global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers 
 // B5  PSS low-pass + error for every sample of the chunk   (time-parallel)
 //     stereo-separation.cpp:60-83 : err = Re(y)*Im(y), y = sum_k h[k] s[i - 1753 - k], i = PSS call index
 // =================================================================================================
-constexpr int PSS_TILE = 256;
-constexpr int PSS_TQ = (PSS_TAPS + 3) / 4 + 1;              // tap groups of four (reversed taps, zero padded): 75
-constexpr int PSS_WB = (PSS_TILE + 4 * PSS_TQ) / 4 + 2;     // window blocks of four s samples
-// One wave per (256-sample tile, channel); a thread computes FOUR adjacent samples.  When their PSS call indices are
-// consecutive (the steady case: every sample calls process_sample) the s window slides through an eight-entry register
-// ring -- per four taps two conflict-free ds_read_b128 (half-plane layout as in the audio kernel), one broadcast read
-// of the taps and 16 packed FMAs (the PSS input is complex, the taps real); otherwise each output reads its own window.
+constexpr int PSS_TILE = 512;
+constexpr int PSS_FPT = 8;                                  // adjacent samples per thread
+constexpr int PSS_TG = (PSS_TAPS + 11) / 12 * 3;            // tap groups of four, a multiple of three (75 groups = 300 taps, zero padded)
+constexpr int PSS_WU = (PSS_TILE + 4 * PSS_TG + 8) / 8 + 2; // window units (a unit = two s samples = one float4) per plane
+// One wave per (512-sample tile, channel); a thread computes EIGHT adjacent samples.  When their PSS call indices are
+// consecutive (the steady case: every sample calls process_sample) the s window slides through a twelve-entry register
+// ring -- per four taps two ds_read_b128 and 32 packed FMAs (the PSS input is complex, the taps real), the taps come in
+// as scalars (wave-uniform loads).  The window sits in LDS in four planes, unit u (samples 2u, 2u+1) in plane u % 4 at
+// offset u / 4: a lane's samples start 4 units after its neighbour's, so every ds_read_b128 of the wave reads consecutive
+// 16-byte slots of one plane.  Otherwise (pilot lock coming or going inside the tile) each output reads its own window.
 __device__ __forceinline__ void pss_fir_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y) {
     const int64_t CP = G.pitch;   // padded row pitch of the sample-major work arrays
-    __shared__ __attribute__((aligned(16))) float4 sW[2][PSS_WB];     // s window: sW[half][block] = entries 4 block + 2 half, +1
-    __shared__ __attribute__((aligned(16))) float sH[4 * PSS_TQ];     // sH[w] = h[PSS_TAPS - 1 - w] (0 beyond)
+    __shared__ __attribute__((aligned(16))) float4 sW[4][PSS_WU];
+    __shared__ __attribute__((aligned(16))) float sH[4 * PSS_TG];     // sH[w] = h[PSS_TAPS - 1 - w] (0 beyond)
     const int ch = bid_y;
     const int lane = threadIdx.x;
     const int q0 = bid_x * PSS_TILE;
@@ -572,96 +601,95 @@ __device__ __forceinline__ void pss_fir_body(DeviceTables T, DeviceBuffers B, Ca
     const int64_t ic = B.state[ch].pss_count;            // PSS call index at the start of this CALL
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    int tg[4];
+    int tg[PSS_FPT];
+    const int q = q0 + PSS_FPT * lane;                   // eight adjacent rows: half a work-array tile, two dwordx4
     {
-        const int q = q0 + 4 * lane;                     // four adjacent rows of one work-array tile: one dwordx4
-        i32x4_t pk = {0, 0, 0, 0};
-        if (q < chunk_len) pk = *reinterpret_cast<const i32x4_t *>(&B.w_tag[widx(rc0 + q, ch, (int)CP)]);
+        i32x4_t pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+        if (q < chunk_len) {
+            const i32x4_t *src = reinterpret_cast<const i32x4_t *>(&B.w_tag[widx(rc0 + q, ch, (int)CP)]);
+            pa = src[0]; pb = src[1];
+        }
 #pragma unroll
-        for (int j = 0; j < 4; j++) tg[j] = (q + j < chunk_len) ? (pk[j] >> 1) - 2 : -2;
+        for (int j = 0; j < 4; j++) { tg[j] = (q + j < chunk_len) ? (pa[j] >> 1) - 2 : -2; tg[4 + j] = (q + 4 + j < chunk_len) ? (pb[j] >> 1) - 2 : -2; }
     }
     int tmin = 0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < 4; j++) if (tg[j] >= 0) tmin = tg[j] < tmin ? tg[j] : tmin;
+    for (int j = 0; j < PSS_FPT; j++) if (tg[j] >= 0) tmin = tg[j] < tmin ? tg[j] : tmin;
     for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(tmin, d, 64); tmin = o < tmin ? o : tmin; }
     if (tmin == 0x7fffffff) return;                      // no PSS call in this tile
     const float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
+    float2 *sW2 = reinterpret_cast<float2 *>(&sW[0][0]);
+    auto wslot = [](int w) { const int u = w >> 1; return (((u & 3) * PSS_WU + (u >> 2)) << 1) | (w & 1); };   // float2 index of window entry w
     // window entry w <-> s index (ic + tmin) - (1753 + 294) + w ; tags in a tile span < PSS_TILE
-    for (int w = lane; w < 4 * PSS_WB; w += 64) {
+    for (int w = lane; w < 8 * (PSS_WU - 1); w += 64) {
         const int64_t idx = ic + tmin - (PSS_DELAY + PSS_TAPS - 1) + w;
         const float2 v = (idx >= 0 && w < PSS_TILE + PSS_TAPS - 1) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
-        reinterpret_cast<float2 *>(&sW[(w >> 1) & 1][w >> 2])[w & 1] = v;
+        sW2[wslot(w)] = v;
     }
-    for (int w = lane; w < 4 * PSS_TQ; w += 64) sH[w] = (w < PSS_TAPS) ? T.pss_taps[PSS_TAPS - 1 - w] : 0.f;
+    for (int w = lane; w < 4 * PSS_TG; w += 64) sH[w] = (w < PSS_TAPS) ? T.pss_taps[PSS_TAPS - 1 - w] : 0.f;
     __syncthreads();
     // y(sample) = sum_w sH[w] * s[w + off], off = tag - tmin
     typedef float v2f_t __attribute__((ext_vector_type(2)));
-    float err4[4];
-    const bool beyond = q0 + 4 * lane >= chunk_len;      // lanes past the end of the chunk compute nothing that is stored
-    const bool consecutive = beyond || ((tg[0] >= 0) && (tg[1] == tg[0] + 1) && (tg[2] == tg[0] + 2) && (tg[3] == tg[0] + 3) &&
-                                        (((tg[0] - tmin) & 3) == 0));
-    if (__all(consecutive)) {
-        const int b0 = beyond ? 0 : (tg[0] - tmin) >> 2; // first window block of this thread
-        const float4 *xa = &sW[0][b0], *xb = &sW[1][b0];
-        const float4 *hr = reinterpret_cast<const float4 *>(sH);
-        v2f_t acc[4], c[8];
+    float err8[PSS_FPT];
+    const bool beyond = q >= chunk_len;                  // lanes past the end of the chunk compute nothing that is stored
+    bool consecutive = (tg[0] >= 0) && (((tg[0] - tmin) & 7) == 0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[j] = (v2f_t){0.f, 0.f};
-        { const float4 a = xa[0], b = xb[0]; c[0] = (v2f_t){a.x, a.y}; c[1] = (v2f_t){a.z, a.w}; c[2] = (v2f_t){b.x, b.y}; c[3] = (v2f_t){b.z, b.w}; }
-        for (int g = 0; g < PSS_TQ - 1; g += 2) {        // PSS_TQ - 1 = 74 groups cover the 295 taps
-            {
-                const float4 a = xa[g + 1], b = xb[g + 1];
-                c[4] = (v2f_t){a.x, a.y}; c[5] = (v2f_t){a.z, a.w}; c[6] = (v2f_t){b.x, b.y}; c[7] = (v2f_t){b.z, b.w};
+    for (int j = 1; j < PSS_FPT; j++) consecutive = consecutive && (tg[j] == tg[0] + j);
+    consecutive = consecutive || beyond;
+    if (__all(consecutive)) {
+        const int m = beyond ? 0 : (tg[0] - tmin) >> 3;  // this thread's first window unit is 4 m
+        const float4 *hr = reinterpret_cast<const float4 *>(sH);
+        v2f_t acc[PSS_FPT], c[12];
+#pragma unroll
+        for (int j = 0; j < PSS_FPT; j++) acc[j] = (v2f_t){0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {                    // ring = window entries 8 m .. 8 m + 11 (units 4 m .. 4 m + 5)
+            const float4 v = sW[k & 3][m + (k >> 2)];
+            c[2 * k] = (v2f_t){v.x, v.y}; c[2 * k + 1] = (v2f_t){v.z, v.w};
+        }
+        for (int g3 = 0; g3 < PSS_TG; g3 += 3) {
+#pragma unroll
+            for (int gg = 0; gg < 3; gg++) {             // group g: taps 4 g .. 4 g + 3 on ring entries (4 gg + q + j) % 12
+                const int g = g3 + gg;
                 const float4 h4 = hr[g];
                 const float hq[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const v2f_t w = (v2f_t){hq[q], hq[q]};
+                for (int qq = 0; qq < 4; qq++) {
+                    const v2f_t w = (v2f_t){hq[qq], hq[qq]};
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[j] = __builtin_elementwise_fma(w, c[q + j], acc[j]);
+                    for (int j = 0; j < PSS_FPT; j++) acc[j] = __builtin_elementwise_fma(w, c[(4 * gg + qq + j) % 12], acc[j]);
                 }
-            }
-            {
-                const float4 a = xa[g + 2], b = xb[g + 2];
-                c[0] = (v2f_t){a.x, a.y}; c[1] = (v2f_t){a.z, a.w}; c[2] = (v2f_t){b.x, b.y}; c[3] = (v2f_t){b.z, b.w};
-                const float4 h4 = hr[g + 1];
-                const float hq[4] = {h4.x, h4.y, h4.z, h4.w};
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const v2f_t w = (v2f_t){hq[q], hq[q]};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc[j] = __builtin_elementwise_fma(w, c[(4 + q + j) & 7], acc[j]);
-                }
+                // entries 4 g + 12 .. 4 g + 15 replace the four oldest: units 4 m + 2 g + 6, + 7
+                const int u0 = 2 * g + 6;
+                const float4 va = sW[u0 & 3][m + (u0 >> 2)], vb = sW[(u0 + 1) & 3][m + ((u0 + 1) >> 2)];
+                c[(4 * gg) % 12] = (v2f_t){va.x, va.y}; c[(4 * gg + 1) % 12] = (v2f_t){va.z, va.w};
+                c[(4 * gg + 2) % 12] = (v2f_t){vb.x, vb.y}; c[(4 * gg + 3) % 12] = (v2f_t){vb.z, vb.w};
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) err4[j] = acc[j].x * acc[j].y;
+        for (int j = 0; j < PSS_FPT; j++) err8[j] = acc[j].x * acc[j].y;
     } else {
-        const float2 *s2 = reinterpret_cast<const float2 *>(&sW[0][0]);
-        auto sat = [&](int w) -> float2 {                // entry w of the window in the half-plane layout
-            return reinterpret_cast<const float2 *>(&sW[(w >> 1) & 1][w >> 2])[w & 1];
-        };
-        (void)s2;
 #pragma unroll 1
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < PSS_FPT; j++) {
             float ar = 0.f, ai = 0.f;
             if (tg[j] >= 0) {
                 const int off = tg[j] - tmin;
-                for (int w = 0; w < PSS_TAPS; w++) { const float2 v = sat(w + off); ar = fmaf(sH[w], v.x, ar); ai = fmaf(sH[w], v.y, ai); }
+                for (int w = 0; w < PSS_TAPS; w++) { const float2 v = sW2[wslot(w + off)]; ar = fmaf(sH[w], v.x, ar); ai = fmaf(sH[w], v.y, ai); }
             }
-            err4[j] = ar * ai;
+            err8[j] = ar * ai;
         }
     }
     {
-        const int q = q0 + 4 * lane;
         float *dst = &B.w_err[widx(q, ch, (int)CP)];
-        if (q + 3 < chunk_len) *reinterpret_cast<f32x4_t *>(dst) = (f32x4_t){err4[0], err4[1], err4[2], err4[3]};
-        else for (int j = 0; j < 4; j++) if (q + j < chunk_len) dst[j] = err4[j];
+        if (q + PSS_FPT - 1 < chunk_len) {
+            reinterpret_cast<f32x4_t *>(dst)[0] = (f32x4_t){err8[0], err8[1], err8[2], err8[3]};
+            reinterpret_cast<f32x4_t *>(dst)[1] = (f32x4_t){err8[4], err8[5], err8[6], err8[7]};
+        } else for (int j = 0; j < PSS_FPT; j++) if (q + j < chunk_len) dst[j] = err8[j];
     }
 }
-__global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+__global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, TSync Y) {
+    if (!tsync_enter(Y, (int)blockIdx.y >> 6)) return;
     pss_fir_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
-    block_done(done);
 }
 
 // =================================================================================================
@@ -875,9 +903,9 @@ __device__ __forceinline__ void pss_mix_body(DeviceTables T, DeviceBuffers B, Ca
         B.lr_ring[(size_t)ch[i] * ring + (j & G.ring_mask)] = audio;
     }
 }
-__global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+__global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, TSync Y) {
+    if (!tsync_enter(Y, (int)blockIdx.y)) return;
     pss_mix_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
-    block_done(done);
 }
 // =================================================================================================
 // B8  de-emphasis   [lane per channel]   fm-processor.cpp:594-595 (the gain of :303-306 is applied by the audio kernel)
@@ -964,9 +992,9 @@ __device__ __forceinline__ void dring_body(DeviceBuffers B, CallGeom G, int C, i
         if (ch < C) B.dring[(size_t)ch * dcap + ((G.J0 + r) & G.dring_mask)] = B.w_x[widx(r, ch, CP)];
     }
 }
-__global__ __launch_bounds__(256) void dring_kernel(DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, int *done) {
+__global__ __launch_bounds__(256) void dring_kernel(DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, TSync Y) {
+    if (!tsync_enter(Y, (int)blockIdx.y)) return;
     dring_body(B, G, C, row0, nrows, (int)blockIdx.x, (int)blockIdx.y);
-    block_done(done);
 }
 
 // =================================================================================================
@@ -1106,16 +1134,22 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
     else if (T.trig2) { if (plldec) launch_recurrences<true, true, false>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, true, false>(T, B, G, C, P, S, groups, DS.rs); }
     else { if (plldec) launch_recurrences<true, false, false>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, false, false>(T, B, G, C, P, S, groups, DS.rs); }
     auto trow = [&](int c) { return dim3((unsigned)((P.len[c] + WT - 1) / WT), (unsigned)groups); };
-    auto signal = [&](hipStream_t q, int *p, int v) { hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, q, p, v); };
-    auto gate = [&](hipStream_t q, int role, int need) { hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, q, S, role, groups, need); };
     hipStream_t tq = DS.ts[0];
+    int *prog = &S->prog[0][0];
+    // the completion word of a kernel travels with the NEXT kernel on the stream (TSync::sig)
+    int *pend_p = nullptr; int pend_v = 0;
+    auto ysync = [&](int role, int need) {
+        TSync Y{};
+        Y.gate = role >= 0 ? prog + role * groups : nullptr; Y.need = need; Y.sig = pend_p; Y.sigv = pend_v; Y.abort_flag = &S->abort;
+        pend_p = nullptr;
+        return Y;
+    };
     auto disc = [&](int c) {
-        hipLaunchKernelGGL(disc_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
-        signal(tq, &S->cnt_disc[c], P.nb_disc[c]);
+        hipLaunchKernelGGL(disc_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(-1, 0));
+        pend_p = &S->cnt_disc[c]; pend_v = P.nb_disc[c];
     };
     auto dring = [&](int c) {
-        gate(tq, 4, c + 1);
-        hipLaunchKernelGGL(dring_kernel, trow(c), dim3(256), 0, tq, B, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
+        hipLaunchKernelGGL(dring_kernel, trow(c), dim3(256), 0, tq, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(4, c + 1));
     };
     // One stream for all the time-parallel kernels.  Chunks are at most HALF the PSS feedback lag long, so the low-pass of
     // chunk c reads s-ring entries the mix wrote no later than chunk c - 2: it does not wait for the integrator of chunk
@@ -1123,16 +1157,14 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
     // its producers:  low-pass(c), disc(c + 3), d-ring(c - 2), mix(c - 1).
     constexpr int LEAD = 3;
     auto fir = [&](int c) {
-        gate(tq, 2, c + 1);
         DeviceBuffers Bc = B;
         Bc.w_err = B.w_err + (size_t)(c & 1) * (PB_CHUNK / WT) * G.pitch * WT;
-        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((P.len[c] + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, tq, T, Bc, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
-        signal(tq, &S->cnt_fir[c], P.nb_fir[c]);
+        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((P.len[c] + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, tq, T, Bc, G, C, (int64_t)P.rc0[c], P.len[c], ysync(2, c + 1));
+        pend_p = &S->cnt_fir[c]; pend_v = P.nb_fir[c];
     };
     auto mix = [&](int c) {
-        gate(tq, 3, c + 1);
-        hipLaunchKernelGGL(pss_mix_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], (int *)nullptr);
-        signal(tq, &S->cnt_mix[c], P.nb_mix[c]);
+        hipLaunchKernelGGL(pss_mix_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(3, c + 1));
+        pend_p = &S->cnt_mix[c]; pend_v = P.nb_mix[c];
     };
     for (int c = 0; c < LEAD && c < P.n; c++) disc(c);
     for (int c = 0; c < P.n + 2; c++) {
@@ -1141,6 +1173,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         if (c >= 2 && c - 2 < P.n) dring(c - 2);
         if (c >= 1 && c - 1 < P.n) mix(c - 1);
     }
+    if (pend_p) hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, tq, pend_p, pend_v);
     hipStream_t ends[2] = { DS.rs, DS.ts[0] };
     for (hipStream_t q : ends) {
         hipEvent_t e = DS.ev[(*DS.ev_next)++ % DS.nev];
@@ -1178,7 +1211,7 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         const int last = (rc0 + len >= nj) ? 1 : 0;
         // the discriminator runs per chunk in front of the AFC (a stage with time to spare), so the first PSS kernel
         // starts after 256 rows of it instead of after the whole call's
-        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[0], T, B, G, C, rc0, len, (int *)nullptr);
+        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[0], T, B, G, C, rc0, len, TSync{});
         if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len, (int *)nullptr);
         else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len, (int *)nullptr);
         hand_over(0, 1, c);
@@ -1188,12 +1221,12 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         hand_over(1, 2, c);
         hipLaunchKernelGGL(lock_kernel, lanes, dim3(64), 0, st[2], T, B, G, C, rc0, len, (int *)nullptr);
         hand_over(2, 3, c);
-        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, st[3], T, B, G, C, rc0, len, (int *)nullptr);
+        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, st[3], T, B, G, C, rc0, len, TSync{});
         hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, st[3], T, B, G, C, rc0, len, (int *)nullptr);
-        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len, (int *)nullptr);
+        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len, TSync{});
         hand_over(3, 4, c);
         hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last, (int *)nullptr);
-        hipLaunchKernelGGL(dring_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[4], B, G, C, rc0, len, (int *)nullptr);
+        hipLaunchKernelGGL(dring_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[4], B, G, C, rc0, len, TSync{});
         rc0 += len;
     }
     if (s3 != s) { (void)hipEventRecord(DS.join, s3); (void)hipStreamWaitEvent(s, DS.join, 0); }
