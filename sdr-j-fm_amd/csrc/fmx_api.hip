@@ -581,8 +581,6 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     const size_t C = (size_t)h->channels;
     HIPCHK(hipMalloc(&h->B.hist, sizeof(float2) * C * DECIM * A_HIST_COLS));
     HIPCHK(hipMalloc(&h->B.zring, sizeof(float2) * C * h->ring));
-    HIPCHK(hipMalloc(&h->B.demod_ring, sizeof(float) * C * h->ring));
-    HIPCHK(hipMalloc(&h->B.lr_ring, sizeof(float2) * C * h->ring));
     HIPCHK(hipMalloc(&h->B.sring, sizeof(float2) * C * h->sring));
     HIPCHK(hipMalloc(&h->B.dring, sizeof(float2) * C * h->dring));
     {
@@ -593,7 +591,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMalloc(&h->B.w_dem, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_cur, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_osc, sizeof(float) * NJ * C));
-        HIPCHK(hipMalloc(&h->B.w_lock, sizeof(uint8_t) * NJ * C));
+        HIPCHK(hipMalloc(&h->B.w_diff, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_err, sizeof(float) * (size_t)(PSS_CHUNK + WT) * C));
         HIPCHK(hipMalloc(&h->B.w_pdp, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_tag, sizeof(int32_t) * NJ * C));
@@ -603,7 +601,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMemset(h->B.w_dem, 0, sizeof(float) * NJ * C));
         HIPCHK(hipMemset(h->B.w_cur, 0, sizeof(float) * NJ * C));
         HIPCHK(hipMemset(h->B.w_osc, 0, sizeof(float) * NJ * C));
-        HIPCHK(hipMemset(h->B.w_lock, 0, sizeof(uint8_t) * NJ * C));
+        HIPCHK(hipMemset(h->B.w_diff, 0, sizeof(float) * NJ * C));
         HIPCHK(hipMemset(h->B.w_err, 0, sizeof(float) * (size_t)(PSS_CHUNK + WT) * C));
         HIPCHK(hipMemset(h->B.w_pdp, 0, sizeof(float) * NJ * C));
         HIPCHK(hipMemset(h->B.w_tag, 0, sizeof(int32_t) * NJ * C));
@@ -613,8 +611,6 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     HIPCHK(hipMalloc(&h->d_params, sizeof(ChanParams) * C));
     HIPCHK(hipMemset(h->B.hist, 0, sizeof(float2) * C * DECIM * A_HIST_COLS));
     HIPCHK(hipMemset(h->B.zring, 0, sizeof(float2) * C * h->ring));
-    HIPCHK(hipMemset(h->B.demod_ring, 0, sizeof(float) * C * h->ring));
-    HIPCHK(hipMemset(h->B.lr_ring, 0, sizeof(float2) * C * h->ring));
     HIPCHK(hipMemset(h->B.sring, 0, sizeof(float2) * C * h->sring));
     HIPCHK(hipMemset(h->B.dring, 0, sizeof(float2) * C * h->dring));
     {
@@ -636,9 +632,9 @@ int fmx_destroy(fmx_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &pr : h->prof) for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
     void *ptrs[] = { h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
-                     h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.zring, h->B.demod_ring,
-                     h->B.lr_ring, h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
-                     h->B.w_osc, h->B.w_lock, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x };
+                     h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.zring,
+                     h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
+                     h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->evs) (void)hipEventDestroy(e);
@@ -815,8 +811,22 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
     switch (tap) {
     case FMX_TAP_FM_IQ: base = (const char *)(h->B.zring + (size_t)channel * h->ring); cap = h->ring; elem = sizeof(float2);
         delay = h->h_front_sets[h->params[channel].front_set].delay_fm; break;
-    case FMX_TAP_DEMOD: base = (const char *)(h->B.demod_ring + (size_t)channel * h->ring); cap = h->ring; elem = sizeof(float); break;
-    case FMX_TAP_LR_RAW: base = (const char *)(h->B.lr_ring + (size_t)channel * h->ring); cap = h->ring; elem = sizeof(float2); break;
+    case FMX_TAP_DEMOD: case FMX_TAP_LR_RAW: {
+        // these two taps are read back from the last call's work arrays (tiles of 16 rows: widx), rows [nj - n, nj)
+        const int64_t nj = h->last_J1 - h->last_J0, r0 = nj - n;
+        if (n == 0) return FMX_OK;
+        const int64_t t0 = r0 / WT, t1 = (nj - 1) / WT + 1;
+        std::vector<float> a((size_t)(t1 - t0) * WT), b;
+        const size_t spitch = (size_t)h->pitch * WT * sizeof(float);
+        HIPCHK(hipMemcpy2D(a.data(), WT * sizeof(float), h->B.w_dem + ((size_t)t0 * h->pitch + channel) * WT, spitch, WT * sizeof(float), (size_t)(t1 - t0), hipMemcpyDeviceToHost));
+        if (tap == FMX_TAP_LR_RAW) {
+            b.resize(a.size());
+            HIPCHK(hipMemcpy2D(b.data(), WT * sizeof(float), h->B.w_diff + ((size_t)t0 * h->pitch + channel) * WT, spitch, WT * sizeof(float), (size_t)(t1 - t0), hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; i++) { dst[2 * i] = a[(size_t)(r0 - t0 * WT + i)]; dst[2 * i + 1] = b[(size_t)(r0 - t0 * WT + i)]; }
+        } else {
+            std::memcpy(dst, a.data() + (r0 - t0 * WT), sizeof(float) * (size_t)n);
+        }
+        return FMX_OK; }
     case FMX_TAP_PRE_RESAMPLER: base = (const char *)(h->B.dring + (size_t)channel * h->dring); cap = h->dring; elem = sizeof(float2); break;
     case 4: {   // FMX_TAP_RDS_IQ: complex @24 kS/s after rdsDecimator (:553): the last n outputs of the last call
         if (!h->rds_alloc) return fail(FMX_E_INVALID, "RDS is off");

@@ -839,7 +839,6 @@ __device__ __forceinline__ void pss_mix_body(DeviceTables T, DeviceBuffers B, Ca
     const int tid = threadIdx.x;
     const int q0 = bid_x * WT;
     const int c0 = bid_y * 64;
-    const int ring = G.ring_mask + 1;
     const float2 *__restrict__ sct = T.sincos;
     const double SC = T.sincos_C;
     constexpr int EPT = 4;
@@ -897,10 +896,7 @@ __device__ __forceinline__ void pss_mix_body(DeviceTables T, DeviceBuffers B, Ca
         case 5: case 6: o = make_float2(dw, dw); break;
         }
         B.w_x[wi[i]] = o;
-        // channel-major tap rings (GUI scope feeds / tests): 16 consecutive entries per channel from 16 lanes
-        const int64_t j = G.J0 + rc0 + q;
-        B.demod_ring[(size_t)ch[i] * ring + (j & G.ring_mask)] = demod[i];
-        B.lr_ring[(size_t)ch[i] * ring + (j & G.ring_mask)] = audio;
+        B.w_diff[wi[i]] = audio.y;                  // (sum, diff) scope tap = (w_dem, w_diff): read back by fmx_get_tap
     }
 }
 __global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, TSync Y) {
@@ -921,7 +917,9 @@ __device__ __forceinline__ void deemph_body(DeviceTables T, DeviceBuffers B, Cal
     const ChanParams &P = B.params[ch];
     const float a = P.deemph_alpha;
     float yl = st->de_l, yr = st->de_r;
-    float2 *x = B.w_x + widx(rc0, ch, CP);
+    const float2 *x = B.w_x + widx(rc0, ch, CP);
+    const int64_t dmask = G.dring_mask, dcap = G.dring_mask + 1;
+    float2 *dr = B.dring + (size_t)ch * dcap;
     constexpr int UB = SEQ_UB;
     const int nfull = (int)(nj / UB);
     const int TS = UB * CP;
@@ -938,13 +936,16 @@ __device__ __forceinline__ void deemph_body(DeviceTables T, DeviceBuffers B, Cal
                 yr = (v[k].y - yr) * a + yr;
                 v[k] = make_float2(yl, yr);
             }
-            wst2(x + tb * TS, v);
+            // straight into the channel-major d ring the audio kernel reads: 16 rows = 128 contiguous bytes per lane
+            const int64_t p0 = (G.J0 + rc0 + (int64_t)tb * UB) & dmask;
+            if (p0 + UB <= dcap && (p0 & 1) == 0) wst2(dr + p0, v);
+            else for (int k = 0; k < UB; k++) dr[(p0 + k) & dmask] = v[k];
         });
     for (int k = 0; k < (int)(nj - (int64_t)nfull * UB); k++) {
         const float2 v = x[nfull * TS + k];
         yl = (v.x - yl) * a + yl;
         yr = (v.y - yr) * a + yr;
-        x[nfull * TS + k] = make_float2(yl, yr);
+        dr[(G.J0 + rc0 + (int64_t)nfull * UB + k) & dmask] = make_float2(yl, yr);
     }
     st->de_l = yl; st->de_r = yr;
     if (!last_chunk) return;
@@ -972,29 +973,6 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
     FMX_RECURRENCE_PRIO();
     deemph_body(T, B, G, C, rc0, chunk_len, last_chunk, (int)blockIdx.x, (int)blockIdx.y);
     block_done(done);
-}
-
-// =================================================================================================
-// B9  work array -> channel-major d ring   (transpose)
-// =================================================================================================
-__device__ __forceinline__ void dring_body(DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, const int bid_x, const int bid_y) {
-    // one block = one work-array tile row (16 samples x 64 channels); threads as (sample in tile, channel): 128-byte runs on
-    // both sides, nothing to transpose
-    const int CP = G.pitch;
-    const int tid = threadIdx.x;
-    const int64_t r = row0 + (int64_t)bid_x * WT + (tid & 15);
-    const int c0 = bid_y * 64;
-    const int dcap = G.dring_mask + 1;
-    if (r >= row0 + nrows) return;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int ch = c0 + (tid >> 4) + 16 * i;
-        if (ch < C) B.dring[(size_t)ch * dcap + ((G.J0 + r) & G.dring_mask)] = B.w_x[widx(r, ch, CP)];
-    }
-}
-__global__ __launch_bounds__(256) void dring_kernel(DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, TSync Y) {
-    if (!tsync_enter(Y, (int)blockIdx.y)) return;
-    dring_body(B, G, C, row0, nrows, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // =================================================================================================
@@ -1148,13 +1126,10 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         hipLaunchKernelGGL(disc_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(-1, 0));
         pend_p = &S->cnt_disc[c]; pend_v = P.nb_disc[c];
     };
-    auto dring = [&](int c) {
-        hipLaunchKernelGGL(dring_kernel, trow(c), dim3(256), 0, tq, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(4, c + 1));
-    };
     // One stream for all the time-parallel kernels.  Chunks are at most HALF the PSS feedback lag long, so the low-pass of
     // chunk c reads s-ring entries the mix wrote no later than chunk c - 2: it does not wait for the integrator of chunk
     // c - 1, the integrator runs chunk after chunk without a gap, and the order below only has to keep every kernel behind
-    // its producers:  low-pass(c), disc(c + 3), d-ring(c - 2), mix(c - 1).
+    // its producers:  low-pass(c), disc(c + 3), mix(c - 1).  (The de-emphasis role writes the d ring itself.)
     constexpr int LEAD = 3;
     auto fir = [&](int c) {
         DeviceBuffers Bc = B;
@@ -1167,10 +1142,9 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         pend_p = &S->cnt_mix[c]; pend_v = P.nb_mix[c];
     };
     for (int c = 0; c < LEAD && c < P.n; c++) disc(c);
-    for (int c = 0; c < P.n + 2; c++) {
+    for (int c = 0; c < P.n + 1; c++) {
         if (c < P.n) fir(c);
         if (c + LEAD < P.n) disc(c + LEAD);
-        if (c >= 2 && c - 2 < P.n) dring(c - 2);
         if (c >= 1 && c - 1 < P.n) mix(c - 1);
     }
     if (pend_p) hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, tq, pend_p, pend_v);
@@ -1226,7 +1200,6 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len, TSync{});
         hand_over(3, 4, c);
         hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last, (int *)nullptr);
-        hipLaunchKernelGGL(dring_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[4], B, G, C, rc0, len, TSync{});
         rc0 += len;
     }
     if (s3 != s) { (void)hipEventRecord(DS.join, s3); (void)hipStreamWaitEvent(s, DS.join, 0); }

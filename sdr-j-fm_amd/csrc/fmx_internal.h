@@ -132,8 +132,6 @@ struct CallGeom {
 struct DeviceBuffers {
     float2 *hist;        // [channels][DECIM][A_HIST_COLS]   mixed input history (column layout)
     float2 *zring;       // [channels][ring]  front-end output v[j]
-    float  *demod_ring;  // [channels][ring]
-    float2 *lr_ring;     // [channels][ring]  (sum, diff)
     float2 *sring;       // [channels][sring] PSS filter input history
     float2 *dring;       // [channels][dring] de-emphasised, gained stereo @ fmRate
     ChanState *state;
@@ -144,7 +142,7 @@ struct DeviceBuffers {
     float2  *w_iq;       // limiter output (only allocated when a channel uses the PLL decoder)
     float   *w_cur;      // pilot phase (currentPilotPhase)
     float   *w_osc;      // pilot NCO sine
-    uint8_t *w_lock;     // (spare byte-per-sample array; the lock flag travels packed in w_tag)
+    float   *w_diff;     // [fm sample][channel] L-R difference before the matrix (LR scope tap, with w_dem)
     float   *w_err;      // [PSS_CHUNK][channel] PSS error for the chunk's call indices
     float   *w_pdp;      // pilotDelayPSS as used by each sample
     int32_t *w_tag;      // -2 mono branch, -1 stereo without PSS, >= 0 PSS call index within the chunk
