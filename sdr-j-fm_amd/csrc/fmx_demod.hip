@@ -1018,6 +1018,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     FMX_RECURRENCE_PRIO();
     const int grp = blockIdx.x, role = blockIdx.y;
     int *prog = &S->prog[0][0];
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&S->started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool first = true;
     for (int c = 0; c < P.n; c++) {
         bool ok = true;
@@ -1048,11 +1049,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
-// Gate in front of a time-parallel kernel on its stream: returns once role `role` has finished chunk `need - 1` in every group.
-__global__ __launch_bounds__(64) void gate_kernel(DemodSync *S, int role, int groups, int need) {
-    const int *prog = &S->prog[0][0] + role * groups;
-    for (int g = threadIdx.x; g < groups; g += 64)
-        if (!pb_wait(&prog[g], need, &S->abort, 100 * need + 10 + role)) return;
+// Head of the time-parallel stream: returns once every workgroup of the recurrence kernel is running.  The time-parallel
+// kernels' blocks wait in place for their group's progress word; where they share CUs with the recurrence kernel they
+// must not be allowed to fill those CUs before the workgroups they wait for are resident.
+__global__ __launch_bounds__(64) void start_gate_kernel(DemodSync *S, int need) {
+    (void)pb_wait(&S->started, need, &S->abort, 9999);
 }
 
 // Completion word of a time-parallel kernel: launched right behind it on the same stream, so the kernel boundary has
@@ -1141,6 +1142,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         hipLaunchKernelGGL(pss_mix_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(3, c + 1));
         pend_p = &S->cnt_mix[c]; pend_v = P.nb_mix[c];
     };
+    hipLaunchKernelGGL(start_gate_kernel, dim3(1), dim3(64), 0, tq, S, PB_ROLES * groups);
     for (int c = 0; c < LEAD && c < P.n; c++) disc(c);
     for (int c = 0; c < P.n + 1; c++) {
         if (c < P.n) fir(c);

@@ -194,7 +194,8 @@ struct DemodSync {                      // zeroed at the start of every call
     int abort;                          // set when a wait ran out of patience (a stalled pipeline must not hang the GPU)
     int info[3];                        // first waiter that gave up: id, value needed, value seen
     int groups;
-    int pad[11];
+    int started;                        // workgroups of the recurrence kernel that have begun (all of them must be resident)
+    int pad[10];
     int snap[64];                       // snapshot of the words below at that moment (diagnostics)
     int cnt_disc[PB_MAX_CHUNKS], cnt_fir[PB_MAX_CHUNKS], cnt_mix[PB_MAX_CHUNKS];     // finished blocks of chunk c's kernel
     int prog[PB_ROLES][1];              // [role][group]: chunks finished; really [PB_ROLES][groups] (allocated to size)
