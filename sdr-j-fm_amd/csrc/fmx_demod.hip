@@ -151,31 +151,39 @@ __device__ __forceinline__ void block_done(int *done) {
 // =================================================================================================
 // B1  limiter + memoryless discriminator   (time-parallel; 64 samples x 64 channels per block)
 // =================================================================================================
+constexpr int DISC_ROWS = 64, DISC_CH = 16;             // one block: four work-array tile rows of sixteen channels
 __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, const int bid_x, const int bid_y) {
-    // One block = one work-array tile row: 16 samples x 64 channels (rows row0 + 16 bid_x ...; row0 is a multiple of 16).
+    // One block = 64 samples x 16 channels: the ring reads are 528-byte runs per channel (the ring is channel-major), the
+    // work-array stores 1 KB runs (16 rows x 16 channels of a tile row are contiguous).
     const int CP = G.pitch;
-    __shared__ float2 sLIM[64][WT + 3];               // limited samples of rows r0-2 .. r0+15 (each is used by up to three outputs)
+    __shared__ float2 sLIM[DISC_CH][DISC_ROWS + 3];   // limited samples of rows r0-2 .. r0+63 (each is used by up to three outputs)
+    __shared__ int sDelay[DISC_CH], sDec[DISC_CH];
     const int tid = threadIdx.x;
     const int64_t nj = row0 + nrows;
-    const int64_t r0 = row0 + (int64_t)bid_x * WT;
-    const int c0 = bid_y * 64;
+    const int64_t r0 = row0 + (int64_t)bid_x * DISC_ROWS;
+    const int c0 = bid_y * DISC_CH;
     const int ring = G.ring_mask + 1;
     const bool want_iq = B.w_iq != nullptr;
-    // ---- limiter (fm-demodulator.cpp:119-126), once per sample: 18 consecutive ring entries per channel
-    for (int i = tid; i < 64 * (WT + 2); i += 256) {
-        const int cl = i / (WT + 2), rl = i - (WT + 2) * cl;      // rl 0..17 <-> row r0 - 2 + rl
+    if (tid < DISC_CH) {
+        const int ch = c0 + tid;
+        sDelay[tid] = ch < C ? T.front_sets[B.params[ch].front_set].delay_fm : 0;
+        sDec[tid] = ch < C ? B.params[ch].decoder : 0;
+    }
+    __syncthreads();
+    // ---- limiter (fm-demodulator.cpp:119-126), once per sample: 66 consecutive ring entries per channel
+    for (int i = tid; i < DISC_CH * (DISC_ROWS + 2); i += 256) {
+        const int cl = i / (DISC_ROWS + 2), rl = i - (DISC_ROWS + 2) * cl;      // rl 0..65 <-> row r0 - 2 + rl
         const int ch = c0 + cl;
         float2 v = make_float2(0.f, 0.f);
         if (ch < C) {
-            const int delay = T.front_sets[B.params[ch].front_set].delay_fm;
             const float2 *zr = B.zring + (size_t)ch * ring;
             const int64_t jj = G.J0 + r0 - 2 + rl;
             // z[j'] is 0 before the filter latency has elapsed; the demodulator's initial Imin/Qmin is 0.01
             // (fm-demodulator.cpp:79-82)
-            const bool am = B.params[ch].decoder == 1;      // the AM decoder works on the unlimited sample (fm-demodulator.cpp:133-134)
+            const bool am = sDec[cl] == 1;                   // the AM decoder works on the unlimited sample (fm-demodulator.cpp:133-134)
             if (jj < 0) v = am ? make_float2(0.f, 0.f) : make_float2((float)0.01, (float)0.01);
             else {
-                const int64_t s = jj - delay;
+                const int64_t s = jj - sDelay[cl];
                 const float2 z = s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f);
                 v = am ? z : limiter(z);
             }
@@ -183,17 +191,18 @@ __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallG
         sLIM[cl][rl] = v;
     }
     __syncthreads();
-    // ---- discriminator; threads as (sample in tile, channel): 64-byte runs in the tiled work arrays
+    // ---- discriminator; threads as (sample in tile row, channel), one tile row per step
+    const int rl16 = tid & 15, cl = tid >> 4;
+    const int ch = c0 + cl;
+    const int decoder = sDec[cl];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int rl = tid & 15, cl = (tid >> 4) + 16 * i;
-        const int ch = c0 + cl;
+    for (int i = 0; i < DISC_ROWS / WT; i++) {
+        const int rl = WT * i + rl16;
         const int64_t r = r0 + rl;
         if (ch < C && r < nj) {
             float res = 0.f;
             const float2 cur = sLIM[cl][rl + 2], p1 = sLIM[cl][rl + 1];
             const float I = cur.x, Q = cur.y, I1 = p1.x, Q1 = p1.y;
-            const int decoder = B.params[ch].decoder;
             if (decoder == 1) {            // AM: |z| for decodeAM (:215-241); the carrier IIR and the PLL run in afc_kernel
                 res = (float)sqrt((double)cur.x * (double)cur.x + (double)cur.y * (double)cur.y);
             } else if (decoder == 5) {     // REAL_BB fm-demodulator.cpp:174-182
@@ -216,7 +225,7 @@ __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallG
     }
 }
 __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, TSync Y) {
-    if (!tsync_enter(Y, (int)blockIdx.y)) return;
+    if (!tsync_enter(Y, (int)blockIdx.y >> 2)) return;
     disc_body(T, B, G, C, row0, nrows, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -1098,7 +1107,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         const int cap = (c == 0 && nj > 2 * FIRST_CHUNK) ? FIRST_CHUNK : PB_CHUNK;
         const int len = (int)((nj - rc0) < cap ? (nj - rc0) : cap);
         P.rc0[c] = (int)rc0; P.len[c] = len;
-        P.nb_disc[c] = ((len + WT - 1) / WT) * groups; P.nb_mix[c] = P.nb_disc[c];
+        P.nb_disc[c] = ((len + DISC_ROWS - 1) / DISC_ROWS) * ((C + DISC_CH - 1) / DISC_CH); P.nb_mix[c] = ((len + WT - 1) / WT) * groups;
         P.nb_fir[c] = ((len + PSS_TILE - 1) / PSS_TILE) * C;
         P.n++; rc0 += len;
     }
@@ -1124,7 +1133,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         return Y;
     };
     auto disc = [&](int c) {
-        hipLaunchKernelGGL(disc_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(-1, 0));
+        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((P.len[c] + DISC_ROWS - 1) / DISC_ROWS), (unsigned)((C + DISC_CH - 1) / DISC_CH)), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(-1, 0));
         pend_p = &S->cnt_disc[c]; pend_v = P.nb_disc[c];
     };
     // One stream for all the time-parallel kernels.  Chunks are at most HALF the PSS feedback lag long, so the low-pass of
@@ -1187,7 +1196,7 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         const int last = (rc0 + len >= nj) ? 1 : 0;
         // the discriminator runs per chunk in front of the AFC (a stage with time to spare), so the first PSS kernel
         // starts after 256 rows of it instead of after the whole call's
-        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[0], T, B, G, C, rc0, len, TSync{});
+        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + DISC_ROWS - 1) / DISC_ROWS), (unsigned)((C + DISC_CH - 1) / DISC_CH)), dim3(256), 0, st[0], T, B, G, C, rc0, len, TSync{});
         if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len, (int *)nullptr);
         else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len, (int *)nullptr);
         hand_over(0, 1, c);
