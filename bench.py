@@ -4,11 +4,13 @@
 
 A "step" = one pass of the whole chain (front-end FIR -> discriminator/pilot PLL/PSS -> audio FIR +
 resampler) over one batch: `channels` independent FM channels x `block` complex samples each,
-IQ already resident in HBM.  Default workload = BASELINE configs[3]'s per-GPU shard (4096 channels
-over 8 GPUs = 512 per GPU) with configs[1]'s per-channel settings (stereo + PSS + de-emphasis +
-input FIR ON).  Multi-GPU: one rank per GPU, channels sharded, no data-path collective (weak scaling).
+IQ already resident in HBM.  Default workload = BASELINE configs[3] -- 4096 independent channels with
+configs[1]'s per-channel settings (stereo + PSS + de-emphasis + input FIR ON) -- which fits one GPU
+(7.5 GB of IQ per step), so every rank runs all of it (weak scaling: 4096 channels per GPU); `--workload
+shard512` is the same config split over eight GPUs.  Multi-GPU: one rank per GPU, channels sharded, no
+data-path collective.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload shard512|config2|config3|config5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config4|shard512|config2|config3|config5]
 """
 import argparse
 import ctypes
@@ -23,8 +25,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# libfmx pipelines stage B on five HIP streams; ROCm maps streams onto 4 hardware queues by default, so two of them
-# would share one.  Must be set before the HIP runtime starts (i.e. before torch is imported).
+# libfmx's event-driven stage-B layout uses five HIP streams; ROCm maps streams onto 4 hardware queues by default, so two
+# of them would share one (the persistent layout has its own CU-masked queues).  Must be set before the HIP runtime starts (i.e. before torch is imported).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 INPUT_RATE = 2304000
@@ -34,8 +36,9 @@ HBM_PEAK_GBPS = 8000.0                    # MI355X_MICROARCH.md: 8 TB/s spec
 
 WORKLOADS = {
     # name: (channels per GPU, streams per GPU (0 = one per channel), description)
-    "shard512": (512, 0, "configs[3] per-GPU shard: 512 independent 2.304 MS/s channels, configs[1] settings "
+    "config4": (4096, 0, "configs[3] whole on each GPU: 4096 independent 2.304 MS/s channels, configs[1] settings "
                          "(stereo + PSS + de-emphasis 50us + input FIR 165 kHz + audio LPF 15 kHz)"),
+    "shard512": (512, 0, "configs[3] split over 8 GPUs, one GPU's shard: 512 independent channels, configs[1] settings"),
     "config2": (1, 0, "configs[1]: 1 channel, stereo + PSS + de-emphasis + input FIR ON"),
     "config3": (256, 24, "configs[2]: 256 carriers in 24 wide-band IQ streams (11 per stream, 200 kHz raster)"),
     "config5": (2048, 0, "configs[4] per-GPU shard: 2048 channels (16384 over 8 GPUs), full chain incl. the RDS front end and "
@@ -129,7 +132,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=12)   # past the pilot-lock / PSS transition of the synthetic signal (calls 5-8)
-    ap.add_argument("--workload", default="shard512", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="config4", choices=sorted(WORKLOADS))
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -14,14 +14,16 @@
 //
 // MI355X design.  The stage is a chain of small kernels over a call's fm-rate samples, of two kinds:
 //   * time-parallel kernels (one thread per (channel, sample)): limiter + LUT discriminator,
-//     the PSS low-pass, the 38 kHz mix + matrix, the ring transposes;
+//     the PSS low-pass, the 38 kHz mix + matrix;
 //   * recurrence kernels (AFC, pilot PLL, lock detector, PSS integrator, de-emphasis): ONE LANE PER
 //     CHANNEL, 64 channels per wavefront, all lanes stepping through time together.  These loops
 //     cannot be parallelised in time (non-linear feedback through LUT indices); their parallelism
 //     is the channel count, and every lane is busy.  Work arrays between the kernels are
 //     sample-major [sample][channel] so both kinds of kernel access them coalesced.
 // The only feedback path with a lag is the PSS loop (error -> integrator -> 38 kHz phase -> mix ->
-// 1753-sample low-pass -> error), so only its kernels are iterated in chunks of <= 1753 samples.
+// 1753-sample low-pass -> error), which is why a call is processed in chunks.  Two schedules exist (launch_demod): the
+// persistent one -- all recurrences of a call in ONE kernel on its own CUs, progress words in device memory -- and the
+// event-driven one (a five-stream software pipeline of per-chunk kernels).
 #include "fmx_internal.h"
 
 namespace fmx {
@@ -985,7 +987,7 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
 }
 
 // =================================================================================================
-// Persistent layout of stage B (large channel counts, see launch_demod_persistent)
+// Persistent layout of stage B (see launch_demod_persistent)
 // =================================================================================================
 struct ChunkPlan { int n; int rc0[PB_MAX_CHUNKS]; int len[PB_MAX_CHUNKS]; int nb_disc[PB_MAX_CHUNKS], nb_fir[PB_MAX_CHUNKS], nb_mix[PB_MAX_CHUNKS]; };
 constexpr int PB_SPIN_LIMIT = 1 << 22;            // x ~0.5 us: a wait longer than ~2 s gives up and raises DemodSync::abort
@@ -1087,14 +1089,13 @@ int recurrences_blocks_per_cu() {
     return n < m ? n : m;
 }
 
-// Stage B for large channel counts.  A time-parallel kernel then fills every CU for tens of microseconds; a recurrence wave
-// that shares a CU with it runs 2-3x slower, and stream events between many queues cost 60-160 us each on this GPU (they
-// are cheap only between two or three queues).  So: the recurrences of the WHOLE call are one persistent kernel on a CU set
-// of their own, the time-parallel kernels run on the remaining CUs in two streams, and the two sides meet through progress
-// words in device memory --
-//   ts[1]: disc(0..2) | per chunk c: [gate de-emphasis(c)] d-ring(c), disc(c+3)
-//   ts[0]: per chunk c: [gate lock(c)] PSS low-pass(c), [gate integrator(c)] mix(c)
-//   rs   : AFC(c) <- disc(c) count;  PLL <- AFC;  lock <- PLL;  integrator(c) <- low-pass(c) count;  de-emphasis(c) <- mix(c) count
+// The persistent schedule of stage B.  Measured on this GPU: a time-parallel kernel at thousands of channels fills every CU
+// for tens of microseconds and a recurrence wave that shares a CU with it runs 2-3x slower; stream events between many
+// queues cost 60-160 us each (they are cheap only between two or three queues).  So the recurrences of the WHOLE call are
+// one persistent kernel on a CU set of their own, the time-parallel kernels run on one other stream, and the two sides
+// meet through progress words in device memory --
+//   ts[0]: start gate | disc(0..2) | per chunk c: low-pass(c) [lock(c)], disc(c+3), mix(c-1) [integrator(c-1)]
+//   rs   : AFC(c) <- disc(c) word;  PLL <- AFC;  lock <- PLL;  integrator(c) <- low-pass(c) word;  de-emphasis(c) <- mix(c) word
 // Stream events remain only at the two ends of the call.
 static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s,
                                     const DemodStreams &DS) {
