@@ -51,6 +51,7 @@ struct fmx_handle_s {
     hipStream_t s_side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the stage-B chunk pipeline
     hipStream_t s_r = nullptr, s_t[2] = {nullptr, nullptr};          // persistent layout of stage B: CU-masked streams
     DemodSync *d_sync = nullptr;
+    int *h_stall = nullptr, *d_stall = nullptr;                      // host-mapped: set by the GPU when the persistent layout stalled
     bool partitioned = false; int ev_next = 0;
     std::vector<hipEvent_t> evs; hipEvent_t ev_join = nullptr;
     std::mutex mtx;                          // guards the mailbox (set_param from any thread)
@@ -356,7 +357,13 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         DemodStreams DS{};
         for (int i = 0; i < 4; i++) DS.side[i] = serial ? nullptr : h->s_side[i];
         DS.ev = h->evs.data(); DS.nev = (int)h->evs.size(); DS.join = h->ev_join;
-        DS.rs = h->s_r; DS.ts[0] = h->s_t[0]; DS.ts[1] = h->s_t[1]; DS.sync = h->d_sync;
+        if (h->partitioned && h->h_stall && *(volatile int *)h->h_stall) {
+            // a wait of the persistent layout ran out of patience in an earlier call (its workgroups were not all resident:
+            // a foreign kernel on the GPU?): that call's output was invalid (fmx_synchronize reports it); use the
+            // event-driven layout from here on
+            h->partitioned = false;
+        }
+        DS.rs = h->s_r; DS.ts[0] = h->s_t[0]; DS.ts[1] = h->s_t[1]; DS.sync = h->d_sync; DS.host_flag = h->d_stall;
         DS.partitioned = (h->partitioned && !serial) ? 1 : 0; DS.ev_next = &h->ev_next;
         launch_demod(h->T, h->B, G, h->channels, s, DS);
     }
@@ -491,6 +498,8 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
                 bool ok = hipExtStreamCreateWithCUMask(&h->s_r, (uint32_t)mr.size(), mr.data()) == hipSuccess;
                 for (auto &ss : h->s_t) ok = ok && hipExtStreamCreateWithCUMask(&ss, (uint32_t)mt.size(), mt.data()) == hipSuccess;
                 ok = ok && hipMalloc(&h->d_sync, sizeof(DemodSync) + sizeof(int) * PB_ROLES * groups) == hipSuccess;
+                ok = ok && hipHostMalloc((void **)&h->h_stall, sizeof(int), hipHostMallocMapped) == hipSuccess;
+                if (ok) { *h->h_stall = 0; ok = hipHostGetDevicePointer((void **)&h->d_stall, h->h_stall, 0) == hipSuccess; }
                 (void)hipGetLastError();
                 h->partitioned = ok;             // otherwise the event-driven layout is used
             }
@@ -643,6 +652,7 @@ int fmx_destroy(fmx_handle h) {
     if (h->s_r) (void)hipStreamDestroy(h->s_r);
     for (auto &ss : h->s_t) if (ss) (void)hipStreamDestroy(ss);
     if (h->d_sync) (void)hipFree(h->d_sync);
+    if (h->h_stall) (void)hipHostFree(h->h_stall);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FMX_OK;
@@ -773,11 +783,12 @@ int fmx_synchronize(fmx_handle h) {
     if (!h) return fail(FMX_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
-    if (h->partitioned && h->d_sync) {          // a stalled stage-B pipeline gives up instead of hanging (fmx_demod.hip pb_wait)
+    if (h->d_sync) {                             // a stalled stage-B pipeline gives up instead of hanging (fmx_demod.hip pb_wait)
         int ab[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpy(ab, h->d_sync, sizeof(ab), hipMemcpyDeviceToHost));
         if (ab[0]) {
             char msg[160];
+            (void)hipMemset(h->d_sync, 0, sizeof(int));          // reported once
             snprintf(msg, sizeof msg, "stage B pipeline stalled (waiter %d needed %d, saw %d): the call's output is invalid", ab[1], ab[2], ab[3]);
             return fail(FMX_E_HIP, msg);
         }

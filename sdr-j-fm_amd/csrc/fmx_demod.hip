@@ -1001,6 +1001,7 @@ __device__ __forceinline__ bool pb_wait(const int *p, int need, int *abort_flag,
         if (++spins > PB_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
             if (__hip_atomic_exchange(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                 DemodSync *S = reinterpret_cast<DemodSync *>(abort_flag);       // diagnostics: who gave up first, and the state then
+                if (S->host_flag) __hip_atomic_store(S->host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 S->info[0] = who; S->info[1] = need; S->info[2] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int g = S->groups;
                 for (int i = 0; i < 16; i++) {
@@ -1074,6 +1075,10 @@ __global__ __launch_bounds__(64) void signal_kernel(int *p, int v) {
     if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__global__ __launch_bounds__(64) void sync_init_kernel(DemodSync *S, int groups, int *host_flag) {
+    if (threadIdx.x == 0) { S->groups = groups; S->host_flag = host_flag; }
+}
+
 template <bool PLLDEC, bool T2, bool W32>
 static void launch_recurrences(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, const ChunkPlan &P,
                                DemodSync *S, int groups, hipStream_t s) {
@@ -1114,7 +1119,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
     }
     DemodSync *S = DS.sync;
     (void)hipMemsetAsync(S, 0, sizeof(DemodSync) + sizeof(int) * PB_ROLES * groups, s);
-    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, s, &S->groups, groups);
+    hipLaunchKernelGGL(sync_init_kernel, dim3(1), dim3(64), 0, s, S, groups, DS.host_flag);
     hipEvent_t e0 = DS.ev[(*DS.ev_next)++ % DS.nev];
     (void)hipEventRecord(e0, s);                                   // the front kernel's output and the cleared words
     (void)hipStreamWaitEvent(DS.rs, e0, 0); (void)hipStreamWaitEvent(DS.ts[0], e0, 0);

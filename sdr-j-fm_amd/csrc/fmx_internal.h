@@ -195,13 +195,14 @@ struct DemodSync {                      // zeroed at the start of every call
     int info[3];                        // first waiter that gave up: id, value needed, value seen
     int groups;
     int started;                        // workgroups of the recurrence kernel that have begun (all of them must be resident)
-    int pad[10];
+    int pad[8];
+    int *host_flag;                     // host-mapped word the first waiter that gives up also sets: the host then stops using this layout
     int snap[64];                       // snapshot of the words below at that moment (diagnostics)
     int cnt_disc[PB_MAX_CHUNKS], cnt_fir[PB_MAX_CHUNKS], cnt_mix[PB_MAX_CHUNKS];     // finished blocks of chunk c's kernel
     int prog[PB_ROLES][1];              // [role][group]: chunks finished; really [PB_ROLES][groups] (allocated to size)
 };
 struct DemodStreams { hipStream_t side[4]; hipEvent_t *ev; int nev; hipEvent_t join; hipStream_t rs; hipStream_t ts[2];
-                      int partitioned; int *ev_next; DemodSync *sync; };
+                      int partitioned; int *ev_next; DemodSync *sync; int *host_flag; };
 int recurrences_blocks_per_cu();
 void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s,
                   const DemodStreams &DS);

@@ -29,7 +29,7 @@ for k in range(K):
         sn = a[16:80]
         print("at abort: cnt_disc", sn[0:16]); print("          cnt_fir ", sn[16:32]); print("          cnt_mix ", sn[32:48])
         print("          prog[role][0]", sn[48:53], " prog[role][last]", sn[56:61])
-        break
+        continue
     print(f"call {k}: {1e3 * (time.perf_counter() - t0):.3f} ms")
 # async: enqueue K calls back to back, synchronise once
 import time as _t
