@@ -358,6 +358,34 @@ def test_edge_inputs(fmx_amd, ol):
     assert e.value.code == M.FMX_E_TOO_LARGE
 
 
+def test_stage_b_layouts_identical(fmx_amd, ol, monkeypatch):
+    """The two schedules of stage B (persistent recurrence kernel + progress words, and the event-driven five-stream
+    pipeline) run the same chunk bodies: PCM, taps and meta must be bit-identical.  130 channels = three 64-channel
+    groups, the last one nearly empty; mixed per-channel settings; four calls, so state crosses call boundaries in both."""
+    nch, block = 130, 16384 * 6
+    iq = ol.synth_iq(4 * block, stereo=1, noiseSigma=0.002)
+    outs = []
+    for minch in ("1", "0"):
+        monkeypatch.setenv("FMX_PERSISTENT_MIN_CHANNELS", minch)
+        f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block)
+        gui_defaults(f, 165000, True)
+        for c in range(0, nch, 7):
+            f.set_param(M.P_FM_DECODER, 2 + c % 5, c)
+        for c in range(3, nch, 11):
+            f.set_param(M.P_FM_MODE, 2, c)
+        for c in range(5, nch, 13):
+            f.set_param(M.P_PSS, 0, c)
+        pcm = run_blocks(f, iq, block)
+        f.synchronize()
+        outs.append((pcm, f.tap(M.TAP_DEMOD, block // 12, 64), f.tap(M.TAP_LR_RAW, block // 12, 129), f.tap(M.TAP_PRE_RESAMPLER, block // 12, 7),
+                     [f.meta(c).PilotPllLocked for c in (0, 64, 129)]))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for k in (1, 2, 3):
+        assert np.array_equal(outs[0][k], outs[1][k])
+    assert outs[0][4] == outs[1][4]
+    assert rms(outs[0][0][0]) > 0.01
+
+
 def test_error_behaviour(fmx_amd):
     f = fmx_amd.Fmx(2, max_block=16384)
     for pid, v, code in [(M.P_FM_MODE, 3, M.FMX_E_INVALID), (M.P_FM_DECODER, 0, M.FMX_E_INVALID),
