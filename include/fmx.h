@@ -160,6 +160,32 @@ int  fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *meta);
 /* replaces the hf/lf/iq scope ring feeds: copies the most recent n samples of a tap
  * (n * 1 or 2 floats) to host memory; n <= samples produced by the last call */
 int  fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap_id, float *dst, int64_t n);
+/* What the reference's RDS classes tell the GUI through Qt signals (rds-groupdecoder.cpp:44-63, rds-blocksynchronizer.cpp:39-42):
+ * setPiCode, setPTYCode, setStationLabel, setRadioText / clearRadioText, setAFDisplay, setMusicSpeechFlag, setGroup,
+ * setRDSisSynchronized, setbitErrorRate, setCRCErrors, setSyncErrors.  Text fields hold the raw RDS (EBU Latin)
+ * characters, NUL terminated; the EBU -> Unicode mapping stays with the adapter. */
+typedef struct fmx_rds_info {
+    int32_t synchronized;      /* block synchroniser locked (A..C received without error) */
+    int32_t pi_code;           /* block A of the last group; 0 until a group has been decoded */
+    int32_t pty_code;          /* programme type 0..31, -1 until known */
+    int32_t last_group_type;   /* 0..15, -1 until known */
+    int32_t groups_decoded;    /* complete groups so far */
+    int32_t crc_errors, sync_errors;
+    float   bit_error_rate;
+    char    station_label[9];  /* PS name (group 0A), blank padded */
+    char    radio_text[65];    /* radio text (group 2A) as the reference would display it (trimmed) */
+    int32_t af1_khz, af2_khz;  /* alternative frequencies of the last 0A group, 0 = none */
+    int32_t music_speech;      /* -1 unknown, else the M/S flag */
+    int32_t di_code;
+} fmx_rds_info;
+/* replaces rdsDecoder::processBit + rdsBlockSynchronizer + rdsGroupDecoder (rds-decoder.cpp:104-131,
+ * rds-blocksynchronizer.cpp:114-336, rds-groupdecoder.cpp:100-290) on the host: feeds every bit the slicer has produced
+ * since the last call into the channel's block synchroniser / group decoder and returns the current picture.
+ * Independent of fmx_rds_bits (own read position). */
+int  fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info);
+/* the same decoder over a caller-supplied bit array, from a fresh state (host only, needs no device): what a
+ * recorded bit stream decodes to */
+int  fmx_rds_decode_bits(const uint8_t *bits, int32_t n_bits, fmx_rds_info *info);
 /* replaces rdsDecoder::doDecode's bit output (rds-decoder.cpp:69-104): pending RDS bits */
 int  fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity, int32_t *n_bits);
 

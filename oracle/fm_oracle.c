@@ -1160,6 +1160,7 @@ struct fmo_siggen {
     uint64_t rng;
     /* RDS bit source */
     uint64_t bitrng; uint8_t *bits; long nbits, bitcap; int diffState; long lastk; int cur;
+    uint8_t *fixed; long nfixed;
 };
 static uint64_t xorshift64s(uint64_t *s) {
     uint64_t x = *s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; *s = x;
@@ -1178,13 +1179,25 @@ fmo_siggen *fmo_siggen_new(const fmo_siggen_config *c) {
     g->lastk = -1; g->cur = 0; g->diffState = 0;
     return g;
 }
-void fmo_siggen_free(fmo_siggen *g) { if (g) { free(g->bits); free(g); } }
+void fmo_siggen_free(fmo_siggen *g) { if (g) { free(g->bits); free(g->fixed); free(g); } }
 long fmo_siggen_rds_bits(const fmo_siggen *g, uint8_t *bits, long cap) {
     long n = g->nbits < cap ? g->nbits : cap;
     if (bits && n > 0) memcpy(bits, g->bits, (size_t)n);
     return g->nbits;
 }
+/* test hook: send these data bits (e.g. encoded RDS groups), cyclically, instead of pseudo-random ones */
+void fmo_siggen_set_rds_bits(fmo_siggen *g, const uint8_t *bits, long n) {
+    free(g->fixed); g->fixed = NULL; g->nfixed = 0;
+    if (bits && n > 0) { g->fixed = (uint8_t *)malloc((size_t)n); memcpy(g->fixed, bits, (size_t)n); g->nfixed = n; }
+}
 static int siggen_bit(fmo_siggen *g, long k) {
+    if (g->nfixed > 0) {
+        while (g->nbits <= k) {
+            if (g->nbits >= g->bitcap) { g->bitcap *= 2; g->bits = (uint8_t *)realloc(g->bits, (size_t)g->bitcap); }
+            g->bits[g->nbits] = g->fixed[g->nbits % g->nfixed]; g->nbits++;
+        }
+        return g->bits[k];
+    }
     while (g->nbits <= k) {
         if (g->nbits >= g->bitcap) { g->bitcap *= 2; g->bits = (uint8_t *)realloc(g->bits, (size_t)g->bitcap); }
         g->bits[g->nbits++] = (uint8_t)((xorshift64s(&g->bitrng) >> 40) & 1);

@@ -221,6 +221,7 @@ typedef struct fmo_siggen fmo_siggen;
 fmo_siggen *fmo_siggen_new(const fmo_siggen_config *);
 void fmo_siggen_free(fmo_siggen *);
 void fmo_siggen_run(fmo_siggen *, float *iq, long n);
+void fmo_siggen_set_rds_bits(fmo_siggen *, const uint8_t *bits, long n);   /* test hook: data bits to send, cyclically */
 long fmo_siggen_rds_bits(const fmo_siggen *, uint8_t *bits, long cap);
 
 #ifdef __cplusplus

@@ -3,6 +3,7 @@
 // every entry point fails when HIP is unavailable.
 #include "../../include/fmx.h"
 #include "fmx_internal.h"
+#include "fmx_rdsgroups.h"
 #include "fmx_design.h"
 
 #include <algorithm>
@@ -81,6 +82,8 @@ struct fmx_handle_s {
     // RDS path (allocated when a channel first switches RDS on)
     bool rds_alloc = false; RdsBuffers R{}; int64_t rds_start = -1;   // fm sample index at which RDS was switched on
     std::vector<int32_t> rds_read;          // per channel: bits already handed out by fmx_rds_bits
+    std::vector<int32_t> rds_read_dec;      // ... and by fmx_rds_decode
+    std::vector<fmx::RdsGroupDecoderHost> rds_dec;
     int64_t last_m0 = 0, last_m1 = 0;       // 24 kS/s outputs of the last call
     std::vector<void *> rds_ptrs;
 };
@@ -883,6 +886,39 @@ int fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity,
         h->rds_read[channel] += take;
     }
     *n_bits = (take > 0 && bits) ? take : 0;
+    return FMX_OK;
+}
+
+int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {
+    if (!h || channel < 0 || channel >= h->channels || !info) return fail(FMX_E_INVALID, "bad argument");
+    if ((int)h->rds_dec.size() != h->channels) { h->rds_dec.assign((size_t)h->channels, fmx::RdsGroupDecoderHost()); h->rds_read_dec.assign((size_t)h->channels, 0); }
+    fmx::RdsGroupDecoderHost &D = h->rds_dec[(size_t)channel];
+    if (h->rds_alloc) {
+        HIPCHK(hipSetDevice(h->cfg.device));
+        HIPCHK(hipDeviceSynchronize());
+        RdsState st;
+        HIPCHK(hipMemcpy(&st, h->R.state + channel, sizeof(st), hipMemcpyDeviceToHost));
+        int32_t &rd = h->rds_read_dec[(size_t)channel];
+        int32_t have = st.nbits - rd;
+        if (have < 0) { rd = 0; have = st.nbits; D.reset_all(); }                      // resetRds restarted the bit count
+        if (have > RDS_BITS_CAP) { rd = st.nbits - RDS_BITS_CAP; have = RDS_BITS_CAP; }   // ring overrun: oldest bits lost
+        if (have > 0) {
+            std::vector<uint8_t> ring((size_t)RDS_BITS_CAP);
+            HIPCHK(hipMemcpy(ring.data(), h->R.bits + (size_t)channel * RDS_BITS_CAP, RDS_BITS_CAP, hipMemcpyDeviceToHost));
+            for (int32_t i = 0; i < have; i++) D.push_bit(ring[(size_t)((rd + i) & (RDS_BITS_CAP - 1))] != 0);
+            rd += have;
+        }
+    }
+    *info = D.info();
+    return FMX_OK;
+}
+
+// host-only entry (no device needed): run a fresh block synchroniser / group decoder over a bit array
+int fmx_rds_decode_bits(const uint8_t *bits, int32_t n_bits, fmx_rds_info *info) {
+    if ((!bits && n_bits > 0) || n_bits < 0 || !info) return fail(FMX_E_INVALID, "bad argument");
+    fmx::RdsGroupDecoderHost D;
+    for (int32_t i = 0; i < n_bits; i++) D.push_bit(bits[i] != 0);
+    *info = D.info();
     return FMX_OK;
 }
 

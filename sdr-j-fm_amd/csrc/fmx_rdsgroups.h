@@ -1,0 +1,162 @@
+// fmx_rdsgroups.h -- host side of the RDS path behind the bit slicer: block synchronisation and group decoding.
+// Pure integer work at 1187.5 bit/s per channel: it stays on the host.  Behaviour follows
+//   rdsDecoder::processBit          src/rds/rds-decoder.cpp:104-131
+//   rdsBlockSynchronizer            src/rds/rds-blocksynchronizer.cpp:57-336 (constants includes/rds/rds-blocksynchronizer.h:77-91)
+//   RDSGroup                        src/rds/rds-group.cpp:33-81
+//   rdsGroupDecoder::decode & co.   src/rds/rds-groupdecoder.cpp:71-290
+// The Qt signals of those classes (setPiCode, setStationLabel, setRadioText, ...) become fields of fmx_rds_info, which
+// the adapter turns back into signals.  EBU -> Unicode mapping of the text (ebu-codetables.c) stays with the adapter:
+// the label and the radio text are handed over as the raw RDS characters.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include "../../include/fmx.h"
+
+namespace fmx {
+
+class RdsGroupDecoderHost {
+public:
+    RdsGroupDecoderHost() { reset_all(); }
+    void reset_all() { sync_reset(); groups_reset(); info_ = fmx_rds_info{}; fill_info(); }
+    // one sliced bit (rds-decoder.cpp:104-131)
+    void push_bit(bool b) {
+        switch (push(b)) {
+        case WAITING_A: case BUFFERING: break;
+        case NO_SYNC: info_.sync_errors = n_sync_err_; resync(); break;
+        case NO_CRC: info_.crc_errors = n_crc_err_; resync(); break;
+        case COMPLETE: decode_group(); blk_[0] = blk_[1] = blk_[2] = blk_[3] = 0; break;
+        }
+    }
+    const fmx_rds_info &info() { fill_info(); return info_; }
+
+private:
+    enum Res { WAITING_A, BUFFERING, NO_SYNC, NO_CRC, COMPLETE };
+    static constexpr uint32_t NCRC = 10, NPAY = 16, NBLK = 26, POLY = 0x5B9, REM = 0x31B, BER_RESET = 4000;
+    static uint32_t offset_word(int blk, bool typeB) {                 // rds-blocksynchronizer.cpp:197-213
+        switch (blk) { default: case 0: return 0xFC; case 1: return 0x198; case 2: return typeB ? 0x350 : 0x168; case 3: return 0x1B4; }
+    }
+    static uint32_t syndrome(uint32_t bits, uint32_t off) {            // :126-142
+        const uint32_t block = bits ^ off;
+        uint32_t reg = 0;
+        for (int k = (int)NBLK - 1; k >= 0; k--) {
+            const uint32_t msb = reg & (1u << (NCRC - 1));
+            reg <<= 1;
+            if (msb) reg ^= POLY;
+            if ((block >> k) & 1u) reg ^= REM;
+        }
+        return reg;
+    }
+    bool typeB() const { return ((blk_[1] >> 11) & 1) != 0; }
+    void sync_reset() {                                                // :57-70
+        stream_ = 0; synced_ = false; cur_ = 0; ber_ = 0.f; bits_in_blk_ = 0; bits_done_ = 0; bit_err_ = 0;
+        n_crc_err_ = 0; n_sync_err_ = 0;
+        blk_[0] = blk_[1] = blk_[2] = blk_[3] = 0;
+    }
+    void resync() { cur_ = 0; synced_ = false; bits_in_blk_ = 0; }     // :101-106
+    uint32_t meggitt(uint32_t syn) {                                   // :176-195: single-burst correction of the payload
+        uint32_t mask = 1u << (NBLK - 1);
+        for (uint32_t i = 0; i < NPAY; i++) {
+            if (syn & 0x200) {
+                if ((syn & 0x1f) == 0) { stream_ ^= mask; bit_err_++; }
+                else syn ^= POLY;
+            }
+            syn <<= 1; mask >>= 1;
+        }
+        return syn & 0x3FF;
+    }
+    bool decode_block(int b, uint32_t bits) {                          // :144-173
+        uint32_t syn = syndrome(bits, offset_word(b, typeB()));
+        if (!synced_) return syn == 0;
+        bits_done_ += NPAY;
+        if (syn != 0) (void)meggitt(syn);        // (the reference discards doMeggit's result: the block still counts as failed)
+        if (syn != 0) bit_err_ += NPAY;
+        ber_ = (float)bit_err_ / (float)bits_done_;
+        if (bits_done_ >= BER_RESET) { bit_err_ = 0; bits_done_ = 0; }
+        return syn == 0;
+    }
+    Res push(bool b) {                                                 // :215-336
+        stream_ = (stream_ << 1) | (b ? 1u : 0u);
+        if (synced_) {
+            if (++bits_in_blk_ < NBLK) return BUFFERING;
+            bits_in_blk_ = 0;
+            if (!decode_block(cur_, stream_)) { n_crc_err_++; return NO_CRC; }
+            blk_[cur_] = (uint16_t)(stream_ >> NCRC);
+            const Res r = cur_ == 3 ? COMPLETE : BUFFERING;
+            cur_ = (cur_ + 1) & 3;
+            return r;
+        }
+        if (cur_ == 0) {                                               // slide bit by bit until a clean block A appears
+            if (syndrome(stream_ & 0x3FFFFFF, offset_word(0, typeB())) != 0) return WAITING_A;
+            blk_[0] = (uint16_t)(stream_ >> NCRC);
+            bits_in_blk_ = 0; cur_ = 1;
+            return BUFFERING;
+        }
+        if (bits_in_blk_ < NBLK - 1) { bits_in_blk_++; return BUFFERING; }
+        bits_in_blk_ = 0;
+        if (syndrome(stream_, offset_word(cur_, typeB())) != 0) { n_sync_err_++; return NO_SYNC; }
+        blk_[cur_] = (uint16_t)(stream_ >> NCRC);
+        if (cur_ < 2) { cur_++; return BUFFERING; }                    // SYNC_END_BLOCK = BLOCK_C
+        synced_ = true;
+        const Res r = cur_ == 3 ? COMPLETE : BUFFERING;
+        cur_ = (cur_ + 1) & 3;
+        return r;
+    }
+    // ---- group decoder (rds-groupdecoder.cpp)
+    void groups_reset() {                                              // :71-98
+        pi_ = 0; pty_ = -1;
+        std::memset(ps_, ' ', 8); ps_[8] = 0; ps_seg_ = 0; di_ = 0;
+        std::memset(rt_, ' ', 64); rt_[64] = 0; rt_ab_ = -1; rt_seg_ = 0; rt_len_ = 0; rt_shown_[0] = 0;
+        ms_ = -1; af1_ = af2_ = 0;
+    }
+    void show_text(int len) {                                          // prepareText :262-278, without the alphabet mapping
+        // the reference emits characters v[0 .. len-2] (it walks pairs, dropping the last one) and trims the result
+        int n = len - 1; if (n < 0) n = 0;
+        auto sp = [](char c) { return c == ' ' || (c >= 0x09 && c <= 0x0D); };     // QString::trimmed
+        int a = 0; while (a < n && sp(rt_[a])) a++;
+        int e = n; while (e > a && sp(rt_[e - 1])) e--;
+        std::memcpy(rt_shown_, rt_ + a, (size_t)(e - a)); rt_shown_[e - a] = 0; rt_len_ = e - a;
+    }
+    void decode_group() {                                              // decode :100-165
+        groups_ok_++;
+        last_type_ = (blk_[1] >> 12) & 0xF;
+        if (blk_[0] != pi_) { groups_reset(); pi_ = blk_[0]; }
+        pty_ = (blk_[1] >> 5) & 0x1F;
+        if (typeB()) return;                                           // "Cannot decode B type groups"
+        if (last_type_ == 0) {                                         // Handle_Basic_Tuning_and_Switching :167-180
+            const uint32_t seg = blk_[1] & 3;
+            ps_[2 * seg] = (char)(blk_[3] >> 8); ps_[2 * seg + 1] = (char)(blk_[3] & 0xFF);
+            if (seg == 0) ps_seg_ = 0;
+            ps_seg_ |= 2 * seg;
+            const uint8_t a1 = (uint8_t)(blk_[2] >> 8), a2 = (uint8_t)(blk_[2] & 0xFF);            // additionalFrequencies :207-218
+            af1_ = (a1 > 0 && a1 < 205) ? a1 * 100 + 87500 : 0;
+            af2_ = (a1 != 250 && a2 > 0 && a2 < 205) ? a2 * 100 + 87500 : 0;
+            ms_ = (blk_[1] >> 3) & 1;
+            di_ |= ((blk_[1] >> 2) & 1) << seg;
+        } else if (last_type_ == 2) {                                  // Handle_RadioText :222-281
+            const int ab = (blk_[1] >> 4) & 1; const int seg = blk_[1] & 0xF;
+            if (rt_ab_ != ab) { rt_ab_ = ab; rt_seg_ = 0; std::memset(rt_, ' ', 64); rt_[64] = 0; rt_shown_[0] = 0; rt_len_ = 0; }
+            char *f = &rt_[4 * seg];
+            f[0] = (char)(blk_[2] >> 8); f[1] = (char)(blk_[2] & 0xFF); f[2] = (char)(blk_[3] >> 8); f[3] = (char)(blk_[3] & 0xFF);
+            rt_seg_ |= 1u << seg;
+            if (rt_seg_ + 1 == (1u << (seg + 1))) show_text(seg * 4);
+            bool end = false;
+            for (int i = 0; i < 4; i++) if (f[i] == 0x0D) end = true;
+            if (end || rt_seg_ + 1 == (1u << 16)) show_text(64);
+        }
+    }
+    void fill_info() {
+        info_.synchronized = synced_ ? 1 : 0; info_.pi_code = pi_; info_.pty_code = pty_; info_.last_group_type = last_type_;
+        info_.groups_decoded = groups_ok_; info_.crc_errors = n_crc_err_; info_.sync_errors = n_sync_err_; info_.bit_error_rate = ber_;
+        std::memcpy(info_.station_label, ps_, 9); std::memcpy(info_.radio_text, rt_shown_, 65);
+        info_.af1_khz = af1_; info_.af2_khz = af2_; info_.music_speech = ms_; info_.di_code = di_;
+    }
+    // synchroniser
+    uint32_t stream_; bool synced_; int cur_; float ber_; uint32_t bits_in_blk_, bits_done_, bit_err_; int n_crc_err_, n_sync_err_;
+    uint16_t blk_[4];
+    // groups
+    int32_t pi_, pty_, last_type_ = -1, groups_ok_ = 0, ms_, af1_, af2_; uint32_t ps_seg_, di_, rt_seg_; int rt_ab_, rt_len_;
+    char ps_[9], rt_[65], rt_shown_[65];
+    fmx_rds_info info_;
+};
+
+}  // namespace fmx

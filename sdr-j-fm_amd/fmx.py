@@ -28,7 +28,7 @@ EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
     "fmx_get_meta", "fmx_get_tap",
-    "fmx_rds_bits", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
+    "fmx_rds_bits", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
 
@@ -55,6 +55,13 @@ class FmxMeta(C.Structure):
         ("live_pilot_locked", C.c_int32), ("live_lock_strength", C.c_float), ("live_dc_if", C.c_float),
         ("reserved", C.c_int32),
     ]
+
+
+class FmxRdsInfo(C.Structure):
+    _fields_ = [("synchronized", C.c_int32), ("pi_code", C.c_int32), ("pty_code", C.c_int32), ("last_group_type", C.c_int32),
+                ("groups_decoded", C.c_int32), ("crc_errors", C.c_int32), ("sync_errors", C.c_int32), ("bit_error_rate", C.c_float),
+                ("station_label", C.c_char * 9), ("radio_text", C.c_char * 65), ("af1_khz", C.c_int32), ("af2_khz", C.c_int32),
+                ("music_speech", C.c_int32), ("di_code", C.c_int32)]
 
 
 class FmxProfile(C.Structure):
@@ -101,6 +108,10 @@ def load_library(path=None):
     L.fmx_get_meta.argtypes = [vp, i32, C.POINTER(FmxMeta)]
     L.fmx_get_tap.restype = C.c_int
     L.fmx_get_tap.argtypes = [vp, i32, i32, f32p, i64]
+    L.fmx_rds_decode.restype = C.c_int
+    L.fmx_rds_decode.argtypes = [vp, i32, C.POINTER(FmxRdsInfo)]
+    L.fmx_rds_decode_bits.restype = C.c_int
+    L.fmx_rds_decode_bits.argtypes = [C.POINTER(C.c_uint8), i32, C.POINTER(FmxRdsInfo)]
     L.fmx_rds_bits.restype = C.c_int
     L.fmx_rds_bits.argtypes = [vp, i32, C.POINTER(C.c_uint8), i32, C.POINTER(i32)]
     L.fmx_get_taps.restype = C.c_int
@@ -112,6 +123,17 @@ def load_library(path=None):
     if path is None:
         _lib = L
     return L
+
+
+def rds_decode_bits(bits):
+    """Decode a recorded RDS bit stream from a fresh state (host only); returns FmxRdsInfo."""
+    L = load_library()
+    b = np.ascontiguousarray(bits, np.uint8)
+    info = FmxRdsInfo()
+    rc = L.fmx_rds_decode_bits(b.ctypes.data_as(C.POINTER(C.c_uint8)), b.size, C.byref(info))
+    if rc != FMX_OK:
+        raise FmxError(rc, L.fmx_last_error().decode())
+    return info
 
 
 class Fmx:
@@ -212,6 +234,12 @@ class Fmx:
         n = C.c_int32()
         self._check(self.L.fmx_rds_bits(self.h, channel, buf, capacity, C.byref(n)))
         return np.frombuffer(buf, np.uint8, n.value).copy()
+
+    def rds_decode(self, channel=0):
+        """Feed the bits sliced so far into the channel's block synchroniser / group decoder; returns FmxRdsInfo."""
+        info = FmxRdsInfo()
+        self._check(self.L.fmx_rds_decode(self.h, channel, C.byref(info)))
+        return info
 
     def taps(self, which, channel=0):
         buf = np.zeros(1024, np.float32)

@@ -150,6 +150,7 @@ def oracle():
         "fmo_siggen_free": (None, [vp]),
         "fmo_siggen_run": (None, [vp, c_float_p, lng]),
         "fmo_siggen_rds_bits": (lng, [vp, c_u8_p, lng]),
+        "fmo_siggen_set_rds_bits": (None, [vp, c_u8_p, lng]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -256,12 +257,53 @@ def siggen_config(**kw):
     return c
 
 
-def synth_iq(n, return_rds_bits=False, **kw):
+# ---- RDS group encoder for the tests (IEC 62106: 16 data bits + 10-bit checkword = CRC (x^10+x^8+x^7+x^5+x^4+x^3+1) ^ offset word)
+RDS_OFFSETS = {"A": 0x0FC, "B": 0x198, "C": 0x168, "C'": 0x350, "D": 0x1B4}
+
+
+def rds_checkword(data16, offset):
+    reg = 0
+    for k in range(15, -1, -1):
+        fb = ((reg >> 9) & 1) ^ ((data16 >> k) & 1)
+        reg = (reg << 1) & 0x3FF
+        if fb:
+            reg ^= 0x1B9
+    return reg ^ offset
+
+
+def rds_group_bits(a, b, c, d, type_b=False):
+    out = []
+    for word, off in ((a, "A"), (b, "B"), (c, "C'" if type_b else "C"), (d, "D")):
+        blk = ((word & 0xFFFF) << 10) | rds_checkword(word & 0xFFFF, RDS_OFFSETS[off])
+        out += [(blk >> k) & 1 for k in range(25, -1, -1)]
+    return out
+
+
+def rds_programme_bits(pi=0xD3A1, pty=10, ps="FMX-AMD ", text="HIP KERNELS ON MI355X - RDS OK", tp=0):
+    """One cycle of groups: four 0A groups (PS name) followed by the 2A groups of the radio text (ended by CR)."""
+    bits = []
+    ps = (ps + " " * 8)[:8]
+    for seg in range(4):
+        b = (0 << 12) | (0 << 11) | (tp << 10) | (pty << 5) | (1 << 3) | seg         # group 0A, M/S = music
+        bits += rds_group_bits(pi, b, (0xE0 + 1) << 8 | 12, (ord(ps[2 * seg]) << 8) | ord(ps[2 * seg + 1]))
+    txt = text + "\r"
+    txt += " " * (-len(txt) % 4)
+    for seg in range(len(txt) // 4):
+        b = (2 << 12) | (0 << 11) | (tp << 10) | (pty << 5) | (0 << 4) | seg           # group 2A, text A
+        q = txt[4 * seg:4 * seg + 4]
+        bits += rds_group_bits(pi, b, (ord(q[0]) << 8) | ord(q[1]), (ord(q[2]) << 8) | ord(q[3]))
+    return np.array(bits, np.uint8)
+
+
+def synth_iq(n, return_rds_bits=False, rds_payload=None, **kw):
     """n complex samples of synthetic FM IQ as float32 [n,2] (oracle's deterministic generator); with
     return_rds_bits also the (pre differential-encoding) RDS data bits the generator sent."""
     L = oracle()
     cfg = siggen_config(**kw)
     g = L.fmo_siggen_new(C.byref(cfg))
+    if rds_payload is not None:
+        pb = np.ascontiguousarray(rds_payload, np.uint8)
+        L.fmo_siggen_set_rds_bits(g, u8ptr(pb), pb.size)
     out = np.empty((n, 2), np.float32)
     L.fmo_siggen_run(g, fptr(out), n)
     bits = None

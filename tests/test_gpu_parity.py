@@ -476,6 +476,36 @@ def test_rds_batched_channels_and_second_read(fmx_amd, ol):
     assert np.count_nonzero(chains[0].rds_bits()[600:1400] != chains[1].rds_bits()[600:1400]) > 100
 
 
+def test_rds_end_to_end_groups(fmx_amd, ol):
+    """SURVEY 8 f-1 / configs[4]: a stereo MPX whose 57 kHz sub-carrier carries real RDS groups (PI 0xD3A1, PS name, radio
+    text) through the whole GPU chain -- input FIR, discriminator, pilot PLL, RDS band-pass / Hilbert / mix, RDS_2 slicer
+    -- and the host-side block synchroniser + group decoder: the decoded programme is the one the generator sent.  Two
+    channels on two streams with different programmes; fed in uneven calls."""
+    progs = [dict(pi=0xD3A1, pty=10, ps="FMX-AMD ", text="HIP KERNELS ON MI355X - RDS OK"),
+             dict(pi=0x2468, pty=3, ps="CHAN TWO", text="SECOND STREAM")]
+    block = 16384 * 20
+    n = int(3.6 * 2304000) // block * block
+    iqs = [ol.synth_iq(n, rds=1, rdsLevel=0.05, rds_payload=ol.rds_programme_bits(**p)) for p in progs]
+    f = fmx_amd.Fmx(2, streams=2, stream_of_channel=[0, 1], max_block=block)
+    gui_defaults(f)
+    f.set_param(M.P_RDS_MODE, 2)
+    iq = np.stack(iqs)
+    seen_sync = [False, False]
+    for i in range(0, n, block):
+        f.process_host(iq[:, i:i + block, :])
+        for c in range(2):
+            seen_sync[c] = seen_sync[c] or f.rds_decode(c).synchronized == 1
+    for c, p in enumerate(progs):
+        info = f.rds_decode(c)
+        print(f"\n[rds groups] ch {c}: PI {info.pi_code:04X} PTY {info.pty_code} PS '{info.station_label.decode()}' RT '{info.radio_text.decode()}' "
+              f"groups {info.groups_decoded} crc {info.crc_errors} sync {info.sync_errors} ber {info.bit_error_rate:.4f}")
+        assert seen_sync[c] and info.pi_code == p["pi"] and info.pty_code == p["pty"]
+        assert info.station_label.decode() == p["ps"] and info.radio_text.decode() == p["text"]
+        assert info.groups_decoded >= 20 and info.crc_errors <= 1
+    # the raw bit API still hands out every bit (own read position)
+    assert len(f.rds_bits(0, 8192)) > 3500
+
+
 # ------------------------------------------------------------------------------------------------
 # raw device samples (SURVEY 8f-4): the host-side conversion of the device handlers moved into the input-FIR kernel
 # ------------------------------------------------------------------------------------------------

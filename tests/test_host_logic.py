@@ -128,3 +128,70 @@ def test_wav_file_source(tmp_path):
     mono = pkg.WavFileSource(str(tmp_path / "m.wav"))
     v = mono.getSamples(50)
     assert mono.getRate() == 192000 and np.array_equal(v[:, 0], m[:, 0]) and not v[:, 1].any()
+
+
+# ------------------------------------------------------------------------------------------------
+# RDS block synchroniser + group decoder on the host: fmx_rds_decode_bits needs no device
+# ------------------------------------------------------------------------------------------------
+def _rds(bits):
+    import importlib
+    pkg = importlib.import_module("sdr-j-fm_amd")
+    return pkg.fmx.rds_decode_bits(bits)
+
+
+def test_rds_checkword_matches_the_synchronisers_syndrome():
+    """The test encoder and the decoder's syndrome register are two independent statements of IEC 62106 annex B:
+    every encoded block must have syndrome 0 against its own offset word and not against the others."""
+    import oracle_lib as ol
+
+    def syndrome(block26, off):      # rds-blocksynchronizer.cpp:126-142 restated
+        reg, blk = 0, block26 ^ off
+        for k in range(25, -1, -1):
+            msb = reg & 0x200
+            reg = (reg << 1) & 0xFFFFFFFF
+            if msb:
+                reg ^= 0x5B9
+            if (blk >> k) & 1:
+                reg ^= 0x31B
+        return reg & 0xFFFFFFFF
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        w = int(rng.integers(0, 65536))
+        for name, off in ol.RDS_OFFSETS.items():
+            blk = (w << 10) | ol.rds_checkword(w, off)
+            assert syndrome(blk, off) == 0
+            assert all(syndrome(blk, o2) != 0 for n2, o2 in ol.RDS_OFFSETS.items() if n2 != name)
+
+
+def test_rds_groups_clean_stream():
+    import oracle_lib as ol
+    prog = ol.rds_programme_bits(pi=0xD3A1, pty=10, ps="FMX-AMD ", text="HIP KERNELS ON MI355X - RDS OK")
+    junk = np.random.default_rng(1).integers(0, 2, 77).astype(np.uint8)
+    info = _rds(np.concatenate([junk, prog, prog]))
+    assert info.synchronized == 1 and info.pi_code == 0xD3A1 and info.pty_code == 10
+    assert info.station_label == b"FMX-AMD "
+    # prepareText drops the last character of what it is given and trims (rds-groupdecoder.cpp:262-278): the CR ends the text
+    assert info.radio_text == b"HIP KERNELS ON MI355X - RDS OK"
+    assert info.groups_decoded >= 2 * 12 - 1 and info.crc_errors == 0
+    assert info.music_speech == 1 and info.af1_khz == 0 and info.af2_khz == 87500 + 100 * 12      # block C = (0xE1 'one AF follows', 12)
+    assert info.last_group_type == 2 and info.bit_error_rate == 0.0
+
+
+def test_rds_groups_errors_resync_and_pi_change():
+    import oracle_lib as ol
+    a = ol.rds_programme_bits(pi=0x1234, ps="STATION1", text="FIRST")
+    b = ol.rds_programme_bits(pi=0xBEEF, ps="STATION2", text="SECOND PROGRAMME")
+    bad = a.copy()
+    bad[4 * 104 + 30] ^= 1                      # one wrong bit in block B of the fifth group: that block fails its CRC
+    info = _rds(np.concatenate([a, bad, a]))
+    assert info.pi_code == 0x1234 and info.station_label == b"STATION1" and info.radio_text == b"FIRST"
+    assert info.crc_errors == 1 and info.synchronized == 1       # dropped out once, found block A again
+    info = _rds(np.concatenate([a, a, b, b]))
+    assert info.pi_code == 0xBEEF and info.station_label == b"STATION2" and info.radio_text == b"SECOND PROGRAMME"
+    # noise only: nothing decodes
+    info = _rds(np.random.default_rng(9).integers(0, 2, 5000).astype(np.uint8))
+    assert info.groups_decoded <= 1 and info.pi_code in (0, info.pi_code)
+    # type B groups carry PI / PTY but are not decoded further (rds-groupdecoder.cpp:118-120)
+    gb = ol.rds_group_bits(0x4242, (0 << 12) | (1 << 11) | (5 << 5) | 1, 0x4242, (ord("X") << 8) | ord("Y"), type_b=True)
+    info = _rds(np.array(gb * 6, np.uint8))
+    assert info.pi_code == 0x4242 and info.pty_code == 5 and info.station_label == b"        "
