@@ -50,7 +50,7 @@ struct fmx_handle_s {
     int channels = 0, streams = 0;
     hipStream_t stream = nullptr;
     hipStream_t s_side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the stage-B chunk pipeline
-    hipStream_t s_r = nullptr, s_t[2] = {nullptr, nullptr};          // persistent layout of stage B: CU-masked streams
+    hipStream_t s_r = nullptr, s_t = nullptr;          // persistent layout of stage B: CU-masked streams
     DemodSync *d_sync = nullptr;
     int *h_stall = nullptr, *d_stall = nullptr;                      // host-mapped: set by the GPU when the persistent layout stalled
     bool partitioned = false; int ev_next = 0;
@@ -366,7 +366,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
             // event-driven layout from here on
             h->partitioned = false;
         }
-        DS.rs = h->s_r; DS.ts[0] = h->s_t[0]; DS.ts[1] = h->s_t[1]; DS.sync = h->d_sync; DS.host_flag = h->d_stall;
+        DS.rs = h->s_r; DS.ts = h->s_t; DS.sync = h->d_sync; DS.host_flag = h->d_stall;
         DS.partitioned = (h->partitioned && !serial) ? 1 : 0; DS.ev_next = &h->ev_next;
         launch_demod(h->T, h->B, G, h->channels, s, DS);
     }
@@ -499,7 +499,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
                 for (int i = 0; i < ncu; i++) (i < rcus ? mr : mt)[i / 32] |= 1u << (i % 32);
                 if (t_everywhere) for (int i = 0; i < ncu; i++) mt[i / 32] |= 1u << (i % 32);
                 bool ok = hipExtStreamCreateWithCUMask(&h->s_r, (uint32_t)mr.size(), mr.data()) == hipSuccess;
-                for (auto &ss : h->s_t) ok = ok && hipExtStreamCreateWithCUMask(&ss, (uint32_t)mt.size(), mt.data()) == hipSuccess;
+                ok = ok && hipExtStreamCreateWithCUMask(&h->s_t, (uint32_t)mt.size(), mt.data()) == hipSuccess;
                 ok = ok && hipMalloc(&h->d_sync, sizeof(DemodSync) + sizeof(int) * PB_ROLES * groups) == hipSuccess;
                 ok = ok && hipHostMalloc((void **)&h->h_stall, sizeof(int), hipHostMallocMapped) == hipSuccess;
                 if (ok) { *h->h_stall = 0; ok = hipHostGetDevicePointer((void **)&h->d_stall, h->h_stall, 0) == hipSuccess; }
@@ -653,7 +653,7 @@ int fmx_destroy(fmx_handle h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto &ss : h->s_side) if (ss) (void)hipStreamDestroy(ss);
     if (h->s_r) (void)hipStreamDestroy(h->s_r);
-    for (auto &ss : h->s_t) if (ss) (void)hipStreamDestroy(ss);
+    if (h->s_t) (void)hipStreamDestroy(h->s_t);
     if (h->d_sync) (void)hipFree(h->d_sync);
     if (h->h_stall) (void)hipHostFree(h->h_stall);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -142,14 +142,6 @@ __device__ __forceinline__ bool tsync_enter(const TSync &Y, int group) {
     return ok != 0;
 }
 
-// Completion count of a time-parallel kernel for the persistent recurrence kernel (launch_demod): every block adds one when
-// its stores are visible device-wide; `done` is null on the event-driven path.
-__device__ __forceinline__ void block_done(int *done) {
-    if (done == nullptr) return;
-    __syncthreads();
-    if (threadIdx.x == 0) { __threadfence(); atomicAdd(done, 1); }
-}
-
 // =================================================================================================
 // B1  limiter + memoryless discriminator   (time-parallel; 64 samples x 64 channels per block)
 // =================================================================================================
@@ -393,10 +385,9 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr; st->am_carr = am;
 }
 template <bool PLLDEC>
-__global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+__global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len) {
     FMX_RECURRENCE_PRIO();
     afc_body<PLLDEC>(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
-    block_done(done);
 }
 
 // ---- B3.  The pilot PLL: the longest dependent chain of the path (phase -> LUT index -> sine -> phase).  One wave
@@ -475,10 +466,9 @@ __device__ __forceinline__ void pll_body(DeviceTables T, DeviceBuffers B, CallGe
     st->pil_phase = phase;
 }
 template <bool T2, bool W32>
-__global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+__global__ __launch_bounds__(64) void pll_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len) {
     FMX_RECURRENCE_PRIO();
     pll_body<T2, W32>(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
-    block_done(done);
 }
 
 // ---- B4
@@ -580,10 +570,9 @@ __device__ __forceinline__ void lock_body(DeviceTables T, DeviceBuffers B, CallG
     st->pil_lock = lock; st->pil_old = old; st->pil_stable = stable; st->pil_locked = locked;
     st->pss_call_total = tagn;
 }
-__global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+__global__ __launch_bounds__(64) void lock_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len) {
     FMX_RECURRENCE_PRIO();
     lock_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
-    block_done(done);
 }
 
 // =================================================================================================
@@ -831,10 +820,9 @@ __device__ __forceinline__ void pss_acc_body(DeviceTables T, DeviceBuffers B, Ca
     st->pss_acc = s.acc; st->pss_mean = s.mean; st->pilot_delay_pss = s.pdp;
     st->pss_lock_cnt = s.lock_cnt; st->pss_unlock_cnt = s.unlock_cnt; st->pss_minimized = s.minimized ? 1 : 0;
 }
-__global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int *done) {
+__global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len) {
     FMX_RECURRENCE_PRIO();
     pss_acc_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
-    block_done(done);
 }
 
 // =================================================================================================
@@ -980,10 +968,9 @@ __device__ __forceinline__ void deemph_body(DeviceTables T, DeviceBuffers B, Cal
     st->pss_count += st->pss_call_total;           // advance the PSS filter time base by this call's process_sample calls
     st->pss_call_total = 0;
 }
-__global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int last_chunk, int *done) {
+__global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, int last_chunk) {
     FMX_RECURRENCE_PRIO();
     deemph_body(T, B, G, C, rc0, chunk_len, last_chunk, (int)blockIdx.x, (int)blockIdx.y);
-    block_done(done);
 }
 
 // =================================================================================================
@@ -1099,7 +1086,7 @@ int recurrences_blocks_per_cu() {
 // queues cost 60-160 us each (they are cheap only between two or three queues).  So the recurrences of the WHOLE call are
 // one persistent kernel on a CU set of their own, the time-parallel kernels run on one other stream, and the two sides
 // meet through progress words in device memory --
-//   ts[0]: start gate | disc(0..2) | per chunk c: low-pass(c) [lock(c)], disc(c+3), mix(c-1) [integrator(c-1)]
+//   ts   : start gate | disc(0..2) | per chunk c: low-pass(c) [lock(c)], disc(c+3), mix(c-1) [integrator(c-1)]
 //   rs   : AFC(c) <- disc(c) word;  PLL <- AFC;  lock <- PLL;  integrator(c) <- low-pass(c) word;  de-emphasis(c) <- mix(c) word
 // Stream events remain only at the two ends of the call.
 static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s,
@@ -1122,13 +1109,13 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
     hipLaunchKernelGGL(sync_init_kernel, dim3(1), dim3(64), 0, s, S, groups, DS.host_flag);
     hipEvent_t e0 = DS.ev[(*DS.ev_next)++ % DS.nev];
     (void)hipEventRecord(e0, s);                                   // the front kernel's output and the cleared words
-    (void)hipStreamWaitEvent(DS.rs, e0, 0); (void)hipStreamWaitEvent(DS.ts[0], e0, 0);
+    (void)hipStreamWaitEvent(DS.rs, e0, 0); (void)hipStreamWaitEvent(DS.ts, e0, 0);
     const bool plldec = B.w_iq != nullptr;
     if (T.trig2 && T.wrap32_ok) { if (plldec) launch_recurrences<true, true, true>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, true, true>(T, B, G, C, P, S, groups, DS.rs); }
     else if (T.trig2) { if (plldec) launch_recurrences<true, true, false>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, true, false>(T, B, G, C, P, S, groups, DS.rs); }
     else { if (plldec) launch_recurrences<true, false, false>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, false, false>(T, B, G, C, P, S, groups, DS.rs); }
     auto trow = [&](int c) { return dim3((unsigned)((P.len[c] + WT - 1) / WT), (unsigned)groups); };
-    hipStream_t tq = DS.ts[0];
+    hipStream_t tq = DS.ts;
     int *prog = &S->prog[0][0];
     // the completion word of a kernel travels with the NEXT kernel on the stream (TSync::sig)
     int *pend_p = nullptr; int pend_v = 0;
@@ -1165,7 +1152,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         if (c >= 1 && c - 1 < P.n) mix(c - 1);
     }
     if (pend_p) hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, tq, pend_p, pend_v);
-    hipStream_t ends[2] = { DS.rs, DS.ts[0] };
+    hipStream_t ends[2] = { DS.rs, DS.ts };
     for (hipStream_t q : ends) {
         hipEvent_t e = DS.ev[(*DS.ev_next)++ % DS.nev];
         (void)hipEventRecord(e, q);
@@ -1203,20 +1190,20 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         // the discriminator runs per chunk in front of the AFC (a stage with time to spare), so the first PSS kernel
         // starts after 256 rows of it instead of after the whole call's
         hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + DISC_ROWS - 1) / DISC_ROWS), (unsigned)((C + DISC_CH - 1) / DISC_CH)), dim3(256), 0, st[0], T, B, G, C, rc0, len, TSync{});
-        if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len, (int *)nullptr);
-        else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len, (int *)nullptr);
+        if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
+        else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
         hand_over(0, 1, c);
-        if (T.trig2 && T.wrap32_ok) hipLaunchKernelGGL((pll_kernel<true, true>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len, (int *)nullptr);
-        else if (T.trig2) hipLaunchKernelGGL((pll_kernel<true, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len, (int *)nullptr);
-        else hipLaunchKernelGGL((pll_kernel<false, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len, (int *)nullptr);
+        if (T.trig2 && T.wrap32_ok) hipLaunchKernelGGL((pll_kernel<true, true>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
+        else if (T.trig2) hipLaunchKernelGGL((pll_kernel<true, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
+        else hipLaunchKernelGGL((pll_kernel<false, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
         hand_over(1, 2, c);
-        hipLaunchKernelGGL(lock_kernel, lanes, dim3(64), 0, st[2], T, B, G, C, rc0, len, (int *)nullptr);
+        hipLaunchKernelGGL(lock_kernel, lanes, dim3(64), 0, st[2], T, B, G, C, rc0, len);
         hand_over(2, 3, c);
         hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, st[3], T, B, G, C, rc0, len, TSync{});
-        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, st[3], T, B, G, C, rc0, len, (int *)nullptr);
+        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, st[3], T, B, G, C, rc0, len);
         hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len, TSync{});
         hand_over(3, 4, c);
-        hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last, (int *)nullptr);
+        hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last);
         rc0 += len;
     }
     if (s3 != s) { (void)hipEventRecord(DS.join, s3); (void)hipStreamWaitEvent(s, DS.join, 0); }

@@ -185,7 +185,7 @@ void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
 // Streams of the stage-B chunk pipeline.  side[]: four unmasked side streams of the event-driven layout.
 // Persistent layout (partitioned != 0): rs / ts[] are bound to two disjoint CU sets (hipExtStreamCreateWithCUMask); ONE
 // persistent kernel on rs runs every recurrence of the call (roles AFC, PLL, lock, PSS integrator, de-emphasis), the
-// time-parallel kernels run chunk by chunk on ts[0] (PSS low-pass, mix) and ts[1] (discriminator, d-ring), and the two
+// time-parallel kernels run chunk by chunk on ts (discriminator, PSS low-pass, mix), and the two
 // sides meet through progress words in `sync` (device memory) instead of stream events.
 constexpr int PB_MAX_CHUNKS = 64;      // chunks of one call in the persistent layout
 constexpr int PB_CHUNK = 864;          // its chunk length: <= PSS_DELAY / 2 and a multiple of the work-array tile
@@ -201,7 +201,7 @@ struct DemodSync {                      // zeroed at the start of every call
     int cnt_disc[PB_MAX_CHUNKS], cnt_fir[PB_MAX_CHUNKS], cnt_mix[PB_MAX_CHUNKS];     // finished blocks of chunk c's kernel
     int prog[PB_ROLES][1];              // [role][group]: chunks finished; really [PB_ROLES][groups] (allocated to size)
 };
-struct DemodStreams { hipStream_t side[4]; hipEvent_t *ev; int nev; hipEvent_t join; hipStream_t rs; hipStream_t ts[2];
+struct DemodStreams { hipStream_t side[4]; hipEvent_t *ev; int nev; hipEvent_t join; hipStream_t rs; hipStream_t ts;
                       int partitioned; int *ev_next; DemodSync *sync; int *host_flag; };
 int recurrences_blocks_per_cu();
 void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s,
