@@ -292,7 +292,8 @@ __device__ __forceinline__ void wst2(float2 *tile, const float2 x[WT]) {
 // samples are consumed and vice versa (block form rather than a rotating window: the compiler's s_waitcnt placement
 // then leaves the full distance).  `load(set, u, tile)` fills registers, `body(set, u, tile)` consumes them; set and u
 // are compile-time after unrolling.  Loads are clamped, never conditional.
-constexpr int PD = 4;           // default depth; the two-array recurrences use 3 so that the persistent kernel keeps two waves per SIMD
+// (depth per kernel: 4 for the one-array recurrences, 3 for the two-array ones so that the persistent kernel keeps two
+// waves per SIMD, 2 for the PLL-decoder AFC)
 template <int PD, typename LoadF, typename BodyF>
 __device__ __forceinline__ void tile_pipeline(int nfull, LoadF load, BodyF body) {
     if (nfull <= 0) return;
@@ -829,34 +830,36 @@ __global__ __launch_bounds__(64) void pss_acc_kernel(DeviceTables T, DeviceBuffe
 // B7  38 kHz mix, PSS input, stereo matrix   (time-parallel; transposing like B1)
 //     fm-processor.cpp:707-730, 517-549
 // =================================================================================================
+constexpr int MIX_ROWS = 64, MIX_CH = 16;               // one block: four work-array tile rows of sixteen channels
 __device__ __forceinline__ void pss_mix_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y) {
-    // One block = one work-array tile row: 16 samples x 64 channels, threads as (sample in tile, channel), four elements
-    // per thread.  With that mapping the tiled work arrays AND the channel-major rings are written in 64-byte runs, so
-    // nothing is transposed.  The loads of all four elements are issued before anything is computed, and the SinCos
-    // gathers of all four before they are used (the kernel sits on the PSS loop's critical path: latency, not bandwidth).
+    // One block = 64 samples x 16 channels, threads as (sample in tile row, channel); a thread's four elements are four
+    // tile rows of ONE channel, so the channel's settings are read once, the tiled work arrays are accessed in 1 KB runs
+    // and the channel-major s ring in 128-byte runs that a block extends to 512 bytes.  The loads of all four elements are
+    // issued before anything is computed, and the SinCos gathers of all four before they are used.
     const int CP = G.pitch;
     const int tid = threadIdx.x;
-    const int q0 = bid_x * WT;
-    const int c0 = bid_y * 64;
+    const int q0 = bid_x * MIX_ROWS;
     const float2 *__restrict__ sct = T.sincos;
     const double SC = T.sincos_C;
-    constexpr int EPT = 4;
-    const int ql = tid & 15, q = q0 + ql;
-    const bool qok = q < chunk_len;
-    const int64_t r = rc0 + (qok ? q : chunk_len - 1);            // clamped: loads stay unconditional
-    int ch[EPT]; bool ok[EPT]; size_t wi[EPT];
+    constexpr int EPT = MIX_ROWS / WT;
+    const int chx = bid_y * MIX_CH + (tid >> 4);
+    const int chc = chx < C ? chx : C - 1;
+    const ChanParams &P = B.params[chc];
+    const int ssel1 = P.sound_sel, fmode1 = P.fm_mode; const float pano1 = P.panorama;
+    const int64_t ic1 = B.state[chc].pss_count;
+    int ch[EPT]; bool ok[EPT]; size_t wi[EPT]; int qq[EPT];
     float demod[EPT], cur[EPT], pdp[EPT]; int tag[EPT];
     int ssel[EPT], fmode[EPT]; float pano[EPT]; int64_t ic[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
-        const int cl = (tid >> 4) + 16 * i;
-        ch[i] = c0 + cl; ok[i] = qok && ch[i] < C;
-        const int chc = ch[i] < C ? ch[i] : C - 1;
+        const int q = q0 + WT * i + (tid & 15);
+        qq[i] = q;
+        const bool qok = q < chunk_len;
+        const int64_t r = rc0 + (qok ? q : chunk_len - 1);            // clamped: loads stay unconditional
+        ch[i] = chx; ok[i] = qok && chx < C;
         wi[i] = widx(r, chc, CP);
         demod[i] = B.w_dem[wi[i]]; tag[i] = (B.w_tag[wi[i]] >> 1) - 2; cur[i] = B.w_cur[wi[i]]; pdp[i] = B.w_pdp[wi[i]];
-        const ChanParams &P = B.params[chc];
-        ssel[i] = P.sound_sel; fmode[i] = P.fm_mode; pano[i] = P.panorama;
-        ic[i] = B.state[chc].pss_count;
+        ssel[i] = ssel1; fmode[i] = fmode1; pano[i] = pano1; ic[i] = ic1;
     }
     float ph[EPT]; float2 e[EPT]; float sn[EPT];
 #pragma unroll
@@ -899,7 +902,7 @@ __device__ __forceinline__ void pss_mix_body(DeviceTables T, DeviceBuffers B, Ca
     }
 }
 __global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, TSync Y) {
-    if (!tsync_enter(Y, (int)blockIdx.y)) return;
+    if (!tsync_enter(Y, (int)blockIdx.y >> 2)) return;
     pss_mix_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
 }
 // =================================================================================================
@@ -1100,7 +1103,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         const int cap = (c == 0 && nj > 2 * FIRST_CHUNK) ? FIRST_CHUNK : PB_CHUNK;
         const int len = (int)((nj - rc0) < cap ? (nj - rc0) : cap);
         P.rc0[c] = (int)rc0; P.len[c] = len;
-        P.nb_disc[c] = ((len + DISC_ROWS - 1) / DISC_ROWS) * ((C + DISC_CH - 1) / DISC_CH); P.nb_mix[c] = ((len + WT - 1) / WT) * groups;
+        P.nb_disc[c] = ((len + DISC_ROWS - 1) / DISC_ROWS) * ((C + DISC_CH - 1) / DISC_CH); P.nb_mix[c] = ((len + MIX_ROWS - 1) / MIX_ROWS) * ((C + MIX_CH - 1) / MIX_CH);
         P.nb_fir[c] = ((len + PSS_TILE - 1) / PSS_TILE) * C;
         P.n++; rc0 += len;
     }
@@ -1114,7 +1117,6 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
     if (T.trig2 && T.wrap32_ok) { if (plldec) launch_recurrences<true, true, true>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, true, true>(T, B, G, C, P, S, groups, DS.rs); }
     else if (T.trig2) { if (plldec) launch_recurrences<true, true, false>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, true, false>(T, B, G, C, P, S, groups, DS.rs); }
     else { if (plldec) launch_recurrences<true, false, false>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, false, false>(T, B, G, C, P, S, groups, DS.rs); }
-    auto trow = [&](int c) { return dim3((unsigned)((P.len[c] + WT - 1) / WT), (unsigned)groups); };
     hipStream_t tq = DS.ts;
     int *prog = &S->prog[0][0];
     // the completion word of a kernel travels with the NEXT kernel on the stream (TSync::sig)
@@ -1141,7 +1143,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         pend_p = &S->cnt_fir[c]; pend_v = P.nb_fir[c];
     };
     auto mix = [&](int c) {
-        hipLaunchKernelGGL(pss_mix_kernel, trow(c), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(3, c + 1));
+        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((P.len[c] + MIX_ROWS - 1) / MIX_ROWS), (unsigned)((C + MIX_CH - 1) / MIX_CH)), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(3, c + 1));
         pend_p = &S->cnt_mix[c]; pend_v = P.nb_mix[c];
     };
     hipLaunchKernelGGL(start_gate_kernel, dim3(1), dim3(64), 0, tq, S, PB_ROLES * groups);
@@ -1201,7 +1203,7 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         hand_over(2, 3, c);
         hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, st[3], T, B, G, C, rc0, len, TSync{});
         hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, st[3], T, B, G, C, rc0, len);
-        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + WT - 1) / WT), (unsigned)((C + 63) / 64)), dim3(256), 0, st[3], T, B, G, C, rc0, len, TSync{});
+        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + MIX_ROWS - 1) / MIX_ROWS), (unsigned)((C + MIX_CH - 1) / MIX_CH)), dim3(256), 0, st[3], T, B, G, C, rc0, len, TSync{});
         hand_over(3, 4, c);
         hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last);
         rc0 += len;
