@@ -386,6 +386,24 @@ def test_stage_b_layouts_identical(fmx_amd, ol, monkeypatch):
     assert rms(outs[0][0][0]) > 0.01
 
 
+def test_large_batch_is_self_consistent(fmx_amd, ol):
+    """2112 channels (33 groups: the regime where the time-parallel kernels share the recurrence kernel's CUs) listening
+    to ONE stream with the same settings: every channel's PCM must be bit-identical to channel 0's, and channel 0 must
+    match the oracle.  A race between the persistent kernel's roles and the time-parallel kernels would show up as a
+    channel that differs."""
+    nch, block = 2112, 16384 * 6
+    iq = ol.synth_iq(5 * block, stereo=1)
+    o = ol.OracleChain(inputFilterBw=165000, fmMode=0)
+    pcm_o = o.process(iq)
+    f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block)
+    gui_defaults(f, 165000, True)
+    pcm = run_blocks(f, iq, block)
+    f.synchronize()
+    assert rms(pcm[0] - pcm_o) <= PCM_RMS_TOL
+    bad = [c for c in range(1, nch) if not np.array_equal(pcm[c], pcm[0])]
+    assert bad == [], f"{len(bad)} channels differ from channel 0, first {bad[:8]}"
+
+
 def test_error_behaviour(fmx_amd):
     f = fmx_amd.Fmx(2, max_block=16384)
     for pid, v, code in [(M.P_FM_MODE, 3, M.FMX_E_INVALID), (M.P_FM_DECODER, 0, M.FMX_E_INVALID),
