@@ -74,8 +74,10 @@ typedef enum {
     FMX_P_AUTO_MONO = 14,      /* setAutoMonoMode                                    (:914-916)  */
     FMX_P_PSS = 15,            /* setPSSMode                                         (:918-920)  */
     FMX_P_DC_REMOVE = 16,      /* setDCRemove (also zeroes RfDC)                     (:922-925)  */
-    FMX_P_SQUELCH_MODE = 17,   /* set_squelchMode: only 0 (OFF) accepted, else FMX_E_UNSUPPORTED */
+    FMX_P_SQUELCH_MODE = 17,   /* set_squelchMode (fm-processor.cpp:882): 0 OFF, 2 LSQ (level squelch, squelchClass.cpp:89-113);
+                                  1 (NSQ, two order-20 IIR filters) is FMX_E_UNSUPPORTED */
     FMX_P_TEST_TONE = 18,      /* setTestTone: only 0 accepted                                   */
+    FMX_P_SQUELCH_VALUE = 19,  /* set_squelchValue 0..100 (:213-215): takes effect at the next call when it differs  */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */
@@ -94,7 +96,7 @@ typedef struct {
     int32_t live_pilot_locked;
     float   live_lock_strength;
     float   live_dc_if;
-    int32_t reserved;
+    int32_t squelch_active;    /* getSquelchState (:217-219): the level squelch is muting the demodulator output */
 } fmx_meta;
 
 typedef enum {

@@ -762,6 +762,8 @@ struct fmo_chain {
     fmo_pilot *pilot; fmo_pss *pss;
     fmo_demod *demod;
     float *rdsPhaseBuffer; int rdsPhaseIndex;
+    /* squelch (level squelch only) squelchClass.cpp:12-29 */
+    float sqLevelThr; int sqCount, sqHold, sqSuppress, sqOldValue;
     int newAudioFilter, inputFilterOn, newInputFilter, audioFilterActive;
     int32_t lowPassFrequency, fmBandwidth;
     float Lgain, Rgain, pilotDelayPSS, deemphAlpha, volumeFactor, panorama, leftChannel, rightChannel;
@@ -788,7 +790,7 @@ void fmo_config_defaults(fmo_config *c) {
     c->volumeDb = -6.0f;          /* radio.cpp:579,1502-1505 : -12 half-dB */
     c->useCtorVolume = 0;
     c->balance = 0; c->panorama = 100; c->attL = 1; c->attR = 1; c->loFrequency = 0;
-    c->dcRemove = 1; c->autoMono = 1; c->pssActive = 1; c->rdsMode = 0;
+    c->dcRemove = 1; c->autoMono = 1; c->pssActive = 1; c->rdsMode = 0; c->squelchMode = 0; c->squelchValue = 0;
 }
 
 static void apply_settings(fmo_chain *ch, const fmo_config *c, int initial) {
@@ -868,6 +870,8 @@ fmo_chain *fmo_chain_new(const fmo_config *c) {
     ch->rdsBitCap = 1 << 16; ch->rdsBits = (uint8_t *)malloc((size_t)ch->rdsBitCap);
     ch->pending = (c32 *)malloc(sizeof(c32) * BLOCK);
     ch->meta.peakLeftDb = ch->meta.peakRightDb = -40.0f;
+    /* mySquelch (1, 70000, fmRate / 20, fmRate) fm-processor.cpp:87; squelchValue = oldSquelchValue = 0 :194-195 */
+    ch->sqLevelThr = powf(10.0f, (1 - 80) / 30.0f); ch->sqHold = ch->cfg.fmRate / 20; ch->sqCount = 0; ch->sqSuppress = 0; ch->sqOldValue = 0;
     apply_settings(ch, c, 1);
     return ch;
 }
@@ -964,6 +968,10 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
         fmo_fftfilter_set_lowpass(ch->audioFilter, ch->lowPassFrequency, fmRate);
         ch->audioFilterActive = 1; ch->newAudioFilter = 0;
     }
+    if (ch->cfg.squelchValue != ch->sqOldValue) {           /* fm-processor.cpp:410-413 */
+        ch->sqLevelThr = powf(10.0f, (ch->cfg.squelchValue - 80) / 30.0f);      /* setSquelchLevel squelchClass.cpp:33-37 */
+        ch->sqOldValue = ch->cfg.squelchValue;
+    }
     if (ch->cfg.dcRemove) {
         for (int32_t i = 0; i < amount; i++) {
             /* :425 */
@@ -989,6 +997,16 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
         }
         tap2(ch, FMO_TAP_FM_IQ, v);
         float demod = fmo_demod_demodulate(ch->demod, v);
+        if (ch->cfg.squelchMode == 2) {
+            /* squelch::do_level_squelch squelchClass.cpp:89-113 (hysteresis 0, LEVELREDUCTIONFACTOR 0, holdPeriod fmRate/20) */
+            if (++ch->sqCount >= ch->sqHold) {
+                ch->sqCount = 0;
+                const float carrier = fmo_demod_carrier(ch->demod);
+                if (carrier < ch->sqLevelThr - 0.000f) ch->sqSuppress = 1;
+                else if (carrier >= ch->sqLevelThr + 0.000f) ch->sqSuppress = 0;
+            }
+            demod = ch->sqSuppress ? demod * 0.000f : demod;
+        }
         tap1(ch, FMO_TAP_DEMOD, demod);
         c32 audio, rdsData = C(0, 0);
         process_signal_with_rds(ch, demod, &audio, &rdsData);
@@ -1083,6 +1101,7 @@ long fmo_chain_process(fmo_chain *ch, const float *iq, long n, float *pcm, long 
 
 void fmo_chain_meta(const fmo_chain *ch, fmo_meta *m) {
     *m = ch->meta; m->fmSamples = ch->fmCount; m->pcmFrames = ch->pcmCount;
+    m->squelchActive = ch->sqSuppress; m->pad_ = 0;
 }
 long fmo_chain_rds_bits(const fmo_chain *ch, uint8_t *bits, long cap) {
     long n = ch->rdsBitCount < cap ? ch->rdsBitCount : cap;

@@ -164,6 +164,8 @@ typedef struct {
     int32_t loFrequency;      /* set_localOscillator                       fm-processor.cpp:866-868 */
     int32_t dcRemove, autoMono, pssActive;
     int32_t rdsMode;          /* 0 off, 1..3 = RDS_1..3 (only 2 is restated) */
+    int32_t squelchMode;      /* 0 OFF, 2 LSQ (level squelch; NSQ = 1 is not restated)   fm-processor.cpp:499-509 */
+    int32_t squelchValue;     /* set_squelchValue 0..100: applied at a block start when it differs from the last one (:410-413) */
 } fmo_config;
 
 void fmo_config_defaults(fmo_config *);   /* GUI-effective defaults, SURVEY 3.3 */
@@ -184,6 +186,8 @@ typedef struct {
     int32_t pilotLocked;
     float   peakLeftDb, peakRightDb;
     int64_t fmSamples, pcmFrames;
+    int32_t squelchActive;    /* getSquelchState */
+    int32_t pad_;
 } fmo_meta;
 
 typedef struct fmo_chain fmo_chain;

@@ -39,6 +39,7 @@ struct ChanUser {
     bool    ctor_volume = true;  // volumeFactor = 0.5f (:127) until setVolume
     float   volume_db = 0.f;
     int32_t balance = 0, panorama = 100;
+    int32_t squelch_value = 0, squelch_old = 0, squelch_level = 1;   // fm-processor.cpp:194-195; mySquelch (1, ...) :87
 };
 
 struct ProfRec { hipEvent_t e[4]; int64_t in_samples, ch_samples; int n; };
@@ -307,11 +308,19 @@ int flush_mailbox(fmx_handle h) {
         if (h->rds_start < 0) h->rds_start = h->g_total / DECIM;       // the RDS filters start counting here (all channels)
     }
     bool any_pll = false;
-    for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1);     // both run pllC on the fm-rate IQ
+    for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode == 2);     // pllC on the fm-rate IQ; |z| for the level squelch
     if (any_pll && !h->B.w_iq) {
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMalloc(&h->B.w_iq, sizeof(float2) * (size_t)h->work_nj * h->pitch));
         HIPCHK(hipMemset(h->B.w_iq, 0, sizeof(float2) * (size_t)h->work_nj * h->pitch));
+    }
+    for (int c = 0; c < h->channels; c++) {            // set_squelchValue takes effect at a block start, when it differs (fm-processor.cpp:410-413)
+        ChanUser &u = h->user[c];
+        if (u.squelch_value != u.squelch_old) {
+            u.squelch_level = u.squelch_value; u.squelch_old = u.squelch_value;
+            h->params[c].squelch_thr = std::pow(10.0f, (float)(u.squelch_level - 80) / 30.0f);       // squelchClass.cpp:33-37
+            h->params_dirty = true;
+        }
     }
     if (h->params_dirty) {
         HIPCHK(hipDeviceSynchronize());   // the previous call may still run on the caller's stream and the side streams
@@ -465,6 +474,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         // constructor defaults fm-processor.cpp:110-160 / fm-demodulator.cpp:66
         p.fm_mode = 0; p.sound_sel = 0; p.decoder = 3; p.auto_mono = 1; p.pss_active = 1; p.dc_remove = 1;
         p.rds_mode = 0; p.lo_freq = 0; p.lo_period = 0; p.att_l = 1.f; p.att_r = 1.f;
+        p.squelch_mode = 0; p.squelch_thr = std::pow(10.0f, (float)(1 - 80) / 30.0f);
         refresh_derived(h, c);
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -683,7 +693,10 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         break;
     case FMX_P_LOCAL_OSCILLATOR:
         if (std::abs(iv) > h->cfg.inputRate) return fail(FMX_E_INVALID, "|lo| must be <= inputRate (oscillator.cpp:49-58)"); break;
-    case FMX_P_SQUELCH_MODE: if (iv != 0) return fail(FMX_E_UNSUPPORTED, "squelch is outside the hot path (SURVEY 8f)"); break;
+    case FMX_P_SQUELCH_MODE:
+        if (iv == 1) return fail(FMX_E_UNSUPPORTED, "the noise squelch (two order-20 IIR filters) is not built; 0 = off, 2 = level squelch");
+        if (iv != 0 && iv != 2) return fail(FMX_E_INVALID, "squelch mode must be 0, 1 or 2"); break;
+    case FMX_P_SQUELCH_VALUE: if (iv < 0 || iv > 100) return fail(FMX_E_INVALID, "squelch value must be 0..100"); break;
     case FMX_P_TEST_TONE: if (iv != 0) return fail(FMX_E_UNSUPPORTED, "test tone is a GUI aid, not built"); break;
     case FMX_P_VOLUME_DB: case FMX_P_LF_CUTOFF: case FMX_P_ATTENUATION_L: case FMX_P_ATTENUATION_R:
     case FMX_P_AUTO_MONO: case FMX_P_PSS: case FMX_P_DC_REMOVE:
@@ -717,6 +730,8 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         }
         case FMX_P_AUTO_MONO: p.auto_mono = iv != 0; break;
         case FMX_P_PSS: p.pss_active = iv != 0; break;
+        case FMX_P_SQUELCH_MODE: p.squelch_mode = iv; break;
+        case FMX_P_SQUELCH_VALUE: u.squelch_value = iv; break;
         case FMX_P_DC_REMOVE: p.dc_remove = iv != 0; p.actions |= ACT_DC_RESET; break;
         case FMX_A_TRIGGER_FREQUENCY_CHANGE: p.actions |= ACT_TRIGGER_FREQ; break;
         case FMX_A_RESTART_PSS: p.actions |= ACT_RESTART_PSS; break;
@@ -810,7 +825,7 @@ int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
     m->PilotPllLockStrength = st.meta_lock_strength; m->PilotPllLocked = st.meta_locked;
     m->live_pilot_locked = (h->params[channel].fm_mode != 2) ? st.pil_locked : 0;
     m->live_lock_strength = (h->params[channel].fm_mode != 2) ? st.pil_lock : 0.f;
-    m->live_dc_if = st.fm_afc; m->reserved = 0;
+    m->live_dc_if = st.fm_afc; m->squelch_active = (h->params[channel].squelch_mode == 2) ? st.sq_suppress : 0;
     m->fm_samples = h->g_total / DECIM; m->pcm_frames = 48 * ((h->g_total / DECIM) / 192);
     return FMX_OK;
 }

@@ -151,6 +151,7 @@ __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallG
     // work-array stores 1 KB runs (16 rows x 16 channels of a tile row are contiguous).
     const int CP = G.pitch;
     __shared__ float2 sLIM[DISC_CH][DISC_ROWS + 3];   // limited samples of rows r0-2 .. r0+63 (each is used by up to three outputs)
+    __shared__ float sABS[DISC_CH][DISC_ROWS + 3];    // |z| of the same samples (AM decoder, level squelch)
     __shared__ int sDelay[DISC_CH], sDec[DISC_CH];
     const int tid = threadIdx.x;
     const int64_t nj = row0 + nrows;
@@ -168,7 +169,7 @@ __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallG
     for (int i = tid; i < DISC_CH * (DISC_ROWS + 2); i += 256) {
         const int cl = i / (DISC_ROWS + 2), rl = i - (DISC_ROWS + 2) * cl;      // rl 0..65 <-> row r0 - 2 + rl
         const int ch = c0 + cl;
-        float2 v = make_float2(0.f, 0.f);
+        float2 v = make_float2(0.f, 0.f); float za = 0.f;
         if (ch < C) {
             const float2 *zr = B.zring + (size_t)ch * ring;
             const int64_t jj = G.J0 + r0 - 2 + rl;
@@ -180,9 +181,10 @@ __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallG
                 const int64_t s = jj - sDelay[cl];
                 const float2 z = s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f);
                 v = am ? z : limiter(z);
+                za = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
             }
         }
-        sLIM[cl][rl] = v;
+        sLIM[cl][rl] = v; sABS[cl][rl] = za;
     }
     __syncthreads();
     // ---- discriminator; threads as (sample in tile row, channel), one tile row per step
@@ -197,8 +199,8 @@ __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallG
             float res = 0.f;
             const float2 cur = sLIM[cl][rl + 2], p1 = sLIM[cl][rl + 1];
             const float I = cur.x, Q = cur.y, I1 = p1.x, Q1 = p1.y;
-            if (decoder == 1) {            // AM: |z| for decodeAM (:215-241); the carrier IIR and the PLL run in afc_kernel
-                res = (float)sqrt((double)cur.x * (double)cur.x + (double)cur.y * (double)cur.y);
+            if (decoder == 1 || decoder == 2) {   // AM: |z| for decodeAM (:215-241); PLL decoder: |z| for the carrier IIR (the
+                res = sABS[cl][rl + 2];           // demod value itself comes from pllC).  Both run in afc_kernel.
             } else if (decoder == 5) {     // REAL_BB fm-demodulator.cpp:174-182
                 res = (float)((double)(I1 * Q - Q1 * I + 1) / 2.0);
                 int index = (int)floorf(res * (float)ARCSINE_N);
@@ -214,7 +216,7 @@ __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallG
                 res = lut_atan2(T.atan_ppy, Q * I1 - I * Q1, I * I1 + Q * Q1);
             }
             B.w_dem[widx(r, ch, CP)] = res;
-            if (want_iq) B.w_iq[widx(r, ch, CP)] = cur;
+            if (want_iq) B.w_iq[widx(r, ch, CP)] = decoder <= 2 ? cur : make_float2(sABS[cl][rl + 2], 0.f);   // (other decoders: |z| for the level squelch)
         }
     }
 }
@@ -320,7 +322,13 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     const int ch = bid_x * 64 + threadIdx.x;
     if (ch >= C) return;
     ChanState *st = B.state + ch;
-    const bool use_pll = PLLDEC && (B.params[ch].decoder == 2), use_am = PLLDEC && (B.params[ch].decoder == 1);
+    const int decoder = B.params[ch].decoder;
+    const bool use_pll = PLLDEC && (decoder == 2), use_am = PLLDEC && (decoder == 1);
+    // level squelch (squelch::do_level_squelch squelchClass.cpp:89-113, fm-processor.cpp:504-506): the carrier amplitude IIR
+    // of the demodulator (fm-demodulator.cpp:130-131) against a threshold, re-evaluated every fmRate / 20 samples
+    const bool lsq = PLLDEC && (B.params[ch].squelch_mode == 2);
+    const float sq_thr = B.params[ch].squelch_thr;
+    int sq_cnt = st->sq_count; bool sq_sup = st->sq_suppress != 0;
     float am = st->am_carr;
     const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha, K = T.K_FM, rK = T.K_FM_rcp;
     const double SC = T.sincos_C;
@@ -328,9 +336,10 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     const size_t ro = widx(rc0, ch, CP);              // rc0 is a multiple of the tile height
     float *wd = B.w_dem + ro;
     const float2 *wiq = PLLDEC ? B.w_iq + ro : nullptr;
-    auto step = [&](float res, float2 sig) -> float {
+    auto demod1 = [&](float res, float2 sig) -> float {
         if (PLLDEC) {
-            if (use_am) am = (1.0f - 0.0010f) * am + 0.0010f * res;      // am_carr_ampl, carrierAlpha (fm-demodulator.cpp:117,130-131)
+            // |z| arrives in the demod array for the AM and PLL decoders, in the first half of the IQ array otherwise (disc_kernel)
+            if (use_am || lsq) am = (1.0f - 0.0010f) * am + 0.0010f * (decoder <= 2 ? res : sig.x);      // am_carr_ampl, carrierAlpha (fm-demodulator.cpp:117,130-131)
             if (use_pll || use_am) {                 // pllC::do_pll pllC.cpp:67-90 (AM: on the unlimited sample, :222)
                 const float2 nco = sc_complex(T.sincos, SC, nco_phase);
                 const float dre = nco.x * sig.x - (-nco.y) * sig.y;      // conj(nco) * signal
@@ -353,6 +362,18 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
         }
         afc = c1 * afc + fmDcAlpha * res;            // fm-demodulator.cpp:197
         return fdiv_const(20.0f * (res - afc) * 1.0f, K, rK);      // :198
+    };
+    auto step = [&](float res, float2 sig) -> float {
+        float r = demod1(res, sig);
+        if (PLLDEC && lsq) {
+            if (++sq_cnt >= SINCOS_N / 20) {         // holdPeriod = fmRate / 20 (fm-processor.cpp:87)
+                sq_cnt = 0;
+                if (am < sq_thr - 0.000f) sq_sup = true;             // SQUELCH_HYSTERESIS_LSQ = 0
+                else if (am >= sq_thr + 0.000f) sq_sup = false;
+            }
+            r = sq_sup ? r * 0.000f : r;             // LEVELREDUCTIONFACTOR = 0
+        }
+        return r;
     };
     constexpr int UB = SEQ_UB;
     const int nfull = chunk_len / UB;
@@ -384,6 +405,7 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
             wdt[k] = step(wdt[k], PLLDEC ? wiqt[k] : make_float2(0.f, 0.f));
     }
     st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr; st->am_carr = am;
+    if (PLLDEC) { st->sq_count = sq_cnt; st->sq_suppress = sq_sup ? 1 : 0; }
 }
 template <bool PLLDEC>
 __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len) {

@@ -51,6 +51,8 @@ struct ChanParams {
     float   att_l, att_r;
     float   deemph_alpha, volume, left_ch, right_ch, panorama;
     int32_t actions;     // one-shot ACT_* bits consumed by the kernels of the next call
+    int32_t squelch_mode;   // 0 off, 2 level squelch (set_squelchMode)
+    float   squelch_thr;    // levelSquelchThreshold squelchClass.cpp:35
 };
 enum { ACT_TRIGGER_FREQ = 1, ACT_RESTART_PSS = 2, ACT_DC_RESET = 4 };
 
@@ -81,6 +83,8 @@ struct ChanState {
     int32_t my_count;
     float   meta_dc_rf, meta_dc_if, meta_pss_deg, meta_pss_change, meta_lock_strength;
     int32_t meta_pss_state, meta_locked;
+    // level squelch (squelchClass.cpp:20-28)
+    int32_t sq_count, sq_suppress;
 };
 
 // Work arrays of stage B (w_*): element (row r, channel ch) lives at ((r / 16) * pitch + ch) * 16 + r % 16 -- tiles of 16

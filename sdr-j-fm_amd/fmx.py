@@ -18,7 +18,7 @@ FMX_OK, FMX_E_INVALID, FMX_E_UNSUPPORTED, FMX_E_NO_DEVICE, FMX_E_HIP, FMX_E_NOME
 # parameter ids (include/fmx.h fmx_param_id)
 P_FM_MODE, P_FM_DECODER, P_SOUND_MODE, P_STEREO_PANORAMA, P_SOUND_BALANCE, P_DEEMPHASIS = 1, 2, 3, 4, 5, 6
 P_VOLUME_DB, P_LF_CUTOFF, P_BANDWIDTH, P_ATTENUATION_L, P_ATTENUATION_R, P_RDS_MODE = 7, 8, 9, 10, 11, 12
-P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE = 13, 14, 15, 16, 17, 18
+P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE, P_SQUELCH_VALUE = 13, 14, 15, 16, 17, 18, 19
 A_TRIGGER_FREQUENCY_CHANGE, A_RESTART_PSS, A_RESET_RDS = 100, 101, 102
 
 TAP_FM_IQ, TAP_DEMOD, TAP_LR_RAW, TAP_PRE_RESAMPLER, TAP_RDS_IQ = 0, 1, 2, 3, 4
@@ -53,7 +53,7 @@ class FmxMeta(C.Structure):
         ("PssPhaseChange", C.c_float), ("PssState", C.c_int32), ("PilotPllLockStrength", C.c_float),
         ("PilotPllLocked", C.c_int32), ("fm_samples", C.c_int64), ("pcm_frames", C.c_int64),
         ("live_pilot_locked", C.c_int32), ("live_lock_strength", C.c_float), ("live_dc_if", C.c_float),
-        ("reserved", C.c_int32),
+        ("squelch_active", C.c_int32),
     ]
 
 

@@ -36,6 +36,7 @@ class FmoConfig(C.Structure):
         ("volumeDb", C.c_float), ("useCtorVolume", C.c_int32), ("balance", C.c_int32), ("panorama", C.c_int32),
         ("attL", C.c_float), ("attR", C.c_float), ("loFrequency", C.c_int32),
         ("dcRemove", C.c_int32), ("autoMono", C.c_int32), ("pssActive", C.c_int32), ("rdsMode", C.c_int32),
+        ("squelchMode", C.c_int32), ("squelchValue", C.c_int32),
     ]
 
 
@@ -44,7 +45,7 @@ class FmoMeta(C.Structure):
         ("dcValRf", C.c_float), ("dcValIf", C.c_float), ("pssPhaseShiftDegree", C.c_float),
         ("pssPhaseChange", C.c_float), ("pssState", C.c_int32), ("pilotLockStrength", C.c_float),
         ("pilotLocked", C.c_int32), ("peakLeftDb", C.c_float), ("peakRightDb", C.c_float),
-        ("fmSamples", C.c_int64), ("pcmFrames", C.c_int64),
+        ("fmSamples", C.c_int64), ("pcmFrames", C.c_int64), ("squelchActive", C.c_int32), ("pad_", C.c_int32),
     ]
 
 

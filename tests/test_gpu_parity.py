@@ -358,6 +358,37 @@ def test_edge_inputs(fmx_amd, ol):
     assert e.value.code == M.FMX_E_TOO_LARGE
 
 
+@pytest.mark.parametrize("decoder", [3, 2, 1])
+def test_level_squelch(fmx_amd, ol, decoder):
+    """set_squelchMode(LSQ) + set_squelchValue (fm-processor.cpp:499-509, squelchClass.cpp:33-37,89-113): the carrier
+    fades from 0.5 to 0.002 and comes back; the demodulator output is muted while the carrier-amplitude IIR sits under the
+    threshold, decisions every fmRate/20 samples.  |z| reaches the squelch by a different route for the AM, the PLL and the
+    LUT decoders -- all three are checked against the oracle, together with the squelch flag of the meta data."""
+    block = 16384 * 10
+    n = 9 * block
+    iq = ol.synth_iq(n, stereo=1)
+    env = np.ones(n, np.float32)
+    env[3 * block:6 * block] = 0.004
+    iq = (iq * env[:, None]).astype(np.float32)
+    o = ol.OracleChain(inputFilterBw=165000, fmMode=0, decoder=decoder, squelchMode=2, squelchValue=50)
+    f = fmx_amd.Fmx(2, max_block=block)
+    gui_defaults(f, 165000, True, decoder=decoder)
+    f.set_param(M.P_SQUELCH_MODE, 2, 0)
+    f.set_param(M.P_SQUELCH_VALUE, 50, 0)              # channel 1 stays unsquelched
+    flags_g, flags_o, pcm_g, pcm_o = [], [], [], []
+    for i in range(0, n, block):
+        pcm_o.append(o.process(iq[i:i + block]))
+        pcm_g.append(f.process_host(np.stack([iq[i:i + block]] * 2)))
+        flags_g.append(f.meta(0).squelch_active); flags_o.append(o.meta().squelchActive)
+    pcm_g = np.concatenate(pcm_g, axis=1); pcm_o = np.concatenate(pcm_o)
+    print(f"\n[LSQ decoder {decoder}] squelch flag per call: gpu {flags_g} oracle {flags_o}; pcm rms {rms(pcm_g[0] - pcm_o):.3e}")
+    assert flags_g == flags_o and 1 in flags_o and flags_o[0] == 0 and flags_o[-1] == 0
+    assert rms(pcm_g[0] - pcm_o) <= PCM_RMS_TOL
+    assert f.meta(1).squelch_active == 0
+    muted = slice(int(5.2 * block) // 48, int(5.9 * block) // 48)
+    assert rms(pcm_g[0][muted]) < 1e-6 and rms(pcm_g[1][muted]) > 1e-4      # muted vs noise of the weak carrier
+
+
 def test_stage_b_layouts_identical(fmx_amd, ol, monkeypatch):
     """The two schedules of stage B (persistent recurrence kernel + progress words, and the event-driven five-stream
     pipeline) run the same chunk bodies: PCM, taps and meta must be bit-identical.  130 channels = three 64-channel
