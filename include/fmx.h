@@ -76,8 +76,10 @@ typedef enum {
     FMX_P_DC_REMOVE = 16,      /* setDCRemove (also zeroes RfDC)                     (:922-925)  */
     FMX_P_SQUELCH_MODE = 17,   /* set_squelchMode (fm-processor.cpp:882): 0 OFF, 2 LSQ (level squelch, squelchClass.cpp:89-113);
                                   1 (NSQ, two order-20 IIR filters) is FMX_E_UNSUPPORTED */
-    FMX_P_TEST_TONE = 18,      /* setTestTone: only 0 accepted                                   */
+    FMX_P_TEST_TONE = 18,      /* setTestTone (:931-933): 1 kHz bursts of 25 ms every 2 s at 0.9, programme at 0.1 (:800-823) */
     FMX_P_SQUELCH_VALUE = 19,  /* set_squelchValue 0..100 (:213-215): takes effect at the next call when it differs  */
+    FMX_P_DISP_DELAY = 20,     /* setDispDelay (:935-937): steps of the peak-level delay line; applies to the windows
+                                  fmx_get_peaks has not handed out yet */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */
@@ -159,6 +161,12 @@ int  fmx_synchronize(fmx_handle h);
 
 /* replaces the showMetaData signal payload / isPilotLocked / get_demodDcComponent */
 int  fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *meta);
+/* replaces the showPeakLevel signal (fm-processor.h:293, evaluatePeakLevel fm-processor.cpp:772-798): every 961 PCM
+ * frames the reference emits (leftDb, rightDb) of the window's absolute maxima, behind a display delay line.  Copies
+ * the (leftDb, rightDb) pairs of the windows that closed since the last fetch, oldest first, at most `capacity` pairs
+ * (the maxima are taken on the GPU next to the audio FIR; dB conversion and delay line run here).  The library keeps
+ * the last 256 windows (5 s) per channel. */
+int  fmx_get_peaks(fmx_handle h, int32_t channel, float *lr_db, int32_t capacity, int32_t *n_events);
 /* replaces the hf/lf/iq scope ring feeds: copies the most recent n samples of a tap
  * (n * 1 or 2 floats) to host memory; n <= samples produced by the last call */
 int  fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap_id, float *dst, int64_t n);

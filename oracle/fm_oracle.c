@@ -770,6 +770,9 @@ struct fmo_chain {
     c32 lastAudioSample, RfDC;
     int32_t suppressMax, suppressCnt;
     int32_t peakCnt, peakMax; float absPeakL, absPeakR, peakLdb, peakRdb;
+    c32 *delayBuf; uint32_t delaySize, delayIdx;          /* DelayLine<DSPCOMPLEX> fm-processor.h:54-75 */
+    float *peakEv; long peakEvN, peakEvCap;               /* what showPeakLevel was emitted with */
+    struct { uint32_t periodCounter, remain; float curPhase, phaseIncr; } tt;   /* TestTone fm-processor.h:241-249 */
     int32_t myCount;
     fmo_meta meta;
     resampler rs; c32 rsIn[192]; int rsInp;
@@ -793,6 +796,7 @@ void fmo_config_defaults(fmo_config *c) {
     c->dcRemove = 1; c->autoMono = 1; c->pssActive = 1; c->rdsMode = 0; c->squelchMode = 0; c->squelchValue = 0;
 }
 
+static void delay_set_steps(fmo_chain *ch, uint32_t steps);
 static void apply_settings(fmo_chain *ch, const fmo_config *c, int initial) {
     const fmo_config old = ch->cfg;
     ch->cfg = *c;
@@ -822,7 +826,9 @@ static void apply_settings(fmo_chain *ch, const fmo_config *c, int initial) {
     ch->Lgain = c->attL; ch->Rgain = c->attR;
     /* setDCRemove :922-925 zeroes RfDC whenever called; we call it only on change */
     if (!initial && c->dcRemove != old.dcRemove) ch->RfDC = C(0, 0);
-    /* setPSSMode / setAutoMonoMode / setfmMode / setSoundMode / set_localOscillator: plain stores */
+    /* setDispDelay :935-937 */
+    if ((initial && c->dispDelay > 0) || (!initial && c->dispDelay != old.dispDelay)) delay_set_steps(ch, (uint32_t)c->dispDelay);
+    /* setPSSMode / setAutoMonoMode / setfmMode / setSoundMode / set_localOscillator / setTestTone: plain stores */
     fmo_demod_set_decoder(ch->demod, c->decoder);
 }
 
@@ -855,6 +861,7 @@ fmo_chain *fmo_chain_new(const fmo_config *c) {
     ch->suppressMax = c->workingRate / 2; ch->suppressCnt = ch->suppressMax;
     ch->RfDC = C(0, 0);
     ch->peakMax = c->workingRate / 50;
+    delay_set_steps(ch, 0);
     ch->fmBandwidth = (int32_t)(0.95 * fmRate);
     /* ctor :148 : inputFilter.setLowPass(0.95*fmRate/2, inputRate) -- f64 -> int32 arg */
     fmo_fftfilter_set_lowpass(ch->inputFilter, (int32_t)(0.95 * fmRate / 2), inputRate);
@@ -883,6 +890,7 @@ void fmo_chain_free(fmo_chain *ch) {
     fmo_fftfilter_free(ch->audioFilter); fmo_fftfilter_free(ch->inputFilter);
     fmo_fftfilter_free(ch->rdsBand); fmo_fftfilter_free(ch->rdsHilbert);
     fmo_pilot_free(ch->pilot); fmo_pss_free(ch->pss); fmo_demod_free(ch->demod);
+    free(ch->delayBuf); free(ch->peakEv);
     free(ch->rdsPhaseBuffer); free(ch->rdsBits); free(ch->pending); free(ch);
 }
 
@@ -941,8 +949,40 @@ static void process_signal_with_rds(fmo_chain *ch, float demod, c32 *audioOut, c
     }
 }
 
+static void delay_set_steps(fmo_chain *ch, uint32_t steps) {
+    /* DelayLine::set_delay_steps fm-processor.h:60-63: vector::resize keeps what is there, new entries = (-40, -40) */
+    ch->delayBuf = (c32 *)realloc(ch->delayBuf, sizeof(c32) * (steps + 1));
+    for (uint32_t i = ch->delaySize; i < steps + 1; i++) ch->delayBuf[i] = C(-40.0f, -40.0f);
+    ch->delaySize = steps + 1; ch->delayIdx = 0;
+}
+
+static void insert_test_tone(fmo_chain *ch, c32 *s) {
+    /* fm-processor.cpp:800-823; `sin` of a float under `using namespace std` (fm-constants.h:66) = sinf */
+    const float toneFreqHz = 1000.0f, level = 0.9f;
+    const float TimePeriod = 2.0f, SignalDuration = 0.025f;           /* fm-processor.h:243-244 */
+    if (!ch->cfg.testTone) return;
+    *s = cscale(*s, 1.0f - level);
+    if (ch->tt.remain > 0) {
+        ch->tt.remain--;
+        ch->tt.curPhase += ch->tt.phaseIncr;
+        ch->tt.curPhase = fmo_pi_constrain(ch->tt.curPhase);
+        const float smpl = sinf(ch->tt.curPhase);
+        s->re = s->re + level * smpl; s->im = s->im + level * smpl;
+    } else if ((float)(++ch->tt.periodCounter) > (float)ch->cfg.workingRate * TimePeriod) {
+        ch->tt.periodCounter = 0;
+        ch->tt.remain = (uint32_t)((float)ch->cfg.workingRate * SignalDuration);
+        ch->tt.curPhase = 0.0f;
+        ch->tt.phaseIncr = (float)(2 * M_PI / ch->cfg.workingRate * toneFreqHz);
+    }
+}
+
+void fmo_test_tone_burst(int32_t workingRate, float *dst, long n) {
+    float ph = 0.0f; const float inc = (float)(2 * M_PI / workingRate * 1000.0f);
+    for (long i = 0; i < n; i++) { ph += inc; ph = fmo_pi_constrain(ph); dst[i] = sinf(ph); }
+}
+
 static void evaluate_peak(fmo_chain *ch, c32 s) {
-    /* fm-processor.cpp:772-798 (delay line of 0 steps -> returns the value just set) */
+    /* fm-processor.cpp:772-798 */
     float aL = fabsf(s.re), aR = fabsf(s.im);
     if (aL > ch->absPeakL) ch->absPeakL = aL;
     if (aR > ch->absPeakR) ch->absPeakR = aR;
@@ -951,7 +991,16 @@ static void evaluate_peak(fmo_chain *ch, c32 s) {
         ch->peakCnt = 0;
         ch->peakLdb = (ch->absPeakL > 0.0f ? 20.0f * log10f(ch->absPeakL) : -40.0f);
         ch->peakRdb = (ch->absPeakR > 0.0f ? 20.0f * log10f(ch->absPeakR) : -40.0f);
-        ch->meta.peakLeftDb = ch->peakLdb; ch->meta.peakRightDb = ch->peakRdb;
+        /* delayLine.get_set_value fm-processor.h:65-69 */
+        ch->delayBuf[ch->delayIdx] = C(ch->peakLdb, ch->peakRdb);
+        ch->delayIdx = (ch->delayIdx + 1) % ch->delaySize;
+        const c32 delayed = ch->delayBuf[ch->delayIdx];
+        ch->meta.peakLeftDb = delayed.re; ch->meta.peakRightDb = delayed.im;
+        if (ch->peakEvN == ch->peakEvCap) {
+            ch->peakEvCap = ch->peakEvCap ? 2 * ch->peakEvCap : 256;
+            ch->peakEv = (float *)realloc(ch->peakEv, sizeof(float) * 2 * (size_t)ch->peakEvCap);
+        }
+        ch->peakEv[2 * ch->peakEvN] = delayed.re; ch->peakEv[2 * ch->peakEvN + 1] = delayed.im; ch->peakEvN++;
         ch->absPeakL = 0.0f; ch->absPeakR = 0.0f;
     }
 }
@@ -1059,6 +1108,7 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
                     p = cscale(p, ((float)ch->suppressMax - (float)ch->suppressCnt) / (float)ch->suppressMax);
                     --ch->suppressCnt;
                 }
+                insert_test_tone(ch, &p);
                 evaluate_peak(ch, p);
                 if (nout < cap) { pcm[2 * nout] = p.re; pcm[2 * nout + 1] = p.im; }
                 nout++; ch->pcmCount++;
@@ -1102,6 +1152,11 @@ long fmo_chain_process(fmo_chain *ch, const float *iq, long n, float *pcm, long 
 void fmo_chain_meta(const fmo_chain *ch, fmo_meta *m) {
     *m = ch->meta; m->fmSamples = ch->fmCount; m->pcmFrames = ch->pcmCount;
     m->squelchActive = ch->sqSuppress; m->pad_ = 0;
+}
+long fmo_chain_peaks(const fmo_chain *ch, float *lr_db, long cap) {
+    long n = ch->peakEvN < cap ? ch->peakEvN : cap;
+    if (lr_db && n > 0) memcpy(lr_db, ch->peakEv, sizeof(float) * 2 * (size_t)n);
+    return ch->peakEvN;
 }
 long fmo_chain_rds_bits(const fmo_chain *ch, uint8_t *bits, long cap) {
     long n = ch->rdsBitCount < cap ? ch->rdsBitCount : cap;

@@ -166,6 +166,8 @@ typedef struct {
     int32_t rdsMode;          /* 0 off, 1..3 = RDS_1..3 (only 2 is restated) */
     int32_t squelchMode;      /* 0 OFF, 2 LSQ (level squelch; NSQ = 1 is not restated)   fm-processor.cpp:499-509 */
     int32_t squelchValue;     /* set_squelchValue 0..100: applied at a block start when it differs from the last one (:410-413) */
+    int32_t testTone;         /* setTestTone (fm-processor.cpp:931-933): 1 kHz bursts of 25 ms every 2 s mixed into the PCM (:800-823) */
+    int32_t dispDelay;        /* setDispDelay (:935-937): steps of the peak-level delay line */
 } fmo_config;
 
 void fmo_config_defaults(fmo_config *);   /* GUI-effective defaults, SURVEY 3.3 */
@@ -201,6 +203,11 @@ long  fmo_chain_tap_count(const fmo_chain *, int tap);   /* floats written */
 /* feed n complex samples (interleaved I,Q); returns PCM frames written (interleaved L,R) */
 long  fmo_chain_process(fmo_chain *, const float *iq, long n, float *pcm, long pcm_cap_frames);
 void  fmo_chain_meta(const fmo_chain *, fmo_meta *);
+/* showPeakLevel events so far (fm-processor.cpp:772-798): (leftDb, rightDb) pairs as emitted, i.e. behind the
+ * delay line; copies up to cap events, returns the total count */
+long  fmo_chain_peaks(const fmo_chain *, float *lr_db, long cap_events);
+/* the 1200 samples of one test-tone burst (fm-processor.cpp:808-813,818-821): the same for every burst */
+void  fmo_test_tone_burst(int32_t workingRate, float *dst, long n);
 /* RDS bits produced so far (rdsMode==2): copies up to cap, returns total count */
 long  fmo_chain_rds_bits(const fmo_chain *, uint8_t *bits, long cap);
 

@@ -40,6 +40,10 @@ struct ChanUser {
     float   volume_db = 0.f;
     int32_t balance = 0, panorama = 100;
     int32_t squelch_value = 0, squelch_old = 0, squelch_level = 1;   // fm-processor.cpp:194-195; mySquelch (1, ...) :87
+    // peak meter, host half: DelayLine<DSPCOMPLEX> (fm-processor.h:54-75) over the dB pairs, windows already fetched
+    std::vector<float2> delay = std::vector<float2>(1, make_float2(-40.0f, -40.0f));
+    uint32_t delay_idx = 0;
+    int32_t pk_read = 0;
 };
 
 struct ProfRec { hipEvent_t e[4]; int64_t in_samples, ch_samples; int n; };
@@ -86,7 +90,7 @@ struct fmx_handle_s {
     std::vector<int32_t> rds_read_dec;      // ... and by fmx_rds_decode
     std::vector<fmx::RdsGroupDecoderHost> rds_dec;
     int64_t last_m0 = 0, last_m1 = 0;       // 24 kS/s outputs of the last call
-    std::vector<void *> rds_ptrs;
+    std::vector<void *> rds_ptrs, tail_ptrs;
 };
 
 namespace {
@@ -631,6 +635,26 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     }
     HIPCHK(hipMalloc(&h->B.state, sizeof(ChanState) * C));
     HIPCHK(hipMalloc(&h->d_params, sizeof(ChanParams) * C));
+    {   // PCM tail: one test-tone burst (fm-processor.cpp:808-813,818-821: float phase += float incr, PI_Constrain, sinf)
+        // and the peak meter's per-tile maxima / window ring
+        std::vector<float> tone((size_t)TT_BURST);
+        float ph = 0.0f; const float inc = (float)(2 * design::kPi / cfg->workingRate * 1000.0f);
+        for (int i = 0; i < TT_BURST; i++) {
+            ph += inc;
+            if (!(0 <= ph && ph < 2 * design::kPi)) ph = (float)std::fmod((double)ph, 2 * design::kPi);   // PI_Constrain fm-constants.h:149-153 (ph > 0 here)
+            tone[i] = std::sin(ph);
+        }
+        float *d_tone = nullptr;
+        HIPCHK(hipMalloc(&d_tone, sizeof(float) * TT_BURST));
+        HIPCHK(hipMemcpy(d_tone, tone.data(), sizeof(float) * TT_BURST, hipMemcpyHostToDevice));
+        h->B.tone = d_tone; h->tail_ptrs.push_back(d_tone);
+        h->B.pk_tiles = (int32_t)((cfg->max_block / 48 + 96) / C_TILE + 2);
+        HIPCHK(hipMalloc(&h->B.pk_part, sizeof(float4) * C * h->B.pk_tiles));
+        HIPCHK(hipMalloc(&h->B.pk_ring, sizeof(float2) * C * PK_RING));
+        HIPCHK(hipMemset(h->B.pk_part, 0, sizeof(float4) * C * h->B.pk_tiles));
+        HIPCHK(hipMemset(h->B.pk_ring, 0, sizeof(float2) * C * PK_RING));
+        h->tail_ptrs.push_back(h->B.pk_part); h->tail_ptrs.push_back(h->B.pk_ring);
+    }
     HIPCHK(hipMemset(h->B.hist, 0, sizeof(float2) * C * DECIM * A_HIST_COLS));
     HIPCHK(hipMemset(h->B.zring, 0, sizeof(float2) * C * h->ring));
     HIPCHK(hipMemset(h->B.sring, 0, sizeof(float2) * C * h->sring));
@@ -659,6 +683,7 @@ int fmx_destroy(fmx_handle h) {
                      h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
+    for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->evs) (void)hipEventDestroy(e);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto &ss : h->s_side) if (ss) (void)hipStreamDestroy(ss);
@@ -697,7 +722,8 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         if (iv == 1) return fail(FMX_E_UNSUPPORTED, "the noise squelch (two order-20 IIR filters) is not built; 0 = off, 2 = level squelch");
         if (iv != 0 && iv != 2) return fail(FMX_E_INVALID, "squelch mode must be 0, 1 or 2"); break;
     case FMX_P_SQUELCH_VALUE: if (iv < 0 || iv > 100) return fail(FMX_E_INVALID, "squelch value must be 0..100"); break;
-    case FMX_P_TEST_TONE: if (iv != 0) return fail(FMX_E_UNSUPPORTED, "test tone is a GUI aid, not built"); break;
+    case FMX_P_DISP_DELAY: if (iv < 0 || iv > 100000) return fail(FMX_E_INVALID, "display delay must be 0..100000 steps"); break;
+    case FMX_P_TEST_TONE:
     case FMX_P_VOLUME_DB: case FMX_P_LF_CUTOFF: case FMX_P_ATTENUATION_L: case FMX_P_ATTENUATION_R:
     case FMX_P_AUTO_MONO: case FMX_P_PSS: case FMX_P_DC_REMOVE:
     case FMX_A_TRIGGER_FREQUENCY_CHANGE: case FMX_A_RESTART_PSS: case FMX_A_RESET_RDS: break;
@@ -732,6 +758,9 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         case FMX_P_PSS: p.pss_active = iv != 0; break;
         case FMX_P_SQUELCH_MODE: p.squelch_mode = iv; break;
         case FMX_P_SQUELCH_VALUE: u.squelch_value = iv; break;
+        case FMX_P_TEST_TONE: p.test_tone = iv != 0; break;
+        case FMX_P_DISP_DELAY:                       // DelayLine::set_delay_steps fm-processor.h:60-63: resize keeps what is there
+            u.delay.resize((size_t)iv + 1, make_float2(-40.0f, -40.0f)); u.delay_idx = 0; break;
         case FMX_P_DC_REMOVE: p.dc_remove = iv != 0; p.actions |= ACT_DC_RESET; break;
         case FMX_A_TRIGGER_FREQUENCY_CHANGE: p.actions |= ACT_TRIGGER_FREQ; break;
         case FMX_A_RESTART_PSS: p.actions |= ACT_RESTART_PSS; break;
@@ -827,6 +856,36 @@ int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
     m->live_lock_strength = (h->params[channel].fm_mode != 2) ? st.pil_lock : 0.f;
     m->live_dc_if = st.fm_afc; m->squelch_active = (h->params[channel].squelch_mode == 2) ? st.sq_suppress : 0;
     m->fm_samples = h->g_total / DECIM; m->pcm_frames = 48 * ((h->g_total / DECIM) / 192);
+    return FMX_OK;
+}
+
+int fmx_get_peaks(fmx_handle h, int32_t channel, float *lr_db, int32_t capacity, int32_t *n_events) {
+    if (!h || !n_events || channel < 0 || channel >= h->channels || capacity < 0 || (capacity > 0 && !lr_db))
+        return fail(FMX_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    ChanState st;
+    HIPCHK(hipMemcpy(&st, h->B.state + channel, sizeof(st), hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lk(h->mtx);
+    ChanUser &u = h->user[channel];
+    if (st.pk_events - u.pk_read > PK_RING) u.pk_read = st.pk_events - PK_RING;      // the caller fell behind: the oldest windows are gone
+    const int avail = st.pk_events - u.pk_read;
+    const int take = std::min(avail, (int)capacity);
+    if (take > 0) {
+        std::vector<float2> ring((size_t)PK_RING);
+        HIPCHK(hipMemcpy(ring.data(), h->B.pk_ring + (size_t)channel * PK_RING, sizeof(float2) * PK_RING, hipMemcpyDeviceToHost));
+        for (int k = 0; k < take; k++) {
+            const float2 pk = ring[(size_t)((u.pk_read + k) & (PK_RING - 1))];
+            // fm-processor.cpp:785-794: float log10 (std::log10 of a float), -40 dB for silence, then the display delay line
+            const float ldb = pk.x > 0.0f ? 20.0f * std::log10(pk.x) : -40.0f;
+            const float rdb = pk.y > 0.0f ? 20.0f * std::log10(pk.y) : -40.0f;
+            u.delay[u.delay_idx] = make_float2(ldb, rdb);
+            u.delay_idx = (u.delay_idx + 1) % (uint32_t)u.delay.size();
+            lr_db[2 * k] = u.delay[u.delay_idx].x; lr_db[2 * k + 1] = u.delay[u.delay_idx].y;
+        }
+        u.pk_read += take;
+    }
+    *n_events = take;
     return FMX_OK;
 }
 

@@ -4,6 +4,7 @@
 //   fmAudioFilter (8192-pt overlap-add, 756 taps)  fm-processor.cpp:76,589-591, fft-filters.cpp:132-163
 //   newConverter audioDecimator (192k -> 48k)      fm-processor.cpp:380,633-634, newconverter.cpp:55-80
 //   start-up fade                                  fm-processor.cpp:636-642
+//   insertTestTone, evaluatePeakLevel              fm-processor.cpp:800-823, 772-798
 //
 // MI355X design: the audio low-pass and the decimate-by-4 resampler are both LTI, so they are
 // folded on the host into ONE polyphase FIR (756 + 128 - 1 = 883 taps) that is only evaluated at
@@ -95,8 +96,15 @@ __global__ __launch_bounds__(64) void audio_kernel(DeviceTables T, DeviceBuffers
     // the output of the folded FIR, so that a volume/balance change takes effect at the call boundary as in
     // the reference (it sits behind the audio low-pass there) rather than one filter latency late.
     const float gl = P.volume * P.left_ch, gr = P.volume * P.right_ch;
-    const int64_t F = B.state[ch].fade_start_frame;
+    const ChanState *__restrict__ st = &B.state[ch];
+    const int64_t F = st->fade_start_frame;
     const int Max = 24000;                               // workingRate / 2
+    // peak meter: frame i of the call is frame cnt0 + i of the window that was open at the call's start; a 256-frame tile
+    // meets at most two 961-frame windows: maxima of the tile's first window in pk[0], pk[1], of its second in pk[2], pk[3]
+    const int cnt0 = st->pk_cnt, tt0 = st->tt_pos;
+    const int i_tile = (int)(m0 - G.M0);
+    const int w_first = (cnt0 + i_tile) / PK_WIN;
+    float pk[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < FPT; j++) {
         const int64_t m = m0 + c0 + j;
@@ -109,8 +117,58 @@ __global__ __launch_bounds__(64) void audio_kernel(DeviceTables T, DeviceBuffers
             const float f = ((float)Max - cnt) / (float)Max;
             al *= f; ar *= f;
         }
+        const int i = (int)(m - G.M0);
+        if (P.test_tone) {
+            // insertTestTone fm-processor.cpp:800-823.  The counters make a fixed cycle -- 96001 attenuated frames, then a
+            // 1200-frame burst whose phase restarts at 0, so every burst is the same 1200 values (tabulated on the host
+            // with the reference's own recurrence); the cycle position only advances while the tone is enabled.
+#pragma clang fp contract(off)
+            const float level = 0.9f;
+            al = al * (1.0f - level); ar = ar * (1.0f - level);
+            const int pos = (int)(((int64_t)tt0 + i) % TT_CYCLE);
+            if (pos >= TT_SILENT) {
+                const float smpl = level * B.tone[pos - TT_SILENT];
+                al = al + smpl; ar = ar + smpl;
+            }
+        }
+        const bool second = (cnt0 + i) / PK_WIN != w_first;
+        pk[second ? 2 : 0] = fmaxf(pk[second ? 2 : 0], fabsf(al));
+        pk[second ? 3 : 1] = fmaxf(pk[second ? 3 : 1], fabsf(ar));
         pcm[(size_t)ch * G.pcm_stride + (m - G.M0)] = make_float2(al, ar);
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) pk[q] = fmaxf(pk[q], __shfl_xor(pk[q], d));
+    if (t == 0) B.pk_part[(size_t)ch * B.pk_tiles + blockIdx.x] = make_float4(pk[0], pk[1], pk[2], pk[3]);
+}
+
+// PCM tail bookkeeping, one thread per channel, after audio_kernel: folds the tiles' maxima into the open window, writes
+// the maxima of every window that closed in this call to the channel's ring (the host turns them into dB and runs the
+// display delay line: fmx_get_peaks), advances the test-tone cycle position.
+__global__ __launch_bounds__(64) void pcm_tail_kernel(DeviceBuffers B, CallGeom G, int channels) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= channels) return;
+    ChanState *st = &B.state[ch];
+    const int frames = (int)(G.M1 - G.M0);
+    const int cnt0 = st->pk_cnt;
+    float L = st->pk_l, R = st->pk_r;
+    int ev = st->pk_events;
+    const int tiles = (frames + C_TILE - 1) / C_TILE;
+    for (int tile = 0; tile < tiles; tile++) {
+        const int i0 = tile * C_TILE, nfr = min(C_TILE, frames - i0);
+        const float4 p = B.pk_part[(size_t)ch * B.pk_tiles + tile];
+        const int w_first = (cnt0 + i0) / PK_WIN;
+        const int to_end = (w_first + 1) * PK_WIN - (cnt0 + i0);          // frames of the tile's first window from i0 on
+        L = fmaxf(L, p.x); R = fmaxf(R, p.y);
+        if (to_end <= nfr) {                                              // the window closes inside this tile
+            B.pk_ring[(size_t)ch * PK_RING + (ev & (PK_RING - 1))] = make_float2(L, R);
+            ev++;
+            L = p.z; R = p.w;
+        }
+    }
+    st->pk_l = L; st->pk_r = R; st->pk_events = ev; st->pk_cnt = (cnt0 + frames) % PK_WIN;
+    if (B.params[ch].test_tone) st->tt_pos = (int)(((int64_t)st->tt_pos + frames) % TT_CYCLE);
 }
 
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,
@@ -119,6 +177,7 @@ void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
     if (frames <= 0) return;
     const int tiles = (int)((frames + C_TILE - 1) / C_TILE);
     hipLaunchKernelGGL(audio_kernel, dim3(tiles, channels), dim3(64), 0, s, T, B, G, pcm);
+    hipLaunchKernelGGL(pcm_tail_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, B, G, channels);
 }
 
 }  // namespace fmx

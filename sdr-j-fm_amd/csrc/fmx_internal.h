@@ -21,6 +21,11 @@ constexpr int AUDIO_DELAY = 8192 - 756;
 constexpr int C_MAX_TAPS = AUDIO_TAPS + RS_TAPS - 1;   // 883
 constexpr int C_TAPS_STRIDE = 896;     // padded
 constexpr int C_TILE = 256;            // PCM frames per audio-FIR tile
+constexpr int TT_SILENT = 96001;       // ++TimePeriodCounter > workingRate * 2.0f fires on the 96001st silent frame (fm-processor.cpp:816-817)
+constexpr int TT_BURST = 1200;         // workingRate * 0.025f (:819)
+constexpr int TT_CYCLE = TT_SILENT + TT_BURST;
+constexpr int PK_WIN = 961;            // ++peakLevelCurSampleCnt > workingRate / 50 (:781-782, :142)
+constexpr int PK_RING = 256;           // finished windows kept per channel (5 s)
 constexpr int SINCOS_N = 192000;
 constexpr int ATAN_N = 8192;
 constexpr int ARCSINE_N = 4 * 8192;
@@ -53,6 +58,8 @@ struct ChanParams {
     int32_t actions;     // one-shot ACT_* bits consumed by the kernels of the next call
     int32_t squelch_mode;   // 0 off, 2 level squelch (set_squelchMode)
     float   squelch_thr;    // levelSquelchThreshold squelchClass.cpp:35
+    int32_t test_tone;      // setTestTone fm-processor.cpp:931-933
+    int32_t pad1;
 };
 enum { ACT_TRIGGER_FREQ = 1, ACT_RESTART_PSS = 2, ACT_DC_RESET = 4 };
 
@@ -85,6 +92,12 @@ struct ChanState {
     int32_t meta_pss_state, meta_locked;
     // level squelch (squelchClass.cpp:20-28)
     int32_t sq_count, sq_suppress;
+    // test tone (fm-processor.cpp:800-823): position in the 97201-frame cycle (96001 silent frames, then the 1200-frame burst)
+    int32_t tt_pos;
+    // peak meter (fm-processor.cpp:772-798): frames in the current 961-frame window, its maxima so far, windows finished so far
+    int32_t pk_cnt;
+    float   pk_l, pk_r;
+    int32_t pk_events, pad1;
 };
 
 // Work arrays of stage B (w_*): element (row r, channel ch) lives at ((r / 16) * pitch + ch) * 16 + r % 16 -- tiles of 16
@@ -151,6 +164,11 @@ struct DeviceBuffers {
     float   *w_pdp;      // pilotDelayPSS as used by each sample
     int32_t *w_tag;      // -2 mono branch, -1 stereo without PSS, >= 0 PSS call index within the chunk
     float2  *w_x;        // matrix output, then de-emphasised + gained stereo (in place)
+    // PCM tail (fmx_audio.hip)
+    const float *tone;   // [TT_BURST] one test-tone burst (the same for every burst: phase restarts at 0)
+    float4  *pk_part;    // [channels][pk_tiles] per audio tile: max |L|, |R| of the frames of the tile's first window, then of its second
+    float2  *pk_ring;    // [channels][PK_RING] maxima of the finished windows
+    int32_t pk_tiles, pad_;
 };
 
 // ---- RDS path (fmx_rds.hip) -------------------------------------------------------------------

@@ -19,6 +19,7 @@ FMX_OK, FMX_E_INVALID, FMX_E_UNSUPPORTED, FMX_E_NO_DEVICE, FMX_E_HIP, FMX_E_NOME
 P_FM_MODE, P_FM_DECODER, P_SOUND_MODE, P_STEREO_PANORAMA, P_SOUND_BALANCE, P_DEEMPHASIS = 1, 2, 3, 4, 5, 6
 P_VOLUME_DB, P_LF_CUTOFF, P_BANDWIDTH, P_ATTENUATION_L, P_ATTENUATION_R, P_RDS_MODE = 7, 8, 9, 10, 11, 12
 P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE, P_SQUELCH_VALUE = 13, 14, 15, 16, 17, 18, 19
+P_DISP_DELAY = 20
 A_TRIGGER_FREQUENCY_CHANGE, A_RESTART_PSS, A_RESET_RDS = 100, 101, 102
 
 TAP_FM_IQ, TAP_DEMOD, TAP_LR_RAW, TAP_PRE_RESAMPLER, TAP_RDS_IQ = 0, 1, 2, 3, 4
@@ -27,7 +28,7 @@ IQ_F32, IQ_U8, IQ_S8, IQ_S16 = 0, 1, 2, 3
 EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
-    "fmx_get_meta", "fmx_get_tap",
+    "fmx_get_meta", "fmx_get_tap", "fmx_get_peaks",
     "fmx_rds_bits", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
@@ -108,6 +109,8 @@ def load_library(path=None):
     L.fmx_get_meta.argtypes = [vp, i32, C.POINTER(FmxMeta)]
     L.fmx_get_tap.restype = C.c_int
     L.fmx_get_tap.argtypes = [vp, i32, i32, f32p, i64]
+    L.fmx_get_peaks.restype = C.c_int
+    L.fmx_get_peaks.argtypes = [vp, i32, f32p, i32, C.POINTER(i32)]
     L.fmx_rds_decode.restype = C.c_int
     L.fmx_rds_decode.argtypes = [vp, i32, C.POINTER(FmxRdsInfo)]
     L.fmx_rds_decode_bits.restype = C.c_int
@@ -229,6 +232,13 @@ class Fmx:
         self._check(self.L.fmx_get_tap(self.h, channel, tap_id, out.ctypes.data_as(C.POINTER(C.c_float)), n))
         return out[:, 0] if width == 1 else out
 
+    def peaks(self, channel=0, capacity=256):
+        """showPeakLevel events since the last fetch as [events, 2] (leftDb, rightDb)."""
+        out = np.zeros((max(capacity, 1), 2), np.float32)
+        n = C.c_int32()
+        self._check(self.L.fmx_get_peaks(self.h, channel, out.ctypes.data_as(C.POINTER(C.c_float)), capacity, C.byref(n)))
+        return out[:n.value].copy()
+
     def rds_bits(self, channel=0, capacity=8192):
         buf = (C.c_uint8 * capacity)()
         n = C.c_int32()
@@ -316,6 +326,7 @@ class FmProcessor:
     def setPSSMode(self, b): self._set(P_PSS, 1 if b else 0)
     def setDCRemove(self, b): self._set(P_DC_REMOVE, 1 if b else 0)
     def setTestTone(self, b): self._set(P_TEST_TONE, 1 if b else 0)
+    def setDispDelay(self, steps): self._set(P_DISP_DELAY, steps)
 
     def isPilotLocked(self):
         m = self.fmx.meta(self.channel)

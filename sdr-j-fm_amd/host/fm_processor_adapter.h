@@ -96,6 +96,8 @@ public:
     void setPSSMode(bool b) { set(FMX_P_PSS, b); }
     void setDCRemove(bool b) { set(FMX_P_DC_REMOVE, b); }
     void setTestTone(bool b) { set(FMX_P_TEST_TONE, b); }
+    void setDispDelay(int steps) { set(FMX_P_DISP_DELAY, steps); }       // fm-processor.cpp:935-937
+    void set_squelchValue(int v) { set(FMX_P_SQUELCH_VALUE, v); }        // :213-215
 
     bool isPilotLocked(float &oLockStrength) {                             // fm-processor.cpp:870-880
         fmx_meta m{};
@@ -133,6 +135,15 @@ public:
         out.PssPhaseChange = m.PssPhaseChange; out.PssState = (SMetaData::EPssState)m.PssState;
         out.PilotPllLockStrength = m.PilotPllLockStrength; out.PilotPllLocked = m.PilotPllLocked != 0;
         return true;
+    }
+
+    // what the reference emits as showPeakLevel (leftDb, rightDb) every 961 PCM frames (fm-processor.cpp:772-798):
+    // calls `emit_fn(leftDb, rightDb)` once per window that closed since the last poll, oldest first
+    template <class F> int poll_peaks(F emit_fn) {
+        float lr[2 * 64]; int32_t n = 0;
+        if (fmx_get_peaks(h, 0, lr, 64, &n) != FMX_OK) return 0;
+        for (int32_t k = 0; k < n; k++) emit_fn(lr[2 * k], lr[2 * k + 1]);
+        return n;
     }
 
     static constexpr int32_t bufferSize = 2 * 8192;                        // fm-processor.cpp:374

@@ -36,7 +36,7 @@ class FmoConfig(C.Structure):
         ("volumeDb", C.c_float), ("useCtorVolume", C.c_int32), ("balance", C.c_int32), ("panorama", C.c_int32),
         ("attL", C.c_float), ("attR", C.c_float), ("loFrequency", C.c_int32),
         ("dcRemove", C.c_int32), ("autoMono", C.c_int32), ("pssActive", C.c_int32), ("rdsMode", C.c_int32),
-        ("squelchMode", C.c_int32), ("squelchValue", C.c_int32),
+        ("squelchMode", C.c_int32), ("squelchValue", C.c_int32), ("testTone", C.c_int32), ("dispDelay", C.c_int32),
     ]
 
 
@@ -147,6 +147,8 @@ def oracle():
         "fmo_chain_process": (lng, [vp, c_float_p, lng, c_float_p, lng]),
         "fmo_chain_meta": (None, [vp, C.POINTER(FmoMeta)]),
         "fmo_chain_rds_bits": (lng, [vp, c_u8_p, lng]),
+        "fmo_chain_peaks": (lng, [vp, c_float_p, lng]),
+        "fmo_test_tone_burst": (None, [i32, c_float_p, lng]),
         "fmo_siggen_new": (vp, [C.POINTER(FmoSiggenConfig)]),
         "fmo_siggen_free": (None, [vp]),
         "fmo_siggen_run": (None, [vp, c_float_p, lng]),
@@ -355,6 +357,13 @@ class OracleChain:
         m = FmoMeta()
         self.L.fmo_chain_meta(self.h, C.byref(m))
         return m
+
+    def peaks(self):
+        """showPeakLevel events so far as [events, 2] (leftDb, rightDb)."""
+        n = self.L.fmo_chain_peaks(self.h, None, 0)
+        a = np.zeros((max(n, 1), 2), np.float32)
+        self.L.fmo_chain_peaks(self.h, fptr(a), n)
+        return a[:n]
 
     def rds_bits(self):
         n = self.L.fmo_chain_rds_bits(self.h, None, 0)

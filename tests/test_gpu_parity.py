@@ -435,6 +435,57 @@ def test_large_batch_is_self_consistent(fmx_amd, ol):
     assert bad == [], f"{len(bad)} channels differ from channel 0, first {bad[:8]}"
 
 
+def test_test_tone_and_peak_meter(fmx_amd, ol):
+    """PCM tail: insertTestTone (fm-processor.cpp:800-823) and evaluatePeakLevel (:772-798) with the
+    display delay line.  Block lengths that are not multiples of the 961-frame window or the 256-frame audio tile; the tone
+    is switched on for channel 1 only, off again, and on again (the cycle position is frozen while it is off)."""
+    block = 16384 * 5
+    nb = 62                                                   # 2.2 s: the first burst starts at frame 96001
+    iq = ol.synth_iq(block * nb)
+    f = fmx_amd.Fmx(2, streams=1, stream_of_channel=[0, 0], max_block=block)
+    gui_defaults(f)
+    f.set_param(M.P_DISP_DELAY, 3, channel=1)
+    chains = [ol.OracleChain(inputFilterBw=165000), ol.OracleChain(inputFilterBw=165000, dispDelay=3)]
+    pcm_g, pcm_o, pk_g = [], [[], []], [[], []]
+    for b in range(nb):
+        tone = 0 if b in (20, 21, 22) else 1
+        f.set_param(M.P_TEST_TONE, tone, channel=1)
+        chains[1].configure(testTone=tone)
+        x = iq[b * block:(b + 1) * block]
+        pcm_g.append(f.process_host(x))
+        for c in range(2):
+            pcm_o[c].append(chains[c].process(x))
+        if b % 7 == 3:                                        # fetch now and then: several windows per fetch
+            for c in range(2):
+                pk_g[c].append(f.peaks(c))
+    pcm_g = np.concatenate(pcm_g, axis=1)
+    for c in range(2):
+        pk_g[c].append(f.peaks(c))
+        po = np.concatenate(pcm_o[c])
+        e = rms(pcm_g[c] - po)
+        pk, pko = np.concatenate(pk_g[c]), chains[c].peaks()
+        print(f"\n[tone/peaks ch{c}] pcm rms {e:.3e}; {len(pk)} peak events, max |dB diff| {np.max(np.abs(pk - pko)):.2e}")
+        assert e <= PCM_RMS_TOL
+        assert pk.shape == pko.shape and len(pk) == pcm_g.shape[1] // 961
+        # the maxima are of PCM that differs by ~1e-7.  The first windows are the filters' latency: exact zeros out of the
+        # GPU's direct-form FIRs (-40 dB, the reference's silence mark), FFT round-off (-190 dB) out of the overlap-add
+        # filters -- compared only where there is programme
+        loud = pko > -60
+        assert loud.sum() > 80 and np.max(np.abs(pk - pko)[loud]) < 1e-3
+        nd = 3 if c == 1 else 0                               # the delay line's defaults come out first, in both
+        assert np.all(pk[:nd] == -40.0) and np.all(pko[:nd] == -40.0)
+    # the burst is there, at the reference's place and level: 0.9 * sin(2 pi 1000 t) for 1200 frames from frame 96001 + 3 blocks of pause
+    po1 = np.concatenate(pcm_o[1])
+    frames_per_block = np.diff([0] + [48 * ((b + 1) * block // 12 // 192) for b in range(nb)])
+    start = 96001 + int(frames_per_block[20:23].sum())
+    burst = pcm_g[1][start:start + 1200, 0] - 0.1 * pcm_g[0][start:start + 1200, 0]
+    tone = np.zeros(1200, np.float32)
+    ol.oracle().fmo_test_tone_burst(48000, ol.fptr(tone), 1200)
+    assert np.max(np.abs(burst - 0.9 * tone)) < 1e-6
+    assert np.max(np.abs(pcm_g[1][start - 5:start, 0] - 0.1 * pcm_g[0][start - 5:start, 0])) < 1e-6
+    assert rms(po1[start:start + 1200, 0]) > 0.5
+
+
 def test_error_behaviour(fmx_amd):
     f = fmx_amd.Fmx(2, max_block=16384)
     for pid, v, code in [(M.P_FM_MODE, 3, M.FMX_E_INVALID), (M.P_FM_DECODER, 0, M.FMX_E_INVALID),
