@@ -648,7 +648,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMalloc(&d_tone, sizeof(float) * TT_BURST));
         HIPCHK(hipMemcpy(d_tone, tone.data(), sizeof(float) * TT_BURST, hipMemcpyHostToDevice));
         h->B.tone = d_tone; h->tail_ptrs.push_back(d_tone);
-        h->B.pk_tiles = (int32_t)((cfg->max_block / 48 + 96) / C_TILE + 2);
+        h->B.pk_tiles = (int32_t)((cfg->max_block / 48 + 96) / C_TILE + 8);
         HIPCHK(hipMalloc(&h->B.pk_part, sizeof(float4) * C * h->B.pk_tiles));
         HIPCHK(hipMalloc(&h->B.pk_ring, sizeof(float2) * C * PK_RING));
         HIPCHK(hipMemset(h->B.pk_part, 0, sizeof(float4) * C * h->B.pk_tiles));

@@ -19,24 +19,28 @@ namespace fmx {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int CQ = C_TAPS_STRIDE / 4;                     // 224 tap columns per phase (zero padded)
-constexpr int CWC = C_TILE + CQ + 16;                     // window columns per phase
+constexpr int AW = 4;                                     // waves per workgroup: AW adjacent 256-frame tiles share one window and the taps
+constexpr int CWC = AW * C_TILE + CQ + 16;                // window columns per phase
 constexpr int FPT = 4;                                    // adjacent output frames per thread
 
-// One wave per (256-frame tile, channel).  The window lives in LDS as four decimation phases X[p][col] (entry w of the
+// One wave per (256-frame tile, channel), four adjacent tiles per workgroup (one window fill and one tap image for the four:
+// 44 KB of LDS for four waves instead of 19 KB for one, so three waves share a SIMD instead of two and one wave's fill --
+// pure memory latency -- hides under the others' FIR).  The window lives in LDS as four decimation phases X[p][col] (entry w of the
 // window = fm index fbase + w sits at X[w & 3][w >> 2]), so output frame f reads X[p][f + q] for tap 4 q + p.  A thread
 // computes FOUR adjacent frames with a sliding register window: per four taps of a phase it fetches four new (L, R)
 // columns (2 ds_read_b128) and the four taps (one broadcast ds_read_b128) and issues 16 packed FMAs -- (L, R) ride in
 // one v_pk_fma_f32 because the taps are real.
-__global__ __launch_bounds__(64) void audio_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
+__global__ __launch_bounds__(64 * AW) void audio_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
                                                    float2 *__restrict__ pcm) {
     // X[p][half][block] = the column pair (4 block + 2 half, + 1) of phase p: a thread's four new columns are one float4
     // from each half-plane, both read at a 16-byte lane stride (conflict-free ds_read_b128)
     __shared__ __attribute__((aligned(16))) float4 X[4][2][CWC / 4];
     __shared__ __attribute__((aligned(16))) float tp[4][CQ];         // taps by phase: tp[p][q] = taps[4 q + p]
     const int ch = blockIdx.y;
-    const int t = threadIdx.x;
-    const int64_t m0 = G.M0 + (int64_t)blockIdx.x * C_TILE;
-    if (m0 >= G.M1) return;
+    const int tb = threadIdx.x, t = tb & 63, wv = tb >> 6;
+    const int64_t mb = G.M0 + (int64_t)blockIdx.x * (AW * C_TILE);     // first frame of the workgroup, of this wave:
+    const int64_t m0 = mb + wv * C_TILE;
+    if (mb >= G.M1) return;
     const ChanParams P = B.params[ch];
     const AudioSet AS = T.audio_sets[P.audio_set];
     const float *__restrict__ taps = T.audio_taps + (size_t)P.audio_set * C_TAPS_STRIDE;   // reversed order, zero padded
@@ -44,23 +48,44 @@ __global__ __launch_bounds__(64) void audio_kernel(DeviceTables T, DeviceBuffers
     const int NC = AS.ntaps;
     const int NG = ((NC + 15) / 16 + 1) & ~1;               // groups of four tap columns per phase, even
     // window entry w <-> fm index fbase + w ; output frame f (0..255) reads w = 4 f + kk, kk = tap index
-    const int64_t fbase = 4 * m0 + 3 - AS.delay - (NC - 1);
-    const int nw = 4 * (C_TILE + 4 * NG + 4);
-    for (int w = t; w < nw; w += 64) {
-        const int64_t f = fbase + w;
-        float2 v = make_float2(0.f, 0.f);
-        if (f >= 0 && w < 4 * (C_TILE - 1) + NC) v = dring[f & G.dring_mask];
-        const int col = w >> 2;
-        reinterpret_cast<float2 *>(&X[w & 3][(col >> 1) & 1][col >> 2])[col & 1] = v;
+    const int64_t fbase = 4 * mb + 3 - AS.delay - (NC - 1);
+    const int nfr = (int)((G.M1 - mb) < (int64_t)(AW * C_TILE) ? (G.M1 - mb) : (int64_t)(AW * C_TILE));   // frames of this workgroup
+    const int nw = 4 * (((nfr + C_TILE - 1) / C_TILE) * C_TILE + 4 * NG + 4);
+    // window and taps fill: the loads of a batch are issued together and only then written to LDS -- one memory round trip
+    // per batch instead of one per 64 entries (a wave has nothing else to do here: the fill is pure latency)
+    constexpr int FB = 8;
+    for (int w0 = 0; w0 < nw; w0 += 64 * AW * FB) {
+        float2 v[FB];
+#pragma unroll
+        for (int k = 0; k < FB; k++) {
+            const int w = w0 + 64 * AW * k + tb;
+            const int64_t f = fbase + w;
+            v[k] = make_float2(0.f, 0.f);
+            if (w < nw && f >= 0 && w < 4 * (nfr - 1) + NC) v[k] = dring[f & G.dring_mask];
+        }
+#pragma unroll
+        for (int k = 0; k < FB; k++) {
+            const int w = w0 + 64 * AW * k + tb;
+            const int col = w >> 2;
+            if (w < nw) reinterpret_cast<float2 *>(&X[w & 3][(col >> 1) & 1][col >> 2])[col & 1] = v[k];
+        }
     }
-    for (int i = t; i < C_TAPS_STRIDE; i += 64) tp[i & 3][i >> 2] = taps[i];
+    {
+        static_assert(C_TAPS_STRIDE / 4 <= 64 * AW, "one float4 of taps per thread");
+        const int i4 = tb;                                                   // float4 index: taps 4 i4 .. 4 i4 + 3 = column i4 of phases 0..3
+        if (i4 < C_TAPS_STRIDE / 4) {
+            const float4 tv = reinterpret_cast<const float4 *>(taps)[i4];
+            tp[0][i4] = tv.x; tp[1][i4] = tv.y; tp[2][i4] = tv.z; tp[3][i4] = tv.w;
+        }
+    }
     __syncthreads();
+    if (m0 >= G.M1) return;
     v2f acc[FPT];
 #pragma unroll
     for (int j = 0; j < FPT; j++) acc[j] = (v2f){0.f, 0.f};
     const int c0 = FPT * t;
     for (int p = 0; p < 4; p++) {
-        const float4 *xa = &X[p][0][t], *xb = &X[p][1][t];               // this thread's blocks t, t+1, ...
+        const float4 *xa = &X[p][0][64 * wv + t], *xb = &X[p][1][64 * wv + t];   // this thread's blocks 64 wv + t, + 1, ...
         const float4 *tr = reinterpret_cast<const float4 *>(&tp[p][0]);
         v2f c[8];
         { const float4 a = xa[0], b = xb[0]; c[0] = (v2f){a.x, a.y}; c[1] = (v2f){a.z, a.w}; c[2] = (v2f){b.x, b.y}; c[3] = (v2f){b.z, b.w}; }
@@ -140,7 +165,7 @@ __global__ __launch_bounds__(64) void audio_kernel(DeviceTables T, DeviceBuffers
     for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) pk[q] = fmaxf(pk[q], __shfl_xor(pk[q], d));
-    if (t == 0) B.pk_part[(size_t)ch * B.pk_tiles + blockIdx.x] = make_float4(pk[0], pk[1], pk[2], pk[3]);
+    if (t == 0) B.pk_part[(size_t)ch * B.pk_tiles + AW * blockIdx.x + wv] = make_float4(pk[0], pk[1], pk[2], pk[3]);
 }
 
 // PCM tail bookkeeping, one thread per channel, after audio_kernel: folds the tiles' maxima into the open window, writes
@@ -175,8 +200,8 @@ void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
                   int channels, hipStream_t s) {
     const int64_t frames = G.M1 - G.M0;
     if (frames <= 0) return;
-    const int tiles = (int)((frames + C_TILE - 1) / C_TILE);
-    hipLaunchKernelGGL(audio_kernel, dim3(tiles, channels), dim3(64), 0, s, T, B, G, pcm);
+    const int tiles = (int)((frames + AW * C_TILE - 1) / (AW * C_TILE));
+    hipLaunchKernelGGL(audio_kernel, dim3(tiles, channels), dim3(64 * AW), 0, s, T, B, G, pcm);
     hipLaunchKernelGGL(pcm_tail_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, B, G, channels);
 }
 

@@ -644,12 +644,31 @@ __device__ __forceinline__ void pss_fir_body(DeviceTables T, DeviceBuffers B, Ca
     float2 *sW2 = reinterpret_cast<float2 *>(&sW[0][0]);
     auto wslot = [](int w) { const int u = w >> 1; return (((u & 3) * PSS_WU + (u >> 2)) << 1) | (w & 1); };   // float2 index of window entry w
     // window entry w <-> s index (ic + tmin) - (1753 + 294) + w ; tags in a tile span < PSS_TILE
-    for (int w = lane; w < 8 * (PSS_WU - 1); w += 64) {
-        const int64_t idx = ic + tmin - (PSS_DELAY + PSS_TAPS - 1) + w;
-        const float2 v = (idx >= 0 && w < PSS_TILE + PSS_TAPS - 1) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
-        sW2[wslot(w)] = v;
+    // (fills in batches: the loads of a batch are in flight together -- the fill is pure memory latency for the wave)
+    {
+        constexpr int NW = 8 * (PSS_WU - 1), FB = 7;
+#pragma unroll
+        for (int w0 = 0; w0 < NW; w0 += 64 * FB) {
+            float2 v[FB];
+#pragma unroll
+            for (int k = 0; k < FB; k++) {
+                const int w = w0 + 64 * k + lane;
+                const int64_t idx = ic + tmin - (PSS_DELAY + PSS_TAPS - 1) + w;
+                v[k] = (w < NW && idx >= 0 && w < PSS_TILE + PSS_TAPS - 1) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < FB; k++) {
+                const int w = w0 + 64 * k + lane;
+                if (w < NW) sW2[wslot(w)] = v[k];
+            }
+        }
+        constexpr int HB = (4 * PSS_TG + 63) / 64;
+        float hv[HB];
+#pragma unroll
+        for (int k = 0; k < HB; k++) { const int w = 64 * k + lane; hv[k] = (w < PSS_TAPS) ? T.pss_taps[PSS_TAPS - 1 - w] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < HB; k++) { const int w = 64 * k + lane; if (w < 4 * PSS_TG) sH[w] = hv[k]; }
     }
-    for (int w = lane; w < 4 * PSS_TG; w += 64) sH[w] = (w < PSS_TAPS) ? T.pss_taps[PSS_TAPS - 1 - w] : 0.f;
     __syncthreads();
     // y(sample) = sum_w sH[w] * s[w + off], off = tag - tmin
     typedef float v2f_t __attribute__((ext_vector_type(2)));
