@@ -501,14 +501,18 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         // count is large and the time-parallel kernels need the CUs more
         const int want = std::max(2, std::min(5, (PB_ROLES * groups + 47) / 48));   // (7 of the 8 possible did not all become resident)
         // From 2048 channels on stage B is bound by the time-parallel kernels' throughput, not by the recurrences' latency:
-        // they then run on every CU (sharing the recurrence CUs), and the recurrence waves are spread three to a CU.
+        // they then run on every CU, and so do the recurrence waves, one or two to a CU (measured at 4096 channels with the
+        // time-parallel kernels switched off: the five roles of 64 groups take 4.0 ms three to a CU on 120 CUs, 3.4 ms two
+        // to a CU on 168 CUs, 2.9 ms spread over all 256 -- the roles slow each other in proportion to the waves per CU).
         const bool t_everywhere = getenv("FMX_T_UNMASKED") ? atoi(getenv("FMX_T_UNMASKED")) != 0 : groups >= 32;
-        const int per_cu = std::min(occ, e3 ? std::max(1, atoi(e3)) : (t_everywhere ? 3 : want));
+        const int per_cu = std::min(occ, e3 ? std::max(1, atoi(e3)) : (t_everywhere ? 1 : want));
         if (getenv("FMX_DEBUG_LAYOUT")) fprintf(stderr, "[fmx] recurrence kernel occupancy %d blocks/CU, %d groups\n", occ, groups);
         if (minch > 0 && h->channels >= minch && ncu >= 64 && ncu <= 1024 && per_cu > 0) {
-            int rcus = (PB_ROLES * groups + per_cu - 1) / per_cu;
+            const int rwaves = PB_ROLES * groups;
+            int rcus = (rwaves + per_cu - 1) / per_cu;
             rcus = std::max(16, (rcus + 7) / 8 * 8 + 8);
-            if (rcus <= ncu * 3 / 4) {
+            if (t_everywhere) rcus = std::min(rcus, ncu);      // (the time-parallel kernels run on every CU anyway)
+            if (rcus <= ncu * 3 / 4 || t_everywhere) {
                 std::vector<uint32_t> mr((ncu + 31) / 32, 0u), mt((ncu + 31) / 32, 0u);
                 for (int i = 0; i < ncu; i++) (i < rcus ? mr : mt)[i / 32] |= 1u << (i % 32);
                 if (t_everywhere) for (int i = 0; i < ncu; i++) mt[i / 32] |= 1u << (i % 32);

@@ -121,7 +121,7 @@ __device__ __forceinline__ float2 limiter(float2 z) {
 // first block, because the kernel boundary in between has made that kernel's stores visible device-wide (a release
 // fence per block would write the XCD's L2 back thousands of times).  `gate`: progress words [group] of the recurrence
 // role this kernel consumes; a block starts once its own group has reached `need`.
-struct TSync { const int *gate; int need; int *sig; int sigv; int *abort_flag; };
+struct TSync { const int *gate; int need; int *sig; int sigv; int *abort_flag; int skip; };
 __device__ __forceinline__ bool tsync_enter(const TSync &Y, int group) {
     if (Y.sig != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         __hip_atomic_store(Y.sig, Y.sigv, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -221,7 +221,7 @@ __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallG
     }
 }
 __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t row0, int nrows, TSync Y) {
-    if (!tsync_enter(Y, (int)blockIdx.y >> 2)) return;
+    if (!tsync_enter(Y, (int)blockIdx.y >> 2) || Y.skip) return;
     disc_body(T, B, G, C, row0, nrows, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -730,7 +730,7 @@ __device__ __forceinline__ void pss_fir_body(DeviceTables T, DeviceBuffers B, Ca
     }
 }
 __global__ __launch_bounds__(64) void pss_fir_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, TSync Y) {
-    if (!tsync_enter(Y, (int)blockIdx.y >> 6)) return;
+    if (!tsync_enter(Y, (int)blockIdx.y >> 6) || Y.skip) return;
     pss_fir_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -943,7 +943,7 @@ __device__ __forceinline__ void pss_mix_body(DeviceTables T, DeviceBuffers B, Ca
     }
 }
 __global__ __launch_bounds__(256) void pss_mix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, TSync Y) {
-    if (!tsync_enter(Y, (int)blockIdx.y >> 2)) return;
+    if (!tsync_enter(Y, (int)blockIdx.y >> 2) || Y.skip) return;
     pss_mix_body(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
 }
 // =================================================================================================
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(64) void deemph_kernel(DeviceTables T, DeviceBuffer
 // =================================================================================================
 // Persistent layout of stage B (see launch_demod_persistent)
 // =================================================================================================
-struct ChunkPlan { int n; int rc0[PB_MAX_CHUNKS]; int len[PB_MAX_CHUNKS]; int nb_disc[PB_MAX_CHUNKS], nb_fir[PB_MAX_CHUNKS], nb_mix[PB_MAX_CHUNKS]; };
+struct ChunkPlan { int n; int role_mask; int rc0[PB_MAX_CHUNKS]; int len[PB_MAX_CHUNKS]; int nb_disc[PB_MAX_CHUNKS], nb_fir[PB_MAX_CHUNKS], nb_mix[PB_MAX_CHUNKS]; };
 constexpr int PB_SPIN_LIMIT = 1 << 22;            // x ~0.5 us: a wait longer than ~2 s gives up and raises DemodSync::abort
 
 // wave-uniform wait until *p >= need; false when the pipeline was aborted.  The polls are relaxed loads (an acquire load
@@ -1059,9 +1059,10 @@ template <bool PLLDEC, bool T2, bool W32>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void recurrences_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, ChunkPlan P,
                                                          DemodSync *S, int groups) {
     FMX_RECURRENCE_PRIO();
-    const int grp = blockIdx.x, role = blockIdx.y;
+    const int grp = blockIdx.x;
     int *prog = &S->prog[0][0];
     if (threadIdx.x == 0) __hip_atomic_fetch_add(&S->started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int role = blockIdx.y;
     bool first = true;
     for (int c = 0; c < P.n; c++) {
         bool ok = true;
@@ -1074,6 +1075,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         if (!ok) return;
         const int64_t rc0 = P.rc0[c]; const int len = P.len[c];
+        if ((P.role_mask >> role) & 1)                    // (diagnostics: roles outside FMX_DEBUG_ROLE_MASK only pass the word on)
         switch (role) {
         case 0: afc_body<PLLDEC>(T, B, G, C, rc0, len, grp, 0); break;
         case 1: pll_body<T2, W32>(T, B, G, C, rc0, len, grp, 0, first); break;
@@ -1148,6 +1150,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         P.nb_fir[c] = ((len + PSS_TILE - 1) / PSS_TILE) * C;
         P.n++; rc0 += len;
     }
+    { static const int rm = getenv("FMX_DEBUG_ROLE_MASK") ? atoi(getenv("FMX_DEBUG_ROLE_MASK")) : 31; P.role_mask = rm; }
     DemodSync *S = DS.sync;
     (void)hipMemsetAsync(S, 0, sizeof(DemodSync) + sizeof(int) * PB_ROLES * groups, s);
     hipLaunchKernelGGL(sync_init_kernel, dim3(1), dim3(64), 0, s, S, groups, DS.host_flag);
@@ -1162,9 +1165,12 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
     int *prog = &S->prog[0][0];
     // the completion word of a kernel travels with the NEXT kernel on the stream (TSync::sig)
     int *pend_p = nullptr; int pend_v = 0;
+    static const bool nogate = getenv("FMX_DEBUG_NO_GATES") != nullptr;   // diagnostics (timing only, results invalid): the time-parallel kernels do not wait for the recurrences
     auto ysync = [&](int role, int need) {
         TSync Y{};
-        Y.gate = role >= 0 ? prog + role * groups : nullptr; Y.need = need; Y.sig = pend_p; Y.sigv = pend_v; Y.abort_flag = &S->abort;
+        static const bool t_empty = getenv("FMX_DEBUG_T_EMPTY") != nullptr;   // diagnostics: the time-parallel kernels do nothing (the recurrences' own speed)
+        Y.skip = t_empty ? 1 : 0;
+        Y.gate = (role >= 0 && !nogate) ? prog + role * groups : nullptr; Y.need = need; Y.sig = pend_p; Y.sigv = pend_v; Y.abort_flag = &S->abort;
         pend_p = nullptr;
         return Y;
     };
@@ -1176,7 +1182,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
     // chunk c reads s-ring entries the mix wrote no later than chunk c - 2: it does not wait for the integrator of chunk
     // c - 1, the integrator runs chunk after chunk without a gap, and the order below only has to keep every kernel behind
     // its producers:  low-pass(c), disc(c + 3), mix(c - 1).  (The de-emphasis role writes the d ring itself.)
-    constexpr int LEAD = 3;
+    static const int LEAD = getenv("FMX_DISC_LEAD") ? atoi(getenv("FMX_DISC_LEAD")) : 3;
     auto fir = [&](int c) {
         DeviceBuffers Bc = B;
         Bc.w_err = B.w_err + (size_t)(c & 1) * (PB_CHUNK / WT) * G.pitch * WT;
