@@ -19,23 +19,25 @@ namespace fmx {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int CQ = C_TAPS_STRIDE / 4;                     // 224 tap columns per phase (zero padded)
+constexpr int NG3MAX = (CQ / 4 + 2) / 3 * 3;              // tap groups (four tap columns each) per phase, a multiple of three
 constexpr int AW = 4;                                     // waves per workgroup: AW adjacent 256-frame tiles share one window and the taps
-constexpr int CWC = AW * C_TILE + CQ + 16;                // window columns per phase
-constexpr int FPT = 4;                                    // adjacent output frames per thread
+constexpr int CWC = AW * C_TILE + 4 * NG3MAX + 16;        // window columns per phase
+constexpr int FPT = 4;                                    // output frames a thread finishes (it computes half of eight)
 
 // One wave per (256-frame tile, channel), four adjacent tiles per workgroup (one window fill and one tap image for the four:
-// 44 KB of LDS for four waves instead of 19 KB for one, so three waves share a SIMD instead of two and one wave's fill --
-// pure memory latency -- hides under the others' FIR).  The window lives in LDS as four decimation phases X[p][col] (entry w of the
-// window = fm index fbase + w sits at X[w & 3][w >> 2]), so output frame f reads X[p][f + q] for tap 4 q + p.  A thread
-// computes FOUR adjacent frames with a sliding register window: per four taps of a phase it fetches four new (L, R)
-// columns (2 ds_read_b128) and the four taps (one broadcast ds_read_b128) and issues 16 packed FMAs -- (L, R) ride in
-// one v_pk_fma_f32 because the taps are real.
+// 44 KB of LDS for four waves, three waves per SIMD, one workgroup's fill -- pure memory latency -- under the others' FIR).
+// The window lives in LDS as four decimation phases (entry w of the window = fm index fbase + w is column w >> 2 of phase
+// w & 3), so output frame f reads column f + q of phase p for tap 4 q + p.  A thread computes EIGHT adjacent frames for TWO
+// of the four phases (lanes 0..31: phases 0, 1; lanes 32..63: phases 2, 3) through a twelve-column register ring: per four
+// taps two ds_read_b128 of data and one of taps feed 32 packed FMAs -- (L, R) ride in one v_pk_fma_f32 because the taps
+// are real.  (Four frames x four phases per thread needed the same three LDS reads per 16 FMAs and was LDS-bound.)  The two
+// half-sums meet through one cross-lane exchange, after which every lane finishes four frames.
 __global__ __launch_bounds__(64 * AW) void audio_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
                                                    float2 *__restrict__ pcm) {
-    // X[p][half][block] = the column pair (4 block + 2 half, + 1) of phase p: a thread's four new columns are one float4
-    // from each half-plane, both read at a 16-byte lane stride (conflict-free ds_read_b128)
-    __shared__ __attribute__((aligned(16))) float4 X[4][2][CWC / 4];
-    __shared__ __attribute__((aligned(16))) float tp[4][CQ];         // taps by phase: tp[p][q] = taps[4 q + p]
+    // X[p][plane][o] = the column pair of unit u = 4 o + plane (columns 2 u, 2 u + 1) of phase p: a thread's units start four
+    // after its neighbour's, so every ds_read_b128 of a half-wave reads consecutive 16-byte slots of one plane
+    __shared__ __attribute__((aligned(16))) float4 X[4][4][CWC / 8 + 1];
+    __shared__ __attribute__((aligned(16))) float tp[4][4 * NG3MAX];  // taps by phase: tp[p][q] = taps[4 q + p], zero padded
     const int ch = blockIdx.y;
     const int tb = threadIdx.x, t = tb & 63, wv = tb >> 6;
     const int64_t mb = G.M0 + (int64_t)blockIdx.x * (AW * C_TILE);     // first frame of the workgroup, of this wave:
@@ -46,11 +48,11 @@ __global__ __launch_bounds__(64 * AW) void audio_kernel(DeviceTables T, DeviceBu
     const float *__restrict__ taps = T.audio_taps + (size_t)P.audio_set * C_TAPS_STRIDE;   // reversed order, zero padded
     const float2 *__restrict__ dring = B.dring + (size_t)ch * (G.dring_mask + 1);
     const int NC = AS.ntaps;
-    const int NG = ((NC + 15) / 16 + 1) & ~1;               // groups of four tap columns per phase, even
+    const int NG3 = ((NC + 15) / 16 + 2) / 3 * 3;           // groups of four tap columns per phase, a multiple of three
     // window entry w <-> fm index fbase + w ; output frame f (0..255) reads w = 4 f + kk, kk = tap index
     const int64_t fbase = 4 * mb + 3 - AS.delay - (NC - 1);
     const int nfr = (int)((G.M1 - mb) < (int64_t)(AW * C_TILE) ? (G.M1 - mb) : (int64_t)(AW * C_TILE));   // frames of this workgroup
-    const int nw = 4 * (((nfr + C_TILE - 1) / C_TILE) * C_TILE + 4 * NG + 4);
+    const int nw = 4 * (((nfr + C_TILE - 1) / C_TILE) * C_TILE + 4 * NG3 + 8);
     // window and taps fill: the loads of a batch are issued together and only then written to LDS -- one memory round trip
     // per batch instead of one per 64 entries (a wave has nothing else to do here: the fill is pure latency)
     constexpr int FB = 8;
@@ -67,56 +69,62 @@ __global__ __launch_bounds__(64 * AW) void audio_kernel(DeviceTables T, DeviceBu
         for (int k = 0; k < FB; k++) {
             const int w = w0 + 64 * AW * k + tb;
             const int col = w >> 2;
-            if (w < nw) reinterpret_cast<float2 *>(&X[w & 3][(col >> 1) & 1][col >> 2])[col & 1] = v[k];
+            if (w < nw) reinterpret_cast<float2 *>(&X[w & 3][(col >> 1) & 3][col >> 3])[col & 1] = v[k];
         }
     }
     {
-        static_assert(C_TAPS_STRIDE / 4 <= 64 * AW, "one float4 of taps per thread");
+        static_assert(NG3MAX <= 64 * AW && C_TAPS_STRIDE / 4 <= 4 * NG3MAX, "one float4 of taps per thread");
         const int i4 = tb;                                                   // float4 index: taps 4 i4 .. 4 i4 + 3 = column i4 of phases 0..3
-        if (i4 < C_TAPS_STRIDE / 4) {
-            const float4 tv = reinterpret_cast<const float4 *>(taps)[i4];
+        if (i4 < 4 * NG3MAX) {
+            const float4 tv = i4 < C_TAPS_STRIDE / 4 ? reinterpret_cast<const float4 *>(taps)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
             tp[0][i4] = tv.x; tp[1][i4] = tv.y; tp[2][i4] = tv.z; tp[3][i4] = tv.w;
         }
     }
     __syncthreads();
     if (m0 >= G.M1) return;
-    v2f acc[FPT];
+    const int tl = t & 31, ph = t >> 5;
+    v2f a8[8];
 #pragma unroll
-    for (int j = 0; j < FPT; j++) acc[j] = (v2f){0.f, 0.f};
-    const int c0 = FPT * t;
-    for (int p = 0; p < 4; p++) {
-        const float4 *xa = &X[p][0][64 * wv + t], *xb = &X[p][1][64 * wv + t];   // this thread's blocks 64 wv + t, + 1, ...
-        const float4 *tr = reinterpret_cast<const float4 *>(&tp[p][0]);
-        v2f c[8];
-        { const float4 a = xa[0], b = xb[0]; c[0] = (v2f){a.x, a.y}; c[1] = (v2f){a.z, a.w}; c[2] = (v2f){b.x, b.y}; c[3] = (v2f){b.z, b.w}; }
-        // two tap groups per iteration: the eight-column register window is used as a ring, so nothing is moved
-        for (int g = 0; g < NG; g += 2) {
-            {
-                const float4 a = xa[g + 1], b = xb[g + 1];
-                c[4] = (v2f){a.x, a.y}; c[5] = (v2f){a.z, a.w}; c[6] = (v2f){b.x, b.y}; c[7] = (v2f){b.z, b.w};
-                const float4 w4 = tr[g];
-                const float wq[4] = {w4.x, w4.y, w4.z, w4.w};
+    for (int j = 0; j < 8; j++) a8[j] = (v2f){0.f, 0.f};
+    const int mu = 32 * wv + tl;                                  // this thread's first window unit is 4 mu
+    for (int pp = 0; pp < 2; pp++) {
+        const int p = 2 * ph + pp;
+        const float4 *hr = reinterpret_cast<const float4 *>(&tp[p][0]);
+        v2f c[12];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const v2f w = (v2f){wq[q], wq[q]};
+        for (int k = 0; k < 6; k++) {                             // ring = columns 8 mu .. 8 mu + 11 (units 4 mu .. 4 mu + 5)
+            const float4 v = X[p][k & 3][mu + (k >> 2)];
+            c[2 * k] = (v2f){v.x, v.y}; c[2 * k + 1] = (v2f){v.z, v.w};
+        }
+        for (int g3 = 0; g3 < NG3; g3 += 3) {
 #pragma unroll
-                    for (int j = 0; j < FPT; j++) acc[j] = __builtin_elementwise_fma(w, c[q + j], acc[j]);
+            for (int gg = 0; gg < 3; gg++) {                      // group g: tap columns 4 g .. 4 g + 3 on ring entries (4 gg + q + j) % 12
+                const int g = g3 + gg;
+                const float4 h4 = hr[g];
+                const float hq[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+                    const v2f w = (v2f){hq[qq], hq[qq]};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) a8[j] = __builtin_elementwise_fma(w, c[(4 * gg + qq + j) % 12], a8[j]);
                 }
-            }
-            {   // (for an odd group count the extra group multiplies zero taps: the tap table is padded, the window too)
-                const float4 a = xa[g + 2], b = xb[g + 2];
-                c[0] = (v2f){a.x, a.y}; c[1] = (v2f){a.z, a.w}; c[2] = (v2f){b.x, b.y}; c[3] = (v2f){b.z, b.w};
-                const float4 w4 = tr[g + 1];
-                const float wq[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const v2f w = (v2f){wq[q], wq[q]};
-#pragma unroll
-                    for (int j = 0; j < FPT; j++) acc[j] = __builtin_elementwise_fma(w, c[(4 + q + j) & 7], acc[j]);
-                }
+                // columns 4 g + 12 .. 4 g + 15 replace the four oldest: units 4 mu + 2 g + 6, + 7
+                const int u0 = 2 * g + 6;
+                const float4 va = X[p][u0 & 3][mu + (u0 >> 2)], vb = X[p][(u0 + 1) & 3][mu + ((u0 + 1) >> 2)];
+                c[(4 * gg) % 12] = (v2f){va.x, va.y}; c[(4 * gg + 1) % 12] = (v2f){va.z, va.w};
+                c[(4 * gg + 2) % 12] = (v2f){vb.x, vb.y}; c[(4 * gg + 3) % 12] = (v2f){vb.z, vb.w};
             }
         }
     }
+    // the other half-wave holds the other two phases of the same eight frames: lane (tl, ph) finishes frames 8 tl + 4 ph + j
+    v2f acc[FPT];
+#pragma unroll
+    for (int j = 0; j < FPT; j++) {
+        const v2f mine = ph ? a8[4 + j] : a8[j], give = ph ? a8[j] : a8[4 + j];
+        const float gx = __shfl_xor(give.x, 32), gy = __shfl_xor(give.y, 32);
+        acc[j] = ph ? (v2f){gx + mine.x, gy + mine.y} : (v2f){mine.x + gx, mine.y + gy};    // (phases 0, 1) + (phases 2, 3) in both
+    }
+    const int c0 = 8 * tl + FPT * ph;
     // audioGainCorrection fm-processor.cpp:303-306: (volumeFactor * leftChannel) * sample.  Applied here, at
     // the output of the folded FIR, so that a volume/balance change takes effect at the call boundary as in
     // the reference (it sits behind the audio low-pass there) rather than one filter latency late.
