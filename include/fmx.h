@@ -74,8 +74,8 @@ typedef enum {
     FMX_P_AUTO_MONO = 14,      /* setAutoMonoMode                                    (:914-916)  */
     FMX_P_PSS = 15,            /* setPSSMode                                         (:918-920)  */
     FMX_P_DC_REMOVE = 16,      /* setDCRemove (also zeroes RfDC)                     (:922-925)  */
-    FMX_P_SQUELCH_MODE = 17,   /* set_squelchMode (fm-processor.cpp:882): 0 OFF, 2 LSQ (level squelch, squelchClass.cpp:89-113);
-                                  1 (NSQ, two order-20 IIR filters) is FMX_E_UNSUPPORTED */
+    FMX_P_SQUELCH_MODE = 17,   /* set_squelchMode (fm-processor.cpp:882): 0 OFF, 1 NSQ (noise squelch, squelchClass.cpp:47-87: two order-20
+                                  Chebyshev filters around 70 kHz on the demodulator output), 2 LSQ (level squelch, :89-113) */
     FMX_P_TEST_TONE = 18,      /* setTestTone (:931-933): 1 kHz bursts of 25 ms every 2 s at 0.9, programme at 0.1 (:800-823) */
     FMX_P_SQUELCH_VALUE = 19,  /* set_squelchValue 0..100 (:213-215): takes effect at the next call when it differs  */
     FMX_P_DISP_DELAY = 20,     /* setDispDelay (:935-937): steps of the peak-level delay line; applies to the windows
@@ -200,7 +200,8 @@ int  fmx_rds_decode_bits(const uint8_t *bits, int32_t n_bits, fmx_rds_info *info
 int  fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity, int32_t *n_bits);
 
 /* introspection used by the parity tests: the filter taps the kernels run with.
- * which: 0 front-end polyphase taps, 1 PSS low-pass, 2 audio+resampler FIR, 3 resampler alone */
+ * which: 0 front-end polyphase taps, 1 PSS low-pass, 2 audio+resampler FIR, 3 resampler alone,
+ * 4 the noise squelch's two order-20 filters: [2][10] x (A1, A2, B1, B2), then the two gains (high-pass first) */
 int  fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32_t capacity, int32_t *n);
 
 int  fmx_profile_enable(fmx_handle h, int32_t on);

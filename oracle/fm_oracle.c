@@ -749,6 +749,119 @@ static int rds2_decode(rds2 *r, c32 v, c32 *m, uint8_t *d) {
 #define RDS_WIDTH (2 * 2400)
 #define BLOCK 16384
 
+
+/* =====================================================================================
+ * Recursive filters: iir-filters.cpp.  DSPFLOAT = float; libm calls take the overload of their
+ * argument type (`using namespace std`, fm-constants.h:66): float arguments -> sinhf / cosf / ...,
+ * double expressions (anything with M_PI, 10.0, 0.1 ...) -> the double functions, narrowed on
+ * assignment to a DSPFLOAT.
+ * ===================================================================================== */
+static float iir_sinhm1(float x) { return logf(x + sqrtf(x * x + 1)); }                 /* :48-51 */
+static float iir_warpDtoA(int fd, int fs) { return (float)(2.0 * fs * tan((2 * M_PI * fd) / (2 * fs))); }   /* :111-113 */
+
+static float iir_butterworth(float q[][6], int nq, int order, int apass) {               /* newButterworth :120-163 */
+    float Eps = (float)sqrt(pow(10.0, -0.1 * apass) - 1);
+    float R = (float)(1.0 / pow((double)Eps, 1.0 / order));
+    int i0 = 0;
+    if (order & 1) { q[0][0] = 0; q[0][1] = 0; q[0][2] = R; q[0][3] = 0; q[0][4] = 1; q[0][5] = R; i0 = 1; }
+    for (int i = i0; i < nq; i++) {
+        float Phim = (order & 1) ? (float)(M_PI * (2 * (i - 1) + order + 1) / (2 * order)) : (float)(M_PI * (2 * i + order + 1) / (2 * order));
+        float sigma = R * cosf(Phim), omega = R * sinf(Phim);
+        q[i][0] = 0; q[i][1] = 0; q[i][2] = sigma * sigma + omega * omega;
+        q[i][3] = 1; q[i][4] = -2 * sigma; q[i][5] = sigma * sigma + omega * omega;
+    }
+    return 1.0f;
+}
+static float iir_chebyshev(float q[][6], int nq, int order, int apass) {                 /* newChebyshev :165-218 */
+    float Eps = (float)sqrt(pow(10.0, -0.1 * apass) - 1);
+    float D = iir_sinhm1((float)(1.0 / Eps)) / order;
+    float sinhD = sinhf(D), coshD = coshf(D);
+    int i0 = 0;
+    if (order & 1) { q[0][0] = 0; q[0][1] = 0; q[0][2] = sinhD; q[0][3] = 0; q[0][4] = 1; q[0][5] = sinhD; i0 = 1; }
+    for (int i = i0; i < nq; i++) {
+        float Phim = (order & 1) ? (float)(M_PI * (2 * (i - 1) + 1) / (2 * order)) : (float)(M_PI * (2 * i + 1) / (2 * order));
+        float sigma = -sinhD * sinf(Phim), omega = coshD * cosf(Phim);
+        q[i][0] = 0; q[i][1] = 0; q[i][2] = sigma * sigma + omega * omega;
+        q[i][3] = 1; q[i][4] = -2 * sigma; q[i][5] = sigma * sigma + omega * omega;
+    }
+    return (order & 1) == 0 ? (float)pow(10.0, 0.05 * apass) : 1.0f;
+}
+static float iir_normalized(float q[][6], int nq, int order, int apass, int ftype) {     /* newNormalized :289-306 */
+    if (order <= 0) order = 6;
+    return ftype == FMO_IIR_CHEBYSHEV ? iir_chebyshev(q, nq, order, apass) : iir_butterworth(q, nq, order, apass);
+}
+static float iir_bilinear(float q[][6], int fs, int nq) {                                 /* Bilineair :73-109 */
+    float gain = 1.0f;
+    const float f2 = (float)(2 * fs), f4 = f2 * f2;
+    for (int i = 0; i < nq; i++) {
+        float *c = q[i];
+        const float N0 = c[0] * f4 + c[1] * f2 + c[2];
+        const float N1 = 2 * (c[2] - c[0] * f4);
+        const float N2 = c[0] * f4 - c[1] * f2 + c[2];
+        const float D0 = c[3] * f4 + c[4] * f2 + c[5];
+        const float D1 = 2 * (c[5] - c[3] * f4);
+        const float D2 = c[3] * f4 - c[4] * f2 + c[5];
+        c[0] = 1.0f; c[1] = N1 / N0; c[2] = N2 / N0;
+        c[3] = 1.0f; c[4] = D1 / D0; c[5] = D2 / D0;
+        gain *= (N0 / D0);
+    }
+    return gain;
+}
+void fmo_iir_lowpass(fmo_iir *f, int order, int32_t fpass, int32_t fs, int ftype) {       /* LowPassIIR :451-490 */
+    memset(f, 0, sizeof(*f));
+    f->nq = ((order + 1) & 0176) / 2;
+    if (2 * fpass >= fs) fpass = fs / 4;
+    const float omega = iir_warpDtoA(fpass, fs);
+    f->gain = iir_normalized(f->q, f->nq, order, -1, ftype);
+    for (int i = 0; i < f->nq; i++) {
+        float *c = f->q[i];
+        c[1] = c[1] * omega; c[4] = c[4] * omega;
+        c[2] = c[2] * omega * omega; c[5] = c[5] * omega * omega;
+    }
+    f->gain *= iir_bilinear(f->q, fs, f->nq);
+}
+void fmo_iir_highpass(fmo_iir *f, int order, int32_t fpass, int32_t fs, int ftype) {      /* HighPassIIR :497-540 */
+    memset(f, 0, sizeof(*f));
+    f->nq = ((order + 1) & 0176) / 2;
+    if (2 * fpass >= fs) fpass = fs / 4;
+    const float omega = iir_warpDtoA(fpass, fs);
+    f->gain = iir_normalized(f->q, f->nq, order, -1, ftype);
+    for (int i = 0; i < f->nq; i++) {
+        float *c = f->q[i];
+        const float A0 = c[0], A1 = c[1], A2 = c[2], B0 = c[3], B1 = c[4], B2 = c[5];
+        f->gain *= A2 / B2;
+        c[0] = 1.0f; c[3] = 1.0f;
+        c[1] = (A1 / A2) * omega; c[4] = (B1 / B2) * omega;
+        c[2] = (A0 / A2) * omega * omega; c[5] = (B0 / B2) * omega * omega;
+    }
+    f->gain *= iir_bilinear(f->q, fs, f->nq);
+}
+float fmo_iir_pass(fmo_iir *f, float v) {                                                  /* Basic_IIR::Pass (DSPFLOAT) iir-filters.h:89-103 */
+    float o = v * f->gain;
+    for (int i = 0; i < f->nq; i++) {
+        const float *c = f->q[i];
+        const float rm1 = f->m1[i], rm2 = f->m2[i];
+        const float w = o - rm1 * c[4] - rm2 * c[5];
+        o = w + rm1 * c[1] + rm2 * c[2];
+        f->m2[i] = f->m1[i]; f->m1[i] = w;
+    }
+    return o;
+}
+void *fmo_iir_new(int kind, int order, int32_t f1, int32_t f2, int32_t fs, int ftype) {
+    (void)f2;
+    fmo_iir *f = (fmo_iir *)calloc(1, sizeof(*f));
+    if (kind == 0) fmo_iir_lowpass(f, order, f1, fs, ftype); else fmo_iir_highpass(f, order, f1, fs, ftype);
+    return f;
+}
+void fmo_iir_free(void *p) { free(p); }
+int fmo_iir_coeffs(void *p, float *out) {
+    fmo_iir *f = (fmo_iir *)p;
+    for (int i = 0; i < f->nq; i++) for (int k = 0; k < 6; k++) out[6 * i + k] = f->q[i][k];
+    out[6 * f->nq] = f->gain;
+    return f->nq;
+}
+void fmo_iir_run(void *p, const float *in, long n, float *out) { fmo_iir *f = (fmo_iir *)p; for (long i = 0; i < n; i++) out[i] = fmo_iir_pass(f, in[i]); }
+
 typedef struct { float *buf; long cap, n; } tapbuf;
 
 struct fmo_chain {
@@ -764,6 +877,7 @@ struct fmo_chain {
     float *rdsPhaseBuffer; int rdsPhaseIndex;
     /* squelch (level squelch only) squelchClass.cpp:12-29 */
     float sqLevelThr; int sqCount, sqHold, sqSuppress, sqOldValue;
+    float sqNoiseThr, sqAvgHigh, sqAvgLow; fmo_iir sqHigh, sqLow;       /* noise squelch squelchClass.cpp:11-31 */
     int newAudioFilter, inputFilterOn, newInputFilter, audioFilterActive;
     int32_t lowPassFrequency, fmBandwidth;
     float Lgain, Rgain, pilotDelayPSS, deemphAlpha, volumeFactor, panorama, leftChannel, rightChannel;
@@ -879,6 +993,9 @@ fmo_chain *fmo_chain_new(const fmo_config *c) {
     ch->meta.peakLeftDb = ch->meta.peakRightDb = -40.0f;
     /* mySquelch (1, 70000, fmRate / 20, fmRate) fm-processor.cpp:87; squelchValue = oldSquelchValue = 0 :194-195 */
     ch->sqLevelThr = powf(10.0f, (1 - 80) / 30.0f); ch->sqHold = ch->cfg.fmRate / 20; ch->sqCount = 0; ch->sqSuppress = 0; ch->sqOldValue = 0;
+    /* squelchHighpass (20, keyFrequency - 100, sampleRate, S_CHEBYSHEV), squelchLowpass (20, keyFrequency, ...) with keyFrequency 70000 */
+    ch->sqNoiseThr = 1.0f - 1 / 100.0f; ch->sqAvgHigh = 0; ch->sqAvgLow = 0;
+    fmo_iir_highpass(&ch->sqHigh, 20, 70000 - 100, ch->cfg.fmRate, FMO_IIR_CHEBYSHEV); fmo_iir_lowpass(&ch->sqLow, 20, 70000, ch->cfg.fmRate, FMO_IIR_CHEBYSHEV);
     apply_settings(ch, c, 1);
     return ch;
 }
@@ -1019,6 +1136,7 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
     }
     if (ch->cfg.squelchValue != ch->sqOldValue) {           /* fm-processor.cpp:410-413 */
         ch->sqLevelThr = powf(10.0f, (ch->cfg.squelchValue - 80) / 30.0f);      /* setSquelchLevel squelchClass.cpp:33-37 */
+        ch->sqNoiseThr = 1.0f - ch->cfg.squelchValue / 100.0f;
         ch->sqOldValue = ch->cfg.squelchValue;
     }
     if (ch->cfg.dcRemove) {
@@ -1053,6 +1171,22 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
                 const float carrier = fmo_demod_carrier(ch->demod);
                 if (carrier < ch->sqLevelThr - 0.000f) ch->sqSuppress = 1;
                 else if (carrier >= ch->sqLevelThr + 0.000f) ch->sqSuppress = 0;
+            }
+            demod = ch->sqSuppress ? demod * 0.000f : demod;
+        }
+        if (ch->cfg.squelchMode == 1) {
+            /* squelch::do_noise_squelch squelchClass.cpp:47-87: the demodulated signal above / below 70 kHz through two
+             * order-20 Chebyshev filters, decaying averages over sampleRate / 100 samples (in double, decayingAverage :40-45) */
+            const float val_1 = fabsf(fmo_iir_pass(&ch->sqHigh, demod));
+            const float val_2 = fabsf(fmo_iir_pass(&ch->sqLow, demod));
+            const float weight = (float)(ch->cfg.fmRate / 100);
+            ch->sqAvgHigh = (float)(val_1 * (1.0 / weight) + ch->sqAvgHigh * (1.0 - (1.0 / weight)));
+            ch->sqAvgLow = (float)(val_2 * (1.0 / weight) + ch->sqAvgLow * (1.0 - (1.0 / weight)));
+            if (++ch->sqCount >= ch->sqHold) {
+                ch->sqCount = 0;
+                if (ch->sqNoiseThr < 0.001f) ch->sqSuppress = 1;
+                else if (ch->sqAvgHigh < ch->sqAvgLow * ch->sqNoiseThr - 0.001f) ch->sqSuppress = 0;
+                else if (ch->sqAvgHigh >= ch->sqAvgLow * ch->sqNoiseThr + 0.001f) ch->sqSuppress = 1;
             }
             demod = ch->sqSuppress ? demod * 0.000f : demod;
         }

@@ -129,6 +129,21 @@ void    fmo_costas_init(fmo_costas *, float sr, float alpha, float beta, float l
 fmo_c32 fmo_costas_process(fmo_costas *, fmo_c32 z);
 
 
+/* ---------- recursive filters (iir-filters.cpp: Chebyshev / Butterworth prototypes :120-218, low-pass :451-490,
+ * high-pass :497-540, Bilineair :73-109, Basic_IIR::Pass(float) iir-filters.h:89-103); all arithmetic in f32 as DSPFLOAT ---------- */
+#define FMO_IIR_CHEBYSHEV 0100
+#define FMO_IIR_BUTTERWORTH 0101
+#define FMO_IIR_MAXQ 16
+typedef struct { int nq; float q[FMO_IIR_MAXQ][6]; /* A0 A1 A2 B0 B1 B2 */ float gain; float m1[FMO_IIR_MAXQ], m2[FMO_IIR_MAXQ]; } fmo_iir;
+void  fmo_iir_lowpass(fmo_iir *f, int order, int32_t fpass, int32_t fs, int ftype);
+void  fmo_iir_highpass(fmo_iir *f, int order, int32_t fpass, int32_t fs, int ftype);
+float fmo_iir_pass(fmo_iir *f, float v);
+/* test helpers with the signatures of ref_iir_* (kind 0 low-pass, 1 high-pass) */
+void *fmo_iir_new(int kind, int order, int32_t f1, int32_t f2, int32_t fs, int ftype);
+void  fmo_iir_free(void *);
+int   fmo_iir_coeffs(void *, float *out);
+void  fmo_iir_run(void *, const float *in, long n, float *out);
+
 /* ---------- batch runners used by the tests (same signatures as oracle/ref_wrap.cpp's ref_*) ---------- */
 void fmo_sincos_eval(const fmo_sincos *, const float *phase, long n, float *s, float *c, float *cplx);
 void fmo_atan2_eval(const float *y, const float *x, long n, float *out);
@@ -164,7 +179,7 @@ typedef struct {
     int32_t loFrequency;      /* set_localOscillator                       fm-processor.cpp:866-868 */
     int32_t dcRemove, autoMono, pssActive;
     int32_t rdsMode;          /* 0 off, 1..3 = RDS_1..3 (only 2 is restated) */
-    int32_t squelchMode;      /* 0 OFF, 2 LSQ (level squelch; NSQ = 1 is not restated)   fm-processor.cpp:499-509 */
+    int32_t squelchMode;      /* 0 OFF, 1 NSQ (noise squelch), 2 LSQ (level squelch)   fm-processor.cpp:499-509 */
     int32_t squelchValue;     /* set_squelchValue 0..100: applied at a block start when it differs from the last one (:410-413) */
     int32_t testTone;         /* setTestTone (fm-processor.cpp:931-933): 1 kHz bursts of 25 ms every 2 s mixed into the PCM (:800-823) */
     int32_t dispDelay;        /* setDispDelay (:935-937): steps of the peak-level delay line */

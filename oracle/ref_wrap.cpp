@@ -8,7 +8,7 @@
 //
 // Classes wrapped (all Qt-free): LowPassFIR, BandPassFIR, DecimatingFIR (fir-filters.h),
 // fftFilter, fftFilterHilbert (fft-filters.h), Fft_transform (fft-complex.h), SinCos, Oscillator,
-// compAtan, pllC, pilotRecovery, PerfectStereoSeparation, ShapingFilter, AGC, Costas,
+// compAtan, pllC, pilotRecovery, PerfectStereoSeparation, ShapingFilter, AGC, Costas, LowPassIIR, HighPassIIR, BandPassIIR,
 // PI_Constrain (fm-constants.h).  With -DFMREF_WITH_QT also fm_Demodulator (needs QString from
 // the image's conda QtCore; built only when those headers exist).
 //
@@ -34,6 +34,7 @@
 #include "shaping_filter.h"
 #include "agc.h"
 #include "costas.h"
+#include "iir-filters.h"
 #ifdef FMREF_WITH_QT
 #include "fm-demodulator.h"
 #endif
@@ -309,4 +310,25 @@ long ref_chain_run(void *p, const float *iq, long n, float *fmiq, float *demodOu
 #endif
 }
 
+
+// ---- recursive filters (iir-filters.cpp): kind 0 LowPassIIR(order, f1, fs, type), 1 HighPassIIR, 2 BandPassIIR(order, f1, f2, fs, type)
+void *ref_iir_new(int kind, int order, int32_t f1, int32_t f2, int32_t fs, int ftype) {
+    if (kind == 0) return (Basic_IIR *)new LowPassIIR((int16_t)order, f1, fs, (int16_t)ftype);
+    if (kind == 1) return (Basic_IIR *)new HighPassIIR((int16_t)order, f1, fs, (int16_t)ftype);
+    return (Basic_IIR *)new BandPassIIR((int16_t)order, f1, f2, fs, (int16_t)ftype);
+}
+void ref_iir_free(void *p) { delete (Basic_IIR *)p; }
+int ref_iir_coeffs(void *p, float *out /* 6 per quad: A0 A1 A2 B0 B1 B2, then the gain */) {
+    Basic_IIR *f = (Basic_IIR *)p;
+    for (int i = 0; i < f->numofQuads; i++) {
+        out[6 * i] = f->Quads[i].A0; out[6 * i + 1] = f->Quads[i].A1; out[6 * i + 2] = f->Quads[i].A2;
+        out[6 * i + 3] = f->Quads[i].B0; out[6 * i + 4] = f->Quads[i].B1; out[6 * i + 5] = f->Quads[i].B2;
+    }
+    out[6 * f->numofQuads] = f->gain;
+    return f->numofQuads;
+}
+void ref_iir_run(void *p, const float *in, long n, float *out) {
+    Basic_IIR *f = (Basic_IIR *)p;
+    for (long i = 0; i < n; i++) out[i] = f->Pass(in[i]);
+}
 }  // extern "C"

@@ -67,7 +67,8 @@ struct fmx_handle_s {
     // unique tap sets
     std::vector<int32_t> front_keys, audio_keys;
     int front_cap = 0, audio_cap = 0;
-    std::vector<float> h_front_taps, h_audio_taps, h_pss_taps, h_rs_taps;
+    std::vector<float> h_front_taps, h_audio_taps, h_pss_taps, h_rs_taps, h_nsq;
+    float *d_nsq = nullptr;
     std::vector<FrontSet> h_front_sets; std::vector<AudioSet> h_audio_sets;
     // device
     float *d_front_taps = nullptr, *d_audio_taps = nullptr, *d_pss_taps = nullptr;
@@ -312,7 +313,28 @@ int flush_mailbox(fmx_handle h) {
         if (h->rds_start < 0) h->rds_start = h->g_total / DECIM;       // the RDS filters start counting here (all channels)
     }
     bool any_pll = false;
-    for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode == 2);     // pllC on the fm-rate IQ; |z| for the level squelch
+    for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0);     // pllC on the fm-rate IQ; |z| for the level squelch; the general AFC body for the noise squelch
+    bool any_nsq = false;
+    for (auto &p : h->params) any_nsq |= (p.squelch_mode == 1);
+    if (any_nsq && !h->d_nsq) {
+        // squelch ctor squelchClass.cpp:11-18 with mySquelch (1, 70000, fmRate / 20, fmRate) fm-processor.cpp:87
+        const design::Iir hp = design::iir_chebyshev_lowhigh(true, 20, 70000 - 100, h->cfg.fmRate);
+        const design::Iir lp = design::iir_chebyshev_lowhigh(false, 20, 70000, h->cfg.fmRate);
+        h->h_nsq.assign(2 * NSQ_QUADS * 4 + 2, 0.f);
+        for (int f = 0; f < 2; f++) {
+            const design::Iir &F = f ? lp : hp;
+            if (F.nq != NSQ_QUADS) return fail(FMX_E_HIP, "unexpected biquad count of the squelch filters");
+            for (int i = 0; i < NSQ_QUADS; i++) {
+                h->h_nsq[(f * NSQ_QUADS + i) * 4 + 0] = F.q[i][1]; h->h_nsq[(f * NSQ_QUADS + i) * 4 + 1] = F.q[i][2];
+                h->h_nsq[(f * NSQ_QUADS + i) * 4 + 2] = F.q[i][4]; h->h_nsq[(f * NSQ_QUADS + i) * 4 + 3] = F.q[i][5];
+            }
+            h->h_nsq[2 * NSQ_QUADS * 4 + f] = F.gain;
+        }
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMalloc(&h->d_nsq, sizeof(float) * h->h_nsq.size()));
+        HIPCHK(hipMemcpy(h->d_nsq, h->h_nsq.data(), sizeof(float) * h->h_nsq.size(), hipMemcpyHostToDevice));
+        h->T.nsq_coef = h->d_nsq; h->tail_ptrs.push_back(h->d_nsq);
+    }
     if (any_pll && !h->B.w_iq) {
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMalloc(&h->B.w_iq, sizeof(float2) * (size_t)h->work_nj * h->pitch));
@@ -323,6 +345,7 @@ int flush_mailbox(fmx_handle h) {
         if (u.squelch_value != u.squelch_old) {
             u.squelch_level = u.squelch_value; u.squelch_old = u.squelch_value;
             h->params[c].squelch_thr = std::pow(10.0f, (float)(u.squelch_level - 80) / 30.0f);       // squelchClass.cpp:33-37
+            h->params[c].squelch_nthr = 1.0f - (float)u.squelch_level / 100.0f;
             h->params_dirty = true;
         }
     }
@@ -478,7 +501,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         // constructor defaults fm-processor.cpp:110-160 / fm-demodulator.cpp:66
         p.fm_mode = 0; p.sound_sel = 0; p.decoder = 3; p.auto_mono = 1; p.pss_active = 1; p.dc_remove = 1;
         p.rds_mode = 0; p.lo_freq = 0; p.lo_period = 0; p.att_l = 1.f; p.att_r = 1.f;
-        p.squelch_mode = 0; p.squelch_thr = std::pow(10.0f, (float)(1 - 80) / 30.0f);
+        p.squelch_mode = 0; p.squelch_thr = std::pow(10.0f, (float)(1 - 80) / 30.0f); p.squelch_nthr = 1.0f - 1 / 100.0f;
         refresh_derived(h, c);
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -723,8 +746,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_LOCAL_OSCILLATOR:
         if (std::abs(iv) > h->cfg.inputRate) return fail(FMX_E_INVALID, "|lo| must be <= inputRate (oscillator.cpp:49-58)"); break;
     case FMX_P_SQUELCH_MODE:
-        if (iv == 1) return fail(FMX_E_UNSUPPORTED, "the noise squelch (two order-20 IIR filters) is not built; 0 = off, 2 = level squelch");
-        if (iv != 0 && iv != 2) return fail(FMX_E_INVALID, "squelch mode must be 0, 1 or 2"); break;
+        if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "squelch mode must be 0 (off), 1 (noise squelch) or 2 (level squelch)"); break;
     case FMX_P_SQUELCH_VALUE: if (iv < 0 || iv > 100) return fail(FMX_E_INVALID, "squelch value must be 0..100"); break;
     case FMX_P_DISP_DELAY: if (iv < 0 || iv > 100000) return fail(FMX_E_INVALID, "display delay must be 0..100000 steps"); break;
     case FMX_P_TEST_TONE:
@@ -858,7 +880,7 @@ int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
     m->PilotPllLockStrength = st.meta_lock_strength; m->PilotPllLocked = st.meta_locked;
     m->live_pilot_locked = (h->params[channel].fm_mode != 2) ? st.pil_locked : 0;
     m->live_lock_strength = (h->params[channel].fm_mode != 2) ? st.pil_lock : 0.f;
-    m->live_dc_if = st.fm_afc; m->squelch_active = (h->params[channel].squelch_mode == 2) ? st.sq_suppress : 0;
+    m->live_dc_if = st.fm_afc; m->squelch_active = (h->params[channel].squelch_mode != 0) ? st.sq_suppress : 0;
     m->fm_samples = h->g_total / DECIM; m->pcm_frames = 48 * ((h->g_total / DECIM) / 192);
     return FMX_OK;
 }
@@ -1024,6 +1046,16 @@ int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32
         for (int k = 0; k < as.ntaps; k++) tmp[k] = t[as.ntaps - 1 - k];
         src = tmp.data(); cnt = as.ntaps; break; }
     case 3: src = h->h_rs_taps.data(); cnt = RS_TAPS; break;
+    case 4: {   // noise-squelch filters as the kernel holds them: [2][10][A1 A2 B1 B2], then the two gains (high-pass first)
+        const design::Iir hp = design::iir_chebyshev_lowhigh(true, 20, 70000 - 100, h->cfg.fmRate);
+        const design::Iir lp = design::iir_chebyshev_lowhigh(false, 20, 70000, h->cfg.fmRate);
+        tmp.assign(2 * NSQ_QUADS * 4 + 2, 0.f);
+        for (int f = 0; f < 2; f++) {
+            const design::Iir &F = f ? lp : hp;
+            for (int i = 0; i < NSQ_QUADS; i++) { tmp[(f * NSQ_QUADS + i) * 4] = F.q[i][1]; tmp[(f * NSQ_QUADS + i) * 4 + 1] = F.q[i][2]; tmp[(f * NSQ_QUADS + i) * 4 + 2] = F.q[i][4]; tmp[(f * NSQ_QUADS + i) * 4 + 3] = F.q[i][5]; }
+            tmp[2 * NSQ_QUADS * 4 + f] = F.gain;
+        }
+        src = tmp.data(); cnt = (int)tmp.size(); break; }
     default: return fail(FMX_E_INVALID, "unknown tap-set id");
     }
     if (cnt > capacity) return fail(FMX_E_TOO_LARGE, "capacity too small");

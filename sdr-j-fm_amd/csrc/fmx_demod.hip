@@ -330,6 +330,18 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     const float sq_thr = B.params[ch].squelch_thr;
     int sq_cnt = st->sq_count; bool sq_sup = st->sq_suppress != 0;
     float am = st->am_carr;
+    // noise squelch (squelch::do_noise_squelch squelchClass.cpp:47-87): |high-pass 69.9 kHz| against |low-pass 70 kHz| of the
+    // demodulator output, two order-20 Chebyshev cascades (Basic_IIR::Pass iir-filters.h:89-103, same f32 operation order)
+    const bool nsq = PLLDEC && (B.params[ch].squelch_mode == 1) && T.nsq_coef != nullptr;
+    const float nsq_thr = B.params[ch].squelch_nthr;
+    // (the forty filter memories of a lane live in LDS, [memory][lane]: the AFC role has the wave's LDS buffer to itself, and
+    // forty more live registers would push the PLL-decoder / AM / level-squelch paths of this body into scratch)
+    float *nmem = reinterpret_cast<float *>(g_rec_lds) + threadIdx.x;
+    float avg_hi = 0.f, avg_lo = 0.f;
+    if (PLLDEC && nsq) {
+        for (int k = 0; k < 4 * NSQ_QUADS; k++) nmem[64 * k] = (&st->sq_m[0][0][0])[k];
+        avg_hi = st->sq_avg_hi; avg_lo = st->sq_avg_lo;
+    }
     const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha, K = T.K_FM, rK = T.K_FM_rcp;
     const double SC = T.sincos_C;
     float afc = st->fm_afc, nco_phase = st->nco_phase, incr = st->phase_incr;
@@ -375,6 +387,38 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
         }
         return r;
     };
+    // the noise squelch of one demodulator output (a pass of its own behind `step`, in rolled loops: inlined sixteen times
+    // into the unrolled tile body it pushed every path of this body into scratch memory)
+    auto nsq1 = [&](float r) __attribute__((always_inline)) -> float {
+        float val[2];
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            const float *cf = T.nsq_coef + f * NSQ_QUADS * 4;
+            float o = r * T.nsq_coef[2 * NSQ_QUADS * 4 + f];
+#pragma unroll 1
+            for (int i = 0; i < NSQ_QUADS; i++) {
+                float *m = nmem + 64 * 2 * (f * NSQ_QUADS + i);               // (m1, m2) of this biquad
+                const float rm1 = m[0], rm2 = m[64];
+                const float w = o - rm1 * cf[4 * i + 2] - rm2 * cf[4 * i + 3];
+                o = w + rm1 * cf[4 * i] + rm2 * cf[4 * i + 1];
+                m[64] = rm1; m[0] = w;
+            }
+            val[f] = fabsf(o);
+        }
+        // decayingAverage squelchClass.cpp:40-45, weight = sampleRate / 100, evaluated in double
+        const double k1 = 1.0 / (double)(float)(SINCOS_N / 100), k2 = 1.0 - k1;
+        avg_hi = (float)((double)val[0] * k1 + (double)avg_hi * k2);
+        avg_lo = (float)((double)val[1] * k1 + (double)avg_lo * k2);
+        if (++sq_cnt >= SINCOS_N / 20) {
+            sq_cnt = 0;
+            if (nsq_thr < 0.001f) sq_sup = true;                                   // SQUELCH_HYSTERESIS_NSQ = 0.001
+            else if (avg_hi < avg_lo * nsq_thr - 0.001f) sq_sup = false;
+            else if (avg_hi >= avg_lo * nsq_thr + 0.001f) sq_sup = true;
+        }
+        return sq_sup ? r * 0.000f : r;
+    };
+    const bool nsq_wave = PLLDEC && __any(nsq);
+    float *nsx = reinterpret_cast<float *>(g_rec_lds) + 64 * 4 * NSQ_QUADS + threadIdx.x;      // [16][lane] staging of a tile's outputs
     constexpr int UB = SEQ_UB;
     const int nfull = chunk_len / UB;
     const int TS = UB * CP;                                       // elements from one tile of this channel to the next
@@ -397,15 +441,33 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
             }
 #pragma unroll
             for (int k = 0; k < UB; k++) x[k] = step(x[k], xq[k]);
+            if (PLLDEC && nsq_wave) {
+#pragma unroll
+                for (int k = 0; k < UB; k++) nsx[64 * k] = x[k];
+                if (nsq) {
+#pragma unroll 1
+                    for (int k = 0; k < UB; k++) nsx[64 * k] = nsq1(nsx[64 * k]);
+                }
+#pragma unroll
+                for (int k = 0; k < UB; k++) x[k] = nsx[64 * k];
+            }
             wst(wd + tb * TS, x);
         });
     {
         float *wdt = wd + nfull * TS; const float2 *wiqt = PLLDEC ? wiq + nfull * TS : nullptr;
         for (int k = 0; k < chunk_len - nfull * UB; k++)          // ragged end of a call: rows of the last, partial tile
-            wdt[k] = step(wdt[k], PLLDEC ? wiqt[k] : make_float2(0.f, 0.f));
+        {
+            float r = step(wdt[k], PLLDEC ? wiqt[k] : make_float2(0.f, 0.f));
+            if (PLLDEC && nsq) r = nsq1(r);
+            wdt[k] = r;
+        }
     }
     st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr; st->am_carr = am;
     if (PLLDEC) { st->sq_count = sq_cnt; st->sq_suppress = sq_sup ? 1 : 0; }
+    if (PLLDEC && nsq) {
+        st->sq_avg_hi = avg_hi; st->sq_avg_lo = avg_lo;
+        for (int k = 0; k < 4 * NSQ_QUADS; k++) (&st->sq_m[0][0][0])[k] = nmem[64 * k];
+    }
 }
 template <bool PLLDEC>
 __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len) {

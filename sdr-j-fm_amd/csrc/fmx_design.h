@@ -139,5 +139,55 @@ inline std::vector<double> convolve(const std::vector<double> &a, const std::vec
 }
 inline std::vector<double> to_double(const std::vector<float> &a) { return std::vector<double>(a.begin(), a.end()); }
 
+
+// ---- recursive filters of the noise squelch: iir-filters.cpp (Chebyshev prototype newChebyshev :165-218, LowPassIIR :451-490,
+// HighPassIIR :497-540, Bilineair :73-109).  DSPFLOAT = float there; a libm call takes the overload of its argument type
+// (float arguments -> float functions, expressions with M_PI / 10.0 / 0.1 -> double, narrowed on assignment).
+struct Iir { int nq; float q[16][6]; float gain; };        // per biquad A0 A1 A2 B0 B1 B2
+inline float iir_chebyshev(float q[][6], int nq, int order, int apass) {
+    const float Eps = (float)std::sqrt(std::pow(10.0, -0.1 * apass) - 1);
+    const float x = (float)(1.0 / Eps);
+    const float D = std::log(x + std::sqrt(x * x + 1)) / order;                 // sinhm1 :48-51 (float overloads)
+    const float sinhD = std::sinh(D), coshD = std::cosh(D);
+    int i0 = 0;
+    if (order & 1) { q[0][0] = 0; q[0][1] = 0; q[0][2] = sinhD; q[0][3] = 0; q[0][4] = 1; q[0][5] = sinhD; i0 = 1; }
+    for (int i = i0; i < nq; i++) {
+        const float Phim = (order & 1) ? (float)(kPi * (2 * (i - 1) + 1) / (2 * order)) : (float)(kPi * (2 * i + 1) / (2 * order));
+        const float sigma = -sinhD * std::sin(Phim), omega = coshD * std::cos(Phim);
+        q[i][0] = 0; q[i][1] = 0; q[i][2] = sigma * sigma + omega * omega;
+        q[i][3] = 1; q[i][4] = -2 * sigma; q[i][5] = sigma * sigma + omega * omega;
+    }
+    return (order & 1) == 0 ? (float)std::pow(10.0, 0.05 * apass) : 1.0f;
+}
+inline float iir_bilinear(float q[][6], int fs, int nq) {
+    float gain = 1.0f;
+    const float f2 = (float)(2 * fs), f4 = f2 * f2;
+    for (int i = 0; i < nq; i++) {
+        float *c = q[i];
+        const float N0 = c[0] * f4 + c[1] * f2 + c[2], N1 = 2 * (c[2] - c[0] * f4), N2 = c[0] * f4 - c[1] * f2 + c[2];
+        const float D0 = c[3] * f4 + c[4] * f2 + c[5], D1 = 2 * (c[5] - c[3] * f4), D2 = c[3] * f4 - c[4] * f2 + c[5];
+        c[0] = 1.0f; c[1] = N1 / N0; c[2] = N2 / N0; c[3] = 1.0f; c[4] = D1 / D0; c[5] = D2 / D0;
+        gain *= (N0 / D0);
+    }
+    return gain;
+}
+inline Iir iir_chebyshev_lowhigh(bool highpass, int order, int32_t fpass, int32_t fs) {
+    Iir f{}; f.nq = ((order + 1) & 0176) / 2;
+    if (2 * fpass >= fs) fpass = fs / 4;
+    const float omega = (float)(2.0 * fs * std::tan((2 * kPi * fpass) / (2 * fs)));      // warpDtoA :111-113
+    f.gain = iir_chebyshev(f.q, f.nq, order, -1);
+    for (int i = 0; i < f.nq; i++) {
+        float *c = f.q[i];
+        if (!highpass) { c[1] = c[1] * omega; c[4] = c[4] * omega; c[2] = c[2] * omega * omega; c[5] = c[5] * omega * omega; }
+        else {
+            const float A0 = c[0], A1 = c[1], A2 = c[2], B0 = c[3], B1 = c[4], B2 = c[5];
+            f.gain *= A2 / B2;
+            c[0] = 1.0f; c[3] = 1.0f; c[1] = (A1 / A2) * omega; c[4] = (B1 / B2) * omega;
+            c[2] = (A0 / A2) * omega * omega; c[5] = (B0 / B2) * omega * omega;
+        }
+    }
+    f.gain *= iir_bilinear(f.q, fs, f.nq);
+    return f;
+}
 }  // namespace design
 }  // namespace fmx

@@ -21,6 +21,7 @@ constexpr int AUDIO_DELAY = 8192 - 756;
 constexpr int C_MAX_TAPS = AUDIO_TAPS + RS_TAPS - 1;   // 883
 constexpr int C_TAPS_STRIDE = 896;     // padded
 constexpr int C_TILE = 256;            // PCM frames per audio-FIR tile
+constexpr int NSQ_QUADS = 10;          // ((20 + 1) & 0176) / 2 biquads per filter (iir-filters.cpp:454)
 constexpr int TT_SILENT = 96001;       // ++TimePeriodCounter > workingRate * 2.0f fires on the 96001st silent frame (fm-processor.cpp:816-817)
 constexpr int TT_BURST = 1200;         // workingRate * 0.025f (:819)
 constexpr int TT_CYCLE = TT_SILENT + TT_BURST;
@@ -59,7 +60,7 @@ struct ChanParams {
     int32_t squelch_mode;   // 0 off, 2 level squelch (set_squelchMode)
     float   squelch_thr;    // levelSquelchThreshold squelchClass.cpp:35
     int32_t test_tone;      // setTestTone fm-processor.cpp:931-933
-    int32_t pad1;
+    float   squelch_nthr;   // noiseSquelchThreshold squelchClass.cpp:36
 };
 enum { ACT_TRIGGER_FREQ = 1, ACT_RESTART_PSS = 2, ACT_DC_RESET = 4 };
 
@@ -98,6 +99,9 @@ struct ChanState {
     int32_t pk_cnt;
     float   pk_l, pk_r;
     int32_t pk_events, pad1;
+    // noise squelch (squelchClass.cpp:47-87): decaying averages and the (m1, m2) memories of the two order-20 filters
+    float   sq_avg_hi, sq_avg_lo;
+    float   sq_m[2][NSQ_QUADS][2];
 };
 
 // Work arrays of stage B (w_*): element (row r, channel ch) lives at ((r / 16) * pitch + ch) * 16 + r % 16 -- tiles of 16
@@ -125,6 +129,7 @@ struct DeviceTables {
     float   K_FM, K_FM_rcp, pil_omega_rcp;   // rcp = RN(1/c) for fdiv_const
     float   pil_omega, pil_gain, pss_alpha, pss_lock_alpha;
     float   pll_beta, pll_lo, pll_hi, pll_center;
+    const float *nsq_coef;       // [2][NSQ_QUADS][4] (A1, A2, B1, B2) + [2] gains: high-pass 69.9 kHz, low-pass 70 kHz (squelchClass.cpp:11-18); null until used
     float   wrap32_c;            // fl32(fl32_above(2 pi) - 2 pi)
     int32_t wrap32_ok;           // the f32 form of the pilot-phase wrap was verified on the host for every float it can see
 };

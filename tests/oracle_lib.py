@@ -148,6 +148,10 @@ def oracle():
         "fmo_chain_meta": (None, [vp, C.POINTER(FmoMeta)]),
         "fmo_chain_rds_bits": (lng, [vp, c_u8_p, lng]),
         "fmo_chain_peaks": (lng, [vp, c_float_p, lng]),
+        "fmo_iir_new": (vp, [C.c_int, C.c_int, i32, i32, i32, C.c_int]),
+        "fmo_iir_free": (None, [vp]),
+        "fmo_iir_coeffs": (C.c_int, [vp, c_float_p]),
+        "fmo_iir_run": (None, [vp, c_float_p, lng, c_float_p]),
         "fmo_test_tone_burst": (None, [i32, c_float_p, lng]),
         "fmo_siggen_new": (vp, [C.POINTER(FmoSiggenConfig)]),
         "fmo_siggen_free": (None, [vp]),
@@ -212,6 +216,10 @@ def ref():
         "ref_pss_run": (None, [i32, f32, c_float_p, c_float_p, lng, c_float_p, c_u8_p]),
         "ref_agc_run": (None, [f32, f32, f32, c_float_p, lng, c_float_p]),
         "ref_costas_run": (None, [f32, f32, f32, f32, c_float_p, lng, c_float_p]),
+        "ref_iir_new": (vp, [C.c_int, C.c_int, i32, i32, i32, C.c_int]),
+        "ref_iir_free": (None, [vp]),
+        "ref_iir_coeffs": (C.c_int, [vp, c_float_p]),
+        "ref_iir_run": (None, [vp, c_float_p, lng, c_float_p]),
         "ref_chain_new": (vp, [i32, i32, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_int]),
         "ref_chain_free": (None, [vp]),

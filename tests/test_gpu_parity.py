@@ -486,11 +486,58 @@ def test_test_tone_and_peak_meter(fmx_amd, ol):
     assert rms(po1[start:start + 1200, 0]) > 0.5
 
 
+def test_noise_squelch(fmx_amd, ol):
+    """set_squelchMode NSQ (squelch::do_noise_squelch squelchClass.cpp:47-87): the two order-20 Chebyshev filters of the kernel are
+    the oracle's (= the reference's, test_oracle_vs_ref) coefficient for coefficient; a channel with programme stays open, a
+    channel of noise is muted, call by call as in the oracle; the slider value changes the decision at the next call."""
+    L = ol.oracle()
+    f0 = fmx_amd.Fmx(1, max_block=16384)
+    co = f0.taps(4)
+    for f, (kind, fc) in enumerate([(1, 69900), (0, 70000)]):
+        h = L.fmo_iir_new(kind, 20, fc, 0, 192000, 0o100)
+        c = np.zeros(64, np.float32)
+        nq = L.fmo_iir_coeffs(h, ol.fptr(c))
+        L.fmo_iir_free(h)
+        assert nq == 10
+        q = c[:60].reshape(10, 6)
+        assert np.array_equal(co[f * 40:(f + 1) * 40].reshape(10, 4).view(np.uint32), q[:, [1, 2, 4, 5]].copy().view(np.uint32))
+        assert co[80 + f] == c[60]
+    block = 16384 * 6
+    nb = 14
+    n = block * nb
+    sig = ol.synth_iq(n)
+    noise = ol.synth_iq(n, carrierAmp=0.0, noiseSeed=77, noiseSigma=0.3)
+    f = fmx_amd.Fmx(2, max_block=block)
+    gui_defaults(f)
+    f.set_param(M.P_SQUELCH_MODE, 1)
+    f.set_param(M.P_SQUELCH_VALUE, 60)
+    chains = [ol.OracleChain(inputFilterBw=165000, squelchMode=1, squelchValue=60) for _ in range(2)]
+    fl_g, fl_o, pg, po = [], [], [], [[], []]
+    for b in range(nb):
+        if b == 8:                                           # open the noise channel again: threshold 0.7 * low band
+            f.set_param(M.P_SQUELCH_VALUE, 30, channel=1)
+            chains[1].configure(squelchValue=30)
+        x = np.stack([sig[b * block:(b + 1) * block], noise[b * block:(b + 1) * block]])
+        pg.append(f.process_host(x))
+        for c in range(2):
+            po[c].append(chains[c].process(x[c]))
+        fl_g.append([f.meta(c).squelch_active for c in range(2)])
+        fl_o.append([chains[c].meta().squelchActive for c in range(2)])
+    pg = np.concatenate(pg, axis=1)
+    print("\n[noise squelch] flags (signal, noise) per call:", fl_g)
+    assert fl_g == fl_o
+    assert [r[0] for r in fl_g] == [0] * nb and fl_g[4][1] == 1 and fl_g[-1][1] == 0
+    for c in range(2):
+        e = rms(pg[c] - np.concatenate(po[c]))
+        print(f"[noise squelch] ch{c} pcm rms {e:.3e}")
+        assert e <= PCM_RMS_TOL
+
+
 def test_error_behaviour(fmx_amd):
     f = fmx_amd.Fmx(2, max_block=16384)
     for pid, v, code in [(M.P_FM_MODE, 3, M.FMX_E_INVALID), (M.P_FM_DECODER, 0, M.FMX_E_INVALID),
                          (M.P_FM_DECODER, 9, M.FMX_E_INVALID), (M.P_DEEMPHASIS, 0, M.FMX_E_INVALID),
-                         (M.P_SQUELCH_MODE, 1, M.FMX_E_UNSUPPORTED), (M.P_RDS_MODE, 1, M.FMX_E_UNSUPPORTED),
+                         (M.P_SQUELCH_MODE, 3, M.FMX_E_INVALID), (M.P_RDS_MODE, 1, M.FMX_E_UNSUPPORTED),
                          (M.P_RDS_MODE, 3, M.FMX_E_UNSUPPORTED), (M.P_RDS_MODE, 4, M.FMX_E_INVALID),
                          (M.P_SOUND_MODE, 7, M.FMX_E_INVALID), (999, 0, M.FMX_E_INVALID)]:
         with pytest.raises(fmx_amd.FmxError) as e:

@@ -184,3 +184,24 @@ def test_chain_against_reference_wired_leaf_classes():
     assert crc(ch.tap(ol.TAP_DEMOD)) == int(G["chain1_demod_crc"])
     assert crc(ch.tap(ol.TAP_PRE_RS)) == int(G["chain1_prers_crc"])
     assert_bitexact(ch.tap(ol.TAP_PRE_RS)[-4096:], G["chain1_prers_tail"], "config-1 pre-resampler tap")
+
+
+def test_recursive_filters():
+    """iir-filters.cpp (LowPassIIR / HighPassIIR, Chebyshev and Butterworth prototypes, bilinear transform, Basic_IIR::Pass):
+    coefficients and responses of the reference's own classes (tests/golden/ref_iir.npz), among them the two order-20
+    filters of the noise squelch (squelchClass.cpp:11-18)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    GI = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_iir.npz"))
+    x = GI["iir_in"]
+    for name, kind, order, f1, ftype in mg.IIR_CASES:
+        f = O.fmo_iir_new(kind, order, f1, 0, 192000, ftype)
+        c = np.zeros(128, np.float32)
+        nq = O.fmo_iir_coeffs(f, fptr(c))
+        y = np.zeros_like(x)
+        O.fmo_iir_run(f, fptr(x), x.size, fptr(y))
+        O.fmo_iir_free(f)
+        assert_bitexact(c[:6 * nq + 1], GI[name + "_coef"], name + " coefficients")
+        assert_bitexact(y, GI[name + "_out"], name + " response")
