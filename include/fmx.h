@@ -68,8 +68,8 @@ typedef enum {
     FMX_P_BANDWIDTH = 9,       /* setBandwidth, Hz (the GUI's "165kHz" -> 165000); 0 = "Off" (:232-239) */
     FMX_P_ATTENUATION_L = 10,  /* setAttenuation (Lgain)                             (:351-359)  */
     FMX_P_ATTENUATION_R = 11,  /* setAttenuation (Rgain)                                         */
-    FMX_P_RDS_MODE = 12,       /* setfmRdsSelector: 0 off, 2 = RDS_2 (rds-decoder-2.cpp); 1 and 3 are
-                                  FMX_E_UNSUPPORTED                                  (:840-847)  */
+    FMX_P_RDS_MODE = 12,       /* setfmRdsSelector: 0 off, 1 = RDS_1 (rds-decoder-1.cpp), 2 = RDS_2 (rds-decoder-2.cpp);
+                                  3 is FMX_E_UNSUPPORTED                             (:840-847)  */
     FMX_P_LOCAL_OSCILLATOR = 13,/* set_localOscillator, Hz                           (:866-868)  */
     FMX_P_AUTO_MONO = 14,      /* setAutoMonoMode                                    (:914-916)  */
     FMX_P_PSS = 15,            /* setPSSMode                                         (:918-920)  */
@@ -201,7 +201,8 @@ int  fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity
 
 /* introspection used by the parity tests: the filter taps the kernels run with.
  * which: 0 front-end polyphase taps, 1 PSS low-pass, 2 audio+resampler FIR, 3 resampler alone,
- * 4 the noise squelch's two order-20 filters: [2][10] x (A1, A2, B1, B2), then the two gains (high-pass first) */
+ * 4 the noise squelch's two order-20 filters: [2][10] x (A1, A2, B1, B2), then the two gains (high-pass first),
+ * 5 the RDS_1 decoder's constants: rdsFilter taps [21], matched filter [43], band-pass [8] x (A1, A2, B1, B2), gain */
 int  fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32_t capacity, int32_t *n);
 
 int  fmx_profile_enable(fmx_handle h, int32_t on);

@@ -848,9 +848,9 @@ float fmo_iir_pass(fmo_iir *f, float v) {                                       
     return o;
 }
 void *fmo_iir_new(int kind, int order, int32_t f1, int32_t f2, int32_t fs, int ftype) {
-    (void)f2;
     fmo_iir *f = (fmo_iir *)calloc(1, sizeof(*f));
-    if (kind == 0) fmo_iir_lowpass(f, order, f1, fs, ftype); else fmo_iir_highpass(f, order, f1, fs, ftype);
+    if (kind == 0) fmo_iir_lowpass(f, order, f1, fs, ftype); else if (kind == 1) fmo_iir_highpass(f, order, f1, fs, ftype);
+    else fmo_iir_bandpass(f, order, f1, f2, fs, ftype);
     return f;
 }
 void fmo_iir_free(void *p) { free(p); }
@@ -861,6 +861,117 @@ int fmo_iir_coeffs(void *p, float *out) {
     return f->nq;
 }
 void fmo_iir_run(void *p, const float *in, long n, float *out) { fmo_iir *f = (fmo_iir *)p; for (long i = 0; i < n; i++) out[i] = fmo_iir_pass(f, in[i]); }
+
+
+/* BandPassIIR iir-filters.cpp:552-595 with unnormalizeBP :325-385 and cQuadratic :308-313.  DSPCOMPLEX = std::complex<float>:
+ * its * and / are the compiler's complex multiply / divide (__mulsc3 / __divsc3), std::sqrt(complex<float>) is csqrtf --
+ * the same three library routines C99's float complex uses. */
+static void iir_cquadratic(float complex A, float complex B, float complex Cc, float complex *D, float complex *E) {
+    const float complex AC = A * Cc;
+    const float complex t = csqrtf(B * B - CMPLXF(crealf(AC) * 4.0f, cimagf(AC) * 4.0f));
+    const float complex A2 = CMPLXF(crealf(A) * 2.0f, cimagf(A) * 2.0f);
+    *D = (-B + t) / A2;
+    *E = (-B - t) / A2;
+}
+void fmo_iir_bandpass(fmo_iir *f, int order, int32_t flow, int32_t fhigh, int32_t fs, int ftype) {
+    memset(f, 0, sizeof(*f));
+    f->nq = (order + 1) & 0176;                       /* Basic_IIR ((order + 1) & MAXORDER) */
+    order = (order + 1) & 0176;
+    float temp[FMO_IIR_MAXQ][6];
+    if (flow >= fs / 2) flow = (int)(0.2 * fs);
+    if (fhigh >= fs / 2) fhigh = (int)(0.3 * fs);
+    const float omegaL = iir_warpDtoA(flow, fs), omegaH = iir_warpDtoA(fhigh, fs);
+    const float Wo = sqrtf(omegaL * omegaH), BW = omegaH - omegaL;
+    const int nb = f->nq / 2;
+    f->gain = iir_normalized(temp, nb, order, -1, ftype);
+    for (int i = 0; i < nb; i++) {                    /* unnormalizeBP */
+        float *t = temp[i], *q0 = f->q[2 * i], *q1 = f->q[2 * i + 1];
+        float complex A, B, Cc, D, E;
+        if (t[0] == 0.0) {
+            q0[0] = 0.0f; q0[1] = sqrtf(t[2]) * BW; q0[2] = 0.0f;
+            q1[0] = 0.0f; q1[1] = sqrtf(t[2]) * BW; q1[2] = 0.0f;
+        } else {
+            A = CMPLXF(t[0], 0.0f); B = CMPLXF(t[1], 0.0f); Cc = CMPLXF(t[2], 0.0f);
+            iir_cquadratic(A, B, Cc, &D, &E);
+            A = CMPLXF(1.0f, 0.0f); B = CMPLXF(crealf(-D) * BW, cimagf(-D) * BW); Cc = CMPLXF(Wo * Wo, 0.0f);
+            iir_cquadratic(A, B, Cc, &D, &E);
+            q0[0] = 1.0f; q0[1] = (float)(-2.0 * crealf(D)); q0[2] = crealf(D * conjf(D));
+            q1[0] = 1.0f; q1[1] = (float)(-2.0 * crealf(E)); q1[2] = crealf(E * conjf(E));
+        }
+        A = CMPLXF(t[3], 0.0f); B = CMPLXF(t[4], 0.0f); Cc = CMPLXF(t[5], 0.0f);
+        iir_cquadratic(A, B, Cc, &D, &E);
+        A = CMPLXF(1.0f, 0.0f); B = CMPLXF(crealf(-D) * BW, cimagf(-D) * BW); Cc = CMPLXF(Wo * Wo, 0.0f);
+        iir_cquadratic(A, B, Cc, &D, &E);
+        q0[3] = 1.0f; q0[4] = (float)(-2.0 * crealf(D)); q0[5] = crealf(D * conjf(D));
+        q1[3] = 1.0f; q1[4] = (float)(-2.0 * crealf(E)); q1[5] = crealf(E * conjf(E));
+    }
+    f->gain *= 1.0f;                                   /* unnormalizeBP returns 1.0 */
+    f->gain *= iir_bilinear(f->q, fs, f->nq);
+}
+
+/* ------------------------------------------------------------------ RDS decoder 1 (rds-decoder-1.cpp:43-142), behind the
+ * rdsDecoder's own Costas loop (rds-decoder.cpp:40-41,76-84) */
+#define RDS1_MATCH 43
+typedef struct {
+    fmo_costas costas;                               /* my_costas (rate, 1/16, 0.02/16, 10) */
+    float fir[21], firbuf[21]; int firip;            /* rdsFilter (21, RDS_WIDTH, rate): LowPassFIR, real Pass fir-filters.h:96-108 */
+    float kernel[RDS1_MATCH], buf[RDS1_MATCH]; int ip;
+    fmo_iir sharp;                                   /* sharpFilter (7, 1187.5 - 6, 1187.5 + 6, rate, S_BUTTERWORTH): int32 arguments */
+    float lastSyncSlope, lastSync, lastData; int previousBit;
+} rds1;
+static void rds1_init(rds1 *r, int32_t rate) {
+    memset(r, 0, sizeof(*r));
+    fmo_costas_init(&r->costas, (float)rate, 1.0f / 16.0f, 0.02f / 16.0f, 10.0f);
+    fmo_lowpass_kernel(21, 2 * 2400, rate, r->fir);
+    fmo_iir_bandpass(&r->sharp, 7, (int32_t)(1187.5 - 6), (int32_t)(1187.5 + 6), rate, FMO_IIR_BUTTERWORTH);
+    const float synchronizerSamples = rate / (float)1187.5;
+    const int symbolCeiling = (int)ceilf(synchronizerSamples);
+    const int length = (symbolCeiling & ~01) + 1;     /* 21; rdsBufferSize = 2 * length + 1 = 43 */
+    r->kernel[length] = 0;
+    for (int i = 1; i <= length; i++) {
+        const float x = (float)(((float)i) / rate * 1187.5);
+        r->kernel[length + i] = (float)(0.75 * cos(4 * M_PI * x) * ((1.0 / (1.0 / x - 64.01 * x)) - ((1.0 / (9.0 / x - 64.01 * x)))));
+        r->kernel[length - i] = (float)(-0.75 * cos(4 * M_PI * x) * ((1.0 / (1.0 / x - 64.01 * x)) - ((1.0 / (9.0 / x - 64.01 * x)))));
+    }
+}
+void fmo_rds1_coeffs(float *out /* 21 + 43 + 8 * 4 + 1 */) {
+    rds1 r; rds1_init(&r, 24000);
+    memcpy(out, r.fir, sizeof(float) * 21); memcpy(out + 21, r.kernel, sizeof(float) * RDS1_MATCH);
+    for (int i = 0; i < r.sharp.nq; i++) { out[64 + 4 * i] = r.sharp.q[i][1]; out[64 + 4 * i + 1] = r.sharp.q[i][2]; out[64 + 4 * i + 2] = r.sharp.q[i][4]; out[64 + 4 * i + 3] = r.sharp.q[i][5]; }
+    out[64 + 4 * r.sharp.nq] = r.sharp.gain;
+}
+static int rds1_decode(rds1 *r, c32 z, c32 *m, uint8_t *d) {
+    z = fmo_costas_process(&r->costas, z);
+    *m = cscale(z, 4.0f);
+    float v = z.re;
+    {   /* rdsFilter.Pass */
+        float tmp = 0;
+        r->firbuf[r->firip] = v;
+        for (int i = 0; i < 21; i++) { int index = r->firip - i; if (index < 0) index += 21; tmp += r->firbuf[index] * r->fir[i]; }
+        r->firip = (r->firip + 1) % 21;
+        v = tmp;
+    }
+    {   /* Match :108-121 */
+        float tmp = 0;
+        r->buf[r->ip] = v;
+        for (int i = 0; i < RDS1_MATCH; i++) { int index = r->ip - i; if (index < 0) index += RDS1_MATCH; tmp += r->buf[index] * r->kernel[i]; }
+        r->ip = (r->ip + 1) % RDS1_MATCH;
+        v = tmp;
+    }
+    const float rdsMag = fmo_iir_pass(&r->sharp, v * v);
+    const float rdsSlope = rdsMag - r->lastSync;
+    int res = 0;
+    r->lastSync = rdsMag;
+    if ((rdsSlope < 0.0) && (r->lastSyncSlope >= 0.0)) {        /* top of the sine wave: get the data */
+        const int theBit = r->lastData >= 0 ? 1 : 0;
+        *d = (uint8_t)(theBit ^ r->previousBit);
+        r->previousBit = theBit;
+        res = 1;
+    }
+    r->lastData = v;
+    r->lastSyncSlope = rdsSlope;
+    return res;
+}
 
 typedef struct { float *buf; long cap, n; } tapbuf;
 
@@ -890,7 +1001,7 @@ struct fmo_chain {
     int32_t myCount;
     fmo_meta meta;
     resampler rs; c32 rsIn[192]; int rsInp;
-    rds2 rds; uint8_t *rdsBits; long rdsBitCount, rdsBitCap;
+    rds2 rds; rds1 rdsA; uint8_t *rdsBits; long rdsBitCount, rdsBitCap;
     /* block intake */
     c32 *pending; long npending;
     tapbuf taps[FMO_TAP_COUNT];
@@ -987,7 +1098,7 @@ fmo_chain *fmo_chain_new(const fmo_config *c) {
     ch->deemphAlpha = (float)(1.0 / (fmRate / (1000000.0 / 50.0 + 1)));
     ch->rdsDecim = fmo_decim_new(11, 24000 / 2, fmRate, fmRate / 24000);
     resampler_init(&ch->rs);
-    rds2_init(&ch->rds, 24000);
+    rds2_init(&ch->rds, 24000); rds1_init(&ch->rdsA, 24000);
     ch->rdsBitCap = 1 << 16; ch->rdsBits = (uint8_t *)malloc((size_t)ch->rdsBitCap);
     ch->pending = (c32 *)malloc(sizeof(c32) * BLOCK);
     ch->meta.peakLeftDb = ch->meta.peakRightDb = -40.0f;
@@ -1210,9 +1321,9 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
             c32 rdsSample;
             if (fmo_decim_pass(ch->rdsDecim, rdsData, &rdsSample)) {
                 tap2(ch, FMO_TAP_RDS_IQ, rdsSample);
-                if (ch->cfg.rdsMode == 2) {
+                if (ch->cfg.rdsMode == 2 || ch->cfg.rdsMode == 1) {
                     c32 mag; uint8_t bit;
-                    if (rds2_decode(&ch->rds, rdsSample, &mag, &bit)) {
+                    if (ch->cfg.rdsMode == 2 ? rds2_decode(&ch->rds, rdsSample, &mag, &bit) : rds1_decode(&ch->rdsA, rdsSample, &mag, &bit)) {
                         if (ch->rdsBitCount >= ch->rdsBitCap) {
                             ch->rdsBitCap *= 2;
                             ch->rdsBits = (uint8_t *)realloc(ch->rdsBits, (size_t)ch->rdsBitCap);

@@ -67,7 +67,7 @@ struct fmx_handle_s {
     // unique tap sets
     std::vector<int32_t> front_keys, audio_keys;
     int front_cap = 0, audio_cap = 0;
-    std::vector<float> h_front_taps, h_audio_taps, h_pss_taps, h_rs_taps, h_nsq;
+    std::vector<float> h_front_taps, h_audio_taps, h_pss_taps, h_rs_taps, h_nsq, h_rds1;
     float *d_nsq = nullptr;
     std::vector<FrontSet> h_front_sets; std::vector<AudioSet> h_audio_sets;
     // device
@@ -295,6 +295,23 @@ int ensure_rds(fmx_handle h) {
         HIPCHK(hipMemcpy(dr, rr.data(), sizeof(float) * 45, hipMemcpyHostToDevice));
         R.dec_taps = dd; R.rrc = dr;
     }
+    {   // RDS_1: Costas state, rdsFilter / Match / sharpFilter coefficients (rds-decoder-1.cpp:43-100), rings at 24 kS/s
+        if ((rc = dalloc((void **)&R.c_ring, sizeof(float) * C * RDS24_RING, true))) return rc;
+        if ((rc = dalloc((void **)&R.f_ring, sizeof(float) * C * RDS24_RING, true))) return rc;
+        if ((rc = dalloc((void **)&R.state1, sizeof(Rds1State) * C, true))) return rc;
+        std::vector<float> co = design::lowpass(RDS1_FIR, 2 * 2400, 24000);            // rdsFilter (21, RDS_WIDTH, rate)
+        const std::vector<float> mk = design::rds1_match_kernel(24000);
+        if ((int)mk.size() != RDS1_MATCH) return fail(FMX_E_HIP, "unexpected length of the RDS_1 matched filter");
+        co.insert(co.end(), mk.begin(), mk.end());
+        const design::Iir bp = design::iir_butterworth_bandpass(7, (int32_t)(1187.5 - 6), (int32_t)(1187.5 + 6), 24000);   // sharpFilter
+        if (bp.nq != RDS1_QUADS) return fail(FMX_E_HIP, "unexpected biquad count of the RDS_1 band-pass");
+        for (int i = 0; i < RDS1_QUADS; i++) { co.push_back(bp.q[i][1]); co.push_back(bp.q[i][2]); co.push_back(bp.q[i][4]); co.push_back(bp.q[i][5]); }
+        co.push_back(bp.gain);
+        float *dc;
+        if ((rc = dalloc((void **)&dc, sizeof(float) * co.size(), false))) return rc;
+        HIPCHK(hipMemcpy(dc, co.data(), sizeof(float) * co.size(), hipMemcpyHostToDevice));
+        R.rds1_coef = dc; h->h_rds1 = co;
+    }
     h->rds_read.assign(C, 0);
     h->rds_alloc = true;
     return FMX_OK;
@@ -412,7 +429,9 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         if (any_rds) {
             if (G.J1 - G.J0 > RDS_BLK) return fail(FMX_E_TOO_LARGE, "with RDS on, a call may cover at most 32000 fm samples (384000 input samples)");
             const int64_t n0 = G.J0 - h->rds_start;
-            launch_rds(h->B, h->R, G, h->channels, n0, s);
+            int modes = 0;
+            for (auto &p : h->params) modes |= 1 << p.rds_mode;
+            launch_rds(h->B, h->R, G, h->channels, n0, modes, s);
             h->last_m0 = n0 / 8; h->last_m1 = (n0 + (G.J1 - G.J0)) / 8;
         }
     }
@@ -739,7 +758,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_BANDWIDTH: if (iv < 0 || iv > h->cfg.inputRate) return fail(FMX_E_INVALID, "bandwidth out of range"); break;
     case FMX_P_RDS_MODE:
         if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "rds mode must be 0..3");
-        if (iv == 1 || iv == 3) return fail(FMX_E_UNSUPPORTED, "only the RDS_2 decoder (rds-decoder-2.cpp) is built");
+        if (iv == 3) return fail(FMX_E_UNSUPPORTED, "the RDS_3 decoder (rds-decoder-3.cpp) is not built; 1 = RDS_1, 2 = RDS_2");
         if (iv == 2 && h->rds_start >= 0 && h->rds_start != h->g_total / DECIM && h->params[channel < 0 ? 0 : channel].rds_mode == 0)
             return fail(FMX_E_UNSUPPORTED, "switch RDS on for all channels in the same call (shared overlap-add block phase)");
         break;
@@ -1055,6 +1074,14 @@ int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32
             for (int i = 0; i < NSQ_QUADS; i++) { tmp[(f * NSQ_QUADS + i) * 4] = F.q[i][1]; tmp[(f * NSQ_QUADS + i) * 4 + 1] = F.q[i][2]; tmp[(f * NSQ_QUADS + i) * 4 + 2] = F.q[i][4]; tmp[(f * NSQ_QUADS + i) * 4 + 3] = F.q[i][5]; }
             tmp[2 * NSQ_QUADS * 4 + f] = F.gain;
         }
+        src = tmp.data(); cnt = (int)tmp.size(); break; }
+    case 5: {   // RDS_1 constants as the kernels hold them: rdsFilter taps [21], Match kernel [43], sharpFilter [8][A1 A2 B1 B2], gain
+        tmp = design::lowpass(RDS1_FIR, 2 * 2400, 24000);
+        const std::vector<float> mk = design::rds1_match_kernel(24000);
+        tmp.insert(tmp.end(), mk.begin(), mk.end());
+        const design::Iir bp = design::iir_butterworth_bandpass(7, (int32_t)(1187.5 - 6), (int32_t)(1187.5 + 6), 24000);
+        for (int i = 0; i < bp.nq; i++) { tmp.push_back(bp.q[i][1]); tmp.push_back(bp.q[i][2]); tmp.push_back(bp.q[i][4]); tmp.push_back(bp.q[i][5]); }
+        tmp.push_back(bp.gain);
         src = tmp.data(); cnt = (int)tmp.size(); break; }
     default: return fail(FMX_E_INVALID, "unknown tap-set id");
     }

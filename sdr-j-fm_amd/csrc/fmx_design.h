@@ -5,6 +5,7 @@
 // host first reproduces the reference taps in the reference's own arithmetic and then convolves
 // them in double precision.  Every function cites the lines it follows.
 #pragma once
+#include <complex>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -188,6 +189,67 @@ inline Iir iir_chebyshev_lowhigh(bool highpass, int order, int32_t fpass, int32_
     }
     f.gain *= iir_bilinear(f.q, fs, f.nq);
     return f;
+}
+
+// BandPassIIR iir-filters.cpp:552-595 (Butterworth prototype newButterworth :120-163, unnormalizeBP :325-385, cQuadratic
+// :308-313): DSPCOMPLEX = std::complex<float>, whose *, / and std::sqrt are used exactly as the reference writes them.
+inline float iir_butterworth(float q[][6], int nq, int order, int apass) {
+    const float Eps = (float)std::sqrt(std::pow(10.0, -0.1 * apass) - 1);
+    const float R = (float)(1.0 / std::pow((double)Eps, 1.0 / order));
+    int i0 = 0;
+    if (order & 1) { q[0][0] = 0; q[0][1] = 0; q[0][2] = R; q[0][3] = 0; q[0][4] = 1; q[0][5] = R; i0 = 1; }
+    for (int i = i0; i < nq; i++) {
+        const float Phim = (order & 1) ? (float)(kPi * (2 * (i - 1) + order + 1) / (2 * order)) : (float)(kPi * (2 * i + order + 1) / (2 * order));
+        const float sigma = R * std::cos(Phim), omega = R * std::sin(Phim);
+        q[i][0] = 0; q[i][1] = 0; q[i][2] = sigma * sigma + omega * omega;
+        q[i][3] = 1; q[i][4] = -2 * sigma; q[i][5] = sigma * sigma + omega * omega;
+    }
+    return 1.0f;
+}
+inline void iir_cquadratic(std::complex<float> A, std::complex<float> B, std::complex<float> C, std::complex<float> *D, std::complex<float> *E) {
+    auto cmul = [](std::complex<float> x, float y) { return std::complex<float>(x.real() * y, x.imag() * y); };
+    const std::complex<float> temp = std::sqrt(B * B - cmul(A * C, 4.0f));
+    *D = (-B + temp) / cmul(A, 2.0f);
+    *E = (-B - temp) / cmul(A, 2.0f);
+}
+inline Iir iir_butterworth_bandpass(int order, int32_t flow, int32_t fhigh, int32_t fs) {
+    typedef std::complex<float> cf;
+    Iir f{}; f.nq = (order + 1) & 0176; order = (order + 1) & 0176;
+    float temp[16][6];
+    if (flow >= fs / 2) flow = (int)(0.2 * fs);
+    if (fhigh >= fs / 2) fhigh = (int)(0.3 * fs);
+    const float omegaL = (float)(2.0 * fs * std::tan((2 * kPi * flow) / (2 * fs))), omegaH = (float)(2.0 * fs * std::tan((2 * kPi * fhigh) / (2 * fs)));
+    const float Wo = std::sqrt(omegaL * omegaH), BW = omegaH - omegaL;
+    const int nb = f.nq / 2;
+    f.gain = iir_butterworth(temp, nb, order, -1);
+    for (int i = 0; i < nb; i++) {
+        float *t = temp[i], *q0 = f.q[2 * i], *q1 = f.q[2 * i + 1];
+        cf A, B, C, D, E;
+        // (Butterworth numerators have A0 == 0: the first branch of unnormalizeBP)
+        q0[0] = 0.0f; q0[1] = std::sqrt(t[2]) * BW; q0[2] = 0.0f;
+        q1[0] = 0.0f; q1[1] = std::sqrt(t[2]) * BW; q1[2] = 0.0f;
+        A = cf(t[3], 0.0f); B = cf(t[4], 0.0f); C = cf(t[5], 0.0f);
+        iir_cquadratic(A, B, C, &D, &E);
+        A = cf(1.0f, 0.0f); B = cf((-D).real() * BW, (-D).imag() * BW); C = cf(Wo * Wo, 0.0f);
+        iir_cquadratic(A, B, C, &D, &E);
+        q0[3] = 1.0f; q0[4] = (float)(-2.0 * D.real()); q0[5] = (D * std::conj(D)).real();
+        q1[3] = 1.0f; q1[4] = (float)(-2.0 * E.real()); q1[5] = (E * std::conj(E)).real();
+    }
+    f.gain *= iir_bilinear(f.q, fs, f.nq);
+    return f;
+}
+// rdsDecoder_1's matched filter, rds-decoder-1.cpp:48-92 (43 taps at 24 kS/s)
+inline std::vector<float> rds1_match_kernel(int32_t rate) {
+    const float synchronizerSamples = rate / (float)1187.5;
+    const int symbolCeiling = (int)std::ceil(synchronizerSamples);
+    const int length = (symbolCeiling & ~01) + 1;
+    std::vector<float> k((size_t)(2 * length + 1), 0.f);
+    for (int i = 1; i <= length; i++) {
+        const float x = (float)(((float)i) / rate * 1187.5);
+        k[length + i] = (float)(0.75 * std::cos(4 * kPi * x) * ((1.0 / (1.0 / x - 64.01 * x)) - ((1.0 / (9.0 / x - 64.01 * x)))));
+        k[length - i] = (float)(-0.75 * std::cos(4 * kPi * x) * ((1.0 / (1.0 / x - 64.01 * x)) - ((1.0 / (9.0 / x - 64.01 * x)))));
+    }
+    return k;
 }
 }  // namespace design
 }  // namespace fmx

@@ -186,6 +186,13 @@ struct RdsState {                           // rdsDecoder_2 + AGC + Costas state
     int32_t sample_count, skip, prev_bit, nbits;
     float2 sb0, sb1, sb2;
 };
+constexpr int RDS1_FIR = 21, RDS1_MATCH = 43, RDS1_QUADS = 8;
+struct Rds1State {                          // rdsDecoder's Costas (rds-decoder.cpp:40-41) + rdsDecoder_1 (rds-decoder-1.h:47-58)
+    float c_freq, c_phase;
+    float m1[RDS1_QUADS], m2[RDS1_QUADS];   // sharpFilter memories
+    float last_sync_slope, last_sync, last_data;
+    int32_t prev_bit;
+};
 struct RdsBuffers {
     float  *in_blk;      // [ch][32000]     demod samples of the block being filled
     float  *bpreal;      // [ch][2][32000]  real part of the band-pass block results (parity = block index & 1)
@@ -201,10 +208,14 @@ struct RdsBuffers {
     const float2 *S_bp, *S_hil;   // [32768] filter spectra
     const float2 *dec_taps;       // [11] rdsDecimator kernel (h/sum, h)
     const float *rrc;             // [45] matched filter
+    // RDS_1 (rds-decoder-1.cpp)
+    float  *c_ring, *f_ring;      // [ch][RDS24_RING] Re of the Costas output, and of rdsFilter's output
+    Rds1State *state1;
+    const float *rds1_coef;       // [21] rdsFilter taps, [43] match kernel, [8][A1 A2 B1 B2] sharpFilter, gain
     int32_t pitch;
 };
 #define C_RDS_PITCH(Rb) ((Rb).pitch)
-void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, int64_t n0, hipStream_t s);
+void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, int64_t n0, int modes, hipStream_t s);   // modes: bit k = some channel runs RDS_k
 
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s);

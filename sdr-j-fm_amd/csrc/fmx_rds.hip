@@ -196,7 +196,7 @@ __global__ void rds_mix_decim(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C,
 __global__ void rds_matched(DeviceBuffers B, RdsBuffers Rb, int64_t m0, int nout) {
     const int ch = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nout || B.params[ch].rds_mode == 0) return;
+    if (q >= nout || B.params[ch].rds_mode != 2) return;
     const int64_t m = m0 + q;
     float2 acc = make_float2(0.f, 0.f);
     for (int i = 0; i < 45; i++) {
@@ -213,7 +213,7 @@ __global__ void rds_matched(DeviceBuffers B, RdsBuffers Rb, int64_t m0, int nout
 //      agc.h:14-18, rds-decoder-2.cpp:101-157, costas.h:21-33
 __global__ __launch_bounds__(64) void rds_slicer(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
     const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= C || B.params[ch].rds_mode == 0) return;
+    if (ch >= C || B.params[ch].rds_mode != 2) return;
     RdsState st = Rb.state[ch];
     const int pitch = C_RDS_PITCH(Rb);
     const float sps = 24000.0f / 1187.5f;                   // samplesPerSymbol = rate / (float)RDS_BITCLK_HZ
@@ -262,6 +262,94 @@ __global__ __launch_bounds__(64) void rds_slicer(DeviceBuffers B, RdsBuffers Rb,
     Rb.state[ch] = st;
 }
 
+
+// =================================================================================================
+// RDS_1 (setfmRdsSelector 1): rdsDecoder::doDecode rds-decoder.cpp:76-84 -> rdsDecoder_1::doDecode rds-decoder-1.cpp:124-142
+//   Costas (1/16, 0.02/16, +-10 Hz)  [lane per channel]  ->  rdsFilter (21-tap low-pass) -> Match (43 taps)  [time-parallel,
+//   each output summed in the reference's tap order]  ->  sharpFilter (order-7 Butterworth band-pass on v^2, eight biquads),
+//   slope detector, differential decode  [lane per channel]
+// =================================================================================================
+__device__ __forceinline__ float pi_constrain_generic(float ph) {                 // PI_Constrain fm-constants.h:149-158
+    const double pv = (double)ph;
+    if (0.0 <= pv && pv < 6.283185307179586) return ph;
+    if (pv >= 6.283185307179586) return (float)fmod(pv, 6.283185307179586);
+    if (pv > -6.283185307179586) return (float)(pv + 6.283185307179586);
+    return (float)(6.283185307179586 - fmod(-pv, 6.283185307179586));
+}
+__global__ __launch_bounds__(64) void rds1_costas(DeviceBuffers B, RdsBuffers Rb, int C, int64_t m0, int nout) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C || B.params[ch].rds_mode != 1) return;
+    Rds1State *st = Rb.state1 + ch;
+    float freq = st->c_freq, phase = st->c_phase;
+    const float alpha = 1.0f / 16.0f, beta = 0.02f / 16.0f, lim = (float)(2 * 3.14159265358979323846 * (double)10.0f / (double)(float)24000);
+    const float2 *in = Rb.rds24 + (size_t)ch * RDS24_RING;
+    float *out = Rb.c_ring + (size_t)ch * RDS24_RING;
+    for (int q = 0; q < nout; q++) {
+        const int64_t m = m0 + q;
+        const float2 z = in[(int)(m & (RDS24_RING - 1))];
+        const float2 r = cmulf(z, make_float2(cosf(-phase), sinf(-phase)));       // z * std::exp(complex(0, -phase))  costas.h:22
+        const float err = r.x * r.y;
+        freq += beta * err;
+        if (fabsf(freq) > lim) freq = 0.f;
+        phase += freq + alpha * err;
+        phase = pi_constrain_generic(phase);
+        out[(int)(m & (RDS24_RING - 1))] = r.x;                                   // decoder_1 -> doDecode (real (v), ...)
+    }
+    st->c_freq = freq; st->c_phase = phase;
+}
+// out[m] = sum_i ring_in[m - i] * taps[i], i ascending from a zero accumulator (Basic_FIR::Pass fir-filters.h:96-108, Match :108-121)
+template <int NT>
+__global__ __launch_bounds__(256) void rds1_fir(DeviceBuffers B, const float *__restrict__ rin, float *__restrict__ rout,
+                                                const float *__restrict__ taps, int64_t m0, int nout, int to_mf, RdsBuffers Rb) {
+    const int ch = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nout || B.params[ch].rds_mode != 1) return;
+    const int64_t m = m0 + q;
+    const float *in = rin + (size_t)ch * RDS24_RING;
+    float tmp = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int64_t j = m - i;
+        const float v = j >= 0 ? in[(int)(j & (RDS24_RING - 1))] : 0.f;
+        tmp += v * taps[i];
+    }
+    if (to_mf) Rb.mf[(size_t)q * C_RDS_PITCH(Rb) + ch] = make_float2(tmp, 0.f);   // sample-major for the lane-per-channel slicer
+    else rout[(size_t)ch * RDS24_RING + (int)(m & (RDS24_RING - 1))] = tmp;
+}
+__global__ __launch_bounds__(64) void rds1_slicer(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C || B.params[ch].rds_mode != 1) return;
+    Rds1State st = Rb.state1[ch];
+    RdsState s2 = Rb.state[ch];                          // the bit ring's write counter is shared with the RDS_2 slicer
+    const int pitch = C_RDS_PITCH(Rb);
+    const float *cf = Rb.rds1_coef + RDS1_FIR + RDS1_MATCH;
+    const float gain = cf[RDS1_QUADS * 4];
+    uint8_t *bits = Rb.bits + (size_t)ch * RDS_BITS_CAP;
+    for (int q = 0; q < nout; q++) {
+        const float v = Rb.mf[(size_t)q * pitch + ch].x;
+        float o = (v * v) * gain;                         // sharpFilter.Pass (v * v): Basic_IIR::Pass iir-filters.h:89-103
+#pragma unroll
+        for (int i = 0; i < RDS1_QUADS; i++) {
+            const float rm1 = st.m1[i], rm2 = st.m2[i];
+            const float w = o - rm1 * cf[4 * i + 2] - rm2 * cf[4 * i + 3];
+            o = w + rm1 * cf[4 * i] + rm2 * cf[4 * i + 1];
+            st.m2[i] = rm1; st.m1[i] = w;
+        }
+        const float slope = o - st.last_sync;
+        st.last_sync = o;
+        if ((slope < 0.0f) && (st.last_sync_slope >= 0.0f)) {                     // top of the sine wave: take the data
+            const int bit = st.last_data >= 0.f ? 1 : 0;
+            bits[s2.nbits & (RDS_BITS_CAP - 1)] = (uint8_t)(bit ^ st.prev_bit);
+            st.prev_bit = bit;
+            s2.nbits++;
+        }
+        st.last_data = v;
+        st.last_sync_slope = slope;
+    }
+    Rb.state1[ch] = st;
+    Rb.state[ch].nbits = s2.nbits;
+}
+
 static void fft_fwd(const RdsBuffers &Rb, int nch, const int *chlist, hipStream_t s) {
     hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nch), dim3(256), 0, s, Rb.U, Rb.V, nch, chlist);
     hipLaunchKernelGGL(rds_fft_step2, dim3(RN1 / 16, nch), dim3(256), 0, s, Rb.V, Rb.U, nch, chlist);
@@ -287,7 +375,7 @@ void launch_rds_block(const RdsBuffers &Rb, int C, int64_t blk, hipStream_t s) {
 }
 
 // the RDS work of one call: rows [0, nj) of the work arrays are rds samples [n0, n0 + nj)
-void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, int64_t n0, hipStream_t s) {
+void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, int64_t n0, int modes, hipStream_t s) {
     const int64_t nj = G.J1 - G.J0;
     if (nj <= 0) return;
     int64_t row = 0;
@@ -309,8 +397,17 @@ void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G,
     const int64_t mend = (n0 + nj) / 8;            // one past the largest m with 8m+7 < n0+nj
     const int nout = (int)(mend - mfirst);
     if (nout <= 0) return;
-    hipLaunchKernelGGL(rds_matched, dim3((unsigned)((nout + 255) / 256), C), dim3(256), 0, s, B, Rb, mfirst, nout);
-    hipLaunchKernelGGL(rds_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
+    if (modes & (1 << 2)) {
+        hipLaunchKernelGGL(rds_matched, dim3((unsigned)((nout + 255) / 256), C), dim3(256), 0, s, B, Rb, mfirst, nout);
+        hipLaunchKernelGGL(rds_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
+    }
+    if (modes & (1 << 1)) {          // (the mf rows of an RDS_1 channel are its own: the two slicers never share a channel)
+        const dim3 gt((unsigned)((nout + 255) / 256), C);
+        hipLaunchKernelGGL(rds1_costas, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, mfirst, nout);
+        hipLaunchKernelGGL(rds1_fir<RDS1_FIR>, gt, dim3(256), 0, s, B, Rb.c_ring, Rb.f_ring, Rb.rds1_coef, mfirst, nout, 0, Rb);
+        hipLaunchKernelGGL(rds1_fir<RDS1_MATCH>, gt, dim3(256), 0, s, B, Rb.f_ring, (float *)nullptr, Rb.rds1_coef + RDS1_FIR, mfirst, nout, 1, Rb);
+        hipLaunchKernelGGL(rds1_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
+    }
 }
 
 }  // namespace fmx

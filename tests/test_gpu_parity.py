@@ -537,7 +537,7 @@ def test_error_behaviour(fmx_amd):
     f = fmx_amd.Fmx(2, max_block=16384)
     for pid, v, code in [(M.P_FM_MODE, 3, M.FMX_E_INVALID), (M.P_FM_DECODER, 0, M.FMX_E_INVALID),
                          (M.P_FM_DECODER, 9, M.FMX_E_INVALID), (M.P_DEEMPHASIS, 0, M.FMX_E_INVALID),
-                         (M.P_SQUELCH_MODE, 3, M.FMX_E_INVALID), (M.P_RDS_MODE, 1, M.FMX_E_UNSUPPORTED),
+                         (M.P_SQUELCH_MODE, 3, M.FMX_E_INVALID),
                          (M.P_RDS_MODE, 3, M.FMX_E_UNSUPPORTED), (M.P_RDS_MODE, 4, M.FMX_E_INVALID),
                          (M.P_SOUND_MODE, 7, M.FMX_E_INVALID), (999, 0, M.FMX_E_INVALID)]:
         with pytest.raises(fmx_amd.FmxError) as e:
@@ -602,6 +602,43 @@ def test_rds_iq_and_bits_vs_oracle(fmx_amd, ol):
     best = min(range(300, 600), key=lambda L: np.count_nonzero(b_g[L + 600:L + 1600] != g[600:1600]))
     ber = np.count_nonzero(b_g[best + 600:] != g[600:len(b_g) - best]) / (len(b_g) - best - 600)
     print(f"[rds] lag {best} bits, BER vs generator after 600 bits: {ber:.4f}")
+    assert ber <= 0.002
+
+
+def test_rds1_decoder(fmx_amd, ol):
+    """setfmRdsSelector RDS_1 (rds-decoder.cpp:76-84, rds-decoder-1.cpp): the kernels' constants (rdsFilter, matched filter,
+    order-7 Butterworth band-pass -- the latter pinned to the reference's BandPassIIR in test_oracle_vs_ref) equal the
+    oracle's bit for bit; one batch runs channel 0 with RDS_2 and channel 1 with RDS_1 on the same stream; the RDS_1 bit
+    stream equals the generator's (BER) and, over the settled part, the oracle's.  (Bit TIMES come from a slope detector
+    behind an IIR: a 1e-6 difference upstream may move a decision by one sample early on, never the data.)"""
+    co = np.zeros(97, np.float32)
+    ol.oracle().fmo_rds1_coeffs(ol.fptr(co))
+    f0 = fmx_amd.Fmx(1, max_block=16384)
+    cg = f0.taps(5)
+    assert cg.size == 97 and np.array_equal(cg.view(np.uint32), co.view(np.uint32))
+    seconds, block = 2.6, 16384 * 20
+    n = int(seconds * 2304000) // block * block
+    iq, sent = ol.synth_iq(n, return_rds_bits=True, rds=1, rdsLevel=0.05, rdsBitsSeed=4242)
+    ch1 = ol.OracleChain(rdsMode=1)
+    ch1.process(iq)
+    ch2 = ol.OracleChain(rdsMode=2)
+    ch2.process(iq)
+    f = fmx_amd.Fmx(2, streams=1, stream_of_channel=[0, 0], max_block=block)
+    gui_defaults(f)
+    f.set_param(M.P_RDS_MODE, 2, channel=0)
+    f.set_param(M.P_RDS_MODE, 1, channel=1)
+    for i in range(0, n, block):
+        f.process_host(iq[i:i + block])
+    b2, b1 = f.rds_bits(0, 8192), f.rds_bits(1, 8192)
+    o2, o1 = ch2.rds_bits(), ch1.rds_bits()
+    assert len(b2) == len(o2) and np.count_nonzero(b2[460:] != o2[460:]) <= 2           # the RDS_2 channel is undisturbed
+    print(f"\n[rds1] bits gpu {len(b1)} oracle {len(o1)}")
+    assert abs(len(b1) - len(o1)) <= 3 and len(o1) > 2500
+    tail = 1500
+    assert np.array_equal(b1[-tail:], o1[-tail:])
+    best = min(range(len(sent) - tail), key=lambda off: np.count_nonzero(b1[-tail:] != sent[off:off + tail]))
+    ber = np.count_nonzero(b1[-tail:] != sent[best:best + tail]) / tail
+    print(f"[rds1] BER vs generator over the last {tail} bits: {ber:.4f}")
     assert ber <= 0.002
 
 

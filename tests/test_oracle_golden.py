@@ -187,17 +187,17 @@ def test_chain_against_reference_wired_leaf_classes():
 
 
 def test_recursive_filters():
-    """iir-filters.cpp (LowPassIIR / HighPassIIR, Chebyshev and Butterworth prototypes, bilinear transform, Basic_IIR::Pass):
+    """iir-filters.cpp (LowPassIIR / HighPassIIR / BandPassIIR, Chebyshev and Butterworth prototypes, bilinear transform, Basic_IIR::Pass):
     coefficients and responses of the reference's own classes (tests/golden/ref_iir.npz), among them the two order-20
-    filters of the noise squelch (squelchClass.cpp:11-18)."""
+    filters of the noise squelch (squelchClass.cpp:11-18) and the band-pass of rdsDecoder_1 (rds-decoder-1.cpp:45-48)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
     GI = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_iir.npz"))
     x = GI["iir_in"]
-    for name, kind, order, f1, ftype in mg.IIR_CASES:
-        f = O.fmo_iir_new(kind, order, f1, 0, 192000, ftype)
+    for name, kind, order, f1, ftype, f2, fs in mg.IIR_CASES:
+        f = O.fmo_iir_new(kind, order, f1, f2, fs, ftype)
         c = np.zeros(128, np.float32)
         nq = O.fmo_iir_coeffs(f, fptr(c))
         y = np.zeros_like(x)

@@ -97,17 +97,20 @@ def test_chain_long(bw):
     assert np.abs(lr[m - 1000:m, 1]).max() > 0.05          # the L-R path is alive (stereo decoded)
 
 
-@pytest.mark.parametrize("kind,order,f1,ftype", [(1, 20, 69900, 0o100), (0, 20, 70000, 0o100), (0, 7, 3000, 0o101),
-                                                   (1, 5, 10000, 0o101), (0, 9, 20000, 0o100), (0, 6, 96000, 0o100), (1, 3, 500, 0o101)])
-def test_recursive_filters_dense(kind, order, f1, ftype):
-    """LowPassIIR / HighPassIIR of the reference (iir-filters.cpp) against the oracle's restatement: coefficients and a long
+@pytest.mark.parametrize("kind,order,f1,ftype,f2,fs", [
+    (1, 20, 69900, 0o100, 0, 192000), (0, 20, 70000, 0o100, 0, 192000), (0, 7, 3000, 0o101, 0, 192000), (1, 5, 10000, 0o101, 0, 192000),
+    (0, 9, 20000, 0o100, 0, 192000), (0, 6, 96000, 0o100, 0, 192000), (1, 3, 500, 0o101, 0, 192000),
+    (2, 7, 1181, 0o101, 1193, 24000), (2, 4, 3000, 0o101, 5000, 48000), (2, 6, 10000, 0o100, 20000, 192000), (2, 3, 100, 0o101, 200, 24000),
+    (2, 5, 13000, 0o101, 14000, 24000)])
+def test_recursive_filters_dense(kind, order, f1, ftype, f2, fs):
+    """LowPassIIR / HighPassIIR / BandPassIIR of the reference (iir-filters.cpp) against the oracle's restatement: coefficients and a long
     response, bit for bit (among them the noise squelch's filters and the `2 * fpass >= fs` guard)."""
     R = ol.ref()
     if R is None:
         pytest.skip("oracle/_ref/libfmref.so not built (no reference tree)")
     L = ol.oracle()
     x = (0.3 * np.random.default_rng(order * 1000 + kind).standard_normal(50000)).astype(np.float32)
-    a, b = L.fmo_iir_new(kind, order, f1, 0, 192000, ftype), R.ref_iir_new(kind, order, f1, 0, 192000, ftype)
+    a, b = L.fmo_iir_new(kind, order, f1, f2, fs, ftype), R.ref_iir_new(kind, order, f1, f2, fs, ftype)
     ca, cb = np.zeros(128, np.float32), np.zeros(128, np.float32)
     na, nb = L.fmo_iir_coeffs(a, ol.fptr(ca)), R.ref_iir_coeffs(b, ol.fptr(cb))
     ya, yb = np.zeros_like(x), np.zeros_like(x)
