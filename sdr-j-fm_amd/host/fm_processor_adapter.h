@@ -106,6 +106,7 @@ public:
         return m.live_pilot_locked != 0;
     }
     float get_demodDcComponent() { fmx_meta m{}; return fmx_get_meta(h, 0, &m) == FMX_OK ? m.live_dc_if : 0.0f; }
+    bool getSquelchState() { fmx_meta m{}; return fmx_get_meta(h, 0, &m) == FMX_OK && m.squelch_active != 0; }      // fm-processor.cpp:217-219
 
     // ---- the processing loop ----
     // One iteration of the while loop of fmProcessor::run() (fm-processor.cpp:387-686).  Returns false
