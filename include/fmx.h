@@ -68,8 +68,8 @@ typedef enum {
     FMX_P_BANDWIDTH = 9,       /* setBandwidth, Hz (the GUI's "165kHz" -> 165000); 0 = "Off" (:232-239) */
     FMX_P_ATTENUATION_L = 10,  /* setAttenuation (Lgain)                             (:351-359)  */
     FMX_P_ATTENUATION_R = 11,  /* setAttenuation (Rgain)                                         */
-    FMX_P_RDS_MODE = 12,       /* setfmRdsSelector: 0 off, 1 = RDS_1 (rds-decoder-1.cpp), 2 = RDS_2 (rds-decoder-2.cpp);
-                                  3 is FMX_E_UNSUPPORTED                             (:840-847)  */
+    FMX_P_RDS_MODE = 12,       /* setfmRdsSelector: 0 off, 1 = RDS_1 (rds-decoder-1.cpp), 2 = RDS_2 (rds-decoder-2.cpp),
+                                  3 = RDS_3 (rds-decoder-3.cpp)                      (:840-847)  */
     FMX_P_LOCAL_OSCILLATOR = 13,/* set_localOscillator, Hz                           (:866-868)  */
     FMX_P_AUTO_MONO = 14,      /* setAutoMonoMode                                    (:914-916)  */
     FMX_P_PSS = 15,            /* setPSSMode                                         (:918-920)  */

@@ -973,6 +973,128 @@ static int rds1_decode(rds1 *r, c32 z, c32 *m, uint8_t *d) {
     return res;
 }
 
+
+/* ------------------------------------------------------------------ RDS block synchroniser, as far as rdsDecoder_3 needs it
+ * (rds-blocksynchronizer.cpp:57-336: syndrome register :126-142, offset words :197-213, pushBit :215-336; rdsDecoder::processBit
+ * rds-decoder.cpp:104-131 resyncs after a failed block and clears the group after a complete one).  Only the state that
+ * decides the NEXT result is kept: the bit-error bookkeeping and the Meggitt pass change no decision (the reference discards
+ * the corrected block). */
+typedef struct { uint32_t stream; int synced, cur, bits_in_blk, n_sync_err; uint16_t blk1; } bsync;
+static uint32_t bsync_offset(int blk, int typeB) { return blk == 0 ? 0xFC : blk == 1 ? 0x198 : blk == 2 ? (typeB ? 0x350 : 0x168) : 0x1B4; }
+static uint32_t bsync_syndrome(uint32_t bits, uint32_t off) {
+    const uint32_t block = bits ^ off;
+    uint32_t reg = 0;
+    for (int k = 25; k >= 0; k--) {
+        const uint32_t msb = reg & (1u << 9);
+        reg <<= 1;
+        if (msb) reg ^= 0x5B9;
+        if ((block >> k) & 1u) reg ^= 0x31B;
+    }
+    return reg;
+}
+static void bsync_resync(bsync *b) { b->cur = 0; b->synced = 0; b->bits_in_blk = 0; }
+static void bsync_push(bsync *b, int bit) {             /* pushBit + the reaction of processBit */
+    const int typeB = (b->blk1 >> 11) & 1;
+    b->stream = (b->stream << 1) | (bit ? 1u : 0u);
+    if (b->synced) {
+        if (++b->bits_in_blk < 26) return;
+        b->bits_in_blk = 0;
+        if (bsync_syndrome(b->stream, bsync_offset(b->cur, typeB)) != 0) { bsync_resync(b); return; }      /* RDS_NO_CRC */
+        if (b->cur == 1) b->blk1 = (uint16_t)(b->stream >> 10);
+        if (b->cur == 3) b->blk1 = 0;                                                                      /* group complete: cleared */
+        b->cur = (b->cur + 1) & 3;
+        return;
+    }
+    if (b->cur == 0) {
+        if (bsync_syndrome(b->stream & 0x3FFFFFF, bsync_offset(0, typeB)) != 0) return;                    /* waiting for block A */
+        b->bits_in_blk = 0; b->cur = 1;
+        return;
+    }
+    if (b->bits_in_blk < 25) { b->bits_in_blk++; return; }
+    b->bits_in_blk = 0;
+    if (bsync_syndrome(b->stream, bsync_offset(b->cur, typeB)) != 0) { b->n_sync_err++; bsync_resync(b); return; }   /* RDS_NO_SYNC */
+    if (b->cur == 1) b->blk1 = (uint16_t)(b->stream >> 10);
+    if (b->cur < 2) { b->cur++; return; }
+    b->synced = 1;
+    if (b->cur == 3) b->blk1 = 0;
+    b->cur = (b->cur + 1) & 3;
+}
+
+void fmo_bsync_run(const uint8_t *bits, long n, int32_t *sync_errors, int32_t *synced) {
+    bsync b; memset(&b, 0, sizeof(b));
+    for (long i = 0; i < n; i++) bsync_push(&b, bits[i]);
+    *sync_errors = b.n_sync_err; *synced = b.synced;
+}
+
+/* ------------------------------------------------------------------ RDS decoder 3 (rds-decoder-3.cpp:44-154) behind the
+ * rdsDecoder's Costas loop (rds-decoder.cpp:92-100) */
+typedef struct {
+    fmo_costas costas; fmo_sincos *sc;
+    float fir[21], firbuf[21]; int firip;
+    float syncBuffer[21]; int p, symbolCeiling, symbolFloor;
+    float omegaRDS, bitIntegrator, bitClkPhase, prev_clkState; int previousBit, Resync;
+    bsync bs;
+} rds3;
+static void rds3_init(rds3 *r, int32_t rate) {
+    memset(r, 0, sizeof(*r));
+    fmo_costas_init(&r->costas, (float)rate, 1.0f / 16.0f, 0.02f / 16.0f, 10.0f);
+    r->sc = fmo_sincos_new(rate);
+    fmo_lowpass_kernel(21, 2 * 2400, rate, r->fir);
+    const float synchronizerSamples = rate / (float)1187.5;
+    r->symbolCeiling = (int)ceilf(synchronizerSamples); r->symbolFloor = (int)floorf(synchronizerSamples);
+    r->omegaRDS = (float)((2 * M_PI * 1187.5) / (float)rate);
+    r->Resync = 1;
+}
+static void rds3_synchronize(rds3 *r, int first) {      /* synchronizeOnBitClk :116-153 */
+    int isHigh = 0, k = 0;
+    float corr[32];
+    memset(corr, 0, sizeof(corr));
+    for (int i = 0; i < r->symbolCeiling; i++) {
+        const float phase = (float)fmod(i * (r->omegaRDS / 2), 2 * M_PI);
+        if (fmo_sincos_sin(r->sc, phase) > 0 && !isHigh) { isHigh = 1; k = 0; }
+        else if (fmo_sincos_sin(r->sc, phase) < 0 && isHigh) { isHigh = 0; k = 0; }
+        corr[k++] += r->syncBuffer[(first + i) % r->symbolCeiling];
+    }
+    int iMin = 0;
+    while (iMin < r->symbolFloor && corr[iMin++] > 0);
+    while (iMin < r->symbolFloor && corr[iMin++] < 0);
+    r->bitClkPhase = (float)fmod(-r->omegaRDS * (iMin - 1), 2 * M_PI);
+    while (r->bitClkPhase < 0) r->bitClkPhase = (float)(r->bitClkPhase + 2 * M_PI);
+}
+static int rds3_decode(rds3 *r, c32 z, c32 *m, uint8_t *d) {
+    z = fmo_costas_process(&r->costas, z);
+    *m = cscale(z, 4.0f);
+    const float v = z.re;
+    int res = 0;
+    {   /* syncBuffer [p] = rdsFilter. Pass (v) */
+        float tmp = 0;
+        r->firbuf[r->firip] = v;
+        for (int i = 0; i < 21; i++) { int index = r->firip - i; if (index < 0) index += 21; tmp += r->firbuf[index] * r->fir[i]; }
+        r->firip = (r->firip + 1) % 21;
+        r->syncBuffer[r->p] = tmp;
+    }
+    r->p = (r->p + 1) % r->symbolCeiling;
+    if (r->Resync || (r->bs.n_sync_err > 3)) {
+        rds3_synchronize(r, r->p);
+        bsync_resync(&r->bs);
+        r->bs.n_sync_err = 0;
+        r->Resync = 0;
+    }
+    const float clkState = fmo_sincos_sin(r->sc, r->bitClkPhase);
+    r->bitIntegrator += clkState * v;
+    if (r->prev_clkState <= 0 && clkState > 0) {         /* rising edge -> look at the integrator */
+        const int theBit = r->bitIntegrator >= 0;
+        *d = (uint8_t)(theBit ^ r->previousBit);
+        r->bitIntegrator = 0;
+        r->previousBit = theBit;
+        res = 1;
+    }
+    r->prev_clkState = clkState;
+    r->bitClkPhase = (float)fmod(r->bitClkPhase + r->omegaRDS, 2 * M_PI);
+    if (res) bsync_push(&r->bs, *d);                     /* rdsDecoder::doDecode: if (b) processBit (theBit) */
+    return res;
+}
+
 typedef struct { float *buf; long cap, n; } tapbuf;
 
 struct fmo_chain {
@@ -1001,7 +1123,7 @@ struct fmo_chain {
     int32_t myCount;
     fmo_meta meta;
     resampler rs; c32 rsIn[192]; int rsInp;
-    rds2 rds; rds1 rdsA; uint8_t *rdsBits; long rdsBitCount, rdsBitCap;
+    rds2 rds; rds1 rdsA; rds3 rdsC; uint8_t *rdsBits; long rdsBitCount, rdsBitCap;
     /* block intake */
     c32 *pending; long npending;
     tapbuf taps[FMO_TAP_COUNT];
@@ -1098,7 +1220,7 @@ fmo_chain *fmo_chain_new(const fmo_config *c) {
     ch->deemphAlpha = (float)(1.0 / (fmRate / (1000000.0 / 50.0 + 1)));
     ch->rdsDecim = fmo_decim_new(11, 24000 / 2, fmRate, fmRate / 24000);
     resampler_init(&ch->rs);
-    rds2_init(&ch->rds, 24000); rds1_init(&ch->rdsA, 24000);
+    rds2_init(&ch->rds, 24000); rds1_init(&ch->rdsA, 24000); rds3_init(&ch->rdsC, 24000);
     ch->rdsBitCap = 1 << 16; ch->rdsBits = (uint8_t *)malloc((size_t)ch->rdsBitCap);
     ch->pending = (c32 *)malloc(sizeof(c32) * BLOCK);
     ch->meta.peakLeftDb = ch->meta.peakRightDb = -40.0f;
@@ -1118,7 +1240,7 @@ void fmo_chain_free(fmo_chain *ch) {
     fmo_fftfilter_free(ch->audioFilter); fmo_fftfilter_free(ch->inputFilter);
     fmo_fftfilter_free(ch->rdsBand); fmo_fftfilter_free(ch->rdsHilbert);
     fmo_pilot_free(ch->pilot); fmo_pss_free(ch->pss); fmo_demod_free(ch->demod);
-    free(ch->delayBuf); free(ch->peakEv);
+    free(ch->delayBuf); free(ch->peakEv); fmo_sincos_free(ch->rdsC.sc);
     free(ch->rdsPhaseBuffer); free(ch->rdsBits); free(ch->pending); free(ch);
 }
 
@@ -1321,9 +1443,10 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
             c32 rdsSample;
             if (fmo_decim_pass(ch->rdsDecim, rdsData, &rdsSample)) {
                 tap2(ch, FMO_TAP_RDS_IQ, rdsSample);
-                if (ch->cfg.rdsMode == 2 || ch->cfg.rdsMode == 1) {
+                if (ch->cfg.rdsMode >= 1 && ch->cfg.rdsMode <= 3) {
                     c32 mag; uint8_t bit;
-                    if (ch->cfg.rdsMode == 2 ? rds2_decode(&ch->rds, rdsSample, &mag, &bit) : rds1_decode(&ch->rdsA, rdsSample, &mag, &bit)) {
+                    if (ch->cfg.rdsMode == 2 ? rds2_decode(&ch->rds, rdsSample, &mag, &bit)
+                        : ch->cfg.rdsMode == 1 ? rds1_decode(&ch->rdsA, rdsSample, &mag, &bit) : rds3_decode(&ch->rdsC, rdsSample, &mag, &bit)) {
                         if (ch->rdsBitCount >= ch->rdsBitCap) {
                             ch->rdsBitCap *= 2;
                             ch->rdsBits = (uint8_t *)realloc(ch->rdsBits, (size_t)ch->rdsBitCap);

@@ -139,6 +139,8 @@ void  fmo_iir_lowpass(fmo_iir *f, int order, int32_t fpass, int32_t fs, int ftyp
 void  fmo_iir_highpass(fmo_iir *f, int order, int32_t fpass, int32_t fs, int ftype);
 void  fmo_iir_bandpass(fmo_iir *f, int order, int32_t flow, int32_t fhigh, int32_t fs, int ftype);   /* :552-595 */
 float fmo_iir_pass(fmo_iir *f, float v);
+/* the block synchroniser as rdsDecoder_3 sees it (sync-error count, lock) over a bit array, from a fresh state */
+void  fmo_bsync_run(const uint8_t *bits, long n, int32_t *sync_errors, int32_t *synced);
 /* rdsDecoder_1's constants as the kernels hold them: rdsFilter taps [21], Match kernel [43], sharpFilter [8][A1 A2 B1 B2], gain */
 void  fmo_rds1_coeffs(float *out);
 /* test helpers with the signatures of ref_iir_* (kind 0 low-pass, 1 high-pass, 2 band-pass) */
@@ -181,7 +183,7 @@ typedef struct {
     float   attL, attR;       /* setAttenuation (Lgain,Rgain)              fm-processor.cpp:351-359 */
     int32_t loFrequency;      /* set_localOscillator                       fm-processor.cpp:866-868 */
     int32_t dcRemove, autoMono, pssActive;
-    int32_t rdsMode;          /* 0 off, 1..3 = RDS_1..3 (1 and 2 are restated) */
+    int32_t rdsMode;          /* 0 off, 1..3 = RDS_1..3 */
     int32_t squelchMode;      /* 0 OFF, 1 NSQ (noise squelch), 2 LSQ (level squelch)   fm-processor.cpp:499-509 */
     int32_t squelchValue;     /* set_squelchValue 0..100: applied at a block start when it differs from the last one (:410-413) */
     int32_t testTone;         /* setTestTone (fm-processor.cpp:931-933): 1 kHz bursts of 25 ms every 2 s mixed into the PCM (:800-823) */

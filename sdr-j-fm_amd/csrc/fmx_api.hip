@@ -312,6 +312,15 @@ int ensure_rds(fmx_handle h) {
         HIPCHK(hipMemcpy(dc, co.data(), sizeof(float) * co.size(), hipMemcpyHostToDevice));
         R.rds1_coef = dc; h->h_rds1 = co;
     }
+    {   // RDS_3: state, and mySinCos (rate) of rdsDecoder_3 (rds-decoder-3.cpp:49): SinCos ctor sincos.cpp:45-54 at Rate 24000
+        if ((rc = dalloc((void **)&R.state3, sizeof(Rds3State) * C, true))) return rc;
+        std::vector<float2> sc24(24000);
+        for (int i = 0; i < 24000; i++) sc24[i] = make_float2((float)std::cos(2 * design::kPi * i / 24000), (float)std::sin(2 * design::kPi * i / 24000));
+        float2 *d24;
+        if ((rc = dalloc((void **)&d24, sizeof(float2) * 24000, false))) return rc;
+        HIPCHK(hipMemcpy(d24, sc24.data(), sizeof(float2) * 24000, hipMemcpyHostToDevice));
+        R.sincos24 = d24;
+    }
     h->rds_read.assign(C, 0);
     h->rds_alloc = true;
     return FMX_OK;
@@ -758,7 +767,6 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_BANDWIDTH: if (iv < 0 || iv > h->cfg.inputRate) return fail(FMX_E_INVALID, "bandwidth out of range"); break;
     case FMX_P_RDS_MODE:
         if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "rds mode must be 0..3");
-        if (iv == 3) return fail(FMX_E_UNSUPPORTED, "the RDS_3 decoder (rds-decoder-3.cpp) is not built; 1 = RDS_1, 2 = RDS_2");
         if (iv == 2 && h->rds_start >= 0 && h->rds_start != h->g_total / DECIM && h->params[channel < 0 ? 0 : channel].rds_mode == 0)
             return fail(FMX_E_UNSUPPORTED, "switch RDS on for all channels in the same call (shared overlap-add block phase)");
         break;

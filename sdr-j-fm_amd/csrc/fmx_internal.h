@@ -193,6 +193,12 @@ struct Rds1State {                          // rdsDecoder's Costas (rds-decoder.
     float last_sync_slope, last_sync, last_data;
     int32_t prev_bit;
 };
+struct Rds3State {                          // rdsDecoder's Costas + rdsDecoder_3 (rds-decoder-3.h:55-70) + the block synchroniser's
+    float c_freq, c_phase;                  // state as far as it decides the next resynchronisation (rds-blocksynchronizer.h:93-99)
+    float bit_integrator, bit_clk_phase, prev_clk_state;
+    int32_t prev_bit, resync_pending, started;
+    uint32_t bs_stream; int32_t bs_synced, bs_cur, bs_bits_in_blk, bs_sync_err, bs_blk1;
+};
 struct RdsBuffers {
     float  *in_blk;      // [ch][32000]     demod samples of the block being filled
     float  *bpreal;      // [ch][2][32000]  real part of the band-pass block results (parity = block index & 1)
@@ -212,6 +218,9 @@ struct RdsBuffers {
     float  *c_ring, *f_ring;      // [ch][RDS24_RING] Re of the Costas output, and of rdsFilter's output
     Rds1State *state1;
     const float *rds1_coef;       // [21] rdsFilter taps, [43] match kernel, [8][A1 A2 B1 B2] sharpFilter, gain
+    // RDS_3 (rds-decoder-3.cpp)
+    Rds3State *state3;
+    const float2 *sincos24;       // [24000] SinCos (rate) table of the bit-clock NCO (sincos.cpp:45-54)
     int32_t pitch;
 };
 #define C_RDS_PITCH(Rb) ((Rb).pitch)

@@ -350,6 +350,135 @@ __global__ __launch_bounds__(64) void rds1_slicer(DeviceBuffers B, RdsBuffers Rb
     Rb.state[ch].nbits = s2.nbits;
 }
 
+
+// =================================================================================================
+// RDS_3 (setfmRdsSelector 3): rdsDecoder::doDecode rds-decoder.cpp:92-100 -> rdsDecoder_3::doDecode rds-decoder-3.cpp:86-113.
+// Everything is one recurrence per channel [lane per channel]: Costas, bit-clock NCO (SinCos table of 24000 entries),
+// integrate-and-dump, differential decode -- and the block synchroniser (rds-blocksynchronizer.cpp:215-336 with the reaction
+// of rdsDecoder::processBit rds-decoder.cpp:104-131), because its sync-error count re-synchronises the bit clock (:95-100).
+// rdsFilter (21 taps) only feeds the 21-entry syncBuffer that synchronizeOnBitClk (:116-153) reads: its outputs are computed
+// when a resynchronisation happens, from the ring of Costas outputs, each summed in the reference's tap order.
+// =================================================================================================
+__device__ __forceinline__ uint32_t bs_offset(int blk, int typeB) { return blk == 0 ? 0xFCu : blk == 1 ? 0x198u : blk == 2 ? (typeB ? 0x350u : 0x168u) : 0x1B4u; }
+__device__ __forceinline__ uint32_t bs_syndrome(uint32_t bits, uint32_t off) {     // :126-142
+    const uint32_t block = bits ^ off;
+    uint32_t reg = 0;
+    for (int k = 25; k >= 0; k--) {
+        const uint32_t msb = reg & (1u << 9);
+        reg <<= 1;
+        if (msb) reg ^= 0x5B9u;
+        if ((block >> k) & 1u) reg ^= 0x31Bu;
+    }
+    return reg;
+}
+__device__ __forceinline__ void bs_resync(Rds3State &s) { s.bs_cur = 0; s.bs_synced = 0; s.bs_bits_in_blk = 0; }
+__device__ __forceinline__ void bs_push(Rds3State &s, int bit) {
+    const int typeB = (s.bs_blk1 >> 11) & 1;
+    s.bs_stream = (s.bs_stream << 1) | (bit ? 1u : 0u);
+    if (s.bs_synced) {
+        if (++s.bs_bits_in_blk < 26) return;
+        s.bs_bits_in_blk = 0;
+        if (bs_syndrome(s.bs_stream, bs_offset(s.bs_cur, typeB)) != 0) { bs_resync(s); return; }          // RDS_NO_CRC -> resync
+        if (s.bs_cur == 1) s.bs_blk1 = (int)((s.bs_stream >> 10) & 0xFFFFu);
+        if (s.bs_cur == 3) s.bs_blk1 = 0;                                                                 // complete group: cleared
+        s.bs_cur = (s.bs_cur + 1) & 3;
+        return;
+    }
+    if (s.bs_cur == 0) {
+        if (bs_syndrome(s.bs_stream & 0x3FFFFFFu, bs_offset(0, typeB)) != 0) return;                      // waiting for block A
+        s.bs_bits_in_blk = 0; s.bs_cur = 1;
+        return;
+    }
+    if (s.bs_bits_in_blk < 25) { s.bs_bits_in_blk++; return; }
+    s.bs_bits_in_blk = 0;
+    if (bs_syndrome(s.bs_stream, bs_offset(s.bs_cur, typeB)) != 0) { s.bs_sync_err++; bs_resync(s); return; }   // RDS_NO_SYNC
+    if (s.bs_cur == 1) s.bs_blk1 = (int)((s.bs_stream >> 10) & 0xFFFFu);
+    if (s.bs_cur < 2) { s.bs_cur++; return; }
+    s.bs_synced = 1;
+    if (s.bs_cur == 3) s.bs_blk1 = 0;
+    s.bs_cur = (s.bs_cur + 1) & 3;
+}
+__device__ __forceinline__ float sin24(const float2 *__restrict__ tab, float phase) {        // SinCos::getSin sincos.cpp:81-85, Rate 24000
+    const double C = 24000 / (2 * 3.14159265358979323846);
+    if (phase < 0) return -tab[((int)((double)(-phase) * C)) % 24000].y;
+    return tab[((int)((double)phase * C)) % 24000].y;
+}
+__global__ __launch_bounds__(64) void rds3_slicer(DeviceBuffers B, RdsBuffers Rb, int C, int64_t m0, int nout) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C || B.params[ch].rds_mode != 3) return;
+    Rds3State st = Rb.state3[ch];
+    RdsState s2 = Rb.state[ch];
+    if (!st.started) { st.started = 1; st.resync_pending = 1; }          // Resync = true (rds-decoder-3.cpp:81)
+    const float alpha = 1.0f / 16.0f, beta = 0.02f / 16.0f, lim = (float)(2 * 3.14159265358979323846 * (double)10.0f / (double)(float)24000);
+    const float omegaRDS = (float)((2 * 3.14159265358979323846 * 1187.5) / (float)24000);
+    const int symbolCeiling = 21, symbolFloor = 20;                      // ceil / floor (24000 / 1187.5f)
+    const float2 *in = Rb.rds24 + (size_t)ch * RDS24_RING;
+    float *cr = Rb.c_ring + (size_t)ch * RDS24_RING;
+    const float *fir = Rb.rds1_coef;                                    // rdsFilter (21, RDS_WIDTH, rate): the same taps as rdsDecoder_1's
+    uint8_t *bits = Rb.bits + (size_t)ch * RDS_BITS_CAP;
+    for (int q = 0; q < nout; q++) {
+        const int64_t m = m0 + q;
+        const float2 z = in[(int)(m & (RDS24_RING - 1))];
+        const float2 r = cmulf(z, make_float2(cosf(-st.c_phase), sinf(-st.c_phase)));
+        const float err = r.x * r.y;
+        st.c_freq += beta * err;
+        if (fabsf(st.c_freq) > lim) st.c_freq = 0.f;
+        st.c_phase += st.c_freq + alpha * err;
+        st.c_phase = pi_constrain_generic(st.c_phase);
+        const float v = r.x;
+        cr[(int)(m & (RDS24_RING - 1))] = v;
+        if (st.resync_pending || st.bs_sync_err > 3) {
+            // synchronizeOnBitClk: the syncBuffer holds rdsFilter's outputs at samples m - 20 .. m, oldest first
+            float corr[21];
+#pragma unroll
+            for (int i = 0; i < 21; i++) corr[i] = 0.f;
+            bool isHigh = false; int k = 0;
+            for (int i = 0; i < symbolCeiling; i++) {
+                const float phase = (float)fmod((double)((float)i * (omegaRDS / 2)), 6.283185307179586);
+                const float sn = sin24(Rb.sincos24, phase);
+                if (sn > 0 && !isHigh) { isHigh = true; k = 0; }
+                else if (sn < 0 && isHigh) { isHigh = false; k = 0; }
+                const int64_t t = m - 20 + i;
+                float f = 0.f;
+                for (int j = 0; j < RDS1_FIR; j++) {
+                    const int64_t u = t - j;
+                    const float cv = u >= 0 ? cr[(int)(u & (RDS24_RING - 1))] : 0.f;
+                    f += cv * fir[j];
+                }
+                // corr[k++] += f with a run-time k: select instead of a dynamically indexed register array
+#pragma unroll
+                for (int kk = 0; kk < 21; kk++) if (kk == k) corr[kk] += f;
+                k++;
+            }
+            int iMin = 0;
+            auto cget = [&](int idx) { float o = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 21; kk++) if (kk == idx) o = corr[kk];
+                return o; };
+            while (iMin < symbolFloor && cget(iMin++) > 0) {}
+            while (iMin < symbolFloor && cget(iMin++) < 0) {}
+            st.bit_clk_phase = (float)fmod((double)(-omegaRDS * (float)(iMin - 1)), 6.283185307179586);
+            while (st.bit_clk_phase < 0) st.bit_clk_phase = (float)((double)st.bit_clk_phase + 6.283185307179586);
+            bs_resync(st); st.bs_sync_err = 0; st.resync_pending = 0;
+        }
+        const float clk = sin24(Rb.sincos24, st.bit_clk_phase);
+        st.bit_integrator += clk * v;
+        if (st.prev_clk_state <= 0 && clk > 0) {                          // rising edge: look at the integrator
+            const int bit = st.bit_integrator >= 0 ? 1 : 0;
+            const int d = bit ^ st.prev_bit;
+            st.bit_integrator = 0.f;
+            st.prev_bit = bit;
+            bits[s2.nbits & (RDS_BITS_CAP - 1)] = (uint8_t)d;
+            s2.nbits++;
+            bs_push(st, d);                                               // rdsDecoder::doDecode: processBit (theBit)
+        }
+        st.prev_clk_state = clk;
+        st.bit_clk_phase = (float)fmod((double)(st.bit_clk_phase + omegaRDS), 6.283185307179586);
+    }
+    Rb.state3[ch] = st;
+    Rb.state[ch].nbits = s2.nbits;
+}
+
 static void fft_fwd(const RdsBuffers &Rb, int nch, const int *chlist, hipStream_t s) {
     hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nch), dim3(256), 0, s, Rb.U, Rb.V, nch, chlist);
     hipLaunchKernelGGL(rds_fft_step2, dim3(RN1 / 16, nch), dim3(256), 0, s, Rb.V, Rb.U, nch, chlist);
@@ -408,6 +537,7 @@ void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G,
         hipLaunchKernelGGL(rds1_fir<RDS1_MATCH>, gt, dim3(256), 0, s, B, Rb.f_ring, (float *)nullptr, Rb.rds1_coef + RDS1_FIR, mfirst, nout, 1, Rb);
         hipLaunchKernelGGL(rds1_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
     }
+    if (modes & (1 << 3)) hipLaunchKernelGGL(rds3_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, mfirst, nout);
 }
 
 }  // namespace fmx

@@ -149,6 +149,7 @@ def oracle():
         "fmo_chain_rds_bits": (lng, [vp, c_u8_p, lng]),
         "fmo_chain_peaks": (lng, [vp, c_float_p, lng]),
         "fmo_rds1_coeffs": (None, [c_float_p]),
+        "fmo_bsync_run": (None, [c_u8_p, lng, c_i32_p, c_i32_p]),
         "fmo_iir_new": (vp, [C.c_int, C.c_int, i32, i32, i32, C.c_int]),
         "fmo_iir_free": (None, [vp]),
         "fmo_iir_coeffs": (C.c_int, [vp, c_float_p]),

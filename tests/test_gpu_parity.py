@@ -538,7 +538,7 @@ def test_error_behaviour(fmx_amd):
     for pid, v, code in [(M.P_FM_MODE, 3, M.FMX_E_INVALID), (M.P_FM_DECODER, 0, M.FMX_E_INVALID),
                          (M.P_FM_DECODER, 9, M.FMX_E_INVALID), (M.P_DEEMPHASIS, 0, M.FMX_E_INVALID),
                          (M.P_SQUELCH_MODE, 3, M.FMX_E_INVALID),
-                         (M.P_RDS_MODE, 3, M.FMX_E_UNSUPPORTED), (M.P_RDS_MODE, 4, M.FMX_E_INVALID),
+                         (M.P_RDS_MODE, 4, M.FMX_E_INVALID),
                          (M.P_SOUND_MODE, 7, M.FMX_E_INVALID), (999, 0, M.FMX_E_INVALID)]:
         with pytest.raises(fmx_amd.FmxError) as e:
             f.set_param(pid, v)
@@ -640,6 +640,36 @@ def test_rds1_decoder(fmx_amd, ol):
     ber = np.count_nonzero(b1[-tail:] != sent[best:best + tail]) / tail
     print(f"[rds1] BER vs generator over the last {tail} bits: {ber:.4f}")
     assert ber <= 0.002
+
+
+def test_rds3_decoder(fmx_amd, ol):
+    """setfmRdsSelector RDS_3 (rds-decoder.cpp:92-100, rds-decoder-3.cpp): bit-clock NCO + integrate-and-dump, re-synchronised
+    from the block synchroniser's error count -- the synchroniser therefore runs on the GPU next to the slicer.  Real groups
+    (PI 0xD3A1, PS, radio text) so that it locks; three decoders in one batch on one stream; the RDS_3 bit stream equals the
+    oracle's over the settled part and the generator's (BER), and the groups come out of fmx_rds_decode as sent."""
+    seconds, block = 3.2, 16384 * 20
+    n = int(seconds * 2304000) // block * block
+    payload = ol.rds_programme_bits()
+    iq, sent = ol.synth_iq(n, return_rds_bits=True, rds=1, rdsLevel=0.05, rds_payload=payload)
+    ch3 = ol.OracleChain(rdsMode=3)
+    ch3.process(iq)
+    f = fmx_amd.Fmx(3, streams=1, stream_of_channel=[0, 0, 0], max_block=block)
+    gui_defaults(f)
+    for c, mode in enumerate((3, 2, 1)):
+        f.set_param(M.P_RDS_MODE, mode, channel=c)
+    for i in range(0, n, block):
+        f.process_host(iq[i:i + block])
+    info = [f.rds_decode(c) for c in range(3)]
+    b3, o3 = f.rds_bits(0, 8192), ch3.rds_bits()
+    print(f"\n[rds3] bits gpu {len(b3)} oracle {len(o3)}; groups decoded (RDS_3, RDS_2, RDS_1): {[i.groups_decoded for i in info]}")
+    assert abs(len(b3) - len(o3)) <= 2 and len(o3) > 3000
+    tail = 2000
+    assert np.array_equal(b3[-tail:], o3[-tail:])
+    best = min(range(len(sent) - tail), key=lambda off: np.count_nonzero(b3[-tail:] != sent[off:off + tail]))
+    assert np.count_nonzero(b3[-tail:] != sent[best:best + tail]) <= 2
+    for i in info:
+        assert i.synchronized == 1 and i.pi_code == 0xD3A1 and i.groups_decoded >= 20
+        assert i.station_label.decode("latin1").rstrip() == "FMX-AMD"
 
 
 def test_rds_batched_channels_and_second_read(fmx_amd, ol):

@@ -195,3 +195,26 @@ def test_rds_groups_errors_resync_and_pi_change():
     gb = ol.rds_group_bits(0x4242, (0 << 12) | (1 << 11) | (5 << 5) | 1, 0x4242, (ord("X") << 8) | ord("Y"), type_b=True)
     info = _rds(np.array(gb * 6, np.uint8))
     assert info.pi_code == 0x4242 and info.pty_code == 5 and info.station_label == b"        "
+
+
+def test_block_synchroniser_two_implementations_agree():
+    """The block synchroniser exists twice: in the library's host decoder (fmx_rds_decode_bits) and, reduced to what decides
+    a resynchronisation, next to the RDS_3 slicer on the GPU / in the oracle (fmo_bsync_run).  Same sync-error count and lock
+    state on clean groups, on groups with bit errors, on type-B groups and on noise."""
+    import ctypes as C
+    import oracle_lib as ol
+    L = ol.oracle()
+    rng = np.random.default_rng(31)
+    a = ol.rds_programme_bits(pi=0x1234, ps="STATION1", text="FIRST")
+    gb = np.array(ol.rds_group_bits(0x4242, (0 << 12) | (1 << 11) | (5 << 5) | 1, 0x4242, (ord("X") << 8) | ord("Y"), type_b=True) * 6, np.uint8)
+    cases = [a, np.concatenate([rng.integers(0, 2, 777).astype(np.uint8), a, a]), gb, rng.integers(0, 2, 20000).astype(np.uint8)]
+    for k in range(6):                                        # groups with scattered bit errors: drops out and re-locks
+        x = np.concatenate([a, a, a]).copy()
+        x[rng.integers(0, x.size, 3 + 5 * k)] ^= 1
+        cases.append(np.concatenate([rng.integers(0, 2, 13 * k).astype(np.uint8), x]))
+    for x in cases:
+        x = np.ascontiguousarray(x, np.uint8)
+        info = _rds(x)
+        se, sy = C.c_int32(), C.c_int32()
+        L.fmo_bsync_run(ol.u8ptr(x), x.size, C.byref(se), C.byref(sy))
+        assert (se.value, sy.value) == (info.sync_errors, info.synchronized)
