@@ -180,8 +180,9 @@ __device__ __forceinline__ void disc_body(DeviceTables T, DeviceBuffers B, CallG
             else {
                 const int64_t s = jj - sDelay[cl];
                 const float2 z = s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f);
-                v = am ? z : limiter(z);
+                // |z| once per sample: the limiter divides by it; the AM / PLL decoders and the level squelch read it from sABS
                 za = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
+                v = am ? z : ((double)za <= 0.001 ? make_float2((float)0.001, (float)0.001) : make_float2(z.x / za, z.y / za));   // limiter :119-126
             }
         }
         sLIM[cl][rl] = v; sABS[cl][rl] = za;
