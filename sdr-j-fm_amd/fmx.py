@@ -321,7 +321,10 @@ class FmProcessor:
     def restartPssAnalyzer(self): self._set(A_RESTART_PSS, 0)
     def resetRds(self): self._set(A_RESET_RDS, 0)
     def set_localOscillator(self, lo): self._set(P_LOCAL_OSCILLATOR, lo)
-    def set_squelchMode(self, m): self._set(P_SQUELCH_MODE, m)
+    def set_squelchMode(self, m): self._set(P_SQUELCH_MODE, m)          # ESqMode: 0 OFF, 1 NSQ, 2 LSQ
+    def set_squelchValue(self, v): self._set(P_SQUELCH_VALUE, v)         # fm-processor.cpp:213-215
+    def getSquelchState(self): return bool(self.fmx.meta(self.channel).squelch_active)      # :217-219
+    def pollPeakLevels(self): return self.fmx.peaks(self.channel)       # what showPeakLevel was emitted with since the last poll
     def setAutoMonoMode(self, b): self._set(P_AUTO_MONO, 1 if b else 0)
     def setPSSMode(self, b): self._set(P_PSS, 1 if b else 0)
     def setDCRemove(self, b): self._set(P_DC_REMOVE, 1 if b else 0)
