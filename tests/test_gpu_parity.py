@@ -826,6 +826,42 @@ def test_tap_sets_match_oracle_design(fmx_amd, ol):
     assert f.taps(0).size == 37 and np.max(np.abs(f.taps(0) - g)) < 1e-8
 
 
+def test_full_size_config4_device_path(fmx_amd, ol):
+    """BASELINE configs[3] at the benchmark's full size, through the entry point bench.py times (`fmx_process_device`:
+    4096 channels x 230400 samples per call, one IQ stream per channel, 7.5 GB resident in HBM, eight calls = 0.8 s of
+    signal, i.e. through pilot lock and the PSS transitions).  Channel c carries programme c % 4, so (i) channels 0..3
+    must match the oracle within the north-star tolerance and (ii) every channel's PCM must be bit-identical to channel
+    c % 4's -- a size-independent property that any race or addressing slip between the 4096 persistent workgroups /
+    64 recurrence groups would break."""
+    torch = pytest.importorskip("torch")
+    C, block, calls = 4096, 230400, 8
+    base = np.stack([ol.synth_iq(block * calls, leftHz=300.0 + 370 * j, rightHz=500.0 + 530 * j) for j in range(4)])
+    want = [ol.OracleChain(inputFilterBw=165000).process(base[j]) for j in range(4)]
+    dev = torch.device("cuda", 0)
+    d_base = torch.from_numpy(base).to(dev)
+    cap = block // 48 + 96
+    d_pcm = torch.zeros((C, cap, 2), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    f = fmx_amd.Fmx(C, max_block=block, device=0)
+    gui_defaults(f)
+    got_pcm, differing = [], 0
+    for i in range(calls):
+        d_iq = d_base[:, i * block:(i + 1) * block].unsqueeze(0).expand(C // 4, 4, block, 2).reshape(C, block, 2).contiguous()
+        frames = f.process_device(d_iq.data_ptr(), block, block, d_pcm.data_ptr(), cap, hip_stream=stream)
+        f.synchronize()
+        out = d_pcm[:, :frames].reshape(C // 4, 4, frames, 2)
+        differing += int((out != out[0:1]).any(dim=3).any(dim=2).sum().item())
+        got_pcm.append(out[0].cpu().numpy())
+        del d_iq
+    assert differing == 0, f"{differing} (channel, call) pairs differ from channel c % 4"
+    got_pcm = np.concatenate(got_pcm, axis=1)
+    for j in range(4):
+        # the oracle consumes whole 16384-sample device blocks (fm-processor.cpp:387-421): it stops up to one block short
+        m = want[j].shape[0]
+        assert got_pcm[j].shape[0] - 16384 // 48 - 1 <= m <= got_pcm[j].shape[0]
+        assert rms(got_pcm[j][:m] - want[j]) <= PCM_RMS_TOL, j
+
+
 def test_many_channels_spot_check(fmx_amd, ol):
     """A 300-channel batch (not a multiple of 64) at a large block: spot-check channels against the oracle."""
     C, block = 300, 16384 * 6
