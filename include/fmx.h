@@ -140,7 +140,9 @@ int64_t fmx_frames_for(fmx_handle h, int64_t n_complex);
 int  fmx_process_host(fmx_handle h, const float *iq, int64_t stream_stride, int64_t n_complex,
                       float *pcm, int64_t pcm_stride, int64_t *n_frames);
 /* Same with DEVICE pointers (IQ already resident in HBM); asynchronous on `hip_stream`
- * (a hipStream_t, NULL = the handle's own stream).  *n_frames is known on return. */
+ * (a hipStream_t, NULL = the handle's own stream, which first waits for the work queued on HIP's default stream -- the
+ * stream NULL names -- at the time of the call, so a producer there needs no extra synchronisation; the results are
+ * ordered by fmx_synchronize).  *n_frames is known on return. */
 int  fmx_process_device(fmx_handle h, const float *d_iq, int64_t stream_stride, int64_t n_complex,
                         float *d_pcm, int64_t pcm_stride, int64_t *n_frames, void *hip_stream);
 /* The same two calls for RAW device samples (the conversion the device handlers do on the host moves into

@@ -59,7 +59,7 @@ struct fmx_handle_s {
     DemodSync *d_sync = nullptr;
     int *h_stall = nullptr, *d_stall = nullptr;                      // host-mapped: set by the GPU when the persistent layout stalled
     bool partitioned = false; int ev_next = 0;
-    std::vector<hipEvent_t> evs; hipEvent_t ev_join = nullptr;
+    std::vector<hipEvent_t> evs; hipEvent_t ev_join = nullptr, ev_in = nullptr;
     std::mutex mtx;                          // guards the mailbox (set_param from any thread)
     std::vector<ChanUser> user;
     std::vector<ChanParams> params;          // host mirror
@@ -580,6 +580,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     h->evs.resize(512);
     for (auto &e : h->evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
 
     // ---- tables -------------------------------------------------------------------------
     const int32_t fmRate = cfg->fmRate;
@@ -741,6 +742,7 @@ int fmx_destroy(fmx_handle h) {
     for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->evs) (void)hipEventDestroy(e);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     for (auto &ss : h->s_side) if (ss) (void)hipStreamDestroy(ss);
     if (h->s_r) (void)hipStreamDestroy(h->s_r);
     if (h->s_t) (void)hipStreamDestroy(h->s_t);
@@ -839,6 +841,14 @@ int fmx_process_device_raw(fmx_handle h, const void *d_iq, int32_t format, float
     if (stream_stride < n) return fail(FMX_E_INVALID, "stream_stride < n_complex");
     HIPCHK(hipSetDevice(h->cfg.device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    if (!hip_stream) {
+        // NULL also names HIP's legacy default stream, where such a caller's producer (e.g. PyTorch's current stream) runs;
+        // the handle's stream is non-blocking, so order this call behind what is queued there now.  (Measured: the default
+        // stream's implicit synchronisation with the CU-masked streams of stage B costs ~0.4 ms per call at 4096 channels;
+        // a caller that passes a stream of its own, as bench.py does, does not pay it.)
+        HIPCHK(hipEventRecord(h->ev_in, nullptr));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_in, 0));
+    }
     return run_call(h, d_iq, format, s16_den, stream_stride, n, reinterpret_cast<float2 *>(d_pcm), pcm_stride, n_frames, s);
 }
 int fmx_process_device(fmx_handle h, const float *d_iq, int64_t stream_stride, int64_t n, float *d_pcm,

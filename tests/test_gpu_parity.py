@@ -841,18 +841,21 @@ def test_full_size_config4_device_path(fmx_amd, ol):
     d_base = torch.from_numpy(base).to(dev)
     cap = block // 48 + 96
     d_pcm = torch.zeros((C, cap, 2), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream(device=dev)         # the caller's own stream: the input is produced on it, the call runs on it
     f = fmx_amd.Fmx(C, max_block=block, device=0)
     gui_defaults(f)
     got_pcm, differing = [], 0
     for i in range(calls):
-        d_iq = d_base[:, i * block:(i + 1) * block].unsqueeze(0).expand(C // 4, 4, block, 2).reshape(C, block, 2).contiguous()
-        frames = f.process_device(d_iq.data_ptr(), block, block, d_pcm.data_ptr(), cap, hip_stream=stream)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            # a fresh buffer per call (the pointer alternates between two allocations), filled just in front of the call
+            d_iq_new = d_base[:, i * block:(i + 1) * block].unsqueeze(0).expand(C // 4, 4, block, 2).reshape(C, block, 2).contiguous()
+        d_iq = d_iq_new
+        frames = f.process_device(d_iq.data_ptr(), block, block, d_pcm.data_ptr(), cap, hip_stream=side.cuda_stream)
         f.synchronize()
         out = d_pcm[:, :frames].reshape(C // 4, 4, frames, 2)
         differing += int((out != out[0:1]).any(dim=3).any(dim=2).sum().item())
         got_pcm.append(out[0].cpu().numpy())
-        del d_iq
     assert differing == 0, f"{differing} (channel, call) pairs differ from channel c % 4"
     got_pcm = np.concatenate(got_pcm, axis=1)
     for j in range(4):
@@ -860,6 +863,50 @@ def test_full_size_config4_device_path(fmx_amd, ol):
         m = want[j].shape[0]
         assert got_pcm[j].shape[0] - 16384 // 48 - 1 <= m <= got_pcm[j].shape[0]
         assert rms(got_pcm[j][:m] - want[j]) <= PCM_RMS_TOL, j
+
+
+def test_full_size_config5_shard_device_path(fmx_amd, ol):
+    """BASELINE configs[4], one GPU's shard at the benchmark's full size (2048 channels x 230400 samples per call, RDS
+    front end + RDS_2 slicer on, eight calls through `fmx_process_device`).  Channel c carries programme c % 2 (two RDS
+    payloads): every channel's PCM and RDS bit stream must be bit-identical to channel c % 2's, and channels 0, 1 must
+    match the oracle (PCM within the north-star tolerance, bits identical once the chain has settled)."""
+    torch = pytest.importorskip("torch")
+    C, block, calls = 2048, 230400, 8
+    base, chains, want = [], [], []
+    for sd in (12345, 777):
+        iq = ol.synth_iq(block * calls, rds=1, rdsLevel=0.05, rdsBitsSeed=sd)
+        ch = ol.OracleChain(inputFilterBw=165000, rdsMode=2)
+        want.append(ch.process(iq)); base.append(iq); chains.append(ch)
+    dev = torch.device("cuda", 0)
+    d_base = torch.from_numpy(np.stack(base)).to(dev)
+    cap = block // 48 + 96
+    d_pcm = torch.zeros((C, cap, 2), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream     # HIP's default stream = NULL: "the handle's own stream, ordered
+    assert stream == 0                                   # behind the default stream" (include/fmx.h); the input of every
+    f = fmx_amd.Fmx(C, max_block=block, device=0)        # call is produced on the default stream just in front of the call
+    gui_defaults(f)
+    f.set_param(M.P_RDS_MODE, 2)
+    got_pcm, differing = [], 0
+    for i in range(calls):
+        d_iq = d_base[:, i * block:(i + 1) * block].unsqueeze(0).expand(C // 2, 2, block, 2).reshape(C, block, 2).contiguous()
+        frames = f.process_device(d_iq.data_ptr(), block, block, d_pcm.data_ptr(), cap, hip_stream=stream)
+        f.synchronize()
+        out = d_pcm[:, :frames].reshape(C // 2, 2, frames, 2)
+        differing += int((out != out[0:1]).any(dim=3).any(dim=2).sum().item())
+        got_pcm.append(out[0].cpu().numpy())
+    assert differing == 0, f"{differing} (channel, call) pairs differ from channel c % 2"
+    got_pcm = np.concatenate(got_pcm, axis=1)
+    bits = [f.rds_bits(c, 8192) for c in range(C)]
+    for j in range(2):
+        m = want[j].shape[0]
+        assert got_pcm[j].shape[0] - 16384 // 48 - 1 <= m <= got_pcm[j].shape[0]
+        assert rms(got_pcm[j][:m] - want[j]) <= PCM_RMS_TOL, j
+        b_o = chains[j].rds_bits()              # the oracle stopped up to one 16384-sample block (8 bits) short
+        assert len(b_o) > 800 and 0 <= len(bits[j]) - len(b_o) <= 9
+        assert np.count_nonzero(bits[j][460:len(b_o)] != b_o[460:]) <= 2
+    bad = [c for c in range(2, C) if not np.array_equal(bits[c], bits[c % 2])]
+    assert bad == [], f"{len(bad)} channels' RDS bits differ from channel c % 2, first {bad[:8]}"
+    assert np.count_nonzero(bits[0][500:900] != bits[1][500:900]) > 50
 
 
 def test_many_channels_spot_check(fmx_amd, ol):
