@@ -59,6 +59,10 @@ struct fmx_handle_s {
     DemodSync *d_sync = nullptr;
     int *h_stall = nullptr, *d_stall = nullptr;                      // host-mapped: set by the GPU when the persistent layout stalled
     bool partitioned = false; int ev_next = 0;
+    bool stall_reported = false;                                     // the host-mapped stall word was turned into an error once
+    std::vector<int32_t> act_up;                                     // one-shot action bits uploaded with the last parameter upload
+    std::vector<uint8_t> rds_reset_req;                              // resetRds / triggerFrequencyChange asked for the group decoder's reset
+    bool rds_rearm = false;                                          // every channel had RDS off: buffers and state restart at the next enable
     std::vector<hipEvent_t> evs; hipEvent_t ev_join = nullptr, ev_in = nullptr;
     std::mutex mtx;                          // guards the mailbox (set_param from any thread)
     std::vector<ChanUser> user;
@@ -231,8 +235,17 @@ int ensure_lo_table(fmx_handle h) {
     return FMX_OK;
 }
 
+int ensure_rds_body(fmx_handle h);
 int ensure_rds(fmx_handle h) {
     if (h->rds_alloc) return FMX_OK;
+    const int rc = ensure_rds_body(h);
+    if (rc) {                                       // partial failure: give everything back, the next enable tries again
+        for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
+        h->rds_ptrs.clear(); h->R = RdsBuffers{};
+    }
+    return rc;
+}
+int ensure_rds_body(fmx_handle h) {
     const size_t C = (size_t)h->channels;
     const int32_t fmRate = h->cfg.fmRate;
     auto dalloc = [&](void **p, size_t bytes, bool zero) -> int {
@@ -326,6 +339,33 @@ int ensure_rds(fmx_handle h) {
     return FMX_OK;
 }
 
+// RDS was off on every channel and is switched on again: zero the block buffers, overlaps, rings and bit rings and put the
+// slicer states back to their constructor values, so that nothing of the signal before the gap is decoded
+int rds_restart(fmx_handle h) {
+    const size_t C = (size_t)h->channels;
+    RdsBuffers &R = h->R;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(R.in_blk, 0, sizeof(float) * C * RDS_BLK));
+    HIPCHK(hipMemset(R.bpreal, 0, sizeof(float) * C * 2 * RDS_BLK));
+    HIPCHK(hipMemset(R.bp_over, 0, sizeof(float2) * C * 768));
+    HIPCHK(hipMemset(R.hil, 0, sizeof(float2) * C * 2 * RDS_BLK));
+    HIPCHK(hipMemset(R.hil_over, 0, sizeof(float2) * C * 768));
+    HIPCHK(hipMemset(R.phase_ring, 0, sizeof(float) * C * RDS_PHASE_RING));
+    HIPCHK(hipMemset(R.rds24, 0, sizeof(float2) * C * RDS24_RING));
+    HIPCHK(hipMemset(R.bits, 0, C * RDS_BITS_CAP));
+    HIPCHK(hipMemset(R.c_ring, 0, sizeof(float) * C * RDS24_RING));
+    HIPCHK(hipMemset(R.f_ring, 0, sizeof(float) * C * RDS24_RING));
+    HIPCHK(hipMemset(R.state1, 0, sizeof(Rds1State) * C));
+    HIPCHK(hipMemset(R.state3, 0, sizeof(Rds3State) * C));
+    RdsState s0; std::memset(&s0, 0, sizeof(s0));
+    s0.gain = 9.0f; s0.mu = 0.f; s0.skip = 3; s0.sample_count = 0;
+    s0.c_limit = (float)(2 * design::kPi * (double)10.0f / (double)(float)24000);
+    std::vector<RdsState> init(C, s0);
+    HIPCHK(hipMemcpy(R.state, init.data(), sizeof(RdsState) * C, hipMemcpyHostToDevice));
+    h->rds_read.assign(C, 0);                       // the bit counters restart at 0 (fmx_rds_decode sees have < 0 and starts over)
+    return FMX_OK;
+}
+
 int flush_mailbox(fmx_handle h) {
     std::lock_guard<std::mutex> lk(h->mtx);
     if (h->sets_dirty) { int rc = ensure_sets(h); if (rc) return rc; h->params_dirty = true; }
@@ -336,7 +376,14 @@ int flush_mailbox(fmx_handle h) {
     for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
     if (any_rds) {
         int rc = ensure_rds(h); if (rc) return rc;
-        if (h->rds_start < 0) h->rds_start = h->g_total / DECIM;       // the RDS filters start counting here (all channels)
+        if (h->rds_start < 0) {
+            if (h->rds_rearm) { rc = rds_restart(h); if (rc) return rc; h->rds_rearm = false; }
+            h->rds_start = h->g_total / DECIM;       // the RDS filters start counting here (all channels)
+        }
+    } else if (h->rds_start >= 0) {
+        // nobody listens any more: the shared overlap-add block phase ends here; the next enable starts from fresh filters,
+        // rings and slicer states (calls in between are not seen by the RDS path at all)
+        h->rds_start = -1; h->rds_rearm = true;
     }
     bool any_pll = false;
     for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0);     // pllC on the fm-rate IQ; |z| for the level squelch; the general AFC body for the noise squelch
@@ -378,11 +425,41 @@ int flush_mailbox(fmx_handle h) {
     if (h->params_dirty) {
         HIPCHK(hipDeviceSynchronize());   // the previous call may still run on the caller's stream and the side streams
         HIPCHK(hipMemcpy(h->d_params, h->params.data(), sizeof(ChanParams) * h->channels, hipMemcpyHostToDevice));
-        bool had_actions = false;
-        for (auto &p : h->params) { had_actions |= (p.actions != 0); p.actions = 0; }
-        h->params_dirty = had_actions;          // re-upload cleared action bits before the following call
+        // one-shot actions stay pending on the host until a call's kernels have consumed them (actions_consumed): an
+        // upload alone -- a call that fails afterwards, or one too short to hold an fm sample -- must not lose them
+        h->act_up.resize((size_t)h->channels);
+        for (int c = 0; c < h->channels; c++) h->act_up[(size_t)c] = h->params[(size_t)c].actions;
+        h->params_dirty = false;
     }
     return FMX_OK;
+}
+
+// The kernels of a call have been enqueued: the action bits they consume are done.  ACT_DC_RESET belongs to the input-FIR
+// kernel (every call), the other two to the PSS integrator, which only looks at them in a call with at least one fm sample.
+void actions_consumed(fmx_handle h, bool had_fm_samples) {
+    std::lock_guard<std::mutex> lk(h->mtx);
+    if (h->act_up.size() != (size_t)h->channels) return;
+    const int32_t done = ACT_DC_RESET | (had_fm_samples ? (ACT_TRIGGER_FREQ | ACT_RESTART_PSS) : 0);
+    for (int c = 0; c < h->channels; c++) {
+        const int32_t clr = h->act_up[(size_t)c] & done;
+        if (clr) { h->params[(size_t)c].actions &= ~clr; h->act_up[(size_t)c] &= ~clr; h->params_dirty = true; }   // upload the cleared bits before the next call
+    }
+}
+
+// The persistent stage-B layout gives up a wait after ~2 s (fmx_demod.hip pb_wait) and raises a host-mapped word.  That
+// word is a STICKY error: the call it happened in produced invalid output and left the channel states half advanced.  It is
+// reported exactly once -- by the host entry point that ran the call, by fmx_synchronize, or by the next fmx_process_* call of
+// an asynchronous caller -- and the handle uses the event-driven layout from then on.
+int check_stall(fmx_handle h) {
+    if (!h->h_stall || *(volatile int *)h->h_stall == 0 || h->stall_reported) return FMX_OK;
+    h->stall_reported = true;
+    h->partitioned = false;
+    int info[4] = {0, 0, 0, 0};
+    if (h->d_sync) { (void)hipDeviceSynchronize(); (void)hipMemcpy(info, h->d_sync, sizeof(info), hipMemcpyDeviceToHost); (void)hipGetLastError(); }
+    char msg[256];
+    snprintf(msg, sizeof msg, "stage B pipeline stalled (waiter %d needed %d, saw %d): the output of the call it happened in is invalid "
+             "and that call's samples are lost to the demodulator; later calls use the event-driven layout", info[1], info[2], info[3]);
+    return fail(FMX_E_HIP, msg);
 }
 
 void frames_geom(const fmx_handle h, int64_t n, CallGeom *G) {
@@ -400,7 +477,9 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         if (!(s16_den >= 1.0f) || m != 0.5f) return fail(FMX_E_INVALID, "s16_denominator must be a power of two >= 1");
     }
     if (n <= 0 || n > h->cfg.max_block) return fail(FMX_E_TOO_LARGE, "n_complex must be in [1, max_block]");
-    int rc = flush_mailbox(h);
+    int rc = check_stall(h);                      // an earlier asynchronous call stalled and nobody has been told yet
+    if (rc) return rc;
+    rc = flush_mailbox(h);
     if (rc) return rc;
     CallGeom G{};
     frames_geom(h, n, &G);
@@ -409,25 +488,23 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     G.iq_format = fmt; G.iq_scale = (fmt == 3) ? 1.0f / s16_den : 1.0f / 128.0f;
     const int64_t frames = G.M1 - G.M0;
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
+    if (h->rds_alloc && h->rds_start >= 0 && G.J1 - G.J0 > RDS_BLK)
+        return fail(FMX_E_TOO_LARGE, "with RDS on, a call may cover at most 32000 fm samples (384000 input samples)");
     ProfRec pr{}; const bool prof = h->prof_on;
     if (prof) {
         for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&pr.e[i]));
         pr.in_samples = n * h->streams; pr.ch_samples = n * h->channels;
         HIPCHK(hipEventRecord(pr.e[0], s));
     }
+    g_launch_err = hipSuccess;
     launch_front(h->T, h->B, G, d_iq, h->channels, s);
+    FMX_LAUNCHED();
     if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
     {
         static const bool serial = getenv("FMX_SERIAL_STAGE_B") != nullptr;     // diagnostics: no side streams
         DemodStreams DS{};
         for (int i = 0; i < 4; i++) DS.side[i] = serial ? nullptr : h->s_side[i];
         DS.ev = h->evs.data(); DS.nev = (int)h->evs.size(); DS.join = h->ev_join;
-        if (h->partitioned && h->h_stall && *(volatile int *)h->h_stall) {
-            // a wait of the persistent layout ran out of patience in an earlier call (its workgroups were not all resident:
-            // a foreign kernel on the GPU?): that call's output was invalid (fmx_synchronize reports it); use the
-            // event-driven layout from here on
-            h->partitioned = false;
-        }
         DS.rs = h->s_r; DS.ts = h->s_t; DS.sync = h->d_sync; DS.host_flag = h->d_stall;
         DS.partitioned = (h->partitioned && !serial) ? 1 : 0; DS.ev_next = &h->ev_next;
         launch_demod(h->T, h->B, G, h->channels, s, DS);
@@ -436,7 +513,6 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         bool any_rds = false;
         for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
         if (any_rds) {
-            if (G.J1 - G.J0 > RDS_BLK) return fail(FMX_E_TOO_LARGE, "with RDS on, a call may cover at most 32000 fm samples (384000 input samples)");
             const int64_t n0 = G.J0 - h->rds_start;
             int modes = 0;
             for (auto &p : h->params) modes |= 1 << p.rds_mode;
@@ -447,7 +523,9 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     if (prof) HIPCHK(hipEventRecord(pr.e[2], s));
     launch_audio(h->T, h->B, G, d_pcm, h->channels, s);
     if (prof) { HIPCHK(hipEventRecord(pr.e[3], s)); h->prof.push_back(pr); }
-    HIPCHK(hipGetLastError());
+    FMX_LAUNCHED();
+    HIPCHK(g_launch_err);
+    actions_consumed(h, G.J1 > G.J0);
     h->last_J0 = G.J0; h->last_J1 = G.J1;
     h->g_total += n;
     if (n_frames) *n_frames = frames;
@@ -515,6 +593,8 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
 
     fmx_handle h = new (std::nothrow) fmx_handle_s();
     if (!h) return fail(FMX_E_NOMEM, "out of host memory");
+    // every failure below goes through fmx_destroy: nothing of a half-built handle stays behind
+    auto init = [&]() -> int {
     h->cfg = *cfg; h->cfg.stream_of_channel = nullptr;
     h->channels = cfg->channels;
     h->streams = cfg->streams > 0 ? cfg->streams : cfg->channels;
@@ -524,7 +604,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         ChanParams &p = h->params[c];
         std::memset(&p, 0, sizeof(p));
         int s = cfg->stream_of_channel ? cfg->stream_of_channel[c] : (cfg->streams > 0 ? c % h->streams : c);
-        if (s < 0 || s >= h->streams) { delete h; return fail(FMX_E_INVALID, "stream_of_channel entry out of range"); }
+        if (s < 0 || s >= h->streams) return fail(FMX_E_INVALID, "stream_of_channel entry out of range");
         p.stream = s;
         // constructor defaults fm-processor.cpp:110-160 / fm-demodulator.cpp:66
         p.fm_mode = 0; p.sound_sel = 0; p.decoder = 3; p.auto_mono = 1; p.pss_active = 1; p.dc_remove = 1;
@@ -722,8 +802,10 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMemcpy(h->B.state, init.data(), sizeof(ChanState) * C, hipMemcpyHostToDevice));
     }
     h->B.params = h->d_params;
-    int rc = ensure_sets(h);
-    if (rc) { fmx_destroy(h); return rc; }
+    return ensure_sets(h);
+    };
+    const int rc = init();
+    if (rc) { const std::string msg = g_err; (void)fmx_destroy(h); g_err = msg; return rc; }
     *out = h;
     return FMX_OK;
 }
@@ -767,11 +849,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_SOUND_BALANCE: if (iv < -100 || iv > 100) return fail(FMX_E_INVALID, "balance must be -100..100"); break;
     case FMX_P_DEEMPHASIS: if (iv < 1) return fail(FMX_E_INVALID, "de-emphasis must be >= 1 us (Q_ASSERT fm-processor.cpp:293)"); break;
     case FMX_P_BANDWIDTH: if (iv < 0 || iv > h->cfg.inputRate) return fail(FMX_E_INVALID, "bandwidth out of range"); break;
-    case FMX_P_RDS_MODE:
-        if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "rds mode must be 0..3");
-        if (iv == 2 && h->rds_start >= 0 && h->rds_start != h->g_total / DECIM && h->params[channel < 0 ? 0 : channel].rds_mode == 0)
-            return fail(FMX_E_UNSUPPORTED, "switch RDS on for all channels in the same call (shared overlap-add block phase)");
-        break;
+    case FMX_P_RDS_MODE: if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "rds mode must be 0..3"); break;
     case FMX_P_LOCAL_OSCILLATOR:
         if (std::abs(iv) > h->cfg.inputRate) return fail(FMX_E_INVALID, "|lo| must be <= inputRate (oscillator.cpp:49-58)"); break;
     case FMX_P_SQUELCH_MODE:
@@ -786,6 +864,18 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     }
     std::lock_guard<std::mutex> lk(h->mtx);
     const int c0 = channel < 0 ? 0 : channel, c1 = channel < 0 ? h->channels : channel + 1;
+    if (id == FMX_P_RDS_MODE && iv != 0 && h->rds_start >= 0 && h->rds_start != h->g_total / DECIM) {
+        // The two 32768-point overlap-add filters of the RDS front end run on ONE block phase for the whole batch (all three
+        // decoders sit behind them): while other channels are decoding, a channel cannot join in the middle of a block run.
+        for (int c = c0; c < c1; c++)
+            if (h->params[(size_t)c].rds_mode == 0)
+                return fail(FMX_E_UNSUPPORTED, "switch RDS on for all channels in the same call (shared overlap-add block phase); "
+                                               "or switch it off everywhere first: the next enable restarts the RDS path");
+    }
+    if (id == FMX_A_RESET_RDS || id == FMX_A_TRIGGER_FREQUENCY_CHANGE) {
+        if (h->rds_reset_req.size() != (size_t)h->channels) h->rds_reset_req.assign((size_t)h->channels, 0);
+        for (int c = c0; c < c1; c++) h->rds_reset_req[(size_t)c] = 1;      // resetRds (:862-864); triggerFrequencyChange calls it (:852)
+    }
     for (int c = c0; c < c1; c++) {
         ChanUser &u = h->user[c]; ChanParams &p = h->params[c];
         switch (id) {
@@ -882,7 +972,7 @@ int fmx_process_host_raw(fmx_handle h, const void *iq, int32_t format, float s16
                                 h->channels, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (n_frames) *n_frames = got;
-    return FMX_OK;
+    return check_stall(h);
 }
 int fmx_process_host(fmx_handle h, const float *iq, int64_t stream_stride, int64_t n, float *pcm,
                      int64_t pcm_stride, int64_t *n_frames) {
@@ -893,17 +983,7 @@ int fmx_synchronize(fmx_handle h) {
     if (!h) return fail(FMX_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
-    if (h->d_sync) {                             // a stalled stage-B pipeline gives up instead of hanging (fmx_demod.hip pb_wait)
-        int ab[4] = {0, 0, 0, 0};
-        HIPCHK(hipMemcpy(ab, h->d_sync, sizeof(ab), hipMemcpyDeviceToHost));
-        if (ab[0]) {
-            char msg[160];
-            (void)hipMemset(h->d_sync, 0, sizeof(int));          // reported once
-            snprintf(msg, sizeof msg, "stage B pipeline stalled (waiter %d needed %d, saw %d): the call's output is invalid", ab[1], ab[2], ab[3]);
-            return fail(FMX_E_HIP, msg);
-        }
-    }
-    return FMX_OK;
+    return check_stall(h);                       // a stalled stage-B pipeline gives up instead of hanging (fmx_demod.hip pb_wait)
 }
 
 int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
@@ -1030,6 +1110,11 @@ int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {
     if (!h || channel < 0 || channel >= h->channels || !info) return fail(FMX_E_INVALID, "bad argument");
     if ((int)h->rds_dec.size() != h->channels) { h->rds_dec.assign((size_t)h->channels, fmx::RdsGroupDecoderHost()); h->rds_read_dec.assign((size_t)h->channels, 0); }
     fmx::RdsGroupDecoderHost &D = h->rds_dec[(size_t)channel];
+    bool do_reset = false;
+    {
+        std::lock_guard<std::mutex> lk(h->mtx);
+        if (h->rds_reset_req.size() == (size_t)h->channels && h->rds_reset_req[(size_t)channel]) { h->rds_reset_req[(size_t)channel] = 0; do_reset = true; }
+    }
     if (h->rds_alloc) {
         HIPCHK(hipSetDevice(h->cfg.device));
         HIPCHK(hipDeviceSynchronize());
@@ -1037,7 +1122,13 @@ int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {
         HIPCHK(hipMemcpy(&st, h->R.state + channel, sizeof(st), hipMemcpyDeviceToHost));
         int32_t &rd = h->rds_read_dec[(size_t)channel];
         int32_t have = st.nbits - rd;
-        if (have < 0) { rd = 0; have = st.nbits; D.reset_all(); }                      // resetRds restarted the bit count
+        if (have < 0) { rd = 0; have = st.nbits; D.reset_all(); }                      // the RDS path was restarted (rds_restart): new bit count
+        if (do_reset) {
+            // rdsGroupDecoder::reset: PI / PTY / labels back to unknown.  The reference resets between two blocks of samples;
+            // here the decoder runs behind the slicer, so the bits still pending belong to the time before the reset (the
+            // old station after a retune) and are dropped.
+            D.reset_groups(); rd = st.nbits; have = 0;
+        }
         if (have > RDS_BITS_CAP) { rd = st.nbits - RDS_BITS_CAP; have = RDS_BITS_CAP; }   // ring overrun: oldest bits lost
         if (have > 0) {
             std::vector<uint8_t> ring((size_t)RDS_BITS_CAP);
@@ -1046,6 +1137,7 @@ int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {
             rd += have;
         }
     }
+    else if (do_reset) D.reset_groups();
     *info = D.info();
     return FMX_OK;
 }
@@ -1061,7 +1153,10 @@ int fmx_rds_decode_bits(const uint8_t *bits, int32_t n_bits, fmx_rds_info *info)
 
 int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32_t capacity, int32_t *n) {
     if (!h || !dst || !n || channel < 0 || channel >= h->channels) return fail(FMX_E_INVALID, "bad argument");
-    { int rc = flush_mailbox(h); if (rc) return rc; }
+    {   // the tap sets of the CURRENT settings; nothing is uploaded and no pending action is touched (introspection)
+        std::lock_guard<std::mutex> lk(h->mtx);
+        if (h->sets_dirty) { HIPCHK(hipSetDevice(h->cfg.device)); int rc = ensure_sets(h); if (rc) return rc; h->params_dirty = true; }
+    }
     const float *src = nullptr; int cnt = 0;
     std::vector<float> tmp;
     switch (which) {

@@ -25,96 +25,11 @@
 // persistent one -- all recurrences of a call in ONE kernel on its own CUs, progress words in device memory -- and the
 // event-driven one (a five-stream software pipeline of per-chunk kernels).
 #include "fmx_internal.h"
+#include "fmx_demod_math.h"
 
 namespace fmx {
 
-#define FMX_2PI 6.283185307179586476925286766559   /* 2 * M_PI as the double the reference uses */
-#define FMX_PI_4 0.78539816339744830962
-
-// exact fmod(x, 2*pi) for |x| < 8*pi by Sterbenz-exact subtractions (the generic ocml fmod is a
-// long loop; every use here is within a few turns).  Falls back to fmod outside that range.
-__device__ __attribute__((noinline)) double fmod_2pi_slow(double x) { return fmod(x, FMX_2PI); }
-__device__ __forceinline__ double fmod_2pi(double x) {
-    double ax = fabs(x);
-    if (__builtin_expect(!(ax < 4 * FMX_2PI), 0)) return fmod_2pi_slow(x);   // also NaN/inf
-    ax = (ax >= 2 * FMX_2PI) ? ax - 2 * FMX_2PI : ax;
-    ax = (ax >= FMX_2PI) ? ax - FMX_2PI : ax;
-    return copysign(ax, x);
-}
-// ---- PI_Constrain fm-constants.h:148-158; the in-range test is done in f32:
-//      val < 2*M_PI (double)  <=>  val < 6.2831855f (the float just above 2*pi)
-__device__ __forceinline__ float pi_constrain(float val) {
-    if (val >= 0.f && val < 6.2831855f) return val;
-    const double v = (double)val;
-    if (v >= FMX_2PI) return (float)fmod_2pi(v);
-    if (v > -FMX_2PI) return (float)(v + FMX_2PI);
-    return (float)(FMX_2PI - fmod_2pi(-v));
-}
-// PI_Constrain for arguments known to lie in (-2*pi, 4*pi) (the pilot phase after one update):
-// branch-free selects; v - 2*pi is exact for v in [2*pi, 4*pi) (Sterbenz), as is fmod there.
-__device__ __forceinline__ float pi_constrain_near(float val) {
-    // (the pilot phase is [0, 2pi) +- 5*|demod|*gain + omega: |5*demod*gain| < 0.01 since |demod| < 4.1)
-    const double v = (double)val;
-    const float hi = (float)(v - FMX_2PI), lo = (float)(v + FMX_2PI);
-    return (val < 0.f) ? lo : ((val < 6.2831855f) ? val : hi);
-}
-// x / c for a CONSTANT c with rc = RN(1/c): q0 = x*rc; r = fma(-q0, c, x); q = fma(r, rc, q0).
-// Markstein's correction step gives the correctly rounded IEEE quotient; verified exhaustively on the
-// host for K_FM and the pilot omega over |x| in [2^-60, 2^60] (DESIGN.md "exact division by constants").
-__device__ __forceinline__ float fdiv_const(float x, float c, float rc) {
-    const float q0 = x * rc;
-    const float r = __fmaf_rn(-q0, c, x);
-    return __fmaf_rn(r, rc, q0);
-}
-// ---- SinCos sincos.cpp:63-97
-__device__ __forceinline__ int sc_index(float phase, double C) {    // phase >= 0
-    return ((int)((double)phase * C)) % SINCOS_N;
-}
-__device__ __forceinline__ float sc_sin(const float2 *__restrict__ tab, double C, float phase) {
-    if (phase < 0) return -tab[sc_index(-phase, C)].y;
-    return tab[sc_index(phase, C)].y;
-}
-__device__ __forceinline__ float sc_wrap(float phase) {
-    while (phase < 0) phase = (float)((double)phase + FMX_2PI);
-    return (float)fmod_2pi((double)phase);
-}
-__device__ __forceinline__ float2 sc_complex(const float2 *__restrict__ tab, double C, float phase) {
-    return tab[sc_index(sc_wrap(phase), C)];
-}
-// ---- compAtan::atan2 Xtan2.cpp:56-100.  Only the PPY table is stored; the other seven tables are
-// the reference's own f32 expressions of it (Xtan2.cpp:31-38), evaluated here with the same ops.
-__device__ __forceinline__ int at_idx(float size, float num, float den) {
-    return (int)((double)(size * num / den) + 0.5);
-}
-// Branch-free: a wavefront's lanes fall into all eight octants (the FM phase step reaches +-2.4 rad), so the
-// reference's if-tree would execute every arm one after the other.  Octant -> (table sign `size`, numerator /
-// denominator, offset A, sign of the table value); every arm is  A + (+-table[idx])  with one f32 addition, which
-// is the reference's own expression (a - t == a + (-t) etc. in IEEE arithmetic).
-__device__ __forceinline__ float lut_atan2(const float *__restrict__ ppy, float y, float x) {
-    const float St = (float)3.14159265358979323846, Sh = St * 0.5f;
-    const bool special = isinf(x) || isinf(y) || isnan(x) || isnan(y) || x == 0.f;
-    const bool xpos = x > 0.f, ypos = y >= 0.f;
-    const bool swap = !(fabsf(x) >= fabsf(y));                 // the ..X arms: |y| > |x|
-    const bool same = xpos == ypos;
-    const float size = same ? (float)ATAN_N : -(float)ATAN_N;  // PPY PPX NNY NNX use +Size, the others -Size
-    const float num = swap ? x : y, den = swap ? y : x;
-    int idx = at_idx(size, num, special ? 1.f : den);
-    idx = special ? 0 : idx;
-    const float tv = ppy[idx];
-    const float A = swap ? (ypos ? Sh : -Sh) : (xpos ? 0.f : (ypos ? St : -St));
-    const float r = A + ((same == swap) ? -tv : tv);
-    if (special) {
-        if (x == 0.f && y != 0.f && !isnan(y) && !isinf(y)) return y > 0.f ? (float)(3.14159265358979323846 / 2) : (float)(-3.14159265358979323846 / 2);
-        return 0.f;
-    }
-    return r;
-}
-// ---- limiter fm-demodulator.cpp:119-126 (std::abs(complex<float>) == hypotf == f64 sqrt of f64 sum)
-__device__ __forceinline__ float2 limiter(float2 z) {
-    const float zAbs = (float)sqrt((double)z.x * (double)z.x + (double)z.y * (double)z.y);
-    if ((double)zAbs <= 0.001) return make_float2((float)0.001, (float)0.001);
-    return make_float2(z.x / zAbs, z.y / zAbs);
-}
+thread_local hipError_t g_launch_err = hipSuccess;
 
 // How a time-parallel kernel meets the persistent recurrence kernel (launch_demod_persistent); all null / zero on the
 // event-driven path.  `sig`: completion word of the kernel in FRONT of this one on the stream -- stored by this kernel's
@@ -1178,7 +1093,7 @@ __global__ __launch_bounds__(64) void sync_init_kernel(DemodSync *S, int groups,
 template <bool PLLDEC, bool T2, bool W32>
 static void launch_recurrences(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, const ChunkPlan &P,
                                DemodSync *S, int groups, hipStream_t s) {
-    hipLaunchKernelGGL((recurrences_kernel<PLLDEC, T2, W32>), dim3((unsigned)groups, PB_ROLES), dim3(64), 0, s, T, B, G, C, P, S, groups);
+    hipLaunchKernelGGL((recurrences_kernel<PLLDEC, T2, W32>), dim3((unsigned)groups, PB_ROLES), dim3(64), 0, s, T, B, G, C, P, S, groups); FMX_LAUNCHED();
 }
 
 // Occupancy of the persistent kernel (blocks per CU), for the co-residency check the host makes before choosing this layout.
@@ -1215,11 +1130,11 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
     }
     { static const int rm = getenv("FMX_DEBUG_ROLE_MASK") ? atoi(getenv("FMX_DEBUG_ROLE_MASK")) : 31; P.role_mask = rm; }
     DemodSync *S = DS.sync;
-    (void)hipMemsetAsync(S, 0, sizeof(DemodSync) + sizeof(int) * PB_ROLES * groups, s);
-    hipLaunchKernelGGL(sync_init_kernel, dim3(1), dim3(64), 0, s, S, groups, DS.host_flag);
+    note_hip(hipMemsetAsync(S, 0, sizeof(DemodSync) + sizeof(int) * PB_ROLES * groups, s));
+    hipLaunchKernelGGL(sync_init_kernel, dim3(1), dim3(64), 0, s, S, groups, DS.host_flag); FMX_LAUNCHED();
     hipEvent_t e0 = DS.ev[(*DS.ev_next)++ % DS.nev];
-    (void)hipEventRecord(e0, s);                                   // the front kernel's output and the cleared words
-    (void)hipStreamWaitEvent(DS.rs, e0, 0); (void)hipStreamWaitEvent(DS.ts, e0, 0);
+    note_hip(hipEventRecord(e0, s));                                   // the front kernel's output and the cleared words
+    note_hip(hipStreamWaitEvent(DS.rs, e0, 0)); note_hip(hipStreamWaitEvent(DS.ts, e0, 0));
     const bool plldec = B.w_iq != nullptr;
     if (T.trig2 && T.wrap32_ok) { if (plldec) launch_recurrences<true, true, true>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, true, true>(T, B, G, C, P, S, groups, DS.rs); }
     else if (T.trig2) { if (plldec) launch_recurrences<true, true, false>(T, B, G, C, P, S, groups, DS.rs); else launch_recurrences<false, true, false>(T, B, G, C, P, S, groups, DS.rs); }
@@ -1238,7 +1153,7 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
         return Y;
     };
     auto disc = [&](int c) {
-        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((P.len[c] + DISC_ROWS - 1) / DISC_ROWS), (unsigned)((C + DISC_CH - 1) / DISC_CH)), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(-1, 0));
+        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((P.len[c] + DISC_ROWS - 1) / DISC_ROWS), (unsigned)((C + DISC_CH - 1) / DISC_CH)), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(-1, 0)); FMX_LAUNCHED();
         pend_p = &S->cnt_disc[c]; pend_v = P.nb_disc[c];
     };
     // One stream for all the time-parallel kernels.  Chunks are at most HALF the PSS feedback lag long, so the low-pass of
@@ -1249,26 +1164,28 @@ static void launch_demod_persistent(const DeviceTables &T, const DeviceBuffers &
     auto fir = [&](int c) {
         DeviceBuffers Bc = B;
         Bc.w_err = B.w_err + (size_t)(c & 1) * (PB_CHUNK / WT) * G.pitch * WT;
-        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((P.len[c] + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, tq, T, Bc, G, C, (int64_t)P.rc0[c], P.len[c], ysync(2, c + 1));
+        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((P.len[c] + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, tq, T, Bc, G, C, (int64_t)P.rc0[c], P.len[c], ysync(2, c + 1)); FMX_LAUNCHED();
         pend_p = &S->cnt_fir[c]; pend_v = P.nb_fir[c];
     };
     auto mix = [&](int c) {
-        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((P.len[c] + MIX_ROWS - 1) / MIX_ROWS), (unsigned)((C + MIX_CH - 1) / MIX_CH)), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(3, c + 1));
+        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((P.len[c] + MIX_ROWS - 1) / MIX_ROWS), (unsigned)((C + MIX_CH - 1) / MIX_CH)), dim3(256), 0, tq, T, B, G, C, (int64_t)P.rc0[c], P.len[c], ysync(3, c + 1)); FMX_LAUNCHED();
         pend_p = &S->cnt_mix[c]; pend_v = P.nb_mix[c];
     };
-    hipLaunchKernelGGL(start_gate_kernel, dim3(1), dim3(64), 0, tq, S, PB_ROLES * groups);
+    // FMX_DEBUG_FORCE_STALL (tests): the gate asks for one workgroup more than exist, so the pipeline gives up after ~2 s
+    const int force_stall = getenv("FMX_DEBUG_FORCE_STALL") ? atoi(getenv("FMX_DEBUG_FORCE_STALL")) : 0;
+    hipLaunchKernelGGL(start_gate_kernel, dim3(1), dim3(64), 0, tq, S, PB_ROLES * groups + (force_stall ? 1 : 0)); FMX_LAUNCHED();
     for (int c = 0; c < LEAD && c < P.n; c++) disc(c);
     for (int c = 0; c < P.n + 1; c++) {
         if (c < P.n) fir(c);
         if (c + LEAD < P.n) disc(c + LEAD);
         if (c >= 1 && c - 1 < P.n) mix(c - 1);
     }
-    if (pend_p) hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, tq, pend_p, pend_v);
+    if (pend_p) hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, tq, pend_p, pend_v); FMX_LAUNCHED();
     hipStream_t ends[2] = { DS.rs, DS.ts };
     for (hipStream_t q : ends) {
         hipEvent_t e = DS.ev[(*DS.ev_next)++ % DS.nev];
-        (void)hipEventRecord(e, q);
-        (void)hipStreamWaitEvent(s, e, 0);
+        note_hip(hipEventRecord(e, q));
+        note_hip(hipStreamWaitEvent(s, e, 0));
     }
 }
 
@@ -1287,8 +1204,8 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
     auto hand_over = [&](int from, int to, int c) {
         if (st[from] == st[to]) return;
         hipEvent_t e = DS.ev[(4 * c + from) % DS.nev];
-        (void)hipEventRecord(e, st[from]);
-        (void)hipStreamWaitEvent(st[to], e, 0);
+        note_hip(hipEventRecord(e, st[from]));
+        note_hip(hipStreamWaitEvent(st[to], e, 0));
     };
     // The first chunk is short: the five-stage pipeline fills in the time of 256 samples instead of 1744 (the call's
     // first PSS kernel starts ~0.2 ms earlier); any chunk length <= PSS_CHUNK that is a multiple of the tile is valid.
@@ -1301,24 +1218,24 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         const int last = (rc0 + len >= nj) ? 1 : 0;
         // the discriminator runs per chunk in front of the AFC (a stage with time to spare), so the first PSS kernel
         // starts after 256 rows of it instead of after the whole call's
-        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + DISC_ROWS - 1) / DISC_ROWS), (unsigned)((C + DISC_CH - 1) / DISC_CH)), dim3(256), 0, st[0], T, B, G, C, rc0, len, TSync{});
+        hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((len + DISC_ROWS - 1) / DISC_ROWS), (unsigned)((C + DISC_CH - 1) / DISC_CH)), dim3(256), 0, st[0], T, B, G, C, rc0, len, TSync{}); FMX_LAUNCHED();
         if (B.w_iq) hipLaunchKernelGGL(afc_kernel<true>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
-        else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len);
+        else hipLaunchKernelGGL(afc_kernel<false>, lanes, dim3(64), 0, st[0], T, B, G, C, rc0, len); FMX_LAUNCHED();
         hand_over(0, 1, c);
         if (T.trig2 && T.wrap32_ok) hipLaunchKernelGGL((pll_kernel<true, true>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
         else if (T.trig2) hipLaunchKernelGGL((pll_kernel<true, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
-        else hipLaunchKernelGGL((pll_kernel<false, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len);
+        else hipLaunchKernelGGL((pll_kernel<false, false>), lanes, dim3(64), 0, st[1], T, B, G, C, rc0, len); FMX_LAUNCHED();
         hand_over(1, 2, c);
-        hipLaunchKernelGGL(lock_kernel, lanes, dim3(64), 0, st[2], T, B, G, C, rc0, len);
+        hipLaunchKernelGGL(lock_kernel, lanes, dim3(64), 0, st[2], T, B, G, C, rc0, len); FMX_LAUNCHED();
         hand_over(2, 3, c);
-        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, st[3], T, B, G, C, rc0, len, TSync{});
-        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, st[3], T, B, G, C, rc0, len);
-        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + MIX_ROWS - 1) / MIX_ROWS), (unsigned)((C + MIX_CH - 1) / MIX_CH)), dim3(256), 0, st[3], T, B, G, C, rc0, len, TSync{});
+        hipLaunchKernelGGL(pss_fir_kernel, dim3((unsigned)((len + PSS_TILE - 1) / PSS_TILE), (unsigned)C), dim3(64), 0, st[3], T, B, G, C, rc0, len, TSync{}); FMX_LAUNCHED();
+        hipLaunchKernelGGL(pss_acc_kernel, lanes, dim3(64), 0, st[3], T, B, G, C, rc0, len); FMX_LAUNCHED();
+        hipLaunchKernelGGL(pss_mix_kernel, dim3((unsigned)((len + MIX_ROWS - 1) / MIX_ROWS), (unsigned)((C + MIX_CH - 1) / MIX_CH)), dim3(256), 0, st[3], T, B, G, C, rc0, len, TSync{}); FMX_LAUNCHED();
         hand_over(3, 4, c);
-        hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last);
+        hipLaunchKernelGGL(deemph_kernel, lanes, dim3(64), 0, st[4], T, B, G, C, rc0, len, last); FMX_LAUNCHED();
         rc0 += len;
     }
-    if (s3 != s) { (void)hipEventRecord(DS.join, s3); (void)hipStreamWaitEvent(s, DS.join, 0); }
+    if (s3 != s) { note_hip(hipEventRecord(DS.join, s3)); note_hip(hipStreamWaitEvent(s, DS.join, 0)); }
 }
 
 }  // namespace fmx

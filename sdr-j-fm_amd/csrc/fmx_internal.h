@@ -251,6 +251,11 @@ struct DemodSync {                      // zeroed at the start of every call
 struct DemodStreams { hipStream_t side[4]; hipEvent_t *ev; int nev; hipEvent_t join; hipStream_t rs; hipStream_t ts;
                       int partitioned; int *ev_next; DemodSync *sync; int *host_flag; };
 int recurrences_blocks_per_cu();
+// first HIP error of the launches / event calls of the current fmx_process_* call (they are enqueued by void helpers);
+// run_call clears it before the launches and turns it into FMX_E_HIP behind them
+extern thread_local hipError_t g_launch_err;
+inline void note_hip(hipError_t e) { if (e != hipSuccess && g_launch_err == hipSuccess) g_launch_err = e; }
+#define FMX_LAUNCHED() ::fmx::note_hip(hipGetLastError())
 void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s,
                   const DemodStreams &DS);
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,

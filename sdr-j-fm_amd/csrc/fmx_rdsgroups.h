@@ -17,7 +17,11 @@ namespace fmx {
 class RdsGroupDecoderHost {
 public:
     RdsGroupDecoderHost() { reset_all(); }
-    void reset_all() { sync_reset(); groups_reset(); info_ = fmx_rds_info{}; fill_info(); }
+    void reset_all() { sync_reset(); groups_reset(); groups_ok_ = 0; last_type_ = -1; info_ = fmx_rds_info{}; fill_info(); }
+    // fmProcessor::resetRds -> rdsDecoder::reset -> rdsGroupDecoder::reset (fm-processor.cpp:862-864, rds-decoder.cpp:65-67,
+    // rds-groupdecoder.cpp:71-98): PI, PTY, station label, radio text, M/S and AF go back to "unknown"; the block
+    // synchroniser keeps running
+    void reset_groups() { groups_reset(); last_type_ = -1; fill_info(); }
     // one sliced bit (rds-decoder.cpp:104-131)
     void push_bit(bool b) {
         switch (push(b)) {

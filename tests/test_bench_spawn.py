@@ -1,0 +1,32 @@
+"""bench.py --gpus N without a torchrun environment must spawn N ranks itself (round-1 finding: the flag was parsed
+and ignored).  The spawn path is driven here on CPU with gloo: two ranks meet, run the max-over-ranks timing reduction
+and the PCM gather leg on host tensors, and rank 0 prints ONE line whose n_gpus equals N.  No GPU work, no oracle."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env=None):
+    e = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=e, capture_output=True, text=True, timeout=600)
+
+
+def test_gpus_flag_spawns_ranks():
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest-spawn"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["selftest"] is True and out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["max_dt"] == 0.75 and out["per_rank"] == [0.0, 1.0] and out["scaling"] == "weak"
+
+
+def test_world_size_mismatch_fails_loudly():
+    p = _run(["--gpus", "4", "--selftest-spawn"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)

@@ -1,0 +1,162 @@
+"""GPU tests added in round 2: error paths and host-side bookkeeping found by the round-1 review (stalled stage-B
+pipeline as a sticky error, resetRds / triggerFrequencyChange reaching the RDS group decoder, one-shot actions surviving
+introspection calls, RDS off-everywhere -> on again), all through the C ABI."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M = importlib.import_module("sdr-j-fm_amd").fmx
+PCM_RMS_TOL = 1e-5
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.asarray(a, np.float64) ** 2)))
+
+
+def gui_defaults(f, bw=165000):
+    f.set_param(M.P_BANDWIDTH, bw)
+    f.set_param(M.P_LF_CUTOFF, 15000)
+    f.set_param(M.P_DEEMPHASIS, 50)
+    f.set_param(M.P_VOLUME_DB, -6.0)
+    f.set_param(M.P_FM_MODE, 0)
+
+
+def test_forced_stall_is_a_sticky_error(fmx_amd, ol, monkeypatch):
+    """The persistent stage-B layout waits on words written by other kernels; a wait that runs out of patience (~2 s) must
+    surface as FMX_E_HIP exactly once -- from the host call it happened in, or from the NEXT call / fmx_synchronize of an
+    asynchronous caller -- never as FMX_OK with garbage PCM, and the handle must keep working on the event-driven layout.
+    FMX_DEBUG_FORCE_STALL makes the start gate ask for one workgroup more than exist.  The PLL decoder keeps the handle on
+    the chunked layouts (the fused per-channel kernel has no inter-workgroup waits)."""
+    block = 16384
+    nb = 24                                         # past the latencies of the input filter (65285 samples) and the audio filter (7436 fm samples)
+    iq = ol.synth_iq(nb * block)
+    monkeypatch.setenv("FMX_PERSISTENT_MIN_CHANNELS", "1")
+    monkeypatch.setenv("FMX_DEBUG_FORCE_STALL", "1")
+    f = fmx_amd.Fmx(1, max_block=block)
+    gui_defaults(f)
+    f.set_param(M.P_FM_DECODER, 2)
+    with pytest.raises(fmx_amd.FmxError) as e:
+        f.process_host(iq[:block])
+    assert e.value.code == M.FMX_E_HIP and "stalled" in str(e.value)
+    monkeypatch.delenv("FMX_DEBUG_FORCE_STALL")
+    f.synchronize()                                   # reported once: the error is not repeated
+    outs = [f.process_host(iq[i:i + block]) for i in range(block, nb * block, block)]     # event-driven layout from here on
+    f.synchronize()
+    pcm = np.concatenate(outs, axis=1)[0]
+    assert np.all(np.isfinite(pcm)) and rms(pcm[-600:]) > 1e-3          # the chain runs again (fade-in under way)
+
+    # asynchronous caller: the stalled call itself returns FMX_OK (nothing is known yet); the NEXT call must refuse
+    import torch
+    monkeypatch.setenv("FMX_DEBUG_FORCE_STALL", "1")
+    g = fmx_amd.Fmx(1, max_block=block)
+    gui_defaults(g)
+    g.set_param(M.P_FM_DECODER, 2)
+    d_iq = torch.from_numpy(iq[:block].copy()).cuda()
+    d_pcm = torch.zeros((1, block // 48 + 8, 2), dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    g.process_device(d_iq.data_ptr(), block, block, d_pcm.data_ptr(), d_pcm.shape[1], hip_stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("FMX_DEBUG_FORCE_STALL")
+    with pytest.raises(fmx_amd.FmxError) as e2:
+        g.process_device(d_iq.data_ptr(), block, block, d_pcm.data_ptr(), d_pcm.shape[1], hip_stream=st.cuda_stream)
+    assert e2.value.code == M.FMX_E_HIP
+    g.process_device(d_iq.data_ptr(), block, block, d_pcm.data_ptr(), d_pcm.shape[1], hip_stream=st.cuda_stream)
+    g.synchronize()
+
+
+def test_reset_rds_and_retune_clear_the_programme(fmx_amd, ol):
+    """resetRds() -> rdsGroupDecoder::reset (fm-processor.cpp:862-864, rds-groupdecoder.cpp:71-98) clears PI, PTY, the
+    station label and the radio text; triggerFrequencyChange() does the same (:849-855).  After a retune to another
+    programme the old PS / RT must not be reported until groups of the new PI arrive."""
+    block = 16384 * 20
+    n = int(2.4 * 2304000) // block * block
+    pa = dict(pi=0xD3A1, pty=10, ps="FMX-AMD ", text="HIP KERNELS ON MI355X - RDS OK")
+    pb = dict(pi=0x2468, pty=3, ps="CHAN TWO", text="SECOND STREAM")
+    iq_a = ol.synth_iq(n, rds=1, rdsLevel=0.05, rds_payload=ol.rds_programme_bits(**pa))
+    iq_b = ol.synth_iq(n, rds=1, rdsLevel=0.05, rds_payload=ol.rds_programme_bits(**pb))
+    f = fmx_amd.Fmx(1, max_block=block)
+    gui_defaults(f)
+    f.set_param(M.P_RDS_MODE, 2)
+    for i in range(0, n, block):
+        f.process_host(iq_a[i:i + block])
+    info = f.rds_decode(0)
+    assert info.pi_code == pa["pi"] and info.station_label.decode() == pa["ps"] and info.groups_decoded >= 8
+    f.set_param(M.A_RESET_RDS, 0)
+    info = f.rds_decode(0)
+    assert info.pi_code == 0 and info.pty_code == -1 and info.station_label.decode().strip() == "" and info.radio_text.decode() == ""
+    assert info.last_group_type == -1
+    # same station keeps sending: the programme comes back
+    for i in range(0, 6 * block, block):
+        f.process_host(iq_a[i:i + block])
+    assert f.rds_decode(0).pi_code == pa["pi"]
+    # retune: triggerFrequencyChange, then the other programme
+    f.set_param(M.A_TRIGGER_FREQUENCY_CHANGE, 0)
+    f.process_host(iq_b[:block])
+    info = f.rds_decode(0)
+    assert info.pi_code in (0, pb["pi"]) and info.station_label.decode() != pa["ps"] and info.radio_text.decode() != pa["text"]
+    for i in range(block, n, block):
+        f.process_host(iq_b[i:i + block])
+    info = f.rds_decode(0)
+    assert info.pi_code == pb["pi"] and info.station_label.decode() == pb["ps"] and info.radio_text.decode() == pb["text"]
+
+
+def test_pending_action_survives_introspection_and_tiny_calls(fmx_amd, ol):
+    """A one-shot action (triggerFrequencyChange: fade-in re-armed, PSS restarted) set before an introspection call
+    (fmx_get_taps), a failing call (pcm capacity too small) and a call too short to hold one fm sample must still be applied
+    by the first call that runs stage B, and only once."""
+    block = 16384
+    iq = ol.synth_iq(40 * block)
+    f = fmx_amd.Fmx(1, max_block=block)
+    gui_defaults(f, 0)
+    ref = fmx_amd.Fmx(1, max_block=block)
+    gui_defaults(ref, 0)
+    for i in range(0, 30 * block, block):
+        f.process_host(iq[i:i + block]); ref.process_host(iq[i:i + block])
+    f.set_param(M.A_TRIGGER_FREQUENCY_CHANGE, 0)
+    ref.set_param(M.A_TRIGGER_FREQUENCY_CHANGE, 0)
+    assert f.taps(0).size == 37                     # introspection between the setter and the call
+    import ctypes as C
+    got = C.c_int64()
+    one = np.zeros((1, 1, 2), np.float32)
+    rc = f.L.fmx_process_host(f.h, iq[30 * block:].ctypes.data_as(C.POINTER(C.c_float)), block, block,
+                              one.ctypes.data_as(C.POINTER(C.c_float)), 1, C.byref(got))
+    assert rc == M.FMX_E_TOO_LARGE                  # fails AFTER the mailbox was flushed; nothing was processed
+    a = [f.process_host(iq[30 * block + i: 30 * block + i + 4]) for i in range(0, 8, 4)]      # 8 samples: no fm sample yet
+    assert all(x.shape[1] == 0 for x in a)
+    b0 = ref.process_host(iq[30 * block: 30 * block + 8])
+    assert b0.shape[1] == 0
+    pa = np.concatenate([f.process_host(iq[30 * block + 8 + i: 30 * block + 8 + i + block]) for i in range(0, 8 * block, block)], axis=1)
+    pb = np.concatenate([ref.process_host(iq[30 * block + 8 + i: 30 * block + 8 + i + block]) for i in range(0, 8 * block, block)], axis=1)
+    assert np.abs(pa[0, :10]).max() < 1e-3          # the fade restarted from 0 in the first call that produced frames
+    assert np.array_equal(pa, pb)                   # and exactly as for a handle that went straight to that call
+
+
+def test_rds_off_everywhere_then_on_again(fmx_amd, ol):
+    """When every channel switches RDS off, the shared block phase of the RDS front end ends; switching it on again later
+    (any decoder) starts from fresh filters and slicer states instead of decoding stale blocks across the gap."""
+    block = 16384 * 20
+    n = int(2.2 * 2304000) // block * block
+    p = dict(pi=0xD3A1, pty=10, ps="FMX-AMD ", text="HIP KERNELS ON MI355X - RDS OK")
+    iq = ol.synth_iq(2 * n, rds=1, rdsLevel=0.05, rds_payload=ol.rds_programme_bits(**p))
+    f = fmx_amd.Fmx(2, streams=1, stream_of_channel=[0, 0], max_block=block)
+    gui_defaults(f)
+    f.set_param(M.P_RDS_MODE, 2)
+    for i in range(0, block * 4, block):
+        f.process_host(iq[i:i + block])
+    with pytest.raises(fmx_amd.FmxError):           # one channel off, the other still decoding: it cannot rejoin mid-block ...
+        f.set_param(M.P_RDS_MODE, 0, 1); f.process_host(iq[4 * block:5 * block]); f.set_param(M.P_RDS_MODE, 1, 1)
+    f.set_param(M.P_RDS_MODE, 0)                    # ... but after RDS went off everywhere
+    for i in range(5 * block, 8 * block, block):
+        f.process_host(iq[i:i + block])
+    f.set_param(M.P_RDS_MODE, 2, 0); f.set_param(M.P_RDS_MODE, 1, 1)      # any decoder may start again
+    k0 = 8 * block
+    for i in range(k0, k0 + n, block):
+        f.process_host(iq[i:i + block])
+    for c in range(2):
+        info = f.rds_decode(c)
+        assert info.synchronized == 1 and info.pi_code == p["pi"] and info.station_label.decode() == p["ps"], c
+        assert info.crc_errors <= 2
