@@ -59,6 +59,9 @@ struct fmx_handle_s {
     DemodSync *d_sync = nullptr;
     int *h_stall = nullptr, *d_stall = nullptr;                      // host-mapped: set by the GPU when the persistent layout stalled
     bool partitioned = false; int ev_next = 0;
+    bool never_fused = false;                                        // FMX_STAGE_B=chunked at fmx_create
+    bool fused = false;                                              // stage B runs as the fused per-channel kernel (fmx_stageb.hip)
+    bool last_lin = false;                                           // ... and did so in the last call (layout of the scope tap arrays)
     bool stall_reported = false;                                     // the host-mapped stall word was turned into an error once
     std::vector<int32_t> act_up;                                     // one-shot action bits uploaded with the last parameter upload
     std::vector<uint8_t> rds_reset_req;                              // resetRds / triggerFrequencyChange asked for the group decoder's reset
@@ -217,6 +220,7 @@ void refresh_derived(fmx_handle h, int c) {
     } else {                                    // ctor :174
         p.deemph_alpha = (float)(1.0 / (fmRate / (1000000.0 / 50.0 + 1)));
     }
+    p.deemph_l2 = (float)std::log2((double)(1.0f - p.deemph_alpha));
     p.volume = u.ctor_volume ? 0.5f : std::pow(10.0f, u.volume_db / 20.0f);        // :127, :299-301
     p.left_ch = (u.balance > 0 ? (float)((100 - u.balance) / 100.0) : 1.0f);       // :282-286
     p.right_ch = (u.balance < 0 ? (float)((100 + u.balance) / 100.0) : 1.0f);
@@ -389,6 +393,11 @@ int flush_mailbox(fmx_handle h) {
     for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0);     // pllC on the fm-rate IQ; |z| for the level squelch; the general AFC body for the noise squelch
     bool any_nsq = false;
     for (auto &p : h->params) any_nsq |= (p.squelch_mode == 1);
+    {   // The fused stage-B layout covers the memoryless discriminators without squelch (every BASELINE config); the PLL / AM
+        // decoders and the squelches -- recurrences of their own -- run on the chunked layouts of fmx_demod.hip.
+        // FMX_STAGE_B=chunked keeps the chunked layouts for everything (A/B runs, tests).
+        h->fused = !h->never_fused && !any_pll;
+    }
     if (any_nsq && !h->d_nsq) {
         // squelch ctor squelchClass.cpp:11-18 with mySquelch (1, 70000, fmRate / 20, fmRate) fm-processor.cpp:87
         const design::Iir hp = design::iir_chebyshev_lowhigh(true, 20, 70000 - 100, h->cfg.fmRate);
@@ -497,6 +506,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         HIPCHK(hipEventRecord(pr.e[0], s));
     }
     g_launch_err = hipSuccess;
+    h->B.lin_rows = h->fused ? (int32_t)h->work_nj : 0;
     launch_front(h->T, h->B, G, d_iq, h->channels, s);
     FMX_LAUNCHED();
     if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
@@ -507,7 +517,10 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         DS.ev = h->evs.data(); DS.nev = (int)h->evs.size(); DS.join = h->ev_join;
         DS.rs = h->s_r; DS.ts = h->s_t; DS.sync = h->d_sync; DS.host_flag = h->d_stall;
         DS.partitioned = (h->partitioned && !serial) ? 1 : 0; DS.ev_next = &h->ev_next;
-        launch_demod(h->T, h->B, G, h->channels, s, DS);
+        h->B.lin_rows = h->fused ? (int32_t)h->work_nj : 0;
+        if (h->fused) launch_demod_fused(h->T, h->B, G, h->channels, s);
+        else launch_demod(h->T, h->B, G, h->channels, s, DS);
+        h->last_lin = h->fused;
     }
     if (h->rds_alloc && h->rds_start >= 0) {
         bool any_rds = false;
@@ -596,6 +609,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     // every failure below goes through fmx_destroy: nothing of a half-built handle stays behind
     auto init = [&]() -> int {
     h->cfg = *cfg; h->cfg.stream_of_channel = nullptr;
+    h->never_fused = getenv("FMX_STAGE_B") && std::string(getenv("FMX_STAGE_B")) == "chunked";
     h->channels = cfg->channels;
     h->streams = cfg->streams > 0 ? cfg->streams : cfg->channels;
     h->user.assign(h->channels, ChanUser());
@@ -670,6 +684,18 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
             sc[i] = make_float2((float)std::cos(2 * design::kPi * i / fmRate), (float)std::sin(2 * design::kPi * i / fmRate));
         HIPCHK(hipMalloc(&h->d_sincos, sizeof(float2) * SINCOS_N));
         HIPCHK(hipMemcpy(h->d_sincos, sc.data(), sizeof(float2) * SINCOS_N, hipMemcpyHostToDevice));
+        {   // the table as two polynomials (SinPoly): accept it only if it reproduces every entry, bar a few listed exceptions
+            SinPoly sp{}; sp.step = 2 * design::kPi / fmRate;
+            bool fits = (fmRate == SINCOS_N);
+            for (int i = 0; fits && i < SINCOS_N; i++) {
+                float sn, cs;
+                sincos_poly(i, sp.step, &sn, &cs);
+                if (std::memcmp(&sn, &sc[i].y, 4) != 0) { if (sp.ns < 4) { sp.s_idx[sp.ns] = i; sp.s_val[sp.ns] = sc[i].y; sp.ns++; } else fits = false; }
+                if (std::memcmp(&cs, &sc[i].x, 4) != 0) { if (sp.nc < 4) { sp.c_idx[sp.nc] = i; sp.c_val[sp.nc] = sc[i].x; sp.nc++; } else fits = false; }
+            }
+            sp.ok = (fits && !getenv("FMX_DEBUG_NO_SINPOLY")) ? 1 : 0;
+            h->T.sp = sp;
+        }
         {   // 2-level factorisation of the sine column for the sequential pilot PLL (LDS resident):
             // sin(2 pi idx/N) = Im(EA[a] EB[b]), idx = 256 a + b.  Used only if the f64 expression rounds to
             // exactly the reference's f32 table entry for EVERY idx (checked here with the same unfused
@@ -734,6 +760,9 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     h->T.K_FM_rcp = 1.0f / h->T.K_FM; h->T.pil_omega_rcp = 1.0f / h->T.pil_omega;
     h->T.pss_alpha = 10.0f / (float)fmRate;
     h->T.pss_lock_alpha = 1.0f / fmRate;
+    h->T.afc_l2 = (float)std::log2((double)(1 - 0.0001f));                              // fm-demodulator.cpp:197 (1 - fmDcAlpha)
+    h->T.lock_l2 = (float)std::log2(1.0 - (double)(1.0f / 3000.0f));                    // pilot-recover.cpp:66 (1.0 - alpha)
+    h->T.pssmean_l2 = (float)std::log2((double)(1.0f - h->T.pss_lock_alpha));          // stereo-separation.cpp:90 (1.0f - lockAlpha)
 
     // ---- per-channel buffers ------------------------------------------------------------
     const int64_t fm_per_call = cfg->max_block / DECIM + 2;
@@ -1046,6 +1075,17 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
         // these two taps are read back from the last call's work arrays (tiles of 16 rows: widx), rows [nj - n, nj)
         const int64_t nj = h->last_J1 - h->last_J0, r0 = nj - n;
         if (n == 0) return FMX_OK;
+        if (h->last_lin) {           // fused layout: this call's rows are contiguous per channel
+            const size_t off = (size_t)channel * (size_t)h->work_nj + (size_t)r0;
+            std::vector<float> a((size_t)n), b;
+            HIPCHK(hipMemcpy(a.data(), h->B.w_dem + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+            if (tap == FMX_TAP_LR_RAW) {
+                b.resize((size_t)n);
+                HIPCHK(hipMemcpy(b.data(), h->B.w_diff + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+                for (int64_t i = 0; i < n; i++) { dst[2 * i] = a[(size_t)i]; dst[2 * i + 1] = b[(size_t)i]; }
+            } else std::memcpy(dst, a.data(), sizeof(float) * (size_t)n);
+            return FMX_OK;
+        }
         const int64_t t0 = r0 / WT, t1 = (nj - 1) / WT + 1;
         std::vector<float> a((size_t)(t1 - t0) * WT), b;
         const size_t spitch = (size_t)h->pitch * WT * sizeof(float);
@@ -1248,15 +1288,15 @@ int fmx_debug_sync_dump(fmx_handle h, int32_t *out, int32_t capacity, int32_t *n
 }
 
 // diagnostics (not part of include/fmx.h): per-phase shader-cycle counters of front_kernel, summed over channels
-int fmx_debug_phase_cycles(fmx_handle h, int32_t enable, unsigned long long *out /*[16], may be null*/) {
+int fmx_debug_phase_cycles(fmx_handle h, int32_t enable, unsigned long long *out /*[DBG_SLOTS = 32], may be null*/) {
     if (!h) return fail(FMX_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
-    const size_t nb = sizeof(unsigned long long) * 16 * (size_t)h->channels;
+    const size_t nb = sizeof(unsigned long long) * DBG_SLOTS * (size_t)h->channels;
     if (out && h->B.dbg) {
-        std::vector<unsigned long long> tmp(16 * (size_t)h->channels);
+        std::vector<unsigned long long> tmp(DBG_SLOTS * (size_t)h->channels);
         HIPCHK(hipMemcpy(tmp.data(), h->B.dbg, nb, hipMemcpyDeviceToHost));
-        for (int k = 0; k < 16; k++) { out[k] = 0; for (int c = 0; c < h->channels; c++) out[k] += tmp[(size_t)c * 16 + k]; }
+        for (int k = 0; k < DBG_SLOTS; k++) { out[k] = 0; for (int c = 0; c < h->channels; c++) out[k] += tmp[(size_t)c * DBG_SLOTS + k]; }
     }
     if (enable && !h->B.dbg) { HIPCHK(hipMalloc(&h->B.dbg, nb)); }
     if (h->B.dbg) HIPCHK(hipMemset(h->B.dbg, 0, nb));

@@ -534,7 +534,7 @@ __device__ __forceinline__ void lock_body(DeviceTables T, DeviceBuffers B, CallG
             //                all_lo -> locked = 0, stable = 0
             const bool easy = all_lo || (all_hi && (locked != 0 || stable + UB <= (SINCOS_N >> 1)));
             const bool fast = __all(easy) != 0;
-            if (B.dbg && threadIdx.x == 0) B.dbg[(size_t)ch * 16 + (fast ? 11 : 12)] += 1;
+            if (B.dbg && threadIdx.x == 0) B.dbg[(size_t)ch * DBG_SLOTS + (fast ? 11 : 12)] += 1;
             if (fast) {
                 if (all_lo) { locked = 0; stable = 0; }
                 else if (!locked) stable += UB;
@@ -787,7 +787,7 @@ __device__ __forceinline__ void pss_acc_body(DeviceTables T, DeviceBuffers B, Ca
                                 ((s.minimized ? s.unlock_cnt : s.lock_cnt) + ACC_UB <= 3 * SINCOS_N);
             const bool idle = (orv & ~2u) == 0;                                      // unlocked, tag < 0 throughout
             const bool f_steady = __all(steady) != 0, f_idle = __all(idle) != 0;
-            if (B.dbg && threadIdx.x == 0) B.dbg[(size_t)ch * 16 + (f_steady ? 8 : (f_idle ? 9 : 10))] += 1;
+            if (B.dbg && threadIdx.x == 0) B.dbg[(size_t)ch * DBG_SLOTS + (f_steady ? 8 : (f_idle ? 9 : 10))] += 1;
             if (f_steady) {
                 const float scale = s.minimized ? 1.0f : 10.0f;                      // error = minimized ? err : err * 10
                 constexpr unsigned ALL = (ACC_UB == 32) ? ~0u : ((1u << (ACC_UB & 31)) - 1u);

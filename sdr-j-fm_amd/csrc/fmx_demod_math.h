@@ -60,6 +60,15 @@ __device__ __forceinline__ float sc_wrap(float phase) {
 __device__ __forceinline__ float2 sc_complex(const float2 *__restrict__ tab, double C, float phase) {
     return tab[sc_index(sc_wrap(phase), C)];
 }
+// table entry `idx` of SinCos (cos, sin) without the memory access (SinPoly in fmx_internal.h); bit-identical to tab[idx]
+__device__ __forceinline__ float2 sc_entry(const DeviceTables &T, int idx) {
+    if (!T.sp.ok) return T.sincos[idx];
+    float sn, cs;
+    sincos_poly(idx, T.sp.step, &sn, &cs);
+    for (int k = 0; k < T.sp.ns; k++) sn = (idx == T.sp.s_idx[k]) ? T.sp.s_val[k] : sn;
+    for (int k = 0; k < T.sp.nc; k++) cs = (idx == T.sp.c_idx[k]) ? T.sp.c_val[k] : cs;
+    return make_float2(cs, sn);
+}
 // ---- compAtan::atan2 Xtan2.cpp:56-100.  Only the PPY table is stored; the other seven tables are
 // the reference's own f32 expressions of it (Xtan2.cpp:31-38), evaluated here with the same ops.
 __device__ __forceinline__ int at_idx(float size, float num, float den) {
@@ -95,5 +104,93 @@ __device__ __forceinline__ float2 limiter(float2 z) {
     return make_float2(z.x / zAbs, z.y / zAbs);
 }
 
+// ---- f32 forms for the fused stage-B kernel (fmx_stageb.hip): the same expressions with the IEEE divisions, the f64 square
+// root and the table gathers replaced by short sequences that agree with them to an ulp.
+// n / d: reciprocal + one Markstein correction (the correctly rounded quotient except in rare half-way cases)
+__device__ __forceinline__ float fdiv_fast(float n, float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = n * r;
+    return __fmaf_rn(__fmaf_rn(-q, d, n), r, q);
+}
+// limiter fm-demodulator.cpp:119-126 with |z| from v_sqrt_f32 (1 ulp) and the two divisions by one reciprocal
+__device__ __forceinline__ float2 limiter_fast(float2 z) {
+    const float a = __fmaf_rn(z.x, z.x, z.y * z.y);
+    const float h = __builtin_amdgcn_sqrtf(a);
+    const float r = __builtin_amdgcn_rcpf(h);
+    const float qx = z.x * r, qy = z.y * r;
+    const float lx = __fmaf_rn(__fmaf_rn(-qx, h, z.x), r, qx), ly = __fmaf_rn(__fmaf_rn(-qy, h, z.y), r, qy);
+    const bool tiny = !(h >= 0.001f);                     // (double) zAbs <= 0.001 <=> zAbs < 0.001f; NaN goes the same way
+    return make_float2(tiny ? 0.001f : lx, tiny ? 0.001f : ly);
+}
+// compAtan::atan2 as lut_atan2 above, split around the table access so that a thread can issue the gathers of all its
+// samples together; the index (int)(size * num / den + 0.5) in f32 (exact there: the quotient is <= 8192)
+struct AtanArm { int idx; float A; float special; unsigned flags; };   // flags: bit 0 negate the table value, bit 1 special
+__device__ __forceinline__ AtanArm atan_arm(float y, float x) {
+    const float St = (float)3.14159265358979323846, Sh = St * 0.5f;
+    const bool special = !(fabsf(x) > 0.f) || !(fabsf(x) < __builtin_inff()) || !(fabsf(y) < __builtin_inff());
+    const bool xpos = x > 0.f, ypos = y >= 0.f;
+    const bool swap = !(fabsf(x) >= fabsf(y));                 // the ..X arms: |y| > |x|
+    const bool same = xpos == ypos;
+    const float size = same ? (float)ATAN_N : -(float)ATAN_N;  // PPY PPX NNY NNX use +Size, the others -Size
+    const float num = swap ? x : y, den = swap ? y : x;
+    int idx = (int)(fdiv_fast(size * num, den) + 0.5f);
+    idx = idx < 0 ? 0 : (idx > ATAN_N ? ATAN_N : idx);
+    AtanArm a;
+    a.idx = special ? 0 : idx;
+    a.A = swap ? (ypos ? Sh : -Sh) : (xpos ? 0.f : (ypos ? St : -St));
+    a.special = (x == 0.f && fabsf(y) > 0.f && fabsf(y) < __builtin_inff()) ? (y > 0.f ? (float)(3.14159265358979323846 / 2) : (float)(-3.14159265358979323846 / 2)) : 0.f;
+    a.flags = ((same == swap) ? 1u : 0u) | (special ? 2u : 0u);
+    return a;
+}
+__device__ __forceinline__ float atan_finish(const AtanArm &a, float tv) {
+    const float r = a.A + ((a.flags & 1u) ? -tv : tv);
+    return (a.flags & 2u) ? a.special : r;
+}
+__device__ __forceinline__ float lut_atan2_fast(const float *__restrict__ ppy, float y, float x) {
+    const AtanArm a = atan_arm(y, x);
+    return atan_finish(a, ppy[a.idx]);
+}
+// SinCos table entries (sincos.cpp:45-54: (float) sin / cos of 2 pi idx / Rate) evaluated in f32 instead of gathered:
+// quadrant / octant reduction of the INDEX in integers (exact), Taylor polynomials on the reduced angle.  |error| < 1.5e-7
+// against the table for every idx (fmx_create checks all 192000 entries with this very code).
+__host__ __device__ __forceinline__ float sin_idx_f32(int idx) {
+    constexpr int QUAD = SINCOS_N / 4;                    // 48000 = 2^7 * 375
+    const int q = (int)(((unsigned)(idx >> 7) * 2797u) >> 20);          // idx / 48000 for idx < 384000
+    const int r = idx - q * QUAD;
+    const int rr = (q & 1) ? QUAD - r : r;
+    const float x = (float)rr * (float)(6.283185307179586476925286766559 / SINCOS_N);
+    const float z = x * x;
+    float p = -1.0f / 39916800.0f;                        // x - x^3/6 + ... - x^11/11! + x^13/13!: truncation < 1e-8 on [0, pi/2]
+    p = __builtin_fmaf(z, 1.0f / 6227020800.0f, p);
+    p = __builtin_fmaf(p, z, 1.0f / 362880.0f);
+    p = __builtin_fmaf(p, z, -1.0f / 5040.0f);
+    p = __builtin_fmaf(p, z, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, z, -1.0f / 6.0f);
+    const float s = __builtin_fmaf(x * z, p, x);
+    return (q & 2) ? -s : s;
+}
+__host__ __device__ __forceinline__ void sincos_idx_f32(int idx, float *sn, float *cs) {
+    constexpr int OCT = SINCOS_N / 8;                     // 24000 = 2^6 * 375
+    const int q = (int)(((unsigned)(idx >> 6) * 2797u) >> 20);          // idx / 24000 for idx < 192000
+    const int r = idx - q * OCT;
+    const int rr = (q & 1) ? OCT - r : r;
+    const float x = (float)rr * (float)(6.283185307179586476925286766559 / SINCOS_N);
+    const float z = x * x;
+    float ps = 1.0f / 362880.0f;                          // sin to x^9, cos to x^8 on [0, pi/4]: truncation < 3e-8
+    ps = __builtin_fmaf(ps, z, -1.0f / 5040.0f);
+    ps = __builtin_fmaf(ps, z, 1.0f / 120.0f);
+    ps = __builtin_fmaf(ps, z, -1.0f / 6.0f);
+    const float sv = __builtin_fmaf(x * z, ps, x);
+    float pc = 1.0f / 40320.0f;
+    pc = __builtin_fmaf(pc, z, -1.0f / 720.0f);
+    pc = __builtin_fmaf(pc, z, 1.0f / 24.0f);
+    pc = __builtin_fmaf(pc, z, -0.5f);
+    const float cv = __builtin_fmaf(z, pc, 1.0f);
+    // angle = k pi/4 + a (k even) or (k + 1) pi/4 - b (k odd), k = q & 3; q >= 4 negates both
+    const bool sw = ((q + 1) & 2) != 0;                   // k = 1, 2: sine from the cosine polynomial
+    const float s = sw ? cv : sv, c = sw ? sv : cv;
+    *sn = (q & 4) ? -s : s;
+    *cs = (((q >> 1) ^ (q >> 2)) & 1) ? -c : c;
+}
 
 }  // namespace fmx

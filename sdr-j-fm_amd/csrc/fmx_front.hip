@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuf
         FMX_TICK(5);
     }
     FMX_TICK(6);
-    if (dbg_on) for (int k = 0; k < 8; k++) B.dbg[(size_t)ch * 16 + k] += dbg_acc[k];
+    if (dbg_on) for (int k = 0; k < 8; k++) B.dbg[(size_t)ch * DBG_SLOTS + k] += dbg_acc[k];
     if (t == 0 && lo != 0) {
         long long m = ((long long)G.n * (long long)lo) % (long long)R;
         int ph = (int)(((long long)lo_phase0 - m) % (long long)R);

@@ -61,6 +61,7 @@ struct ChanParams {
     float   squelch_thr;    // levelSquelchThreshold squelchClass.cpp:35
     int32_t test_tone;      // setTestTone fm-processor.cpp:931-933
     float   squelch_nthr;   // noiseSquelchThreshold squelchClass.cpp:36
+    float   deemph_l2;      // log2 (1.0f - deemph_alpha) (fused stage B: scan weights)
 };
 enum { ACT_TRIGGER_FREQ = 1, ACT_RESTART_PSS = 2, ACT_DC_RESET = 4 };
 
@@ -114,6 +115,43 @@ __host__ __device__ __forceinline__ size_t widx(int64_t r, int ch, int pitch) {
     return ((size_t)(r >> 4) * (size_t)pitch + (size_t)ch) * WT + (size_t)(r & 15);
 }
 
+// The SinCos table (sincos.cpp:45-54: (float)cos / (float)sin of 2 pi i / Rate in f64) WITHOUT the table: octant reduction of
+// the index, two f64 Taylor polynomials on [0, pi/4] (sin to x^15, cos to x^16: truncation < 5e-17), rounded to f32.
+// fmx_create runs the very same operation sequence (explicit fma) over all 192000 indices against the reference's entries;
+// the entries that differ (the exact zero crossings, where the reference's f64 angle is not exact) go into the exception
+// lists; with more than four per list `ok` stays 0 and the kernels gather from the table in memory.
+struct SinPoly {
+    double step;                 // 2 pi / Rate
+    int32_t ok, ns, nc, pad_;
+    int32_t s_idx[4]; float s_val[4];     // sine entries that differ
+    int32_t c_idx[4]; float c_val[4];     // cosine entries that differ
+};
+__host__ __device__ __forceinline__ void sincos_poly(int idx, double step, float *sn, float *cs) {
+    constexpr int OCT = SINCOS_N / 8;
+    const int q = idx / OCT, r = idx - OCT * q, k = q & 3;
+    const int rr = (k & 1) ? OCT - r : r;
+    const double x = (double)rr * step, z = x * x;
+    double ps = -1.0 / 1307674368000.0;
+    ps = __builtin_fma(ps, z, 1.0 / 6227020800.0); ps = __builtin_fma(ps, z, -1.0 / 39916800); ps = __builtin_fma(ps, z, 1.0 / 362880);
+    ps = __builtin_fma(ps, z, -1.0 / 5040); ps = __builtin_fma(ps, z, 1.0 / 120); ps = __builtin_fma(ps, z, -1.0 / 6);
+    const double sv = __builtin_fma(x * z, ps, x);
+    double pc = 1.0 / 20922789888000.0;
+    pc = __builtin_fma(pc, z, -1.0 / 87178291200.0); pc = __builtin_fma(pc, z, 1.0 / 479001600); pc = __builtin_fma(pc, z, -1.0 / 3628800);
+    pc = __builtin_fma(pc, z, 1.0 / 40320); pc = __builtin_fma(pc, z, -1.0 / 720); pc = __builtin_fma(pc, z, 1.0 / 24); pc = __builtin_fma(pc, z, -0.5);
+    const double cv = __builtin_fma(z, pc, 1.0);
+    // angle = k pi/4 + a (k even, x = a) or (k + 1) pi/4 - b (k odd, x = b)
+    double s, c;
+    switch (k) {
+    default:
+    case 0: s = sv; c = cv; break;
+    case 1: s = cv; c = sv; break;
+    case 2: s = cv; c = -sv; break;
+    case 3: s = sv; c = -cv; break;
+    }
+    if (q >= 4) { s = -s; c = -c; }
+    *sn = (float)s; *cs = (float)c;
+}
+
 struct DeviceTables {
     const float2 *sincos;        // [SINCOS_N] (cos, sin)
     const float  *atan_ppy;      // [ATAN_N + 1]
@@ -128,8 +166,10 @@ struct DeviceTables {
     double  sincos_C;            // Rate / (2*M_PI)  (sincos.cpp:42)
     float   K_FM, K_FM_rcp, pil_omega_rcp;   // rcp = RN(1/c) for fdiv_const
     float   pil_omega, pil_gain, pss_alpha, pss_lock_alpha;
+    float   afc_l2, lock_l2, pssmean_l2;   // log2 of the decays of the AFC, the lock metric and the PSS mean error (fused stage B: scan weights)
     float   pll_beta, pll_lo, pll_hi, pll_center;
     const float *nsq_coef;       // [2][NSQ_QUADS][4] (A1, A2, B1, B2) + [2] gains: high-pass 69.9 kHz, low-pass 70 kHz (squelchClass.cpp:11-18); null until used
+    SinPoly sp;
     float   wrap32_c;            // fl32(fl32_above(2 pi) - 2 pi)
     int32_t wrap32_ok;           // the f32 form of the pilot-phase wrap was verified on the host for every float it can see
 };
@@ -151,6 +191,7 @@ struct CallGeom {
     float   iq_scale;    // 1/128 (U8, S8) or 1/denominator (S16)
 };
 
+constexpr int DBG_SLOTS = 32;
 struct DeviceBuffers {
     float2 *hist;        // [channels][DECIM][A_HIST_COLS]   mixed input history (column layout)
     float2 *zring;       // [channels][ring]  front-end output v[j]
@@ -158,7 +199,8 @@ struct DeviceBuffers {
     float2 *dring;       // [channels][dring] de-emphasised, gained stereo @ fmRate
     ChanState *state;
     const ChanParams *params;
-    unsigned long long *dbg;   // optional [channels][16] per-phase cycle counters of front_kernel (null = off; diagnostics)
+    unsigned long long *dbg;   // optional [channels][DBG_SLOTS] diagnostics (null = off): 0-7 per-phase cycles of front_kernel, 8-12 path / round
+                               // counters of stage B, 16-27 per-phase cycles of stageb_seg_kernel
     // sample-major [fm sample of this call][channel] work arrays of stage B
     float   *w_dem;      // discriminator output, then demod (in place)
     float2  *w_iq;       // limiter output (only allocated when a channel uses the PLL decoder)
@@ -173,8 +215,14 @@ struct DeviceBuffers {
     const float *tone;   // [TT_BURST] one test-tone burst (the same for every burst: phase restarts at 0)
     float4  *pk_part;    // [channels][pk_tiles] per audio tile: max |L|, |R| of the frames of the tile's first window, then of its second
     float2  *pk_ring;    // [channels][PK_RING] maxima of the finished windows
-    int32_t pk_tiles, pad_;
+    int32_t pk_tiles;
+    int32_t lin_rows;    // != 0 (fused stage-B layout): w_dem / w_diff / w_cur hold this call's rows channel-major, [channel][lin_rows], and
+                         // w_err the PSS errors of one segment, [channel][1536]; 0: the 16-row tiles of widx()
 };
+// element (row r, channel ch) of a per-call scope / RDS tap array in either layout
+__host__ __device__ __forceinline__ size_t tap_idx(const DeviceBuffers &B, int64_t r, int ch, int pitch) {
+    return B.lin_rows ? (size_t)ch * (size_t)B.lin_rows + (size_t)r : widx(r, ch, pitch);
+}
 
 // ---- RDS path (fmx_rds.hip) -------------------------------------------------------------------
 constexpr int RDS_BLK = 32000;              // overlap-add block of the two 32768-pt filters (fft-filters.cpp:34)
@@ -258,6 +306,8 @@ inline void note_hip(hipError_t e) { if (e != hipSuccess && g_launch_err == hipS
 #define FMX_LAUNCHED() ::fmx::note_hip(hipGetLastError())
 void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s,
                   const DemodStreams &DS);
+// stage B as one time-parallel workgroup per channel and segment (fmx_stageb.hip): everything on the caller's stream
+void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,
                   int channels, hipStream_t s);
 

@@ -153,8 +153,8 @@ __global__ void rds_collect(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, i
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nrows || B.params[ch].rds_mode == 0) return;
     const int64_t r = row0 + q, n = n0 + q;
-    const float demod = B.w_dem[widx(r, ch, G.pitch)];
-    const float cur = B.w_cur[widx(r, ch, G.pitch)];             // unconstrained pilot phase; PI_Constrain gives currentPilotPhase
+    const float demod = B.w_dem[tap_idx(B, r, ch, G.pitch)];
+    const float cur = B.w_cur[tap_idx(B, r, ch, G.pitch)];             // unconstrained pilot phase; PI_Constrain gives currentPilotPhase
     Rb.in_blk[(size_t)ch * RBLK + (int)(n % RBLK)] = demod;
     float c = cur;
     {   // PI_Constrain fm-constants.h:148-158 (arguments are within (-2pi, 4pi))
