@@ -3,6 +3,7 @@
 // every entry point fails when HIP is unavailable.
 #include "../../include/fmx.h"
 #include "fmx_internal.h"
+#include "fmx_fftconv.h"
 #include "fmx_rdsgroups.h"
 #include "fmx_design.h"
 
@@ -79,6 +80,7 @@ struct fmx_handle_s {
     std::vector<FrontSet> h_front_sets; std::vector<AudioSet> h_audio_sets;
     // device
     float *d_front_taps = nullptr, *d_audio_taps = nullptr, *d_pss_taps = nullptr;
+    float2 *d_fft_w = nullptr, *d_pss_hs = nullptr;
     FrontSet *d_front_sets = nullptr; AudioSet *d_audio_sets = nullptr;
     float2 *d_sincos = nullptr, *d_lo = nullptr; float *d_atan = nullptr, *d_arcsine = nullptr; double2 *d_trig3 = nullptr;
     ChanParams *d_params = nullptr;
@@ -744,6 +746,17 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     }
     h->T.sincos = h->d_sincos; h->T.atan_ppy = h->d_atan; h->T.arcsine = h->d_arcsine; h->T.lo_table = nullptr; h->T.trig2 = h->d_trig3;
     h->T.pss_taps = h->d_pss_taps;
+    {   // fast-convolution form of the PSS low-pass (fmx_fftconv.h): twiddles and the taps' spectrum in the device transform's own order
+        std::vector<float2> W(fftc::W_COUNT), Hs(fftc::N);
+        fftc::make_twiddles(W.data());
+        fftc::make_spectrum(h->h_pss_taps.data(), PSS_TAPS, Hs.data(), W.data());
+        HIPCHK(hipMalloc(&h->d_fft_w, sizeof(float2) * fftc::W_COUNT));
+        HIPCHK(hipMalloc(&h->d_pss_hs, sizeof(float2) * fftc::N));
+        HIPCHK(hipMemcpy(h->d_fft_w, W.data(), sizeof(float2) * fftc::W_COUNT, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_pss_hs, Hs.data(), sizeof(float2) * fftc::N, hipMemcpyHostToDevice));
+        h->T.fft_w = h->d_fft_w;
+        h->T.pss_hs = (getenv("FMX_PSS_FIR") && std::string(getenv("FMX_PSS_FIR")) == "direct") ? nullptr : h->d_pss_hs;
+    }
     h->T.sincos_C = fmRate / (2 * design::kPi);
     {   // fm_Demodulator ctor fm-demodulator.cpp:57-72
         const float F_G = (float)(0.65 * fmRate / 2), Delta_F = (float)(0.95 * fmRate / 2);
@@ -844,7 +857,7 @@ int fmx_destroy(fmx_handle h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &pr : h->prof) for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
-    void *ptrs[] = { h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
+    void *ptrs[] = { h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
                      h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
                      h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x };

@@ -1,0 +1,207 @@
+// fmx_fftconv.h -- a 2048-point circular convolution for one 256-thread workgroup (eight points per thread), written so that
+// the very same arithmetic runs on the host: fmx_create pushes the PSS low-pass taps through the forward half (which yields
+// their spectrum in exactly the order the device's forward transform leaves its output in, whatever that order is), and
+// tests/test_fftconv_cpu.py drives the whole thing thread by thread against a direct convolution.
+//
+// The reference filters with fftFilter (fft-filters.cpp:132-163: 2048-point overlap-add, 295 taps); stage B needs the same
+// linear convolution for 1536 fresh outputs per segment: a window of 1536 + 294 inputs, zero-padded to 2048, forward
+// transform, times the taps' spectrum (1 / N folded in), backward transform; outputs 294 .. 294 + 1535 are free of wrap-around.
+//
+// 2048 = 8 * 8 * 8 * 4, decimation in frequency forward (natural order in, digit-reversed out), the mirror image backward,
+// so no reordering pass exists: thread t starts with the natural-order points t + 256 p straight from global memory and ends
+// with the natural-order outputs t + 256 p in registers.  The radix-4 stage in the middle works on four points that sit in
+// the same register of four adjacent lanes, so it runs across the quad in DPP (forward, times the spectrum, backward) and the
+// data meets LDS only four times.  Stage L = 256 and L = 32 read and write the same addresses from the same half-wave / quad:
+// in place, no barrier between load and store; four barriers per convolution.
+// LDS index i -> i + 4 (i >> 5): every access pattern below is conflict-free for 8-byte elements.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <vector>
+
+namespace fmx {
+namespace fftc {
+
+constexpr int N = 2048, T = 256, LDS_N = N + 4 * (N >> 5);
+__host__ __device__ __forceinline__ int pad(int i) { return i + 4 * (i >> 5); }
+
+__host__ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__host__ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__host__ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__host__ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj (b)
+// multiplication by SIGN * j
+template <int SIGN> __host__ __device__ __forceinline__ float2 mulj(float2 a) { return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+
+// X[q] = sum_p a[p] w^(p q), w = exp (SIGN * 2 pi i / 4)
+template <int SIGN> __host__ __device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
+    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = mulj<SIGN>(csub(a1, a3));
+    a0 = cadd(s02, s13); a2 = csub(s02, s13); a1 = cadd(d02, d13); a3 = csub(d02, d13);
+}
+// X[q] = sum_p a[p] w^(p q), w = exp (SIGN * 2 pi i / 8), in place
+template <int SIGN> __host__ __device__ __forceinline__ void dft8(float2 *a) {
+    const float R = 0.70710678118654752440f;
+    float2 e0 = cadd(a[0], a[4]), e1 = cadd(a[1], a[5]), e2 = cadd(a[2], a[6]), e3 = cadd(a[3], a[7]);
+    float2 o0 = csub(a[0], a[4]), o1 = csub(a[1], a[5]), o2 = csub(a[2], a[6]), o3 = csub(a[3], a[7]);
+    {   // o_p *= w^p: w = (1 + SIGN j) / sqrt 2, w^2 = SIGN j, w^3 = (-1 + SIGN j) / sqrt 2
+        const float2 j1 = mulj<SIGN>(o1), j3 = mulj<SIGN>(o3);
+        o1 = make_float2((o1.x + j1.x) * R, (o1.y + j1.y) * R);
+        o2 = mulj<SIGN>(o2);
+        o3 = make_float2((j3.x - o3.x) * R, (j3.y - o3.y) * R);
+    }
+    dft4<SIGN>(e0, e1, e2, e3);          // X[0], X[2], X[4], X[6]
+    dft4<SIGN>(o0, o1, o2, o3);          // X[1], X[3], X[5], X[7]
+    a[0] = e0; a[2] = e1; a[4] = e2; a[6] = e3; a[1] = o0; a[3] = o1; a[5] = o2; a[7] = o3;
+}
+
+// A radix-8 stage works on blocks of length L: the butterfly j of a block (j < S = L / 8) takes the points base + j + p S,
+// forward: DFT8, output q times exp (-2 pi i j q / L), stored at base + q S + j; backward: the inverse.
+template <int L> __host__ __device__ __forceinline__ void geom8(int t, int &base, int &j) {
+    constexpr int S = L / 8;
+    j = t % S; base = (t / S) * L;       // (L = 32: the four butterflies of a block are the four lanes of a quad)
+}
+// The twiddles a stage needs, stored per stage as [q - 1][j]: a wave's loads are contiguous (the plain table exp (-2 pi i k / N)
+// indexed by (j q) (N / L) costs a cache line per lane).
+constexpr int W_OFF_2048 = 0, W_OFF_256 = 7 * 256, W_OFF_32 = W_OFF_256 + 7 * 32, W_COUNT = W_OFF_32 + 7 * 4;
+template <int L> __host__ __device__ __forceinline__ int w_index(int q, int j) {
+    return (L == 2048 ? W_OFF_2048 : (L == 256 ? W_OFF_256 : W_OFF_32)) + (q - 1) * (L / 8) + j;
+}
+template <int L> __host__ __device__ __forceinline__ void fwd8(float2 *a, int j, const float2 *__restrict__ W) {
+    dft8<-1>(a);
+#pragma unroll
+    for (int q = 1; q < 8; q++) a[q] = cmul(a[q], W[w_index<L>(q, j)]);
+}
+template <int L> __host__ __device__ __forceinline__ void inv8(float2 *a, int j, const float2 *__restrict__ W) {
+#pragma unroll
+    for (int q = 1; q < 8; q++) a[q] = cmulc(a[q], W[w_index<L>(q, j)]);
+    dft8<+1>(a);
+}
+// points base + j + p S (the inputs of a forward / outputs of a backward butterfly)
+template <int L> __host__ __device__ __forceinline__ void load_p(float2 *a, const float2 *X, int base, int j) {
+#pragma unroll
+    for (int p = 0; p < 8; p++) a[p] = X[pad(base + j + p * (L / 8))];
+}
+template <int L> __host__ __device__ __forceinline__ void store_p(const float2 *a, float2 *X, int base, int j) {
+#pragma unroll
+    for (int p = 0; p < 8; p++) X[pad(base + j + p * (L / 8))] = a[p];
+}
+// points base + q S + j (the outputs of a forward / inputs of a backward butterfly)
+template <int L> __host__ __device__ __forceinline__ void load_q(float2 *a, const float2 *X, int base, int j) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) a[q] = X[pad(base + q * (L / 8) + j)];
+}
+template <int L> __host__ __device__ __forceinline__ void store_q(const float2 *a, float2 *X, int base, int j) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) X[pad(base + q * (L / 8) + j)] = a[q];
+}
+
+// The radix-4 stage across a quad: lane j (= t & 3) holds point j of a block of four.  Two exchanges (partner = lane ^ 2, then
+// lane ^ 1) leave (Y0, Y2, Y1, Y3) in lanes (0, 1, 2, 3); the backward pair undoes them (times 4).  `own` / `other` = this
+// lane's and the partner's value.
+template <int SIGN> __host__ __device__ __forceinline__ float2 quad_f1(int j, float2 own, float2 other) {
+    const float2 s = (j & 2) ? csub(other, own) : cadd(own, other);
+    return j == 3 ? mulj<SIGN>(s) : s;
+}
+__host__ __device__ __forceinline__ float2 quad_f2(int j, float2 own, float2 other) { return (j & 1) ? csub(other, own) : cadd(own, other); }
+template <int SIGN> __host__ __device__ __forceinline__ float2 quad_b1(int j, float2 own, float2 other) {
+    const float2 s = (j & 1) ? csub(other, own) : cadd(own, other);
+    return j == 3 ? mulj<-SIGN>(s) : s;
+}
+__host__ __device__ __forceinline__ float2 quad_b2(int j, float2 own, float2 other) { return (j & 2) ? csub(other, own) : cadd(own, other); }
+
+template <int CTRL> __device__ __forceinline__ float2 quad_get(float2 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return make_float2(__int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.x), CTRL, 0xf, 0xf, true)),
+                       __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.y), CTRL, 0xf, 0xf, true)));
+#else
+    return v;
+#endif
+}
+// thread t of the workgroup: `a` = the natural-order inputs t + 256 p on entry, the natural-order outputs t + 256 p on return.
+// X: LDS_N complex of LDS; W: twiddles; Hs: the spectrum in "slot" order (entry 8 t + q = what thread t holds in register q in
+// front of the multiplication, make_spectrum below), 1 / N included.
+__device__ __forceinline__ void convolve(int t, float2 *a, float2 *X, const float2 *__restrict__ W, const float2 *__restrict__ Hs) {
+    int base, j;
+    fwd8<2048>(a, t, W); store_q<2048>(a, X, 0, t);
+    __syncthreads();
+    geom8<256>(t, base, j);
+    load_p<256>(a, X, base, j); fwd8<256>(a, j, W); store_q<256>(a, X, base, j);
+    __syncthreads();
+    geom8<32>(t, base, j);
+    load_p<32>(a, X, base, j); fwd8<32>(a, j, W);
+    {
+        const float4 *H4 = reinterpret_cast<const float4 *>(Hs + 8 * t);
+        float2 h[8];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const float4 v = H4[q]; h[2 * q] = make_float2(v.x, v.y); h[2 * q + 1] = make_float2(v.z, v.w); }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            float2 v = a[q];
+            v = quad_f1<-1>(j, v, quad_get<0x4E>(v));            // quad_perm [2, 3, 0, 1]
+            v = quad_f2(j, v, quad_get<0xB1>(v));                // quad_perm [1, 0, 3, 2]
+            v = cmul(v, h[q]);
+            v = quad_b1<-1>(j, v, quad_get<0xB1>(v));
+            v = quad_b2(j, v, quad_get<0x4E>(v));
+            a[q] = v;
+        }
+    }
+    inv8<32>(a, j, W); store_p<32>(a, X, base, j);
+    __syncthreads();
+    geom8<256>(t, base, j);
+    load_q<256>(a, X, base, j); inv8<256>(a, j, W); store_p<256>(a, X, base, j);
+    __syncthreads();
+    load_q<2048>(a, X, 0, t); inv8<2048>(a, t, W);
+}
+
+// ---- host side: the same arithmetic, all 256 threads in turn between the barriers --------------------------------------
+template <int L> inline void make_twiddles_stage(float2 *W) {
+    for (int q = 1; q < 8; q++)
+        for (int j = 0; j < L / 8; j++) {
+            const double ang = -2.0 * 3.14159265358979323846 * (double)(j * q) / (double)L;
+            W[w_index<L>(q, j)] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+}
+inline void make_twiddles(float2 *W /*[W_COUNT]*/) { make_twiddles_stage<2048>(W); make_twiddles_stage<256>(W); make_twiddles_stage<32>(W); }
+// forward half for all threads: in[n] natural order -> slot[8 t + q] (what thread t holds in register q in front of the multiplication)
+inline void host_forward(const float2 *in, float2 *slot, const float2 *W) {
+    std::vector<float2> X(LDS_N), R((size_t)T * 8);
+    float2 a[8];
+    int base, j;
+    for (int t = 0; t < T; t++) { for (int p = 0; p < 8; p++) a[p] = in[t + 256 * p]; fwd8<2048>(a, t, W); store_q<2048>(a, X.data(), 0, t); }
+    for (int t = 0; t < T; t++) { geom8<256>(t, base, j); load_p<256>(a, X.data(), base, j); fwd8<256>(a, j, W); for (int q = 0; q < 8; q++) R[(size_t)t * 8 + q] = a[q]; }
+    for (int t = 0; t < T; t++) { geom8<256>(t, base, j); store_q<256>(&R[(size_t)t * 8], X.data(), base, j); }
+    for (int t = 0; t < T; t++) { geom8<32>(t, base, j); load_p<32>(a, X.data(), base, j); fwd8<32>(a, j, W); for (int q = 0; q < 8; q++) R[(size_t)t * 8 + q] = a[q]; }
+    for (int t0 = 0; t0 < T; t0 += 4)
+        for (int q = 0; q < 8; q++) {
+            float2 v[4], s[4];
+            for (int k = 0; k < 4; k++) v[k] = R[(size_t)(t0 + k) * 8 + q];
+            for (int k = 0; k < 4; k++) s[k] = quad_f1<-1>(k, v[k], v[k ^ 2]);
+            for (int k = 0; k < 4; k++) slot[(size_t)(t0 + k) * 8 + q] = quad_f2(k, s[k], s[k ^ 1]);
+        }
+}
+// backward half for all threads: slot order in -> natural order out (times N)
+inline void host_backward(const float2 *slot, float2 *out, const float2 *W) {
+    std::vector<float2> X(LDS_N), R((size_t)T * 8);
+    float2 a[8];
+    int base, j;
+    for (int t0 = 0; t0 < T; t0 += 4)
+        for (int q = 0; q < 8; q++) {
+            float2 v[4], s[4];
+            for (int k = 0; k < 4; k++) v[k] = slot[(size_t)(t0 + k) * 8 + q];
+            for (int k = 0; k < 4; k++) s[k] = quad_b1<-1>(k, v[k], v[k ^ 1]);
+            for (int k = 0; k < 4; k++) R[(size_t)(t0 + k) * 8 + q] = quad_b2(k, s[k], s[k ^ 2]);
+        }
+    for (int t = 0; t < T; t++) { geom8<32>(t, base, j); for (int q = 0; q < 8; q++) a[q] = R[(size_t)t * 8 + q]; inv8<32>(a, j, W); store_p<32>(a, X.data(), base, j); }
+    for (int t = 0; t < T; t++) { geom8<256>(t, base, j); load_q<256>(a, X.data(), base, j); inv8<256>(a, j, W); for (int q = 0; q < 8; q++) R[(size_t)t * 8 + q] = a[q]; }
+    for (int t = 0; t < T; t++) { geom8<256>(t, base, j); store_p<256>(&R[(size_t)t * 8], X.data(), base, j); }
+    for (int t = 0; t < T; t++) { load_q<2048>(a, X.data(), 0, t); inv8<2048>(a, t, W); for (int p = 0; p < 8; p++) out[t + 256 * p] = a[p]; }
+}
+// spectrum of `ntaps` real taps in slot order, 1 / N included
+inline void make_spectrum(const float *taps, int ntaps, float2 *Hs, const float2 *W) {
+    std::vector<float2> in(N, make_float2(0.f, 0.f));
+    for (int k = 0; k < ntaps; k++) in[k] = make_float2(taps[k], 0.f);
+    host_forward(in.data(), Hs, W);
+    for (int k = 0; k < N; k++) { Hs[k].x *= 1.0f / N; Hs[k].y *= 1.0f / N; }
+}
+
+}  // namespace fftc
+}  // namespace fmx

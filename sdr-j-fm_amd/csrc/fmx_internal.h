@@ -161,6 +161,8 @@ struct DeviceTables {
     const float  *front_taps;    // [sets][DECIM][A_TAPS_ROW]  Trd[r][d] = G[12 d + off - r] (0 outside)
     const FrontSet *front_sets;
     const float  *pss_taps;      // [PSS_TAPS]
+    const float2 *fft_w;         // [fftc::W_COUNT] stage twiddles of fmx_fftconv.h
+    const float2 *pss_hs;        // [2048] spectrum of the PSS taps in the forward transform's slot order, 1 / N included; null: direct FIR (FMX_PSS_FIR=direct)
     const float  *audio_taps;    // [sets][C_TAPS_STRIDE]
     const AudioSet *audio_sets;
     double  sincos_C;            // Rate / (2*M_PI)  (sincos.cpp:42)

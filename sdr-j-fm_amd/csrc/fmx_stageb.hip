@@ -41,6 +41,7 @@
 // at least one segment old.  Everything runs on the caller's stream: no side streams, no events, no waiting kernels.
 #include "fmx_internal.h"
 #include "fmx_demod_math.h"
+#include "fmx_fftconv.h"
 
 namespace fmx {
 
@@ -307,6 +308,33 @@ __global__ __launch_bounds__(64) void pssfir_seg_kernel(DeviceTables T, DeviceBu
     } else {
 #pragma unroll
         for (int j = 0; j < SF_FPT; j++) if (q + j < A.w) dst[j] = acc[j].x * acc[j].y;
+    }
+}
+
+// The same errors by fast convolution (fmx_fftconv.h): one 256-thread workgroup per channel transforms the segment's window of
+// w + 294 s-ring entries (zero-padded to 2048 points), multiplies by the taps' spectrum and transforms back -- the reference's
+// own method (fft-filters.cpp:132-163, 2048 points), about a fifth of the direct form's arithmetic.
+__global__ __launch_bounds__(fftc::T) void pssfft_seg_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, SegArgs A) {
+    __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];
+    const int ch = blockIdx.x, t = threadIdx.x;
+    const ChanParams &P = B.params[ch];
+    if (P.fm_mode == 2 || !P.pss_active) return;
+    const ChanState &st = B.state[ch];
+    const int64_t i0 = st.pss_count + (A.first ? 0 : st.pss_call_total);           // call index of the segment's first output
+    const float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
+    float2 a[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {          // window entry n <-> s index i0 - (1753 + 294) + n; entries past the segment's need are padding
+        const int n = t + fftc::T * p;
+        const int64_t idx = i0 - (PSS_DELAY + PSS_TAPS - 1) + n;
+        a[p] = (n < A.w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
+    }
+    fftc::convolve(t, a, X, T.fft_w, T.pss_hs);
+    float *dst = B.w_err + (size_t)ch * FB_W;
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const int m = t + fftc::T * p - (PSS_TAPS - 1);
+        if (m >= 0 && m < A.w) dst[m] = a[p].x * a[p].y;
     }
 }
 
@@ -832,7 +860,9 @@ void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const Cal
         SegArgs A;
         A.seg0 = (int)seg0; A.w = (int)((nj - seg0) < FB_W ? (nj - seg0) : FB_W);
         A.first = seg0 == 0 ? 1 : 0; A.last = (seg0 + FB_W >= nj) ? 1 : 0;
-        hipLaunchKernelGGL(pssfir_seg_kernel, dim3((unsigned)((A.w + SF_TILE - 1) / SF_TILE), (unsigned)C), dim3(64), 0, s, T, B, G, C, A); FMX_LAUNCHED();
+        if (T.pss_hs) hipLaunchKernelGGL(pssfft_seg_kernel, dim3((unsigned)C), dim3(fftc::T), 0, s, T, B, G, C, A);
+        else hipLaunchKernelGGL(pssfir_seg_kernel, dim3((unsigned)((A.w + SF_TILE - 1) / SF_TILE), (unsigned)C), dim3(64), 0, s, T, B, G, C, A);
+        FMX_LAUNCHED();
         hipLaunchKernelGGL(stageb_seg_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, T, B, G, C, A);
         FMX_LAUNCHED();
     }
