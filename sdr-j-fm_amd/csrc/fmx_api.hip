@@ -798,6 +798,9 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMalloc(&h->B.w_diff, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_err, sizeof(float) * (size_t)(PSS_CHUNK + WT) * C));
         HIPCHK(hipMalloc(&h->B.w_pdp, sizeof(float) * NJ * C));
+        h->B.lockm_stride = (int32_t)(NJ / 6 + 512);
+        HIPCHK(hipMalloc(&h->B.w_lockm, (size_t)h->B.lockm_stride * C));
+        HIPCHK(hipMemset(h->B.w_lockm, 0, (size_t)h->B.lockm_stride * C));
         HIPCHK(hipMalloc(&h->B.w_tag, sizeof(int32_t) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_x, sizeof(float2) * NJ * C));
         h->B.w_iq = nullptr;
@@ -860,7 +863,7 @@ int fmx_destroy(fmx_handle h) {
     void *ptrs[] = { h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
                      h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
-                     h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x };
+                     h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x, h->B.w_lockm };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
     for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);

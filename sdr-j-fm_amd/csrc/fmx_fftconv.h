@@ -65,16 +65,23 @@ constexpr int W_OFF_2048 = 0, W_OFF_256 = 7 * 256, W_OFF_32 = W_OFF_256 + 7 * 32
 template <int L> __host__ __device__ __forceinline__ int w_index(int q, int j) {
     return (L == 2048 ? W_OFF_2048 : (L == 256 ? W_OFF_256 : W_OFF_32)) + (q - 1) * (L / 8) + j;
 }
-template <int L> __host__ __device__ __forceinline__ void fwd8(float2 *a, int j, const float2 *__restrict__ W) {
+// tw[q - 1] = twiddle of output q
+template <int L> __host__ __device__ __forceinline__ void load_tw(float2 *tw, int j, const float2 *__restrict__ W) {
+#pragma unroll
+    for (int q = 1; q < 8; q++) tw[q - 1] = W[w_index<L>(q, j)];
+}
+__host__ __device__ __forceinline__ void fwd8(float2 *a, const float2 *tw) {
     dft8<-1>(a);
 #pragma unroll
-    for (int q = 1; q < 8; q++) a[q] = cmul(a[q], W[w_index<L>(q, j)]);
+    for (int q = 1; q < 8; q++) a[q] = cmul(a[q], tw[q - 1]);
 }
-template <int L> __host__ __device__ __forceinline__ void inv8(float2 *a, int j, const float2 *__restrict__ W) {
+__host__ __device__ __forceinline__ void inv8(float2 *a, const float2 *tw) {
 #pragma unroll
-    for (int q = 1; q < 8; q++) a[q] = cmulc(a[q], W[w_index<L>(q, j)]);
+    for (int q = 1; q < 8; q++) a[q] = cmulc(a[q], tw[q - 1]);
     dft8<+1>(a);
 }
+template <int L> __host__ __device__ __forceinline__ void fwd8(float2 *a, int j, const float2 *__restrict__ W) { float2 tw[7]; load_tw<L>(tw, j, W); fwd8(a, tw); }
+template <int L> __host__ __device__ __forceinline__ void inv8(float2 *a, int j, const float2 *__restrict__ W) { float2 tw[7]; load_tw<L>(tw, j, W); inv8(a, tw); }
 // points base + j + p S (the inputs of a forward / outputs of a backward butterfly)
 template <int L> __host__ __device__ __forceinline__ void load_p(float2 *a, const float2 *X, int base, int j) {
 #pragma unroll
@@ -120,36 +127,42 @@ template <int CTRL> __device__ __forceinline__ float2 quad_get(float2 v) {
 // X: LDS_N complex of LDS; W: twiddles; Hs: the spectrum in "slot" order (entry 8 t + q = what thread t holds in register q in
 // front of the multiplication, make_spectrum below), 1 / N included.
 __device__ __forceinline__ void convolve(int t, float2 *a, float2 *X, const float2 *__restrict__ W, const float2 *__restrict__ Hs) {
-    int base, j;
-    fwd8<2048>(a, t, W); store_q<2048>(a, X, 0, t);
+    // the twiddles of a stage and the spectrum are asked for one barrier ahead of their use: their latency (L2) passes under the
+    // barrier and the LDS round trip instead of in front of the butterflies
+    int b256, j256, b32, j32;
+    geom8<256>(t, b256, j256); geom8<32>(t, b32, j32);
+    float2 tw[7], tn[7];
+    load_tw<2048>(tw, t, W);
+    load_tw<256>(tn, j256, W);
+    fwd8(a, tw); store_q<2048>(a, X, 0, t);
     __syncthreads();
-    geom8<256>(t, base, j);
-    load_p<256>(a, X, base, j); fwd8<256>(a, j, W); store_q<256>(a, X, base, j);
-    __syncthreads();
-    geom8<32>(t, base, j);
-    load_p<32>(a, X, base, j); fwd8<32>(a, j, W);
+    load_tw<32>(tw, j32, W);
+    load_p<256>(a, X, b256, j256); fwd8(a, tn); store_q<256>(a, X, b256, j256);
+    float2 h[8];
     {
         const float4 *H4 = reinterpret_cast<const float4 *>(Hs + 8 * t);
-        float2 h[8];
 #pragma unroll
         for (int q = 0; q < 4; q++) { const float4 v = H4[q]; h[2 * q] = make_float2(v.x, v.y); h[2 * q + 1] = make_float2(v.z, v.w); }
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            float2 v = a[q];
-            v = quad_f1<-1>(j, v, quad_get<0x4E>(v));            // quad_perm [2, 3, 0, 1]
-            v = quad_f2(j, v, quad_get<0xB1>(v));                // quad_perm [1, 0, 3, 2]
-            v = cmul(v, h[q]);
-            v = quad_b1<-1>(j, v, quad_get<0xB1>(v));
-            v = quad_b2(j, v, quad_get<0x4E>(v));
-            a[q] = v;
-        }
     }
-    inv8<32>(a, j, W); store_p<32>(a, X, base, j);
     __syncthreads();
-    geom8<256>(t, base, j);
-    load_q<256>(a, X, base, j); inv8<256>(a, j, W); store_p<256>(a, X, base, j);
+    load_p<32>(a, X, b32, j32); fwd8(a, tw);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        float2 v = a[q];
+        v = quad_f1<-1>(j32, v, quad_get<0x4E>(v));              // quad_perm [2, 3, 0, 1]
+        v = quad_f2(j32, v, quad_get<0xB1>(v));                  // quad_perm [1, 0, 3, 2]
+        v = cmul(v, h[q]);
+        v = quad_b1<-1>(j32, v, quad_get<0xB1>(v));
+        v = quad_b2(j32, v, quad_get<0x4E>(v));
+        a[q] = v;
+    }
+    load_tw<256>(tn, j256, W);
+    inv8(a, tw); store_p<32>(a, X, b32, j32);
     __syncthreads();
-    load_q<2048>(a, X, 0, t); inv8<2048>(a, t, W);
+    load_tw<2048>(tw, t, W);
+    load_q<256>(a, X, b256, j256); inv8(a, tn); store_p<256>(a, X, b256, j256);
+    __syncthreads();
+    load_q<2048>(a, X, 0, t); inv8(a, tw);
 }
 
 // ---- host side: the same arithmetic, all 256 threads in turn between the barriers --------------------------------------

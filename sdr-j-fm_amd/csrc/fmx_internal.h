@@ -213,6 +213,8 @@ struct DeviceBuffers {
     float   *w_pdp;      // pilotDelayPSS as used by each sample
     int32_t *w_tag;      // -2 mono branch, -1 stereo without PSS, >= 0 PSS call index within the chunk
     float2  *w_x;        // matrix output, then de-emphasised + gained stereo (in place)
+    uint8_t *w_lockm;    // fused layout: [channel][lockm_stride] pilot-lock flags of this call, one byte (six samples) per thread and segment
+    int32_t lockm_stride, pad_lm;
     // PCM tail (fmx_audio.hip)
     const float *tone;   // [TT_BURST] one test-tone burst (the same for every burst: phase restarts at 0)
     float4  *pk_part;    // [channels][pk_tiles] per audio tile: max |L|, |R| of the frames of the tile's first window, then of its second

@@ -1,4 +1,4 @@
-// fmx_stageb.hip -- stage B as ONE time-parallel kernel per channel ("fused layout").  COMPILED WITH -ffp-contract=off.
+// fmx_stageb.hip -- stage B time-parallel, one workgroup per channel ("fused layout").  COMPILED WITH -ffp-contract=off.
 //
 // Replaces per channel, like fmx_demod.hip:
 //   fm_Demodulator::demodulate        fm-demodulator.cpp:111-205 (memoryless decoders: Mixed / ComplexBB / RealBB / Diff)
@@ -11,7 +11,12 @@
 // fmx_demod.hip runs the per-sample recurrences with one LANE per channel: their parallelism is the channel count, every
 // sample costs a 180-cycle dependent chain, and five kinds of kernels hand chunks to each other through progress words.
 // Here the parallelism is TIME: one 256-thread workgroup owns one channel and a segment of up to 1536 fm samples (six
-// adjacent samples per thread); every recurrence becomes a scan over the workgroup --
+// adjacent samples per thread); every recurrence becomes a scan over the workgroup.  Two kernels:
+//   stageb_pll_kernel  once per call -- limiter, discriminator, AFC, pilot PLL, lock detector for all the call's segments in
+//                      turn (none of it depends on the PSS feedback);
+//   stageb_pss_kernel  once per segment -- PSS low-pass and error by fast convolution (fmx_fftconv.h), PSS integrator, 38 kHz
+//                      mix, matrix, de-emphasis.
+// The recurrences:
 //   * linear recurrences with a constant decay (AFC, lock metric, PSS mean error, de-emphasis): a weighted wave scan in DPP
 //     carries the state ACROSS threads, each thread then re-runs its own six samples in the reference's exact f32 / f64
 //     expression.  The cross-thread carry differs from the sequential evaluation by rounding (1e-7 relative);
@@ -36,9 +41,9 @@
 //   * flags and counters (pilot lock, PSS call index, the "error minimised" state machine) follow from max / sum scans in
 //     closed form; a segment in which a closed form does not apply (lock transitions inside a PSS segment, a counter next to
 //     its 3 s threshold) is replayed sample by sample by one thread from LDS.
-// The only feedback with a lag, the PSS error (low-pass of the 38 kHz mix, 1753 samples behind), bounds the segment: its
-// errors are computed by a separate time-parallel kernel in front of each segment's launch, from s-ring entries that are
-// at least one segment old.  Everything runs on the caller's stream: no side streams, no events, no waiting kernels.
+// The only feedback with a lag, the PSS error (low-pass of the 38 kHz mix, 1753 samples behind), bounds the segment of the
+// second kernel: its errors come from s-ring entries that are at least one segment old.  Everything runs on the caller's stream:
+// no side streams, no events, no waiting kernels.
 #include "fmx_internal.h"
 #include "fmx_demod_math.h"
 #include "fmx_fftconv.h"
@@ -131,20 +136,19 @@ __device__ __forceinline__ float wscan_decay(float v, const DecayW &w) {
 // a thread can only write slot k again after passing the barrier of the step in between, which every thread reaches only
 // after it has read slot k.
 // ---------------------------------------------------------------------------------------------------------------------
-struct SegLds {
+struct ScanLds {
     double wd[2][4][2];          // per wave: f64 totals
     float  wf[2][4][4];          // per wave: f32 totals
     int    wi[2][4][4];          // per wave: int totals / flags
     float  edge[FB_T];           // a value every thread hands to its right neighbour
-    int    pk[FB_W];             // replay path: ((tag + 2) << 1) | locked per sample
-    float  er[FB_W];             // replay path: PSS error in, pilotDelayPSS used out
 };
+
 
 struct SegArgs { int seg0, w, first, last; };
 
 // Workgroup-wide pieces.  `sl` is the scratch slot, toggled by every call; all threads of the workgroup make the same calls.
 struct WG {
-    SegLds *L; int tid, lane, wv, sl;
+    ScanLds *L; int tid, lane, wv, sl;
     // y[j] = d y[j-1] + u[j]: the value in front of this thread's first sample, given this thread's run from zero `Lt`
     // (its contribution at its own last sample) and the state Y0 in front of the segment
     __device__ __forceinline__ float decay_incoming(float Lt, float Y0, const DecayW &w) {
@@ -155,6 +159,18 @@ struct WG {
         for (int v = 0; v < wv; v++) C = fmaf(C, w.d64, L->wf[sl][v][0]);
         sl ^= 1;
         return fmaf(w.dl, C, lane_prev_f(Z, 0.f));
+    }
+    // the same, and the value behind a FULL segment (what the next segment of the same workgroup starts from)
+    __device__ __forceinline__ float decay_incoming2(float Lt, float Y0, const DecayW &w, float *Yend) {
+        const float Z = wscan_decay(Lt, w);
+        if (lane == 63) L->wf[sl][wv][0] = Z;
+        __syncthreads();
+        float C = Y0, Cin = Y0;
+#pragma unroll
+        for (int v = 0; v < 4; v++) { C = fmaf(C, w.d64, L->wf[sl][v][0]); Cin = (v + 1 == wv) ? C : Cin; }
+        sl ^= 1;
+        *Yend = C;
+        return fmaf(w.dl, Cin, lane_prev_f(Z, 0.f));
     }
     // exclusive prefix of an f64 sum over the threads (+ the workgroup total), with an OR-reduction of a flag riding along
     __device__ __forceinline__ double excl_add_d(double tot, double *total, bool flag, bool *any_flag) {
@@ -213,6 +229,15 @@ struct WG {
             a = xa > a ? xa : a; b = xb > b ? xb : b; c = xc > c ? xc : c; d = xd > d ? xd : d;
         }
         sl ^= 1;
+    }
+    // the value the left neighbour hands over (`first` for thread 0) and the last thread's value
+    __device__ __forceinline__ float from_left2(float mine, float first, float *last) {
+        L->edge[tid] = mine;
+        __syncthreads();
+        const float v = tid ? L->edge[tid - 1] : first;
+        *last = L->edge[FB_T - 1];
+        __syncthreads();
+        return v;
     }
     // the value the left neighbour hands over (`first` for thread 0)
     __device__ __forceinline__ float from_left(float mine, float first) {
@@ -311,33 +336,6 @@ __global__ __launch_bounds__(64) void pssfir_seg_kernel(DeviceTables T, DeviceBu
     }
 }
 
-// The same errors by fast convolution (fmx_fftconv.h): one 256-thread workgroup per channel transforms the segment's window of
-// w + 294 s-ring entries (zero-padded to 2048 points), multiplies by the taps' spectrum and transforms back -- the reference's
-// own method (fft-filters.cpp:132-163, 2048 points), about a fifth of the direct form's arithmetic.
-__global__ __launch_bounds__(fftc::T) void pssfft_seg_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, SegArgs A) {
-    __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];
-    const int ch = blockIdx.x, t = threadIdx.x;
-    const ChanParams &P = B.params[ch];
-    if (P.fm_mode == 2 || !P.pss_active) return;
-    const ChanState &st = B.state[ch];
-    const int64_t i0 = st.pss_count + (A.first ? 0 : st.pss_call_total);           // call index of the segment's first output
-    const float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
-    float2 a[8];
-#pragma unroll
-    for (int p = 0; p < 8; p++) {          // window entry n <-> s index i0 - (1753 + 294) + n; entries past the segment's need are padding
-        const int n = t + fftc::T * p;
-        const int64_t idx = i0 - (PSS_DELAY + PSS_TAPS - 1) + n;
-        a[p] = (n < A.w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
-    }
-    fftc::convolve(t, a, X, T.fft_w, T.pss_hs);
-    float *dst = B.w_err + (size_t)ch * FB_W;
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-        const int m = t + fftc::T * p - (PSS_TAPS - 1);
-        if (m >= 0 && m < A.w) dst[m] = a[p].x * a[p].y;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // one step of the PSS integrator and its state machines, every lane / thread in any state (fm-processor.cpp:699-718,
 // stereo-separation.cpp:84-109); the replay path runs it sample by sample
@@ -364,10 +362,288 @@ __device__ __forceinline__ float pss_step(PssSt &s, float alpha, float la, float
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// the segment kernel: one workgroup = one channel x fm samples [seg0, seg0 + w) of the call
+// Kernel 1 of 2, once per call: one workgroup = one channel, looping over the call's segments of up to 1536 fm samples --
+// limiter + discriminator, AFC, pilot PLL, lock detector.  Nothing here depends on the PSS feedback, so the whole call runs in
+// one launch: the recurrences' states ride from segment to segment in registers (every thread holds the same copy), the
+// next segment's ring entries are loaded while the current one is computed.  Out: demod and pilot phase per sample
+// (w_dem / w_cur, which are also the scope / RDS taps) and one byte of lock flags per thread and segment (w_lockm).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FB_T, 4) void stageb_seg_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, SegArgs A) {
-    __shared__ SegLds lds;
+__global__ __launch_bounds__(FB_T, 3) void stageb_pll_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
+    __shared__ ScanLds lds;
+    const int ch = blockIdx.x;
+    if (ch >= C) return;
+    WG wg; wg.L = &lds; wg.tid = threadIdx.x; wg.lane = threadIdx.x & 63; wg.wv = threadIdx.x >> 6; wg.sl = 0;
+    const int tid = wg.tid, lane = wg.lane;
+    const ChanParams &P = B.params[ch];
+    ChanState *st = B.state + ch;
+    const int nj = (int)(G.J1 - G.J0);
+    const int j0 = tid * FB_K;                                   // segment-relative index of this thread's first sample
+    const int lin = B.lin_rows;                                  // row stride of the channel-major tap arrays
+    const bool dbg_on = (B.dbg != nullptr) && (tid == 0);
+    unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
+    const int decoder = P.decoder;
+    const int delay = T.front_sets[P.front_set].delay_fm;
+    const float2 *zr = B.zring + (size_t)ch * (G.ring_mask + 1);
+    // ring entries of the samples j0 - 2 .. j0 + K - 1 of the segment at seg0 (clamped to the call's last sample: never past what
+    // stage A wrote; zero until the filter latency has elapsed; the marker NaN where the reference's start values 0.01 apply)
+    auto fetch = [&](int seg0, int w, float2 *z) {
+#pragma unroll
+        for (int t = 0; t < FB_K + 2; t++) {
+            const int jr = j0 - 2 + t;
+            const int64_t jj = G.J0 + seg0 + (jr < w ? jr : w - 1);
+            const int64_t s = jj - delay;
+            z[t] = jj < 0 ? make_float2(__builtin_nanf(""), 0.f) : (s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f));
+        }
+    };
+    // the recurrences' states in front of the segment (the same in every thread)
+    float afc0 = st->fm_afc, x0s = st->pil_phase, old0 = st->pil_old, lock0 = st->pil_lock;
+    int locked0 = st->pil_locked, stable0 = st->pil_stable;
+    float2 zn[FB_K + 2];
+    fetch(0, nj < FB_W ? nj : FB_W, zn);
+    for (int seg0 = 0; seg0 < nj; seg0 += FB_W) {
+        const int w = (nj - seg0) < FB_W ? (nj - seg0) : FB_W;
+        const bool lastseg = seg0 + FB_W >= nj;
+        bool ok[FB_K];
+#pragma unroll
+        for (int i = 0; i < FB_K; i++) ok[i] = j0 + i < w;
+        const bool owner = (w - 1 >= j0) && (w - 1 < j0 + FB_K);     // this thread owns the segment's last sample
+        const int il = w - 1 - j0;                                   // ... at this position
+        const size_t lrow = (size_t)ch * lin + seg0 + j0;
+
+        // ================= limiter + discriminator (fm-demodulator.cpp:119-126, 168-189) =================
+        float res[FB_K];
+        {
+            float2 lim[FB_K + 2];                                // limited samples j0-2 .. j0+K-1 (the two in front recomputed: cheaper
+#pragma unroll                                                   // than an exchange through LDS with its two barriers)
+            for (int t = 0; t < FB_K + 2; t++) lim[t] = (zn[t].x != zn[t].x) ? make_float2((float)0.01, (float)0.01) : limiter_fast(zn[t]);
+            if (!lastseg) { const int wn = (nj - seg0 - FB_W) < FB_W ? (nj - seg0 - FB_W) : FB_W; fetch(seg0 + FB_W, wn, zn); }   // lands under this segment's work
+            // (one loop per decoder: the six table gathers of a thread are issued back to back, not one per branch arm)
+            if (decoder == 5) {                                      // REAL_BB :174-182
+                int index[FB_K];
+    #pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
+                    const float r = (float)((double)(I1 * Q - Q1 * I + 1) / 2.0);
+                    int ix = (int)floorf(r * (float)ARCSINE_N);
+                    ix = ix < 0 ? 0 : ix;
+                    index[i] = ix >= ARCSINE_N ? ARCSINE_N : ix;
+                }
+    #pragma unroll
+                for (int i = 0; i < FB_K; i++) res[i] = T.arcsine[index[i]];
+            } else if (decoder == 6) {                               // DIFF :184-189
+    #pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
+                    const float Scaler = (float)1.4142135623730951;
+                    const float r = (I1 * (Q - lim[i].y) - Q1 * (I - lim[i].x));
+    #ifdef SB_EXACT_DIV
+                    res[i] = r / ((I1 * I1 + Q1 * Q1) * Scaler);
+    #else
+                    res[i] = fdiv_fast(r, (I1 * I1 + Q1 * Q1) * Scaler);
+    #endif
+                }
+            } else {                                                 // MIXED :168-172 (COMPLEX_BB is bitwise the same)
+                AtanArm arm[FB_K];
+    #pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
+                    arm[i] = atan_arm(Q * I1 - I * Q1, I * I1 + Q * Q1);
+                }
+                float tv[FB_K];
+    #pragma unroll
+                for (int i = 0; i < FB_K; i++) tv[i] = T.atan_ppy[arm[i].idx];
+    #pragma unroll
+                for (int i = 0; i < FB_K; i++) res[i] = atan_finish(arm[i], tv[i]);
+            }
+    #pragma unroll
+            for (int i = 0; i < FB_K; i++) res[i] = ok[i] ? res[i] : 0.f;
+        }
+
+
+        SB_TICK(0);
+        // ================= AFC + scaling (fm-demodulator.cpp:197-198) =================
+        float dem[FB_K];
+        {
+            const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha;
+            float Lt = 0.f;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) Lt = c1 * Lt + fmDcAlpha * res[i];
+            float afc_next;
+            float afc = wg.decay_incoming2(Lt, afc0, make_decay(T.afc_l2, lane), &afc_next);
+            float afc_end = 0.f;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) {
+                afc = c1 * afc + fmDcAlpha * res[i];
+                dem[i] = fdiv_const(20.0f * (res[i] - afc) * 1.0f, T.K_FM, T.K_FM_rcp);
+                if (i == il) afc_end = afc;
+            }
+            if (lastseg && owner) st->fm_afc = afc_end;
+            afc0 = afc_next;
+        }
+
+        SB_TICK(1);
+        // ================= pilot PLL (pilot-recover.cpp:54-61): fixed point of the f32 trajectory =================
+        float cur[FB_K], osc[FB_K];
+        float osc_in;                                            // NCO sine of the sample in front of this thread's first
+        {
+            const float gain = T.pil_gain, omega = T.pil_omega;
+            const float SC32 = (float)T.sincos_C;
+            const float P32 = 6.2831855f, C32 = T.wrap32_c;
+            float x0 = x0s;
+            if (!(x0 >= 0.f && x0 < P32)) x0 = pi_constrain(x0);
+            float ph[FB_K];
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) {
+                // first guess: the free-running ramp x0 + j omega
+                const double r = (double)x0 + (double)(j0 + i) * (double)omega;
+                ph[i] = (j0 + i == 0) ? x0 : (float)(r - floor(r * (1.0 / FMX_2PI)) * FMX_2PI);
+            }
+            const double x0d = (double)x0;
+            float xend = x0;
+            for (int it = 0; ; it++) {
+                double e[FB_K], tot = 0.0;
+    #pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    float phase = ph[i];
+                    // a guess outside [0, 2 pi) (guesses of unfinished rounds only: a wrap that sits one sample earlier or later in the
+                    // guess than in the step's result shifts everything behind it by a turn) is taken modulo 2 pi
+                    if (__any(!(phase >= 0.f && phase < P32))) {
+                        const double pd = (double)phase;
+                        const float pw = (float)(pd - floor(pd * (1.0 / FMX_2PI)) * FMX_2PI);
+                        phase = (phase >= 0.f && phase < P32) ? phase : ((pw >= 0.f && pw < P32) ? pw : 0.f);
+                    }
+                    // SinCos::getSin sincos.cpp:81-85 for phase >= 0: table entry (int)(phase * C) % Rate, the entry itself from
+                    // sin_idx_f32 (the index in f32: it differs from the f64 product's in < 2 % of the samples, by one entry)
+    #ifdef SB_IDX64
+                    int idx = (int)((double)phase * T.sincos_C);
+    #else
+                    int idx = (int)(phase * SC32);
+    #endif
+                    idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+                    const float o = sin_idx_f32(idx);
+                    const float perr = (5 * dem[i]) * o;             // pilot-recover.cpp:56-58 (pilot = 5 * demod fm-processor.cpp:696)
+                    const float t = phase + perr * gain;
+                    const float val = t + omega;
+                    const float wrapped = T.wrap32_ok ? (val - P32) + C32 : (float)((double)val - FMX_2PI);
+                    float nx = (val < P32) ? val : wrapped;          // PI_Constrain fm-constants.h:148-158
+                    // (a correction of more than a turn: the DIFF decoder's spike where the limiter output jumps from its 0.001 floor
+                    // to the unit circle at signal onset -- the general PI_Constrain, wave-uniformly skipped otherwise)
+                    if (__any(!(val >= 0.f && val < 2.f * P32))) nx = pi_constrain(val);
+                    cur[i] = t; osc[i] = o;
+                    e[i] = tot;
+                    tot += ok[i] ? (double)nx - (double)phase : 0.0;
+                }
+                double total; bool any;
+                const double pre = wg.excl_add_d(tot, &total, false, &any);
+                bool open_ = false;
+    #pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    const float nph = (float)(x0d + (pre + e[i]));
+                    // distance between the guess this round evaluated and the one it produced (a wrap that moved by one sample
+                    // shows as 2 pi)
+                    float dd = fabsf(nph - ph[i]);
+                    dd = fminf(dd, fabsf(dd - P32));
+                    open_ = open_ || (ok[i] && !(dd < PLL_TOL));
+                    ph[i] = nph;
+                }
+                {   // (a guess chain may carry whole turns: dd above takes them for "no change", so the end state is taken modulo 2 pi)
+                    const double xe = x0d + total;
+                    xend = (float)(xe - floor(xe * (1.0 / FMX_2PI)) * FMX_2PI);
+                }
+                // every thread must know whether ANY thread is still moving: one more reduction (flags only)
+                const int wopen = __any(open_) ? 1 : 0;              // (evaluated by the whole wave, not under the lane-0 branch)
+                if (lane == 0) lds.wi[wg.sl][wg.wv][0] = wopen;
+                __syncthreads();
+                const int anych = lds.wi[wg.sl][0][0] | lds.wi[wg.sl][1][0] | lds.wi[wg.sl][2][0] | lds.wi[wg.sl][3][0];
+                wg.sl ^= 1;
+                if (!anych || it == PLL_MAX_ROUNDS - 1) { if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it + 1; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; } break; }
+            }
+        // (cur / osc are those of the last round's evaluation: of a trajectory the round moved by less than PLL_TOL)
+            x0s = (xend >= 0.f && xend < P32) ? xend : 0.f;
+            if (lastseg && tid == 0) st->pil_phase = x0s;
+            float old_next;
+            osc_in = wg.from_left2(osc[FB_K - 1], old0, &old_next);
+            old0 = old_next;
+            if (lastseg && owner) {
+                float oe = 0.f;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) if (i == il) oe = osc[i];
+                st->pil_old = oe;
+            }
+        }
+
+        SB_TICK(2);
+        // ================= lock detector (pilot-recover.cpp:62-80) =================
+        {
+            const float lockA = 1.0f / 3000.0f;
+            const double keep = 1.0 - (double)lockA;
+            const float keepf = (float)keep;
+            const float omega = T.pil_omega, romega = T.pil_omega_rcp;
+            float xq[FB_K];
+            {
+                float old = osc_in;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    const float quadRef = fdiv_const(osc[i] - old, omega, romega);
+                    old = osc[i];
+                    xq[i] = ok[i] ? lockA * (-quadRef * (5 * dem[i])) : 0.f;
+                }
+            }
+            float Lt = 0.f;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) Lt = xq[i] + Lt * keepf;
+            float lock_next;
+            float lock = wg.decay_incoming2(Lt, lock0, make_decay(T.lock_l2, lane), &lock_next);
+            bool hi[FB_K]; int lastf = -1; float lock_end = 0.f;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) {
+                lock = (float)((double)xq[i] + (double)lock * keep);
+                hi[i] = lock > 0.07f;
+                if (ok[i] && !hi[i]) lastf = j0 + i;
+                if (i == il) lock_end = lock;
+            }
+            // locked[j] = no sample <= j below the threshold AND (locked before, or the run has lasted long enough)
+            int cnt_dummy, tot_dummy, preF, totF;
+            wg.excl_add_max_i(0, lastf, &cnt_dummy, &tot_dummy, &preF, &totF);
+            unsigned mask = 0;
+            {
+                int F = preF;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    if (ok[i] && !hi[i]) F = j0 + i;
+                    const bool lk = (F < 0) && (locked0 != 0 || stable0 + (j0 + i) + 1 > (SINCOS_N >> 1));
+                    mask |= lk ? (1u << i) : 0u;
+                }
+            }
+            B.w_lockm[(size_t)ch * B.lockm_stride + (size_t)(seg0 / FB_K) + tid] = (uint8_t)mask;
+            int nl, ns;
+            if (totF < 0) { nl = (locked0 != 0 || stable0 + w > (SINCOS_N >> 1)) ? 1 : 0;
+                            ns = locked0 ? stable0 : (stable0 + w < (SINCOS_N >> 1) + 1 ? stable0 + w : (SINCOS_N >> 1) + 1); }
+            else { nl = 0; ns = w - 1 - totF; }
+            if (lastseg && owner) { st->pil_lock = lock_end; st->pil_locked = nl; st->pil_stable = ns; }
+            locked0 = nl; stable0 = ns; lock0 = lock_next;
+        }
+        // scope taps and the inputs of the second kernel / the RDS path: channel-major rows of this call
+#pragma unroll
+        for (int i = 0; i < FB_K; i++) if (ok[i]) { B.w_dem[lrow + i] = dem[i]; B.w_cur[lrow + i] = cur[i]; }
+        SB_TICK(3);
+    }
+    if (dbg_on) for (int k = 0; k < 4; k++) B.dbg[(size_t)ch * DBG_SLOTS + 16 + k] += dbg_acc[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Kernel 2 of 2, once per segment: one workgroup = one channel x fm samples [seg0, seg0 + w) of the call -- the PSS error of
+// the calls the segment can make (fast convolution of the s ring, fmx_fftconv.h), the PSS integrator, 38 kHz mix, matrix,
+// de-emphasis.  The segment length is bounded by the PSS feedback lag (1753 samples): its errors only need s-ring entries of
+// earlier segments.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FB_T, 4) void stageb_pss_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, SegArgs A) {
+    __shared__ ScanLds lds;
+    __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];     // the convolution's buffer, afterwards er / pk:
+    float *er = reinterpret_cast<float *>(X);                        // [FB_W] PSS error per call of the segment; replay path: error in, pilotDelayPSS used out
+    int *pk = reinterpret_cast<int *>(X) + FB_W;                     // [FB_W] replay path: ((tag + 2) << 1) | locked per sample
+    static_assert(2 * FB_W * 4 <= sizeof(float2) * fftc::LDS_N, "er and pk live in the convolution buffer");
     const int ch = blockIdx.x;
     if (ch >= C) return;
     WG wg; wg.L = &lds; wg.tid = threadIdx.x; wg.lane = threadIdx.x & 63; wg.wv = threadIdx.x >> 6; wg.sl = 0;
@@ -375,253 +651,73 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_seg_kernel(DeviceTables T, Dev
     const ChanParams &P = B.params[ch];
     ChanState *st = B.state + ch;
     const int w = A.w;
-    const int j0 = tid * FB_K;                                   // segment-relative index of this thread's first sample
+    const int j0 = tid * FB_K;
     bool ok[FB_K];
 #pragma unroll
     for (int i = 0; i < FB_K; i++) ok[i] = j0 + i < w;
-    const bool owner = (w - 1 >= j0) && (w - 1 < j0 + FB_K);     // this thread owns the segment's last sample
-    const int il = w - 1 - j0;                                   // ... at this position
-    const int lin = B.lin_rows;                                  // row stride of the channel-major tap arrays
+    const bool owner = (w - 1 >= j0) && (w - 1 < j0 + FB_K);
+    const int il = w - 1 - j0;
+    const int lin = B.lin_rows;
     const size_t lrow = (size_t)ch * lin + A.seg0 + j0;
     const bool dbg_on = (B.dbg != nullptr) && (tid == 0);
     unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
-
-    // ================= limiter + discriminator (fm-demodulator.cpp:119-126, 168-189) =================
-    float res[FB_K];
-    {
-        const int decoder = P.decoder;
-        const int delay = T.front_sets[P.front_set].delay_fm;
-        const float2 *zr = B.zring + (size_t)ch * (G.ring_mask + 1);
-        auto limited = [&](int jr) -> float2 {                   // limited sample at segment-relative index jr
-            const int64_t jj = G.J0 + A.seg0 + (jr < w ? jr : w - 1);                  // clamped: never past what stage A wrote
-            if (jj < 0) return make_float2((float)0.01, (float)0.01);                  // Imin1 / Qmin1 at start (fm-demodulator.cpp:79-82)
-            const int64_t s = jj - delay;
-#ifdef SB_EXACT_DIV
-            return limiter(s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f));
-#endif
-            return limiter_fast(s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f)); // 0 until the filter latency has elapsed
-        };
-        float2 lim[FB_K + 2];                                    // limited samples j0-2 .. j0+K-1 (the two in front recomputed: cheaper
-#pragma unroll                                                   // than an exchange through LDS with its two barriers)
-        for (int t = 0; t < FB_K + 2; t++) lim[t] = limited(j0 - 2 + t);
-        // (one loop per decoder: the six table gathers of a thread are issued back to back, not one per branch arm)
-        if (decoder == 5) {                                      // REAL_BB :174-182
-            int index[FB_K];
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
-                const float r = (float)((double)(I1 * Q - Q1 * I + 1) / 2.0);
-                int ix = (int)floorf(r * (float)ARCSINE_N);
-                ix = ix < 0 ? 0 : ix;
-                index[i] = ix >= ARCSINE_N ? ARCSINE_N : ix;
-            }
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) res[i] = T.arcsine[index[i]];
-        } else if (decoder == 6) {                               // DIFF :184-189
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
-                const float Scaler = (float)1.4142135623730951;
-                const float r = (I1 * (Q - lim[i].y) - Q1 * (I - lim[i].x));
-#ifdef SB_EXACT_DIV
-                res[i] = r / ((I1 * I1 + Q1 * Q1) * Scaler);
-#else
-                res[i] = fdiv_fast(r, (I1 * I1 + Q1 * Q1) * Scaler);
-#endif
-            }
-        } else {                                                 // MIXED :168-172 (COMPLEX_BB is bitwise the same)
-            AtanArm arm[FB_K];
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
-                arm[i] = atan_arm(Q * I1 - I * Q1, I * I1 + Q * Q1);
-            }
-            float tv[FB_K];
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) tv[i] = T.atan_ppy[arm[i].idx];
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) res[i] = atan_finish(arm[i], tv[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) res[i] = ok[i] ? res[i] : 0.f;
-    }
-
-    SB_TICK(0);
-    // ================= AFC + scaling (fm-demodulator.cpp:197-198) =================
-    float dem[FB_K];
-    {
-        const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha;
-        const DecayW dw = make_decay(T.afc_l2, lane);
-        float Lt = 0.f;
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) Lt = c1 * Lt + fmDcAlpha * res[i];
-        float afc = wg.decay_incoming(Lt, st->fm_afc, dw);
-        float afc_end = 0.f;
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) {
-            afc = c1 * afc + fmDcAlpha * res[i];
-            dem[i] = fdiv_const(20.0f * (res[i] - afc) * 1.0f, T.K_FM, T.K_FM_rcp);
-            if (i == il) afc_end = afc;
-        }
-        if (owner) st->fm_afc = afc_end;
-    }
-
-    SB_TICK(1);
-    // ================= pilot PLL (pilot-recover.cpp:54-61): fixed point of the f32 trajectory =================
-    float cur[FB_K], osc[FB_K];
-    float osc_in;                                                // NCO sine of the sample in front of this thread's first
-    {
-        const float gain = T.pil_gain, omega = T.pil_omega;
-        const float SC32 = (float)T.sincos_C;
-        const float P32 = 6.2831855f, C32 = T.wrap32_c;
-        float x0 = st->pil_phase;
-        if (!(x0 >= 0.f && x0 < P32)) x0 = pi_constrain(x0);
-        float ph[FB_K], p5[FB_K];
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) {
-            // first guess: the free-running ramp x0 + j omega
-            const double r = (double)x0 + (double)(j0 + i) * (double)omega;
-            ph[i] = (j0 + i == 0) ? x0 : (float)(r - floor(r * (1.0 / FMX_2PI)) * FMX_2PI);
-            p5[i] = 5 * dem[i];
-        }
-        const double x0d = (double)x0;
-        float xend = x0;
-        for (int it = 0; ; it++) {
-            double e[FB_K], tot = 0.0;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                float phase = ph[i];
-                // a guess outside [0, 2 pi) (guesses of unfinished rounds only: a wrap that sits one sample earlier or later in the
-                // guess than in the step's result shifts everything behind it by a turn) is taken modulo 2 pi
-                if (__any(!(phase >= 0.f && phase < P32))) {
-                    const double pd = (double)phase;
-                    const float pw = (float)(pd - floor(pd * (1.0 / FMX_2PI)) * FMX_2PI);
-                    phase = (phase >= 0.f && phase < P32) ? phase : ((pw >= 0.f && pw < P32) ? pw : 0.f);
-                }
-                // SinCos::getSin sincos.cpp:81-85 for phase >= 0: table entry (int)(phase * C) % Rate, the entry itself from
-                // sin_idx_f32 (the index in f32: it differs from the f64 product's in < 2 % of the samples, by one entry)
-#ifdef SB_IDX64
-                int idx = (int)((double)phase * T.sincos_C);
-#else
-                int idx = (int)(phase * SC32);
-#endif
-                idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
-                const float o = sin_idx_f32(idx);
-                const float perr = p5[i] * o;                    // pilot-recover.cpp:56-58
-                const float t = phase + perr * gain;
-                const float val = t + omega;
-                const float wrapped = T.wrap32_ok ? (val - P32) + C32 : (float)((double)val - FMX_2PI);
-                float nx = (val < P32) ? val : wrapped;          // PI_Constrain fm-constants.h:148-158
-                // (a correction of more than a turn: the DIFF decoder's spike where the limiter output jumps from its 0.001 floor
-                // to the unit circle at signal onset -- the general PI_Constrain, wave-uniformly skipped otherwise)
-                if (__any(!(val >= 0.f && val < 2.f * P32))) nx = pi_constrain(val);
-                cur[i] = t; osc[i] = o;
-                e[i] = tot;
-                tot += ok[i] ? (double)nx - (double)phase : 0.0;
-            }
-            double total; bool any;
-            const double pre = wg.excl_add_d(tot, &total, false, &any);
-            bool open_ = false;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                const float nph = (float)(x0d + (pre + e[i]));
-                // distance between the guess this round evaluated and the one it produced (a wrap that moved by one sample
-                // shows as 2 pi)
-                float dd = fabsf(nph - ph[i]);
-                dd = fminf(dd, fabsf(dd - P32));
-                open_ = open_ || (ok[i] && !(dd < PLL_TOL));
-                ph[i] = nph;
-            }
-            {   // (a guess chain may carry whole turns: dd above takes them for "no change", so the end state is taken modulo 2 pi)
-                const double xe = x0d + total;
-                xend = (float)(xe - floor(xe * (1.0 / FMX_2PI)) * FMX_2PI);
-            }
-            // every thread must know whether ANY thread is still moving: one more reduction (flags only)
-            const int wopen = __any(open_) ? 1 : 0;              // (evaluated by the whole wave, not under the lane-0 branch)
-            if (lane == 0) lds.wi[wg.sl][wg.wv][0] = wopen;
-            __syncthreads();
-            const int anych = lds.wi[wg.sl][0][0] | lds.wi[wg.sl][1][0] | lds.wi[wg.sl][2][0] | lds.wi[wg.sl][3][0];
-            wg.sl ^= 1;
-            if (!anych || it == PLL_MAX_ROUNDS - 1) { if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it + 1; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; } break; }
-        }
-        // (cur / osc are those of the last round's evaluation: of a trajectory the round moved by less than PLL_TOL)
-        if (tid == 0) st->pil_phase = (xend >= 0.f && xend < P32) ? xend : 0.f;
-        osc_in = wg.from_left(osc[FB_K - 1], st->pil_old);
-        if (owner) {
-            float oe = 0.f;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) if (i == il) oe = osc[i];
-            st->pil_old = oe;
-        }
-    }
-
-    SB_TICK(2);
-    // ================= lock detector (pilot-recover.cpp:62-80) and the PSS call index (fm-processor.cpp:704-718) =================
     const bool stereo_possible = P.fm_mode != 2, auto_mono = P.auto_mono != 0, pss_active = P.pss_active != 0;
-    bool locked[FB_K]; int tag[FB_K];
-    int ncalls, calls_before;
-    {
-        const float lockA = 1.0f / 3000.0f;
-        const double keep = 1.0 - (double)lockA;
-        const float keepf = (float)keep;
-        const float omega = T.pil_omega, romega = T.pil_omega_rcp;
-        float xq[FB_K];
-        {
-            float old = osc_in;
+    const int calls_before = A.first ? 0 : st->pss_call_total;
+    // this thread's samples out of the first kernel
+    float dem[FB_K], cur[FB_K];
 #pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                const float quadRef = fdiv_const(osc[i] - old, omega, romega);
-                old = osc[i];
-                xq[i] = ok[i] ? lockA * (-quadRef * (5 * dem[i])) : 0.f;
+    for (int i = 0; i < FB_K; i++) { dem[i] = ok[i] ? B.w_dem[lrow + i] : 0.f; cur[i] = ok[i] ? B.w_cur[lrow + i] : 0.f; }
+    const unsigned lmask = B.w_lockm[(size_t)ch * B.lockm_stride + (size_t)(A.seg0 / FB_K) + tid];
+
+    // ================= PSS errors of the calls this segment can make: err[m] = Re (y) Im (y), y = low-pass of the s ring
+    // (stereo-separation.cpp:60-83), m = call index within the segment, into lds.er =================
+    if (stereo_possible && pss_active) {
+        if (T.pss_hs) {
+            const int64_t i0 = st->pss_count + calls_before;                         // call index of the segment's first output
+            const float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
+            float2 a[8];
+#pragma unroll
+            for (int p = 0; p < 8; p++) {      // window entry n <-> s index i0 - (1753 + 294) + n; entries past the segment's need are padding
+                const int n = tid + fftc::T * p;
+                const int64_t idx = i0 - (PSS_DELAY + PSS_TAPS - 1) + n;
+                a[p] = (n < w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
             }
-        }
-        const DecayW dw = make_decay(T.lock_l2, lane);
-        float Lt = 0.f;
+            fftc::convolve(tid, a, X, T.fft_w, T.pss_hs);
+            __syncthreads();                   // (er overlays the buffer the last stage was read from)
 #pragma unroll
-        for (int i = 0; i < FB_K; i++) Lt = xq[i] + Lt * keepf;
-        float lock = wg.decay_incoming(Lt, st->pil_lock, dw);
-        bool hi[FB_K]; int lastf = -1; float lock_end = 0.f;
+            for (int p = 0; p < 8; p++) {
+                const int m = tid + fftc::T * p - (PSS_TAPS - 1);
+                if (m >= 0 && m < FB_W) er[m] = a[p].x * a[p].y;
+            }
+        } else {                               // (FMX_PSS_FIR=direct: pssfir_seg_kernel ran in front of this kernel)
+            const float *errc = B.w_err + (size_t)ch * FB_W;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) er[j0 + i] = errc[j0 + i];
+        }
+    }
+    __syncthreads();
+    SB_TICK(0);
+
+    // ================= the PSS call index of every sample (fm-processor.cpp:704-718) =================
+    bool locked[FB_K]; int tag[FB_K];
+    int ncalls;
+    {
+        int ncall_t = 0;
 #pragma unroll
         for (int i = 0; i < FB_K; i++) {
-            lock = (float)((double)xq[i] + (double)lock * keep);
-            hi[i] = lock > 0.07f;
-            if (ok[i] && !hi[i]) lastf = j0 + i;
-            if (i == il) lock_end = lock;
-        }
-        // locked[j] = no sample <= j below the threshold AND (locked before, or the run has lasted long enough)
-        const int locked0 = st->pil_locked, stable0 = st->pil_stable;
-        int cnt_dummy, tot_dummy, preF, totF;
-        wg.excl_add_max_i(0, lastf, &cnt_dummy, &tot_dummy, &preF, &totF);
-        int ncall_t = 0;
-        {
-            int F = preF;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                if (ok[i] && !hi[i]) F = j0 + i;
-                locked[i] = (F < 0) && (locked0 != 0 || stable0 + (j0 + i) + 1 > (SINCOS_N >> 1));
-                const bool branch = stereo_possible && (locked[i] || !auto_mono);
-                tag[i] = branch ? (pss_active ? 0 : -1) : -2;
-                ncall_t += (ok[i] && branch && pss_active) ? 1 : 0;
-            }
+            locked[i] = (lmask >> i) & 1u;
+            const bool branch = stereo_possible && (locked[i] || !auto_mono);
+            tag[i] = branch ? (pss_active ? 0 : -1) : -2;
+            ncall_t += (ok[i] && branch && pss_active) ? 1 : 0;
         }
         int preC, dm1, dm2;
         wg.excl_add_max_i(ncall_t, 0, &preC, &ncalls, &dm1, &dm2);
-        calls_before = A.first ? 0 : st->pss_call_total;
-        {
-            int c = preC;
+        int c = preC;
 #pragma unroll
-            for (int i = 0; i < FB_K; i++) if (tag[i] == 0) { tag[i] = ok[i] ? c : -2; c += ok[i] ? 1 : 0; }    // index of the call within the segment
-        }
-        if (owner) {
-            st->pil_lock = lock_end;
-            if (totF < 0) { st->pil_locked = (locked0 != 0 || stable0 + w > (SINCOS_N >> 1)) ? 1 : 0;
-                            st->pil_stable = locked0 ? stable0 : (stable0 + w < (SINCOS_N >> 1) + 1 ? stable0 + w : (SINCOS_N >> 1) + 1); }
-            else { st->pil_locked = 0; st->pil_stable = w - 1 - totF; }
-        }
+        for (int i = 0; i < FB_K; i++) if (tag[i] == 0) { tag[i] = ok[i] ? c : -2; c += ok[i] ? 1 : 0; }    // index of the call within the segment
     }
 
-    SB_TICK(3);
     // ================= PSS integrator (stereo-separation.cpp:84-109, fm-processor.cpp:699-718) =================
     float used[FB_K];                                            // pilotDelayPSS as used by each sample
     {
@@ -636,10 +732,9 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_seg_kernel(DeviceTables T, Dev
         const float alpha = T.pss_alpha, la = T.pss_lock_alpha, keep = 1.0f - la;
         const float c4 = 0.785398185253143310546875f;
         const bool pss_on = stereo_possible && pss_active;
-        const float *errc = B.w_err + (size_t)ch * FB_W;
         float err[FB_K];
 #pragma unroll
-        for (int i = 0; i < FB_K; i++) err[i] = (pss_on && tag[i] >= 0) ? errc[tag[i]] : 0.f;
+        for (int i = 0; i < FB_K; i++) err[i] = (pss_on && tag[i] >= 0) ? er[tag[i]] : 0.f;
         // classification (the same for every thread)
         int firstU = -0x7fffffff - 1, firstZ = -0x7fffffff - 1, anyl = 0, alll = 0;            // as maxima of negated indices
 #pragma unroll
@@ -722,21 +817,21 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_seg_kernel(DeviceTables T, Dev
         } else {
             // replay (lock transitions inside a PSS segment, a counter within a segment of its 3 s threshold)
 #pragma unroll
-            for (int i = 0; i < FB_K; i++) if (ok[i]) { lds.pk[j0 + i] = ((tag[i] + 2) << 1) | (locked[i] ? 1 : 0); lds.er[j0 + i] = err[i]; }
+            for (int i = 0; i < FB_K; i++) if (ok[i]) { pk[j0 + i] = ((tag[i] + 2) << 1) | (locked[i] ? 1 : 0); er[j0 + i] = err[i]; }
             __syncthreads();
             if (B.dbg && tid == 0) B.dbg[(size_t)ch * DBG_SLOTS + 10] += 1;
             if (tid == 0) {
                 PssSt r = s;
                 for (int j = 0; j < w; j++) {
-                    const int p = lds.pk[j];
-                    lds.er[j] = pss_step(r, alpha, la, keep, (p & 1) != 0, (p >> 1) - 2, lds.er[j]);
+                    const int p = pk[j];
+                    er[j] = pss_step(r, alpha, la, keep, (p & 1) != 0, (p >> 1) - 2, er[j]);
                 }
                 lds.wf[0][0][3] = r.acc; lds.wf[0][1][3] = r.mean; lds.wf[0][2][3] = r.pdp;
                 lds.wi[0][0][3] = r.lock_cnt; lds.wi[0][1][3] = r.unlock_cnt; lds.wi[0][2][3] = r.minimized ? 1 : 0;
             }
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < FB_K; i++) used[i] = ok[i] ? lds.er[j0 + i] : 0.f;
+            for (int i = 0; i < FB_K; i++) used[i] = ok[i] ? er[j0 + i] : 0.f;
             e.acc = lds.wf[0][0][3]; e.mean = lds.wf[0][1][3]; e.pdp = lds.wf[0][2][3];
             e.lock_cnt = lds.wi[0][0][3]; e.unlock_cnt = lds.wi[0][1][3]; e.minimized = lds.wi[0][2][3] != 0;
             __syncthreads();
@@ -747,7 +842,7 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_seg_kernel(DeviceTables T, Dev
         }
     }
 
-    SB_TICK(4);
+    SB_TICK(1);
     // ================= 38 kHz mix, PSS input, stereo matrix (fm-processor.cpp:707-730, 517-549) =================
     float2 x[FB_K];
     {
@@ -791,12 +886,12 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_seg_kernel(DeviceTables T, Dev
             x[i] = ok[i] ? o : make_float2(0.f, 0.f);
             diffv[i] = audio.y;
         }
-        // scope taps and the RDS path's inputs: channel-major rows of this call (fmx_get_tap, rds_collect)
+        // scope tap (fmx_get_tap): channel-major rows of this call
 #pragma unroll
-        for (int i = 0; i < FB_K; i++) if (ok[i]) { B.w_dem[lrow + i] = dem[i]; B.w_diff[lrow + i] = diffv[i]; B.w_cur[lrow + i] = cur[i]; }
+        for (int i = 0; i < FB_K; i++) if (ok[i]) B.w_diff[lrow + i] = diffv[i];
     }
 
-    SB_TICK(5);
+    SB_TICK(2);
     // ================= de-emphasis (fm-processor.cpp:594-595) into the d ring =================
     {
         const float a = P.deemph_alpha;
@@ -819,7 +914,7 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_seg_kernel(DeviceTables T, Dev
         if (owner) { st->de_l = el; st->de_r = er; }
     }
 
-    SB_TICK(6);
+    SB_TICK(3);
     // ================= bookkeeping behind the segment =================
     __syncthreads();                                             // every thread has read what it needs of the channel state
     if (tid == 0) {
@@ -847,24 +942,25 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_seg_kernel(DeviceTables T, Dev
             st->pss_call_total = 0;
         }
     }
-    SB_TICK(7);
-    if (dbg_on) { B.dbg[(size_t)ch * DBG_SLOTS + 13] = __float_as_uint(st->pil_phase); B.dbg[(size_t)ch * DBG_SLOTS + 14] = __float_as_uint(st->pil_lock); }   // (diagnostics: state behind the segment)
-    if (dbg_on) for (int k = 0; k < 8; k++) B.dbg[(size_t)ch * DBG_SLOTS + 16 + k] += dbg_acc[k];
+    SB_TICK(4);
+    if (dbg_on) {
+        for (int k = 0; k < 5; k++) B.dbg[(size_t)ch * DBG_SLOTS + 20 + k] += dbg_acc[k];
+        B.dbg[(size_t)ch * DBG_SLOTS + 13] = __float_as_uint(st->pil_phase); B.dbg[(size_t)ch * DBG_SLOTS + 14] = __float_as_uint(st->pil_lock);   // (diagnostics: state behind the segment)
+    }
 }
 
-// The fused schedule: per segment, the PSS low-pass of the calls it may make, then the segment itself.
+// The fused schedule: the PLL kernel for the whole call, then per segment the PSS kernel (whose errors need the s-ring entries
+// the segment in front of it wrote).
 void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s) {
     const int64_t nj = G.J1 - G.J0;
     if (nj <= 0) return;
+    hipLaunchKernelGGL(stageb_pll_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, T, B, G, C); FMX_LAUNCHED();
     for (int64_t seg0 = 0; seg0 < nj; seg0 += FB_W) {
         SegArgs A;
         A.seg0 = (int)seg0; A.w = (int)((nj - seg0) < FB_W ? (nj - seg0) : FB_W);
         A.first = seg0 == 0 ? 1 : 0; A.last = (seg0 + FB_W >= nj) ? 1 : 0;
-        if (T.pss_hs) hipLaunchKernelGGL(pssfft_seg_kernel, dim3((unsigned)C), dim3(fftc::T), 0, s, T, B, G, C, A);
-        else hipLaunchKernelGGL(pssfir_seg_kernel, dim3((unsigned)((A.w + SF_TILE - 1) / SF_TILE), (unsigned)C), dim3(64), 0, s, T, B, G, C, A);
-        FMX_LAUNCHED();
-        hipLaunchKernelGGL(stageb_seg_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, T, B, G, C, A);
-        FMX_LAUNCHED();
+        if (!T.pss_hs) { hipLaunchKernelGGL(pssfir_seg_kernel, dim3((unsigned)((A.w + SF_TILE - 1) / SF_TILE), (unsigned)C), dim3(64), 0, s, T, B, G, C, A); FMX_LAUNCHED(); }
+        hipLaunchKernelGGL(stageb_pss_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, T, B, G, C, A); FMX_LAUNCHED();
     }
 }
 

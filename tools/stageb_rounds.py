@@ -37,6 +37,6 @@ for k in range(calls):
         v = list(out)
         print("calls %2d-%2d: PLL rounds/segment %.2f  integrator rounds/segment %.2f (of %d steady segments)  replayed %d of %d segments"
               % (k - 7, k, v[8] / max(v[11], 1), v[9] / max(v[12], 1), v[12], v[10], v[11]))
-        names = ["disc", "afc", "pll", "lock", "pss", "mix", "deemph", "tail"]
-        tot = sum(v[16:24]) or 1
+        names = ["disc", "afc", "pll", "lock", "| fft", "pss", "mix", "deemph", "tail"]
+        tot = sum(v[16:25]) or 1
         print("   thread-0 cycles per phase: " + "  ".join("%s %.1f%%" % (nm, 100.0 * v[16 + i] / tot) for i, nm in enumerate(names)) + "  | per segment %.0f cycles" % (tot / max(v[11], 1)))
