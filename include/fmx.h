@@ -200,6 +200,15 @@ int  fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info);
 int  fmx_rds_decode_bits(const uint8_t *bits, int32_t n_bits, fmx_rds_info *info);
 /* replaces rdsDecoder::doDecode's bit output (rds-decoder.cpp:69-104): pending RDS bits */
 int  fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity, int32_t *n_bits);
+/* replaces doDecode's second output (`*m`, rds-decoder-2.cpp:108-114), the constellation point every bit was decided on, which
+ * fmProcessor::run pushes into the IQ scope ring (fm-processor.cpp:555-563): pending symbols as interleaved (I, Q), oldest
+ * first, own read position.  RDS_2 only; the library keeps the last 1024. */
+int  fmx_rds_symbols(fmx_handle h, int32_t channel, float *iq, int32_t capacity, int32_t *n_symbols);
+/* fm-rate samples (inputRate / 12) the last fmx_process_* call produced per channel: the n that fmx_get_tap accepts for the
+ * fm-rate taps, and the number of entries the reference's run() pushed into its LF scope vector for the same block */
+int64_t fmx_last_fm_samples(fmx_handle h);
+/* ... and 24 kS/s RDS samples (rdsDecimator outputs, fm-processor.cpp:553): the n that fmx_get_tap accepts for FMX_TAP_RDS_IQ */
+int64_t fmx_last_rds_samples(fmx_handle h);
 
 /* introspection used by the parity tests: the filter taps the kernels run with.
  * which: 0 front-end polyphase taps, 1 PSS low-pass, 2 audio+resampler FIR, 3 resampler alone,

@@ -98,6 +98,7 @@ struct fmx_handle_s {
     bool rds_alloc = false; RdsBuffers R{}; int64_t rds_start = -1;   // fm sample index at which RDS was switched on
     std::vector<int32_t> rds_read;          // per channel: bits already handed out by fmx_rds_bits
     std::vector<int32_t> rds_read_dec;      // ... and by fmx_rds_decode
+    std::vector<int32_t> rds_read_sym;      // ... symbols handed out by fmx_rds_symbols
     std::vector<fmx::RdsGroupDecoderHost> rds_dec;
     int64_t last_m0 = 0, last_m1 = 0;       // 24 kS/s outputs of the last call
     std::vector<void *> rds_ptrs, tail_ptrs;
@@ -274,6 +275,7 @@ int ensure_rds_body(fmx_handle h) {
     R.pitch = h->pitch;
     if ((rc = dalloc((void **)&R.mf, sizeof(float2) * (size_t)(h->work_nj / 8 + 8) * h->pitch, false))) return rc;
     if ((rc = dalloc((void **)&R.bits, C * RDS_BITS_CAP, true))) return rc;
+    if ((rc = dalloc((void **)&R.sym, sizeof(float2) * C * RDS_SYM_CAP, true))) return rc;
     {   // rdsDecoder_2 / AGC / Costas constructor state (rds-decoder-2.cpp:44-78, rds-decoder.cpp:41-43)
         RdsState s0; std::memset(&s0, 0, sizeof(s0));
         s0.gain = 9.0f; s0.mu = 0.f; s0.skip = 3; s0.sample_count = 0;
@@ -1161,6 +1163,33 @@ int fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity,
     *n_bits = (take > 0 && bits) ? take : 0;
     return FMX_OK;
 }
+
+int fmx_rds_symbols(fmx_handle h, int32_t channel, float *iq, int32_t capacity, int32_t *n_symbols) {
+    if (!h || channel < 0 || channel >= h->channels || !n_symbols || capacity < 0) return fail(FMX_E_INVALID, "bad argument");
+    *n_symbols = 0;
+    if (!h->rds_alloc) return FMX_OK;
+    if ((int)h->rds_read_sym.size() != h->channels) h->rds_read_sym.assign((size_t)h->channels, 0);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    RdsState st;
+    HIPCHK(hipMemcpy(&st, h->R.state + channel, sizeof(st), hipMemcpyDeviceToHost));
+    int32_t &rd = h->rds_read_sym[(size_t)channel];
+    int32_t have = st.nbits - rd;
+    if (have < 0) { rd = 0; have = st.nbits; }                                          // the RDS path was restarted
+    if (have > RDS_SYM_CAP) { rd = st.nbits - RDS_SYM_CAP; have = RDS_SYM_CAP; }        // ring overrun: oldest symbols lost
+    const int32_t take = have < capacity ? have : capacity;
+    if (take > 0 && iq) {
+        std::vector<float2> ring((size_t)RDS_SYM_CAP);
+        HIPCHK(hipMemcpy(ring.data(), h->R.sym + (size_t)channel * RDS_SYM_CAP, sizeof(float2) * RDS_SYM_CAP, hipMemcpyDeviceToHost));
+        for (int32_t i = 0; i < take; i++) { const float2 v = ring[(size_t)((rd + i) & (RDS_SYM_CAP - 1))]; iq[2 * i] = v.x; iq[2 * i + 1] = v.y; }
+        rd += take;
+        *n_symbols = take;
+    }
+    return FMX_OK;
+}
+
+int64_t fmx_last_fm_samples(fmx_handle h) { return h ? (int64_t)(h->last_J1 - h->last_J0) : 0; }
+int64_t fmx_last_rds_samples(fmx_handle h) { return (h && h->rds_alloc) ? (int64_t)(h->last_m1 - h->last_m0) : 0; }
 
 int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {
     if (!h || channel < 0 || channel >= h->channels || !info) return fail(FMX_E_INVALID, "bad argument");

@@ -233,6 +233,7 @@ constexpr int RDS_BLK = 32000;              // overlap-add block of the two 3276
 constexpr int RDS_PHASE_RING = 131072;      // pilot-phase delay line (>= 64000 + one block + one call)
 constexpr int RDS24_RING = 8192;            // 24 kS/s decimator output ring
 constexpr int RDS_BITS_CAP = 8192;          // per-channel bit ring (>= 6 s of bits)
+constexpr int RDS_SYM_CAP = 1024;           // per-channel ring of the decided symbols (the IQ scope's constellation points)
 struct RdsState {                           // rdsDecoder_2 + AGC + Costas state (rds-decoder-2.cpp:44-78)
     float gain, mu, c_freq, c_phase, c_limit;
     int32_t sample_count, skip, prev_bit, nbits;
@@ -263,6 +264,7 @@ struct RdsBuffers {
     float2 *mf;          // [rows][pitch]   matched-filter output of the call (sample-major)
     RdsState *state;
     uint8_t *bits;       // [ch][RDS_BITS_CAP]
+    float2 *sym;         // [ch][RDS_SYM_CAP] RDS_2: the sample every bit was decided on (rds-decoder-2.cpp:108-114, `*m = r`), index = bit count
     const float2 *S_bp, *S_hil;   // [32768] filter spectra
     const float2 *dec_taps;       // [11] rdsDecimator kernel (h/sum, h)
     const float *rrc;             // [45] matched filter

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(64) void rds_slicer(DeviceBuffers B, RdsBuffers Rb,
             }
             const int bit = r.x >= 0.f ? 1 : 0;
             bits[st.nbits & (RDS_BITS_CAP - 1)] = (uint8_t)(bit ^ st.prev_bit);
+            Rb.sym[(size_t)ch * RDS_SYM_CAP + (st.nbits & (RDS_SYM_CAP - 1))] = r;      // *m = r: what the IQ scope shows (fm-processor.cpp:555-563)
             st.prev_bit = bit;
             st.nbits++;
         }

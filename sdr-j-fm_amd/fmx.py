@@ -29,7 +29,7 @@ EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
     "fmx_get_meta", "fmx_get_tap", "fmx_get_peaks",
-    "fmx_rds_bits", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
+    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_last_rds_samples", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
 
@@ -117,6 +117,12 @@ def load_library(path=None):
     L.fmx_rds_decode_bits.argtypes = [C.POINTER(C.c_uint8), i32, C.POINTER(FmxRdsInfo)]
     L.fmx_rds_bits.restype = C.c_int
     L.fmx_rds_bits.argtypes = [vp, i32, C.POINTER(C.c_uint8), i32, C.POINTER(i32)]
+    L.fmx_rds_symbols.restype = C.c_int
+    L.fmx_rds_symbols.argtypes = [vp, i32, f32p, i32, C.POINTER(i32)]
+    L.fmx_last_fm_samples.restype = C.c_int64
+    L.fmx_last_fm_samples.argtypes = [vp]
+    L.fmx_last_rds_samples.restype = C.c_int64
+    L.fmx_last_rds_samples.argtypes = [vp]
     L.fmx_get_taps.restype = C.c_int
     L.fmx_get_taps.argtypes = [vp, i32, i32, f32p, i32, C.POINTER(i32)]
     L.fmx_profile_enable.restype = C.c_int
@@ -244,6 +250,16 @@ class Fmx:
         n = C.c_int32()
         self._check(self.L.fmx_rds_bits(self.h, channel, buf, capacity, C.byref(n)))
         return np.frombuffer(buf, np.uint8, n.value).copy()
+
+    def rds_symbols(self, channel=0, capacity=1024):
+        """The constellation points the pending bits were decided on, [n, 2]."""
+        out = np.zeros((max(capacity, 1), 2), np.float32)
+        n = C.c_int32()
+        self._check(self.L.fmx_rds_symbols(self.h, channel, out.ctypes.data_as(C.POINTER(C.c_float)), capacity, C.byref(n)))
+        return out[:n.value].copy()
+
+    def last_fm_samples(self):
+        return int(self.L.fmx_last_fm_samples(self.h))
 
     def rds_decode(self, channel=0):
         """Feed the bits sliced so far into the channel's block synchroniser / group decoder; returns FmxRdsInfo."""

@@ -114,6 +114,7 @@ public:
     bool run_block() {
         if (!h || myRig->Samples() < bufferSize) return false;
         const int32_t amount = myRig->getSamples(inBuf.data(), bufferSize);
+        lastN = amount;
         int64_t frames = 0;
         if (!check(fmx_process_host(h, reinterpret_cast<const float *>(inBuf.data()), amount, amount,
                                     reinterpret_cast<float *>(outBuf.data()), (int64_t)outBuf.size(), &frames)))
@@ -149,6 +150,14 @@ public:
 
     static constexpr int32_t bufferSize = 2 * 8192;                        // fm-processor.cpp:374
 
+    // what the GUI side-band feeds of run() need (fm-processor.cpp:420-421, 555-563, 597-660): the raw block just processed
+    // and the library handle for fmx_get_tap / fmx_rds_*
+    const std::complex<float> *lastBlock() const { return inBuf.data(); }
+    int32_t lastAmount() const { return lastN; }
+    fmx_handle handle() const { return h; }
+    void set_ptyLocale(int l) { ptyLocale = l; }                            // fm-processor.cpp:939-941 (used by the adapter's PTY names)
+    int get_ptyLocale() const { return ptyLocale; }
+
 protected:
     virtual void idle() {}                                                  // the Qt build calls msleep(1) here
 
@@ -162,6 +171,8 @@ private:
     std::atomic<bool> running{false};
     std::string err;
     int64_t fmCount = 0, lastMeta = 0;
+    int32_t lastN = 0;
+    int ptyLocale = 0;
 };
 
 }  // namespace fmx_host

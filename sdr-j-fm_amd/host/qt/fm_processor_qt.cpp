@@ -1,22 +1,86 @@
 // fm_processor_qt.cpp -- see fm_processor_qt.h.  Build: moc fm_processor_qt.h -o moc_fm_processor_qt.cpp;
-//   g++ -std=c++17 -fPIC -I$QT/include/qt -I$QT/include/qt/QtCore fm_processor_qt.cpp moc_fm_processor_qt.cpp -lQt5Core -lfmx
+//   g++ -std=c++17 -fPIC -I<dir of fmx_qt_host.h> -I$QT/include/qt -I$QT/include/qt/QtCore fm_processor_qt.cpp
+//       moc_fm_processor_qt.cpp -lQt5Core -lfmx
 #include "fm_processor_qt.h"
+#include "fmx_qt_host.h"       // deviceHandler, audioSink, RadioInterface, RingBuffer<>: the GUI's own headers (see fm_processor_qt.h)
+
+#include <cmath>
+#include <cstring>
 
 namespace fmx_qt {
 
-fmProcessor::fmProcessor(DeviceHandler *theDevice, QObject *RI, AudioSink *mySink, int32_t inputRate, int32_t fmRate_,
-                         int32_t workingRate, int32_t audioRate, int32_t, int32_t spectrumSize_, int32_t repeatRate_, int gpu)
-    : core(theDevice, mySink, inputRate, fmRate_, workingRate, audioRate, gpu), fmRate(fmRate_), repeatRate(repeatRate_),
-      spectrumSize(spectrumSize_) {
-    core.owner = this;
+void (*fmProcessor::dumpWriter)(sf_private_tag *, const float *, int32_t) = nullptr;
+
+namespace {
+// the two calls run() makes on the device and the sink, on the GUI's own classes
+struct DeviceOfGui : fmx_host::DeviceHandler {
+    deviceHandler *dev;
+    explicit DeviceOfGui(deviceHandler *d) : dev(d) {}
+    int32_t Samples() override { return dev->Samples(); }
+    int32_t getSamples(std::complex<float> *dst, int32_t n) override { return dev->getSamples(dst, n, 0100 /* IandQ, fm-constants.h:86 */); }
+    int32_t getRate() override { return dev->getRate(); }
+};
+struct SinkOfGui : fmx_host::AudioSink {
+    audioSink *sink;
+    explicit SinkOfGui(audioSink *s) : sink(s) {}
+    int32_t putSamples(std::complex<float> *frames, int32_t n) override { return sink->putSamples(frames, n); }
+};
+class Core : public fmx_host::FmProcessor {
+public:
+    using fmx_host::FmProcessor::FmProcessor;
+protected:
+    void idle() override { QThread::msleep(1); }                          // fm-processor.cpp:389
+};
+}  // namespace
+
+struct fmProcessor::Impl {
+    DeviceOfGui dev;
+    SinkOfGui sink;
+    Core core;
+    RingBuffer<std::complex<float>> *hfBuffer, *lfBuffer, *iqBuffer;
+    // LF scope (fm-processor.cpp:566-627, 650-660)
+    std::vector<std::complex<float>> spectrumBuffer_lf;
+    std::vector<float> tapbuf;
+    int32_t lfCount = 0;
+    // RDS (fm-processor.cpp:555-563 and the signals of the RDS objects)
+    int iqCounter = 0;
+    fmx_rds_info last{};
+    bool haveLast = false;
+    Impl(deviceHandler *d, audioSink *s, int32_t inputRate, int32_t fmRate, int32_t workingRate, int32_t audioRate, int gpu,
+         RingBuffer<std::complex<float>> *hf, RingBuffer<std::complex<float>> *lf, RingBuffer<std::complex<float>> *iq)
+        : dev(d), sink(s), core(&dev, &sink, inputRate, fmRate, workingRate, audioRate, gpu), hfBuffer(hf), lfBuffer(lf), iqBuffer(iq) {}
+};
+
+fmProcessor::fmProcessor(deviceHandler *theDevice, RadioInterface *RI, audioSink *mySink, fm_Demodulator *, int32_t inputRate,
+                         int32_t fmRate_, int32_t workingRate, int32_t audioRate, int32_t, int spectrumSize_, int32_t repeatRate_,
+                         int ptyLocale, RingBuffer<std::complex<float>> *hfBuffer, RingBuffer<std::complex<float>> *lfBuffer,
+                         RingBuffer<std::complex<float>> *iqBuffer, int16_t, int gpu)
+    : d(new Impl(theDevice, mySink, inputRate, fmRate_, workingRate, audioRate, gpu, hfBuffer, lfBuffer, iqBuffer)), fmRate(fmRate_),
+      repeatRate(repeatRate_), spectrumSize(spectrumSize_) {
+    d->core.set_ptyLocale(ptyLocale);
     qRegisterMetaType<const fmx_qt::fmProcessor::SMetaData *>("const fmx_qt::fmProcessor::SMetaData*");
-    if (RI) {       // by name, as fm-processor.cpp:179-192 (a slot the GUI object lacks only prints Qt's warning, as there)
-        connect(this, SIGNAL(setSquelchIsActive(bool)), RI, SLOT(setSquelchIsActive(bool)));
-        connect(this, SIGNAL(hfBufferLoaded()), RI, SLOT(hfBufferLoaded()));
-        connect(this, SIGNAL(lfBufferLoaded(bool, bool, int)), RI, SLOT(lfBufferLoaded(bool, bool, int)));
-        connect(this, SIGNAL(iqBufferLoaded()), RI, SLOT(iqBufferLoaded()));
-        connect(this, SIGNAL(showPeakLevel(float, float)), RI, SLOT(showPeakLevel(float, float)));
-        connect(this, SIGNAL(showMetaData(const fmx_qt::fmProcessor::SMetaData *)), RI, SLOT(showMetaData(const fmx_qt::fmProcessor::SMetaData *)));
+    QObject *gui = RI;
+    if (gui) {      // by name, as the reference's constructors do (a slot the GUI object lacks only prints Qt's warning, as there)
+        connect(this, SIGNAL(setSquelchIsActive(bool)), gui, SLOT(setSquelchIsActive(bool)));
+        connect(this, SIGNAL(hfBufferLoaded()), gui, SLOT(hfBufferLoaded()));
+        connect(this, SIGNAL(lfBufferLoaded(bool, bool, int)), gui, SLOT(lfBufferLoaded(bool, bool, int)));
+        connect(this, SIGNAL(iqBufferLoaded()), gui, SLOT(iqBufferLoaded()));
+        connect(this, SIGNAL(showPeakLevel(float, float)), gui, SLOT(showPeakLevel(float, float)));
+        connect(this, SIGNAL(showMetaData(const fmx_qt::fmProcessor::SMetaData *)), gui, SLOT(showMetaData(const fmx_qt::fmProcessor::SMetaData *)));
+        connect(this, SIGNAL(scanresult()), gui, SLOT(scanresult()));
+        connect(this, SIGNAL(setCRCErrors(int)), gui, SLOT(setCRCErrors(int)));
+        connect(this, SIGNAL(setSyncErrors(int)), gui, SLOT(setSyncErrors(int)));
+        connect(this, SIGNAL(setGroup(int)), gui, SLOT(setGroup(int)));
+        connect(this, SIGNAL(setPTYCode(int, const QString &)), gui, SLOT(setPTYCode(int, const QString &)));
+        connect(this, SIGNAL(setPiCode(int)), gui, SLOT(setPiCode(int)));
+        connect(this, SIGNAL(setStationLabel(const QString &)), gui, SLOT(setStationLabel(const QString &)));
+        connect(this, SIGNAL(setRadioText(const QString &)), gui, SLOT(setRadioText(const QString &)));
+        connect(this, SIGNAL(clearRadioText()), gui, SLOT(clearRadioText()));
+        connect(this, SIGNAL(setAFDisplay(int, int)), gui, SLOT(setAFDisplay(int, int)));
+        connect(this, SIGNAL(setMusicSpeechFlag(int)), gui, SLOT(setMusicSpeechFlag(int)));
+        connect(this, SIGNAL(clearMusicSpeechFlag()), gui, SLOT(clearMusicSpeechFlag()));
+        connect(this, SIGNAL(setRDSisSynchronized(bool)), gui, SLOT(setRDSisSynchronized(bool)));
+        connect(this, SIGNAL(setbitErrorRate(double)), gui, SLOT(setbitErrorRate(double)));
     }
 }
 
@@ -29,26 +93,200 @@ void fmProcessor::stop() {                             // fm-processor.cpp:204-2
     }
 }
 
+bool fmProcessor::ok() const { return d->core.ok(); }
+std::string fmProcessor::lastError() const { return d->core.lastError(); }
+
+void fmProcessor::setfmMode(FM_Mode m) { d->core.setfmMode(m); }
+void fmProcessor::setFMdecoder(const QString &name) { d->core.setFMdecoder(name.toStdString()); }
+void fmProcessor::setSoundMode(uint8_t selector) { d->core.setSoundMode(selector); }
+void fmProcessor::setStereoPanorama(int16_t pan) { d->core.setStereoPanorama(pan); }
+void fmProcessor::setSoundBalance(int16_t balance) { d->core.setSoundBalance(balance); }
+void fmProcessor::setDeemphasis(float us) { d->core.setDeemphasis((int16_t)us); }
+void fmProcessor::setVolume(float gainDb) { d->core.setVolume(gainDb); }
+void fmProcessor::setlfcutoff(int32_t hz) { d->core.setlfcutoff(hz); }
+void fmProcessor::setBandwidth(const QString &f) { d->core.setBandwidth(f.toStdString()); }
+void fmProcessor::setAttenuation(float l, float r) { d->core.setAttenuation(l, r); }
+void fmProcessor::setfmRdsSelector(int mode) { rdsMode.store(mode); d->core.setfmRdsSelector(mode); }
+void fmProcessor::triggerFrequencyChange() { d->core.triggerFrequencyChange(); }
+void fmProcessor::restartPssAnalyzer() { d->core.restartPssAnalyzer(); }
+void fmProcessor::resetRds() { d->core.resetRds(); }
+void fmProcessor::set_localOscillator(int32_t lo) { d->core.set_localOscillator(lo); }
+void fmProcessor::set_squelchMode(ESqMode m) { d->core.set_squelchMode((int)m); }
+void fmProcessor::set_squelchValue(int16_t v) { d->core.set_squelchValue(v); }
+void fmProcessor::setAutoMonoMode(bool b) { d->core.setAutoMonoMode(b); }
+void fmProcessor::setPSSMode(bool b) { d->core.setPSSMode(b); }
+void fmProcessor::setDCRemove(bool b) { d->core.setDCRemove(b); }
+void fmProcessor::setTestTone(bool b) { d->core.setTestTone(b); }
+void fmProcessor::setDispDelay(int steps) { d->core.setDispDelay(steps); }
+void fmProcessor::set_ptyLocale(int l) { d->core.set_ptyLocale(l); }
+bool fmProcessor::isPilotLocked(float &oLockStrength) { return d->core.isPilotLocked(oLockStrength); }
+float fmProcessor::get_demodDcComponent() { return d->core.get_demodDcComponent(); }
+
+// ---- LF scope: one entry per fm sample (per 24 kS/s RDS sample for the two RDS views) into spectrumBuffer_lf; every
+//      fmRate / repeatRate + 1 fm samples the first spectrumSize entries go to the LF ring (fm-processor.cpp:566-627, 650-660, 906-912)
+void fmProcessor::feed_lf_scope() {
+    Impl &I = *d;
+    fmx_handle h = I.core.handle();
+    const int64_t nfm = fmx_last_fm_samples(h);
+    if (nfm <= 0) return;
+    const ELfPlot type = (ELfPlot)lfPlot.load();
+    const bool rdsView = (type == ELfPlot::RDS_INPUT || type == ELfPlot::RDS_DEMOD);
+    std::vector<std::complex<float>> fresh;               // this block's entries, in order
+    if (type == ELfPlot::OFF) fresh.assign((size_t)nfm, std::complex<float>(0, 0));
+    else if (!rdsView) {
+        int tap = FMX_TAP_PRE_RESAMPLER, per = 2;
+        if (type == ELfPlot::IF_FILTERED) tap = FMX_TAP_FM_IQ;
+        else if (type == ELfPlot::DEMODULATOR) { tap = FMX_TAP_DEMOD; per = 1; }
+        else if (type == ELfPlot::AF_SUM || type == ELfPlot::AF_DIFF) tap = FMX_TAP_LR_RAW;
+        I.tapbuf.resize((size_t)(nfm * per));
+        if (fmx_get_tap(h, 0, tap, I.tapbuf.data(), nfm) != FMX_OK) return;
+        fresh.resize((size_t)nfm);
+        for (int64_t k = 0; k < nfm; k++) {
+            const float a = I.tapbuf[(size_t)(per * k)], b = per == 2 ? I.tapbuf[(size_t)(2 * k + 1)] : 0.f;
+            switch (type) {
+            case ELfPlot::IF_FILTERED: fresh[(size_t)k] = std::complex<float>(a, b); break;              // v
+            case ELfPlot::DEMODULATOR: fresh[(size_t)k] = std::complex<float>(a, 0); break;              // demod
+            case ELfPlot::AF_SUM: fresh[(size_t)k] = std::complex<float>(a, 0); break;                   // sumLR
+            case ELfPlot::AF_DIFF: fresh[(size_t)k] = std::complex<float>(b, 0); break;                  // diffLR
+            case ELfPlot::AF_MONO_FILTERED: fresh[(size_t)k] = std::complex<float>(a + b, 0); break;     // audio (this build: in front of the audio low-pass)
+            case ELfPlot::AF_LEFT_FILTERED: fresh[(size_t)k] = std::complex<float>(a, 0); break;
+            default: fresh[(size_t)k] = std::complex<float>(b, 0); break;                                // AF_RIGHT_FILTERED
+            }
+        }
+    }
+    // RDS views: an entry per rdsDecimator output (RDS on) or a zero per fm sample (RDS off), :566-589
+    std::vector<std::complex<float>> rdsv;
+    int64_t nrds = 0;
+    if (rdsView && rdsMode.load() != 0) {
+        nrds = fmx_last_rds_samples(h);
+        if (nrds > 0) {
+            I.tapbuf.resize((size_t)(2 * nrds));
+            if (fmx_get_tap(h, 0, FMX_TAP_RDS_IQ, I.tapbuf.data(), nrds) != FMX_OK) nrds = 0;
+        }
+        rdsv.resize((size_t)nrds);
+        // RDS_INPUT: 20 rdsSample.  RDS_DEMOD shows the decoder's symbol (`magCplx`, which only changes once per bit): the same
+        // decimator output stands in between the decisions; the decided symbols themselves go to the IQ ring (feed_rds)
+        for (int64_t k = 0; k < nrds; k++) rdsv[(size_t)k] = (type == ELfPlot::RDS_INPUT ? 20.0f : 1.0f) * std::complex<float>(I.tapbuf[(size_t)(2 * k)], I.tapbuf[(size_t)(2 * k + 1)]);
+    } else if (rdsView) fresh.assign((size_t)nfm, std::complex<float>(0, 0));
+    // the reference's counters, sample by sample
+    int64_t rdsPushed = 0;
+    for (int64_t k = 0; k < nfm; k++) {
+        if (rdsView && rdsMode.load() != 0) {
+            // the decimator delivers one output per eight fm samples: spread this block's outputs evenly over it
+            const int64_t due = ((k + 1) * nrds) / nfm;
+            while (rdsPushed < due) I.spectrumBuffer_lf.push_back(rdsv[(size_t)rdsPushed++]);
+        } else I.spectrumBuffer_lf.push_back(fresh[(size_t)k]);
+        if (++I.lfCount > fmRate / repeatRate) {
+            if (I.spectrumBuffer_lf.size() >= (size_t)spectrumSize) {
+                if (I.lfBuffer) I.lfBuffer->putDataIntoBuffer(I.spectrumBuffer_lf.data(), spectrumSize);       // processLfSpectrum :906-912
+                emit lfBufferLoaded(showFullSpectrum.load(), lfBuffer_newFlag.load(), zoomFactor.load());
+                lfBuffer_newFlag.store(false);
+                I.spectrumBuffer_lf.resize(0);
+            }
+            I.lfCount = 0;
+        }
+    }
+}
+
+// ---- RDS: the decided symbols into the IQ ring (fm-processor.cpp:555-563), the text / status signals of rdsDecoder,
+//      rdsGroupDecoder and rdsBlockSynchronizer from the differences of the library's picture
+void fmProcessor::feed_rds() {
+    Impl &I = *d;
+    fmx_handle h = I.core.handle();
+    if (rdsMode.load() == 0) return;
+    float sym[2 * 64]; int32_t n = 0;
+    while (fmx_rds_symbols(h, 0, sym, 64, &n) == FMX_OK && n > 0) {
+        for (int32_t k = 0; k < n; k++) {
+            const std::complex<float> m(sym[2 * k], sym[2 * k + 1]);
+            if (I.iqBuffer) I.iqBuffer->putDataIntoBuffer(&m, 1);
+            if (++I.iqCounter > 100) { emit iqBufferLoaded(); I.iqCounter = 0; }
+        }
+        if (n < 64) break;
+    }
+    fmx_rds_info now{};
+    if (fmx_rds_decode(h, 0, &now) != FMX_OK) return;
+    const fmx_rds_info &was = I.last;
+    const bool first = !I.haveLast;
+    if (first || now.synchronized != was.synchronized) emit setRDSisSynchronized(now.synchronized != 0);          // rds-blocksynchronizer.cpp
+    if (first || now.bit_error_rate != was.bit_error_rate) emit setbitErrorRate((double)now.bit_error_rate);
+    if (first || now.crc_errors != was.crc_errors) emit setCRCErrors(now.crc_errors);                              // rds-decoder.cpp:116-121
+    if (first || now.sync_errors != was.sync_errors) emit setSyncErrors(now.sync_errors);
+    if (now.groups_decoded != (first ? 0 : was.groups_decoded) && now.last_group_type >= 0) emit setGroup(now.last_group_type);
+    if (now.pi_code != (first ? 0 : was.pi_code)) emit setPiCode(now.pi_code);                                     // rds-groupdecoder.cpp:100-125
+    if (now.pty_code >= 0 && (first || now.pty_code != was.pty_code)) emit setPTYCode(now.pty_code, pty_name(now.pty_code, I.core.get_ptyLocale()));
+    if (first || std::memcmp(now.station_label, was.station_label, sizeof(now.station_label)) != 0)
+        if (now.station_label[0]) emit setStationLabel(ebu_latin_to_qstring(now.station_label));
+    if (first || std::strcmp(now.radio_text, was.radio_text) != 0) {
+        if (now.radio_text[0]) emit setRadioText(ebu_latin_to_qstring(now.radio_text));
+        else if (!first) emit clearRadioText();
+    }
+    if ((now.af1_khz || now.af2_khz) && (first || now.af1_khz != was.af1_khz || now.af2_khz != was.af2_khz)) emit setAFDisplay(now.af1_khz, now.af2_khz);
+    if (first || now.music_speech != was.music_speech) {
+        if (now.music_speech >= 0) emit setMusicSpeechFlag(now.music_speech);
+        else if (!first) emit clearMusicSpeechFlag();
+    }
+    I.last = now; I.haveLast = true;
+}
+
 void fmProcessor::run() {
+    Impl &I = *d;
     running.store(true);
-    int64_t fm = 0, lastLf = 0;
     bool lastSquelch = false, first = true;
     while (running.load()) {
-        if (!core.run_block()) { QThread::msleep(1); continue; }          // fewer than 16384 samples waiting (:388-391)
-        emit hfBufferLoaded();                                             // the raw block went to the HF scope ring (:420-421)
-        core.poll_peaks([this](float l, float r) { emit showPeakLevel(l, r); });   // :645, 772-798
-        fm += fmx_host::FmProcessor::bufferSize / 12;
-        if (fm - lastLf > fmRate / repeatRate) {                           // LF scope (:650-660)
-            emit lfBufferLoaded(false, false, zoomFactor.load());
-            lastLf = fm;
-        }
-        if (core.poll_meta(metaData)) {                                    // every fmRate / 2 samples (:662-684)
+        if (!I.core.run_block()) { QThread::msleep(1); continue; }        // fewer than 16384 samples waiting (:388-391)
+        const int32_t amount = I.core.lastAmount();
+        if (I.hfBuffer) I.hfBuffer->putDataIntoBuffer(I.core.lastBlock(), amount);          // :420
+        emit hfBufferLoaded();                                                              // :421
+        if (sf_private_tag *f = dumpFile.load()) if (dumpWriter) dumpWriter(f, reinterpret_cast<const float *>(I.core.lastBlock()), amount);   // :448-455
+        feed_rds();
+        feed_lf_scope();
+        I.core.poll_peaks([this](float l, float r) { emit showPeakLevel(l, r); });          // :645, 772-798
+        if (I.core.poll_meta(metaData)) {                                                   // every fmRate / 2 samples (:662-684)
             emit showMetaData(&metaData);
-            const bool sq = core.getSquelchState();
+            const bool sq = I.core.getSquelchState();
             if (first || sq != lastSquelch) { emit setSquelchIsActive(sq); lastSquelch = sq; first = false; }   // squelchClass.cpp:74-77
             squelchState.store(sq);
         }
     }
+}
+
+// ---- RDS character set and programme type names ------------------------------------------------------------------
+QString ebu_latin_to_qstring(const char *s) {
+    // EN 50067 annex E, table E.1, codes 0x80 .. 0xFF (0x20 .. 0x7D are ISO 646 apart from the four listed below)
+    static const char16_t hi[128] = {
+        u'á', u'à', u'é', u'è', u'í', u'ì', u'ó', u'ò', u'ú', u'ù', u'Ñ', u'Ç', u'Ş', u'ß', u'¡', u'Ĳ',
+        u'â', u'ä', u'ê', u'ë', u'î', u'ï', u'ô', u'ö', u'û', u'ü', u'ñ', u'ç', u'ş', u'ǧ', u'ı', u'ĳ',
+        u'ª', u'α', u'©', u'‰', u'Ǧ', u'ě', u'ň', u'ő', u'π', u'€', u'£', u'$', u'←', u'↑', u'→', u'↓',
+        u'º', u'¹', u'²', u'³', u'±', u'İ', u'ń', u'ű', u'µ', u'¿', u'÷', u'°', u'¼', u'½', u'¾', u'§',
+        u'Á', u'À', u'É', u'È', u'Í', u'Ì', u'Ó', u'Ò', u'Ú', u'Ù', u'Ř', u'Č', u'Š', u'Ž', u'Ð', u'Ŀ',
+        u'Â', u'Ä', u'Ê', u'Ë', u'Î', u'Ï', u'Ô', u'Ö', u'Û', u'Ü', u'ř', u'č', u'š', u'ž', u'đ', u'ŀ',
+        u'Ã', u'Å', u'Æ', u'Œ', u'ŷ', u'Ý', u'Õ', u'Ø', u'Þ', u'Ŋ', u'Ŕ', u'Ć', u'Ś', u'Ź', u'Ŧ', u'ð',
+        u'ã', u'å', u'æ', u'œ', u'ŵ', u'ý', u'õ', u'ø', u'þ', u'ŋ', u'ŕ', u'ć', u'ś', u'ź', u'ŧ', u' ' };
+    QString out;
+    for (const unsigned char *p = reinterpret_cast<const unsigned char *>(s); *p; p++) {
+        const unsigned char c = *p;
+        if (c >= 0x80) out.append(QChar(hi[c - 0x80]));
+        else if (c == 0x24) out.append(QChar(0x00a4));      // currency sign
+        else if (c == 0x5e) out.append(QChar(0x2015));      // horizontal bar
+        else if (c == 0x60) out.append(QChar(0x2016));      // double vertical line
+        else if (c == 0x7e) out.append(QChar(0x00af));      // macron
+        else if (c < 0x20) out.append(QChar(' '));
+        else out.append(QChar(c));
+    }
+    return out;
+}
+
+QString pty_name(int pty, int ptyLocale) {
+    static const char *eu[32] = { "None", "News", "Current Affairs", "Information", "Sport", "Education", "Drama", "Culture", "Science",
+        "Varied", "Pop Music", "Rock Music", "Easy Listening", "Light Classical", "Serious Classical", "Other Music", "Weather", "Finance",
+        "Children's Programmes", "Social Affairs", "Religion", "Phone In", "Travel", "Leisure", "Jazz Music", "Country Music",
+        "National Music", "Oldies Music", "Folk Music", "Documentary", "Alarm Test", "Alarm" };
+    static const char *us[32] = { "None", "News", "Information", "Sports", "Talk", "Rock", "Classic Rock", "Adult Hits", "Soft Rock", "Top 40",
+        "Country", "Oldies", "Soft", "Nostalgia", "Jazz", "Classical", "Rhythm and Blues", "Soft Rhythm and Blues", "Foreign Language",
+        "Religious Music", "Religious Talk", "Personality", "Public", "College", "Spanish Talk", "Spanish Music", "Hip Hop", "Unassigned",
+        "Unassigned", "Weather", "Emergency Test", "Emergency" };
+    if (pty < 0 || pty > 31) return QString();
+    return QString::fromLatin1(ptyLocale == 1 ? us[pty] : eu[pty]);
 }
 
 }  // namespace fmx_qt
