@@ -1097,6 +1097,57 @@ static int rds3_decode(rds3 *r, c32 z, c32 *m, uint8_t *d) {
 
 typedef struct { float *buf; long cap, n; } tapbuf;
 
+/* ---- squelch (squelchClass.cpp): the object fmProcessor calls per demodulated sample ------------------------------ */
+void fmo_squelch_set_level(fmo_squelch *q, int n) {                      /* squelchClass.cpp:33-37 */
+    q->levelThr = powf(10.0f, (n - 80) / 30.0f);
+    q->noiseThr = 1.0f - n / 100.0f;
+}
+void fmo_squelch_init(fmo_squelch *q, int32_t threshold, int32_t keyFrequency, int32_t bufsize, int32_t sampleRate) {   /* :11-31 */
+    fmo_iir_highpass(&q->high, 20, keyFrequency - 100, sampleRate, FMO_IIR_CHEBYSHEV);
+    fmo_iir_lowpass(&q->low, 20, keyFrequency, sampleRate, FMO_IIR_CHEBYSHEV);
+    fmo_squelch_set_level(q, threshold);
+    q->hold = bufsize; q->rate = sampleRate; q->suppress = 0; q->count = 0; q->avgHigh = 0; q->avgLow = 0;
+}
+static float sq_decaying_average(float old, float input, float weight) {  /* :40-45: the arithmetic is double (1.0 / weight) */
+    if (weight <= 1) return input;
+    return (float)(input * (1.0 / weight) + old * (1.0 - (1.0 / weight)));
+}
+float fmo_squelch_noise(fmo_squelch *q, float soundSample) {             /* do_noise_squelch :47-87 */
+    const float val_1 = fabsf(fmo_iir_pass(&q->high, soundSample));
+    const float val_2 = fabsf(fmo_iir_pass(&q->low, soundSample));
+    q->avgHigh = sq_decaying_average(q->avgHigh, val_1, (float)(q->rate / 100));
+    q->avgLow = sq_decaying_average(q->avgLow, val_2, (float)(q->rate / 100));
+    if (++q->count >= q->hold) {
+        q->count = 0;
+        if (q->noiseThr < 0.001f) q->suppress = 1;                                        /* SQUELCH_HYSTERESIS_NSQ */
+        else if (q->avgHigh < q->avgLow * q->noiseThr - 0.001f) q->suppress = 0;
+        else if (q->avgHigh >= q->avgLow * q->noiseThr + 0.001f) q->suppress = 1;
+    }
+    return q->suppress ? soundSample * 0.000f : soundSample;                              /* LEVELREDUCTIONFACTOR */
+}
+float fmo_squelch_level(fmo_squelch *q, float soundSample, float carrierLevel) {          /* do_level_squelch :89-113 */
+    if (++q->count >= q->hold) {
+        q->count = 0;
+        if (carrierLevel < q->levelThr - 0.000f) q->suppress = 1;                         /* SQUELCH_HYSTERESIS_LSQ */
+        else if (carrierLevel >= q->levelThr + 0.000f) q->suppress = 0;
+    }
+    return q->suppress ? soundSample * 0.000f : soundSample;
+}
+fmo_squelch *fmo_squelch_new(int32_t threshold, int32_t keyFrequency, int32_t bufsize, int32_t sampleRate) {
+    fmo_squelch *q = (fmo_squelch *)calloc(1, sizeof(fmo_squelch));
+    fmo_squelch_init(q, threshold, keyFrequency, bufsize, sampleRate);
+    return q;
+}
+void fmo_squelch_free(fmo_squelch *q) { free(q); }
+int fmo_squelch_active(const fmo_squelch *q) { return q->suppress; }
+/* n samples through do_noise_squelch (carrier == NULL) or do_level_squelch; flags[i] = getSquelchActive() after sample i */
+void fmo_squelch_run(fmo_squelch *q, const float *in, const float *carrier, float *out, uint8_t *flags, long n) {
+    for (long i = 0; i < n; i++) {
+        out[i] = carrier ? fmo_squelch_level(q, in[i], carrier[i]) : fmo_squelch_noise(q, in[i]);
+        if (flags) flags[i] = (uint8_t)q->suppress;
+    }
+}
+
 struct fmo_chain {
     fmo_config cfg;           /* live settings */
     /* members of fmProcessor (fm-processor.h:157-280) */
@@ -1108,9 +1159,7 @@ struct fmo_chain {
     fmo_pilot *pilot; fmo_pss *pss;
     fmo_demod *demod;
     float *rdsPhaseBuffer; int rdsPhaseIndex;
-    /* squelch (level squelch only) squelchClass.cpp:12-29 */
-    float sqLevelThr; int sqCount, sqHold, sqSuppress, sqOldValue;
-    float sqNoiseThr, sqAvgHigh, sqAvgLow; fmo_iir sqHigh, sqLow;       /* noise squelch squelchClass.cpp:11-31 */
+    fmo_squelch sq; int sqOldValue;                                      /* mySquelch, oldSquelchValue (fm-processor.cpp:87,195) */
     int newAudioFilter, inputFilterOn, newInputFilter, audioFilterActive;
     int32_t lowPassFrequency, fmBandwidth;
     float Lgain, Rgain, pilotDelayPSS, deemphAlpha, volumeFactor, panorama, leftChannel, rightChannel;
@@ -1225,10 +1274,7 @@ fmo_chain *fmo_chain_new(const fmo_config *c) {
     ch->pending = (c32 *)malloc(sizeof(c32) * BLOCK);
     ch->meta.peakLeftDb = ch->meta.peakRightDb = -40.0f;
     /* mySquelch (1, 70000, fmRate / 20, fmRate) fm-processor.cpp:87; squelchValue = oldSquelchValue = 0 :194-195 */
-    ch->sqLevelThr = powf(10.0f, (1 - 80) / 30.0f); ch->sqHold = ch->cfg.fmRate / 20; ch->sqCount = 0; ch->sqSuppress = 0; ch->sqOldValue = 0;
-    /* squelchHighpass (20, keyFrequency - 100, sampleRate, S_CHEBYSHEV), squelchLowpass (20, keyFrequency, ...) with keyFrequency 70000 */
-    ch->sqNoiseThr = 1.0f - 1 / 100.0f; ch->sqAvgHigh = 0; ch->sqAvgLow = 0;
-    fmo_iir_highpass(&ch->sqHigh, 20, 70000 - 100, ch->cfg.fmRate, FMO_IIR_CHEBYSHEV); fmo_iir_lowpass(&ch->sqLow, 20, 70000, ch->cfg.fmRate, FMO_IIR_CHEBYSHEV);
+    fmo_squelch_init(&ch->sq, 1, 70000, ch->cfg.fmRate / 20, ch->cfg.fmRate); ch->sqOldValue = 0;
     apply_settings(ch, c, 1);
     return ch;
 }
@@ -1368,8 +1414,7 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
         ch->audioFilterActive = 1; ch->newAudioFilter = 0;
     }
     if (ch->cfg.squelchValue != ch->sqOldValue) {           /* fm-processor.cpp:410-413 */
-        ch->sqLevelThr = powf(10.0f, (ch->cfg.squelchValue - 80) / 30.0f);      /* setSquelchLevel squelchClass.cpp:33-37 */
-        ch->sqNoiseThr = 1.0f - ch->cfg.squelchValue / 100.0f;
+        fmo_squelch_set_level(&ch->sq, ch->cfg.squelchValue);
         ch->sqOldValue = ch->cfg.squelchValue;
     }
     if (ch->cfg.dcRemove) {
@@ -1397,32 +1442,8 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
         }
         tap2(ch, FMO_TAP_FM_IQ, v);
         float demod = fmo_demod_demodulate(ch->demod, v);
-        if (ch->cfg.squelchMode == 2) {
-            /* squelch::do_level_squelch squelchClass.cpp:89-113 (hysteresis 0, LEVELREDUCTIONFACTOR 0, holdPeriod fmRate/20) */
-            if (++ch->sqCount >= ch->sqHold) {
-                ch->sqCount = 0;
-                const float carrier = fmo_demod_carrier(ch->demod);
-                if (carrier < ch->sqLevelThr - 0.000f) ch->sqSuppress = 1;
-                else if (carrier >= ch->sqLevelThr + 0.000f) ch->sqSuppress = 0;
-            }
-            demod = ch->sqSuppress ? demod * 0.000f : demod;
-        }
-        if (ch->cfg.squelchMode == 1) {
-            /* squelch::do_noise_squelch squelchClass.cpp:47-87: the demodulated signal above / below 70 kHz through two
-             * order-20 Chebyshev filters, decaying averages over sampleRate / 100 samples (in double, decayingAverage :40-45) */
-            const float val_1 = fabsf(fmo_iir_pass(&ch->sqHigh, demod));
-            const float val_2 = fabsf(fmo_iir_pass(&ch->sqLow, demod));
-            const float weight = (float)(ch->cfg.fmRate / 100);
-            ch->sqAvgHigh = (float)(val_1 * (1.0 / weight) + ch->sqAvgHigh * (1.0 - (1.0 / weight)));
-            ch->sqAvgLow = (float)(val_2 * (1.0 / weight) + ch->sqAvgLow * (1.0 - (1.0 / weight)));
-            if (++ch->sqCount >= ch->sqHold) {
-                ch->sqCount = 0;
-                if (ch->sqNoiseThr < 0.001f) ch->sqSuppress = 1;
-                else if (ch->sqAvgHigh < ch->sqAvgLow * ch->sqNoiseThr - 0.001f) ch->sqSuppress = 0;
-                else if (ch->sqAvgHigh >= ch->sqAvgLow * ch->sqNoiseThr + 0.001f) ch->sqSuppress = 1;
-            }
-            demod = ch->sqSuppress ? demod * 0.000f : demod;
-        }
+        if (ch->cfg.squelchMode == 1) demod = fmo_squelch_noise(&ch->sq, demod);                                   /* fm-processor.cpp:499-509 */
+        else if (ch->cfg.squelchMode == 2) demod = fmo_squelch_level(&ch->sq, demod, fmo_demod_carrier(ch->demod));
         tap1(ch, FMO_TAP_DEMOD, demod);
         c32 audio, rdsData = C(0, 0);
         process_signal_with_rds(ch, demod, &audio, &rdsData);
@@ -1519,7 +1540,7 @@ long fmo_chain_process(fmo_chain *ch, const float *iq, long n, float *pcm, long 
 
 void fmo_chain_meta(const fmo_chain *ch, fmo_meta *m) {
     *m = ch->meta; m->fmSamples = ch->fmCount; m->pcmFrames = ch->pcmCount;
-    m->squelchActive = ch->sqSuppress; m->pad_ = 0;
+    m->squelchActive = ch->sq.suppress; m->pad_ = 0;
 }
 long fmo_chain_peaks(const fmo_chain *ch, float *lr_db, long cap) {
     long n = ch->peakEvN < cap ? ch->peakEvN : cap;

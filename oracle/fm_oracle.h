@@ -144,6 +144,16 @@ void  fmo_bsync_run(const uint8_t *bits, long n, int32_t *sync_errors, int32_t *
 /* rdsDecoder_1's constants as the kernels hold them: rdsFilter taps [21], Match kernel [43], sharpFilter [8][A1 A2 B1 B2], gain */
 void  fmo_rds1_coeffs(float *out);
 /* test helpers with the signatures of ref_iir_* (kind 0 low-pass, 1 high-pass, 2 band-pass) */
+/* squelch (squelchClass.cpp:11-113): state + the calls fmProcessor makes (fm-processor.cpp:87, 410-413, 499-509) */
+typedef struct { float noiseThr, levelThr, avgHigh, avgLow; int32_t hold, rate, count, suppress; fmo_iir high, low; } fmo_squelch;
+void  fmo_squelch_init(fmo_squelch *q, int32_t threshold, int32_t keyFrequency, int32_t bufsize, int32_t sampleRate);
+void  fmo_squelch_set_level(fmo_squelch *q, int n);
+float fmo_squelch_noise(fmo_squelch *q, float soundSample);
+float fmo_squelch_level(fmo_squelch *q, float soundSample, float carrierLevel);
+fmo_squelch *fmo_squelch_new(int32_t threshold, int32_t keyFrequency, int32_t bufsize, int32_t sampleRate);
+void  fmo_squelch_free(fmo_squelch *q);
+int   fmo_squelch_active(const fmo_squelch *q);
+void  fmo_squelch_run(fmo_squelch *q, const float *in, const float *carrier, float *out, uint8_t *flags, long n);
 void *fmo_iir_new(int kind, int order, int32_t f1, int32_t f2, int32_t fs, int ftype);
 void  fmo_iir_free(void *);
 int   fmo_iir_coeffs(void *, float *out);

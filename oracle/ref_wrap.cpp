@@ -37,6 +37,7 @@
 #include "iir-filters.h"
 #ifdef FMREF_WITH_QT
 #include "fm-demodulator.h"
+#include "squelchClass.h"       // QObject + moc (oracle/Makefile runs the image's moc on the reference's header, output in _ref/)
 #endif
 
 typedef std::complex<float> cf;
@@ -331,4 +332,39 @@ void ref_iir_run(void *p, const float *in, long n, float *out) {
     Basic_IIR *f = (Basic_IIR *)p;
     for (long i = 0; i < n; i++) out[i] = f->Pass(in[i]);
 }
+// ---- squelch (src/various/squelchClass.cpp): the reference's own object, sample by sample ----
+void *ref_squelch_new(int32_t threshold, int32_t keyFrequency, int32_t bufsize, int32_t sampleRate) {
+#ifdef FMREF_WITH_QT
+    return new squelch(threshold, keyFrequency, bufsize, sampleRate);
+#else
+    (void)threshold; (void)keyFrequency; (void)bufsize; (void)sampleRate; return nullptr;
+#endif
+}
+void ref_squelch_free(void *p) {
+#ifdef FMREF_WITH_QT
+    delete (squelch *)p;
+#else
+    (void)p;
+#endif
+}
+void ref_squelch_set_level(void *p, int n) {
+#ifdef FMREF_WITH_QT
+    ((squelch *)p)->setSquelchLevel(n);
+#else
+    (void)p; (void)n;
+#endif
+}
+// n samples through do_noise_squelch (carrier == NULL) or do_level_squelch; flags[i] = getSquelchActive() after sample i
+void ref_squelch_run(void *p, const float *in, const float *carrier, float *out, uint8_t *flags, long n) {
+#ifdef FMREF_WITH_QT
+    squelch *q = (squelch *)p;
+    for (long i = 0; i < n; i++) {
+        out[i] = carrier ? q->do_level_squelch(in[i], carrier[i]) : q->do_noise_squelch(in[i]);
+        if (flags) flags[i] = q->getSquelchActive() ? 1 : 0;
+    }
+#else
+    (void)p; (void)in; (void)carrier; (void)out; (void)flags; (void)n;
+#endif
+}
+
 }  // extern "C"

@@ -98,6 +98,10 @@ def oracle():
         "fmo_decim_new": (vp, [C.c_int, i32, i32, C.c_int]),
         "fmo_decim_free": (None, [vp]),
         "fmo_decim_run": (lng, [vp, c_float_p, lng, c_float_p]),
+        "fmo_squelch_new": (vp, [i32, i32, i32, i32]),
+        "fmo_squelch_free": (None, [vp]),
+        "fmo_squelch_set_level": (None, [vp, C.c_int]),
+        "fmo_squelch_run": (None, [vp, c_float_p, c_float_p, c_float_p, C.POINTER(C.c_uint8), lng]),
         "fmo_sincos_new": (vp, [i32]),
         "fmo_sincos_free": (None, [vp]),
         "fmo_sincos_sin": (f32, [vp, f32]),
@@ -232,6 +236,10 @@ def ref():
         fn.restype = res
         fn.argtypes = args
     if L.ref_has_qt():
+        for name, (res, args) in {"ref_squelch_new": (vp, [i32, i32, i32, i32]), "ref_squelch_free": (None, [vp]),
+                                  "ref_squelch_set_level": (None, [vp, C.c_int]),
+                                  "ref_squelch_run": (None, [vp, c_float_p, c_float_p, c_float_p, C.POINTER(C.c_uint8), lng])}.items():
+            fn = getattr(L, name); fn.restype = res; fn.argtypes = args
         L.ref_demod_run.restype = None
         L.ref_demod_run.argtypes = [i32, C.c_int, c_float_p, lng, c_float_p, c_float_p, c_float_p, c_float_p]
     _ref = L

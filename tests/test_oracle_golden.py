@@ -205,3 +205,30 @@ def test_recursive_filters():
         O.fmo_iir_free(f)
         assert_bitexact(c[:6 * nq + 1], GI[name + "_coef"], name + " coefficients")
         assert_bitexact(y, GI[name + "_out"], name + " response")
+
+
+@pytest.mark.parametrize("mode", ["noise", "level"])
+def test_squelch_object(mode):
+    """squelch (squelchClass.cpp:11-113): getSquelchActive() transitions and the output of the reference's own object
+    (tests/golden/ref_squelch.npz, made from the moc'ed class by make_golden.py) reproduced by the oracle, bit for bit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    GS = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_squelch.npz"))
+    x, carrier, schedule = mg.squelch_case(mode)
+    q = O.fmo_squelch_new(1, 70000, 192000 // 20, 192000)
+    y = np.zeros_like(x); fl = np.zeros(x.size, np.uint8)
+    pos = 0
+    for k, (level, chunk) in enumerate(schedule):
+        if k:
+            O.fmo_squelch_set_level(q, level)
+        xin = np.ascontiguousarray(x[pos:pos + chunk]); yo = np.zeros(chunk, np.float32); fo = np.zeros(chunk, np.uint8)
+        cin = None if carrier is None else fptr(np.ascontiguousarray(carrier[pos:pos + chunk]))
+        O.fmo_squelch_run(q, fptr(xin), cin, fptr(yo), ol.u8ptr(fo), chunk)
+        y[pos:pos + chunk] = yo; fl[pos:pos + chunk] = fo; pos += chunk
+    O.fmo_squelch_free(q)
+    assert fl[0] == GS[mode + "_flag0"][0]
+    assert np.array_equal(np.nonzero(np.diff(fl.astype(np.int8)))[0], GS[mode + "_transitions"]) and len(GS[mode + "_transitions"]) >= 3
+    assert_bitexact(y[:4096], GS[mode + "_out_head"], mode + " squelch output")
+    assert mg.crc(y) == int(GS[mode + "_out_crc"][0])

@@ -120,3 +120,40 @@ def test_recursive_filters_dense(kind, order, f1, ftype, f2, fs):
     assert na == nb
     assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
     assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+
+
+@pytest.mark.skipif(R is not None and not R.ref_has_qt(), reason="squelchClass.cpp needs the image's QtCore + moc")
+@pytest.mark.parametrize("mode", ["noise", "level"])
+def test_squelch_object(mode):
+    """squelch (src/various/squelchClass.cpp:11-113), the reference's own object (moc'ed header, QtCore) against the oracle's
+    restatement: output AND getSquelchActive() after every sample, bit for bit -- a programme that fades into noise and back
+    for the noise squelch, a carrier level that ramps through the threshold for the level squelch, with slider changes in
+    between (setSquelchLevel :33-37) as fm-processor.cpp:410-413 applies them."""
+    rng = np.random.default_rng(7)
+    fs, n = 192000, 192000 * 2
+    t = np.arange(n) / fs
+    prog = 0.4 * np.sin(2 * np.pi * 1000 * t) + 0.05 * np.sin(2 * np.pi * 19000 * t)
+    noise = rng.standard_normal(n) * 0.6
+    fade = np.clip(np.abs(np.sin(2 * np.pi * 0.9 * t)) * 1.6 - 0.3, 0, 1)            # programme <-> wide-band noise
+    x = (prog * fade + noise * (1 - fade)).astype(np.float32)
+    carrier = (0.02 + 0.5 * np.abs(np.sin(2 * np.pi * 1.3 * t)) ** 3).astype(np.float32) if mode == "level" else None
+    a = O.fmo_squelch_new(1, 70000, fs // 20, fs)
+    b = R.ref_squelch_new(1, 70000, fs // 20, fs)
+    ya, yb = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    fa, fb = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    pos = 0
+    for k, (level, chunk) in enumerate([(0, 16384), (40, 100000), (70, 77777), (100, 50000), (55, n - 16384 - 100000 - 77777 - 50000)]):
+        if k:
+            O.fmo_squelch_set_level(a, level); R.ref_squelch_set_level(b, level)
+        sl = slice(pos, pos + chunk)
+        cin = None if carrier is None else fptr(np.ascontiguousarray(carrier[sl]))
+        xin = np.ascontiguousarray(x[sl])
+        oa, ob = np.zeros(chunk, np.float32), np.zeros(chunk, np.float32)
+        ga, gb = np.zeros(chunk, np.uint8), np.zeros(chunk, np.uint8)
+        O.fmo_squelch_run(a, fptr(xin), cin, fptr(oa), u8ptr(ga), chunk)
+        R.ref_squelch_run(b, fptr(xin), cin, fptr(ob), u8ptr(gb), chunk)
+        ya[sl], yb[sl], fa[sl], fb[sl] = oa, ob, ga, gb
+        pos += chunk
+    O.fmo_squelch_free(a); R.ref_squelch_free(b)
+    assert np.array_equal(fa, fb) and same(ya, yb)
+    assert 0 < int(fa.sum()) < n and int(np.abs(np.diff(fa.astype(np.int8))).sum()) >= 3          # the squelch opened and closed
