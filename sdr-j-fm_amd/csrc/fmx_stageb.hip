@@ -361,6 +361,14 @@ __device__ __forceinline__ float pss_step(PssSt &s, float alpha, float la, float
     return used;
 }
 
+// the PSS part of the metaData snapshot (fm-processor.cpp:673-682) from the state behind the snapshot sample
+__device__ __forceinline__ void meta_snapshot(ChanState *st, const ChanParams &P, float pdp, float mean, bool minimized, bool locked) {
+    const bool lk = P.fm_mode != 2 && locked;
+    st->meta_pss_deg = (float)((double)pdp / 3.14159265358979323846 * 180.0f);
+    st->meta_pss_change = mean * 1000;
+    st->meta_pss_state = (P.pss_active && lk) ? (minimized ? 2 : 1) : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Kernel 1 of 2, once per call: one workgroup = one channel, looping over the call's segments of up to 1536 fm samples --
 // limiter + discriminator, AFC, pilot PLL, lock detector.  Nothing here depends on the PSS feedback, so the whole call runs in
@@ -385,6 +393,10 @@ __global__ __launch_bounds__(FB_T, 3) void stageb_pll_kernel(DeviceTables T, Dev
     const int decoder = P.decoder;
     const int delay = T.front_sets[P.front_set].delay_fm;
     const float2 *zr = B.zring + (size_t)ch * (G.ring_mask + 1);
+    // the sample behind which the reference takes its metaData snapshot (++myCount > fmRate / 2, fm-processor.cpp:662-684), call-relative;
+    // the values this kernel owns (lock strength, lock flag, demodulator DC) are stored from exactly that sample
+    const bool stereo_possible = P.fm_mode != 2;
+    const int jx = (SINCOS_N >> 1) - st->my_count;
     // ring entries of the samples j0 - 2 .. j0 + K - 1 of the segment at seg0 (clamped to the call's last sample: never past what
     // stage A wrote; zero until the filter latency has elapsed; the marker NaN where the reference's start values 0.01 apply)
     auto fetch = [&](int seg0, int w, float2 *z) {
@@ -477,6 +489,7 @@ __global__ __launch_bounds__(FB_T, 3) void stageb_pll_kernel(DeviceTables T, Dev
                 afc = c1 * afc + fmDcAlpha * res[i];
                 dem[i] = fdiv_const(20.0f * (res[i] - afc) * 1.0f, T.K_FM, T.K_FM_rcp);
                 if (i == il) afc_end = afc;
+                if (i == jx - seg0 - j0 && ok[i]) st->meta_dc_if = afc;                   // get_demodDcComponent () at the snapshot
             }
             if (lastseg && owner) st->fm_afc = afc_end;
             afc0 = afc_next;
@@ -595,13 +608,14 @@ __global__ __launch_bounds__(FB_T, 3) void stageb_pll_kernel(DeviceTables T, Dev
             for (int i = 0; i < FB_K; i++) Lt = xq[i] + Lt * keepf;
             float lock_next;
             float lock = wg.decay_incoming2(Lt, lock0, make_decay(T.lock_l2, lane), &lock_next);
-            bool hi[FB_K]; int lastf = -1; float lock_end = 0.f;
+            bool hi[FB_K]; int lastf = -1; float lock_end = 0.f, lock_x = 0.f;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) {
                 lock = (float)((double)xq[i] + (double)lock * keep);
                 hi[i] = lock > 0.07f;
                 if (ok[i] && !hi[i]) lastf = j0 + i;
                 if (i == il) lock_end = lock;
+                if (i == jx - seg0 - j0) lock_x = lock;
             }
             // locked[j] = no sample <= j below the threshold AND (locked before, or the run has lasted long enough)
             int cnt_dummy, tot_dummy, preF, totF;
@@ -614,6 +628,10 @@ __global__ __launch_bounds__(FB_T, 3) void stageb_pll_kernel(DeviceTables T, Dev
                     if (ok[i] && !hi[i]) F = j0 + i;
                     const bool lk = (F < 0) && (locked0 != 0 || stable0 + (j0 + i) + 1 > (SINCOS_N >> 1));
                     mask |= lk ? (1u << i) : 0u;
+                    if (i == jx - seg0 - j0 && ok[i]) {                      // isPilotLocked (PilotPllLockStrength) :870-880
+                        st->meta_locked = (stereo_possible && lk) ? 1 : 0;
+                        st->meta_lock_strength = stereo_possible ? lock_x : 0.f;
+                    }
                 }
             }
             B.w_lockm[(size_t)ch * B.lockm_stride + (size_t)(seg0 / FB_K) + tid] = (uint8_t)mask;
@@ -664,6 +682,8 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_pss_kernel(DeviceTables T, Dev
     unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
     const bool stereo_possible = P.fm_mode != 2, auto_mono = P.auto_mono != 0, pss_active = P.pss_active != 0;
     const int calls_before = A.first ? 0 : st->pss_call_total;
+    const int ix = (SINCOS_N >> 1) - st->my_count - A.seg0 - j0;    // this thread's index of the metaData snapshot sample (see stageb_pll_kernel), if 0 .. K-1
+    const int jxs = (SINCOS_N >> 1) - st->my_count - A.seg0;        // ... segment-relative
     // this thread's samples out of the first kernel
     float dem[FB_K], cur[FB_K];
 #pragma unroll
@@ -798,6 +818,7 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_pss_kernel(DeviceTables T, Dev
                 mean = la * er10[i] + mean * keep;
                 if (ok[i]) { if (fabsf(mean) < 0.001f) lastS = j0 + i; else lastN = j0 + i; }
                 if (i == il) mean_end = mean;
+                if (i == ix && ok[i]) meta_snapshot(st, P, fminf(fmaxf(a[i] + xa[i], -c4), c4), mean, mz, true);   // (mz: no flip inside a steady segment)
             }
             wg.reduce_max4(lastS, lastN, d3, d4);
             if (owner) lds.wf[0][0][3] = mean_end;               // (slot-free word: read after the next barrier below)
@@ -812,6 +833,11 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_pss_kernel(DeviceTables T, Dev
             const int fu = (firstU == -0x7fffffff - 1) ? 0x7fffffff : -firstU, fz = (firstZ == -0x7fffffff - 1) ? 0x7fffffff : -firstZ;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) used[i] = (j0 + i >= fu || j0 + i > fz) ? 0.f : s.pdp;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) if (i == ix && ok[i]) {
+                const bool cleared = j0 + i >= fu;
+                meta_snapshot(st, P, (cleared || j0 + i >= fz) ? 0.f : s.pdp, cleared ? 0.f : s.mean, cleared ? false : s.minimized, locked[i]);
+            }
             if (fu != 0x7fffffff) { e.pdp = 0.f; e.acc = 0.f; e.mean = 0.f; e.minimized = false; e.lock_cnt = 0; e.unlock_cnt = 0; }
             else if (fz != 0x7fffffff) e.pdp = 0.f;
         } else {
@@ -825,6 +851,7 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_pss_kernel(DeviceTables T, Dev
                 for (int j = 0; j < w; j++) {
                     const int p = pk[j];
                     er[j] = pss_step(r, alpha, la, keep, (p & 1) != 0, (p >> 1) - 2, er[j]);
+                    if (j == jxs) meta_snapshot(st, P, r.pdp, r.mean, r.minimized, (p & 1) != 0);
                 }
                 lds.wf[0][0][3] = r.acc; lds.wf[0][1][3] = r.mean; lds.wf[0][2][3] = r.pdp;
                 lds.wi[0][0][3] = r.lock_cnt; lds.wi[0][1][3] = r.unlock_cnt; lds.wi[0][2][3] = r.minimized ? 1 : 0;
@@ -921,20 +948,14 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_pss_kernel(DeviceTables T, Dev
         const int tot = calls_before + ncalls;
         if (!A.last) st->pss_call_total = tot;
         else {
-            // meta snapshot: emitted by the reference every fmRate/2 samples (fm-processor.cpp:662-684); taken at the end of
-            // the call in which that count is crossed
+            // metaData: the snapshot behind sample fmRate / 2 - myCount of the call was stored sample-exactly by the two kernels
+            // (meta_snapshot above; lock strength / flag / demodulator DC in stageb_pll_kernel); the RF DC level moves by 1e-7 of
+            // its distance per input sample and is taken here, at the end of that call
             __threadfence_block();
             int cnt = st->my_count + (int)(G.J1 - G.J0);
             if (cnt > (SINCOS_N >> 1)) {
-                const bool lk = stereo_possible && st->pil_locked;
-                st->meta_locked = lk ? 1 : 0;
-                st->meta_lock_strength = stereo_possible ? st->pil_lock : 0.f;
                 const float dcabs = (float)sqrt((double)st->dc_re * (double)st->dc_re + (double)st->dc_im * (double)st->dc_im);
                 st->meta_dc_rf = P.dc_remove ? 20 * log10f(dcabs + 1.0f / 32768) : (float)-99.99;
-                st->meta_dc_if = st->fm_afc;
-                st->meta_pss_deg = (float)((double)st->pilot_delay_pss / 3.14159265358979323846 * 180.0f);
-                st->meta_pss_change = st->pss_mean * 1000;
-                st->meta_pss_state = (P.pss_active && lk) ? (st->pss_minimized ? 2 : 1) : 0;
                 cnt -= (SINCOS_N >> 1) + 1;
             }
             st->my_count = cnt;
