@@ -72,6 +72,8 @@ struct fmx_handle_s {
     std::vector<ChanUser> user;
     std::vector<ChanParams> params;          // host mirror
     bool params_dirty = true, sets_dirty = true;
+    bool gain_dirty = true;                                          // volume / balance set since the last call (and before the first): gain_fix_kernel runs
+    float *d_audio_lp = nullptr, *d_rs_taps = nullptr;               // the audio low-pass and the resampler alone (gain_fix_kernel)
     // unique tap sets
     std::vector<int32_t> front_keys, audio_keys;
     int front_cap = 0, audio_cap = 0;
@@ -207,6 +209,15 @@ int ensure_sets(fmx_handle h) {
         HIPCHK(hipMemcpy(h->d_audio_taps, h->h_audio_taps.data(), sizeof(float) * h->h_audio_taps.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_audio_sets, h->h_audio_sets.data(), sizeof(AudioSet) * ak.size(), hipMemcpyHostToDevice));
         h->T.audio_taps = h->d_audio_taps; h->T.audio_sets = h->d_audio_sets;
+        {   // the two factors of the folded FIR, separately (gain_fix_kernel)
+            std::vector<float> lp(ak.size() * AUDIO_TAPS, 0.f);
+            for (size_t i = 0; i < ak.size(); i++) if (ak[i] > 0) { const std::vector<float> ha = design::lowpass(AUDIO_TAPS, ak[i], h->cfg.fmRate); std::copy(ha.begin(), ha.end(), lp.begin() + i * AUDIO_TAPS); }
+            if (h->d_audio_lp) (void)hipFree(h->d_audio_lp);
+            HIPCHK(hipMalloc(&h->d_audio_lp, sizeof(float) * lp.size()));
+            HIPCHK(hipMemcpy(h->d_audio_lp, lp.data(), sizeof(float) * lp.size(), hipMemcpyHostToDevice));
+            if (!h->d_rs_taps) { HIPCHK(hipMalloc(&h->d_rs_taps, sizeof(float) * RS_TAPS)); HIPCHK(hipMemcpy(h->d_rs_taps, h->h_rs_taps.data(), sizeof(float) * RS_TAPS, hipMemcpyHostToDevice)); }
+            h->T.audio_lp_taps = h->d_audio_lp; h->T.rs_taps = h->d_rs_taps;
+        }
     }
     h->sets_dirty = false;
     return FMX_OK;
@@ -538,6 +549,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         }
     }
     if (prof) HIPCHK(hipEventRecord(pr.e[2], s));
+    if (h->gain_dirty && G.M1 > G.M0) { G.gain_fix = 1; launch_gain_fix(h->T, h->B, G, h->channels, s); FMX_LAUNCHED(); h->gain_dirty = false; }
     launch_audio(h->T, h->B, G, d_pcm, h->channels, s);
     if (prof) { HIPCHK(hipEventRecord(pr.e[3], s)); h->prof.push_back(pr); }
     FMX_LAUNCHED();
@@ -800,6 +812,8 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMalloc(&h->B.w_diff, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_err, sizeof(float) * (size_t)(PSS_CHUNK + WT) * C));
         HIPCHK(hipMalloc(&h->B.w_pdp, sizeof(float) * NJ * C));
+        HIPCHK(hipMalloc(&h->B.gfix, sizeof(float2) * GAIN_FIX_FRAMES * C));
+        HIPCHK(hipMemset(h->B.gfix, 0, sizeof(float2) * GAIN_FIX_FRAMES * C));
         h->B.lockm_stride = (int32_t)(NJ / 6 + 512);
         HIPCHK(hipMalloc(&h->B.w_lockm, (size_t)h->B.lockm_stride * C));
         HIPCHK(hipMemset(h->B.w_lockm, 0, (size_t)h->B.lockm_stride * C));
@@ -862,7 +876,7 @@ int fmx_destroy(fmx_handle h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &pr : h->prof) for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
-    void *ptrs[] = { h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
+    void *ptrs[] = { h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
                      h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
                      h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x, h->B.w_lockm };
@@ -930,9 +944,9 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         case FMX_P_FM_DECODER: p.decoder = iv; break;
         case FMX_P_SOUND_MODE: p.sound_sel = iv; break;
         case FMX_P_STEREO_PANORAMA: u.panorama = iv; break;
-        case FMX_P_SOUND_BALANCE: u.balance = iv; break;
+        case FMX_P_SOUND_BALANCE: u.balance = iv; h->gain_dirty = true; break;
         case FMX_P_DEEMPHASIS: u.deemph_us = iv; break;
-        case FMX_P_VOLUME_DB: u.volume_db = (float)value; u.ctor_volume = false; break;
+        case FMX_P_VOLUME_DB: u.volume_db = (float)value; u.ctor_volume = false; h->gain_dirty = true; break;
         case FMX_P_LF_CUTOFF: u.lf_cutoff = iv > 0 ? iv : 0; h->sets_dirty = true; break;
         case FMX_P_BANDWIDTH: u.bandwidth = iv; h->sets_dirty = true; break;
         case FMX_P_ATTENUATION_L: p.att_l = (float)value; break;

@@ -127,7 +127,9 @@ __global__ __launch_bounds__(64 * AW) void audio_kernel(DeviceTables T, DeviceBu
     const int c0 = 8 * tl + FPT * ph;
     // audioGainCorrection fm-processor.cpp:303-306: (volumeFactor * leftChannel) * sample.  Applied here, at
     // the output of the folded FIR, so that a volume/balance change takes effect at the call boundary as in
-    // the reference (it sits behind the audio low-pass there) rather than one filter latency late.
+    // the reference (it sits behind the audio low-pass there) rather than one filter latency late; the reference
+    // multiplies in FRONT of the resampler, whose 128-sample memory blends old and new gain over 32 frames:
+    // gain_fix_kernel supplies that blend for the call in front of which a gain changed.
     const float gl = P.volume * P.left_ch, gr = P.volume * P.right_ch;
     const ChanState *__restrict__ st = &B.state[ch];
     const int64_t F = st->fade_start_frame;
@@ -143,6 +145,10 @@ __global__ __launch_bounds__(64 * AW) void audio_kernel(DeviceTables T, DeviceBu
         const int64_t m = m0 + c0 + j;
         if (m >= G.M1) break;
         float al = acc[j].x * gl, ar = acc[j].y * gr;
+        if (G.gain_fix && m - G.M0 < GAIN_FIX_FRAMES) {      // the part of the resampler's memory that entered under the old gain
+            const float2 c = B.gfix[(size_t)ch * GAIN_FIX_FRAMES + (m - G.M0)];
+            al += c.x; ar += c.y;
+        }
         // start-up fade fm-processor.cpp:638-642: factor = (Max - cnt)/Max with cnt = Max - (m - F)
         const int64_t since = m - F;
         if (since >= 0 && since < Max) {
@@ -202,6 +208,60 @@ __global__ __launch_bounds__(64) void pcm_tail_kernel(DeviceBuffers B, CallGeom 
     }
     st->pk_l = L; st->pk_r = R; st->pk_events = ev; st->pk_cnt = (cnt0 + frames) % PK_WIN;
     if (B.params[ch].test_tone) st->tt_pos = (int)(((int64_t)st->tt_pos + frames) % TT_CYCLE);
+}
+
+// A volume / balance change between two calls (fm-processor.cpp:299-306, 630): the reference multiplies the sample that enters
+// the resampler, so PCM frame m = sum_k h_rs[k] g(4 m + 3 - k) a[4 m + 3 - k] with a = audio low-pass output; for the frames
+// whose window reaches behind the call's first fm sample J0 the old gain still weighs in.  audio_kernel computes
+// g_new * (folded FIR); this kernel computes the rest, (g_old - g_new) * sum over the window entries older than J0, for the
+// call's first 32 frames: A[q] = a[J0 - q] (q = 1 .. 127, one thread each, 756 taps of the d ring), then
+// corr[r] = sum_q h_rs[e_r + q] A[q], e_r = 4 (M0 + r) + 3 - J0.  One workgroup per channel; channels whose gain did not change
+// write zeros.  Also records the gains for the next change.
+__global__ __launch_bounds__(128) void gain_fix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int channels) {
+    __shared__ float2 A[RS_TAPS];
+    const int ch = blockIdx.x, t = threadIdx.x;
+    const ChanParams &P = B.params[ch];
+    ChanState *st = &B.state[ch];
+    const float gl = P.volume * P.left_ch, gr = P.volume * P.right_ch;
+    const bool valid = st->gain_valid != 0;
+    const float dl = valid ? st->prev_gl - gl : 0.f, dr = valid ? st->prev_gr - gr : 0.f;
+    float2 *out = B.gfix + (size_t)ch * GAIN_FIX_FRAMES;
+    __syncthreads();                                              // (every thread has read the previous gains)
+    if (t == 0) { st->prev_gl = gl; st->prev_gr = gr; st->gain_valid = 1; }
+    if (dl == 0.f && dr == 0.f) { if (t < GAIN_FIX_FRAMES) out[t] = make_float2(0.f, 0.f); return; }
+    const AudioSet AS = T.audio_sets[P.audio_set];
+    const float2 *__restrict__ dring = B.dring + (size_t)ch * (G.dring_mask + 1);
+    {
+        const int q = t;                                          // A[q] = a[J0 - q]; q = 0 unused
+        float2 acc = make_float2(0.f, 0.f);
+        if (q >= 1) {
+            const int64_t j = G.J0 - q - AS.delay;
+            if (AS.delay > 0) {                                   // audio low-pass on: a[j'] = sum_i h_a[i] d[j' - delay - i]
+                const float *__restrict__ ha = T.audio_lp_taps + (size_t)P.audio_set * AUDIO_TAPS;
+                for (int i = 0; i < AUDIO_TAPS; i++) {
+                    const int64_t idx = j - i;
+                    const float2 v = idx >= 0 ? dring[idx & G.dring_mask] : make_float2(0.f, 0.f);
+                    acc.x = fmaf(ha[i], v.x, acc.x); acc.y = fmaf(ha[i], v.y, acc.y);
+                }
+            } else acc = j >= 0 ? dring[j & G.dring_mask] : make_float2(0.f, 0.f);
+        }
+        A[q] = acc;
+    }
+    __syncthreads();
+    if (t < GAIN_FIX_FRAMES) {
+        const int e = (int)(4 * (G.M0 + t) + 3 - G.J0);           // newest window entry of frame M0 + t, relative to J0
+        float2 c = make_float2(0.f, 0.f);
+        for (int q = 1; e + q < RS_TAPS; q++) {
+            if (e + q < 0) continue;
+            const float h = T.rs_taps[e + q];
+            c.x = fmaf(h, A[q].x, c.x); c.y = fmaf(h, A[q].y, c.y);
+        }
+        out[t] = make_float2(dl * c.x, dr * c.y);
+    }
+}
+
+void launch_gain_fix(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s) {
+    hipLaunchKernelGGL(gain_fix_kernel, dim3(channels), dim3(128), 0, s, T, B, G, channels);
 }
 
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,

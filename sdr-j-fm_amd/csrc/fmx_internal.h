@@ -21,6 +21,7 @@ constexpr int AUDIO_DELAY = 8192 - 756;
 constexpr int C_MAX_TAPS = AUDIO_TAPS + RS_TAPS - 1;   // 883
 constexpr int C_TAPS_STRIDE = 896;     // padded
 constexpr int C_TILE = 256;            // PCM frames per audio-FIR tile
+constexpr int GAIN_FIX_FRAMES = RS_TAPS / 4;   // PCM frames whose resampler memory straddles a gain change (32)
 constexpr int NSQ_QUADS = 10;          // ((20 + 1) & 0176) / 2 biquads per filter (iir-filters.cpp:454)
 constexpr int TT_SILENT = 96001;       // ++TimePeriodCounter > workingRate * 2.0f fires on the 96001st silent frame (fm-processor.cpp:816-817)
 constexpr int TT_BURST = 1200;         // workingRate * 0.025f (:819)
@@ -86,6 +87,9 @@ struct ChanState {
     int32_t pad0;
     // de-emphasis (fm-processor.cpp:594-595)
     float   de_l, de_r;
+    // audioGainCorrection (fm-processor.cpp:303-306): the gains of the previous call, for the transient of a change
+    float   prev_gl, prev_gr;
+    int32_t gain_valid, pad_g;
     // fade-in (fm-processor.cpp:130-131,638-642)
     int64_t fade_start_frame;    // PCM frame index at which suppressAudioSampleCnt was (re)armed
     // meta snapshot (fm-processor.cpp:662-684)
@@ -164,6 +168,8 @@ struct DeviceTables {
     const float2 *fft_w;         // [fftc::W_COUNT] stage twiddles of fmx_fftconv.h
     const float2 *pss_hs;        // [2048] spectrum of the PSS taps in the forward transform's slot order, 1 / N included; null: direct FIR (FMX_PSS_FIR=direct)
     const float  *audio_taps;    // [sets][C_TAPS_STRIDE]
+    const float  *audio_lp_taps; // [sets][AUDIO_TAPS] the audio low-pass alone (gain_fix_kernel), h[0] first
+    const float  *rs_taps;       // [RS_TAPS] the resampler alone, h[0] first
     const AudioSet *audio_sets;
     double  sincos_C;            // Rate / (2*M_PI)  (sincos.cpp:42)
     float   K_FM, K_FM_rcp, pil_omega_rcp;   // rcp = RN(1/c) for fdiv_const
@@ -191,6 +197,8 @@ struct CallGeom {
     int64_t stream_stride, pcm_stride;   // in complex samples / frames
     int32_t iq_format;   // fmx_iq_format of the input buffer
     float   iq_scale;    // 1/128 (U8, S8) or 1/denominator (S16)
+    int32_t gain_fix;    // the call's first GAIN_FIX_FRAMES frames take a correction from B.gfix (a volume / balance change, fmx_audio.hip)
+    int32_t pad_gf;
 };
 
 constexpr int DBG_SLOTS = 32;
@@ -213,6 +221,7 @@ struct DeviceBuffers {
     float   *w_pdp;      // pilotDelayPSS as used by each sample
     int32_t *w_tag;      // -2 mono branch, -1 stereo without PSS, >= 0 PSS call index within the chunk
     float2  *w_x;        // matrix output, then de-emphasised + gained stereo (in place)
+    float2  *gfix;       // [channels][GAIN_FIX_FRAMES] what a gain change adds to the first frames of the call (gain_fix_kernel)
     uint8_t *w_lockm;    // fused layout: [channel][lockm_stride] pilot-lock flags of this call, one byte (six samples) per thread and segment
     int32_t lockm_stride, pad_lm;
     // PCM tail (fmx_audio.hip)
@@ -316,5 +325,7 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
 void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,
                   int channels, hipStream_t s);
+// before launch_audio of a call in front of which volume / balance may have changed (and of the first call)
+void launch_gain_fix(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
 
 }  // namespace fmx

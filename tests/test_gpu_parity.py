@@ -326,11 +326,11 @@ def test_actions_and_runtime_changes(fmx_amd, ol):
         outs_o.append(o.process(x)); outs_g.append(f.process_host(x)[0])
     a, b = np.concatenate(outs_g), np.concatenate(outs_o)
     assert a.shape == b.shape
-    # the reference applies the gain in front of the resampler, this build behind it: a gain CHANGE differs for
-    # the 128-tap resampler's memory (32 frames); everywhere else the streams agree to the usual tolerance
+    # the gain sits in front of the resampler in the reference (fm-processor.cpp:630): a change blends old and new gain over the
+    # resampler's 32-frame memory; the library reproduces that blend (gain_fix_kernel), so no frame is exempt
     d = a - b
-    d[start[45]: start[45] + 40] = 0
     assert rms(d) <= PCM_RMS_TOL
+    assert np.abs(d[start[45]: start[45] + 40]).max() <= 5e-6
     assert np.abs(b[start[40]: start[40] + 10]).max() < 1e-3      # fade restarted from 0
 
 
