@@ -73,7 +73,8 @@ struct fmx_handle_s {
     std::vector<ChanParams> params;          // host mirror
     bool params_dirty = true, sets_dirty = true;
     bool gain_dirty = true;                                          // volume / balance set since the last call (and before the first): gain_fix_kernel runs
-    float *d_audio_lp = nullptr, *d_rs_taps = nullptr;               // the audio low-pass and the resampler alone (gain_fix_kernel)
+    float *d_audio_lp = nullptr, *d_rs_taps = nullptr;
+    float2 *d_audio_spec = nullptr;               // the audio low-pass and the resampler alone (gain_fix_kernel)
     // unique tap sets
     std::vector<int32_t> front_keys, audio_keys;
     int front_cap = 0, audio_cap = 0;
@@ -217,6 +218,22 @@ int ensure_sets(fmx_handle h) {
             HIPCHK(hipMemcpy(h->d_audio_lp, lp.data(), sizeof(float) * lp.size(), hipMemcpyHostToDevice));
             if (!h->d_rs_taps) { HIPCHK(hipMalloc(&h->d_rs_taps, sizeof(float) * RS_TAPS)); HIPCHK(hipMemcpy(h->d_rs_taps, h->h_rs_taps.data(), sizeof(float) * RS_TAPS, hipMemcpyHostToDevice)); }
             h->T.audio_lp_taps = h->d_audio_lp; h->T.rs_taps = h->d_rs_taps;
+            // spectra of the four decimation phases g_p[i] = g[4 i + p] of the folded FIR (audio_fft_kernel); h_audio_taps holds g reversed
+            std::vector<float2> W(fftc::W_COUNT), spec(ak.size() * 4 * fftc::N);
+            fftc::make_twiddles(W.data());
+            for (size_t i = 0; i < ak.size(); i++) {
+                const int nt = h->h_audio_sets[i].ntaps;
+                const float *rev = &h->h_audio_taps[i * C_TAPS_STRIDE];
+                for (int p = 0; p < 4; p++) {
+                    std::vector<float> gp;
+                    for (int kk = p; kk < nt; kk += 4) gp.push_back(rev[nt - 1 - kk]);
+                    fftc::make_spectrum(gp.data(), (int)gp.size(), &spec[(i * 4 + p) * fftc::N], W.data());
+                }
+            }
+            if (h->d_audio_spec) (void)hipFree(h->d_audio_spec);
+            HIPCHK(hipMalloc(&h->d_audio_spec, sizeof(float2) * spec.size()));
+            HIPCHK(hipMemcpy(h->d_audio_spec, spec.data(), sizeof(float2) * spec.size(), hipMemcpyHostToDevice));
+            h->T.audio_spec = (getenv("FMX_AUDIO_FIR") && std::string(getenv("FMX_AUDIO_FIR")) == "direct") ? nullptr : h->d_audio_spec;
         }
     }
     h->sets_dirty = false;
@@ -876,7 +893,7 @@ int fmx_destroy(fmx_handle h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &pr : h->prof) for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
-    void *ptrs[] = { h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
+    void *ptrs[] = { h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
                      h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
                      h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x, h->B.w_lockm };

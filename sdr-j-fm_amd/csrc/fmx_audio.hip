@@ -14,6 +14,7 @@
 // the per-channel d ring.  libsamplerate itself is third-party and absent: the resampler is the
 // documented fmx design (oracle/fm_oracle.c fmo_resampler_taps), "parity unpinned" for that stage.
 #include "fmx_internal.h"
+#include "fmx_fftconv.h"
 
 namespace fmx {
 
@@ -210,6 +211,111 @@ __global__ __launch_bounds__(64) void pcm_tail_kernel(DeviceBuffers B, CallGeom 
     if (B.params[ch].test_tone) st->tt_pos = (int)(((int64_t)st->tt_pos + frames) % TT_CYCLE);
 }
 
+// The same FIR by fast convolution (fmx_fftconv.h) -- the reference's own method for its audio filter (fft-filters.cpp:132-163,
+// 8192 points).  The folded FIR is only wanted at every fourth fm sample, so it is split into its four decimation phases:
+//   out[m] = sum_p (g_p * x_p)[m],  g_p[i] = g[4 i + p] (221 taps),  x_p[n] = d[4 n + 3 - delay - p]   (all at 48 kHz),
+// four forward transforms of 2048 points (the (L, R) pair rides as one complex number: the taps are real), the four spectra
+// products summed in registers, ONE backward transform: 2048 - 220 outputs, of which a workgroup keeps 1792 = seven 256-frame
+// tiles (the peak meter's unit).  A third of the direct form's instructions.  One 256-thread workgroup per (block, channel);
+// the four phases of a thread's eight window entries are 32 contiguous bytes of the d ring each.
+constexpr int AF_HIST = (C_MAX_TAPS + 3) / 4 - 1;        // 220 frames of history in front of a block
+constexpr int AF_VALID = 7 * C_TILE;                     // frames a block delivers
+static_assert(AF_HIST + AF_VALID <= fftc::N, "block + history fit one transform");
+static_assert(AUDIO_DELAY % 4 == 0, "the four phases of a frame are one aligned group of four ring entries");
+__global__ __launch_bounds__(fftc::T) void audio_fft_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, float2 *__restrict__ pcm) {
+    __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];
+    __shared__ int pkt[7][4];
+    const int ch = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const int64_t mb = G.M0 + (int64_t)blockIdx.x * AF_VALID;
+    if (mb >= G.M1) return;
+    const ChanParams P = B.params[ch];
+    const AudioSet AS = T.audio_sets[P.audio_set];
+    const float2 *__restrict__ dring = B.dring + (size_t)ch * (G.dring_mask + 1);
+    const float2 *__restrict__ Gs = T.audio_spec + (size_t)P.audio_set * 4 * fftc::N;
+    if (t < 28) pkt[t >> 2][t & 3] = 0;
+    // window entry n' <-> frame mb - 220 + n': its four phases are d[4 (mb - 220 + n') - delay + 0 .. 3], phase p = entry 3 - p.
+    // A phase's eight entries are loaded in front of its transform (the four phases share their cache lines; holding all four
+    // windows in registers costs 48 VGPRs and a third of the occupancy)
+    float2 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc[q] = make_float2(0.f, 0.f);
+#pragma unroll 1
+    for (int p = 0; p < 4; p++) {
+        float2 a[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int64_t fr = mb - AF_HIST + t + fftc::T * k;
+            const int64_t f0 = 4 * fr - AS.delay;
+            a[k] = (f0 >= 0 && fr < G.M1) ? dring[(f0 + 3 - p) & G.dring_mask] : make_float2(0.f, 0.f);     // (frames past the call's last are never used)
+        }
+        __syncthreads();                                  // (the previous transform's last reads of X are done)
+        fftc::forward_slots(t, a, X, T.fft_w);
+        fftc::times_spectrum(t, a, Gs + (size_t)p * fftc::N);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { acc[q].x += a[q].x; acc[q].y += a[q].y; }
+    }
+    __syncthreads();
+    fftc::backward_slots(t, acc, X, T.fft_w);
+    // ---- per frame: gain, fade, test tone, peaks, store (as audio_kernel)
+    const float gl = P.volume * P.left_ch, gr = P.volume * P.right_ch;
+    const ChanState *__restrict__ st = &B.state[ch];
+    const int64_t F = st->fade_start_frame;
+    const int Max = 24000;
+    const int cnt0 = st->pk_cnt, tt0 = st->tt_pos;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int rel = t + fftc::T * k - AF_HIST;        // frame of the block
+        const int64_t m = mb + rel;
+        const bool live = rel >= 0 && rel < AF_VALID && m < G.M1;
+        const int tile = rel >= 0 ? rel / C_TILE : 0;
+        float al = acc[k].x * gl, ar = acc[k].y * gr;
+        float pv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            if (G.gain_fix && m - G.M0 < GAIN_FIX_FRAMES) {
+                const float2 c = B.gfix[(size_t)ch * GAIN_FIX_FRAMES + (m - G.M0)];
+                al += c.x; ar += c.y;
+            }
+            const int64_t since = m - F;                  // start-up fade fm-processor.cpp:638-642
+            if (since >= 0 && since < Max) {
+                const float cnt = (float)(Max - (int)since);
+                const float f = ((float)Max - cnt) / (float)Max;
+                al *= f; ar *= f;
+            }
+            const int i = (int)(m - G.M0);
+            if (P.test_tone) {                            // insertTestTone fm-processor.cpp:800-823 (see audio_kernel)
+#pragma clang fp contract(off)
+                const float level = 0.9f;
+                al = al * (1.0f - level); ar = ar * (1.0f - level);
+                const int pos = (int)(((int64_t)tt0 + i) % TT_CYCLE);
+                if (pos >= TT_SILENT) {
+                    const float smpl = level * B.tone[pos - TT_SILENT];
+                    al = al + smpl; ar = ar + smpl;
+                }
+            }
+            const int i_tile = (int)(mb - G.M0) + tile * C_TILE;
+            const bool second = (cnt0 + i) / PK_WIN != (cnt0 + i_tile) / PK_WIN;
+            pv[second ? 2 : 0] = fabsf(al); pv[second ? 3 : 1] = fabsf(ar);
+            pcm[(size_t)ch * G.pcm_stride + (m - G.M0)] = make_float2(al, ar);
+        }
+        // peak maxima per 256-frame tile: for a given k a wave's frames lie in one tile except the wave that holds t = 220
+        if (t < 192) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float v = pv[q];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+                if (lane == 0 && k >= 1) atomicMax(&pkt[k - 1][q], __float_as_int(v));
+            }
+        } else if (live) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) atomicMax(&pkt[tile][q], __float_as_int(pv[q]));
+        }
+    }
+    __syncthreads();
+    const int tiles = (int)(((G.M1 - mb) < AF_VALID ? (G.M1 - mb) : AF_VALID) + C_TILE - 1) / C_TILE;
+    if (t < tiles) B.pk_part[(size_t)ch * B.pk_tiles + 7 * blockIdx.x + t] = make_float4(__int_as_float(pkt[t][0]), __int_as_float(pkt[t][1]), __int_as_float(pkt[t][2]), __int_as_float(pkt[t][3]));
+}
+
 // A volume / balance change between two calls (fm-processor.cpp:299-306, 630): the reference multiplies the sample that enters
 // the resampler, so PCM frame m = sum_k h_rs[k] g(4 m + 3 - k) a[4 m + 3 - k] with a = audio low-pass output; for the frames
 // whose window reaches behind the call's first fm sample J0 the old gain still weighs in.  audio_kernel computes
@@ -268,8 +374,11 @@ void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
                   int channels, hipStream_t s) {
     const int64_t frames = G.M1 - G.M0;
     if (frames <= 0) return;
-    const int tiles = (int)((frames + AW * C_TILE - 1) / (AW * C_TILE));
-    hipLaunchKernelGGL(audio_kernel, dim3(tiles, channels), dim3(64 * AW), 0, s, T, B, G, pcm);
+    if (T.audio_spec) hipLaunchKernelGGL(audio_fft_kernel, dim3((unsigned)((frames + AF_VALID - 1) / AF_VALID), channels), dim3(fftc::T), 0, s, T, B, G, pcm);
+    else {
+        const int tiles = (int)((frames + AW * C_TILE - 1) / (AW * C_TILE));
+        hipLaunchKernelGGL(audio_kernel, dim3(tiles, channels), dim3(64 * AW), 0, s, T, B, G, pcm);
+    }
     hipLaunchKernelGGL(pcm_tail_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, B, G, channels);
 }
 

@@ -126,43 +126,52 @@ template <int CTRL> __device__ __forceinline__ float2 quad_get(float2 v) {
 // thread t of the workgroup: `a` = the natural-order inputs t + 256 p on entry, the natural-order outputs t + 256 p on return.
 // X: LDS_N complex of LDS; W: twiddles; Hs: the spectrum in "slot" order (entry 8 t + q = what thread t holds in register q in
 // front of the multiplication, make_spectrum below), 1 / N included.
-__device__ __forceinline__ void convolve(int t, float2 *a, float2 *X, const float2 *__restrict__ W, const float2 *__restrict__ Hs) {
-    // the twiddles of a stage and the spectrum are asked for one barrier ahead of their use: their latency (L2) passes under the
-    // barrier and the LDS round trip instead of in front of the butterflies
-    int b256, j256, b32, j32;
-    geom8<256>(t, b256, j256); geom8<32>(t, b32, j32);
-    float2 tw[7], tn[7];
-    load_tw<2048>(tw, t, W);
-    load_tw<256>(tn, j256, W);
-    fwd8(a, tw); store_q<2048>(a, X, 0, t);
+// forward half: `a` = natural-order inputs t + 256 p on entry, slot values (register q of thread t) on return
+__device__ __forceinline__ void forward_slots(int t, float2 *a, float2 *X, const float2 *__restrict__ W) {
+    int base, j;
+    fwd8<2048>(a, t, W); store_q<2048>(a, X, 0, t);
     __syncthreads();
-    load_tw<32>(tw, j32, W);
-    load_p<256>(a, X, b256, j256); fwd8(a, tn); store_q<256>(a, X, b256, j256);
-    float2 h[8];
-    {
-        const float4 *H4 = reinterpret_cast<const float4 *>(Hs + 8 * t);
-#pragma unroll
-        for (int q = 0; q < 4; q++) { const float4 v = H4[q]; h[2 * q] = make_float2(v.x, v.y); h[2 * q + 1] = make_float2(v.z, v.w); }
-    }
+    geom8<256>(t, base, j);
+    load_p<256>(a, X, base, j); fwd8<256>(a, j, W); store_q<256>(a, X, base, j);
     __syncthreads();
-    load_p<32>(a, X, b32, j32); fwd8(a, tw);
+    geom8<32>(t, base, j);
+    load_p<32>(a, X, base, j); fwd8<32>(a, j, W);
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         float2 v = a[q];
-        v = quad_f1<-1>(j32, v, quad_get<0x4E>(v));              // quad_perm [2, 3, 0, 1]
-        v = quad_f2(j32, v, quad_get<0xB1>(v));                  // quad_perm [1, 0, 3, 2]
-        v = cmul(v, h[q]);
-        v = quad_b1<-1>(j32, v, quad_get<0xB1>(v));
-        v = quad_b2(j32, v, quad_get<0x4E>(v));
-        a[q] = v;
+        v = quad_f1<-1>(j, v, quad_get<0x4E>(v));                // quad_perm [2, 3, 0, 1]
+        a[q] = quad_f2(j, v, quad_get<0xB1>(v));                 // quad_perm [1, 0, 3, 2]
     }
-    load_tw<256>(tn, j256, W);
-    inv8(a, tw); store_p<32>(a, X, b32, j32);
+}
+// backward half: slot values in, natural-order outputs t + 256 p out (times N)
+__device__ __forceinline__ void backward_slots(int t, float2 *a, float2 *X, const float2 *__restrict__ W) {
+    int base, j;
+    geom8<32>(t, base, j);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        float2 v = a[q];
+        v = quad_b1<-1>(j, v, quad_get<0xB1>(v));
+        a[q] = quad_b2(j, v, quad_get<0x4E>(v));
+    }
+    inv8<32>(a, j, W); store_p<32>(a, X, base, j);
     __syncthreads();
-    load_tw<2048>(tw, t, W);
-    load_q<256>(a, X, b256, j256); inv8(a, tn); store_p<256>(a, X, b256, j256);
+    geom8<256>(t, base, j);
+    load_q<256>(a, X, base, j); inv8<256>(a, j, W); store_p<256>(a, X, base, j);
     __syncthreads();
-    load_q<2048>(a, X, 0, t); inv8(a, tw);
+    load_q<2048>(a, X, 0, t); inv8<2048>(a, t, W);
+}
+// a[q] *= Hs[8 t + q]
+__device__ __forceinline__ void times_spectrum(int t, float2 *a, const float2 *__restrict__ Hs) {
+    const float4 *H4 = reinterpret_cast<const float4 *>(Hs + 8 * t);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const float4 v = H4[q]; a[2 * q] = cmul(a[2 * q], make_float2(v.x, v.y)); a[2 * q + 1] = cmul(a[2 * q + 1], make_float2(v.z, v.w)); }
+}
+// (the caller must put a barrier between the last LDS read of one transform and the first LDS write of the next: the end of
+// forward_slots and of backward_slots reads X)
+__device__ __forceinline__ void convolve(int t, float2 *a, float2 *X, const float2 *__restrict__ W, const float2 *__restrict__ Hs) {
+    forward_slots(t, a, X, W);
+    times_spectrum(t, a, Hs);
+    backward_slots(t, a, X, W);
 }
 
 // ---- host side: the same arithmetic, all 256 threads in turn between the barriers --------------------------------------

@@ -170,6 +170,8 @@ struct DeviceTables {
     const float  *audio_taps;    // [sets][C_TAPS_STRIDE]
     const float  *audio_lp_taps; // [sets][AUDIO_TAPS] the audio low-pass alone (gain_fix_kernel), h[0] first
     const float  *rs_taps;       // [RS_TAPS] the resampler alone, h[0] first
+    const float2 *audio_spec;    // [sets][4][2048] spectra of the folded FIR's four decimation phases, slot order of fmx_fftconv.h, 1 / N
+                                 // included; null: the direct form (FMX_AUDIO_FIR=direct)
     const AudioSet *audio_sets;
     double  sincos_C;            // Rate / (2*M_PI)  (sincos.cpp:42)
     float   K_FM, K_FM_rcp, pil_omega_rcp;   // rcp = RN(1/c) for fdiv_const
