@@ -268,3 +268,51 @@ def test_meta_snapshot_is_taken_at_the_reference_sample(fmx_amd, ol):
         assert abs(a.PssPhaseShiftDegree - b.pssPhaseShiftDegree) <= 2e-3, (k, a.PssPhaseShiftDegree, b.pssPhaseShiftDegree)
         assert abs(a.PssPhaseChange - b.pssPhaseChange) <= 2e-3 + 1e-3 * abs(b.pssPhaseChange), (k, a.PssPhaseChange, b.pssPhaseChange)
     assert seen >= 15
+
+
+def test_full_size_config3_shared_wideband_streams(fmx_amd, ol):
+    """BASELINE configs[2] at its full layout: 256 channels on 24 wide-band IQ streams, eleven (ten on the last streams) carriers
+    per stream on a 200 kHz raster selected with set_localOscillator, every channel of a stream reading the SAME buffer
+    (stream_of_channel).  The 24 streams carry three different contents (stream s = content s % 3), so (i) every channel must be
+    bit-identical to the channel with the same carrier in the first stream of its content, and (ii) channels spot-checked against
+    the oracle (which mixes the same wide-band stream with the same LO) stay within the north-star tolerance.  0.1 s device-sized
+    calls through process_host, six calls."""
+    block, calls, C, S = 230400, 6, 256, 24
+    n = block * calls
+    offs = [(k - 5) * 200000 for k in range(11)]
+    contents = []
+    for j in range(3):
+        wide = np.zeros((n, 2), np.float64)
+        for k, o in enumerate(offs):
+            wide += ol.synth_iq(n, offsetHz=float(o), leftHz=300.0 + 170 * k + 40 * j, rightHz=800.0 + 90 * k + 25 * j, carrierAmp=0.085)
+        contents.append(wide.astype(np.float32))
+    smap = [c * S // C for c in range(C)]                      # 10 or 11 channels per stream, as bench.py's config3
+    first_of_stream = {}
+    lo = []
+    for c in range(C):
+        first_of_stream.setdefault(smap[c], c)
+        lo.append(offs[c - first_of_stream[smap[c]]])
+    f = fmx_amd.Fmx(C, streams=S, stream_of_channel=smap, max_block=block)
+    gui_defaults(f)
+    for c in range(C):
+        f.set_param(M.P_LOCAL_OSCILLATOR, lo[c], c)
+    iq = np.stack([contents[s % 3] for s in range(S)])          # [24, n, 2]
+    pcm = np.concatenate([f.process_host(iq[:, i * block:(i + 1) * block]) for i in range(calls)], axis=1)
+    assert pcm.shape[0] == C
+    # (i) duplicates: channel c against the channel of stream (s % 3) with the same carrier index
+    ref_of = {}
+    for c in range(C):
+        key = (smap[c] % 3, lo[c])
+        if key in ref_of:
+            assert np.array_equal(pcm[c], pcm[ref_of[key]]), (c, ref_of[key])
+        else:
+            ref_of[key] = c
+    assert len(ref_of) >= 30                                     # (10 or 11 carriers in use per content)
+    # (ii) oracle spot checks: an edge carrier, the centre one, one of each content
+    for c in (0, 5, first_of_stream[1] + 10, first_of_stream[2] + 3, C - 1):
+        want = ol.OracleChain(inputFilterBw=165000, loFrequency=int(lo[c])).process(contents[smap[c] % 3])
+        m = want.shape[0]
+        assert pcm[c].shape[0] - 16384 // 48 - 1 <= m <= pcm[c].shape[0]
+        e = rms(pcm[c][:m] - want)
+        assert e <= 1e-5, (c, lo[c], e)
+    assert rms(pcm[0][-4800:]) > 1e-3
