@@ -57,6 +57,7 @@ struct fmx_handle_s {
     hipStream_t stream = nullptr;
     hipStream_t s_side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the stage-B chunk pipeline
     hipStream_t s_r = nullptr, s_t = nullptr;          // persistent layout of stage B: CU-masked streams
+    int n_cus = 256; size_t lds_per_block = 65536;     // device limits the stage-A layout choice looks at
     DemodSync *d_sync = nullptr;
     int *h_stall = nullptr, *d_stall = nullptr;                      // host-mapped: set by the GPU when the persistent layout stalled
     bool partitioned = false; int ev_next = 0;
@@ -539,7 +540,23 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     }
     g_launch_err = hipSuccess;
     h->B.lin_rows = h->fused ? (int32_t)h->work_nj : 0;
-    launch_front(h->T, h->B, G, d_iq, h->channels, s);
+    {
+        // Stage A layout: wave pairs + matrix FIR (fmx_front2.hip) once the batch fills the GPU with four-channel workgroups,
+        // four waves per channel (fmx_front.hip) below that.  FMX_FRONT=classic|pairs forces one.
+        static const char *fe = getenv("FMX_FRONT");
+        bool pairs = fe ? std::string(fe) == "pairs" : false;             // (measured slower than the classic layout so far: opt-in)
+        int ntab = 1, lo_cap = 0;
+        if (pairs) {
+            for (int c = 0; c < h->channels; c++) {
+                if (h->params[c].front_set != h->params[0].front_set) ntab = 4;
+                if (h->params[c].lo_freq != 0) lo_cap = std::max(lo_cap, (int)h->params[c].lo_period);
+            }
+            if (front2_lds_bytes(ntab, lo_cap) > h->lds_per_block) lo_cap = 0;          // LO phases from the table in memory then
+            if (front2_lds_bytes(ntab, lo_cap) > h->lds_per_block) pairs = false;
+        }
+        if (pairs) note_hip(launch_front2(h->T, h->B, G, d_iq, h->channels, ntab, lo_cap, s));
+        else launch_front(h->T, h->B, G, d_iq, h->channels, s);
+    }
     FMX_LAUNCHED();
     if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
     {
@@ -658,6 +675,14 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         p.rds_mode = 0; p.lo_freq = 0; p.lo_period = 0; p.att_l = 1.f; p.att_r = 1.f;
         p.squelch_mode = 0; p.squelch_thr = std::pow(10.0f, (float)(1 - 80) / 30.0f); p.squelch_nthr = 1.0f - 1 / 100.0f;
         refresh_derived(h, c);
+    }
+    {
+        hipDeviceProp_t dp;
+        HIPCHK(hipGetDeviceProperties(&dp, cfg->device));
+        h->n_cus = dp.multiProcessorCount;
+        int optin = 0;
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) != hipSuccess) optin = 0;
+        h->lds_per_block = std::max((size_t)dp.sharedMemPerBlock, (size_t)optin);
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto &ss : h->s_side) HIPCHK(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));

@@ -293,6 +293,12 @@ void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G,
 
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s);
+// producer / consumer layout of stage A (fmx_front2.hip): four channels per 512-thread workgroup, FIR on the matrix pipe.
+// ntab = 1 when every channel uses the tap set of channel 0 (one tap image per workgroup), else 4; lo_cap = LDS entries per
+// channel for one LO period (0: none).  front2_lds_bytes = dynamic LDS the launch needs.
+size_t front2_lds_bytes(int ntab, int lo_cap);
+hipError_t launch_front2(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels,
+                         int ntab, int lo_cap, hipStream_t s);
 // side streams + events for the chunk pipeline of stage B (null streams = run everything on the caller's stream)
 // Streams of the stage-B chunk pipeline.  side[]: four unmasked side streams of the event-driven layout.
 // Persistent layout (partitioned != 0): rs / ts[] are bound to two disjoint CU sets (hipExtStreamCreateWithCUMask); ONE

@@ -1,8 +1,12 @@
 #!/bin/bash
-# Diagnostic variant of libfmx.so: fmx_front.hip rebuilt with extra -D flags, the other objects as built.
-#   tools/build_variant.sh <tag> -DFMX_FRONT_VALU_FIR=1 ...   ->  sdr-j-fm_amd/lib/ab/libfmx_<tag>.so   (run with FMX_LIB=...)
-R=$(cd $(dirname $0)/.. && pwd); L=$R/sdr-j-fm_amd/lib; TAG=$1; shift
+# Diagnostic variant of libfmx.so: one source rebuilt with extra -D flags, the other objects as built.
+#   tools/build_variant.sh <tag> <source stem, e.g. fmx_front2> -DF2_ABL=1 ...   ->  sdr-j-fm_amd/lib/ab/libfmx_<tag>.so   (run with FMX_LIB=...)
+R=$(cd $(dirname $0)/.. && pwd); L=$R/sdr-j-fm_amd/lib; TAG=$1; SRC=$2; shift; shift
 mkdir -p $L/ab
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $R/sdr-j-fm_amd/csrc/fmx_front.hip -o $L/ab/front_$TAG.o || exit 1
-hipcc --offload-arch=gfx950 -shared -fPIC -o $L/ab/libfmx_$TAG.so $L/ab/front_$TAG.o $L/fmx_demod.o $L/fmx_stageb.o $L/fmx_audio.o $L/fmx_rds.o $L/fmx_api.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $R/sdr-j-fm_amd/csrc/$SRC.hip -o $L/ab/${SRC}_$TAG.o || exit 1
+OBJS=""
+for o in fmx_front fmx_front2 fmx_demod fmx_stageb fmx_audio fmx_rds fmx_api; do
+  if [ $o = $SRC ]; then OBJS="$OBJS $L/ab/${SRC}_$TAG.o"; else OBJS="$OBJS $L/$o.o"; fi
+done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $L/ab/libfmx_$TAG.so $OBJS
 echo $L/ab/libfmx_$TAG.so
