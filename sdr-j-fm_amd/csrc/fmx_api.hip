@@ -541,9 +541,11 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     g_launch_err = hipSuccess;
     h->B.lin_rows = h->fused ? (int32_t)h->work_nj : 0;
     {
-        // Stage A layout: wave pairs + matrix FIR (fmx_front2.hip) once the batch fills the GPU with four-channel workgroups,
-        // four waves per channel (fmx_front.hip) below that.  FMX_FRONT=classic|pairs forces one.
-        static const char *fe = getenv("FMX_FRONT");
+        // Stage A layout: four waves per channel with the packed-FMA FIR (fmx_front.hip).  FMX_FRONT=pairs selects the
+        // producer / consumer wave pairs with the FIR as f32 matrix instructions (fmx_front2.hip): parity-equal, measured
+        // slower (2.3 against 2.04 ms per launch at 4096 channels) because on gfx950 a wave streaming MFMAs leaves the other
+        // wave of its SIMD one VALU issue per matrix instruction (tools/ubench/mfma_valu_share.hip) -- DESIGN.md section 3.1.
+        const char *fe = getenv("FMX_FRONT");
         bool pairs = fe ? std::string(fe) == "pairs" : false;             // (measured slower than the classic layout so far: opt-in)
         int ntab = 1, lo_cap = 0;
         if (pairs) {

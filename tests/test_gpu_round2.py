@@ -316,3 +316,37 @@ def test_full_size_config3_shared_wideband_streams(fmx_amd, ol):
         e = rms(pcm[c][:m] - want)
         assert e <= 1e-5, (c, lo[c], e)
     assert rms(pcm[0][-4800:]) > 1e-3
+
+
+def test_front_pairs_layout_matches_classic_and_oracle(fmx_amd, ol, monkeypatch):
+    """The opt-in stage-A layout of fmx_front2.hip (FMX_FRONT=pairs: producer / consumer wave pairs, the polyphase FIR as
+    v_mfma_f32_16x16x4_f32 in Toeplitz form) against the default four-waves-per-channel kernel and the oracle: six channels
+    (two workgroups, the second half empty) on two streams, DC offset, an LO shift on one channel, calls of uneven length
+    (partial first / last tiles), input filter on."""
+    nch = 6
+    blocks = [16384 * 3, 16384 * 5 + 12 * 77 + 5, 1200, 16384 * 9, 230400]
+    n = sum(blocks)
+    iq = np.stack([ol.synth_iq(n), ol.synth_iq(n, stereo=0)], axis=0)
+    iq[0, :, 0] += 0.004; iq[0, :, 1] -= 0.003              # a DC offset the RF DC removal has to track
+    res = {}
+    for layout in ("classic", "pairs"):
+        monkeypatch.setenv("FMX_FRONT", layout)
+        f = fmx_amd.Fmx(nch, streams=2, stream_of_channel=[c % 2 for c in range(nch)], max_block=max(blocks))
+        gui_defaults(f)
+        f.set_param(M.P_LOCAL_OSCILLATOR, 200000, 5)
+        pcm, pos = [], 0
+        for b in blocks:
+            pcm.append(f.process_host(np.ascontiguousarray(iq[:, pos:pos + b]))); pos += b
+        f.synchronize()
+        res[layout] = (np.concatenate(pcm, axis=1), f.tap(M.TAP_FM_IQ, 4000, 0), f.tap(M.TAP_FM_IQ, 4000, 5))
+    monkeypatch.delenv("FMX_FRONT")
+    pa, za, wa = res["classic"]; pb, zb, wb = res["pairs"]
+    assert pa.shape == pb.shape
+    for c in range(nch):
+        assert rms(pa[c] - pb[c]) <= 2e-6, (c, rms(pa[c] - pb[c]))
+    assert rms(za - zb) <= 2e-6 * rms(za) and rms(wa - wb) <= 5e-7      # the fm-rate ring: summation order only (channel 5 is shifted out of its band: residue)
+    assert np.array_equal(pb[0], pb[2]) and np.array_equal(pb[0], pb[4])                     # same stream, same settings
+    ch = ol.OracleChain(inputFilterBw=165000)
+    pcm_o = ch.process(iq[0])
+    m = min(pb.shape[1], pcm_o.shape[0])                     # (the oracle works in the reference's 16384-sample blocks: its tail is still pending)
+    assert m > 10000 and rms(pb[0][:m] - pcm_o[:m]) <= PCM_RMS_TOL
