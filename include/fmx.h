@@ -50,7 +50,8 @@ typedef struct {
     int32_t inputRate;         /* 2304000 (fm-constants.h:35); the only rate this build accepts */
     int32_t fmRate;            /* 192000 */
     int32_t workingRate;       /* 48000 */
-    int32_t audioRate;         /* 48000 (== workingRate: sendSampletoOutput's direct path, :826-829) */
+    int32_t audioRate;         /* 48000 = workingRate: sendSampletoOutput's direct path (:826-829); any other rate in 8000 .. 192000
+                                  with audioRate / gcd <= 640 runs the second converter (theConverter :89-91, :830-837; main.cpp:57-65 -m) */
     int32_t max_block;         /* max complex samples per stream per call (reference block = 16384, :374) */
 } fmx_config;
 

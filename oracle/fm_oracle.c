@@ -688,6 +688,63 @@ static int resampler_push(resampler *r, c32 v, c32 *out) {
     return 1;
 }
 
+/* ---------- second converter (sendSampletoOutput fm-processor.cpp:825-838: theConverter (workingRate, audioRate, ...), again
+ * libsamplerate in the reference, again the documented fmx design here): rational resampler p / q = audioRate / workingRate,
+ * polyphase Kaiser (beta 9) windowed sinc, cut-off 0.92 of the lower Nyquist rate, nt = 32 max (1, ceil (q / p)) taps per phase;
+ * output m = sum_k taps[(m q) mod p][k] x[floor (m q / p) - k], produced as soon as its newest input exists. */
+static int32_t gcd32(int32_t a, int32_t b) { while (b) { int32_t t = a % b; a = b; b = t; } return a; }
+int fmo_conv2_design(int32_t inRate, int32_t outRate, int32_t *pp, int32_t *pq, int32_t *pnt, float *taps /* [p][nt], may be NULL */) {
+    const int32_t g = gcd32(inRate, outRate), p = outRate / g, q = inRate / g;
+    int32_t nt = 32 * ((q + p - 1) / p > 1 ? (q + p - 1) / p : 1);
+    if (nt > FMO_CONV2_MAXNT) nt = FMO_CONV2_MAXNT;
+    *pp = p; *pq = q; *pnt = nt;
+    if (p > FMO_CONV2_MAXP) return -1;
+    if (!taps) return 0;
+    const long N = (long)nt * p;
+    const double beta = 9.0, fc = 0.5 * 0.92 / (double)(p > q ? p : q), c = (N - 1) / 2.0;
+    double *h = (double *)malloc(sizeof(double) * (size_t)N), sum = 0;
+    for (long i = 0; i < N; i++) {
+        const double t = i - c, x = 2.0 * i / (N - 1) - 1.0;
+        const double w = bessel_i0(beta * sqrt(1.0 - x * x)) / bessel_i0(beta);
+        const double sv = (t == 0.0) ? 2 * fc : sin(2 * M_PI * fc * t) / (M_PI * t);
+        h[i] = sv * w; sum += h[i];
+    }
+    for (int32_t ph = 0; ph < p; ph++)
+        for (int32_t k = 0; k < nt; k++) taps[(size_t)ph * nt + k] = (float)(h[(long)k * p + ph] * (double)p / sum);
+    free(h);
+    return 0;
+}
+typedef struct { int32_t p, q, nt; float *taps; c32 hist[FMO_CONV2_MAXNT]; int pos; long in_count, out_count; } conv2;
+static void conv2_init(conv2 *r, int32_t inRate, int32_t outRate) {
+    memset(r, 0, sizeof(*r));
+    fmo_conv2_design(inRate, outRate, &r->p, &r->q, &r->nt, NULL);
+    r->taps = (float *)malloc(sizeof(float) * (size_t)r->p * (size_t)r->nt);
+    fmo_conv2_design(inRate, outRate, &r->p, &r->q, &r->nt, r->taps);
+}
+/* push one input frame; writes the output frames that became computable, returns their number */
+static int conv2_push(conv2 *r, c32 v, c32 *out, int cap) {
+    r->hist[r->pos] = v;
+    const int newest = r->pos;
+    r->pos = (r->pos + 1) % FMO_CONV2_MAXNT;
+    r->in_count++;
+    int n = 0;
+    while ((long long)r->out_count * r->q < (long long)r->in_count * r->p && n < cap) {
+        const long long mq = (long long)r->out_count * r->q;
+        const long n0 = (long)(mq / r->p); const int ph = (int)(mq - (long long)n0 * r->p);
+        const int back = (int)(r->in_count - 1 - n0);            /* newest input is in_count - 1 */
+        const float *t = r->taps + (size_t)ph * r->nt;
+        float ar = 0, ai = 0;
+        for (int k = 0; k < r->nt; k++) {
+            if (n0 - k < 0) break;
+            int j = newest - back - k; j %= FMO_CONV2_MAXNT; if (j < 0) j += FMO_CONV2_MAXNT;
+            ar += t[k] * r->hist[j].re; ai += t[k] * r->hist[j].im;
+        }
+        out[n++] = C(ar, ai);
+        r->out_count++;
+    }
+    return n;
+}
+
 /* ------------------------------------------------------------------ RDS decoder 2 */
 #define RDS_MF_TAPS 45
 typedef struct {
@@ -1159,6 +1216,7 @@ struct fmo_chain {
     fmo_pilot *pilot; fmo_pss *pss;
     fmo_demod *demod;
     float *rdsPhaseBuffer; int rdsPhaseIndex;
+    conv2 cv2; int cv2On;                                                /* theConverter (fm-processor.cpp:89-91): audioRate != workingRate */
     fmo_squelch sq; int sqOldValue;                                      /* mySquelch, oldSquelchValue (fm-processor.cpp:87,195) */
     int newAudioFilter, inputFilterOn, newInputFilter, audioFilterActive;
     int32_t lowPassFrequency, fmBandwidth;
@@ -1269,6 +1327,8 @@ fmo_chain *fmo_chain_new(const fmo_config *c) {
     ch->deemphAlpha = (float)(1.0 / (fmRate / (1000000.0 / 50.0 + 1)));
     ch->rdsDecim = fmo_decim_new(11, 24000 / 2, fmRate, fmRate / 24000);
     resampler_init(&ch->rs);
+    ch->cv2On = ch->cfg.audioRate != ch->cfg.workingRate;
+    if (ch->cv2On) conv2_init(&ch->cv2, ch->cfg.workingRate, ch->cfg.audioRate);
     rds2_init(&ch->rds, 24000); rds1_init(&ch->rdsA, 24000); rds3_init(&ch->rdsC, 24000);
     ch->rdsBitCap = 1 << 16; ch->rdsBits = (uint8_t *)malloc((size_t)ch->rdsBitCap);
     ch->pending = (c32 *)malloc(sizeof(c32) * BLOCK);
@@ -1499,8 +1559,15 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
                 }
                 insert_test_tone(ch, &p);
                 evaluate_peak(ch, p);
-                if (nout < cap) { pcm[2 * nout] = p.re; pcm[2 * nout + 1] = p.im; }
-                nout++; ch->pcmCount++;
+                if (!ch->cv2On) {                                /* sendSampletoOutput :825-838 */
+                    if (nout < cap) { pcm[2 * nout] = p.re; pcm[2 * nout + 1] = p.im; }
+                    nout++;
+                } else {
+                    c32 o2[FMO_CONV2_MAXP / 16 + 8];
+                    const int n2 = conv2_push(&ch->cv2, p, o2, (int)(sizeof(o2) / sizeof(o2[0])));
+                    for (int i2 = 0; i2 < n2; i2++) { if (nout < cap) { pcm[2 * nout] = o2[i2].re; pcm[2 * nout + 1] = o2[i2].im; } nout++; }
+                }
+                ch->pcmCount++;
             }
             ch->rsInp = 0;
         }

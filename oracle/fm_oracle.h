@@ -176,6 +176,10 @@ void fmo_pilot_constants(int32_t fmRate, float *omega, float *gain, float *pssAl
 /* ---------- fmx resampler (own design; replaces libsamplerate, see header note) ---------- */
 #define FMO_RS_TAPS 128
 void fmo_resampler_taps(float *h /* FMO_RS_TAPS */);
+/* second converter workingRate -> audioRate (fm-processor.cpp:89-91, 825-838; own design like the first): p / q, taps per phase */
+#define FMO_CONV2_MAXP 640
+#define FMO_CONV2_MAXNT 256
+int fmo_conv2_design(int32_t inRate, int32_t outRate, int32_t *p, int32_t *q, int32_t *nt, float *taps /* [p][nt] or NULL */);
 
 /* ---------- whole chain (fm-processor.cpp:373-759,772-838) ---------- */
 typedef struct {

@@ -95,6 +95,8 @@ struct fmx_handle_s {
     int pitch = 0;                           // their row pitch in elements
     // staging for the host-pointer entry point
     float2 *d_iq = nullptr, *d_pcm = nullptr; int64_t pcm_cap = 0;
+    // second converter (audioRate != workingRate, fm-processor.cpp:89-91,825-838)
+    int cv_p = 1, cv_q = 1, cv_nt = 0; float *d_cv_taps = nullptr; float2 *d_x48 = nullptr; int64_t x48_stride = 0;
     // profiling
     bool prof_on = false; std::vector<ProfRec> prof; fmx_profile prof_acc{};
     int64_t last_J0 = 0, last_J1 = 0;
@@ -510,6 +512,8 @@ void frames_geom(const fmx_handle h, int64_t n, CallGeom *G) {
     // newConverter: 192 frames in -> 48 out (newconverter.cpp:55-80, inputLimit = fmRate/1000)
     G->M0 = 48 * (G->J0 / 192); G->M1 = 48 * (G->J1 / 192);
 }
+// frames the second converter has put out after `in` frames at the working rate: outputs m with m q < in p
+int64_t conv2_out(const fmx_handle h, int64_t in) { return h->cv_nt ? (in * h->cv_p + h->cv_q - 1) / h->cv_q : in; }
 
 int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
              int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
@@ -528,7 +532,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     G.ring_mask = h->ring - 1; G.dring_mask = h->dring - 1; G.sring_mask = h->sring - 1;
     G.input_rate = h->cfg.inputRate; G.pitch = h->pitch; G.pad_ = 0; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
     G.iq_format = fmt; G.iq_scale = (fmt == 3) ? 1.0f / s16_den : 1.0f / 128.0f;
-    const int64_t frames = G.M1 - G.M0;
+    const int64_t frames = conv2_out(h, G.M1) - conv2_out(h, G.M0);
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
     if (h->rds_alloc && h->rds_start >= 0 && G.J1 - G.J0 > RDS_BLK)
         return fail(FMX_E_TOO_LARGE, "with RDS on, a call may cover at most 32000 fm samples (384000 input samples)");
@@ -586,7 +590,14 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     }
     if (prof) HIPCHK(hipEventRecord(pr.e[2], s));
     if (h->gain_dirty && G.M1 > G.M0) { G.gain_fix = 1; launch_gain_fix(h->T, h->B, G, h->channels, s); FMX_LAUNCHED(); h->gain_dirty = false; }
-    launch_audio(h->T, h->B, G, d_pcm, h->channels, s);
+    if (!h->cv_nt) launch_audio(h->T, h->B, G, d_pcm, h->channels, s);
+    else {
+        // the audio stage writes its 48 kHz frames behind the converter's history; theConverter's output goes to the caller
+        CallGeom G48 = G; G48.pcm_stride = h->x48_stride;
+        launch_audio(h->T, h->B, G48, h->d_x48 + h->cv_nt, h->channels, s);
+        launch_conv2(h->d_x48, h->x48_stride, h->d_cv_taps, h->cv_p, h->cv_q, h->cv_nt, G.M0, G.M1 - G.M0, conv2_out(h, G.M0), frames,
+                     d_pcm, pcm_stride, h->channels, s);
+    }
     if (prof) { HIPCHK(hipEventRecord(pr.e[3], s)); h->prof.push_back(pr); }
     FMX_LAUNCHED();
     HIPCHK(g_launch_err);
@@ -647,8 +658,14 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     if (!cfg || !out) return fail(FMX_E_INVALID, "null argument");
     if (cfg->struct_size != (int32_t)sizeof(fmx_config)) return fail(FMX_E_INVALID, "fmx_config.struct_size mismatch");
     if (cfg->channels < 1) return fail(FMX_E_INVALID, "channels must be >= 1");
-    if (cfg->inputRate != 2304000 || cfg->fmRate != 192000 || cfg->workingRate != 48000 || cfg->audioRate != 48000)
-        return fail(FMX_E_UNSUPPORTED, "this build implements inputRate 2304000 / fmRate 192000 / workingRate = audioRate 48000");
+    if (cfg->inputRate != 2304000 || cfg->fmRate != 192000 || cfg->workingRate != 48000)
+        return fail(FMX_E_UNSUPPORTED, "this build implements inputRate 2304000 / fmRate 192000 / workingRate 48000");
+    std::vector<float> cv_taps; int cv_p = 1, cv_q = 1, cv_nt = 0;
+    if (cfg->audioRate != cfg->workingRate) {
+        if (cfg->audioRate < 8000 || cfg->audioRate > 192000 ||
+            !design::design_conv2(cfg->workingRate, cfg->audioRate, &cv_p, &cv_q, &cv_nt, &cv_taps))
+            return fail(FMX_E_UNSUPPORTED, "audioRate: 8000 .. 192000 with audioRate / gcd (audioRate, workingRate) <= 640 (the second converter's phases)");
+    }
     if (cfg->max_block < 12 || cfg->max_block > (1 << 20)) return fail(FMX_E_INVALID, "max_block must be in [12, 1048576]");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -664,6 +681,14 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     h->never_fused = getenv("FMX_STAGE_B") && std::string(getenv("FMX_STAGE_B")) == "chunked";
     h->channels = cfg->channels;
     h->streams = cfg->streams > 0 ? cfg->streams : cfg->channels;
+    if (cv_nt) {
+        h->cv_p = cv_p; h->cv_q = cv_q; h->cv_nt = cv_nt;
+        h->x48_stride = cv_nt + cfg->max_block / 48 + 96;
+        HIPCHK(hipMalloc(&h->d_cv_taps, sizeof(float) * cv_taps.size()));
+        HIPCHK(hipMemcpy(h->d_cv_taps, cv_taps.data(), sizeof(float) * cv_taps.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&h->d_x48, sizeof(float2) * (size_t)h->channels * h->x48_stride));
+        HIPCHK(hipMemset(h->d_x48, 0, sizeof(float2) * (size_t)h->channels * h->x48_stride));
+    }
     h->user.assign(h->channels, ChanUser());
     h->params.assign(h->channels, ChanParams());
     for (int c = 0; c < h->channels; c++) {
@@ -923,7 +948,7 @@ int fmx_destroy(fmx_handle h) {
     void *ptrs[] = { h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
                      h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
-                     h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x, h->B.w_lockm };
+                     h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x, h->B.w_lockm, h->d_cv_taps, h->d_x48 };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
     for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);
@@ -1025,7 +1050,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
 int64_t fmx_frames_for(fmx_handle h, int64_t n) {
     if (!h || n < 0) return -1;
     CallGeom G{}; frames_geom(h, n, &G);
-    return G.M1 - G.M0;
+    return conv2_out(h, G.M1) - conv2_out(h, G.M0);
 }
 
 static int bytes_per_sample(int32_t fmt) { return fmt == FMX_IQ_F32 ? 8 : (fmt == FMX_IQ_S16 ? 4 : 2); }
@@ -1058,7 +1083,7 @@ int fmx_process_host_raw(fmx_handle h, const void *iq, int32_t format, float s16
     if (stream_stride < n) return fail(FMX_E_INVALID, "stream_stride < n_complex");
     if (n <= 0 || n > h->cfg.max_block) return fail(FMX_E_TOO_LARGE, "n_complex must be in [1, max_block]");
     HIPCHK(hipSetDevice(h->cfg.device));
-    const int64_t cap = h->cfg.max_block / 48 + 96;
+    const int64_t cap = conv2_out(h, h->cfg.max_block / 48 + 96) + 2;
     if (!h->d_iq) {
         HIPCHK(hipMalloc(&h->d_iq, sizeof(float2) * (size_t)h->streams * h->cfg.max_block));    // sized for the widest format
         HIPCHK(hipMalloc(&h->d_pcm, sizeof(float2) * (size_t)h->channels * cap));
@@ -1103,7 +1128,7 @@ int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
     m->live_pilot_locked = (h->params[channel].fm_mode != 2) ? st.pil_locked : 0;
     m->live_lock_strength = (h->params[channel].fm_mode != 2) ? st.pil_lock : 0.f;
     m->live_dc_if = st.fm_afc; m->squelch_active = (h->params[channel].squelch_mode != 0) ? st.sq_suppress : 0;
-    m->fm_samples = h->g_total / DECIM; m->pcm_frames = 48 * ((h->g_total / DECIM) / 192);
+    m->fm_samples = h->g_total / DECIM; m->pcm_frames = conv2_out(h, 48 * ((h->g_total / DECIM) / 192));
     return FMX_OK;
 }
 

@@ -382,4 +382,42 @@ void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
     hipLaunchKernelGGL(pcm_tail_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, B, G, channels);
 }
 
+// ---- second converter (sendSampletoOutput fm-processor.cpp:825-838 with audioRate != workingRate; design::design_conv2): one
+// thread per output frame, out[m] = sum_k taps[(m q) mod p][k] x[floor (m q / p) - k] in the oracle's order (k ascending,
+// unfused).  x = the 48 kHz frames of this call behind the nt frames in front of them (x48[ch][nt + i], i relative to the call).
+__global__ __launch_bounds__(256) void conv2_kernel(const float2 *__restrict__ x48, int64_t x_stride, const float *__restrict__ taps,
+                                                    int p, int q, int nt, int64_t in0, int64_t out0, int64_t nout,
+                                                    float2 *__restrict__ pcm, int64_t pcm_stride) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nout) return;
+    const int ch = blockIdx.y;
+    const int64_t mq = (out0 + i) * q, n0 = mq / p;
+    const int ph = (int)(mq - n0 * p);
+    const float *t = taps + (size_t)ph * nt;
+    const float2 *x = x48 + (size_t)ch * x_stride + nt + (n0 - in0);       // x[-k] = frame n0 - k
+    float ar = 0.f, ai = 0.f;
+    for (int k = 0; k < nt; k++) {
+        if (n0 - k < 0) break;                                             // in front of the stream: nothing
+        const float2 v = x[-k];
+        ar = __fadd_rn(ar, __fmul_rn(t[k], v.x)); ai = __fadd_rn(ai, __fmul_rn(t[k], v.y));
+    }
+    pcm[(size_t)ch * pcm_stride + i] = make_float2(ar, ai);
+}
+// the last nt frames of the call become the history in front of the next one (one block per channel)
+__global__ __launch_bounds__(256) void conv2_shift_kernel(float2 *x48, int64_t x_stride, int nt, int64_t frames) {
+    float2 *x = x48 + (size_t)blockIdx.x * x_stride;
+    const int t = threadIdx.x;
+    float2 v = make_float2(0.f, 0.f);
+    if (t < nt) v = x[frames + t];
+    __syncthreads();
+    if (t < nt) x[t] = v;
+}
+void launch_conv2(float2 *x48, int64_t x_stride, const float *taps, int p, int q, int nt, int64_t in0, int64_t frames_in,
+                  int64_t out0, int64_t nout, float2 *pcm, int64_t pcm_stride, int channels, hipStream_t s) {
+    if (nout > 0)
+        hipLaunchKernelGGL(conv2_kernel, dim3((unsigned)((nout + 255) / 256), channels), dim3(256), 0, s, x48, x_stride, taps, p, q, nt,
+                           in0, out0, nout, pcm, pcm_stride);
+    if (frames_in > 0) hipLaunchKernelGGL(conv2_shift_kernel, dim3(channels), dim3(256), 0, s, x48, x_stride, nt, frames_in);
+}
+
 }  // namespace fmx

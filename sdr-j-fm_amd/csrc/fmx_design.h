@@ -251,5 +251,32 @@ inline std::vector<float> rds1_match_kernel(int32_t rate) {
     }
     return k;
 }
+// Second converter workingRate -> audioRate (sendSampletoOutput fm-processor.cpp:825-838, theConverter :89-91: libsamplerate in
+// the reference; the fmx design here, the same as the oracle's fmo_conv2_design): rational resampler p / q = audioRate /
+// workingRate, polyphase Kaiser (beta 9) windowed sinc, cut-off 0.92 of the lower Nyquist rate, nt = 32 max (1, ceil (q / p))
+// taps per phase; out[m] = sum_k taps[(m q) mod p][k] x[floor (m q / p) - k].
+constexpr int CONV2_MAXP = 640, CONV2_MAXNT = 256;
+inline bool design_conv2(int inRate, int outRate, int *pp, int *pq, int *pnt, std::vector<float> *taps) {
+    int a = inRate, b = outRate; while (b) { const int t = a % b; a = b; b = t; }
+    const int p = outRate / a, q = inRate / a;
+    int nt = 32 * std::max(1, (q + p - 1) / p);
+    if (nt > CONV2_MAXNT) nt = CONV2_MAXNT;
+    *pp = p; *pq = q; *pnt = nt;
+    if (p > CONV2_MAXP) return false;
+    const long N = (long)nt * p;
+    const double beta = 9.0, fc = 0.5 * 0.92 / (double)std::max(p, q), c = (N - 1) / 2.0;
+    std::vector<double> h((size_t)N); double sum = 0;
+    for (long i = 0; i < N; i++) {
+        const double t = i - c, x = 2.0 * i / (N - 1) - 1.0;
+        const double w = bessel_i0(beta * std::sqrt(1.0 - x * x)) / bessel_i0(beta);
+        const double sv = (t == 0.0) ? 2 * fc : std::sin(2 * kPi * fc * t) / (kPi * t);
+        h[(size_t)i] = sv * w; sum += h[(size_t)i];
+    }
+    taps->assign((size_t)p * nt, 0.f);
+    for (int ph = 0; ph < p; ph++)
+        for (int k = 0; k < nt; k++) (*taps)[(size_t)ph * nt + k] = (float)(h[(size_t)((long)k * p + ph)] * (double)p / sum);
+    return true;
+}
 }  // namespace design
+
 }  // namespace fmx

@@ -333,6 +333,10 @@ void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
 void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,
                   int channels, hipStream_t s);
+// second converter workingRate -> audioRate (fm-processor.cpp:825-838): x48 = [channels][x_stride] with nt history frames in front of
+// the call's frames_in 48 kHz frames; writes output frames out0 .. out0 + nout - 1, then moves the history up
+void launch_conv2(float2 *x48, int64_t x_stride, const float *taps, int p, int q, int nt, int64_t in0, int64_t frames_in,
+                  int64_t out0, int64_t nout, float2 *pcm, int64_t pcm_stride, int channels, hipStream_t s);
 // before launch_audio of a call in front of which volume / balance may have changed (and of the first call)
 void launch_gain_fix(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
 

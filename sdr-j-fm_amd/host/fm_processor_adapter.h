@@ -11,6 +11,7 @@
 // poll_meta(); see INTEGRATION.md.  Header-only; links against libfmx.so only.
 #pragma once
 #include <atomic>
+#include <algorithm>
 #include <complex>
 #include <cstdint>
 #include <cstdlib>
@@ -58,7 +59,7 @@ public:
         c.max_block = bufferSize;
         check(fmx_create(&c, &h));
         inBuf.resize(bufferSize);
-        outBuf.resize(bufferSize / 48 + 64);
+        outBuf.resize((size_t)((int64_t)(bufferSize / 48 + 64) * std::max(audioRate, workingRate) / workingRate + 8));   // second converter: audioRate / workingRate frames per 48 kHz frame
     }
     ~FmProcessor() { stop(); if (h) fmx_destroy(h); }
     FmProcessor(const FmProcessor &) = delete;

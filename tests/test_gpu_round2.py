@@ -350,3 +350,35 @@ def test_front_pairs_layout_matches_classic_and_oracle(fmx_amd, ol, monkeypatch)
     pcm_o = ch.process(iq[0])
     m = min(pb.shape[1], pcm_o.shape[0])                     # (the oracle works in the reference's 16384-sample blocks: its tail is still pending)
     assert m > 10000 and rms(pb[0][:m] - pcm_o[:m]) <= PCM_RMS_TOL
+
+
+@pytest.mark.parametrize("audio_rate", [44100, 96000, 32000])
+def test_second_converter_audio_rate(fmx_amd, ol, audio_rate):
+    """audioRate != workingRate (main.cpp:57-65 -m; theConverter fm-processor.cpp:89-91, sendSampletoOutput :825-838): the 48 kHz
+    frames go through the second converter -- like the first one libsamplerate in the reference, the documented fmx design
+    (p / q polyphase Kaiser sinc) in the oracle and on the GPU.  Frame counts call by call and PCM against the oracle."""
+    blocks = [16384 * 4, 16384 * 4 + 12 * 100, 230400, 16384 * 3, 16384 * 5 - 1200]
+    n = sum(blocks)
+    iq = ol.synth_iq(n)
+    ch = ol.OracleChain(inputFilterBw=165000, audioRate=audio_rate)
+    pcm_o = ch.process(iq)
+    f = fmx_amd.Fmx(2, streams=1, stream_of_channel=[0, 0], max_block=max(blocks), audioRate=audio_rate)
+    gui_defaults(f)
+    f.set_param(M.P_VOLUME_DB, -12.0, 1)                 # channel 1 six dB down: the converter is linear and per channel
+    outs, pos = [], 0
+    for b in blocks:
+        want = f.frames_for(b)
+        o = f.process_host(iq[pos:pos + b]); pos += b
+        assert o.shape[1] == want
+        outs.append(o)
+    pcm_g = np.concatenate(outs, axis=1)
+    g = int(np.gcd(48000, audio_rate)); p_, q_ = audio_rate // g, 48000 // g
+    frames48 = 48 * ((n // 12) // 192)
+    assert pcm_g.shape[1] == (frames48 * p_ + q_ - 1) // q_ == f.meta(0).pcm_frames
+    m = min(pcm_g.shape[1], pcm_o.shape[0])
+    assert m > 0.9 * pcm_g.shape[1]
+    e = rms(pcm_g[0][:m] - pcm_o[:m])
+    print(f"\n[second converter {audio_rate}] {pcm_g.shape[1]} frames, rms diff vs oracle {e:.3e} (signal {rms(pcm_o):.3f})")
+    assert e <= PCM_RMS_TOL and rms(pcm_o[m // 2:m]) > 0.01
+    k = 10.0 ** (-6.0 / 20.0)
+    assert rms(pcm_g[1]) > 0.005 and rms(pcm_g[1] - k * pcm_g[0]) <= 1e-6

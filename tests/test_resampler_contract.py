@@ -50,3 +50,31 @@ def test_resampler_numeric_contract():
     sel = f[:-1] <= 15000
     assert abs(gd[sel].min() - 63.5) < 1e-6 and abs(gd[sel].max() - 63.5) < 1e-6   # constant group delay: 15.875 frames at 48 kHz
 
+
+
+def test_second_converter_design():
+    """fmo_conv2_design (the oracle's and, expression for expression, the library's design::design_conv2): p / q, taps per phase,
+    unity DC gain of every phase, the prototype below -80 dB where images / aliases of the 15 kHz audio band fall (and from 8 %
+    above the lower Nyquist rate on when that is higher), flat over the audio band."""
+    import ctypes as C
+    import numpy as np
+    import oracle_lib as ol
+    L = ol.oracle()
+    L.fmo_conv2_design.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+    L.fmo_conv2_design.restype = C.c_int
+    for rate, want in ((44100, (147, 160, 64)), (96000, (2, 1, 32)), (32000, (2, 3, 64)), (22050, (147, 320, 96))):
+        p, q, nt = C.c_int32(), C.c_int32(), C.c_int32()
+        assert L.fmo_conv2_design(48000, rate, C.byref(p), C.byref(q), C.byref(nt), None) == 0
+        assert (p.value, q.value, nt.value) == want
+        taps = np.zeros(p.value * nt.value, np.float32)
+        assert L.fmo_conv2_design(48000, rate, C.byref(p), C.byref(q), C.byref(nt), taps.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        t = taps.reshape(p.value, nt.value).astype(np.float64)
+        assert np.max(np.abs(t.sum(axis=1) - 1.0)) < 2e-3                     # every phase passes DC with gain 1
+        proto = np.zeros(p.value * nt.value); proto[:] = t.T.reshape(-1) / p.value      # h[k p + ph]
+        H = np.abs(np.fft.rfft(proto, 1 << 18))
+        fgrid = np.arange(H.size) / float(1 << 18) * p.value * 48000.0        # prototype runs at p * 48 kHz
+        lo = min(rate, 48000)
+        stop = fgrid >= max(0.54 * lo, lo - 15000.0)
+        assert 20 * np.log10(H[stop].max() / H[0]) < -80.0
+        passb = fgrid <= min(15000.0, 0.4 * lo)
+        assert np.max(np.abs(20 * np.log10(H[passb] / H[0]))) < 0.05          # flat over the 15 kHz audio band
