@@ -1,0 +1,142 @@
+// file_source.h -- the file input of BASELINE configs[0] ("filereader .wav @ 2.304 MS/s") as a deviceHandler-shaped C++ source
+// with the behaviour of the reference's fileHulp (devices/filereader/filehulp.cpp), real-time pacing included:
+//   * rate and channel count come from the header (:61-63); 2 channels = (I, Q), 1 channel = I with Q = 0 (:127-137);
+//   * samples are what libsndfile's sf_readf_float returns: PCM16 / 32768, PCM8 (unsigned) (v - 128) / 128, PCM32 / 2^31,
+//     float32 as is -- parsed here from RIFF/WAVE directly (libsndfile is not in the image);
+//   * a reader thread (:159-202) moves 10 ms of samples (2 * rate / 100 floats) per 10 ms period into a ring of 32768 * 32
+//     floats (:30), waits while the ring is full, pauses while the reader is stopped (restartReader / stopReader :83-92; it
+//     starts PAUSED, :67), and sleeps until the next period's deadline: the file plays at its own sample rate;
+//   * at end of file it seeks back to the start and goes on; the short read is NOT padded (:141-143); a read of nothing is a
+//     period of zeros (:187-191);
+//   * Samples () = complex samples in the ring (:94-98); getSamples (V, n, attenuation) blocks in 100 us naps until n are there
+//     and multiplies by the attenuation (:100-119).
+// `realtime = false` drops only the deadline sleep (tests, batch conversion): everything else is the same code path.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fm_processor_adapter.h"
+
+namespace fmx_host {
+
+class FileSource : public DeviceHandler {
+public:
+    FileSource(const std::string &path, bool *success, bool realtime = true) : realtime_(realtime), ring_(kRing) {
+        *success = parse(path);
+        readerOK_ = *success;
+        if (readerOK_) worker_ = std::thread([this] { run(); });
+    }
+    ~FileSource() override {
+        exit_ = true;
+        if (worker_.joinable()) worker_.join();
+    }
+    bool restartReader() { if (readerOK_) pausing_ = false; return readerOK_; }
+    void stopReader() { if (readerOK_) pausing_ = true; }
+    bool isWorking() const { return readerOK_; }
+    int32_t getRate() override { return inputRate_; }
+    int64_t samplesinFile() const { return frames_; }
+    int64_t currPos() const { return currPos_; }
+    int32_t Samples() override { return exit_ ? 0 : (int32_t)(avail() / 2); }
+    int32_t getSamples(std::complex<float> *V, int32_t n) override { return getSamples(V, n, 1.0f); }
+    int32_t getSamples(std::complex<float> *V, int32_t n, float attenuation) {
+        while (!exit_ && avail() < (size_t)(2 * n)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        if (exit_) return 0;
+        size_t r = rd_.load(std::memory_order_relaxed);
+        for (int32_t i = 0; i < n; i++) {
+            V[i] = std::complex<float>(ring_[r % kRing] * attenuation, ring_[(r + 1) % kRing] * attenuation);
+            r += 2;
+        }
+        rd_.store(r, std::memory_order_release);
+        return n;
+    }
+
+private:
+    static constexpr size_t kRing = 32768 * 32;
+    size_t avail() const { return wr_.load(std::memory_order_acquire) - rd_.load(std::memory_order_acquire); }
+    size_t space() const { return kRing - avail(); }
+
+    bool parse(const std::string &path) {
+        FILE *f = std::fopen(path.c_str(), "rb");
+        if (!f) { std::fprintf(stderr, "file %s no legitimate sound file\n", path.c_str()); return false; }
+        std::fseek(f, 0, SEEK_END); const long bytes = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+        std::vector<uint8_t> d((size_t)std::max(0L, bytes));
+        const bool got = bytes > 12 && std::fread(d.data(), 1, d.size(), f) == d.size();
+        std::fclose(f);
+        if (!got || std::memcmp(d.data(), "RIFF", 4) != 0 || std::memcmp(d.data() + 8, "WAVE", 4) != 0) return false;
+        auto u16 = [&](size_t p) { return (uint32_t)d[p] | ((uint32_t)d[p + 1] << 8); };
+        auto u32 = [&](size_t p) { return u16(p) | (u16(p + 2) << 16); };
+        size_t pos = 12, fmt = 0, fmt_size = 0, body = 0, body_size = 0;
+        while (pos + 8 <= d.size()) {
+            const uint32_t size = u32(pos + 4);
+            if (std::memcmp(d.data() + pos, "fmt ", 4) == 0) { fmt = pos + 8; fmt_size = size; }
+            else if (std::memcmp(d.data() + pos, "data", 4) == 0) { body = pos + 8; body_size = std::min<size_t>(size, d.size() - body); break; }
+            pos += 8 + (size_t)size + (size & 1);
+        }
+        if (!fmt || !body || fmt_size < 16) return false;
+        uint32_t tag = u16(fmt); const uint32_t ch = u16(fmt + 2), bits = u16(fmt + 14);
+        if (tag == 0xFFFE && fmt_size >= 26) tag = u16(fmt + 24);          // WAVE_FORMAT_EXTENSIBLE: the sub-format's first word
+        if (ch != 1 && ch != 2) return false;
+        inputRate_ = (int32_t)u32(fmt + 4); channels_ = (int)ch;
+        const size_t bps = bits / 8, n = bps ? body_size / bps : 0;
+        data_.resize(n);
+        const uint8_t *b = d.data() + body;
+        if (tag == 1 && bits == 16) for (size_t i = 0; i < n; i++) data_[i] = (float)(int16_t)(b[2 * i] | (b[2 * i + 1] << 8)) / 32768.0f;
+        else if (tag == 1 && bits == 8) for (size_t i = 0; i < n; i++) data_[i] = ((float)b[i] - 128.0f) / 128.0f;
+        else if (tag == 1 && bits == 32) for (size_t i = 0; i < n; i++) { int32_t v; std::memcpy(&v, b + 4 * i, 4); data_[i] = (float)((double)v / 2147483648.0); }
+        else if (tag == 3 && bits == 32) std::memcpy(data_.data(), b, 4 * n);
+        else return false;
+        frames_ = (int64_t)(n / ch);
+        return frames_ > 0;
+    }
+    // filehulp.cpp:127-147: `length` floats wanted; returns the floats delivered; wraps to the start after a short read
+    int32_t readBuffer(float *out, int32_t length) {
+        const int64_t want = length / 2, left = frames_ - filePos_;
+        const int64_t n = std::min(want, left);
+        if (channels_ == 2) std::memcpy(out, data_.data() + 2 * filePos_, sizeof(float) * 2 * (size_t)n);
+        else for (int64_t i = 0; i < n; i++) { out[2 * i] = data_[(size_t)(filePos_ + i)]; out[2 * i + 1] = 0.f; }
+        filePos_ += n; currPos_ += n;
+        if (n < want) filePos_ = 0;
+        return (int32_t)(2 * n);
+    }
+    void run() {
+        using clock = std::chrono::steady_clock;
+        const auto period = std::chrono::microseconds(10000);
+        const int32_t bufferSize = 2 * inputRate_ / 100;
+        std::vector<float> bi((size_t)bufferSize);
+        auto nextStop = clock::now();
+        while (!exit_) {
+            if (pausing_) { std::this_thread::sleep_for(std::chrono::microseconds(1000)); nextStop = clock::now(); continue; }
+            while (space() < (size_t)bufferSize + 10) {
+                if (exit_) break;
+                std::this_thread::sleep_for(std::chrono::microseconds(1000));
+            }
+            if (exit_) break;
+            nextStop += period;
+            int32_t t = readBuffer(bi.data(), bufferSize);
+            if (t <= 0) { std::fill(bi.begin(), bi.end(), 0.f); t = bufferSize; }
+            size_t w = wr_.load(std::memory_order_relaxed);
+            for (int32_t i = 0; i < t; i++) ring_[(w + (size_t)i) % kRing] = bi[(size_t)i];
+            wr_.store(w + (size_t)t, std::memory_order_release);
+            if (realtime_ && nextStop > clock::now()) std::this_thread::sleep_until(nextStop);
+        }
+    }
+
+    bool realtime_, readerOK_ = false;
+    std::atomic<bool> exit_{false}, pausing_{true};
+    int32_t inputRate_ = 192000; int channels_ = 2;
+    int64_t frames_ = 0, filePos_ = 0;
+    std::atomic<int64_t> currPos_{0};
+    std::vector<float> data_, ring_;
+    std::atomic<size_t> rd_{0}, wr_{0};
+    std::thread worker_;
+};
+
+}  // namespace fmx_host

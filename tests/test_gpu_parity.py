@@ -929,7 +929,7 @@ def test_cpp_adapter_drop_in(fmx_amd, ol, tmp_path):
     import subprocess
     host = os.path.join(os.path.dirname(fmx_amd.__file__), "host")
     exe = str(tmp_path / "adapter_demo")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(host, "adapter_demo.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(host, "adapter_demo.cpp"),
                            "-L" + os.path.dirname(fmx_amd.LIB_PATH), "-lfmx",
                            "-Wl,-rpath," + os.path.dirname(fmx_amd.LIB_PATH), "-o", exe])
     n = 16384 * 80 + 1000                                  # the tail < 16384 is never pulled (fm-processor.cpp:388)

@@ -382,3 +382,28 @@ def test_second_converter_audio_rate(fmx_amd, ol, audio_rate):
     assert e <= PCM_RMS_TOL and rms(pcm_o[m // 2:m]) > 0.01
     k = 10.0 ** (-6.0 / 20.0)
     assert rms(pcm_g[1]) > 0.005 and rms(pcm_g[1] - k * pcm_g[0]) <= 1e-6
+
+
+def test_config1_cpp_file_source_realtime(fmx_amd, ol, tmp_path):
+    """BASELINE configs[0] through the C++ host side only: a PCM16 stereo .wav at 2.304 MS/s -> fmx_host::FileSource (fileHulp's
+    paced reader thread, real time ON) -> fmx_host::FmProcessor -> sink, mono FM, input filter off; PCM against the oracle fed
+    with the floats libsndfile would deliver, and the wall time of the run against the signal's duration."""
+    import os, struct, subprocess, time
+    host = os.path.join(os.path.dirname(fmx_amd.__file__), "host")
+    exe = str(tmp_path / "adapter_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(host, "adapter_demo.cpp"),
+                           "-L" + os.path.dirname(fmx_amd.LIB_PATH), "-lfmx", "-Wl,-rpath," + os.path.dirname(fmx_amd.LIB_PATH), "-o", exe])
+    blocks = 30
+    n = 16384 * blocks
+    iq = ol.synth_iq(n, stereo=0)
+    s16 = np.clip(np.round(iq * 32768.0 * 0.9), -32768, 32767).astype(np.int16)
+    body = s16.astype("<i2").tobytes()
+    with open(tmp_path / "c1.wav", "wb") as f:
+        f.write(struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(body), b"WAVE", b"fmt ", 16, 1, 2, 2304000, 2304000 * 4, 4, 16, b"data", len(body)) + body)
+    t0 = time.time()
+    subprocess.check_call([exe, str(tmp_path / "c1.wav"), str(tmp_path / "pcm.f32"), str(blocks), "1"], stdout=subprocess.DEVNULL)
+    wall = time.time() - t0
+    pcm = np.fromfile(str(tmp_path / "pcm.f32"), np.float32).reshape(-1, 2)
+    want = ol.OracleChain(inputFilterBw=0, fmMode=2).process((s16.astype(np.float32) / np.float32(32768.0)).astype(np.float32))
+    assert pcm.shape == want.shape and rms(pcm - want) <= PCM_RMS_TOL
+    assert wall >= 0.9 * n / 2304000.0                         # paced: 0.21 s of signal does not arrive faster than real time

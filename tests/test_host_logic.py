@@ -98,6 +98,8 @@ def _write_wav(path, x, rate, fmt):
     ch = x.shape[1]
     if fmt == "pcm16":
         body, tag, bits = x.astype("<i2").tobytes(), 1, 16
+    elif fmt == "pcm8":
+        body, tag, bits = x.astype(np.uint8).tobytes(), 1, 8
     else:
         body, tag, bits = x.astype("<f4").tobytes(), 3, 32
     hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(body), b"WAVE", b"fmt ", 16, tag, ch, rate,
@@ -128,6 +130,41 @@ def test_wav_file_source(tmp_path):
     mono = pkg.WavFileSource(str(tmp_path / "m.wav"))
     v = mono.getSamples(50)
     assert mono.getRate() == 192000 and np.array_equal(v[:, 0], m[:, 0]) and not v[:, 1].any()
+
+
+def test_cpp_file_source_paced_reader(tmp_path):
+    """The C++ file source (sdr-j-fm_amd/host/file_source.h) against fileHulp's behaviour (filehulp.cpp:41-202): starts paused,
+    plays at the file's own sample rate (10 ms of samples per 10 ms period), wraps at end of file without padding, attenuation,
+    mono -> Q = 0; the same samples as the Python WavFileSource."""
+    import importlib, os, subprocess, time
+    pkg = importlib.import_module("sdr-j-fm_amd")
+    host = os.path.join(os.path.dirname(pkg.__file__), "host")
+    exe = str(tmp_path / "file_source_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(host, "file_source_demo.cpp"), "-o", exe])
+    rng = np.random.default_rng(9)
+    rate = 192000
+    s = rng.integers(-20000, 20000, size=(rate // 4 + 123, 2)).astype(np.int16)        # 0.25 s and a bit: not a multiple of the 10 ms period
+    _write_wav(tmp_path / "a.wav", s, rate, "pcm16")
+    n = int(1.6 * len(s))                                                              # wraps once
+    out = subprocess.check_output([exe, str(tmp_path / "a.wav"), str(tmp_path / "o.f32"), str(n), "16384", "1", "0.5"]).decode()
+    f = dict(zip(out.split()[0::2], out.split()[1::2]))
+    got = np.fromfile(str(tmp_path / "o.f32"), np.float32).reshape(-1, 2)
+    want = pkg.WavFileSource(str(tmp_path / "a.wav"), attenuation=0.5).getSamples(n)
+    assert int(f["rate"]) == rate and int(f["frames"]) == len(s)
+    assert int(f["paused_before"]) == 0 and int(f["paused_after"]) == 0                 # readerPausing = true until restartReader ()
+    assert np.array_equal(got, want)
+    sec = float(f["seconds"])
+    assert 0.9 * n / rate - 0.02 <= sec <= 1.5 * n / rate + 0.2, (sec, n / rate)         # real time, not as fast as the disk
+    t0 = time.time()
+    subprocess.check_call([exe, str(tmp_path / "a.wav"), str(tmp_path / "o2.f32"), str(n), "16384", "0"], stdout=subprocess.DEVNULL)
+    assert time.time() - t0 < 0.5 * n / rate + 0.3                                       # realtime = false: only the deadline sleep is gone
+    got2 = np.fromfile(str(tmp_path / "o2.f32"), np.float32).reshape(-1, 2)
+    assert np.array_equal(got2, pkg.WavFileSource(str(tmp_path / "a.wav")).getSamples(n))
+    m = rng.integers(0, 255, size=(5000, 1)).astype(np.uint8)
+    _write_wav(tmp_path / "m.wav", m, 48000, "pcm8")
+    subprocess.check_call([exe, str(tmp_path / "m.wav"), str(tmp_path / "o3.f32"), "7000", "1000", "0"], stdout=subprocess.DEVNULL)
+    got3 = np.fromfile(str(tmp_path / "o3.f32"), np.float32).reshape(-1, 2)
+    assert np.array_equal(got3, pkg.WavFileSource(str(tmp_path / "m.wav")).getSamples(7000)) and not got3[:, 1].any()
 
 
 # ------------------------------------------------------------------------------------------------
