@@ -61,6 +61,10 @@ __device__ __forceinline__ Aff aff_then(const Aff &f, const Aff &g) {      // ap
 #ifndef FMX_EARLY_PREFETCH
 #define FMX_EARLY_PREFETCH 1
 #endif
+#ifndef FMX_WAVES_ATTR
+/* LDS allows two workgroups per CU = two waves per SIMD: say so, or the register allocator aims at four (128 VGPRs, spills) */
+#define FMX_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 #ifndef FMX_ABL
 #define FMX_ABL 0      /* diagnostic builds only (tools/ablate_front.sh): bit 0 no scatter, 1 no DC/mix pass, 2 no FIR */
 #endif
@@ -111,7 +115,7 @@ __device__ __forceinline__ void fir_rows(const float4 *__restrict__ X4, int cg, 
 // (u8 - 127) / 128, s8 / 128, s16 / denominator, all exact as in the reference's device handlers
 // (rtlsdr-handler.cpp:291, hackrf-handler.cpp:364, lime-handler.cpp:250) -- into the same register layout.
 template <int FMT>
-__global__ __launch_bounds__(256, 2) void front_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
+__global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
                                                        const void *__restrict__ iq_raw) {
     constexpr int BPS = (FMT == 0) ? 8 : (FMT == 3 ? 4 : 2);          // bytes per complex sample
     __shared__ __attribute__((aligned(16))) float4 Xall[4][XUNITS];       // one image per wave (62208 B)

@@ -10,6 +10,7 @@ import torch
 import bench
 pkg = importlib.import_module("sdr-j-fm_amd"); m = pkg.fmx
 half = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+parts = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 n = bench.BLOCK
 dev = torch.device("cuda", 0)
 
@@ -30,14 +31,15 @@ def run(handles, iqs, pcms, streams, steps, warm=12):
     return (time.perf_counter() - t0) / steps * 1e3
 
 cap = n // 48 + 96
-iqa = bench.synth_device(torch, half, n, dev, seed=1); iqb = bench.synth_device(torch, half, n, dev, seed=2)
-pa = torch.zeros((half, cap, 2), device=dev); pb = torch.zeros((half, cap, 2), device=dev)
-sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-fa, fb = make(half), make(half)
-ms2 = run([fa, fb], [iqa, iqb], [pa, pb], [sa, sb], 10)
-del fa, fb
-big = torch.cat([iqa, iqb]); pbig = torch.zeros((2 * half, cap, 2), device=dev)
-f1 = make(2 * half)
-ms1 = run([f1], [big], [pbig], [sa], 10)
-print("two handles x %d channels, interleaved: %.3f ms per round -> %.1f GS/s;  one handle x %d: %.3f ms -> %.1f GS/s" %
-      (half, ms2, 2 * half * n / ms2 / 1e6, 2 * half, ms1, 2 * half * n / ms1 / 1e6))
+iqs = [bench.synth_device(torch, half, n, dev, seed=1 + k) for k in range(parts)]
+pcms = [torch.zeros((half, cap, 2), device=dev) for _ in range(parts)]
+streams = [torch.cuda.Stream() for _ in range(parts)]
+hs = [make(half) for _ in range(parts)]
+ms2 = run(hs, iqs, pcms, streams, 10)
+del hs
+big = torch.cat(iqs); pbig = torch.zeros((parts * half, cap, 2), device=dev)
+del iqs
+f1 = make(parts * half)
+ms1 = run([f1], [big], [pbig], [streams[0]], 10)
+print("%d handles x %d channels, interleaved: %.3f ms per round -> %.1f GS/s;  one handle x %d: %.3f ms -> %.1f GS/s" %
+      (parts, half, ms2, parts * half * n / ms2 / 1e6, parts * half, ms1, parts * half * n / ms1 / 1e6))
