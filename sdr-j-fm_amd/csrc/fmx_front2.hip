@@ -595,11 +595,13 @@ template <int FMT>
 static hipError_t launch_front2_fmt(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels,
                                     int ntab, int lo_cap, hipStream_t s) {
     const size_t lds = front2_lds_bytes(ntab, lo_cap);
-    static size_t granted = 0;                                    // per instantiation
-    if (lds > granted) {
+    static size_t granted[64] = {};                               // per instantiation and device (function attributes are per device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (lds > granted[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(f2::front2_kernel<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        granted = lds;
+        granted[dev] = lds;
     }
     hipLaunchKernelGGL(f2::front2_kernel<FMT>, dim3((channels + 3) / 4), dim3(512), lds, s, T, B, G, iq, channels, ntab, lo_cap);
     return hipSuccess;
