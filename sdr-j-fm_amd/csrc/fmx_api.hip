@@ -147,6 +147,19 @@ void build_front_set(int32_t bw, int32_t inputRate, int32_t fmRate, float *taps 
     // complex gain of the (h/sum, h) kernels: (1 + j S1)(1 + j S2)  (fir-filters.cpp:345-346)
     const double S1 = k1.sum, S2 = k2.sum;
     fs->gain_re = (float)(1.0 - S1 * S2); fs->gain_im = (float)(S1 + S2);
+    // the FIR's response to the slowly moving RfDC value: sum of the taps (as the kernel sums them: f32 taps) times the value at
+    // the taps' centre of mass.  Output column q has its newest input at sample 12 q + off; "RfDC applied to sample s" is the state
+    // behind s, interpolated between the column boundaries: boundary column q - dc_k, weight dc_w towards the next boundary.
+    double hs = 0, mk = 0;
+    for (int d = 0; d < A_MAX_ND; d++)
+        for (int r = 0; r < DECIM; r++) {
+            const double v = (double)taps[(d + 1) * DECIM + r];
+            hs += v; mk += v * (double)(12 * d + off - r);
+        }
+    fs->hsum = (float)hs;
+    const double q0 = (double)off - mk / hs + 1.0;
+    const int K = -(int)std::floor(q0 / 12.0);
+    fs->dc_k = K; fs->dc_w = (float)((q0 + 12.0 * K) / 12.0); fs->pad_ = 0;
 }
 
 void build_audio_set(int32_t lf, int32_t fmRate, const std::vector<float> &rs, float *taps /*C_TAPS_STRIDE*/, AudioSet *as) {
@@ -867,6 +880,8 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     h->sring = 4096;
     const size_t C = (size_t)h->channels;
     HIPCHK(hipMalloc(&h->B.hist, sizeof(float2) * C * DECIM * A_HIST_COLS));
+    HIPCHK(hipMalloc(&h->B.dcv_hist, sizeof(float2) * C * DCV_SAVE));
+    HIPCHK(hipMemset(h->B.dcv_hist, 0, sizeof(float2) * C * DCV_SAVE));
     HIPCHK(hipMalloc(&h->B.zring, sizeof(float2) * C * h->ring));
     HIPCHK(hipMalloc(&h->B.sring, sizeof(float2) * C * h->sring));
     HIPCHK(hipMalloc(&h->B.dring, sizeof(float2) * C * h->dring));
@@ -946,7 +961,7 @@ int fmx_destroy(fmx_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &pr : h->prof) for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
     void *ptrs[] = { h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
-                     h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.zring,
+                     h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.dcv_hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
                      h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x, h->B.w_lockm, h->d_cv_taps, h->d_x48 };
     for (void *p : ptrs) if (p) (void)hipFree(p);

@@ -30,6 +30,7 @@ constexpr int WSAMP = WCOLS * DECIM;           // 1536 input samples per wave ti
 constexpr int XCOLS = HL + WCOLS;              // 152 columns in a wave's LDS image
 constexpr int SPT = 2 * DECIM;                 // 24 samples per lane per tile (two adjacent columns)
 constexpr int FCOLS = 8;                       // adjacent outputs per lane in the FIR phase
+constexpr int DCV_N = 1024;                    // ring of RfDC column-boundary values: eight tiles deep (the four waves are never that far apart)
 constexpr int RPQ = DECIM / 4;                 // polyphase rows per lane quarter in the FIR phase
 
 // LDS image of a wave tile: X[r][C], r = sample index mod 12, C = column (0..23 history, 24..151 fresh).  The unit of
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
     __shared__ __attribute__((aligned(16))) float4 Xall[4][XUNITS];       // one image per wave (62208 B)
     __shared__ __attribute__((aligned(16))) float sT[A_TAPS_DEV];          // the channel's tap set Trd[r][d]
     __shared__ float2 sLO[LO_LDS_MAX];                                     // one period of the LO (when the channel's lo has a short one)
+    __shared__ float2 dcv[DCV_N];                                          // RfDC in front of call-relative column q at [q & (DCV_N - 1)] (channels without LO)
     __shared__ float carry[8][2];                                          // DC state after tile ti, slot = ti & 7
     __shared__ int carry_seq;                                              // tiles whose carry is published
     __shared__ int hist_seq[4], free_seq[4];                               // per wave image: history of tile (n-1) is in / tile (n-1) is done
@@ -161,6 +163,8 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
             X2[xidx(r, c)] = v;
         }
     }
+    // RfDC in front of the 13 columns before this call's first column and of that column itself (ring slots -13 .. 0)
+    if (t < 14) dcv[(t - 13) & (DCV_N - 1)] = B.dcv_hist[(size_t)ch * DCV_SAVE + t];
     // per-channel state is read by every wave BEFORE the barrier (the wave that ends the call rewrites it)
     const int lo_phase0 = st->lo_phase;
     const bool dc_rst = (P.actions & ACT_DC_RESET) != 0;          // setDCRemove zeroes RfDC (:922-925)
@@ -184,6 +188,16 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
     const float alpha = 1.0f / (float)R;              // rfDcAlpha fm-processor.cpp:379
     const float Lg = P.att_l, Rg = P.att_r;
     const bool touch = dcr || mix || Lg != 1.0f || Rg != 1.0f;
+    // Channels without an LO keep their samples RAW in the image: the RfDC value moves by at most alpha |x| = 4e-7 |x| per
+    // sample, so  sum_i h_i clamp (RfDC[n - i])  =  (sum h) clamp (RfDC at the taps' centre of mass)  to ~1e-7, and the
+    // subtraction -- and the IQ balance, a gain per component -- happens on the 128 outputs of a tile instead of its 1536 inputs.
+    // The DC pass then only SUMS the lane's samples (first order in alpha: the terms dropped are alpha^2 k^2 |x| < 5e-7 |RfDC| over
+    // a tile; the decay between tiles stays exact), scans, and leaves the RfDC value at every column boundary in `dcv`.
+    const bool fast = !mix;
+    const bool fastdc = fast && dcr;
+    const bool dc_phase = mix ? touch : dcr;
+    const float hsum = FS.hsum, dcw = FS.dc_w;
+    const int dck = FS.dc_k;
     // a lane's sample PAIR is one 16 / 4 / 8 byte load when the buffer is aligned that far
     const bool aligned16 = ((g0 & 1) == 0) && ((G.stream_stride & 1) == 0) &&
                            ((reinterpret_cast<uintptr_t>(iq_raw) & (2 * BPS - 1)) == 0);
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
         const bool wave_full = __all(first == 0 && lastp1 == SPT);
         float c_out_r = 0.f, c_out_i = 0.f;           // DC state after this tile
 
-        if (touch && !(FMX_ABL & 2)) {
+        if (dc_phase && !(FMX_ABL & 2)) {
             v2f x[SPT];
 #pragma unroll
             for (int r = 0; r < DECIM; r++) {
@@ -334,7 +348,15 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
                 Aff a; a.u = 0.f;
                 v2f aa = (v2f){0.f, 0.f};
                 const v2f al = (v2f){alpha, alpha};
-                if (wave_full) {
+                v2f sA = (v2f){0.f, 0.f};                 // fast path: sum of the lane's first column
+                if (wave_full && fast) {
+                    v2f t4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) t4[j] = (x[6 * j] + x[6 * j + 1]) + (x[6 * j + 2] + x[6 * j + 3]) + (x[6 * j + 4] + x[6 * j + 5]);
+                    sA = t4[0] + t4[1];
+                    aa = al * (sA + (t4[2] + t4[3]));
+                    a.u = u_full;
+                } else if (wave_full) {
 #pragma unroll
                     for (int k = 0; k < SPT; k++) aa = __builtin_elementwise_fma(x[k] - aa, al, aa);
                     a.u = u_full;
@@ -395,6 +417,19 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) seq_post(&carry_seq, ti + 1);              // look-back hand-off, before this wave's pass 2
                 v2f rr = (v2f){c0 - c0 * pre.u + pre.ar, c1 - c1 * pre.u + pre.ai};
+                if (fast) {
+                    // RfDC in front of the lane's two columns (= behind the sample in front of each) into the ring; the boundary in
+                    // front of column 0 of a call that starts inside it belongs to the previous call (kept from dcv_hist)
+                    v2f b1;
+                    if (wave_full) b1 = __builtin_elementwise_fma(al, sA, __builtin_elementwise_fma((v2f){-12.0f * alpha, -12.0f * alpha}, rr, rr));
+                    else {
+                        b1 = rr;
+#pragma unroll
+                        for (int k = 0; k < DECIM; k++) if (k >= first && k < lastp1) b1 = __builtin_elementwise_fma(x[k] - b1, al, b1);
+                    }
+                    if (q * 12 >= g0) dcv[q & (DCV_N - 1)] = make_float2(rr.x, rr.y);
+                    dcv[(q + 1) & (DCV_N - 1)] = make_float2(b1.x, b1.y);
+                } else
                 if (wave_full) {
 #pragma unroll
                     for (int k = 0; k < SPT; k++) {
@@ -411,7 +446,9 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
                     }
                 }
             }
-            // ---- IQ balance + LO mix (fm-processor.cpp:462-466, oscillator.cpp:49-58)
+            // ---- IQ balance + LO mix (fm-processor.cpp:462-466, oscillator.cpp:49-58); without an LO the balance is applied to the
+            //      outputs and the image stays as it is
+            if (!fast) {
             if (Lg != 1.0f || Rg != 1.0f) {
 #pragma unroll
                 for (int k = 0; k < SPT; k++) if (k >= first && k < lastp1) { x[k].x *= Lg; x[k].y *= Rg; }
@@ -450,6 +487,7 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
 #pragma unroll
             for (int r = 0; r < DECIM; r++)
                 X4[dc_unit + r * XRS] = make_float4(x[r].x, x[r].y, x[r + DECIM].x, x[r + DECIM].y);
+            }
             __builtin_amdgcn_wave_barrier();
         }
         FMX_TICK(2);
@@ -495,6 +533,13 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
                     hist[i] = v;
                 }
                 if (lane == 0 && (dcr || dc_rst)) { st->dc_re = dcr ? c_out_r : dc0r; st->dc_im = dcr ? c_out_i : dc0i; }
+                if (fast) {
+                    // RfDC in front of the 13 columns before the next call's first column qn and of qn itself (the state behind the
+                    // call when the call ends on a column boundary; zero history when DC removal is off)
+                    if ((gend % 12) == 0 && lane == 0) dcv[qn & (DCV_N - 1)] = make_float2(dcr ? c_out_r : dc0r, dcr ? c_out_i : dc0i);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 14) B.dcv_hist[(size_t)ch * DCV_SAVE + lane] = dcr ? dcv[(qn - 13 + lane) & (DCV_N - 1)] : make_float2(dc0r, dc0i);
+                }
                 __builtin_amdgcn_wave_barrier();
             }
 #pragma unroll
@@ -508,8 +553,17 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
             const int fg = lane >> 2, pr = ((lane & 3) + (fg >> 1)) & 3;
             const float4 s0 = X4[(0 * 16 + fg) * 4 + pr], s1 = X4[(1 * 16 + fg) * 4 + pr];
             const float4 s2 = X4[(2 * 16 + fg) * 4 + pr], s3 = X4[(3 * 16 + fg) * 4 + pr];
-            const float2 aA = make_float2((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
-            const float2 aB = make_float2((s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+            float2 aA = make_float2((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+            float2 aB = make_float2((s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+            if (fastdc) {
+                // what the FIR makes of the RfDC values the reference subtracts in front of it (limited to +-0.01, DCRlimit :429-442)
+                const float2 e0 = dcv[(q - dck) & (DCV_N - 1)], e1 = dcv[(q - dck + 1) & (DCV_N - 1)], e2 = dcv[(q - dck + 2) & (DCV_N - 1)];
+                const float dAr = fmaf(dcw, e1.x - e0.x, e0.x), dAi = fmaf(dcw, e1.y - e0.y, e0.y);
+                const float dBr = fmaf(dcw, e2.x - e1.x, e1.x), dBi = fmaf(dcw, e2.y - e1.y, e1.y);
+                aA.x = fmaf(-hsum, __builtin_amdgcn_fmed3f(dAr, -0.01f, 0.01f), aA.x); aA.y = fmaf(-hsum, __builtin_amdgcn_fmed3f(dAi, -0.01f, 0.01f), aA.y);
+                aB.x = fmaf(-hsum, __builtin_amdgcn_fmed3f(dBr, -0.01f, 0.01f), aB.x); aB.y = fmaf(-hsum, __builtin_amdgcn_fmed3f(dBi, -0.01f, 0.01f), aB.y);
+            }
+            if (fast && (Lg != 1.0f || Rg != 1.0f)) { aA.x *= Lg; aA.y *= Rg; aB.x *= Lg; aB.y *= Rg; }      // IQ balance :462-464
             if (q >= ja && q < jb)
                 zring[(zr0 + q) & G.ring_mask] = make_float2(aA.x * FS.gain_re - aA.y * FS.gain_im, aA.x * FS.gain_im + aA.y * FS.gain_re);
             if (q + 1 >= ja && q + 1 < jb)

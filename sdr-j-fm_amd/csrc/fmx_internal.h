@@ -41,7 +41,12 @@ struct FrontSet {
     int32_t off;         // newest input sample of output j is 12*j + off
     int32_t delay_fm;    // pure delay in fm samples applied after the FIR (overlap-add latency)
     float   gain_re, gain_im;   // complex gain (1 + j*S1)(1 + j*S2) of the two DecimatingFIRs
+    // RF DC removal applied BEHIND the FIR (channels without LO mix, fmx_front.hip): the taps' sum, and where the RfDC value an
+    // output takes sits -- the taps' centre of mass: boundary column = output column - dc_k, weight dc_w towards the next one
+    float   hsum, dc_w;
+    int32_t dc_k, pad_;
 };
+constexpr int DCV_SAVE = 16;           // RfDC boundary values kept per channel between calls (14 used)
 
 struct AudioSet {
     int32_t ntaps;       // 883 (audio filter on) or 128
@@ -205,7 +210,8 @@ struct CallGeom {
 
 constexpr int DBG_SLOTS = 32;
 struct DeviceBuffers {
-    float2 *hist;        // [channels][DECIM][A_HIST_COLS]   mixed input history (column layout)
+    float2 *hist;        // [channels][DECIM][A_HIST_COLS]   input history (column layout): raw samples; DC-corrected and mixed ones for channels with an LO
+    float2 *dcv_hist;    // [channels][DCV_SAVE] RfDC in front of the 13 columns before the next call's first column, and of that column
     float2 *zring;       // [channels][ring]  front-end output v[j]
     float2 *sring;       // [channels][sring] PSS filter input history
     float2 *dring;       // [channels][dring] de-emphasised, gained stereo @ fmRate

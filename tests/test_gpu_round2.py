@@ -132,7 +132,10 @@ def test_pending_action_survives_introspection_and_tiny_calls(fmx_amd, ol):
     pa = np.concatenate([f.process_host(iq[30 * block + 8 + i: 30 * block + 8 + i + block]) for i in range(0, 8 * block, block)], axis=1)
     pb = np.concatenate([ref.process_host(iq[30 * block + 8 + i: 30 * block + 8 + i + block]) for i in range(0, 8 * block, block)], axis=1)
     assert np.abs(pa[0, :10]).max() < 1e-3          # the fade restarted from 0 in the first call that produced frames
-    assert np.array_equal(pa, pb)                   # and exactly as for a handle that went straight to that call
+    # ... and as for a handle that went straight to that call: to rounding only -- the two handles reached sample 30 * block + 8 in
+    # calls of different lengths, and the RfDC state composes over a call's runs with call-dependent rounding (1e-9), which the
+    # correction behind the FIR turns into last-bit differences of the fm-rate samples
+    assert np.abs(pa - pb).max() <= 2e-7
 
 
 def test_rds_off_everywhere_then_on_again(fmx_amd, ol):
