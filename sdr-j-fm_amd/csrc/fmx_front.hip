@@ -66,6 +66,12 @@ __device__ __forceinline__ Aff aff_then(const Aff &f, const Aff &g) {      // ap
 /* LDS allows two workgroups per CU = two waves per SIMD: say so, or the register allocator aims at four (128 VGPRs, spills) */
 #define FMX_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
+#ifndef FMX_NT_LOADS
+#define FMX_NT_LOADS 0   /* 1: the tile loads as nontemporal loads (A/B builds) */
+#endif
+#ifndef FMX_WAVE_SHR
+#define FMX_WAVE_SHR 1   /* 0: ds_bpermute (__shfl_up) for the one-lane shift of the scan (A/B builds) */
+#endif
 #ifndef FMX_ABL
 #define FMX_ABL 0      /* diagnostic builds only (tools/ablate_front.sh): bit 0 no scatter, 1 no DC/mix pass, 2 no FIR */
 #endif
@@ -254,9 +260,16 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
         const int wbase = ti * WSAMP;                             // index of the tile's first sample
         if (aligned16 && wbase >= g0 && wbase + WSAMP <= gend) {
             if (FMT == 0) {
+#if FMX_NT_LOADS
+                typedef float v4f_ __attribute__((ext_vector_type(4)));
+                const v4f_ *p4 = reinterpret_cast<const v4f_ *>(in + (wbase - g0));
+#pragma unroll
+                for (int k = 0; k < SPT / 2; k++) { const v4f_ v = __builtin_nontemporal_load(p4 + lane + 64 * k); raw[k] = make_float4(v.x, v.y, v.z, v.w); }
+#else
                 const float4 *p4 = reinterpret_cast<const float4 *>(in + (wbase - g0));
 #pragma unroll
                 for (int k = 0; k < SPT / 2; k++) raw[k] = p4[lane + 64 * k];
+#endif
             } else if (FMT == 1 || FMT == 2) {
                 const uint32_t *p1 = reinterpret_cast<const uint32_t *>(inb + (size_t)(wbase - g0) * BPS);
 #pragma unroll
@@ -388,8 +401,14 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
                     FMX_SCAN_STEP(0x142, 0xa, mA)
                     FMX_SCAN_STEP(0x143, 0xc, mB)
 #undef FMX_SCAN_STEP
+#if FMX_WAVE_SHR
+                    // exclusive prefix = the inclusive one of the lane to the left: wave_shr:1 (DPP, lane 0 gets the zero of `old`)
+                    pre.ar = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x138, 0xf, 0xf, false));
+                    pre.ai = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x138, 0xf, 0xf, false));
+#else
                     pre.ar = __shfl_up(sr, 1, 64); pre.ai = __shfl_up(si, 1, 64);
                     if (lane == 0) { pre.ar = 0.f; pre.ai = 0.f; }
+#endif
                     pre.u = u_exc;
                     tu = u_tile;
                     tar = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sr), 63));
