@@ -161,11 +161,21 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
     for (int i = t; i < A_TAPS_DEV; i += 256) sT[i] = T.front_taps[(size_t)P.front_set * A_TAPS_DEV + i];
     if (t == 0) { carry_seq = 0; for (int i = 0; i < 4; i++) { hist_seq[i] = 0; free_seq[i] = 0; } }
     // ---- history -> the image of tile 0 (wave 0): columns qa-24 .. qa-1 at C 0..23, partial column qa at C 24
+    const bool hist_convert = (P.lo_freq != 0) && (T.lo_table != nullptr) && (st->hist_fmt == 0) && (P.dc_remove != 0 || P.att_l != 1.0f || P.att_r != 1.0f);
     if (wave == 0) {
         for (int i = lane; i < DECIM * A_HIST_COLS; i += 64) {
             int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;
             float2 v = hist[i];
             if (c == HL && r >= r0) v = make_float2(0.f, 0.f);
+            else if (hist_convert) {
+                // the LO was switched on since the last call: the history is still raw, the reference's filter memory holds these
+                // samples DC-corrected and balanced (mixed with the LO of their time: none) -- RfDC of their column from the saved
+                // boundaries (the oldest one for the columns in front of them)
+                const int tb = c - HL + 13;
+                const float2 d = B.dcv_hist[(size_t)ch * DCV_SAVE + (tb < 0 ? 0 : tb)];
+                v.x = (v.x - __builtin_amdgcn_fmed3f(d.x, -0.01f, 0.01f)) * P.att_l;
+                v.y = (v.y - __builtin_amdgcn_fmed3f(d.y, -0.01f, 0.01f)) * P.att_r;
+            }
             X2[xidx(r, c)] = v;
         }
     }
@@ -552,6 +562,7 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
                     hist[i] = v;
                 }
                 if (lane == 0 && (dcr || dc_rst)) { st->dc_re = dcr ? c_out_r : dc0r; st->dc_im = dcr ? c_out_i : dc0i; }
+                if (lane == 0) st->hist_fmt = mix ? 1 : 0;
                 if (fast) {
                     // RfDC in front of the 13 columns before the next call's first column qn and of qn itself (the state behind the
                     // call when the call ends on a column boundary; zero history when DC removal is off)

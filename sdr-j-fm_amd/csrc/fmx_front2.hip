@@ -551,6 +551,7 @@ __global__ __launch_bounds__(512, 2) void front2_kernel(DeviceTables T, DeviceBu
                 hist[i] = v;
             }
             if (lane == 0 && (dcr || dc_rst)) { st->dc_re = dcr ? c0 : dc0r; st->dc_im = dcr ? c1 : dc0i; }
+            if (lane == 0) st->hist_fmt = 1;          // this layout keeps the history DC-corrected / mixed (fmx_front.hip converts)
             __builtin_amdgcn_wave_barrier();
         }
 #ifdef F2_SUBTICK

@@ -108,7 +108,8 @@ struct ChanState {
     // peak meter (fm-processor.cpp:772-798): frames in the current 961-frame window, its maxima so far, windows finished so far
     int32_t pk_cnt;
     float   pk_l, pk_r;
-    int32_t pk_events, pad1;
+    int32_t pk_events;
+    int32_t hist_fmt;    // stage-A history (DeviceBuffers::hist): 0 raw samples (channel without LO), 1 DC-corrected, balanced and mixed ones
     // noise squelch (squelchClass.cpp:47-87): decaying averages and the (m1, m2) memories of the two order-20 filters
     float   sq_avg_hi, sq_avg_lo;
     float   sq_m[2][NSQ_QUADS][2];

@@ -410,3 +410,28 @@ def test_config1_cpp_file_source_realtime(fmx_amd, ol, tmp_path):
     want = ol.OracleChain(inputFilterBw=0, fmMode=2).process((s16.astype(np.float32) / np.float32(32768.0)).astype(np.float32))
     assert pcm.shape == want.shape and rms(pcm - want) <= PCM_RMS_TOL
     assert wall >= 0.9 * n / 2304000.0                         # paced: 0.21 s of signal does not arrive faster than real time
+
+
+def test_lo_switched_on_mid_stream_with_dc_offset(fmx_amd, ol):
+    """set_localOscillator going from 0 to a fine-tuning offset in the middle of a stream that carries a DC offset (what the GUI's AFC
+    loop does, radio.cpp:1786-1809): channels without an LO keep their stage-A history raw and correct RfDC behind the FIR, channels with
+    one keep it DC-corrected and mixed -- at the switch the raw history is converted, so the filter memory holds what the reference's
+    holds and no click appears.  PCM against the oracle over the switch."""
+    block = 16384
+    nb = 40
+    iq = ol.synth_iq(nb * block)
+    iq[:, 0] += 0.006; iq[:, 1] -= 0.004
+    ch = ol.OracleChain(inputFilterBw=165000)
+    f = fmx_amd.Fmx(1, max_block=block)
+    gui_defaults(f)
+    po, pg = [], []
+    for b in range(nb):
+        if b == 24:
+            ch.configure(loFrequency=3000); f.set_param(M.P_LOCAL_OSCILLATOR, 3000)
+        po.append(ch.process(iq[b * block:(b + 1) * block])); pg.append(f.process_host(iq[b * block:(b + 1) * block])[0])
+    po, pg = np.concatenate(po), np.concatenate(pg)
+    assert po.shape == pg.shape
+    k = 24 * block // 48                                     # frames in front of the switch
+    e_all, e_sw = rms(pg - po), rms(pg[k - 200:k + 600] - po[k - 200:k + 600])
+    print(f"\n[LO on mid-stream] rms diff all {e_all:.3e}, around the switch {e_sw:.3e}, max {np.abs(pg - po).max():.3e}")
+    assert e_all <= PCM_RMS_TOL and e_sw <= PCM_RMS_TOL
