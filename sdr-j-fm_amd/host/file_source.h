@@ -2,7 +2,7 @@
 // with the behaviour of the reference's fileHulp (devices/filereader/filehulp.cpp), real-time pacing included:
 //   * rate and channel count come from the header (:61-63); 2 channels = (I, Q), 1 channel = I with Q = 0 (:127-137);
 //   * samples are what libsndfile's sf_readf_float returns: PCM16 / 32768, PCM8 (unsigned) (v - 128) / 128, PCM32 / 2^31,
-//     float32 as is -- parsed here from RIFF/WAVE directly (libsndfile is not in the image);
+//     float32 as is -- parsed here from RIFF/WAVE directly (libsndfile is not in the image), streamed from the file 10 ms at a time;
 //   * a reader thread (:159-202) moves 10 ms of samples (2 * rate / 100 floats) per 10 ms period into a ring of 32768 * 32
 //     floats (:30), waits while the ring is full, pauses while the reader is stopped (restartReader / stopReader :83-92; it
 //     starts PAUSED, :67), and sleeps until the next period's deadline: the file plays at its own sample rate;
@@ -37,6 +37,7 @@ public:
     ~FileSource() override {
         exit_ = true;
         if (worker_.joinable()) worker_.join();
+        if (file_) std::fclose(file_);
     }
     bool restartReader() { if (readerOK_) pausing_ = false; return readerOK_; }
     void stopReader() { if (readerOK_) pausing_ = true; }
@@ -63,48 +64,65 @@ private:
     size_t avail() const { return wr_.load(std::memory_order_acquire) - rd_.load(std::memory_order_acquire); }
     size_t space() const { return kRing - avail(); }
 
+    // header only: the samples are read and converted 10 ms at a time by the reader thread, as sf_readf_float does
     bool parse(const std::string &path) {
-        FILE *f = std::fopen(path.c_str(), "rb");
-        if (!f) { std::fprintf(stderr, "file %s no legitimate sound file\n", path.c_str()); return false; }
-        std::fseek(f, 0, SEEK_END); const long bytes = std::ftell(f); std::fseek(f, 0, SEEK_SET);
-        std::vector<uint8_t> d((size_t)std::max(0L, bytes));
-        const bool got = bytes > 12 && std::fread(d.data(), 1, d.size(), f) == d.size();
-        std::fclose(f);
-        if (!got || std::memcmp(d.data(), "RIFF", 4) != 0 || std::memcmp(d.data() + 8, "WAVE", 4) != 0) return false;
-        auto u16 = [&](size_t p) { return (uint32_t)d[p] | ((uint32_t)d[p + 1] << 8); };
-        auto u32 = [&](size_t p) { return u16(p) | (u16(p + 2) << 16); };
-        size_t pos = 12, fmt = 0, fmt_size = 0, body = 0, body_size = 0;
-        while (pos + 8 <= d.size()) {
-            const uint32_t size = u32(pos + 4);
-            if (std::memcmp(d.data() + pos, "fmt ", 4) == 0) { fmt = pos + 8; fmt_size = size; }
-            else if (std::memcmp(d.data() + pos, "data", 4) == 0) { body = pos + 8; body_size = std::min<size_t>(size, d.size() - body); break; }
-            pos += 8 + (size_t)size + (size & 1);
+        file_ = std::fopen(path.c_str(), "rb");
+        if (!file_) { std::fprintf(stderr, "file %s no legitimate sound file\n", path.c_str()); return false; }
+        uint8_t hd[12];
+        if (std::fread(hd, 1, 12, file_) != 12 || std::memcmp(hd, "RIFF", 4) != 0 || std::memcmp(hd + 8, "WAVE", 4) != 0) return false;
+        auto u16 = [](const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); };
+        auto u32 = [&](const uint8_t *p) { return u16(p) | (u16(p + 2) << 16); };
+        uint32_t tag = 0, ch = 0, bits = 0; bool have_fmt = false;
+        for (;;) {
+            uint8_t ck[8];
+            if (std::fread(ck, 1, 8, file_) != 8) return false;
+            const uint32_t size = u32(ck + 4);
+            if (std::memcmp(ck, "fmt ", 4) == 0) {
+                std::vector<uint8_t> f(size);
+                if (size < 16 || std::fread(f.data(), 1, size, file_) != size) return false;
+                tag = u16(&f[0]); ch = u16(&f[2]); inputRate_ = (int32_t)u32(&f[4]); bits = u16(&f[14]);
+                if (tag == 0xFFFE && size >= 26) tag = u16(&f[24]);              // WAVE_FORMAT_EXTENSIBLE: the sub-format's first word
+                have_fmt = true;
+                if (size & 1) std::fseek(file_, 1, SEEK_CUR);
+            } else if (std::memcmp(ck, "data", 4) == 0) {
+                dataStart_ = std::ftell(file_);
+                std::fseek(file_, 0, SEEK_END);
+                const long end = std::ftell(file_);
+                dataBytes_ = std::min<int64_t>((int64_t)size, (int64_t)end - dataStart_);
+                break;
+            } else if (std::fseek(file_, (long)size + (long)(size & 1), SEEK_CUR) != 0) return false;
         }
-        if (!fmt || !body || fmt_size < 16) return false;
-        uint32_t tag = u16(fmt); const uint32_t ch = u16(fmt + 2), bits = u16(fmt + 14);
-        if (tag == 0xFFFE && fmt_size >= 26) tag = u16(fmt + 24);          // WAVE_FORMAT_EXTENSIBLE: the sub-format's first word
-        if (ch != 1 && ch != 2) return false;
-        inputRate_ = (int32_t)u32(fmt + 4); channels_ = (int)ch;
-        const size_t bps = bits / 8, n = bps ? body_size / bps : 0;
-        data_.resize(n);
-        const uint8_t *b = d.data() + body;
-        if (tag == 1 && bits == 16) for (size_t i = 0; i < n; i++) data_[i] = (float)(int16_t)(b[2 * i] | (b[2 * i + 1] << 8)) / 32768.0f;
-        else if (tag == 1 && bits == 8) for (size_t i = 0; i < n; i++) data_[i] = ((float)b[i] - 128.0f) / 128.0f;
-        else if (tag == 1 && bits == 32) for (size_t i = 0; i < n; i++) { int32_t v; std::memcpy(&v, b + 4 * i, 4); data_[i] = (float)((double)v / 2147483648.0); }
-        else if (tag == 3 && bits == 32) std::memcpy(data_.data(), b, 4 * n);
-        else return false;
-        frames_ = (int64_t)(n / ch);
+        if (!have_fmt || (ch != 1 && ch != 2)) return false;
+        if (tag == 1 && bits == 16) fmt_ = 0; else if (tag == 1 && bits == 8) fmt_ = 1; else if (tag == 1 && bits == 32) fmt_ = 2;
+        else if (tag == 3 && bits == 32) fmt_ = 3; else return false;
+        channels_ = (int)ch; bytesPerValue_ = (int)bits / 8;
+        frames_ = dataBytes_ / ((int64_t)bytesPerValue_ * channels_);
+        std::fseek(file_, dataStart_, SEEK_SET);
         return frames_ > 0;
     }
     // filehulp.cpp:127-147: `length` floats wanted; returns the floats delivered; wraps to the start after a short read
     int32_t readBuffer(float *out, int32_t length) {
         const int64_t want = length / 2, left = frames_ - filePos_;
         const int64_t n = std::min(want, left);
-        if (channels_ == 2) std::memcpy(out, data_.data() + 2 * filePos_, sizeof(float) * 2 * (size_t)n);
-        else for (int64_t i = 0; i < n; i++) { out[2 * i] = data_[(size_t)(filePos_ + i)]; out[2 * i + 1] = 0.f; }
-        filePos_ += n; currPos_ += n;
-        if (n < want) filePos_ = 0;
-        return (int32_t)(2 * n);
+        const size_t vals = (size_t)n * (size_t)channels_;
+        raw_.resize(vals * (size_t)bytesPerValue_);
+        const size_t got = raw_.empty() ? 0 : std::fread(raw_.data(), (size_t)bytesPerValue_ * (size_t)channels_, (size_t)n, file_);
+        const uint8_t *b = raw_.data();
+        auto value = [&](size_t i) -> float {                    // what sf_readf_float delivers for value i of the chunk
+            switch (fmt_) {
+            case 0: return (float)(int16_t)(b[2 * i] | (b[2 * i + 1] << 8)) / 32768.0f;
+            case 1: return ((float)b[i] - 128.0f) / 128.0f;
+            case 2: { int32_t v; std::memcpy(&v, b + 4 * i, 4); return (float)((double)v / 2147483648.0); }
+            default: { float v; std::memcpy(&v, b + 4 * i, 4); return v; }
+            }
+        };
+        for (size_t i = 0; i < got; i++) {
+            if (channels_ == 2) { out[2 * i] = value(2 * i); out[2 * i + 1] = value(2 * i + 1); }
+            else { out[2 * i] = value(i); out[2 * i + 1] = 0.f; }
+        }
+        filePos_ += (int64_t)got; currPos_ += (int64_t)got;
+        if ((int64_t)got < want) { filePos_ = 0; std::fseek(file_, dataStart_, SEEK_SET); }
+        return (int32_t)(2 * got);
     }
     void run() {
         using clock = std::chrono::steady_clock;
@@ -134,7 +152,9 @@ private:
     int32_t inputRate_ = 192000; int channels_ = 2;
     int64_t frames_ = 0, filePos_ = 0;
     std::atomic<int64_t> currPos_{0};
-    std::vector<float> data_, ring_;
+    std::vector<float> ring_;
+    std::vector<uint8_t> raw_;
+    FILE *file_ = nullptr; long dataStart_ = 0; int64_t dataBytes_ = 0; int fmt_ = 0, bytesPerValue_ = 2;
     std::atomic<size_t> rd_{0}, wr_{0};
     std::thread worker_;
 };
