@@ -351,6 +351,18 @@ int ensure_rds_body(fmx_handle h) {
         HIPCHK(hipMemcpy(dS, S.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(dM, M.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
         R.S_bp = dS; R.S_hil = dM;
+        {   // the band-pass kernel is complex and only the real part of its result is kept (fm-processor.cpp:741): for a real input
+            // Re (a * s) = a * Re (s), the DFT of Re (s) is the Hermitian part of S -- the filter vector of the paired transforms
+            std::vector<float2> Sr((size_t)N);
+            for (int f = 0; f < N; f++) {
+                const float2 a = S[(size_t)f], b = S[(size_t)((N - f) & (N - 1))];
+                Sr[(size_t)f] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+            }
+            float2 *dSr;
+            if ((rc = dalloc((void **)&dSr, sizeof(float2) * N, false))) return rc;
+            HIPCHK(hipMemcpy(dSr, Sr.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
+            R.S_bp_re = dSr;
+        }
         std::vector<float> dk = design::decim_complex(11, 24000 / 2, fmRate);      // rdsDecimator fm-processor.cpp:382
         std::vector<float> rr = design::rrc(1.0, 24000, 2 * 1187.5f, 1.0, 45);       // rds-decoder-2.cpp:67-71
         float2 *dd; float *dr;

@@ -284,6 +284,7 @@ struct RdsBuffers {
     uint8_t *bits;       // [ch][RDS_BITS_CAP]
     float2 *sym;         // [ch][RDS_SYM_CAP] RDS_2: the sample every bit was decided on (rds-decoder-2.cpp:108-114, `*m = r`), index = bit count
     const float2 *S_bp, *S_hil;   // [32768] filter spectra
+    const float2 *S_bp_re;        // [32768] spectrum of the band-pass kernel's real part (paired transforms, fmx_rds.hip)
     const float2 *dec_taps;       // [11] rdsDecimator kernel (h/sum, h)
     const float *rrc;             // [45] matched filter
     // RDS_1 (rds-decoder-1.cpp)

@@ -484,10 +484,82 @@ static void fft_fwd(const RdsBuffers &Rb, int nch, const int *chlist, hipStream_
     hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nch), dim3(256), 0, s, Rb.U, Rb.V, nch, chlist);
     hipLaunchKernelGGL(rds_fft_step2, dim3(RN1 / 16, nch), dim3(256), 0, s, Rb.V, Rb.U, nch, chlist);
 }
+// the same transform of the rows of A in place, B as scratch
+static void fft_rows(float2 *A, float2 *Bs, int nrows, hipStream_t s) {
+    hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nrows), dim3(256), 0, s, A, Bs, nrows, (const int *)nullptr);
+    hipLaunchKernelGGL(rds_fft_step2, dim3(RN1 / 16, nrows), dim3(256), 0, s, Bs, A, nrows, (const int *)nullptr);
+}
+
+// ---- Two channels per transform.  The inputs of both block filters are REAL, so channels 2 p and 2 p + 1 ride as the real and
+// imaginary part of one complex row: the band-pass -- complex taps s, but only Re (a * s) = a * Re (s) is kept, and with the real
+// kernel Re (s), (a + j b) * Re (s) = a * Re (s) + j b * Re (s) -- keeps the pair through the backward transform as well and the two
+// results are the row's real and imaginary parts; the Hilbert filter's output is complex,
+// so its spectra are taken apart behind the forward transform (A[k] = (Z[k] + conj Z[N - k]) / 2, B[k] = (Z[k] - conj Z[N - k]) / 2j)
+// and the backward transforms run per channel.  2.5 instead of 4 transforms per channel and block: the four-step transform is
+// bound by its HBM passes.
+__global__ void rds_load_real_pair(const float *__restrict__ src, size_t src_stride, float2 *__restrict__ Z, int C) {
+    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= RN) return;
+    const int a = 2 * p, b = 2 * p + 1;
+    Z[(size_t)p * RN + i] = make_float2(i < RBLK ? src[(size_t)a * src_stride + i] : 0.f, (i < RBLK && b < C) ? src[(size_t)b * src_stride + i] : 0.f);
+}
+// band-pass pair behind the second transform: conj / N, overlap add (real parts), the two real block results, the tails
+__global__ void rds_finish_pair(const float2 *__restrict__ Z, float2 *__restrict__ over, float *__restrict__ out_real, size_t out_stride, int C) {
+    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= RN) return;
+    const int a = 2 * p, b = 2 * p + 1;
+    const float f = 1.0f / (float)RN;
+    const float2 z = Z[(size_t)p * RN + i];
+    float va = z.x * f, vb = -z.y * f;
+    if (i < RDEG) { va += over[(size_t)a * RDEG + i].x; if (b < C) vb += over[(size_t)b * RDEG + i].x; }
+    if (i < RBLK) { out_real[(size_t)a * out_stride + i] = va; if (b < C) out_real[(size_t)b * out_stride + i] = vb; }
+}
+__global__ void rds_save_tail_pair(const float2 *__restrict__ Z, float2 *__restrict__ over, int C) {
+    const int p = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= RDEG) return;
+    const int a = 2 * p, b = 2 * p + 1;
+    const float f = 1.0f / (float)RN;
+    const float2 z = Z[(size_t)p * RN + RBLK + j];
+    over[(size_t)a * RDEG + j] = make_float2(z.x * f, 0.f);
+    if (b < C) over[(size_t)b * RDEG + j] = make_float2(-z.y * f, 0.f);
+}
+// Hilbert: the pair's spectrum Z apart, each times the filter vector, conjugated (rds_spectrum's step) into the channels' own rows
+__global__ void rds_hil_split(const float2 *__restrict__ Z, const float2 *__restrict__ S, float2 *__restrict__ U, int C) {
+    const int p = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= RN) return;
+    const int a = 2 * p, b = 2 * p + 1;
+    const float2 zk = Z[(size_t)p * RN + k], zn = Z[(size_t)p * RN + ((RN - k) & (RN - 1))];
+    const float2 xa = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    const float2 xb = make_float2(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
+    const float2 sk = S[k];
+    float2 v = cmulf(xa, sk);
+    U[(size_t)a * RN + k] = make_float2(v.x, -v.y);
+    if (b < C) { v = cmulf(xb, sk); U[(size_t)b * RN + k] = make_float2(v.x, -v.y); }
+}
 
 // one block boundary: BP filter of the demod block just completed (block index blk), Hilbert of the previous BP result
 void launch_rds_block(const RdsBuffers &Rb, int C, int64_t blk, hipStream_t s) {
     const dim3 g(RN / 256, C);
+    static const bool pair = !(getenv("FMX_RDS_PAIR") && atoi(getenv("FMX_RDS_PAIR")) == 0);
+    if (pair && C >= 2) {
+        const int P = (C + 1) / 2;
+        const dim3 gp(RN / 256, P);
+        // Hilbert of the previous band-pass result: pairs forward (rows of V, U as scratch), apart into U, backward per channel
+        hipLaunchKernelGGL(rds_load_real_pair, gp, dim3(256), 0, s, Rb.bpreal + (size_t)((blk + 1) & 1) * RBLK, (size_t)2 * RBLK, Rb.V, C);
+        fft_rows(Rb.V, Rb.U, P, s);
+        hipLaunchKernelGGL(rds_hil_split, gp, dim3(256), 0, s, Rb.V, Rb.S_hil, Rb.U, C);
+        fft_fwd(Rb, C, nullptr, s);
+        hipLaunchKernelGGL(rds_finish, g, dim3(256), 0, s, Rb.U, Rb.hil_over, (float *)nullptr, Rb.hil + (size_t)(blk & 1) * RBLK, (size_t)2 * RBLK, nullptr);
+        hipLaunchKernelGGL(rds_save_tail, dim3(3, C), dim3(256), 0, s, Rb.U, Rb.hil_over, nullptr);
+        // band-pass of the demod block just completed: pairs all the way
+        hipLaunchKernelGGL(rds_load_real_pair, gp, dim3(256), 0, s, Rb.in_blk, (size_t)RBLK, Rb.U, C);
+        fft_fwd(Rb, P, nullptr, s);
+        hipLaunchKernelGGL(rds_spectrum, gp, dim3(256), 0, s, Rb.U, Rb.S_bp_re, 3.0f, nullptr);
+        fft_fwd(Rb, P, nullptr, s);
+        hipLaunchKernelGGL(rds_finish_pair, gp, dim3(256), 0, s, Rb.U, Rb.bp_over, Rb.bpreal + (size_t)(blk & 1) * RBLK, (size_t)2 * RBLK, C);
+        hipLaunchKernelGGL(rds_save_tail_pair, dim3(3, P), dim3(256), 0, s, Rb.U, Rb.bp_over, C);
+        return;
+    }
     // Hilbert first: its input is bpreal[(blk-1)&1] (zeros when blk == 0), output hil[blk & 1]
     hipLaunchKernelGGL(rds_load_real, g, dim3(256), 0, s, Rb.bpreal + (size_t)((blk + 1) & 1) * RBLK, (size_t)2 * RBLK, Rb.U, nullptr);
     fft_fwd(Rb, C, nullptr, s);
