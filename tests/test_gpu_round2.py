@@ -435,3 +435,49 @@ def test_lo_switched_on_mid_stream_with_dc_offset(fmx_amd, ol):
     e_all, e_sw = rms(pg - po), rms(pg[k - 200:k + 600] - po[k - 200:k + 600])
     print(f"\n[LO on mid-stream] rms diff all {e_all:.3e}, around the switch {e_sw:.3e}, max {np.abs(pg - po).max():.3e}")
     assert e_all <= PCM_RMS_TOL and e_sw <= PCM_RMS_TOL
+
+
+def test_random_settings_batch_against_oracle(fmx_amd, ol):
+    """Twelve channels with settings drawn at random (seeded) -- input filter width / off, IQ balance, LO offset, DC removal on / off,
+    decoder, mode, selector, panorama, de-emphasis, volume, audio filter -- on three streams with different DC offsets and noise, calls of
+    uneven length (not multiples of 12 or 192): every channel against an oracle chain with the same settings.  Covers the combinations
+    the single-setting tests do not: IQ balance with and without an LO next to DC removal behind / in front of the FIR, tap sets of
+    different widths in one batch."""
+    rng = np.random.default_rng(2026)
+    nch, nstreams = 12, 3
+    blocks = [16384 * 4 + 7, 16384 * 6 - 5, 230400, 12 * 1000 + 1, 16384 * 9 + 100, 16384 * 5]
+    n = sum(blocks)
+    streams = []
+    for sidx in range(nstreams):
+        x = ol.synth_iq(n, stereo=1 if sidx != 1 else 0, noiseSeed=100 + sidx, noiseSigma=0.002 * sidx)
+        x[:, 0] += (0.0, 0.007, -0.02)[sidx]; x[:, 1] += (0.0, -0.004, 0.015)[sidx]      # the last one beyond the +-0.01 limiter
+        streams.append(x)
+    iq = np.stack(streams, axis=0)
+    bw_choices = [0, 165000, 130000, 200000]
+    cfgs = []
+    for c in range(nch):
+        kw = dict(inputFilterBw=int(rng.choice(bw_choices)), attL=float(rng.choice([1.0, 0.9, 1.15])), attR=float(rng.choice([1.0, 1.1, 0.85])),
+                  loFrequency=int(rng.choice([0, 0, 2500, -4000])), dcRemove=int(rng.choice([1, 1, 1, 0])), decoder=int(rng.choice([3, 4, 5, 6])),
+                  fmMode=int(rng.choice([0, 0, 1, 2])), soundSelector=int(rng.choice([0, 1, 4])), panorama=int(rng.choice([100, 60, 140])),
+                  deemphasis=int(rng.choice([50, 75])), volumeDb=float(rng.choice([-6.0, -10.5, 0.0])), lfCutoff=int(rng.choice([15000, 12000, 0])),
+                  autoMono=int(rng.choice([1, 0])))
+        cfgs.append(kw)
+    f = fmx_amd.Fmx(nch, streams=nstreams, stream_of_channel=[c % nstreams for c in range(nch)], max_block=max(blocks))
+    pid = dict(inputFilterBw=M.P_BANDWIDTH, attL=M.P_ATTENUATION_L, attR=M.P_ATTENUATION_R, loFrequency=M.P_LOCAL_OSCILLATOR, dcRemove=M.P_DC_REMOVE,
+               decoder=M.P_FM_DECODER, fmMode=M.P_FM_MODE, soundSelector=M.P_SOUND_MODE, panorama=M.P_STEREO_PANORAMA, deemphasis=M.P_DEEMPHASIS,
+               volumeDb=M.P_VOLUME_DB, lfCutoff=M.P_LF_CUTOFF, autoMono=M.P_AUTO_MONO)
+    for c, kw in enumerate(cfgs):
+        for k, v in kw.items():
+            f.set_param(pid[k], v, c)
+    outs, pos = [], 0
+    for b in blocks:
+        outs.append(f.process_host(np.ascontiguousarray(iq[:, pos:pos + b]))); pos += b
+    pcm = np.concatenate(outs, axis=1)
+    worst = 0.0
+    for c, kw in enumerate(cfgs):
+        po = ol.OracleChain(**kw).process(iq[c % nstreams])
+        m = min(pcm.shape[1], po.shape[0])
+        e = rms(pcm[c][:m] - po[:m])
+        worst = max(worst, e)
+        assert m > 0.95 * pcm.shape[1] and e <= PCM_RMS_TOL, (c, kw, e)
+    print(f"\n[random settings] worst PCM RMS difference over {nch} channels {worst:.3e}")
