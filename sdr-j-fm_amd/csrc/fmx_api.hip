@@ -309,9 +309,9 @@ int ensure_rds_body(fmx_handle h) {
     int rc;
     if ((rc = dalloc((void **)&R.in_blk, sizeof(float) * C * RDS_BLK, true))) return rc;
     if ((rc = dalloc((void **)&R.bpreal, sizeof(float) * C * 2 * RDS_BLK, true))) return rc;
-    if ((rc = dalloc((void **)&R.bp_over, sizeof(float2) * C * 768, true))) return rc;
+    if ((rc = dalloc((void **)&R.bp_over, sizeof(float2) * 2 * C * 768, true))) return rc;
     if ((rc = dalloc((void **)&R.hil, sizeof(float2) * C * 2 * RDS_BLK, true))) return rc;
-    if ((rc = dalloc((void **)&R.hil_over, sizeof(float2) * C * 768, true))) return rc;
+    if ((rc = dalloc((void **)&R.hil_over, sizeof(float2) * 2 * C * 768, true))) return rc;
     if ((rc = dalloc((void **)&R.phase_ring, sizeof(float) * C * RDS_PHASE_RING, true))) return rc;
     if ((rc = dalloc((void **)&R.U, sizeof(float2) * C * 32768, false))) return rc;
     if ((rc = dalloc((void **)&R.V, sizeof(float2) * C * 32768, false))) return rc;
@@ -411,9 +411,9 @@ int rds_restart(fmx_handle h) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(R.in_blk, 0, sizeof(float) * C * RDS_BLK));
     HIPCHK(hipMemset(R.bpreal, 0, sizeof(float) * C * 2 * RDS_BLK));
-    HIPCHK(hipMemset(R.bp_over, 0, sizeof(float2) * C * 768));
+    HIPCHK(hipMemset(R.bp_over, 0, sizeof(float2) * 2 * C * 768));
     HIPCHK(hipMemset(R.hil, 0, sizeof(float2) * C * 2 * RDS_BLK));
-    HIPCHK(hipMemset(R.hil_over, 0, sizeof(float2) * C * 768));
+    HIPCHK(hipMemset(R.hil_over, 0, sizeof(float2) * 2 * C * 768));
     HIPCHK(hipMemset(R.phase_ring, 0, sizeof(float) * C * RDS_PHASE_RING));
     HIPCHK(hipMemset(R.rds24, 0, sizeof(float2) * C * RDS24_RING));
     HIPCHK(hipMemset(R.bits, 0, C * RDS_BITS_CAP));

@@ -273,9 +273,9 @@ struct Rds3State {                          // rdsDecoder's Costas + rdsDecoder_
 struct RdsBuffers {
     float  *in_blk;      // [ch][32000]     demod samples of the block being filled
     float  *bpreal;      // [ch][2][32000]  real part of the band-pass block results (parity = block index & 1)
-    float2 *bp_over;     // [ch][768]       band-pass Overloop
+    float2 *bp_over;     // [2][ch][768]    band-pass Overloop (paired transforms: parity = block index & 1; one channel per transform: [0] only)
     float2 *hil;         // [ch][2][32000]  Hilbert block results
-    float2 *hil_over;    // [ch][768]
+    float2 *hil_over;    // [2][ch][768]
     float  *phase_ring;  // [ch][RDS_PHASE_RING]
     float2 *U, *V;       // [ch][32768]     FFT scratch
     float2 *rds24;       // [ch][RDS24_RING]

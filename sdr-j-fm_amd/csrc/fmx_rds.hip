@@ -26,8 +26,11 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2
 
 // ---- four-step FFT, step 1: 256 column FFTs of length 128 (+ twiddle), 16 columns per workgroup.
 //      in  : x[n], n = 256*n1 + n2          out : a[k1*256 + n2] = W_N^(n2 k1) * sum_n1 x[256 n1 + n2] W_128^(n1 k1)
+// pair_src != null: the row is not read from `in` but built on the fly from two real 32000-sample blocks, channels 2 p and 2 p + 1 as
+// real and imaginary part, zero padded (rds_load_real_pair fused into the transform's first pass)
 __global__ __launch_bounds__(256) void rds_fft_step1(const float2 *__restrict__ in, float2 *__restrict__ out, int nch,
-                                                     const int *__restrict__ chlist) {
+                                                     const int *__restrict__ chlist, const float *__restrict__ pair_src = nullptr,
+                                                     size_t pair_stride = 0, int C = 0) {
     __shared__ float2 s[16][RN1 + 1];
     __shared__ float2 tw[RN1 / 2];
     const int tid = threadIdx.x;
@@ -36,6 +39,14 @@ __global__ __launch_bounds__(256) void rds_fft_step1(const float2 *__restrict__ 
     const float2 *x = in + (size_t)ch * RN;
     float2 *a = out + (size_t)ch * RN;
     if (tid < RN1 / 2) { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN1, &sn, &cs); tw[tid] = make_float2(cs, sn); }
+    if (pair_src) {
+        const float *pa = pair_src + (size_t)(2 * ch) * pair_stride, *pb = pair_src + (size_t)(2 * ch + 1) * pair_stride;
+        const bool hb = 2 * ch + 1 < C;
+        for (int i = tid; i < RN1 * 16; i += 256) {
+            const int n1 = i >> 4, c = i & 15, n = n1 * RN2 + c0 + c;
+            s[c][n1] = make_float2(n < RBLK ? pa[n] : 0.f, (n < RBLK && hb) ? pb[n] : 0.f);
+        }
+    } else
     for (int i = tid; i < RN1 * 16; i += 256) { const int n1 = i >> 4, c = i & 15; s[c][n1] = x[n1 * RN2 + c0 + c]; }
     __syncthreads();
     // 16 independent FFT-128, 16 threads each
@@ -68,8 +79,19 @@ __global__ __launch_bounds__(256) void rds_fft_step1(const float2 *__restrict__ 
     }
 }
 // ---- step 2: 128 row FFTs of length 256, 16 rows per workgroup; X[k1 + 128 k2] = sum_n2 a[k1][n2] W_256^(n2 k2)
+// EPI: what happens to the transform's result on its way out (the element-wise passes of the block filters fused into the
+// transform's last pass): 0 stored as it is; 1 times the filter vector S (and `scale`), conjugated (rds_spectrum); 2 band-pass
+// pair behind the second transform -- conj / N, overlap add, the two real block results, the two new tails (rds_finish_pair +
+// rds_save_tail_pair); 3 one channel's complex result likewise (rds_finish + rds_save_tail).  The tails of block b go to the
+// overlap buffer of parity b & 1 and are read from the other one: no pass reads what another one is writing.
+struct RdsEpi {
+    const float2 *S; float scale;                 // 1
+    const float2 *over_old; float2 *over_new;     // 2, 3: [ch][RDEG]
+    float *out_real; float2 *out_cplx; size_t out_stride; int C;
+};
+template <int EPI>
 __global__ __launch_bounds__(256) void rds_fft_step2(const float2 *__restrict__ in, float2 *__restrict__ out, int nch,
-                                                     const int *__restrict__ chlist) {
+                                                     const int *__restrict__ chlist, RdsEpi E) {
     __shared__ float2 s[16][RN2 + 1];
     __shared__ float2 tw[RN2 / 2];
     const int tid = threadIdx.x;
@@ -101,7 +123,32 @@ __global__ __launch_bounds__(256) void rds_fft_step2(const float2 *__restrict__ 
             __syncthreads();
         }
     }
-    for (int i = tid; i < RN2 * 16; i += 256) { const int k2 = i >> 4, r = i & 15; X[(k10 + r) + RN1 * k2] = s[r][k2]; }
+    for (int i = tid; i < RN2 * 16; i += 256) {
+        const int k2 = i >> 4, r = i & 15, k = (k10 + r) + RN1 * k2;
+        const float2 v = s[r][k2];
+        if (EPI == 0) X[k] = v;
+        else if (EPI == 1) { float2 w = cmulf(v, E.S[k]); X[k] = make_float2(w.x * E.scale, -(w.y * E.scale)); }
+        else if (EPI == 2) {
+            const int a = 2 * ch, b = 2 * ch + 1;
+            const bool hb = b < E.C;
+            const float f = 1.0f / (float)RN;
+            float va = v.x * f, vb = -v.y * f;
+            if (k < RBLK) {
+                if (k < RDEG) { va += E.over_old[(size_t)a * RDEG + k].x; if (hb) vb += E.over_old[(size_t)b * RDEG + k].x; }
+                E.out_real[(size_t)a * E.out_stride + k] = va; if (hb) E.out_real[(size_t)b * E.out_stride + k] = vb;
+            } else {
+                E.over_new[(size_t)a * RDEG + (k - RBLK)] = make_float2(va, 0.f);
+                if (hb) E.over_new[(size_t)b * RDEG + (k - RBLK)] = make_float2(vb, 0.f);
+            }
+        } else {
+            const float f = 1.0f / (float)RN;
+            float2 w = make_float2(v.x * f, -v.y * f);
+            if (k < RBLK) {
+                if (k < RDEG) { const float2 o = E.over_old[(size_t)ch * RDEG + k]; w.x += o.x; w.y += o.y; }
+                E.out_cplx[(size_t)ch * E.out_stride + k] = w;
+            } else E.over_new[(size_t)ch * RDEG + (k - RBLK)] = w;
+        }
+    }
 }
 
 // ---- load a 32000-sample real block, zero padded (fft-filters.cpp:104-107)
@@ -481,13 +528,14 @@ __global__ __launch_bounds__(64) void rds3_slicer(DeviceBuffers B, RdsBuffers Rb
 }
 
 static void fft_fwd(const RdsBuffers &Rb, int nch, const int *chlist, hipStream_t s) {
-    hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nch), dim3(256), 0, s, Rb.U, Rb.V, nch, chlist);
-    hipLaunchKernelGGL(rds_fft_step2, dim3(RN1 / 16, nch), dim3(256), 0, s, Rb.V, Rb.U, nch, chlist);
+    hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nch), dim3(256), 0, s, Rb.U, Rb.V, nch, chlist, (const float *)nullptr, (size_t)0, 0);
+    hipLaunchKernelGGL(rds_fft_step2<0>, dim3(RN1 / 16, nch), dim3(256), 0, s, Rb.V, Rb.U, nch, chlist, RdsEpi{});
 }
-// the same transform of the rows of A in place, B as scratch
-static void fft_rows(float2 *A, float2 *Bs, int nrows, hipStream_t s) {
-    hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nrows), dim3(256), 0, s, A, Bs, nrows, (const int *)nullptr);
-    hipLaunchKernelGGL(rds_fft_step2, dim3(RN1 / 16, nrows), dim3(256), 0, s, Bs, A, nrows, (const int *)nullptr);
+// the transform of `nrows` rows: first pass A -> Bs (or from the real pair source), last pass Bs -> A with the epilogue
+template <int EPI>
+static void fft_rows(float2 *A, float2 *Bs, int nrows, const RdsEpi &E, hipStream_t s, const float *pair_src = nullptr, size_t pair_stride = 0, int C = 0) {
+    hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nrows), dim3(256), 0, s, A, Bs, nrows, (const int *)nullptr, pair_src, pair_stride, C);
+    hipLaunchKernelGGL(rds_fft_step2<EPI>, dim3(RN1 / 16, nrows), dim3(256), 0, s, Bs, A, nrows, (const int *)nullptr, E);
 }
 
 // ---- Two channels per transform.  The inputs of both block filters are REAL, so channels 2 p and 2 p + 1 ride as the real and
@@ -496,33 +544,8 @@ static void fft_rows(float2 *A, float2 *Bs, int nrows, hipStream_t s) {
 // results are the row's real and imaginary parts; the Hilbert filter's output is complex,
 // so its spectra are taken apart behind the forward transform (A[k] = (Z[k] + conj Z[N - k]) / 2, B[k] = (Z[k] - conj Z[N - k]) / 2j)
 // and the backward transforms run per channel.  2.5 instead of 4 transforms per channel and block: the four-step transform is
-// bound by its HBM passes.
-__global__ void rds_load_real_pair(const float *__restrict__ src, size_t src_stride, float2 *__restrict__ Z, int C) {
-    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= RN) return;
-    const int a = 2 * p, b = 2 * p + 1;
-    Z[(size_t)p * RN + i] = make_float2(i < RBLK ? src[(size_t)a * src_stride + i] : 0.f, (i < RBLK && b < C) ? src[(size_t)b * src_stride + i] : 0.f);
-}
-// band-pass pair behind the second transform: conj / N, overlap add (real parts), the two real block results, the tails
-__global__ void rds_finish_pair(const float2 *__restrict__ Z, float2 *__restrict__ over, float *__restrict__ out_real, size_t out_stride, int C) {
-    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= RN) return;
-    const int a = 2 * p, b = 2 * p + 1;
-    const float f = 1.0f / (float)RN;
-    const float2 z = Z[(size_t)p * RN + i];
-    float va = z.x * f, vb = -z.y * f;
-    if (i < RDEG) { va += over[(size_t)a * RDEG + i].x; if (b < C) vb += over[(size_t)b * RDEG + i].x; }
-    if (i < RBLK) { out_real[(size_t)a * out_stride + i] = va; if (b < C) out_real[(size_t)b * out_stride + i] = vb; }
-}
-__global__ void rds_save_tail_pair(const float2 *__restrict__ Z, float2 *__restrict__ over, int C) {
-    const int p = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= RDEG) return;
-    const int a = 2 * p, b = 2 * p + 1;
-    const float f = 1.0f / (float)RN;
-    const float2 z = Z[(size_t)p * RN + RBLK + j];
-    over[(size_t)a * RDEG + j] = make_float2(z.x * f, 0.f);
-    if (b < C) over[(size_t)b * RDEG + j] = make_float2(-z.y * f, 0.f);
-}
+// bound by its HBM passes -- for the same reason the element-wise passes (load, filter vector, finish, tails) are fused into the
+// transforms' first / last passes (rds_fft_step1's pair source, rds_fft_step2's epilogues).
 // Hilbert: the pair's spectrum Z apart, each times the filter vector, conjugated (rds_spectrum's step) into the channels' own rows
 __global__ void rds_hil_split(const float2 *__restrict__ Z, const float2 *__restrict__ S, float2 *__restrict__ U, int C) {
     const int p = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
@@ -544,20 +567,26 @@ void launch_rds_block(const RdsBuffers &Rb, int C, int64_t blk, hipStream_t s) {
     if (pair && C >= 2) {
         const int P = (C + 1) / 2;
         const dim3 gp(RN / 256, P);
-        // Hilbert of the previous band-pass result: pairs forward (rows of V, U as scratch), apart into U, backward per channel
-        hipLaunchKernelGGL(rds_load_real_pair, gp, dim3(256), 0, s, Rb.bpreal + (size_t)((blk + 1) & 1) * RBLK, (size_t)2 * RBLK, Rb.V, C);
-        fft_rows(Rb.V, Rb.U, P, s);
+        const size_t ov = (size_t)C * RDEG;                       // one parity of an overlap buffer
+        // Hilbert of the previous band-pass result: pairs forward straight from the real blocks (rows of V, U as scratch), apart into U,
+        // backward per channel with the finishing pass in the transform
+        fft_rows<0>(Rb.V, Rb.U, P, RdsEpi{}, s, Rb.bpreal + (size_t)((blk + 1) & 1) * RBLK, (size_t)2 * RBLK, C);
         hipLaunchKernelGGL(rds_hil_split, gp, dim3(256), 0, s, Rb.V, Rb.S_hil, Rb.U, C);
-        fft_fwd(Rb, C, nullptr, s);
-        hipLaunchKernelGGL(rds_finish, g, dim3(256), 0, s, Rb.U, Rb.hil_over, (float *)nullptr, Rb.hil + (size_t)(blk & 1) * RBLK, (size_t)2 * RBLK, nullptr);
-        hipLaunchKernelGGL(rds_save_tail, dim3(3, C), dim3(256), 0, s, Rb.U, Rb.hil_over, nullptr);
-        // band-pass of the demod block just completed: pairs all the way
-        hipLaunchKernelGGL(rds_load_real_pair, gp, dim3(256), 0, s, Rb.in_blk, (size_t)RBLK, Rb.U, C);
-        fft_fwd(Rb, P, nullptr, s);
-        hipLaunchKernelGGL(rds_spectrum, gp, dim3(256), 0, s, Rb.U, Rb.S_bp_re, 3.0f, nullptr);
-        fft_fwd(Rb, P, nullptr, s);
-        hipLaunchKernelGGL(rds_finish_pair, gp, dim3(256), 0, s, Rb.U, Rb.bp_over, Rb.bpreal + (size_t)(blk & 1) * RBLK, (size_t)2 * RBLK, C);
-        hipLaunchKernelGGL(rds_save_tail_pair, dim3(3, P), dim3(256), 0, s, Rb.U, Rb.bp_over, C);
+        {
+            RdsEpi E{}; E.over_old = Rb.hil_over + (size_t)((blk + 1) & 1) * ov; E.over_new = Rb.hil_over + (size_t)(blk & 1) * ov;
+            E.out_cplx = Rb.hil + (size_t)(blk & 1) * RBLK; E.out_stride = (size_t)2 * RBLK; E.C = C;
+            fft_rows<3>(Rb.U, Rb.V, C, E, s);
+        }
+        // band-pass of the demod block just completed: pairs all the way, the filter vector and the finishing pass in the transforms
+        {
+            RdsEpi E{}; E.S = Rb.S_bp_re; E.scale = 3.0f;
+            fft_rows<1>(Rb.U, Rb.V, P, E, s, Rb.in_blk, (size_t)RBLK, C);
+        }
+        {
+            RdsEpi E{}; E.over_old = Rb.bp_over + (size_t)((blk + 1) & 1) * ov; E.over_new = Rb.bp_over + (size_t)(blk & 1) * ov;
+            E.out_real = Rb.bpreal + (size_t)(blk & 1) * RBLK; E.out_stride = (size_t)2 * RBLK; E.C = C;
+            fft_rows<2>(Rb.U, Rb.V, P, E, s);
+        }
         return;
     }
     // Hilbert first: its input is bpreal[(blk-1)&1] (zeros when blk == 0), output hil[blk & 1]
