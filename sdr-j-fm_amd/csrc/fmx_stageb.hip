@@ -47,6 +47,8 @@
 #include "fmx_internal.h"
 #include "fmx_demod_math.h"
 #include "fmx_fftconv.h"
+#include <cstdlib>
+#include <string>
 
 namespace fmx {
 
@@ -61,6 +63,9 @@ constexpr float PLL_TOL = 3e-5f;                               // a PLL round th
 constexpr int PLL_MAX_ROUNDS = 32, PSS_MAX_ROUNDS = 64;
 #endif
 static_assert(FB_W <= PSS_CHUNK, "the error array holds PSS_CHUNK rows per channel");
+#ifndef SB_WG_PER_SIMD
+#define SB_WG_PER_SIMD 3
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // wave scans in DPP: four steps inside the 16-lane rows (row_shr 1, 2, 4, 8), then the row totals ride row_bcast:15
@@ -108,6 +113,9 @@ struct DecayW { float m1, m2, m4, m8, mA, mB, dl, d64; };
 // to 1536 must not carry the 3e-8 of a rounded base); v_exp_f32 is good to an ulp, like the f32 the weights are stored in
 __device__ __forceinline__ DecayW make_decay(float l2, int lane) {
     DecayW w;
+#ifndef SB_HOIST_DECAY
+    asm volatile("" : "+v"(l2));        // opaque: the eight weights are recomputed where they are used (hoisted out of the segment loop they
+#endif                                  // would occupy 8 VGPRs per recurrence for the whole kernel)
 #ifdef SB_DECAY_OLD
     {
         const double D = exp2((double)l2 * FB_K);
@@ -970,11 +978,588 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_pss_kernel(DeviceTables T, Dev
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole of stage B in ONE kernel per call: one workgroup = one channel, looping over the call's segments of up to 1536 fm
+// samples.  Per segment: limiter + discriminator, AFC, pilot PLL, lock detector (nothing of which depends on the PSS feedback),
+// then the PSS error of the calls the segment can make (fast convolution of the s ring, fmx_fftconv.h), the PSS integrator,
+// 38 kHz mix, matrix, de-emphasis.  The PSS feedback lags by 1753 samples, so a segment's errors only need s-ring entries that
+// EARLIER segments of the same workgroup wrote: the barriers between them order those stores and loads (workgroup scope: one
+// CU, one L1).  demod / pilot phase / lock flags never leave the registers between the two halves; every recurrence's state
+// rides from segment to segment in registers (each thread holds the same copy); the next segment's ring entries are loaded
+// while the current one is computed.  Out: the d ring (stage C's input), the s ring, and the scope / RDS taps w_dem, w_cur,
+// w_diff (channel-major rows of this call).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
+    __shared__ ScanLds lds;
+    // the recurrences' states in front of the next segment: the same for every thread, so they live in LDS, not in everybody's registers
+    // (written by one thread behind a phase, read by all in front of the same phase of the next segment: barriers in between)
+    __shared__ struct { float afc, x0, old, lock; int locked, stable; PssSt ps; float de_l, de_r; int calls; } cy;
+    __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];     // the convolution's buffer, afterwards er / pk:
+    float *er = reinterpret_cast<float *>(X);                        // [FB_W] PSS error per call of the segment; replay path: error in, pilotDelayPSS used out
+    int *pk = reinterpret_cast<int *>(X) + FB_W;                     // [FB_W] replay path: ((tag + 2) << 1) | locked per sample
+    static_assert(2 * FB_W * 4 <= sizeof(float2) * fftc::LDS_N, "er and pk live in the convolution buffer");
+    const int ch = blockIdx.x;
+    if (ch >= C) return;
+    WG wg; wg.L = &lds; wg.tid = threadIdx.x; wg.lane = threadIdx.x & 63; wg.wv = threadIdx.x >> 6; wg.sl = 0;
+    const ChanParams &P = B.params[ch];
+    ChanState *st = B.state + ch;
+    const int nj = (int)(G.J1 - G.J0);
+    const int lin = B.lin_rows;                                  // row stride of the channel-major tap arrays
+#ifdef SB_PHASE_CYCLES                                           // (diagnostic build, tools/build_variant.sh: cycles per phase of thread 0 -- 20 VGPRs)
+    const bool dbg_on = (B.dbg != nullptr) && (threadIdx.x == 0);
+    unsigned long long dbg_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
+#define SB_TICK1(k) SB_TICK1(k)
+#else
+#define SB_TICK1(k) do { } while (0)
+#endif
+    const int decoder = P.decoder;
+    const int delay = T.front_sets[P.front_set].delay_fm;
+    const float2 *zr = B.zring + (size_t)ch * (G.ring_mask + 1);
+    const bool stereo_possible = P.fm_mode != 2, auto_mono = P.auto_mono != 0, pss_active = P.pss_active != 0;
+    const bool pss_on = stereo_possible && pss_active;
+    // the sample behind which the reference takes its metaData snapshot (++myCount > fmRate / 2, fm-processor.cpp:662-684), call-relative
+    const int my_count0 = st->my_count;
+    const int jx = (SINCOS_N >> 1) - my_count0;
+    // ring entries of the samples j0 - 2 .. j0 + K - 1 of the segment at seg0 (clamped to the call's last sample: never past what
+    // stage A wrote; zero until the filter latency has elapsed; the marker NaN where the reference's start values 0.01 apply)
+    auto fetch = [&](int j0, int seg0, int w, float2 *z) {
+#pragma unroll
+        for (int t = 0; t < FB_K + 2; t++) {
+            const int jr = j0 - 2 + t;
+            const int64_t jj = G.J0 + seg0 + (jr < w ? jr : w - 1);
+            const int64_t s = jj - delay;
+            z[t] = jj < 0 ? make_float2(__builtin_nanf(""), 0.f) : (s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f));
+        }
+    };
+    // the recurrences' states in front of the segment (the same in every thread)
+    if (threadIdx.x == 0) {
+    cy.afc = st->fm_afc; cy.x0 = st->pil_phase; cy.old = st->pil_old; cy.lock = st->pil_lock;
+    cy.locked = st->pil_locked; cy.stable = st->pil_stable;
+    PssSt ps;
+    ps.acc = st->pss_acc; ps.mean = st->pss_mean; ps.pdp = st->pilot_delay_pss;
+    ps.lock_cnt = st->pss_lock_cnt; ps.unlock_cnt = st->pss_unlock_cnt; ps.minimized = st->pss_minimized != 0;
+    if (P.actions & (ACT_TRIGGER_FREQ | ACT_RESTART_PSS)) {
+        // triggerFrequencyChange / restartPssAnalyzer fm-processor.cpp:849-860
+        ps.pdp = 0.f; ps.acc = 0.f; ps.minimized = false; ps.mean = 0.f; ps.lock_cnt = 0; ps.unlock_cnt = 0;
+        if (P.actions & ACT_TRIGGER_FREQ) st->fade_start_frame = G.M0;
+    }
+    cy.ps = ps; cy.de_l = st->de_l; cy.de_r = st->de_r;
+    cy.calls = 0;                                                // process_sample calls of this call's earlier segments
+    }
+    const int64_t pss_count0 = st->pss_count;
+    float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
+    float2 zn[FB_K + 2];
+    fetch((int)threadIdx.x * FB_K, 0, nj < FB_W ? nj : FB_W, zn);
+    __syncthreads();
+    for (int seg0 = 0; seg0 < nj; seg0 += FB_W) {
+        // Everything below that only depends on the thread index (table addresses, twiddles, scan weights, the ramp) is
+        // loop-invariant, and the compiler would keep it all in registers across the loop (346 VGPRs): the index is made opaque
+        // per segment, so those values are recomputed / reloaded (L1 hits) where they are used.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        wg.tid = tid; wg.lane = tid & 63; wg.wv = tid >> 6;
+        const int lane = wg.lane;
+        const int j0 = tid * FB_K;                                   // segment-relative index of this thread's first sample
+        const int w = (nj - seg0) < FB_W ? (nj - seg0) : FB_W;
+        const bool lastseg = seg0 + FB_W >= nj;
+        bool ok[FB_K];
+#pragma unroll
+        for (int i = 0; i < FB_K; i++) ok[i] = j0 + i < w;
+        const bool owner = (w - 1 >= j0) && (w - 1 < j0 + FB_K);     // this thread owns the segment's last sample
+        const int il = w - 1 - j0;                                   // ... at this position
+        const size_t lrow = (size_t)ch * lin + seg0 + j0;
+        const int ix = jx - seg0 - j0;                               // this thread's index of the metaData snapshot sample, if 0 .. K-1
+
+        // ================= limiter + discriminator (fm-demodulator.cpp:119-126, 168-189) =================
+        float res[FB_K];
+        {
+            float2 lim[FB_K + 2];                                // limited samples j0-2 .. j0+K-1 (the two in front recomputed: cheaper
+#pragma unroll                                                   // than an exchange through LDS with its two barriers)
+            for (int t = 0; t < FB_K + 2; t++) lim[t] = (zn[t].x != zn[t].x) ? make_float2((float)0.01, (float)0.01) : limiter_fast(zn[t]);
+            // (one loop per decoder: the six table gathers of a thread are issued back to back, not one per branch arm)
+            if (decoder == 5) {                                      // REAL_BB :174-182
+                int index[FB_K];
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
+                    const float r = (float)((double)(I1 * Q - Q1 * I + 1) / 2.0);
+                    int ixx = (int)floorf(r * (float)ARCSINE_N);
+                    ixx = ixx < 0 ? 0 : ixx;
+                    index[i] = ixx >= ARCSINE_N ? ARCSINE_N : ixx;
+                }
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) res[i] = T.arcsine[index[i]];
+            } else if (decoder == 6) {                               // DIFF :184-189
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
+                    const float Scaler = (float)1.4142135623730951;
+                    const float r = (I1 * (Q - lim[i].y) - Q1 * (I - lim[i].x));
+                    res[i] = fdiv_fast(r, (I1 * I1 + Q1 * Q1) * Scaler);
+                }
+            } else {                                                 // MIXED :168-172 (COMPLEX_BB is bitwise the same)
+                AtanArm arm[FB_K];
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
+                    arm[i] = atan_arm(Q * I1 - I * Q1, I * I1 + Q * Q1);
+                }
+                float tv[FB_K];
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) tv[i] = T.atan_ppy[arm[i].idx];
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) res[i] = atan_finish(arm[i], tv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) res[i] = ok[i] ? res[i] : 0.f;
+        }
+        SB_TICK1(0);
+
+        // ================= AFC + scaling (fm-demodulator.cpp:197-198) =================
+        float dem[FB_K];
+        {
+            const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha;
+            float Lt = 0.f;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) Lt = c1 * Lt + fmDcAlpha * res[i];
+            float afc_next;
+            float afc = wg.decay_incoming2(Lt, cy.afc, make_decay(T.afc_l2, lane), &afc_next);
+            float afc_end = 0.f;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) {
+                afc = c1 * afc + fmDcAlpha * res[i];
+                dem[i] = fdiv_const(20.0f * (res[i] - afc) * 1.0f, T.K_FM, T.K_FM_rcp);
+                if (i == il) afc_end = afc;
+                if (i == ix && ok[i]) st->meta_dc_if = afc;                   // get_demodDcComponent () at the snapshot
+            }
+            if (lastseg && owner) st->fm_afc = afc_end;
+            if (tid == 0) cy.afc = afc_next;
+        }
+        SB_TICK1(1);
+
+        // ================= pilot PLL (pilot-recover.cpp:54-61): fixed point of the f32 trajectory =================
+        float cur[FB_K], osc[FB_K];
+        float osc_in;                                            // NCO sine of the sample in front of this thread's first
+        {
+            const float gain = T.pil_gain, omega = T.pil_omega;
+            const float SC32 = (float)T.sincos_C;
+            const float P32 = 6.2831855f, C32 = T.wrap32_c;
+            float x0 = cy.x0;
+            if (!(x0 >= 0.f && x0 < P32)) x0 = pi_constrain(x0);
+            float ph[FB_K];
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) {
+                // first guess: the free-running ramp x0 + j omega
+                const double r = (double)x0 + (double)(j0 + i) * (double)omega;
+                ph[i] = (j0 + i == 0) ? x0 : (float)(r - floor(r * (1.0 / FMX_2PI)) * FMX_2PI);
+            }
+            const double x0d = (double)x0;
+            float xend = x0;
+            for (int it = 0; ; it++) {
+                double e[FB_K], tot = 0.0;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    float phase = ph[i];
+                    // a guess outside [0, 2 pi) (guesses of unfinished rounds only: a wrap that sits one sample earlier or later in the
+                    // guess than in the step's result shifts everything behind it by a turn) is taken modulo 2 pi
+                    if (__any(!(phase >= 0.f && phase < P32))) {
+                        const double pd = (double)phase;
+                        const float pw = (float)(pd - floor(pd * (1.0 / FMX_2PI)) * FMX_2PI);
+                        phase = (phase >= 0.f && phase < P32) ? phase : ((pw >= 0.f && pw < P32) ? pw : 0.f);
+                    }
+                    // SinCos::getSin sincos.cpp:81-85 for phase >= 0: table entry (int)(phase * C) % Rate, the entry itself from
+                    // sin_idx_f32 (the index in f32: it differs from the f64 product's in < 2 % of the samples, by one entry)
+                    int idx = (int)(phase * SC32);
+                    idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+                    const float o = sin_idx_f32(idx);
+                    const float perr = (5 * dem[i]) * o;             // pilot-recover.cpp:56-58 (pilot = 5 * demod fm-processor.cpp:696)
+                    const float t = phase + perr * gain;
+                    const float val = t + omega;
+                    const float wrapped = T.wrap32_ok ? (val - P32) + C32 : (float)((double)val - FMX_2PI);
+                    float nx = (val < P32) ? val : wrapped;          // PI_Constrain fm-constants.h:148-158
+                    // (a correction of more than a turn: the DIFF decoder's spike where the limiter output jumps from its 0.001 floor
+                    // to the unit circle at signal onset -- the general PI_Constrain, wave-uniformly skipped otherwise)
+                    if (__any(!(val >= 0.f && val < 2.f * P32))) nx = pi_constrain(val);
+                    cur[i] = t; osc[i] = o;
+                    e[i] = tot;
+                    tot += ok[i] ? (double)nx - (double)phase : 0.0;
+                }
+                double total; bool any;
+                const double pre = wg.excl_add_d(tot, &total, false, &any);
+                bool open_ = false;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    const float nph = (float)(x0d + (pre + e[i]));
+                    // distance between the guess this round evaluated and the one it produced (a wrap that moved by one sample
+                    // shows as 2 pi)
+                    float dd = fabsf(nph - ph[i]);
+                    dd = fminf(dd, fabsf(dd - P32));
+                    open_ = open_ || (ok[i] && !(dd < PLL_TOL));
+                    ph[i] = nph;
+                }
+                {   // (a guess chain may carry whole turns: dd above takes them for "no change", so the end state is taken modulo 2 pi)
+                    const double xe = x0d + total;
+                    xend = (float)(xe - floor(xe * (1.0 / FMX_2PI)) * FMX_2PI);
+                }
+                // every thread must know whether ANY thread is still moving: one more reduction (flags only)
+                const int wopen = __any(open_) ? 1 : 0;              // (evaluated by the whole wave, not under the lane-0 branch)
+                if (lane == 0) lds.wi[wg.sl][wg.wv][0] = wopen;
+                __syncthreads();
+                const int anych = lds.wi[wg.sl][0][0] | lds.wi[wg.sl][1][0] | lds.wi[wg.sl][2][0] | lds.wi[wg.sl][3][0];
+                wg.sl ^= 1;
+                if (!anych || it == PLL_MAX_ROUNDS - 1) { if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it + 1; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; } break; }
+            }
+            // (cur / osc are those of the last round's evaluation: of a trajectory the round moved by less than PLL_TOL)
+            const float x0s = (xend >= 0.f && xend < P32) ? xend : 0.f;
+            if (tid == 0) { cy.x0 = x0s; if (lastseg) st->pil_phase = x0s; }
+            float old_next;
+            osc_in = wg.from_left2(osc[FB_K - 1], cy.old, &old_next);
+            if (tid == 0) cy.old = old_next;
+            if (lastseg && owner) {
+                float oe = 0.f;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) if (i == il) oe = osc[i];
+                st->pil_old = oe;
+            }
+        }
+        SB_TICK1(2);
+
+        // ================= lock detector (pilot-recover.cpp:62-80) =================
+        bool locked[FB_K];
+        {
+            const float lockA = 1.0f / 3000.0f;
+            const double keep = 1.0 - (double)lockA;
+            const float keepf = (float)keep;
+            const float omega = T.pil_omega, romega = T.pil_omega_rcp;
+            float xq[FB_K];
+            {
+                float old = osc_in;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    const float quadRef = fdiv_const(osc[i] - old, omega, romega);
+                    old = osc[i];
+                    xq[i] = ok[i] ? lockA * (-quadRef * (5 * dem[i])) : 0.f;
+                }
+            }
+            float Lt = 0.f;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) Lt = xq[i] + Lt * keepf;
+            float lock_next;
+            const int locked0 = cy.locked, stable0 = cy.stable;
+            float lock = wg.decay_incoming2(Lt, cy.lock, make_decay(T.lock_l2, lane), &lock_next);
+            bool hi[FB_K]; int lastf = -1; float lock_end = 0.f, lock_x = 0.f;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) {
+                lock = (float)((double)xq[i] + (double)lock * keep);
+                hi[i] = lock > 0.07f;
+                if (ok[i] && !hi[i]) lastf = j0 + i;
+                if (i == il) lock_end = lock;
+                if (i == ix) lock_x = lock;
+            }
+            // locked[j] = no sample <= j below the threshold AND (locked before, or the run has lasted long enough)
+            int cnt_dummy, tot_dummy, preF, totF;
+            wg.excl_add_max_i(0, lastf, &cnt_dummy, &tot_dummy, &preF, &totF);
+            {
+                int F = preF;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    if (ok[i] && !hi[i]) F = j0 + i;
+                    const bool lk = (F < 0) && (locked0 != 0 || stable0 + (j0 + i) + 1 > (SINCOS_N >> 1));
+                    locked[i] = lk;
+                    if (i == ix && ok[i]) {                                  // isPilotLocked (PilotPllLockStrength) :870-880
+                        st->meta_locked = (stereo_possible && lk) ? 1 : 0;
+                        st->meta_lock_strength = stereo_possible ? lock_x : 0.f;
+                    }
+                }
+            }
+            int nl, ns;
+            if (totF < 0) { nl = (locked0 != 0 || stable0 + w > (SINCOS_N >> 1)) ? 1 : 0;
+                            ns = locked0 ? stable0 : (stable0 + w < (SINCOS_N >> 1) + 1 ? stable0 + w : (SINCOS_N >> 1) + 1); }
+            else { nl = 0; ns = w - 1 - totF; }
+            if (lastseg && owner) { st->pil_lock = lock_end; st->pil_locked = nl; st->pil_stable = ns; }
+            if (tid == 0) { cy.locked = nl; cy.stable = ns; cy.lock = lock_next; }
+        }
+        // scope taps and the inputs of the RDS path: channel-major rows of this call
+#pragma unroll
+        for (int i = 0; i < FB_K; i++) if (ok[i]) { B.w_dem[lrow + i] = dem[i]; B.w_cur[lrow + i] = cur[i]; }
+        SB_TICK1(3);
+
+        // ================= PSS errors of the calls this segment can make: err[m] = Re (y) Im (y), y = low-pass of the s ring
+        // (stereo-separation.cpp:60-83), m = call index within the segment, into er =================
+        if (pss_on) {
+            const int64_t i0 = pss_count0 + cy.calls;                                // call index of the segment's first output
+            float2 a[8];
+#pragma unroll
+            for (int p = 0; p < 8; p++) {      // window entry n <-> s index i0 - (1753 + 294) + n; entries past the segment's need are padding
+                const int n = tid + fftc::T * p;
+                const int64_t idx = i0 - (PSS_DELAY + PSS_TAPS - 1) + n;
+                a[p] = (n < w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
+            }
+            fftc::convolve(tid, a, X, T.fft_w, T.pss_hs);
+            __syncthreads();                   // (er overlays the buffer the last stage was read from)
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int m = tid + fftc::T * p - (PSS_TAPS - 1);
+                if (m >= 0 && m < FB_W) er[m] = a[p].x * a[p].y;
+            }
+        }
+        __syncthreads();
+        SB_TICK1(4);
+
+        // ================= the PSS call index of every sample (fm-processor.cpp:704-718) =================
+        int tag[FB_K];
+        int ncalls;
+        {
+            int ncall_t = 0;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) {
+                const bool branch = stereo_possible && (locked[i] || !auto_mono);
+                tag[i] = branch ? (pss_active ? 0 : -1) : -2;
+                ncall_t += (ok[i] && branch && pss_active) ? 1 : 0;
+            }
+            int preC, dm1, dm2;
+            wg.excl_add_max_i(ncall_t, 0, &preC, &ncalls, &dm1, &dm2);
+            int c = preC;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) if (tag[i] == 0) { tag[i] = ok[i] ? c : -2; c += ok[i] ? 1 : 0; }    // index of the call within the segment
+        }
+
+        // ================= PSS integrator (stereo-separation.cpp:84-109, fm-processor.cpp:699-718) =================
+        float used[FB_K];                                            // pilotDelayPSS as used by each sample
+        {
+            const PssSt s = cy.ps;
+            const float alpha = T.pss_alpha, la = T.pss_lock_alpha, keep = 1.0f - la;
+            const float c4 = 0.785398185253143310546875f;
+            float err[FB_K];
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) err[i] = (pss_on && tag[i] >= 0) ? er[tag[i]] : 0.f;
+            // classification (the same for every thread)
+            int firstU = -0x7fffffff - 1, firstZ = -0x7fffffff - 1, anyl = 0, alll = 0;            // as maxima of negated indices
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) if (ok[i]) {
+                if (!locked[i]) { const int v = -(j0 + i); firstU = v > firstU ? v : firstU; alll = 1; }
+                else anyl = 1;
+                if (tag[i] == -1) { const int v = -(j0 + i); firstZ = v > firstZ ? v : firstZ; }
+            }
+            wg.reduce_max4(firstU, firstZ, anyl, alll);              // alll = 1 when some sample is NOT locked
+            const bool all_locked = alll == 0;
+            const bool steady = pss_on && ncalls == w && all_locked && ((s.minimized ? s.unlock_cnt : s.lock_cnt) + w <= 3 * SINCOS_N);
+            const bool nocall = ncalls == 0;
+            PssSt e = s;                                             // state behind the segment
+            if (steady) {
+                const bool mz = s.minimized;
+                float xa[FB_K], er10[FB_K];
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) { er10[i] = mz ? err[i] : err[i] * 10.0f; xa[i] = alpha * er10[i]; }
+                // accPhaseShift: fixed point of the exact f32 trajectory a[j] = value in front of sample j
+                float a[FB_K];
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) a[i] = s.acc;
+                const double a0 = (double)s.acc;
+                float aend = s.acc;
+                for (int it = 0; ; it++) {
+                    double d[FB_K], ex[FB_K], tot = 0.0;
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) {
+                        const float na = fminf(fmaxf(a[i] + xa[i], -c4), c4);
+                        d[i] = ok[i] ? (double)na - (double)a[i] : 0.0;
+                        ex[i] = tot; tot += d[i];
+                    }
+                    double total; bool any;
+                    const double pre = wg.excl_add_d(tot, &total, false, &any);
+                    bool changed = false;
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) {
+                        const float na = (float)(a0 + (pre + ex[i]));
+                        changed = changed || (ok[i] && __float_as_int(na) != __float_as_int(a[i]));
+                        a[i] = na;
+                    }
+                    aend = (float)(a0 + total);
+                    if (lane == 0) lds.wi[wg.sl][wg.wv][0] = 0;
+                    if (__any(changed) && lane == 0) lds.wi[wg.sl][wg.wv][0] = 1;
+                    __syncthreads();
+                    const int anych = lds.wi[wg.sl][0][0] | lds.wi[wg.sl][1][0] | lds.wi[wg.sl][2][0] | lds.wi[wg.sl][3][0];
+                    wg.sl ^= 1;
+                    if (!anych || it == PSS_MAX_ROUNDS - 1) { if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 9] += it + 1; B.dbg[(size_t)ch * DBG_SLOTS + 12] += 1; } break; }
+                }
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) used[i] = (j0 + i == 0) ? s.pdp : a[i];
+                // mean_error (1 / rate smoothing) and the "minimised" bookkeeping in closed form
+                const DecayW dw = make_decay(T.pssmean_l2, lane);
+                float Lt = 0.f;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) Lt = (ok[i] ? la * er10[i] : 0.f) + Lt * keep;
+                float mean = wg.decay_incoming(Lt, s.mean, dw);
+                int lastS = -1, lastN = -1, d3 = 0, d4 = 0; float mean_end = 0.f;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    mean = la * er10[i] + mean * keep;
+                    if (ok[i]) { if (fabsf(mean) < 0.001f) lastS = j0 + i; else lastN = j0 + i; }
+                    if (i == il) mean_end = mean;
+                    if (i == ix && ok[i]) meta_snapshot(st, P, fminf(fmaxf(a[i] + xa[i], -c4), c4), mean, mz, true);   // (mz: no flip inside a steady segment)
+                }
+                wg.reduce_max4(lastS, lastN, d3, d4);
+                if (owner) lds.wf[0][0][3] = mean_end;               // (slot-free word: read after the next barrier below)
+                __syncthreads();
+                e.mean = lds.wf[0][0][3];
+                e.acc = aend; e.pdp = aend; e.minimized = mz;
+                const bool all_small = lastN < 0, any_small = lastS >= 0;
+                if (mz) { e.lock_cnt = all_small ? s.lock_cnt : 0; e.unlock_cnt = any_small ? (w - 1 - lastS) : s.unlock_cnt + w; }
+                else { e.lock_cnt = all_small ? s.lock_cnt + w : (w - 1 - lastN); e.unlock_cnt = any_small ? 0 : s.unlock_cnt; }
+            } else if (nocall) {
+                // nobody calls process_sample: an unlocked sample clears everything, a stereo sample without PSS clears pilotDelayPSS
+                const int fu = (firstU == -0x7fffffff - 1) ? 0x7fffffff : -firstU, fz = (firstZ == -0x7fffffff - 1) ? 0x7fffffff : -firstZ;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) used[i] = (j0 + i >= fu || j0 + i > fz) ? 0.f : s.pdp;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) if (i == ix && ok[i]) {
+                    const bool cleared = j0 + i >= fu;
+                    meta_snapshot(st, P, (cleared || j0 + i >= fz) ? 0.f : s.pdp, cleared ? 0.f : s.mean, cleared ? false : s.minimized, locked[i]);
+                }
+                if (fu != 0x7fffffff) { e.pdp = 0.f; e.acc = 0.f; e.mean = 0.f; e.minimized = false; e.lock_cnt = 0; e.unlock_cnt = 0; }
+                else if (fz != 0x7fffffff) e.pdp = 0.f;
+            } else {
+                // replay (lock transitions inside a PSS segment, a counter within a segment of its 3 s threshold)
+                __syncthreads();                                     // (every thread has taken its errors out of er)
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) if (ok[i]) { pk[j0 + i] = ((tag[i] + 2) << 1) | (locked[i] ? 1 : 0); er[j0 + i] = err[i]; }
+                __syncthreads();
+                if (B.dbg && tid == 0) B.dbg[(size_t)ch * DBG_SLOTS + 10] += 1;
+                if (tid == 0) {
+                    PssSt r = s;
+                    const int jxs = jx - seg0;
+                    for (int j = 0; j < w; j++) {
+                        const int p = pk[j];
+                        er[j] = pss_step(r, alpha, la, keep, (p & 1) != 0, (p >> 1) - 2, er[j]);
+                        if (j == jxs) meta_snapshot(st, P, r.pdp, r.mean, r.minimized, (p & 1) != 0);
+                    }
+                    lds.wf[0][0][3] = r.acc; lds.wf[0][1][3] = r.mean; lds.wf[0][2][3] = r.pdp;
+                    lds.wi[0][0][3] = r.lock_cnt; lds.wi[0][1][3] = r.unlock_cnt; lds.wi[0][2][3] = r.minimized ? 1 : 0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) used[i] = ok[i] ? er[j0 + i] : 0.f;
+                e.acc = lds.wf[0][0][3]; e.mean = lds.wf[0][1][3]; e.pdp = lds.wf[0][2][3];
+                e.lock_cnt = lds.wi[0][0][3]; e.unlock_cnt = lds.wi[0][1][3]; e.minimized = lds.wi[0][2][3] != 0;
+                __syncthreads();
+            }
+            __syncthreads();                                         // (everybody has its copy of the state in front of the segment)
+            if (tid == 0) cy.ps = e;
+        }
+        SB_TICK1(5);
+
+        // ================= 38 kHz mix, PSS input, stereo matrix (fm-processor.cpp:707-730, 517-549) =================
+        float2 x[FB_K];
+        {
+            constexpr double INV2PI = 1.0 / FMX_2PI;
+            const int ssel = P.sound_sel, fmode = P.fm_mode; const float pano = P.panorama;
+            const int64_t ic = pss_count0 + cy.calls;                // call index of the segment's first call
+            float diffv[FB_K];
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) {
+                // phaseforLRDiff fm-processor.cpp:707-714: 2 (currentPilotPhase + pi/4) - pilotDelayPSS lies in (0, 4 pi + 2.4), so the
+                // "< -2 pi" branch never runs and fmod (., 2 pi) is the fraction of the turn count
+                float cc = pi_constrain_near(cur[i]);
+                if (__any(!(cur[i] > -6.f && cur[i] < 12.f))) cc = pi_constrain(cur[i]);    // (see the pilot PLL: corrections of more than a turn)
+                const float p = (float)(2 * ((double)cc + FMX_PI_4 + 0) - (double)used[i]);
+                const double u = __builtin_amdgcn_fract((double)p * INV2PI);
+                int idx = (int)(u * (double)SINCOS_N);               // SinCos::getComplex sincos.cpp:93-97
+                idx = idx >= SINCOS_N ? SINCOS_N - 1 : idx;
+                float2 e;
+                sincos_idx_f32(idx, &e.y, &e.x);
+                const float sn = e.y;                                // S_LEFTminusRIGHT_Test mixes with the sine
+                float2 audio = make_float2(dem[i], 0.f);
+                if (tag[i] != -2) {
+                    if (tag[i] >= 0 && ok[i]) sring[(ic + tag[i]) & G.sring_mask] = make_float2(e.x * dem[i], e.y * dem[i]);
+                    const float lut = (ssel == 6) ? sn : e.x;
+                    audio.y = 2.0f * (lut * dem[i]);                 // (float)(2.0 * lut * demod): one rounding of the exact product either way
+                }
+                const float sumLR = audio.x, diffLR = audio.y;
+                const float dw = diffLR * (fmode == 1 ? pano : 1.0f);
+                const float left = sumLR + dw, right = sumLR - dw;
+                float2 o;
+                switch (ssel) {
+                default:
+                case 0: o = make_float2(left, right); break;
+                case 1: o = make_float2(right, left); break;
+                case 2: o = make_float2(left, left); break;
+                case 3: o = make_float2(right, right); break;
+                case 4: o = make_float2(sumLR, sumLR); break;
+                case 5: case 6: o = make_float2(dw, dw); break;
+                }
+                x[i] = ok[i] ? o : make_float2(0.f, 0.f);
+                diffv[i] = audio.y;
+            }
+            // scope tap (fmx_get_tap): channel-major rows of this call
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) if (ok[i]) B.w_diff[lrow + i] = diffv[i];
+        }
+        SB_TICK1(6);
+
+        // ================= de-emphasis (fm-processor.cpp:594-595) into the d ring =================
+        // (the next segment's ring entries are requested here: they land under the de-emphasis, and are not in the way of the
+        // register-hungry phases above)
+        if (!lastseg) { const int wn = (nj - seg0 - FB_W) < FB_W ? (nj - seg0 - FB_W) : FB_W; fetch(j0, seg0 + FB_W, wn, zn); }
+        {
+            const float a = P.deemph_alpha;
+            const DecayW dw = make_decay(P.deemph_l2, lane);
+            float Ll = 0.f, Lr = 0.f;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) { Ll = (x[i].x - Ll) * a + Ll; Lr = (x[i].y - Lr) * a + Lr; }
+            float yl = wg.decay_incoming(Ll, cy.de_l, dw);
+            float yr = wg.decay_incoming(Lr, cy.de_r, dw);
+            if (tid == 0) cy.calls += ncalls;                        // (the mix above was the last reader; two barriers in between)
+            const int64_t dmask = G.dring_mask;
+            float2 *dr = B.dring + (size_t)ch * (dmask + 1);
+            float el = 0.f, er_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) {
+                yl = (x[i].x - yl) * a + yl;
+                yr = (x[i].y - yr) * a + yr;
+                if (ok[i]) dr[(G.J0 + seg0 + j0 + i) & dmask] = make_float2(yl, yr);
+                if (i == il) { el = yl; er_ = yr; }
+            }
+            // the state behind the segment's last sample, as its owner computed it (read again behind the next segment's barriers)
+            if (owner) { cy.de_l = el; cy.de_r = er_; }
+        }
+        SB_TICK1(7);
+    }
+    // ================= bookkeeping behind the call =================
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const PssSt ps = cy.ps;
+        st->pss_acc = ps.acc; st->pss_mean = ps.mean; st->pilot_delay_pss = ps.pdp;
+        st->pss_lock_cnt = ps.lock_cnt; st->pss_unlock_cnt = ps.unlock_cnt; st->pss_minimized = ps.minimized ? 1 : 0;
+        st->de_l = cy.de_l; st->de_r = cy.de_r;
+        // metaData: the snapshot behind sample fmRate / 2 - myCount of the call was stored sample-exactly above; the RF DC level moves
+        // by 1e-7 of its distance per input sample and is taken here, at the end of that call
+        int cnt = my_count0 + nj;
+        if (cnt > (SINCOS_N >> 1)) {
+            const float dcabs = (float)sqrt((double)st->dc_re * (double)st->dc_re + (double)st->dc_im * (double)st->dc_im);
+            st->meta_dc_rf = P.dc_remove ? 20 * log10f(dcabs + 1.0f / 32768) : (float)-99.99;
+            cnt -= (SINCOS_N >> 1) + 1;
+        }
+        st->my_count = cnt;
+        st->pss_count = pss_count0 + cy.calls;               // the PSS filter time base advances by this call's process_sample calls
+        st->pss_call_total = 0;
+    }
+    SB_TICK1(8);
+#ifdef SB_PHASE_CYCLES
+    if (dbg_on) for (int k = 0; k < 9; k++) B.dbg[(size_t)ch * DBG_SLOTS + 16 + k] += dbg_acc[k];
+#endif
+    if (B.dbg && threadIdx.x == 0) {
+        B.dbg[(size_t)ch * DBG_SLOTS + 13] = __float_as_uint(cy.x0); B.dbg[(size_t)ch * DBG_SLOTS + 14] = __float_as_uint(cy.lock);   // (diagnostics: state behind the call)
+    }
+}
+
 // The fused schedule: the PLL kernel for the whole call, then per segment the PSS kernel (whose errors need the s-ring entries
 // the segment in front of it wrote).
 void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s) {
     const int64_t nj = G.J1 - G.J0;
     if (nj <= 0) return;
+    static const bool split = getenv("FMX_STAGE_B") && std::string(getenv("FMX_STAGE_B")) == "split";     // (A/B runs: the two-kernel schedule)
+    if (!split && T.pss_hs) { hipLaunchKernelGGL(stageb_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, T, B, G, C); FMX_LAUNCHED(); return; }
     hipLaunchKernelGGL(stageb_pll_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, T, B, G, C); FMX_LAUNCHED();
     for (int64_t seg0 = 0; seg0 < nj; seg0 += FB_W) {
         SegArgs A;
