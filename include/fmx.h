@@ -81,6 +81,11 @@ typedef enum {
     FMX_P_SQUELCH_VALUE = 19,  /* set_squelchValue 0..100 (:213-215): takes effect at the next call when it differs  */
     FMX_P_DISP_DELAY = 20,     /* setDispDelay (:935-937): steps of the peak-level delay line; applies to the windows
                                   fmx_get_peaks has not handed out yet */
+    FMX_P_PLL_SOLVER = 21,     /* how stage B evaluates the pilot PLL loop of pilot-recover.cpp:54-61 (no counterpart in the reference, whose
+                                  loop runs sample by sample): 1 = sequentially, one thread per channel -- the reference's f32 trajectory
+                                  bit for bit (about 45 us per 1536 fm samples and channel); 2 = all samples of a segment at once by
+                                  Newton's method -- the trajectory to ~1e-5 rad (the loop's own f32 rounding noise, integrated), what
+                                  large batches need; 0 = automatic: 1 up to 64 channels per handle, 2 above (default) */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */
@@ -109,6 +114,7 @@ typedef enum {
     FMX_TAP_PRE_RESAMPLER = 3, /* complex @fmRate after de-emphasis (:594-595), before gain; this
                                   build applies the audio low-pass AFTER this point */
     FMX_TAP_RDS_IQ = 4,        /* complex @24 kS/s after rdsDecimator (RDS_INPUT scope, :566-569)        */
+    FMX_TAP_PILOT_PHASE = 5,   /* float   @fmRate currentPilotPhase (:695; the value the RDS mixer's phase buffer takes, :747) */
 } fmx_tap_id;
 
 /* per-kernel timing collected with HIP events on the processing stream */
@@ -208,6 +214,11 @@ int  fmx_rds_symbols(fmx_handle h, int32_t channel, float *iq, int32_t capacity,
 /* fm-rate samples (inputRate / 12) the last fmx_process_* call produced per channel: the n that fmx_get_tap accepts for the
  * fm-rate taps, and the number of entries the reference's run() pushed into its LF scope vector for the same block */
 int64_t fmx_last_fm_samples(fmx_handle h);
+/* Health counter of the pilot PLL (no counterpart in the reference, whose loop is sequential): stage B finds the loop's
+ * trajectory of a 1536-sample segment by Newton's method on the whole segment; a segment that does not settle within the
+ * round limit is replayed sample by sample by one thread -- correct, only slower.  Returns the number of such segments
+ * of `channel` since fmx_create (channel < 0: summed over all channels), or a negative fmx error code. */
+int64_t fmx_pll_replays(fmx_handle h, int32_t channel);
 /* ... and 24 kS/s RDS samples (rdsDecimator outputs, fm-processor.cpp:553): the n that fmx_get_tap accepts for FMX_TAP_RDS_IQ */
 int64_t fmx_last_rds_samples(fmx_handle h);
 

@@ -430,6 +430,8 @@ int rds_restart(fmx_handle h) {
     return FMX_OK;
 }
 
+constexpr int PLL_SEQ_AUTO_MAX = 64;   // FMX_P_PLL_SOLVER = 0: handles up to this many channels evaluate the pilot PLL sequentially
+
 int flush_mailbox(fmx_handle h) {
     std::lock_guard<std::mutex> lk(h->mtx);
     if (h->sets_dirty) { int rc = ensure_sets(h); if (rc) return rc; h->params_dirty = true; }
@@ -725,6 +727,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         // constructor defaults fm-processor.cpp:110-160 / fm-demodulator.cpp:66
         p.fm_mode = 0; p.sound_sel = 0; p.decoder = 3; p.auto_mono = 1; p.pss_active = 1; p.dc_remove = 1;
         p.rds_mode = 0; p.lo_freq = 0; p.lo_period = 0; p.att_l = 1.f; p.att_r = 1.f;
+        p.pll_seq = h->channels <= PLL_SEQ_AUTO_MAX ? 1 : 0;
         p.squelch_mode = 0; p.squelch_thr = std::pow(10.0f, (float)(1 - 80) / 30.0f); p.squelch_nthr = 1.0f - 1 / 100.0f;
         refresh_derived(h, c);
     }
@@ -1012,6 +1015,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_SQUELCH_MODE:
         if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "squelch mode must be 0 (off), 1 (noise squelch) or 2 (level squelch)"); break;
     case FMX_P_SQUELCH_VALUE: if (iv < 0 || iv > 100) return fail(FMX_E_INVALID, "squelch value must be 0..100"); break;
+    case FMX_P_PLL_SOLVER: if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "PLL solver must be 0 (automatic), 1 (sequential) or 2 (parallel)"); break;
     case FMX_P_DISP_DELAY: if (iv < 0 || iv > 100000) return fail(FMX_E_INVALID, "display delay must be 0..100000 steps"); break;
     case FMX_P_TEST_TONE:
     case FMX_P_VOLUME_DB: case FMX_P_LF_CUTOFF: case FMX_P_ATTENUATION_L: case FMX_P_ATTENUATION_R:
@@ -1061,6 +1065,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         case FMX_P_SQUELCH_MODE: p.squelch_mode = iv; break;
         case FMX_P_SQUELCH_VALUE: u.squelch_value = iv; break;
         case FMX_P_TEST_TONE: p.test_tone = iv != 0; break;
+        case FMX_P_PLL_SOLVER: p.pll_seq = (iv == 1 || (iv == 0 && h->channels <= PLL_SEQ_AUTO_MAX)) ? 1 : 0; break;
         case FMX_P_DISP_DELAY:                       // DelayLine::set_delay_steps fm-processor.h:60-63: resize keeps what is there
             u.delay.resize((size_t)iv + 1, make_float2(-40.0f, -40.0f)); u.delay_idx = 0; break;
         case FMX_P_DC_REMOVE: p.dc_remove = iv != 0; p.actions |= ACT_DC_RESET; break;
@@ -1199,14 +1204,14 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
     switch (tap) {
     case FMX_TAP_FM_IQ: base = (const char *)(h->B.zring + (size_t)channel * h->ring); cap = h->ring; elem = sizeof(float2);
         delay = h->h_front_sets[h->params[channel].front_set].delay_fm; break;
-    case FMX_TAP_DEMOD: case FMX_TAP_LR_RAW: {
+    case FMX_TAP_DEMOD: case FMX_TAP_LR_RAW: case FMX_TAP_PILOT_PHASE: {
         // these two taps are read back from the last call's work arrays (tiles of 16 rows: widx), rows [nj - n, nj)
         const int64_t nj = h->last_J1 - h->last_J0, r0 = nj - n;
         if (n == 0) return FMX_OK;
         if (h->last_lin) {           // fused layout: this call's rows are contiguous per channel
             const size_t off = (size_t)channel * (size_t)h->work_nj + (size_t)r0;
             std::vector<float> a((size_t)n), b;
-            HIPCHK(hipMemcpy(a.data(), h->B.w_dem + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(a.data(), (tap == FMX_TAP_PILOT_PHASE ? h->B.w_cur : h->B.w_dem) + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
             if (tap == FMX_TAP_LR_RAW) {
                 b.resize((size_t)n);
                 HIPCHK(hipMemcpy(b.data(), h->B.w_diff + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
@@ -1217,7 +1222,7 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
         const int64_t t0 = r0 / WT, t1 = (nj - 1) / WT + 1;
         std::vector<float> a((size_t)(t1 - t0) * WT), b;
         const size_t spitch = (size_t)h->pitch * WT * sizeof(float);
-        HIPCHK(hipMemcpy2D(a.data(), WT * sizeof(float), h->B.w_dem + ((size_t)t0 * h->pitch + channel) * WT, spitch, WT * sizeof(float), (size_t)(t1 - t0), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy2D(a.data(), WT * sizeof(float), (tap == FMX_TAP_PILOT_PHASE ? h->B.w_cur : h->B.w_dem) + ((size_t)t0 * h->pitch + channel) * WT, spitch, WT * sizeof(float), (size_t)(t1 - t0), hipMemcpyDeviceToHost));
         if (tap == FMX_TAP_LR_RAW) {
             b.resize(a.size());
             HIPCHK(hipMemcpy2D(b.data(), WT * sizeof(float), h->B.w_diff + ((size_t)t0 * h->pitch + channel) * WT, spitch, WT * sizeof(float), (size_t)(t1 - t0), hipMemcpyDeviceToHost));
@@ -1299,6 +1304,16 @@ int fmx_rds_symbols(fmx_handle h, int32_t channel, float *iq, int32_t capacity, 
 }
 
 int64_t fmx_last_fm_samples(fmx_handle h) { return h ? (int64_t)(h->last_J1 - h->last_J0) : 0; }
+int64_t fmx_pll_replays(fmx_handle h, int32_t channel) {
+    if (!h || channel >= h->channels) return (int64_t)fail(FMX_E_INVALID, "bad argument");
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return (int64_t)fail(FMX_E_HIP, "device error");
+    const int c0 = channel < 0 ? 0 : channel, c1 = channel < 0 ? h->channels : channel + 1;
+    std::vector<ChanState> st((size_t)(c1 - c0));
+    if (hipMemcpy(st.data(), h->B.state + c0, sizeof(ChanState) * st.size(), hipMemcpyDeviceToHost) != hipSuccess) return (int64_t)fail(FMX_E_HIP, "device error");
+    int64_t n = 0;
+    for (auto &s : st) n += s.pll_replays;
+    return n;
+}
 int64_t fmx_last_rds_samples(fmx_handle h) { return (h && h->rds_alloc) ? (int64_t)(h->last_m1 - h->last_m0) : 0; }
 
 int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {

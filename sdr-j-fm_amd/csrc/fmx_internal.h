@@ -68,6 +68,7 @@ struct ChanParams {
     int32_t test_tone;      // setTestTone fm-processor.cpp:931-933
     float   squelch_nthr;   // noiseSquelchThreshold squelchClass.cpp:36
     float   deemph_l2;      // log2 (1.0f - deemph_alpha) (fused stage B: scan weights)
+    int32_t pll_seq;        // the pilot PLL of this channel is evaluated sample by sample (FMX_P_PLL_SOLVER resolved on the host)
 };
 enum { ACT_TRIGGER_FREQ = 1, ACT_RESTART_PSS = 2, ACT_DC_RESET = 4 };
 
@@ -113,6 +114,8 @@ struct ChanState {
     // noise squelch (squelchClass.cpp:47-87): decaying averages and the (m1, m2) memories of the two order-20 filters
     float   sq_avg_hi, sq_avg_lo;
     float   sq_m[2][NSQ_QUADS][2];
+    // segments of the pilot PLL that did not settle and were replayed sample by sample (fmx_stageb.hip), since fmx_create
+    int32_t pll_replays, pad_r;
 };
 
 // Work arrays of stage B (w_*): element (row r, channel ch) lives at ((r / 16) * pitch + ch) * 16 + r % 16 -- tiles of 16

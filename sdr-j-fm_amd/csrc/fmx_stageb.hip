@@ -55,6 +55,7 @@ namespace fmx {
 #define SB_TICK(k) do { if (dbg_on) { const unsigned long long now_ = clock64(); dbg_acc[k] += now_ - dbg_t; dbg_t = now_; } } while (0)
 
 constexpr int FB_T = 256, FB_K = 6, FB_W = FB_T * FB_K;        // threads, samples per thread, segment length
+static_assert(FB_T == fftc::T, "the convolution is written for the workgroup size");
 static_assert(FB_W <= PSS_DELAY, "a segment's PSS errors must only need s-ring entries of earlier segments");
 #ifdef SB_TOL
 constexpr float PLL_TOL = SB_TOL; constexpr int PLL_MAX_ROUNDS = SB_ROUNDS, PSS_MAX_ROUNDS = 64;
@@ -989,13 +990,45 @@ __global__ __launch_bounds__(FB_T, 4) void stageb_pss_kernel(DeviceTables T, Dev
 // while the current one is computed.  Out: the d ring (stage C's input), the s ring, and the scope / RDS taps w_dem, w_cur,
 // w_diff (channel-major rows of this call).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
+// The kernel's arguments are read THROUGH the kernarg segment pointer, phase by phase (SB_ARGS_FRESH): taken by value the ~160
+// dwords of tables / buffers / geometry are all loaded up front and then spilled to VGPR lanes -- a v_readlane per use, 12 % of
+// the kernel's VALU instructions.  Scalar loads from the kernarg segment cost no VALU issue slot.
+struct StageBArgs { DeviceTables T; DeviceBuffers B; CallGeom G; int C; };
+typedef const StageBArgs __attribute__((address_space(4))) *StageBArgsP;
+#define SB_ARGS_FRESH() asm volatile("" : "+s"(ka))
+
+// inclusive wave scan of affine maps d -> A d + Bv (composition: the later map after the earlier one)
+struct Aff { float A, Bv; };
+template <int CTRL, int RM> __device__ __forceinline__ Aff aff_step(Aff c) {
+    const float pA = dppf<CTRL, RM>(1.f, c.A), pB = dppf<CTRL, RM>(0.f, c.Bv);     // lanes without a source compose with the identity
+    Aff r; r.Bv = fmaf(c.A, pB, c.Bv); r.A = c.A * pA;
+    return r;
+}
+__device__ __forceinline__ Aff wscan_aff(Aff v) {
+    v = aff_step<0x111, 0xf>(v); v = aff_step<0x112, 0xf>(v); v = aff_step<0x114, 0xf>(v); v = aff_step<0x118, 0xf>(v);
+    v = aff_step<0x142, 0xa>(v); v = aff_step<0x143, 0xc>(v);
+    return v;
+}
+
+#ifndef SB_NEWTON_TOL
+#define SB_NEWTON_TOL 2e-3f
+#endif
+constexpr float PLL_NEWTON_TOL = SB_NEWTON_TOL;   // a Newton round whose largest update is below this ends the iteration: what it leaves is of second order,
+                                          // 0.5 sum |g| d^2 < 2e-6 rad over a segment (g = 5 demod gain, sum |g| < 1 for programme material)
+constexpr int PLL_NEWTON_MAX = 10;        // rounds before the segment is replayed sample by sample (ChanState::pll_replays counts those)
+
+__global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs by_value_never_touched) {
+    StageBArgsP ka = (StageBArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+#define T (ka->T)
+#define B (ka->B)
+#define G (ka->G)
+    const int C = ka->C;
     __shared__ ScanLds lds;
     // the recurrences' states in front of the next segment: the same for every thread, so they live in LDS, not in everybody's registers
     // (written by one thread behind a phase, read by all in front of the same phase of the next segment: barriers in between)
     __shared__ struct { float afc, x0, old, lock; int locked, stable; PssSt ps; float de_l, de_r; int calls; } cy;
     __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];     // the convolution's buffer, afterwards er / pk:
-    float *er = reinterpret_cast<float *>(X);                        // [FB_W] PSS error per call of the segment; replay path: error in, pilotDelayPSS used out
+    float *er = reinterpret_cast<float *>(X);                        // [FB_W] PSS error per call of the segment; replay paths: inputs in, results out
     int *pk = reinterpret_cast<int *>(X) + FB_W;                     // [FB_W] replay path: ((tag + 2) << 1) | locked per sample
     static_assert(2 * FB_W * 4 <= sizeof(float2) * fftc::LDS_N, "er and pk live in the convolution buffer");
     const int ch = blockIdx.x;
@@ -1004,18 +1037,14 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
     const ChanParams &P = B.params[ch];
     ChanState *st = B.state + ch;
     const int nj = (int)(G.J1 - G.J0);
-    const int lin = B.lin_rows;                                  // row stride of the channel-major tap arrays
 #ifdef SB_PHASE_CYCLES                                           // (diagnostic build, tools/build_variant.sh: cycles per phase of thread 0 -- 20 VGPRs)
     const bool dbg_on = (B.dbg != nullptr) && (threadIdx.x == 0);
     unsigned long long dbg_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
-#define SB_TICK1(k) SB_TICK1(k)
+#define SB_TICK1(k) SB_TICK(k)
 #else
-#define SB_TICK1(k) do { } while (0)
+#define SB_TICK1(k) asm volatile("; SB_PHASE_END " #k)           /* (a marker in the assembly listing: tools/isa_phases.py) */
 #endif
-    const int decoder = P.decoder;
-    const int delay = T.front_sets[P.front_set].delay_fm;
-    const float2 *zr = B.zring + (size_t)ch * (G.ring_mask + 1);
     const bool stereo_possible = P.fm_mode != 2, auto_mono = P.auto_mono != 0, pss_active = P.pss_active != 0;
     const bool pss_on = stereo_possible && pss_active;
     // the sample behind which the reference takes its metaData snapshot (++myCount > fmRate / 2, fm-processor.cpp:662-684), call-relative
@@ -1024,31 +1053,32 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
     // ring entries of the samples j0 - 2 .. j0 + K - 1 of the segment at seg0 (clamped to the call's last sample: never past what
     // stage A wrote; zero until the filter latency has elapsed; the marker NaN where the reference's start values 0.01 apply)
     auto fetch = [&](int j0, int seg0, int w, float2 *z) {
+        const int delay = T.front_sets[P.front_set].delay_fm;
+        const float2 *zr = B.zring + (size_t)ch * (G.ring_mask + 1);
+        const int64_t base = G.J0 + seg0;
 #pragma unroll
         for (int t = 0; t < FB_K + 2; t++) {
             const int jr = j0 - 2 + t;
-            const int64_t jj = G.J0 + seg0 + (jr < w ? jr : w - 1);
+            const int64_t jj = base + (jr < w ? jr : w - 1);
             const int64_t s = jj - delay;
             z[t] = jj < 0 ? make_float2(__builtin_nanf(""), 0.f) : (s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f));
         }
     };
-    // the recurrences' states in front of the segment (the same in every thread)
     if (threadIdx.x == 0) {
-    cy.afc = st->fm_afc; cy.x0 = st->pil_phase; cy.old = st->pil_old; cy.lock = st->pil_lock;
-    cy.locked = st->pil_locked; cy.stable = st->pil_stable;
-    PssSt ps;
-    ps.acc = st->pss_acc; ps.mean = st->pss_mean; ps.pdp = st->pilot_delay_pss;
-    ps.lock_cnt = st->pss_lock_cnt; ps.unlock_cnt = st->pss_unlock_cnt; ps.minimized = st->pss_minimized != 0;
-    if (P.actions & (ACT_TRIGGER_FREQ | ACT_RESTART_PSS)) {
-        // triggerFrequencyChange / restartPssAnalyzer fm-processor.cpp:849-860
-        ps.pdp = 0.f; ps.acc = 0.f; ps.minimized = false; ps.mean = 0.f; ps.lock_cnt = 0; ps.unlock_cnt = 0;
-        if (P.actions & ACT_TRIGGER_FREQ) st->fade_start_frame = G.M0;
-    }
-    cy.ps = ps; cy.de_l = st->de_l; cy.de_r = st->de_r;
-    cy.calls = 0;                                                // process_sample calls of this call's earlier segments
+        cy.afc = st->fm_afc; cy.x0 = st->pil_phase; cy.old = st->pil_old; cy.lock = st->pil_lock;
+        cy.locked = st->pil_locked; cy.stable = st->pil_stable;
+        PssSt ps;
+        ps.acc = st->pss_acc; ps.mean = st->pss_mean; ps.pdp = st->pilot_delay_pss;
+        ps.lock_cnt = st->pss_lock_cnt; ps.unlock_cnt = st->pss_unlock_cnt; ps.minimized = st->pss_minimized != 0;
+        if (P.actions & (ACT_TRIGGER_FREQ | ACT_RESTART_PSS)) {
+            // triggerFrequencyChange / restartPssAnalyzer fm-processor.cpp:849-860
+            ps.pdp = 0.f; ps.acc = 0.f; ps.minimized = false; ps.mean = 0.f; ps.lock_cnt = 0; ps.unlock_cnt = 0;
+            if (P.actions & ACT_TRIGGER_FREQ) st->fade_start_frame = G.M0;
+        }
+        cy.ps = ps; cy.de_l = st->de_l; cy.de_r = st->de_r;
+        cy.calls = 0;                                            // process_sample calls of this call's earlier segments
     }
     const int64_t pss_count0 = st->pss_count;
-    float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
     float2 zn[FB_K + 2];
     fetch((int)threadIdx.x * FB_K, 0, nj < FB_W ? nj : FB_W, zn);
     __syncthreads();
@@ -1063,17 +1093,15 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
         const int j0 = tid * FB_K;                                   // segment-relative index of this thread's first sample
         const int w = (nj - seg0) < FB_W ? (nj - seg0) : FB_W;
         const bool lastseg = seg0 + FB_W >= nj;
-        bool ok[FB_K];
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) ok[i] = j0 + i < w;
-        const bool owner = (w - 1 >= j0) && (w - 1 < j0 + FB_K);     // this thread owns the segment's last sample
-        const int il = w - 1 - j0;                                   // ... at this position
-        const size_t lrow = (size_t)ch * lin + seg0 + j0;
+        const int nv = w - j0;                                       // sample i of this thread exists when i < nv
+        const bool owner = nv >= 1 && nv <= FB_K;                    // this thread owns the segment's last sample
+        const int il = nv - 1;                                       // ... at this position
         const int ix = jx - seg0 - j0;                               // this thread's index of the metaData snapshot sample, if 0 .. K-1
 
         // ================= limiter + discriminator (fm-demodulator.cpp:119-126, 168-189) =================
         float res[FB_K];
         {
+            const int decoder = P.decoder;
             float2 lim[FB_K + 2];                                // limited samples j0-2 .. j0+K-1 (the two in front recomputed: cheaper
 #pragma unroll                                                   // than an exchange through LDS with its two barriers)
             for (int t = 0; t < FB_K + 2; t++) lim[t] = (zn[t].x != zn[t].x) ? make_float2((float)0.01, (float)0.01) : limiter_fast(zn[t]);
@@ -1112,9 +1140,9 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
                 for (int i = 0; i < FB_K; i++) res[i] = atan_finish(arm[i], tv[i]);
             }
 #pragma unroll
-            for (int i = 0; i < FB_K; i++) res[i] = ok[i] ? res[i] : 0.f;
+            for (int i = 0; i < FB_K; i++) res[i] = (i < nv) ? res[i] : 0.f;
         }
-        SB_TICK1(0);
+        SB_ARGS_FRESH(); SB_TICK1(0);
 
         // ================= AFC + scaling (fm-demodulator.cpp:197-198) =================
         float dem[FB_K];
@@ -1126,95 +1154,217 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
             float afc_next;
             float afc = wg.decay_incoming2(Lt, cy.afc, make_decay(T.afc_l2, lane), &afc_next);
             float afc_end = 0.f;
+            const float K_FM = T.K_FM, K_FM_rcp = T.K_FM_rcp;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) {
                 afc = c1 * afc + fmDcAlpha * res[i];
-                dem[i] = fdiv_const(20.0f * (res[i] - afc) * 1.0f, T.K_FM, T.K_FM_rcp);
+                dem[i] = fdiv_const(20.0f * (res[i] - afc) * 1.0f, K_FM, K_FM_rcp);
                 if (i == il) afc_end = afc;
-                if (i == ix && ok[i]) st->meta_dc_if = afc;                   // get_demodDcComponent () at the snapshot
+                if (i == ix && i < nv) st->meta_dc_if = afc;                 // get_demodDcComponent () at the snapshot
             }
             if (lastseg && owner) st->fm_afc = afc_end;
             if (tid == 0) cy.afc = afc_next;
         }
-        SB_TICK1(1);
+        SB_ARGS_FRESH(); SB_TICK1(1);
 
-        // ================= pilot PLL (pilot-recover.cpp:54-61): fixed point of the f32 trajectory =================
+        // ================= pilot PLL (pilot-recover.cpp:54-61) =================
+        // The loop is non-linear (the phase feeds the sine look-up that corrects it).  Two ways to its f32 trajectory
+        // x[j+1] = step (x[j]), step = the reference's own f32 expression:
+        //  * sequentially, by one thread from LDS (ChanParams::pll_seq, FMX_P_PLL_SOLVER): the reference's trajectory bit for bit
+        //    (1e-7 rad against the oracle, from stage A's 1e-6 input differences) at ~45 us per segment -- what a handle with few
+        //    channels (the drop-in receiver) uses;
+        //  * by Newton's method on the whole segment at once.  With a guess x, P = the f64 prefix sum of the exact increments
+        //    step (x) - x and d = x0 + P - x (what Picard's iteration would add), the update solves the linearised recurrence: the
+        //    next guess is fl (x0 + P[j] + S[j]), S[j+1] = (1 + c[j]) S[j] + c[j] d[j], c = g cos x, g = 5 demod gain -- a scan of
+        //    affine maps in f32.  The first guess is the free-running ramp improved by two rounds of x = ramp + sum g sin (x) in
+        //    plain f32 with the hardware sine (within ~1e-4 rad), so ONE Newton round normally settles it and the trajectory is
+        //    evaluated once more for its outputs.  What this cannot reproduce is the loop's own rounding noise: the step rounds
+        //    twice per sample (half an ulp, 2.4e-7 rad), the loop integrates that over its time constant (~12000 samples), and a
+        //    guess a few ulps off rounds differently at every sample -- the result wanders around the reference's trajectory by
+        //    ~1.5e-5 rad RMS whatever the number of rounds (tools/pll_fixed_point.py; the Picard iteration of round 2 did the same).
+        //    A segment that does not settle in PLL_NEWTON_MAX rounds is evaluated sequentially (ChanState::pll_replays counts them).
         float cur[FB_K], osc[FB_K];
         float osc_in;                                            // NCO sine of the sample in front of this thread's first
         {
             const float gain = T.pil_gain, omega = T.pil_omega;
-            const float SC32 = (float)T.sincos_C;
-            const float P32 = 6.2831855f, C32 = T.wrap32_c;
+            const double SC64 = T.sincos_C;
+            const float P32 = 6.2831855f, C32 = T.wrap32_c, INV2PI32 = 0.159154943f;
+            const bool wrap_ok = T.wrap32_ok != 0;
             float x0 = cy.x0;
             if (!(x0 >= 0.f && x0 < P32)) x0 = pi_constrain(x0);
-            float ph[FB_K];
+            float g[FB_K];
 #pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                // first guess: the free-running ramp x0 + j omega
-                const double r = (double)x0 + (double)(j0 + i) * (double)omega;
-                ph[i] = (j0 + i == 0) ? x0 : (float)(r - floor(r * (1.0 / FMX_2PI)) * FMX_2PI);
+            for (int i = 0; i < FB_K; i++) g[i] = (i < nv) ? (5 * dem[i]) * gain : 0.f;
+            float ph[FB_K];
+            // the reference's step on one guess: table index in f64 as sincos.cpp:81-85 computes it, everything else in f32
+            float nxl = 0.f;                                     // step result of this thread's last evaluated sample `il` (the owner's: the next segment's start)
+            auto eval = [&](int i, float phase, float *nx_out) {
+                int idx = (int)((double)phase * SC64);           // SinCos::getSin sincos.cpp:81-85 for phase >= 0: entry (int)(phase * C) % Rate
+                idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+                const float o = sin_idx_f32(idx);
+                const float perr = (5 * dem[i]) * o;             // pilot-recover.cpp:56-58 (pilot = 5 * demod fm-processor.cpp:696)
+                const float t = phase + perr * gain;
+                const float val = t + omega;
+                const float wrapped = wrap_ok ? (val - P32) + C32 : (float)((double)val - FMX_2PI);
+                float nx = (val < P32) ? val : wrapped;          // PI_Constrain fm-constants.h:148-158
+                // (a correction of more than a turn: the DIFF decoder's spike where the limiter output jumps from its 0.001 floor
+                // to the unit circle at signal onset -- the general PI_Constrain, wave-uniformly skipped otherwise)
+                if (__any(!(val >= 0.f && val < 2.f * P32))) nx = pi_constrain(val);
+                cur[i] = t; osc[i] = o;
+                *nx_out = nx;
+            };
+            // a guess outside [0, 2 pi) (unfinished rounds only) is taken modulo 2 pi
+            auto into_range = [&](float phase) {
+                if (__any(!(phase >= 0.f && phase < P32))) {
+                    const double pd = (double)phase;
+                    const float pw = (float)(pd - floor(pd * (1.0 / FMX_2PI)) * FMX_2PI);
+                    phase = (phase >= 0.f && phase < P32) ? phase : ((pw >= 0.f && pw < P32) ? pw : 0.f);
+                }
+                return phase;
+            };
+            // the loop sample by sample: one thread, operands through LDS (the convolution's buffer is free here); leaves the phases in ph
+            auto sequential = [&](bool count) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) if (i < nv) er[j0 + i] = dem[i];
+                __syncthreads();
+                if (tid == 0) {
+                    float phase = x0;
+                    for (int j = 0; j < w; j++) {
+                        const float d5 = 5 * er[j];
+                        er[FB_W + j] = phase;
+                        int idx = (int)((double)phase * SC64);
+                        idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+                        const float val = (phase + (d5 * sin_idx_f32(idx)) * gain) + omega;
+                        phase = (val >= 0.f && val < P32) ? val : pi_constrain(val);
+                    }
+                    if (count) st->pll_replays += 1;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) ph[i] = (i < nv) ? er[FB_W + j0 + i] : 0.f;
+                __syncthreads();
+            };
+            auto for_each_eval = [&](float *nx) {
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) eval(i, ph[i], &nx[i]);
+            };
+            if (P.pll_seq) {
+                float nx[FB_K];
+                sequential(false);
+                for_each_eval(nx);
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) if (i == il) nxl = nx[i];
+            } else {
+            {   // ---- the first guess
+                float rv[FB_K];                                  // the ramp x0 + j omega in turns, fraction
+                const double tb = ((double)x0 + (double)j0 * (double)omega) * (1.0 / FMX_2PI);
+                const float tbf = (float)(tb - floor(tb));
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) { const float v = tbf + (float)i * (omega * INV2PI32); rv[i] = v - floorf(v); }
+                float cor[FB_K];                                 // sum of the corrections in front of each sample (rad)
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) cor[i] = 0.f;
+#pragma unroll
+                for (int round = 0; round < 2; round++) {
+                    float c[FB_K], run = 0.f;
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) { c[i] = run; run += g[i] * __builtin_amdgcn_sinf(rv[i] + cor[i] * INV2PI32); }
+                    float total;
+                    const float pre = wg.excl_add_f(run, &total);
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) cor[i] = pre + c[i];
+                }
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    float v = rv[i] + cor[i] * INV2PI32;
+                    v = (v - floorf(v)) * P32;
+                    ph[i] = (j0 + i == 0) ? x0 : (v < P32 ? v : 0.f);
+                }
             }
+            // Every guess is x[j] = fl (x0 + P[j] + S[j]): P = the f64 prefix sum of the exact increments step (x) - x of the previous
+            // guess (what Picard's iteration would take), S = the Newton correction, S[j+1] = (1 + c[j]) S[j] + c[j] d[j] with
+            // c = g cos x, d = x0 + P - x -- a scan of affine maps in f32 (S is small).  One rounding per sample, none accumulated:
+            // an update d -> x + d in f32 would leave half an ulp of residual at EVERY step, which the loop integrates to 1e-5 rad.
+            bool open_ = true;                                   // this thread's last update was not small yet
             const double x0d = (double)x0;
-            float xend = x0;
             for (int it = 0; ; it++) {
                 double e[FB_K], tot = 0.0;
+                float nx[FB_K];
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) {
-                    float phase = ph[i];
-                    // a guess outside [0, 2 pi) (guesses of unfinished rounds only: a wrap that sits one sample earlier or later in the
-                    // guess than in the step's result shifts everything behind it by a turn) is taken modulo 2 pi
-                    if (__any(!(phase >= 0.f && phase < P32))) {
-                        const double pd = (double)phase;
-                        const float pw = (float)(pd - floor(pd * (1.0 / FMX_2PI)) * FMX_2PI);
-                        phase = (phase >= 0.f && phase < P32) ? phase : ((pw >= 0.f && pw < P32) ? pw : 0.f);
-                    }
-                    // SinCos::getSin sincos.cpp:81-85 for phase >= 0: table entry (int)(phase * C) % Rate, the entry itself from
-                    // sin_idx_f32 (the index in f32: it differs from the f64 product's in < 2 % of the samples, by one entry)
-                    int idx = (int)(phase * SC32);
-                    idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
-                    const float o = sin_idx_f32(idx);
-                    const float perr = (5 * dem[i]) * o;             // pilot-recover.cpp:56-58 (pilot = 5 * demod fm-processor.cpp:696)
-                    const float t = phase + perr * gain;
-                    const float val = t + omega;
-                    const float wrapped = T.wrap32_ok ? (val - P32) + C32 : (float)((double)val - FMX_2PI);
-                    float nx = (val < P32) ? val : wrapped;          // PI_Constrain fm-constants.h:148-158
-                    // (a correction of more than a turn: the DIFF decoder's spike where the limiter output jumps from its 0.001 floor
-                    // to the unit circle at signal onset -- the general PI_Constrain, wave-uniformly skipped otherwise)
-                    if (__any(!(val >= 0.f && val < 2.f * P32))) nx = pi_constrain(val);
-                    cur[i] = t; osc[i] = o;
+                    const float phase = into_range(ph[i]);
+                    ph[i] = phase;
+                    eval(i, phase, &nx[i]);
                     e[i] = tot;
-                    tot += ok[i] ? (double)nx - (double)phase : 0.0;
+                    tot += (i < nv) ? (double)nx[i] - (double)phase : 0.0;
                 }
-                double total; bool any;
-                const double pre = wg.excl_add_d(tot, &total, false, &any);
-                bool open_ = false;
+                // the increments' prefix sums; with the same barrier: has the previous round's update been small everywhere?
+                const double inc = wscan_add_d(tot);
+                {
+                    const int wopen = __any(open_) ? 1 : 0;
+                    if (lane == 63) lds.wd[wg.sl][wg.wv][0] = inc;
+                    if (lane == 0) lds.wi[wg.sl][wg.wv][1] = wopen;
+                }
+                __syncthreads();
+                const int anyopen = lds.wi[wg.sl][0][1] | lds.wi[wg.sl][1][1] | lds.wi[wg.sl][2][1] | lds.wi[wg.sl][3][1];
+                double pre = inc - tot;
+#pragma unroll
+                for (int v = 0; v < 3; v++) pre += (v < wg.wv) ? lds.wd[wg.sl][v][0] : 0.0;
+                wg.sl ^= 1;
+                if (!anyopen || it == PLL_NEWTON_MAX) {
+                    if (anyopen) { sequential(true); for_each_eval(nx); }      // not settled: sample by sample, evaluated once more
+                    // (the evaluation just made is the final one)
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) if (i == il) nxl = nx[i];
+                    if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; }
+                    break;
+                }
+                // ---- the Newton correction
+                float d[FB_K], c[FB_K];
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) {
-                    const float nph = (float)(x0d + (pre + e[i]));
-                    // distance between the guess this round evaluated and the one it produced (a wrap that moved by one sample
-                    // shows as 2 pi)
-                    float dd = fabsf(nph - ph[i]);
-                    dd = fminf(dd, fabsf(dd - P32));
-                    open_ = open_ || (ok[i] && !(dd < PLL_TOL));
-                    ph[i] = nph;
+                    double dd = (x0d + (pre + e[i])) - (double)ph[i];
+                    dd = dd > 3.14159265358979323846 ? dd - FMX_2PI : (dd < -3.14159265358979323846 ? dd + FMX_2PI : dd);   // (a wrap that sits one sample apart in guess and step)
+                    d[i] = (i < nv) ? (float)dd : 0.f;
+                    c[i] = g[i] * __builtin_amdgcn_cosf(ph[i] * INV2PI32);
                 }
-                {   // (a guess chain may carry whole turns: dd above takes them for "no change", so the end state is taken modulo 2 pi)
-                    const double xe = x0d + total;
-                    xend = (float)(xe - floor(xe * (1.0 / FMX_2PI)) * FMX_2PI);
-                }
-                // every thread must know whether ANY thread is still moving: one more reduction (flags only)
-                const int wopen = __any(open_) ? 1 : 0;              // (evaluated by the whole wave, not under the lane-0 branch)
-                if (lane == 0) lds.wi[wg.sl][wg.wv][0] = wopen;
+                Aff m; m.A = 1.f; m.Bv = 0.f;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) { m.Bv = fmaf(1.f + c[i], m.Bv, c[i] * d[i]); m.A *= 1.f + c[i]; }
+                const Aff ain = wscan_aff(m);
+                if (lane == 63) { lds.wf[wg.sl][wg.wv][2] = ain.A; lds.wf[wg.sl][wg.wv][3] = ain.Bv; }
                 __syncthreads();
-                const int anych = lds.wi[wg.sl][0][0] | lds.wi[wg.sl][1][0] | lds.wi[wg.sl][2][0] | lds.wi[wg.sl][3][0];
+                float S = 0.f;                                   // the correction at the wave's first sample
+#pragma unroll
+                for (int v = 0; v < 3; v++) if (v < wg.wv) S = fmaf(lds.wf[wg.sl][v][2], S, lds.wf[wg.sl][v][3]);
                 wg.sl ^= 1;
-                if (!anych || it == PLL_MAX_ROUNDS - 1) { if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it + 1; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; } break; }
+                {   // ... at this thread's first sample: the maps of the lanes in front applied to it
+                    const float eA = dppf<0x138, 0xf>(1.f, ain.A), eB = dppf<0x138, 0xf>(0.f, ain.Bv);
+                    S = fmaf(eA, S, eB);
+                }
+                float dmax = 0.f;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) {
+                    if (i < nv) {
+                        dmax = fmaxf(dmax, fabsf(d[i] + S));
+                        ph[i] = (j0 + i == 0) ? x0 : (float)((x0d + (pre + e[i])) + (double)S);
+                    }
+                    S = fmaf(1.f + c[i], S, c[i] * d[i]);
+                }
+                open_ = !(dmax < PLL_NEWTON_TOL);
             }
-            // (cur / osc are those of the last round's evaluation: of a trajectory the round moved by less than PLL_TOL)
-            const float x0s = (xend >= 0.f && xend < P32) ? xend : 0.f;
-            if (tid == 0) { cy.x0 = x0s; if (lastseg) st->pil_phase = x0s; }
-            float old_next;
-            osc_in = wg.from_left2(osc[FB_K - 1], cy.old, &old_next);
+            }
+            // (cur / osc are those of the last evaluation: of the trajectory the iteration ended on)
+            if (owner) { const float xe = (nxl >= 0.f && nxl < P32) ? nxl : 0.f; cy.x0 = xe; if (lastseg) st->pil_phase = xe; }
+            // the NCO sine in front of each thread's first sample; the last one behind a full segment
+            if (lane == 63) lds.wf[wg.sl][wg.wv][1] = osc[FB_K - 1];
+            const float cold = cy.old;
+            __syncthreads();
+            osc_in = dppf<0x138, 0xf>(0.f, osc[FB_K - 1]);
+            if (lane == 0) osc_in = wg.wv ? lds.wf[wg.sl][(wg.wv + 3) & 3][1] : cold;
+            const float old_next = lds.wf[wg.sl][3][1];
+            wg.sl ^= 1;
             if (tid == 0) cy.old = old_next;
             if (lastseg && owner) {
                 float oe = 0.f;
@@ -1223,10 +1373,11 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
                 st->pil_old = oe;
             }
         }
-        SB_TICK1(2);
+        SB_ARGS_FRESH(); SB_TICK1(2);
 
         // ================= lock detector (pilot-recover.cpp:62-80) =================
         bool locked[FB_K];
+        bool all_locked;                                         // every sample of the segment (the same in every thread)
         {
             const float lockA = 1.0f / 3000.0f;
             const double keep = 1.0 - (double)lockA;
@@ -1239,7 +1390,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
                 for (int i = 0; i < FB_K; i++) {
                     const float quadRef = fdiv_const(osc[i] - old, omega, romega);
                     old = osc[i];
-                    xq[i] = ok[i] ? lockA * (-quadRef * (5 * dem[i])) : 0.f;
+                    xq[i] = (i < nv) ? lockA * (-quadRef * (5 * dem[i])) : 0.f;
                 }
             }
             float Lt = 0.f;
@@ -1253,7 +1404,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
             for (int i = 0; i < FB_K; i++) {
                 lock = (float)((double)xq[i] + (double)lock * keep);
                 hi[i] = lock > 0.07f;
-                if (ok[i] && !hi[i]) lastf = j0 + i;
+                if (i < nv && !hi[i]) lastf = j0 + i;
                 if (i == il) lock_end = lock;
                 if (i == ix) lock_x = lock;
             }
@@ -1264,15 +1415,16 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
                 int F = preF;
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) {
-                    if (ok[i] && !hi[i]) F = j0 + i;
+                    if (i < nv && !hi[i]) F = j0 + i;
                     const bool lk = (F < 0) && (locked0 != 0 || stable0 + (j0 + i) + 1 > (SINCOS_N >> 1));
                     locked[i] = lk;
-                    if (i == ix && ok[i]) {                                  // isPilotLocked (PilotPllLockStrength) :870-880
+                    if (i == ix && i < nv) {                                 // isPilotLocked (PilotPllLockStrength) :870-880
                         st->meta_locked = (stereo_possible && lk) ? 1 : 0;
                         st->meta_lock_strength = stereo_possible ? lock_x : 0.f;
                     }
                 }
             }
+            all_locked = totF < 0 && (locked0 != 0 || stable0 + 1 > (SINCOS_N >> 1));
             int nl, ns;
             if (totF < 0) { nl = (locked0 != 0 || stable0 + w > (SINCOS_N >> 1)) ? 1 : 0;
                             ns = locked0 ? stable0 : (stable0 + w < (SINCOS_N >> 1) + 1 ? stable0 + w : (SINCOS_N >> 1) + 1); }
@@ -1280,49 +1432,69 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
             if (lastseg && owner) { st->pil_lock = lock_end; st->pil_locked = nl; st->pil_stable = ns; }
             if (tid == 0) { cy.locked = nl; cy.stable = ns; cy.lock = lock_next; }
         }
-        // scope taps and the inputs of the RDS path: channel-major rows of this call
+        {   // scope taps and the inputs of the RDS path: channel-major rows of this call
+            const size_t lrow = (size_t)ch * B.lin_rows + seg0 + j0;
+            float *wd = B.w_dem + lrow, *wc = B.w_cur + lrow;
 #pragma unroll
-        for (int i = 0; i < FB_K; i++) if (ok[i]) { B.w_dem[lrow + i] = dem[i]; B.w_cur[lrow + i] = cur[i]; }
-        SB_TICK1(3);
+            for (int i = 0; i < FB_K; i++) if (i < nv) { wd[i] = dem[i]; wc[i] = cur[i]; }
+        }
+        SB_ARGS_FRESH(); SB_TICK1(3);
 
         // ================= PSS errors of the calls this segment can make: err[m] = Re (y) Im (y), y = low-pass of the s ring
         // (stereo-separation.cpp:60-83), m = call index within the segment, into er =================
+        const int calls_before = cy.calls;
+        float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
+        const int smask = G.sring_mask;
         if (pss_on) {
-            const int64_t i0 = pss_count0 + cy.calls;                                // call index of the segment's first output
+            const int64_t i0 = pss_count0 + calls_before;                            // call index of the segment's first output
             float2 a[8];
 #pragma unroll
             for (int p = 0; p < 8; p++) {      // window entry n <-> s index i0 - (1753 + 294) + n; entries past the segment's need are padding
-                const int n = tid + fftc::T * p;
+                const int n = tid + FB_T * p;
                 const int64_t idx = i0 - (PSS_DELAY + PSS_TAPS - 1) + n;
-                a[p] = (n < w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
+                a[p] = (n < w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & smask] : make_float2(0.f, 0.f);
             }
             fftc::convolve(tid, a, X, T.fft_w, T.pss_hs);
             __syncthreads();                   // (er overlays the buffer the last stage was read from)
 #pragma unroll
             for (int p = 0; p < 8; p++) {
-                const int m = tid + fftc::T * p - (PSS_TAPS - 1);
+                const int m = tid + FB_T * p - (PSS_TAPS - 1);
                 if (m >= 0 && m < FB_W) er[m] = a[p].x * a[p].y;
             }
         }
         __syncthreads();
-        SB_TICK1(4);
+        SB_ARGS_FRESH(); SB_TICK1(4);
 
         // ================= the PSS call index of every sample (fm-processor.cpp:704-718) =================
         int tag[FB_K];
         int ncalls;
-        {
+        int firstU = -0x7fffffff - 1, firstZ = -0x7fffffff - 1;              // first unlocked sample / first stereo sample without PSS, as maxima of negated indices
+        if (all_locked) {
+            // (the usual case: no scan, no reduction)
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) tag[i] = stereo_possible ? (pss_active ? ((i < nv) ? j0 + i : -2) : -1) : -2;
+            ncalls = pss_on ? w : 0;
+            if (stereo_possible && !pss_active) firstZ = 0;
+        } else {
             int ncall_t = 0;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) {
                 const bool branch = stereo_possible && (locked[i] || !auto_mono);
                 tag[i] = branch ? (pss_active ? 0 : -1) : -2;
-                ncall_t += (ok[i] && branch && pss_active) ? 1 : 0;
+                ncall_t += (i < nv && branch && pss_active) ? 1 : 0;
             }
             int preC, dm1, dm2;
             wg.excl_add_max_i(ncall_t, 0, &preC, &ncalls, &dm1, &dm2);
             int c = preC;
 #pragma unroll
-            for (int i = 0; i < FB_K; i++) if (tag[i] == 0) { tag[i] = ok[i] ? c : -2; c += ok[i] ? 1 : 0; }    // index of the call within the segment
+            for (int i = 0; i < FB_K; i++) if (tag[i] == 0) { tag[i] = (i < nv) ? c : -2; c += (i < nv) ? 1 : 0; }    // index of the call within the segment
+            int anyl = 0, alll = 0;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) if (i < nv) {
+                if (!locked[i]) { const int v = -(j0 + i); firstU = v > firstU ? v : firstU; }
+                if (tag[i] == -1) { const int v = -(j0 + i); firstZ = v > firstZ ? v : firstZ; }
+            }
+            wg.reduce_max4(firstU, firstZ, anyl, alll);
         }
 
         // ================= PSS integrator (stereo-separation.cpp:84-109, fm-processor.cpp:699-718) =================
@@ -1334,17 +1506,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
             float err[FB_K];
 #pragma unroll
             for (int i = 0; i < FB_K; i++) err[i] = (pss_on && tag[i] >= 0) ? er[tag[i]] : 0.f;
-            // classification (the same for every thread)
-            int firstU = -0x7fffffff - 1, firstZ = -0x7fffffff - 1, anyl = 0, alll = 0;            // as maxima of negated indices
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) if (ok[i]) {
-                if (!locked[i]) { const int v = -(j0 + i); firstU = v > firstU ? v : firstU; alll = 1; }
-                else anyl = 1;
-                if (tag[i] == -1) { const int v = -(j0 + i); firstZ = v > firstZ ? v : firstZ; }
-            }
-            wg.reduce_max4(firstU, firstZ, anyl, alll);              // alll = 1 when some sample is NOT locked
-            const bool all_locked = alll == 0;
-            const bool steady = pss_on && ncalls == w && all_locked && ((s.minimized ? s.unlock_cnt : s.lock_cnt) + w <= 3 * SINCOS_N);
+            const bool steady = pss_on && all_locked && ((s.minimized ? s.unlock_cnt : s.lock_cnt) + w <= 3 * SINCOS_N);
             const bool nocall = ncalls == 0;
             PssSt e = s;                                             // state behind the segment
             if (steady) {
@@ -1352,78 +1514,125 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
                 float xa[FB_K], er10[FB_K];
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) { er10[i] = mz ? err[i] : err[i] * 10.0f; xa[i] = alpha * er10[i]; }
-                // accPhaseShift: fixed point of the exact f32 trajectory a[j] = value in front of sample j
+                // accPhaseShift: the exact f32 trajectory a[j] = value in front of sample j.  The increments are often below half an
+                // ulp of the accumulator and must be absorbed as the reference absorbs them: d[j] = fl (a[j] + xa[j]) - a[j] depends
+                // on a[j] only through its binade, the clamp and ties, so d evaluated at the segment's first value, summed in f64,
+                // is normally already the trajectory -- verified by evaluating d again at the values found (no second scan; the flag
+                // rides with the next scan's barrier); a segment where it is not iterates to the fixed point as before.
                 float a[FB_K];
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) a[i] = s.acc;
                 const double a0 = (double)s.acc;
-                float aend = s.acc;
-                for (int it = 0; ; it++) {
-                    double d[FB_K], ex[FB_K], tot = 0.0;
+                float aend;
+                bool changed = false;
+                {
+                    double d1[FB_K], ex[FB_K], tot = 0.0;
 #pragma unroll
                     for (int i = 0; i < FB_K; i++) {
-                        const float na = fminf(fmaxf(a[i] + xa[i], -c4), c4);
-                        d[i] = ok[i] ? (double)na - (double)a[i] : 0.0;
-                        ex[i] = tot; tot += d[i];
+                        const float na = fminf(fmaxf(s.acc + xa[i], -c4), c4);
+                        d1[i] = (i < nv) ? (double)na - (double)s.acc : 0.0;
+                        ex[i] = tot; tot += d1[i];
                     }
                     double total; bool any;
                     const double pre = wg.excl_add_d(tot, &total, false, &any);
-                    bool changed = false;
 #pragma unroll
                     for (int i = 0; i < FB_K; i++) {
-                        const float na = (float)(a0 + (pre + ex[i]));
-                        changed = changed || (ok[i] && __float_as_int(na) != __float_as_int(a[i]));
-                        a[i] = na;
+                        const double exact = a0 + (pre + ex[i]);
+                        a[i] = (float)exact;
+                        const float na = fminf(fmaxf(a[i] + xa[i], -c4), c4);
+                        // the value found must reproduce itself: representable, and the same increment from it
+                        changed = changed || (i < nv && ((double)a[i] != exact || (double)na - (double)a[i] != d1[i]));
                     }
                     aend = (float)(a0 + total);
-                    if (lane == 0) lds.wi[wg.sl][wg.wv][0] = 0;
-                    if (__any(changed) && lane == 0) lds.wi[wg.sl][wg.wv][0] = 1;
-                    __syncthreads();
-                    const int anych = lds.wi[wg.sl][0][0] | lds.wi[wg.sl][1][0] | lds.wi[wg.sl][2][0] | lds.wi[wg.sl][3][0];
-                    wg.sl ^= 1;
-                    if (!anych || it == PSS_MAX_ROUNDS - 1) { if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 9] += it + 1; B.dbg[(size_t)ch * DBG_SLOTS + 12] += 1; } break; }
+                    changed = changed || (double)aend != a0 + total;
                 }
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) used[i] = (j0 + i == 0) ? s.pdp : a[i];
                 // mean_error (1 / rate smoothing) and the "minimised" bookkeeping in closed form
                 const DecayW dw = make_decay(T.pssmean_l2, lane);
                 float Lt = 0.f;
 #pragma unroll
-                for (int i = 0; i < FB_K; i++) Lt = (ok[i] ? la * er10[i] : 0.f) + Lt * keep;
-                float mean = wg.decay_incoming(Lt, s.mean, dw);
+                for (int i = 0; i < FB_K; i++) Lt = ((i < nv) ? la * er10[i] : 0.f) + Lt * keep;
+                float mean_next;
+                float mean;
+                {   // (decay_incoming2 with the integrator's flag riding along)
+                    const float Z = wscan_decay(Lt, dw);
+                    const int wch = __any(changed) ? 1 : 0;
+                    if (lane == 63) lds.wf[wg.sl][wg.wv][0] = Z;
+                    if (lane == 0) lds.wi[wg.sl][wg.wv][0] = wch;
+                    __syncthreads();
+                    float Cc = s.mean, Cin = s.mean;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) { Cc = fmaf(Cc, dw.d64, lds.wf[wg.sl][v][0]); Cin = (v + 1 == wg.wv) ? Cc : Cin; }
+                    changed = (lds.wi[wg.sl][0][0] | lds.wi[wg.sl][1][0] | lds.wi[wg.sl][2][0] | lds.wi[wg.sl][3][0]) != 0;
+                    wg.sl ^= 1;
+                    mean_next = Cc;
+                    mean = fmaf(dw.dl, Cin, lane_prev_f(Z, 0.f));
+                }
+                int rounds = 1;
+                if (changed) {
+                    for (int it = 0; ; it++) {
+                        double d[FB_K], ex[FB_K], tot = 0.0;
+#pragma unroll
+                        for (int i = 0; i < FB_K; i++) {
+                            const float na = fminf(fmaxf(a[i] + xa[i], -c4), c4);
+                            d[i] = (i < nv) ? (double)na - (double)a[i] : 0.0;
+                            ex[i] = tot; tot += d[i];
+                        }
+                        double total; bool any;
+                        const double pre = wg.excl_add_d(tot, &total, false, &any);
+                        bool ch2 = false;
+#pragma unroll
+                        for (int i = 0; i < FB_K; i++) {
+                            const float na = (float)(a0 + (pre + ex[i]));
+                            ch2 = ch2 || (i < nv && __float_as_int(na) != __float_as_int(a[i]));
+                            a[i] = na;
+                        }
+                        aend = (float)(a0 + total);
+                        if (lane == 0) lds.wi[wg.sl][wg.wv][0] = 0;
+                        if (__any(ch2) && lane == 0) lds.wi[wg.sl][wg.wv][0] = 1;
+                        __syncthreads();
+                        const int anych = lds.wi[wg.sl][0][0] | lds.wi[wg.sl][1][0] | lds.wi[wg.sl][2][0] | lds.wi[wg.sl][3][0];
+                        wg.sl ^= 1;
+                        rounds++;
+                        if (!anych || it == PSS_MAX_ROUNDS - 1) break;
+                    }
+                }
+                if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 9] += rounds; B.dbg[(size_t)ch * DBG_SLOTS + 12] += 1; }
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) used[i] = (j0 + i == 0) ? s.pdp : a[i];
                 int lastS = -1, lastN = -1, d3 = 0, d4 = 0; float mean_end = 0.f;
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) {
                     mean = la * er10[i] + mean * keep;
-                    if (ok[i]) { if (fabsf(mean) < 0.001f) lastS = j0 + i; else lastN = j0 + i; }
+                    if (i < nv) { if (fabsf(mean) < 0.001f) lastS = j0 + i; else lastN = j0 + i; }
                     if (i == il) mean_end = mean;
-                    if (i == ix && ok[i]) meta_snapshot(st, P, fminf(fmaxf(a[i] + xa[i], -c4), c4), mean, mz, true);   // (mz: no flip inside a steady segment)
+                    if (i == ix && i < nv) meta_snapshot(st, P, fminf(fmaxf(a[i] + xa[i], -c4), c4), mean, mz, true);   // (mz: no flip inside a steady segment)
                 }
                 wg.reduce_max4(lastS, lastN, d3, d4);
-                if (owner) lds.wf[0][0][3] = mean_end;               // (slot-free word: read after the next barrier below)
-                __syncthreads();
-                e.mean = lds.wf[0][0][3];
+                e.mean = mean_next;                                  // (behind a full segment; the owner's own value replaces it below)
                 e.acc = aend; e.pdp = aend; e.minimized = mz;
                 const bool all_small = lastN < 0, any_small = lastS >= 0;
                 if (mz) { e.lock_cnt = all_small ? s.lock_cnt : 0; e.unlock_cnt = any_small ? (w - 1 - lastS) : s.unlock_cnt + w; }
                 else { e.lock_cnt = all_small ? s.lock_cnt + w : (w - 1 - lastN); e.unlock_cnt = any_small ? 0 : s.unlock_cnt; }
+                // (reduce_max4's barrier: everybody has its copy of the state in front of the segment)
+                if (tid == 0) { cy.ps.acc = e.acc; cy.ps.pdp = e.pdp; cy.ps.minimized = e.minimized; cy.ps.lock_cnt = e.lock_cnt; cy.ps.unlock_cnt = e.unlock_cnt; }
+                if (owner) cy.ps.mean = mean_end;
             } else if (nocall) {
                 // nobody calls process_sample: an unlocked sample clears everything, a stereo sample without PSS clears pilotDelayPSS
                 const int fu = (firstU == -0x7fffffff - 1) ? 0x7fffffff : -firstU, fz = (firstZ == -0x7fffffff - 1) ? 0x7fffffff : -firstZ;
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) used[i] = (j0 + i >= fu || j0 + i > fz) ? 0.f : s.pdp;
 #pragma unroll
-                for (int i = 0; i < FB_K; i++) if (i == ix && ok[i]) {
+                for (int i = 0; i < FB_K; i++) if (i == ix && i < nv) {
                     const bool cleared = j0 + i >= fu;
                     meta_snapshot(st, P, (cleared || j0 + i >= fz) ? 0.f : s.pdp, cleared ? 0.f : s.mean, cleared ? false : s.minimized, locked[i]);
                 }
                 if (fu != 0x7fffffff) { e.pdp = 0.f; e.acc = 0.f; e.mean = 0.f; e.minimized = false; e.lock_cnt = 0; e.unlock_cnt = 0; }
                 else if (fz != 0x7fffffff) e.pdp = 0.f;
+                __syncthreads();                                     // (everybody has its copy of the state in front of the segment)
+                if (tid == 0) cy.ps = e;
             } else {
                 // replay (lock transitions inside a PSS segment, a counter within a segment of its 3 s threshold)
                 __syncthreads();                                     // (every thread has taken its errors out of er)
 #pragma unroll
-                for (int i = 0; i < FB_K; i++) if (ok[i]) { pk[j0 + i] = ((tag[i] + 2) << 1) | (locked[i] ? 1 : 0); er[j0 + i] = err[i]; }
+                for (int i = 0; i < FB_K; i++) if (i < nv) { pk[j0 + i] = ((tag[i] + 2) << 1) | (locked[i] ? 1 : 0); er[j0 + i] = err[i]; }
                 __syncthreads();
                 if (B.dbg && tid == 0) B.dbg[(size_t)ch * DBG_SLOTS + 10] += 1;
                 if (tid == 0) {
@@ -1434,49 +1643,53 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
                         er[j] = pss_step(r, alpha, la, keep, (p & 1) != 0, (p >> 1) - 2, er[j]);
                         if (j == jxs) meta_snapshot(st, P, r.pdp, r.mean, r.minimized, (p & 1) != 0);
                     }
-                    lds.wf[0][0][3] = r.acc; lds.wf[0][1][3] = r.mean; lds.wf[0][2][3] = r.pdp;
-                    lds.wi[0][0][3] = r.lock_cnt; lds.wi[0][1][3] = r.unlock_cnt; lds.wi[0][2][3] = r.minimized ? 1 : 0;
+                    cy.ps = r;
                 }
                 __syncthreads();
 #pragma unroll
-                for (int i = 0; i < FB_K; i++) used[i] = ok[i] ? er[j0 + i] : 0.f;
-                e.acc = lds.wf[0][0][3]; e.mean = lds.wf[0][1][3]; e.pdp = lds.wf[0][2][3];
-                e.lock_cnt = lds.wi[0][0][3]; e.unlock_cnt = lds.wi[0][1][3]; e.minimized = lds.wi[0][2][3] != 0;
-                __syncthreads();
+                for (int i = 0; i < FB_K; i++) used[i] = (i < nv) ? er[j0 + i] : 0.f;
             }
-            __syncthreads();                                         // (everybody has its copy of the state in front of the segment)
-            if (tid == 0) cy.ps = e;
         }
-        SB_TICK1(5);
+        SB_ARGS_FRESH(); SB_TICK1(5);
 
         // ================= 38 kHz mix, PSS input, stereo matrix (fm-processor.cpp:707-730, 517-549) =================
         float2 x[FB_K];
         {
             constexpr double INV2PI = 1.0 / FMX_2PI;
-            const int ssel = P.sound_sel, fmode = P.fm_mode; const float pano = P.panorama;
-            const int64_t ic = pss_count0 + cy.calls;                // call index of the segment's first call
-            float diffv[FB_K];
+            const int ssel = P.sound_sel; const float pano = (P.fm_mode == 1) ? P.panorama : 1.0f;
+            const int64_t ic = pss_count0 + calls_before;            // call index of the segment's first call
+            const float P32 = 6.2831855f, C32 = T.wrap32_c;
+            const bool wrap_ok = T.wrap32_ok != 0;
+            float sumv[FB_K], diffv[FB_K];
 #pragma unroll
             for (int i = 0; i < FB_K; i++) {
                 // phaseforLRDiff fm-processor.cpp:707-714: 2 (currentPilotPhase + pi/4) - pilotDelayPSS lies in (0, 4 pi + 2.4), so the
                 // "< -2 pi" branch never runs and fmod (., 2 pi) is the fraction of the turn count
-                float cc = pi_constrain_near(cur[i]);
-                if (__any(!(cur[i] > -6.f && cur[i] < 12.f))) cc = pi_constrain(cur[i]);    // (see the pilot PLL: corrections of more than a turn)
+                float cc = (cur[i] < P32) ? cur[i] : (cur[i] - P32) + C32;                   // PI_Constrain of [0, 2 pi + 0.7), see the pilot PLL
+                if (__any(!(cur[i] >= 0.f && cur[i] < P32 + 0.5f) || !wrap_ok)) cc = pi_constrain(cur[i]);
                 const float p = (float)(2 * ((double)cc + FMX_PI_4 + 0) - (double)used[i]);
                 const double u = __builtin_amdgcn_fract((double)p * INV2PI);
                 int idx = (int)(u * (double)SINCOS_N);               // SinCos::getComplex sincos.cpp:93-97
                 idx = idx >= SINCOS_N ? SINCOS_N - 1 : idx;
                 float2 e;
                 sincos_idx_f32(idx, &e.y, &e.x);
-                const float sn = e.y;                                // S_LEFTminusRIGHT_Test mixes with the sine
-                float2 audio = make_float2(dem[i], 0.f);
+                float dif = 0.f;
                 if (tag[i] != -2) {
-                    if (tag[i] >= 0 && ok[i]) sring[(ic + tag[i]) & G.sring_mask] = make_float2(e.x * dem[i], e.y * dem[i]);
-                    const float lut = (ssel == 6) ? sn : e.x;
-                    audio.y = 2.0f * (lut * dem[i]);                 // (float)(2.0 * lut * demod): one rounding of the exact product either way
+                    if (tag[i] >= 0 && i < nv) sring[(ic + tag[i]) & smask] = make_float2(e.x * dem[i], e.y * dem[i]);
+                    const float lut = (ssel == 6) ? e.y : e.x;       // S_LEFTminusRIGHT_Test mixes with the sine
+                    dif = 2.0f * (lut * dem[i]);                     // (float)(2.0 * lut * demod): one rounding of the exact product either way
                 }
-                const float sumLR = audio.x, diffLR = audio.y;
-                const float dw = diffLR * (fmode == 1 ? pano : 1.0f);
+                sumv[i] = dem[i]; diffv[i] = dif;
+            }
+            {   // scope tap (fmx_get_tap): channel-major rows of this call
+                float *wf = B.w_diff + (size_t)ch * B.lin_rows + seg0 + j0;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) if (i < nv) wf[i] = diffv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) {
+                const float sumLR = sumv[i];
+                const float dw = diffv[i] * pano;
                 const float left = sumLR + dw, right = sumLR - dw;
                 float2 o;
                 switch (ssel) {
@@ -1488,14 +1701,10 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
                 case 4: o = make_float2(sumLR, sumLR); break;
                 case 5: case 6: o = make_float2(dw, dw); break;
                 }
-                x[i] = ok[i] ? o : make_float2(0.f, 0.f);
-                diffv[i] = audio.y;
+                x[i] = (i < nv) ? o : make_float2(0.f, 0.f);
             }
-            // scope tap (fmx_get_tap): channel-major rows of this call
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) if (ok[i]) B.w_diff[lrow + i] = diffv[i];
         }
-        SB_TICK1(6);
+        SB_ARGS_FRESH(); SB_TICK1(6);
 
         // ================= de-emphasis (fm-processor.cpp:594-595) into the d ring =================
         // (the next segment's ring entries are requested here: they land under the de-emphasis, and are not in the way of the
@@ -1507,23 +1716,33 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
             float Ll = 0.f, Lr = 0.f;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) { Ll = (x[i].x - Ll) * a + Ll; Lr = (x[i].y - Lr) * a + Lr; }
-            float yl = wg.decay_incoming(Ll, cy.de_l, dw);
-            float yr = wg.decay_incoming(Lr, cy.de_r, dw);
-            if (tid == 0) cy.calls += ncalls;                        // (the mix above was the last reader; two barriers in between)
-            const int64_t dmask = G.dring_mask;
+            float yl, yr;
+            {   // (both channels behind one barrier)
+                const float Zl = wscan_decay(Ll, dw), Zr = wscan_decay(Lr, dw);
+                if (lane == 63) { lds.wf[wg.sl][wg.wv][0] = Zl; lds.wf[wg.sl][wg.wv][1] = Zr; }
+                const float cl0 = cy.de_l, cr0 = cy.de_r;
+                __syncthreads();
+                float Cl = cl0, Cr = cr0;
+                for (int v = 0; v < wg.wv; v++) { Cl = fmaf(Cl, dw.d64, lds.wf[wg.sl][v][0]); Cr = fmaf(Cr, dw.d64, lds.wf[wg.sl][v][1]); }
+                wg.sl ^= 1;
+                yl = fmaf(dw.dl, Cl, lane_prev_f(Zl, 0.f)); yr = fmaf(dw.dl, Cr, lane_prev_f(Zr, 0.f));
+            }
+            if (tid == 0) cy.calls = calls_before + ncalls;          // (the mix above was the last reader; a barrier in between)
+            const int dmask = G.dring_mask;
             float2 *dr = B.dring + (size_t)ch * (dmask + 1);
+            const int jb = (int)((G.J0 + seg0 + j0) & dmask);
             float el = 0.f, er_ = 0.f;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) {
                 yl = (x[i].x - yl) * a + yl;
                 yr = (x[i].y - yr) * a + yr;
-                if (ok[i]) dr[(G.J0 + seg0 + j0 + i) & dmask] = make_float2(yl, yr);
+                if (i < nv) dr[(jb + i) & dmask] = make_float2(yl, yr);
                 if (i == il) { el = yl; er_ = yr; }
             }
             // the state behind the segment's last sample, as its owner computed it (read again behind the next segment's barriers)
             if (owner) { cy.de_l = el; cy.de_r = er_; }
         }
-        SB_TICK1(7);
+        SB_ARGS_FRESH(); SB_TICK1(7);
     }
     // ================= bookkeeping behind the call =================
     __syncthreads();
@@ -1541,7 +1760,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
             cnt -= (SINCOS_N >> 1) + 1;
         }
         st->my_count = cnt;
-        st->pss_count = pss_count0 + cy.calls;               // the PSS filter time base advances by this call's process_sample calls
+        st->pss_count = pss_count0 + cy.calls;                   // the PSS filter time base advances by this call's process_sample calls
         st->pss_call_total = 0;
     }
     SB_TICK1(8);
@@ -1552,6 +1771,9 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(DeviceTabl
         B.dbg[(size_t)ch * DBG_SLOTS + 13] = __float_as_uint(cy.x0); B.dbg[(size_t)ch * DBG_SLOTS + 14] = __float_as_uint(cy.lock);   // (diagnostics: state behind the call)
     }
 }
+#undef T
+#undef B
+#undef G
 
 // The fused schedule: the PLL kernel for the whole call, then per segment the PSS kernel (whose errors need the s-ring entries
 // the segment in front of it wrote).
@@ -1559,7 +1781,8 @@ void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const Cal
     const int64_t nj = G.J1 - G.J0;
     if (nj <= 0) return;
     static const bool split = getenv("FMX_STAGE_B") && std::string(getenv("FMX_STAGE_B")) == "split";     // (A/B runs: the two-kernel schedule)
-    if (!split && T.pss_hs) { hipLaunchKernelGGL(stageb_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, T, B, G, C); FMX_LAUNCHED(); return; }
+    if (!split && T.pss_hs) { StageBArgs A; A.T = T; A.B = B; A.G = G; A.C = C;
+                           hipLaunchKernelGGL(stageb_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED(); return; }
     hipLaunchKernelGGL(stageb_pll_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, T, B, G, C); FMX_LAUNCHED();
     for (int64_t seg0 = 0; seg0 < nj; seg0 += FB_W) {
         SegArgs A;

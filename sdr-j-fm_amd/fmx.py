@@ -20,16 +20,17 @@ P_FM_MODE, P_FM_DECODER, P_SOUND_MODE, P_STEREO_PANORAMA, P_SOUND_BALANCE, P_DEE
 P_VOLUME_DB, P_LF_CUTOFF, P_BANDWIDTH, P_ATTENUATION_L, P_ATTENUATION_R, P_RDS_MODE = 7, 8, 9, 10, 11, 12
 P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE, P_SQUELCH_VALUE = 13, 14, 15, 16, 17, 18, 19
 P_DISP_DELAY = 20
+P_PLL_SOLVER = 21             # 0 automatic, 1 sequential (the reference's trajectory bit for bit), 2 parallel (Newton)
 A_TRIGGER_FREQUENCY_CHANGE, A_RESTART_PSS, A_RESET_RDS = 100, 101, 102
 
-TAP_FM_IQ, TAP_DEMOD, TAP_LR_RAW, TAP_PRE_RESAMPLER, TAP_RDS_IQ = 0, 1, 2, 3, 4
+TAP_FM_IQ, TAP_DEMOD, TAP_LR_RAW, TAP_PRE_RESAMPLER, TAP_RDS_IQ, TAP_PILOT_PHASE = 0, 1, 2, 3, 4, 5
 IQ_F32, IQ_U8, IQ_S8, IQ_S16 = 0, 1, 2, 3
 
 EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
     "fmx_get_meta", "fmx_get_tap", "fmx_get_peaks",
-    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_last_rds_samples", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
+    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_last_rds_samples", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
 
@@ -121,6 +122,8 @@ def load_library(path=None):
     L.fmx_rds_symbols.argtypes = [vp, i32, f32p, i32, C.POINTER(i32)]
     L.fmx_last_fm_samples.restype = C.c_int64
     L.fmx_last_fm_samples.argtypes = [vp]
+    L.fmx_pll_replays.restype = C.c_int64
+    L.fmx_pll_replays.argtypes = [vp, C.c_int32]
     L.fmx_last_rds_samples.restype = C.c_int64
     L.fmx_last_rds_samples.argtypes = [vp]
     L.fmx_get_taps.restype = C.c_int
@@ -233,7 +236,7 @@ class Fmx:
         return m
 
     def tap(self, tap_id, n, channel=0):
-        width = 1 if tap_id == TAP_DEMOD else 2
+        width = 1 if tap_id in (TAP_DEMOD, TAP_PILOT_PHASE) else 2
         out = np.zeros((n, width), np.float32)
         self._check(self.L.fmx_get_tap(self.h, channel, tap_id, out.ctypes.data_as(C.POINTER(C.c_float)), n))
         return out[:, 0] if width == 1 else out
@@ -260,6 +263,13 @@ class Fmx:
 
     def last_fm_samples(self):
         return int(self.L.fmx_last_fm_samples(self.h))
+
+    def pll_replays(self, channel=-1):
+        """Segments of the pilot PLL that were replayed sequentially (fmx_pll_replays)."""
+        n = int(self.L.fmx_pll_replays(self.h, channel))
+        if n < 0:
+            self._check(n)
+        return n
 
     def rds_decode(self, channel=0):
         """Feed the bits sliced so far into the channel's block synchroniser / group decoder; returns FmxRdsInfo."""

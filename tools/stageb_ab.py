@@ -40,6 +40,8 @@ def child(out):
             res["meta%d_%d" % (k, c)] = np.array([m.PilotPllLocked, m.PilotPllLockStrength, m.PssState, m.PssPhaseShiftDegree, m.PssPhaseChange, m.DcValIf], np.float64)
         res["dem%d" % k] = f.tap(M.TAP_DEMOD, nf, 0)
         res["lr%d" % k] = f.tap(M.TAP_LR_RAW, nf, 5)
+        res["lrnopss%d" % k] = f.tap(M.TAP_LR_RAW, nf, 4)
+    res["replays"] = np.array([f.pll_replays()], np.int64)
     np.savez(out, **res)
 
 
@@ -66,5 +68,9 @@ for key in a.files:
     worst = max(worst, d)
     if not same:
         nbad += 1
-        print("%-10s differs: max |d| %.3e (rms of a %.3e)" % (key, d, float(np.sqrt(np.mean(x * x))) if x.size else 0.0))
-print("arrays compared %d, not bit-identical %d, worst |d| %.3e" % (len(a.files), nbad, worst))
+        if d > 2e-6 or key.startswith("meta"):
+            print("%-10s differs: max |d| %.3e (rms of a %.3e)" % (key, d, float(np.sqrt(np.mean(x * x))) if x.size else 0.0))
+for k in range(22):
+    def r(x): return float(np.sqrt(np.mean(np.square(x.astype(np.float64)))))
+    print("call %2d: rms diff  lr(pss) %.2e  lr(no pss) %.2e  pcm %.2e | pss deg split %.6f one %.6f | lock strength %.6f %.6f" % (k, r(a["lr%d" % k] - b["lr%d" % k]), r(a["lrnopss%d" % k] - b["lrnopss%d" % k]), r(a["pcm%d" % k] - b["pcm%d" % k]), a["meta%d_0" % k][3], b["meta%d_0" % k][3], a["meta%d_0" % k][1], b["meta%d_0" % k][1]))
+print("arrays compared %d, not bit-identical %d, worst |d| %.3e; PLL replays %s / %s" % (len(a.files), nbad, worst, a["replays"], b["replays"]))
