@@ -1,4 +1,4 @@
-// fmx_stageb.hip -- stage B time-parallel, one workgroup per channel ("fused layout").  COMPILED WITH -ffp-contract=off.
+// fmx_stageb.hip -- stage B time-parallel, one workgroup per channel, ONE kernel per call.  COMPILED WITH -ffp-contract=off.
 //
 // Replaces per channel, like fmx_demod.hip:
 //   fm_Demodulator::demodulate        fm-demodulator.cpp:111-205 (memoryless decoders: Mixed / ComplexBB / RealBB / Diff)
@@ -10,45 +10,30 @@
 //
 // fmx_demod.hip runs the per-sample recurrences with one LANE per channel: their parallelism is the channel count, every
 // sample costs a 180-cycle dependent chain, and five kinds of kernels hand chunks to each other through progress words.
-// Here the parallelism is TIME: one 256-thread workgroup owns one channel and a segment of up to 1536 fm samples (six
-// adjacent samples per thread); every recurrence becomes a scan over the workgroup.  Two kernels:
-//   stageb_pll_kernel  once per call -- limiter, discriminator, AFC, pilot PLL, lock detector for all the call's segments in
-//                      turn (none of it depends on the PSS feedback);
-//   stageb_pss_kernel  once per segment -- PSS low-pass and error by fast convolution (fmx_fftconv.h), PSS integrator, 38 kHz
-//                      mix, matrix, de-emphasis.
-// The recurrences:
+// Here the parallelism is TIME: one 256-thread workgroup owns one channel and walks the call in segments of up to 1536 fm
+// samples (six adjacent samples per thread); every recurrence becomes a scan over the workgroup (stageb_kernel below):
 //   * linear recurrences with a constant decay (AFC, lock metric, PSS mean error, de-emphasis): a weighted wave scan in DPP
 //     carries the state ACROSS threads, each thread then re-runs its own six samples in the reference's exact f32 / f64
 //     expression.  The cross-thread carry differs from the sequential evaluation by rounding (1e-7 relative);
-//   * the pilot PLL -- non-linear: the phase feeds the sine look-up that corrects it -- as a FIXED-POINT ITERATION on the f32
-//     trajectory.  Given a guess x[j] of the state in front of every sample, each thread evaluates the reference's own f32
-//     step on it, d[j] = step(x[j]) - x[j] (an exact difference of two floats in f64), a workgroup scan sums the d in f64 and
-//     x[j] = x[0] + sum d[< j] is the next guess.  The step must be the reference's f32 step: its roundings are not noise
-//     but a pattern (adding the f32 omega to a phase in [4, 8) adds omega rounded to that binade's grid), a frequency offset
-//     of ~1e-7 rad per sample that the loop turns into a standing phase offset of ~5e-4 rad -- an evaluation in higher
-//     precision misses the reference by that much (tools/pll_fixed_point.py).  The correction per sample is < 1e-3 rad, so
-//     the map contracts over a segment: from the free-running ramp the guess is within 2e-5 rad after two rounds and at the
-//     trajectory's own noise floor (4e-6) after three.  It does NOT go on to reproduce the sequential trajectory bit for
-//     bit in a useful number of rounds (a guess a few ulps off flips a table index here and a rounding there, each flip
-//     shifts everything behind it by an ulp: measured, the exact front advances ~3 samples per round, 560 rounds per
-//     segment), and nothing is gained by that: the trajectory is exactly as sensitive to the 1e-6 differences stage A's
-//     summation order leaves in its input.  The iteration ends when a round moves no phase by PLL_TOL = 3e-5 rad (3-4
-//     rounds); the result then differs from the sequential evaluation by ~7e-6 rad RMS;
+//   * the pilot PLL -- non-linear: the phase feeds the sine look-up that corrects it -- by Newton's method on the f32
+//     trajectory of the whole segment (large batches), or sample by sample by one thread (few channels, and as the
+//     fail-safe): see the kernel.  The step evaluated is always the reference's own f32 step: its roundings are not noise
+//     but a pattern (adding the f32 omega to a phase in [4, 8) adds omega rounded to that binade's grid), a frequency
+//     offset of ~1e-7 rad per sample that the loop turns into a standing phase offset of ~5e-4 rad -- an evaluation in
+//     higher precision misses the reference by that much (tools/pll_fixed_point.py);
 //   * the PSS phase integrator (whose increments are often smaller than half an ulp of the accumulator, so they must be
-//     absorbed exactly as the reference absorbs them): the same iteration run to the EXACT fixed point, which IS the
-//     sequential f32 trajectory (induction over j); its increment depends on the guess only through the binade, 2-3 rounds
-//     (a few dozen while the accumulator is still next to zero), capped at PSS_MAX_ROUNDS;
+//     absorbed exactly as the reference absorbs them): increments evaluated at the segment's first value and summed in
+//     f64, verified against the values found; a segment where that is not yet the trajectory iterates to the EXACT fixed
+//     point, which IS the sequential f32 trajectory (induction over j), capped at PSS_MAX_ROUNDS;
 //   * flags and counters (pilot lock, PSS call index, the "error minimised" state machine) follow from max / sum scans in
 //     closed form; a segment in which a closed form does not apply (lock transitions inside a PSS segment, a counter next to
 //     its 3 s threshold) is replayed sample by sample by one thread from LDS.
-// The only feedback with a lag, the PSS error (low-pass of the 38 kHz mix, 1753 samples behind), bounds the segment of the
-// second kernel: its errors come from s-ring entries that are at least one segment old.  Everything runs on the caller's stream:
-// no side streams, no events, no waiting kernels.
+// The only feedback with a lag, the PSS error (low-pass of the 38 kHz mix, 1753 samples behind), bounds the segment: its
+// errors come from s-ring entries that are at least one segment old.  Everything runs on the caller's stream: no side
+// streams, no events, no waiting kernels.
 #include "fmx_internal.h"
 #include "fmx_demod_math.h"
 #include "fmx_fftconv.h"
-#include <cstdlib>
-#include <string>
 
 namespace fmx {
 
@@ -57,13 +42,7 @@ namespace fmx {
 constexpr int FB_T = 256, FB_K = 6, FB_W = FB_T * FB_K;        // threads, samples per thread, segment length
 static_assert(FB_T == fftc::T, "the convolution is written for the workgroup size");
 static_assert(FB_W <= PSS_DELAY, "a segment's PSS errors must only need s-ring entries of earlier segments");
-#ifdef SB_TOL
-constexpr float PLL_TOL = SB_TOL; constexpr int PLL_MAX_ROUNDS = SB_ROUNDS, PSS_MAX_ROUNDS = 64;
-#else
-constexpr float PLL_TOL = 3e-5f;                               // a PLL round that moves no phase by this much (rad) ends the iteration
-constexpr int PLL_MAX_ROUNDS = 32, PSS_MAX_ROUNDS = 64;
-#endif
-static_assert(FB_W <= PSS_CHUNK, "the error array holds PSS_CHUNK rows per channel");
+constexpr int PSS_MAX_ROUNDS = 64;
 #ifndef SB_WG_PER_SIMD
 #define SB_WG_PER_SIMD 3
 #endif
@@ -117,15 +96,6 @@ __device__ __forceinline__ DecayW make_decay(float l2, int lane) {
 #ifndef SB_HOIST_DECAY
     asm volatile("" : "+v"(l2));        // opaque: the eight weights are recomputed where they are used (hoisted out of the segment loop they
 #endif                                  // would occupy 8 VGPRs per recurrence for the whole kernel)
-#ifdef SB_DECAY_OLD
-    {
-        const double D = exp2((double)l2 * FB_K);
-        w.m1 = (float)D; w.m2 = (float)(D * D); w.m4 = (float)powi(D, 4); w.m8 = (float)powi(D, 8);
-        w.mA = (float)powi(D, (lane & 15) + 1); w.mB = (float)powi(D, (lane & 31) + 1);
-        w.dl = (float)powi(D, lane); w.d64 = (float)powi(D, 64);
-        return w;
-    }
-#endif
     const float L = l2 * (float)FB_K;                            // log2 of D = d^FB_K
     w.m1 = __builtin_amdgcn_exp2f(L); w.m2 = __builtin_amdgcn_exp2f(2 * L); w.m4 = __builtin_amdgcn_exp2f(4 * L); w.m8 = __builtin_amdgcn_exp2f(8 * L);
     w.mA = __builtin_amdgcn_exp2f((float)((lane & 15) + 1) * L); w.mB = __builtin_amdgcn_exp2f((float)((lane & 31) + 1) * L);
@@ -153,7 +123,6 @@ struct ScanLds {
 };
 
 
-struct SegArgs { int seg0, w, first, last; };
 
 // Workgroup-wide pieces.  `sl` is the scratch slot, toggled by every call; all threads of the workgroup make the same calls.
 struct WG {
@@ -259,93 +228,6 @@ struct WG {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// PSS low-pass + error for the calls a segment can make: err[m] = Re(y) Im(y), y = sum_k h[k] s[i0 + m - 1753 - k],
-// i0 = the channel's next PSS call index, m = 0 .. w-1 (stereo-separation.cpp:60-83).  All these s-ring entries were
-// written by earlier segments.  One wave per (512 calls, channel), eight adjacent calls per thread through a twelve-entry
-// register ring, the window in LDS in four planes (see pss_fir_body in fmx_demod.hip, whose steady path this is).
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int SF_TILE = 512, SF_FPT = 8;
-constexpr int SF_TG = (PSS_TAPS + 11) / 12 * 3;
-constexpr int SF_WU = (SF_TILE + 4 * SF_TG + 8) / 8 + 2;
-__global__ __launch_bounds__(64) void pssfir_seg_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, SegArgs A) {
-    __shared__ __attribute__((aligned(16))) float4 sW[4][SF_WU];
-    __shared__ __attribute__((aligned(16))) float sH[4 * SF_TG];
-    const int ch = blockIdx.y, lane = threadIdx.x;
-    const int q0 = blockIdx.x * SF_TILE;
-    const ChanParams &P = B.params[ch];
-    if (P.fm_mode == 2 || !P.pss_active) return;
-    const ChanState &st = B.state[ch];
-    const int64_t i0 = st.pss_count + (A.first ? 0 : st.pss_call_total) + q0;      // call index of this tile's first output
-    const float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
-    float2 *sW2 = reinterpret_cast<float2 *>(&sW[0][0]);
-    auto wslot = [](int w) { const int u = w >> 1; return (((u & 3) * SF_WU + (u >> 2)) << 1) | (w & 1); };
-    {   // window entry w <-> s index i0 - (1753 + 294) + w
-        constexpr int NW = 8 * (SF_WU - 1), FB = 7;
-#pragma unroll
-        for (int w0 = 0; w0 < NW; w0 += 64 * FB) {
-            float2 v[FB];
-#pragma unroll
-            for (int k = 0; k < FB; k++) {
-                const int w = w0 + 64 * k + lane;
-                const int64_t idx = i0 - (PSS_DELAY + PSS_TAPS - 1) + w;
-                v[k] = (w < NW && idx >= 0 && w < SF_TILE + PSS_TAPS - 1) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < FB; k++) {
-                const int w = w0 + 64 * k + lane;
-                if (w < NW) sW2[wslot(w)] = v[k];
-            }
-        }
-        constexpr int HB = (4 * SF_TG + 63) / 64;
-        float hv[HB];
-#pragma unroll
-        for (int k = 0; k < HB; k++) { const int w = 64 * k + lane; hv[k] = (w < PSS_TAPS) ? T.pss_taps[PSS_TAPS - 1 - w] : 0.f; }
-#pragma unroll
-        for (int k = 0; k < HB; k++) { const int w = 64 * k + lane; if (w < 4 * SF_TG) sH[w] = hv[k]; }
-    }
-    __syncthreads();
-    typedef float v2f_t __attribute__((ext_vector_type(2)));
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    const int q = q0 + SF_FPT * lane;
-    const int m = lane;                                  // this thread's first window unit is 4 m
-    const float4 *hr = reinterpret_cast<const float4 *>(sH);
-    v2f_t acc[SF_FPT], c[12];
-#pragma unroll
-    for (int j = 0; j < SF_FPT; j++) acc[j] = (v2f_t){0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const float4 v = sW[k & 3][m + (k >> 2)];
-        c[2 * k] = (v2f_t){v.x, v.y}; c[2 * k + 1] = (v2f_t){v.z, v.w};
-    }
-    for (int g3 = 0; g3 < SF_TG; g3 += 3) {
-#pragma unroll
-        for (int gg = 0; gg < 3; gg++) {
-            const int g = g3 + gg;
-            const float4 h4 = hr[g];
-            const float hq[4] = {h4.x, h4.y, h4.z, h4.w};
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                const v2f_t w = (v2f_t){hq[qq], hq[qq]};
-#pragma unroll
-                for (int j = 0; j < SF_FPT; j++) acc[j] = __builtin_elementwise_fma(w, c[(4 * gg + qq + j) % 12], acc[j]);
-            }
-            const int u0 = 2 * g + 6;
-            const float4 va = sW[u0 & 3][m + (u0 >> 2)], vb = sW[(u0 + 1) & 3][m + ((u0 + 1) >> 2)];
-            c[(4 * gg) % 12] = (v2f_t){va.x, va.y}; c[(4 * gg + 1) % 12] = (v2f_t){va.z, va.w};
-            c[(4 * gg + 2) % 12] = (v2f_t){vb.x, vb.y}; c[(4 * gg + 3) % 12] = (v2f_t){vb.z, vb.w};
-        }
-    }
-    float *dst = B.w_err + (size_t)ch * FB_W + q;
-    if (q + SF_FPT <= A.w) {
-        reinterpret_cast<f32x4_t *>(dst)[0] = (f32x4_t){acc[0].x * acc[0].y, acc[1].x * acc[1].y, acc[2].x * acc[2].y, acc[3].x * acc[3].y};
-        reinterpret_cast<f32x4_t *>(dst)[1] = (f32x4_t){acc[4].x * acc[4].y, acc[5].x * acc[5].y, acc[6].x * acc[6].y, acc[7].x * acc[7].y};
-    } else {
-#pragma unroll
-        for (int j = 0; j < SF_FPT; j++) if (q + j < A.w) dst[j] = acc[j].x * acc[j].y;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // one step of the PSS integrator and its state machines, every lane / thread in any state (fm-processor.cpp:699-718,
 // stereo-separation.cpp:84-109); the replay path runs it sample by sample
 // ---------------------------------------------------------------------------------------------------------------------
@@ -376,607 +258,6 @@ __device__ __forceinline__ void meta_snapshot(ChanState *st, const ChanParams &P
     st->meta_pss_deg = (float)((double)pdp / 3.14159265358979323846 * 180.0f);
     st->meta_pss_change = mean * 1000;
     st->meta_pss_state = (P.pss_active && lk) ? (minimized ? 2 : 1) : 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Kernel 1 of 2, once per call: one workgroup = one channel, looping over the call's segments of up to 1536 fm samples --
-// limiter + discriminator, AFC, pilot PLL, lock detector.  Nothing here depends on the PSS feedback, so the whole call runs in
-// one launch: the recurrences' states ride from segment to segment in registers (every thread holds the same copy), the
-// next segment's ring entries are loaded while the current one is computed.  Out: demod and pilot phase per sample
-// (w_dem / w_cur, which are also the scope / RDS taps) and one byte of lock flags per thread and segment (w_lockm).
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FB_T, 3) void stageb_pll_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C) {
-    __shared__ ScanLds lds;
-    const int ch = blockIdx.x;
-    if (ch >= C) return;
-    WG wg; wg.L = &lds; wg.tid = threadIdx.x; wg.lane = threadIdx.x & 63; wg.wv = threadIdx.x >> 6; wg.sl = 0;
-    const int tid = wg.tid, lane = wg.lane;
-    const ChanParams &P = B.params[ch];
-    ChanState *st = B.state + ch;
-    const int nj = (int)(G.J1 - G.J0);
-    const int j0 = tid * FB_K;                                   // segment-relative index of this thread's first sample
-    const int lin = B.lin_rows;                                  // row stride of the channel-major tap arrays
-    const bool dbg_on = (B.dbg != nullptr) && (tid == 0);
-    unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
-    const int decoder = P.decoder;
-    const int delay = T.front_sets[P.front_set].delay_fm;
-    const float2 *zr = B.zring + (size_t)ch * (G.ring_mask + 1);
-    // the sample behind which the reference takes its metaData snapshot (++myCount > fmRate / 2, fm-processor.cpp:662-684), call-relative;
-    // the values this kernel owns (lock strength, lock flag, demodulator DC) are stored from exactly that sample
-    const bool stereo_possible = P.fm_mode != 2;
-    const int jx = (SINCOS_N >> 1) - st->my_count;
-    // ring entries of the samples j0 - 2 .. j0 + K - 1 of the segment at seg0 (clamped to the call's last sample: never past what
-    // stage A wrote; zero until the filter latency has elapsed; the marker NaN where the reference's start values 0.01 apply)
-    auto fetch = [&](int seg0, int w, float2 *z) {
-#pragma unroll
-        for (int t = 0; t < FB_K + 2; t++) {
-            const int jr = j0 - 2 + t;
-            const int64_t jj = G.J0 + seg0 + (jr < w ? jr : w - 1);
-            const int64_t s = jj - delay;
-            z[t] = jj < 0 ? make_float2(__builtin_nanf(""), 0.f) : (s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f));
-        }
-    };
-    // the recurrences' states in front of the segment (the same in every thread)
-    float afc0 = st->fm_afc, x0s = st->pil_phase, old0 = st->pil_old, lock0 = st->pil_lock;
-    int locked0 = st->pil_locked, stable0 = st->pil_stable;
-    float2 zn[FB_K + 2];
-    fetch(0, nj < FB_W ? nj : FB_W, zn);
-    for (int seg0 = 0; seg0 < nj; seg0 += FB_W) {
-        const int w = (nj - seg0) < FB_W ? (nj - seg0) : FB_W;
-        const bool lastseg = seg0 + FB_W >= nj;
-        bool ok[FB_K];
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) ok[i] = j0 + i < w;
-        const bool owner = (w - 1 >= j0) && (w - 1 < j0 + FB_K);     // this thread owns the segment's last sample
-        const int il = w - 1 - j0;                                   // ... at this position
-        const size_t lrow = (size_t)ch * lin + seg0 + j0;
-
-        // ================= limiter + discriminator (fm-demodulator.cpp:119-126, 168-189) =================
-        float res[FB_K];
-        {
-            float2 lim[FB_K + 2];                                // limited samples j0-2 .. j0+K-1 (the two in front recomputed: cheaper
-#pragma unroll                                                   // than an exchange through LDS with its two barriers)
-            for (int t = 0; t < FB_K + 2; t++) lim[t] = (zn[t].x != zn[t].x) ? make_float2((float)0.01, (float)0.01) : limiter_fast(zn[t]);
-            if (!lastseg) { const int wn = (nj - seg0 - FB_W) < FB_W ? (nj - seg0 - FB_W) : FB_W; fetch(seg0 + FB_W, wn, zn); }   // lands under this segment's work
-            // (one loop per decoder: the six table gathers of a thread are issued back to back, not one per branch arm)
-            if (decoder == 5) {                                      // REAL_BB :174-182
-                int index[FB_K];
-    #pragma unroll
-                for (int i = 0; i < FB_K; i++) {
-                    const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
-                    const float r = (float)((double)(I1 * Q - Q1 * I + 1) / 2.0);
-                    int ix = (int)floorf(r * (float)ARCSINE_N);
-                    ix = ix < 0 ? 0 : ix;
-                    index[i] = ix >= ARCSINE_N ? ARCSINE_N : ix;
-                }
-    #pragma unroll
-                for (int i = 0; i < FB_K; i++) res[i] = T.arcsine[index[i]];
-            } else if (decoder == 6) {                               // DIFF :184-189
-    #pragma unroll
-                for (int i = 0; i < FB_K; i++) {
-                    const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
-                    const float Scaler = (float)1.4142135623730951;
-                    const float r = (I1 * (Q - lim[i].y) - Q1 * (I - lim[i].x));
-    #ifdef SB_EXACT_DIV
-                    res[i] = r / ((I1 * I1 + Q1 * Q1) * Scaler);
-    #else
-                    res[i] = fdiv_fast(r, (I1 * I1 + Q1 * Q1) * Scaler);
-    #endif
-                }
-            } else {                                                 // MIXED :168-172 (COMPLEX_BB is bitwise the same)
-                AtanArm arm[FB_K];
-    #pragma unroll
-                for (int i = 0; i < FB_K; i++) {
-                    const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
-                    arm[i] = atan_arm(Q * I1 - I * Q1, I * I1 + Q * Q1);
-                }
-                float tv[FB_K];
-    #pragma unroll
-                for (int i = 0; i < FB_K; i++) tv[i] = T.atan_ppy[arm[i].idx];
-    #pragma unroll
-                for (int i = 0; i < FB_K; i++) res[i] = atan_finish(arm[i], tv[i]);
-            }
-    #pragma unroll
-            for (int i = 0; i < FB_K; i++) res[i] = ok[i] ? res[i] : 0.f;
-        }
-
-
-        SB_TICK(0);
-        // ================= AFC + scaling (fm-demodulator.cpp:197-198) =================
-        float dem[FB_K];
-        {
-            const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha;
-            float Lt = 0.f;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) Lt = c1 * Lt + fmDcAlpha * res[i];
-            float afc_next;
-            float afc = wg.decay_incoming2(Lt, afc0, make_decay(T.afc_l2, lane), &afc_next);
-            float afc_end = 0.f;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                afc = c1 * afc + fmDcAlpha * res[i];
-                dem[i] = fdiv_const(20.0f * (res[i] - afc) * 1.0f, T.K_FM, T.K_FM_rcp);
-                if (i == il) afc_end = afc;
-                if (i == jx - seg0 - j0 && ok[i]) st->meta_dc_if = afc;                   // get_demodDcComponent () at the snapshot
-            }
-            if (lastseg && owner) st->fm_afc = afc_end;
-            afc0 = afc_next;
-        }
-
-        SB_TICK(1);
-        // ================= pilot PLL (pilot-recover.cpp:54-61): fixed point of the f32 trajectory =================
-        float cur[FB_K], osc[FB_K];
-        float osc_in;                                            // NCO sine of the sample in front of this thread's first
-        {
-            const float gain = T.pil_gain, omega = T.pil_omega;
-            const float SC32 = (float)T.sincos_C;
-            const float P32 = 6.2831855f, C32 = T.wrap32_c;
-            float x0 = x0s;
-            if (!(x0 >= 0.f && x0 < P32)) x0 = pi_constrain(x0);
-            float ph[FB_K];
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                // first guess: the free-running ramp x0 + j omega
-                const double r = (double)x0 + (double)(j0 + i) * (double)omega;
-                ph[i] = (j0 + i == 0) ? x0 : (float)(r - floor(r * (1.0 / FMX_2PI)) * FMX_2PI);
-            }
-            const double x0d = (double)x0;
-            float xend = x0;
-            for (int it = 0; ; it++) {
-                double e[FB_K], tot = 0.0;
-    #pragma unroll
-                for (int i = 0; i < FB_K; i++) {
-                    float phase = ph[i];
-                    // a guess outside [0, 2 pi) (guesses of unfinished rounds only: a wrap that sits one sample earlier or later in the
-                    // guess than in the step's result shifts everything behind it by a turn) is taken modulo 2 pi
-                    if (__any(!(phase >= 0.f && phase < P32))) {
-                        const double pd = (double)phase;
-                        const float pw = (float)(pd - floor(pd * (1.0 / FMX_2PI)) * FMX_2PI);
-                        phase = (phase >= 0.f && phase < P32) ? phase : ((pw >= 0.f && pw < P32) ? pw : 0.f);
-                    }
-                    // SinCos::getSin sincos.cpp:81-85 for phase >= 0: table entry (int)(phase * C) % Rate, the entry itself from
-                    // sin_idx_f32 (the index in f32: it differs from the f64 product's in < 2 % of the samples, by one entry)
-    #ifdef SB_IDX64
-                    int idx = (int)((double)phase * T.sincos_C);
-    #else
-                    int idx = (int)(phase * SC32);
-    #endif
-                    idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
-                    const float o = sin_idx_f32(idx);
-                    const float perr = (5 * dem[i]) * o;             // pilot-recover.cpp:56-58 (pilot = 5 * demod fm-processor.cpp:696)
-                    const float t = phase + perr * gain;
-                    const float val = t + omega;
-                    const float wrapped = T.wrap32_ok ? (val - P32) + C32 : (float)((double)val - FMX_2PI);
-                    float nx = (val < P32) ? val : wrapped;          // PI_Constrain fm-constants.h:148-158
-                    // (a correction of more than a turn: the DIFF decoder's spike where the limiter output jumps from its 0.001 floor
-                    // to the unit circle at signal onset -- the general PI_Constrain, wave-uniformly skipped otherwise)
-                    if (__any(!(val >= 0.f && val < 2.f * P32))) nx = pi_constrain(val);
-                    cur[i] = t; osc[i] = o;
-                    e[i] = tot;
-                    tot += ok[i] ? (double)nx - (double)phase : 0.0;
-                }
-                double total; bool any;
-                const double pre = wg.excl_add_d(tot, &total, false, &any);
-                bool open_ = false;
-    #pragma unroll
-                for (int i = 0; i < FB_K; i++) {
-                    const float nph = (float)(x0d + (pre + e[i]));
-                    // distance between the guess this round evaluated and the one it produced (a wrap that moved by one sample
-                    // shows as 2 pi)
-                    float dd = fabsf(nph - ph[i]);
-                    dd = fminf(dd, fabsf(dd - P32));
-                    open_ = open_ || (ok[i] && !(dd < PLL_TOL));
-                    ph[i] = nph;
-                }
-                {   // (a guess chain may carry whole turns: dd above takes them for "no change", so the end state is taken modulo 2 pi)
-                    const double xe = x0d + total;
-                    xend = (float)(xe - floor(xe * (1.0 / FMX_2PI)) * FMX_2PI);
-                }
-                // every thread must know whether ANY thread is still moving: one more reduction (flags only)
-                const int wopen = __any(open_) ? 1 : 0;              // (evaluated by the whole wave, not under the lane-0 branch)
-                if (lane == 0) lds.wi[wg.sl][wg.wv][0] = wopen;
-                __syncthreads();
-                const int anych = lds.wi[wg.sl][0][0] | lds.wi[wg.sl][1][0] | lds.wi[wg.sl][2][0] | lds.wi[wg.sl][3][0];
-                wg.sl ^= 1;
-                if (!anych || it == PLL_MAX_ROUNDS - 1) { if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it + 1; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; } break; }
-            }
-        // (cur / osc are those of the last round's evaluation: of a trajectory the round moved by less than PLL_TOL)
-            x0s = (xend >= 0.f && xend < P32) ? xend : 0.f;
-            if (lastseg && tid == 0) st->pil_phase = x0s;
-            float old_next;
-            osc_in = wg.from_left2(osc[FB_K - 1], old0, &old_next);
-            old0 = old_next;
-            if (lastseg && owner) {
-                float oe = 0.f;
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) if (i == il) oe = osc[i];
-                st->pil_old = oe;
-            }
-        }
-
-        SB_TICK(2);
-        // ================= lock detector (pilot-recover.cpp:62-80) =================
-        {
-            const float lockA = 1.0f / 3000.0f;
-            const double keep = 1.0 - (double)lockA;
-            const float keepf = (float)keep;
-            const float omega = T.pil_omega, romega = T.pil_omega_rcp;
-            float xq[FB_K];
-            {
-                float old = osc_in;
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) {
-                    const float quadRef = fdiv_const(osc[i] - old, omega, romega);
-                    old = osc[i];
-                    xq[i] = ok[i] ? lockA * (-quadRef * (5 * dem[i])) : 0.f;
-                }
-            }
-            float Lt = 0.f;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) Lt = xq[i] + Lt * keepf;
-            float lock_next;
-            float lock = wg.decay_incoming2(Lt, lock0, make_decay(T.lock_l2, lane), &lock_next);
-            bool hi[FB_K]; int lastf = -1; float lock_end = 0.f, lock_x = 0.f;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                lock = (float)((double)xq[i] + (double)lock * keep);
-                hi[i] = lock > 0.07f;
-                if (ok[i] && !hi[i]) lastf = j0 + i;
-                if (i == il) lock_end = lock;
-                if (i == jx - seg0 - j0) lock_x = lock;
-            }
-            // locked[j] = no sample <= j below the threshold AND (locked before, or the run has lasted long enough)
-            int cnt_dummy, tot_dummy, preF, totF;
-            wg.excl_add_max_i(0, lastf, &cnt_dummy, &tot_dummy, &preF, &totF);
-            unsigned mask = 0;
-            {
-                int F = preF;
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) {
-                    if (ok[i] && !hi[i]) F = j0 + i;
-                    const bool lk = (F < 0) && (locked0 != 0 || stable0 + (j0 + i) + 1 > (SINCOS_N >> 1));
-                    mask |= lk ? (1u << i) : 0u;
-                    if (i == jx - seg0 - j0 && ok[i]) {                      // isPilotLocked (PilotPllLockStrength) :870-880
-                        st->meta_locked = (stereo_possible && lk) ? 1 : 0;
-                        st->meta_lock_strength = stereo_possible ? lock_x : 0.f;
-                    }
-                }
-            }
-            B.w_lockm[(size_t)ch * B.lockm_stride + (size_t)(seg0 / FB_K) + tid] = (uint8_t)mask;
-            int nl, ns;
-            if (totF < 0) { nl = (locked0 != 0 || stable0 + w > (SINCOS_N >> 1)) ? 1 : 0;
-                            ns = locked0 ? stable0 : (stable0 + w < (SINCOS_N >> 1) + 1 ? stable0 + w : (SINCOS_N >> 1) + 1); }
-            else { nl = 0; ns = w - 1 - totF; }
-            if (lastseg && owner) { st->pil_lock = lock_end; st->pil_locked = nl; st->pil_stable = ns; }
-            locked0 = nl; stable0 = ns; lock0 = lock_next;
-        }
-        // scope taps and the inputs of the second kernel / the RDS path: channel-major rows of this call
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) if (ok[i]) { B.w_dem[lrow + i] = dem[i]; B.w_cur[lrow + i] = cur[i]; }
-        SB_TICK(3);
-    }
-    if (dbg_on) for (int k = 0; k < 4; k++) B.dbg[(size_t)ch * DBG_SLOTS + 16 + k] += dbg_acc[k];
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Kernel 2 of 2, once per segment: one workgroup = one channel x fm samples [seg0, seg0 + w) of the call -- the PSS error of
-// the calls the segment can make (fast convolution of the s ring, fmx_fftconv.h), the PSS integrator, 38 kHz mix, matrix,
-// de-emphasis.  The segment length is bounded by the PSS feedback lag (1753 samples): its errors only need s-ring entries of
-// earlier segments.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FB_T, 4) void stageb_pss_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, SegArgs A) {
-    __shared__ ScanLds lds;
-    __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];     // the convolution's buffer, afterwards er / pk:
-    float *er = reinterpret_cast<float *>(X);                        // [FB_W] PSS error per call of the segment; replay path: error in, pilotDelayPSS used out
-    int *pk = reinterpret_cast<int *>(X) + FB_W;                     // [FB_W] replay path: ((tag + 2) << 1) | locked per sample
-    static_assert(2 * FB_W * 4 <= sizeof(float2) * fftc::LDS_N, "er and pk live in the convolution buffer");
-    const int ch = blockIdx.x;
-    if (ch >= C) return;
-    WG wg; wg.L = &lds; wg.tid = threadIdx.x; wg.lane = threadIdx.x & 63; wg.wv = threadIdx.x >> 6; wg.sl = 0;
-    const int tid = wg.tid, lane = wg.lane;
-    const ChanParams &P = B.params[ch];
-    ChanState *st = B.state + ch;
-    const int w = A.w;
-    const int j0 = tid * FB_K;
-    bool ok[FB_K];
-#pragma unroll
-    for (int i = 0; i < FB_K; i++) ok[i] = j0 + i < w;
-    const bool owner = (w - 1 >= j0) && (w - 1 < j0 + FB_K);
-    const int il = w - 1 - j0;
-    const int lin = B.lin_rows;
-    const size_t lrow = (size_t)ch * lin + A.seg0 + j0;
-    const bool dbg_on = (B.dbg != nullptr) && (tid == 0);
-    unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
-    const bool stereo_possible = P.fm_mode != 2, auto_mono = P.auto_mono != 0, pss_active = P.pss_active != 0;
-    const int calls_before = A.first ? 0 : st->pss_call_total;
-    const int ix = (SINCOS_N >> 1) - st->my_count - A.seg0 - j0;    // this thread's index of the metaData snapshot sample (see stageb_pll_kernel), if 0 .. K-1
-    const int jxs = (SINCOS_N >> 1) - st->my_count - A.seg0;        // ... segment-relative
-    // this thread's samples out of the first kernel
-    float dem[FB_K], cur[FB_K];
-#pragma unroll
-    for (int i = 0; i < FB_K; i++) { dem[i] = ok[i] ? B.w_dem[lrow + i] : 0.f; cur[i] = ok[i] ? B.w_cur[lrow + i] : 0.f; }
-    const unsigned lmask = B.w_lockm[(size_t)ch * B.lockm_stride + (size_t)(A.seg0 / FB_K) + tid];
-
-    // ================= PSS errors of the calls this segment can make: err[m] = Re (y) Im (y), y = low-pass of the s ring
-    // (stereo-separation.cpp:60-83), m = call index within the segment, into lds.er =================
-    if (stereo_possible && pss_active) {
-        if (T.pss_hs) {
-            const int64_t i0 = st->pss_count + calls_before;                         // call index of the segment's first output
-            const float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
-            float2 a[8];
-#pragma unroll
-            for (int p = 0; p < 8; p++) {      // window entry n <-> s index i0 - (1753 + 294) + n; entries past the segment's need are padding
-                const int n = tid + fftc::T * p;
-                const int64_t idx = i0 - (PSS_DELAY + PSS_TAPS - 1) + n;
-                a[p] = (n < w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & G.sring_mask] : make_float2(0.f, 0.f);
-            }
-            fftc::convolve(tid, a, X, T.fft_w, T.pss_hs);
-            __syncthreads();                   // (er overlays the buffer the last stage was read from)
-#pragma unroll
-            for (int p = 0; p < 8; p++) {
-                const int m = tid + fftc::T * p - (PSS_TAPS - 1);
-                if (m >= 0 && m < FB_W) er[m] = a[p].x * a[p].y;
-            }
-        } else {                               // (FMX_PSS_FIR=direct: pssfir_seg_kernel ran in front of this kernel)
-            const float *errc = B.w_err + (size_t)ch * FB_W;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) er[j0 + i] = errc[j0 + i];
-        }
-    }
-    __syncthreads();
-    SB_TICK(0);
-
-    // ================= the PSS call index of every sample (fm-processor.cpp:704-718) =================
-    bool locked[FB_K]; int tag[FB_K];
-    int ncalls;
-    {
-        int ncall_t = 0;
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) {
-            locked[i] = (lmask >> i) & 1u;
-            const bool branch = stereo_possible && (locked[i] || !auto_mono);
-            tag[i] = branch ? (pss_active ? 0 : -1) : -2;
-            ncall_t += (ok[i] && branch && pss_active) ? 1 : 0;
-        }
-        int preC, dm1, dm2;
-        wg.excl_add_max_i(ncall_t, 0, &preC, &ncalls, &dm1, &dm2);
-        int c = preC;
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) if (tag[i] == 0) { tag[i] = ok[i] ? c : -2; c += ok[i] ? 1 : 0; }    // index of the call within the segment
-    }
-
-    // ================= PSS integrator (stereo-separation.cpp:84-109, fm-processor.cpp:699-718) =================
-    float used[FB_K];                                            // pilotDelayPSS as used by each sample
-    {
-        PssSt s;
-        s.acc = st->pss_acc; s.mean = st->pss_mean; s.pdp = st->pilot_delay_pss;
-        s.lock_cnt = st->pss_lock_cnt; s.unlock_cnt = st->pss_unlock_cnt; s.minimized = st->pss_minimized != 0;
-        if ((P.actions & (ACT_TRIGGER_FREQ | ACT_RESTART_PSS)) && A.first) {
-            // triggerFrequencyChange / restartPssAnalyzer fm-processor.cpp:849-860
-            s.pdp = 0.f; s.acc = 0.f; s.minimized = false; s.mean = 0.f; s.lock_cnt = 0; s.unlock_cnt = 0;
-            if ((P.actions & ACT_TRIGGER_FREQ) && tid == 0) st->fade_start_frame = G.M0;
-        }
-        const float alpha = T.pss_alpha, la = T.pss_lock_alpha, keep = 1.0f - la;
-        const float c4 = 0.785398185253143310546875f;
-        const bool pss_on = stereo_possible && pss_active;
-        float err[FB_K];
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) err[i] = (pss_on && tag[i] >= 0) ? er[tag[i]] : 0.f;
-        // classification (the same for every thread)
-        int firstU = -0x7fffffff - 1, firstZ = -0x7fffffff - 1, anyl = 0, alll = 0;            // as maxima of negated indices
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) if (ok[i]) {
-            if (!locked[i]) { const int v = -(j0 + i); firstU = v > firstU ? v : firstU; alll = 1; }
-            else anyl = 1;
-            if (tag[i] == -1) { const int v = -(j0 + i); firstZ = v > firstZ ? v : firstZ; }
-        }
-        wg.reduce_max4(firstU, firstZ, anyl, alll);              // alll = 1 when some sample is NOT locked
-        const bool all_locked = alll == 0;
-        const bool steady = pss_on && ncalls == w && all_locked && ((s.minimized ? s.unlock_cnt : s.lock_cnt) + w <= 3 * SINCOS_N);
-        const bool nocall = ncalls == 0;
-        PssSt e = s;                                             // state behind the segment
-        if (steady) {
-            const bool mz = s.minimized;
-            float xa[FB_K], er10[FB_K];
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) { er10[i] = mz ? err[i] : err[i] * 10.0f; xa[i] = alpha * er10[i]; }
-            // accPhaseShift: fixed point of the exact f32 trajectory a[j] = value in front of sample j
-            float a[FB_K];
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) a[i] = s.acc;
-            const double a0 = (double)s.acc;
-            float aend = s.acc;
-            for (int it = 0; ; it++) {
-                double d[FB_K], ex[FB_K], tot = 0.0;
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) {
-                    const float na = fminf(fmaxf(a[i] + xa[i], -c4), c4);
-                    d[i] = ok[i] ? (double)na - (double)a[i] : 0.0;
-                    ex[i] = tot; tot += d[i];
-                }
-                double total; bool any;
-                const double pre = wg.excl_add_d(tot, &total, false, &any);
-                bool changed = false;
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) {
-                    const float na = (float)(a0 + (pre + ex[i]));
-                    changed = changed || (ok[i] && __float_as_int(na) != __float_as_int(a[i]));
-                    a[i] = na;
-                }
-                aend = (float)(a0 + total);
-                if (lane == 0) lds.wi[wg.sl][wg.wv][0] = 0;
-                if (__any(changed) && lane == 0) lds.wi[wg.sl][wg.wv][0] = 1;
-                __syncthreads();
-                const int anych = lds.wi[wg.sl][0][0] | lds.wi[wg.sl][1][0] | lds.wi[wg.sl][2][0] | lds.wi[wg.sl][3][0];
-                wg.sl ^= 1;
-                if (!anych || it == PSS_MAX_ROUNDS - 1) { if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 9] += it + 1; B.dbg[(size_t)ch * DBG_SLOTS + 12] += 1; } break; }
-            }
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) used[i] = (j0 + i == 0) ? s.pdp : a[i];
-            // mean_error (1 / rate smoothing) and the "minimised" bookkeeping in closed form
-            const DecayW dw = make_decay(T.pssmean_l2, lane);
-            float Lt = 0.f;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) Lt = (ok[i] ? la * er10[i] : 0.f) + Lt * keep;
-            float mean = wg.decay_incoming(Lt, s.mean, dw);
-            int lastS = -1, lastN = -1, d3 = 0, d4 = 0; float mean_end = 0.f;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) {
-                mean = la * er10[i] + mean * keep;
-                if (ok[i]) { if (fabsf(mean) < 0.001f) lastS = j0 + i; else lastN = j0 + i; }
-                if (i == il) mean_end = mean;
-                if (i == ix && ok[i]) meta_snapshot(st, P, fminf(fmaxf(a[i] + xa[i], -c4), c4), mean, mz, true);   // (mz: no flip inside a steady segment)
-            }
-            wg.reduce_max4(lastS, lastN, d3, d4);
-            if (owner) lds.wf[0][0][3] = mean_end;               // (slot-free word: read after the next barrier below)
-            __syncthreads();
-            e.mean = lds.wf[0][0][3];
-            e.acc = aend; e.pdp = aend; e.minimized = mz;
-            const bool all_small = lastN < 0, any_small = lastS >= 0;
-            if (mz) { e.lock_cnt = all_small ? s.lock_cnt : 0; e.unlock_cnt = any_small ? (w - 1 - lastS) : s.unlock_cnt + w; }
-            else { e.lock_cnt = all_small ? s.lock_cnt + w : (w - 1 - lastN); e.unlock_cnt = any_small ? 0 : s.unlock_cnt; }
-        } else if (nocall) {
-            // nobody calls process_sample: an unlocked sample clears everything, a stereo sample without PSS clears pilotDelayPSS
-            const int fu = (firstU == -0x7fffffff - 1) ? 0x7fffffff : -firstU, fz = (firstZ == -0x7fffffff - 1) ? 0x7fffffff : -firstZ;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) used[i] = (j0 + i >= fu || j0 + i > fz) ? 0.f : s.pdp;
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) if (i == ix && ok[i]) {
-                const bool cleared = j0 + i >= fu;
-                meta_snapshot(st, P, (cleared || j0 + i >= fz) ? 0.f : s.pdp, cleared ? 0.f : s.mean, cleared ? false : s.minimized, locked[i]);
-            }
-            if (fu != 0x7fffffff) { e.pdp = 0.f; e.acc = 0.f; e.mean = 0.f; e.minimized = false; e.lock_cnt = 0; e.unlock_cnt = 0; }
-            else if (fz != 0x7fffffff) e.pdp = 0.f;
-        } else {
-            // replay (lock transitions inside a PSS segment, a counter within a segment of its 3 s threshold)
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) if (ok[i]) { pk[j0 + i] = ((tag[i] + 2) << 1) | (locked[i] ? 1 : 0); er[j0 + i] = err[i]; }
-            __syncthreads();
-            if (B.dbg && tid == 0) B.dbg[(size_t)ch * DBG_SLOTS + 10] += 1;
-            if (tid == 0) {
-                PssSt r = s;
-                for (int j = 0; j < w; j++) {
-                    const int p = pk[j];
-                    er[j] = pss_step(r, alpha, la, keep, (p & 1) != 0, (p >> 1) - 2, er[j]);
-                    if (j == jxs) meta_snapshot(st, P, r.pdp, r.mean, r.minimized, (p & 1) != 0);
-                }
-                lds.wf[0][0][3] = r.acc; lds.wf[0][1][3] = r.mean; lds.wf[0][2][3] = r.pdp;
-                lds.wi[0][0][3] = r.lock_cnt; lds.wi[0][1][3] = r.unlock_cnt; lds.wi[0][2][3] = r.minimized ? 1 : 0;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < FB_K; i++) used[i] = ok[i] ? er[j0 + i] : 0.f;
-            e.acc = lds.wf[0][0][3]; e.mean = lds.wf[0][1][3]; e.pdp = lds.wf[0][2][3];
-            e.lock_cnt = lds.wi[0][0][3]; e.unlock_cnt = lds.wi[0][1][3]; e.minimized = lds.wi[0][2][3] != 0;
-            __syncthreads();
-        }
-        if (tid == 0) {
-            st->pss_acc = e.acc; st->pss_mean = e.mean; st->pilot_delay_pss = e.pdp;
-            st->pss_lock_cnt = e.lock_cnt; st->pss_unlock_cnt = e.unlock_cnt; st->pss_minimized = e.minimized ? 1 : 0;
-        }
-    }
-
-    SB_TICK(1);
-    // ================= 38 kHz mix, PSS input, stereo matrix (fm-processor.cpp:707-730, 517-549) =================
-    float2 x[FB_K];
-    {
-        constexpr double INV2PI = 1.0 / FMX_2PI;
-        const int ssel = P.sound_sel, fmode = P.fm_mode; const float pano = P.panorama;
-        const int64_t ic = st->pss_count + calls_before;         // call index of the segment's first call
-        float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
-        float diffv[FB_K];
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) {
-            // phaseforLRDiff fm-processor.cpp:707-714: 2 (currentPilotPhase + pi/4) - pilotDelayPSS lies in (0, 4 pi + 2.4), so the
-            // "< -2 pi" branch never runs and fmod (., 2 pi) is the fraction of the turn count
-            float cc = pi_constrain_near(cur[i]);
-            if (__any(!(cur[i] > -6.f && cur[i] < 12.f))) cc = pi_constrain(cur[i]);    // (see the pilot PLL: corrections of more than a turn)
-            const float p = (float)(2 * ((double)cc + FMX_PI_4 + 0) - (double)used[i]);
-            const double u = __builtin_amdgcn_fract((double)p * INV2PI);
-            int idx = (int)(u * (double)SINCOS_N);               // SinCos::getComplex sincos.cpp:93-97
-            idx = idx >= SINCOS_N ? SINCOS_N - 1 : idx;
-            float2 e;
-            sincos_idx_f32(idx, &e.y, &e.x);
-            const float sn = e.y;                                // S_LEFTminusRIGHT_Test mixes with the sine
-            float2 audio = make_float2(dem[i], 0.f);
-            if (tag[i] != -2) {
-                if (tag[i] >= 0 && ok[i]) sring[(ic + tag[i]) & G.sring_mask] = make_float2(e.x * dem[i], e.y * dem[i]);
-                const float lut = (ssel == 6) ? sn : e.x;
-                audio.y = 2.0f * (lut * dem[i]);                 // (float)(2.0 * lut * demod): one rounding of the exact product either way
-            }
-            const float sumLR = audio.x, diffLR = audio.y;
-            const float dw = diffLR * (fmode == 1 ? pano : 1.0f);
-            const float left = sumLR + dw, right = sumLR - dw;
-            float2 o;
-            switch (ssel) {
-            default:
-            case 0: o = make_float2(left, right); break;
-            case 1: o = make_float2(right, left); break;
-            case 2: o = make_float2(left, left); break;
-            case 3: o = make_float2(right, right); break;
-            case 4: o = make_float2(sumLR, sumLR); break;
-            case 5: case 6: o = make_float2(dw, dw); break;
-            }
-            x[i] = ok[i] ? o : make_float2(0.f, 0.f);
-            diffv[i] = audio.y;
-        }
-        // scope tap (fmx_get_tap): channel-major rows of this call
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) if (ok[i]) B.w_diff[lrow + i] = diffv[i];
-    }
-
-    SB_TICK(2);
-    // ================= de-emphasis (fm-processor.cpp:594-595) into the d ring =================
-    {
-        const float a = P.deemph_alpha;
-        const DecayW dw = make_decay(P.deemph_l2, lane);
-        float Ll = 0.f, Lr = 0.f;
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) { Ll = (x[i].x - Ll) * a + Ll; Lr = (x[i].y - Lr) * a + Lr; }
-        float yl = wg.decay_incoming(Ll, st->de_l, dw);
-        float yr = wg.decay_incoming(Lr, st->de_r, dw);
-        const int64_t dmask = G.dring_mask;
-        float2 *dr = B.dring + (size_t)ch * (dmask + 1);
-        float el = 0.f, er = 0.f;
-#pragma unroll
-        for (int i = 0; i < FB_K; i++) {
-            yl = (x[i].x - yl) * a + yl;
-            yr = (x[i].y - yr) * a + yr;
-            if (ok[i]) dr[(G.J0 + A.seg0 + j0 + i) & dmask] = make_float2(yl, yr);
-            if (i == il) { el = yl; er = yr; }
-        }
-        if (owner) { st->de_l = el; st->de_r = er; }
-    }
-
-    SB_TICK(3);
-    // ================= bookkeeping behind the segment =================
-    __syncthreads();                                             // every thread has read what it needs of the channel state
-    if (tid == 0) {
-        const int tot = calls_before + ncalls;
-        if (!A.last) st->pss_call_total = tot;
-        else {
-            // metaData: the snapshot behind sample fmRate / 2 - myCount of the call was stored sample-exactly by the two kernels
-            // (meta_snapshot above; lock strength / flag / demodulator DC in stageb_pll_kernel); the RF DC level moves by 1e-7 of
-            // its distance per input sample and is taken here, at the end of that call
-            __threadfence_block();
-            int cnt = st->my_count + (int)(G.J1 - G.J0);
-            if (cnt > (SINCOS_N >> 1)) {
-                const float dcabs = (float)sqrt((double)st->dc_re * (double)st->dc_re + (double)st->dc_im * (double)st->dc_im);
-                st->meta_dc_rf = P.dc_remove ? 20 * log10f(dcabs + 1.0f / 32768) : (float)-99.99;
-                cnt -= (SINCOS_N >> 1) + 1;
-            }
-            st->my_count = cnt;
-            st->pss_count += tot;                                // the PSS filter time base advances by this call's process_sample calls
-            st->pss_call_total = 0;
-        }
-    }
-    SB_TICK(4);
-    if (dbg_on) {
-        for (int k = 0; k < 5; k++) B.dbg[(size_t)ch * DBG_SLOTS + 20 + k] += dbg_acc[k];
-        B.dbg[(size_t)ch * DBG_SLOTS + 13] = __float_as_uint(st->pil_phase); B.dbg[(size_t)ch * DBG_SLOTS + 14] = __float_as_uint(st->pil_lock);   // (diagnostics: state behind the segment)
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1222,41 +503,8 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 }
                 return phase;
             };
-            // the loop sample by sample: one thread, operands through LDS (the convolution's buffer is free here); leaves the phases in ph
-            auto sequential = [&](bool count) {
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) if (i < nv) er[j0 + i] = dem[i];
-                __syncthreads();
-                if (tid == 0) {
-                    float phase = x0;
-                    for (int j = 0; j < w; j++) {
-                        const float d5 = 5 * er[j];
-                        er[FB_W + j] = phase;
-                        int idx = (int)((double)phase * SC64);
-                        idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
-                        const float val = (phase + (d5 * sin_idx_f32(idx)) * gain) + omega;
-                        phase = (val >= 0.f && val < P32) ? val : pi_constrain(val);
-                    }
-                    if (count) st->pll_replays += 1;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) ph[i] = (i < nv) ? er[FB_W + j0 + i] : 0.f;
-                __syncthreads();
-            };
-            auto for_each_eval = [&](float *nx) {
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) eval(i, ph[i], &nx[i]);
-            };
-            if (P.pll_seq) {
-                float nx[FB_K];
-                sequential(false);
-                for_each_eval(nx);
-#pragma unroll
-                for (int i = 0; i < FB_K; i++) if (i == il) nxl = nx[i];
-            } else {
-            {   // ---- the first guess
+            bool seq = P.pll_seq != 0;                           // this pass evaluates the loop sample by sample (the same in every thread)
+            if (!seq) {   // ---- the first guess
                 float rv[FB_K];                                  // the ramp x0 + j omega in turns, fraction
                 const double tb = ((double)x0 + (double)j0 * (double)omega) * (1.0 / FMX_2PI);
                 const float tbf = (float)(tb - floor(tb));
@@ -1265,7 +513,6 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 float cor[FB_K];                                 // sum of the corrections in front of each sample (rad)
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) cor[i] = 0.f;
-#pragma unroll
                 for (int round = 0; round < 2; round++) {
                     float c[FB_K], run = 0.f;
 #pragma unroll
@@ -1286,9 +533,33 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             // guess (what Picard's iteration would take), S = the Newton correction, S[j+1] = (1 + c[j]) S[j] + c[j] d[j] with
             // c = g cos x, d = x0 + P - x -- a scan of affine maps in f32 (S is small).  One rounding per sample, none accumulated:
             // an update d -> x + d in f32 would leave half an ulp of residual at EVERY step, which the loop integrates to 1e-5 rad.
+            // (One loop for both ways, so that the step's evaluation exists once in the code.)
             bool open_ = true;                                   // this thread's last update was not small yet
             const double x0d = (double)x0;
             for (int it = 0; ; it++) {
+                if (seq) {
+                    // the loop sample by sample: one thread, operands through LDS (the convolution's buffer is free here)
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) if (i < nv) er[j0 + i] = dem[i];
+                    __syncthreads();
+                    if (tid == 0) {
+                        float phase = x0;
+                        for (int j = 0; j < w; j++) {
+                            const float d5 = 5 * er[j];
+                            er[FB_W + j] = phase;
+                            int idx = (int)((double)phase * SC64);
+                            idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+                            const float val = (phase + (d5 * sin_idx_f32(idx)) * gain) + omega;
+                            phase = (val >= 0.f && val < P32) ? val : pi_constrain(val);
+                        }
+                        if (it > 0) st->pll_replays += 1;        // (a Newton iteration that did not settle)
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) ph[i] = (i < nv) ? er[FB_W + j0 + i] : 0.f;
+                    __syncthreads();
+                }
                 double e[FB_K], tot = 0.0;
                 float nx[FB_K];
 #pragma unroll
@@ -1299,27 +570,31 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     e[i] = tot;
                     tot += (i < nv) ? (double)nx[i] - (double)phase : 0.0;
                 }
-                // the increments' prefix sums; with the same barrier: has the previous round's update been small everywhere?
-                const double inc = wscan_add_d(tot);
-                {
-                    const int wopen = __any(open_) ? 1 : 0;
-                    if (lane == 63) lds.wd[wg.sl][wg.wv][0] = inc;
-                    if (lane == 0) lds.wi[wg.sl][wg.wv][1] = wopen;
-                }
-                __syncthreads();
-                const int anyopen = lds.wi[wg.sl][0][1] | lds.wi[wg.sl][1][1] | lds.wi[wg.sl][2][1] | lds.wi[wg.sl][3][1];
-                double pre = inc - tot;
+                int anyopen = 0;
+                double pre = 0.0;
+                if (!seq) {
+                    // the increments' prefix sums; with the same barrier: has the previous round's update been small everywhere?
+                    const double inc = wscan_add_d(tot);
+                    {
+                        const int wopen = __any(open_) ? 1 : 0;
+                        if (lane == 63) lds.wd[wg.sl][wg.wv][0] = inc;
+                        if (lane == 0) lds.wi[wg.sl][wg.wv][1] = wopen;
+                    }
+                    __syncthreads();
+                    anyopen = lds.wi[wg.sl][0][1] | lds.wi[wg.sl][1][1] | lds.wi[wg.sl][2][1] | lds.wi[wg.sl][3][1];
+                    pre = inc - tot;
 #pragma unroll
-                for (int v = 0; v < 3; v++) pre += (v < wg.wv) ? lds.wd[wg.sl][v][0] : 0.0;
-                wg.sl ^= 1;
-                if (!anyopen || it == PLL_NEWTON_MAX) {
-                    if (anyopen) { sequential(true); for_each_eval(nx); }      // not settled: sample by sample, evaluated once more
+                    for (int v = 0; v < 3; v++) pre += (v < wg.wv) ? lds.wd[wg.sl][v][0] : 0.0;
+                    wg.sl ^= 1;
+                }
+                if (!anyopen) {
                     // (the evaluation just made is the final one)
 #pragma unroll
                     for (int i = 0; i < FB_K; i++) if (i == il) nxl = nx[i];
-                    if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; }
+                    if (B.dbg && tid == 0 && !P.pll_seq) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; }
                     break;
                 }
+                if (it == PLL_NEWTON_MAX - 1) { seq = true; continue; }       // not settled: sample by sample
                 // ---- the Newton correction
                 float d[FB_K], c[FB_K];
 #pragma unroll
@@ -1353,7 +628,6 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     S = fmaf(1.f + c[i], S, c[i] * d[i]);
                 }
                 open_ = !(dmax < PLL_NEWTON_TOL);
-            }
             }
             // (cur / osc are those of the last evaluation: of the trajectory the iteration ended on)
             if (owner) { const float xe = (nxl >= 0.f && nxl < P32) ? nxl : 0.f; cy.x0 = xe; if (lastseg) st->pil_phase = xe; }
@@ -1775,22 +1049,10 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
 #undef B
 #undef G
 
-// The fused schedule: the PLL kernel for the whole call, then per segment the PSS kernel (whose errors need the s-ring entries
-// the segment in front of it wrote).
 void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s) {
-    const int64_t nj = G.J1 - G.J0;
-    if (nj <= 0) return;
-    static const bool split = getenv("FMX_STAGE_B") && std::string(getenv("FMX_STAGE_B")) == "split";     // (A/B runs: the two-kernel schedule)
-    if (!split && T.pss_hs) { StageBArgs A; A.T = T; A.B = B; A.G = G; A.C = C;
-                           hipLaunchKernelGGL(stageb_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED(); return; }
-    hipLaunchKernelGGL(stageb_pll_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, T, B, G, C); FMX_LAUNCHED();
-    for (int64_t seg0 = 0; seg0 < nj; seg0 += FB_W) {
-        SegArgs A;
-        A.seg0 = (int)seg0; A.w = (int)((nj - seg0) < FB_W ? (nj - seg0) : FB_W);
-        A.first = seg0 == 0 ? 1 : 0; A.last = (seg0 + FB_W >= nj) ? 1 : 0;
-        if (!T.pss_hs) { hipLaunchKernelGGL(pssfir_seg_kernel, dim3((unsigned)((A.w + SF_TILE - 1) / SF_TILE), (unsigned)C), dim3(64), 0, s, T, B, G, C, A); FMX_LAUNCHED(); }
-        hipLaunchKernelGGL(stageb_pss_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, T, B, G, C, A); FMX_LAUNCHED();
-    }
+    if (G.J1 - G.J0 <= 0) return;
+    StageBArgs A; A.T = T; A.B = B; A.G = G; A.C = C;
+    hipLaunchKernelGGL(stageb_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
 }
 
 }  // namespace fmx
