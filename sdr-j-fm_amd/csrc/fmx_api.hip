@@ -54,6 +54,7 @@ struct ProfRec { hipEvent_t e[4]; int64_t in_samples, ch_samples; int n; };
 struct fmx_handle_s {
     fmx_config cfg{};
     int channels = 0, streams = 0;
+    bool streams_private = false;                                    // no two channels listen to the same stream
     hipStream_t stream = nullptr;
     hipStream_t s_side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the stage-B chunk pipeline
     hipStream_t s_r = nullptr, s_t = nullptr;          // persistent layout of stage B: CU-masked streams
@@ -557,7 +558,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     CallGeom G{};
     frames_geom(h, n, &G);
     G.ring_mask = h->ring - 1; G.dring_mask = h->dring - 1; G.sring_mask = h->sring - 1;
-    G.input_rate = h->cfg.inputRate; G.pitch = h->pitch; G.pad_ = 0; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
+    G.input_rate = h->cfg.inputRate; G.pitch = h->pitch; G.streams_private = h->streams_private ? 1 : 0; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
     G.iq_format = fmt; G.iq_scale = (fmt == 3) ? 1.0f / s16_den : 1.0f / 128.0f;
     const int64_t frames = conv2_out(h, G.M1) - conv2_out(h, G.M0);
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
@@ -730,6 +731,11 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         p.pll_seq = h->channels <= PLL_SEQ_AUTO_MAX ? 1 : 0;
         p.squelch_mode = 0; p.squelch_thr = std::pow(10.0f, (float)(1 - 80) / 30.0f); p.squelch_nthr = 1.0f - 1 / 100.0f;
         refresh_derived(h, c);
+    }
+    {
+        std::vector<int> users((size_t)h->streams, 0);
+        h->streams_private = true;
+        for (auto &p : h->params) if (++users[(size_t)p.stream] > 1) h->streams_private = false;
     }
     {
         hipDeviceProp_t dp;

@@ -30,7 +30,16 @@ constexpr int WSAMP = WCOLS * DECIM;           // 1536 input samples per wave ti
 constexpr int XCOLS = HL + WCOLS;              // 152 columns in a wave's LDS image
 constexpr int SPT = 2 * DECIM;                 // 24 samples per lane per tile (two adjacent columns)
 constexpr int FCOLS = 8;                       // adjacent outputs per lane in the FIR phase
-constexpr int DCV_N = 1024;                    // ring of RfDC column-boundary values: eight tiles deep (the four waves are never that far apart)
+#ifndef FMX_NW
+#define FMX_NW 4                               /* waves (= tile images) per workgroup */
+#endif
+constexpr int NW = FMX_NW, NTHR = 64 * NW;
+#ifndef FMX_AUX_N
+#define FMX_AUX_N LO_LDS_MAX
+#endif
+constexpr int AUX_N = FMX_AUX_N;               // entries of the LO period table / the RfDC ring (one LDS array, see the kernel)
+static_assert(AUX_N <= LO_LDS_MAX && (AUX_N & (AUX_N - 1)) == 0, "power of two, at most what the host tabulates");
+constexpr int DCV_N = AUX_N;                   // ring of RfDC column-boundary values: several tiles deep (the waves of a workgroup are never that far apart)
 constexpr int RPQ = DECIM / 4;                 // polyphase rows per lane quarter in the FIR phase
 
 // LDS image of a wave tile: X[r][C], r = sample index mod 12, C = column (0..23 history, 24..151 fresh).  The unit of
@@ -66,8 +75,8 @@ __device__ __forceinline__ Aff aff_then(const Aff &f, const Aff &g) {      // ap
 /* LDS allows two workgroups per CU = two waves per SIMD: say so, or the register allocator aims at four (128 VGPRs, spills) */
 #define FMX_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
-#ifndef FMX_NT_LOADS
-#define FMX_NT_LOADS 0   /* 1: the tile loads as nontemporal loads (A/B builds) */
+#ifndef FMX_WG_PER_CU
+#define FMX_WG_PER_CU 2
 #endif
 #ifndef FMX_WAVE_SHR
 #define FMX_WAVE_SHR 1   /* 0: ds_bpermute (__shfl_up) for the one-lane shift of the scan (A/B builds) */
@@ -121,17 +130,21 @@ __device__ __forceinline__ void fir_rows(const float4 *__restrict__ X4, int cg, 
 // FMT: fmx_iq_format of the input (include/fmx.h).  Raw integer samples are converted while they are loaded --
 // (u8 - 127) / 128, s8 / 128, s16 / denominator, all exact as in the reference's device handlers
 // (rtlsdr-handler.cpp:291, hackrf-handler.cpp:364, lime-handler.cpp:250) -- into the same register layout.
-template <int FMT>
-__global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
+// NTL: the tile loads are nontemporal -- every sample of a stream that only this channel listens to is read exactly once, so it
+// should not displace the tables and rings in L2 / MALL (1 % of the launch time at 4096 channels); shared streams keep the cache.
+template <int FMT, bool NTL>
+__global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
                                                        const void *__restrict__ iq_raw) {
     constexpr int BPS = (FMT == 0) ? 8 : (FMT == 3 ? 4 : 2);          // bytes per complex sample
-    __shared__ __attribute__((aligned(16))) float4 Xall[4][XUNITS];       // one image per wave (62208 B)
+    __shared__ __attribute__((aligned(16))) float4 Xall[NW][XUNITS];      // one image per wave (15552 B each)
     __shared__ __attribute__((aligned(16))) float sT[A_TAPS_DEV];          // the channel's tap set Trd[r][d]
-    __shared__ float2 sLO[LO_LDS_MAX];                                     // one period of the LO (when the channel's lo has a short one)
-    __shared__ float2 dcv[DCV_N];                                          // RfDC in front of call-relative column q at [q & (DCV_N - 1)] (channels without LO)
+    // a channel either mixes with an LO (one period of it here, when it has a short one) or takes its RF DC removal behind the FIR
+    // (RfDC in front of call-relative column q at [q & (DCV_N - 1)]): never both, one array
+    __shared__ float2 aux[AUX_N];
+    float2 *const sLO = aux, *const dcv = aux;
     __shared__ float carry[8][2];                                          // DC state after tile ti, slot = ti & 7
     __shared__ int carry_seq;                                              // tiles whose carry is published
-    __shared__ int hist_seq[4], free_seq[4];                               // per wave image: history of tile (n-1) is in / tile (n-1) is done
+    __shared__ int hist_seq[NW], free_seq[NW];                               // per wave image: history of tile (n-1) is in / tile (n-1) is done
 
     const int ch = blockIdx.x;
     const int t = threadIdx.x;
@@ -158,8 +171,8 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
     const int NT = qb / WCOLS + 1;                    // wave tiles in this call
     const int zr0 = (int)(qa & (int64_t)G.ring_mask);
 
-    for (int i = t; i < A_TAPS_DEV; i += 256) sT[i] = T.front_taps[(size_t)P.front_set * A_TAPS_DEV + i];
-    if (t == 0) { carry_seq = 0; for (int i = 0; i < 4; i++) { hist_seq[i] = 0; free_seq[i] = 0; } }
+    for (int i = t; i < A_TAPS_DEV; i += NTHR) sT[i] = T.front_taps[(size_t)P.front_set * A_TAPS_DEV + i];
+    if (t == 0) { carry_seq = 0; for (int i = 0; i < NW; i++) { hist_seq[i] = 0; free_seq[i] = 0; } }
     // ---- history -> the image of tile 0 (wave 0): columns qa-24 .. qa-1 at C 0..23, partial column qa at C 24
     const bool hist_convert = (P.lo_freq != 0) && (T.lo_table != nullptr) && (st->hist_fmt == 0) && (P.dc_remove != 0 || P.att_l != 1.0f || P.att_r != 1.0f);
     if (wave == 0) {
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
         }
     }
     // RfDC in front of the 13 columns before this call's first column and of that column itself (ring slots -13 .. 0)
-    if (t < 14) dcv[(t - 13) & (DCV_N - 1)] = B.dcv_hist[(size_t)ch * DCV_SAVE + t];
+    if (t < 14 && !(P.lo_freq != 0 && T.lo_table != nullptr)) dcv[(t - 13) & (DCV_N - 1)] = B.dcv_hist[(size_t)ch * DCV_SAVE + t];
     // per-channel state is read by every wave BEFORE the barrier (the wave that ends the call rewrites it)
     const int lo_phase0 = st->lo_phase;
     const bool dc_rst = (P.actions & ACT_DC_RESET) != 0;          // setDCRemove zeroes RfDC (:922-925)
@@ -189,8 +202,8 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
     //      (channels on a raster: 200 kHz at 2.304 MS/s gives p = 288) the p table entries the call will use sit in LDS,
     //      sLO[m] = T[(P0 - m lo) mod R] with m = (i + 1) mod p, instead of 24 scattered reads of the 18 MB table per lane
     //      and tile
-    const int lo_per = (P.lo_freq != 0 && T.lo_table != nullptr) ? P.lo_period : 0;
-    for (int m = t; m < lo_per; m += 256) {
+    const int lo_per = (P.lo_freq != 0 && T.lo_table != nullptr && P.lo_period <= AUX_N) ? P.lo_period : 0;
+    for (int m = t; m < lo_per; m += NTHR) {
         long long ph = ((long long)lo_phase0 - (long long)m * (long long)P.lo_freq) % (long long)G.input_rate;
         if (ph < 0) ph += G.input_rate;
         sLO[m] = T.lo_table[ph];
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
         if (i < (lane & 31) + 1) mB *= m1;
     }
     // history hand-off: the 24 newest columns of this image go straight into the next wave's image (144 float4 units)
-    float4 *Xn = Xall[(wave + 1) & 3];
+    float4 *Xn = Xall[(wave + 1) % NW];
     int ho_src[3], ho_dst[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -269,17 +282,15 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
     auto load_tile = [&](int ti) {
         const int wbase = ti * WSAMP;                             // index of the tile's first sample
         if (aligned16 && wbase >= g0 && wbase + WSAMP <= gend) {
-            if (FMT == 0) {
-#if FMX_NT_LOADS
+            if (FMT == 0 && NTL) {
                 typedef float v4f_ __attribute__((ext_vector_type(4)));
                 const v4f_ *p4 = reinterpret_cast<const v4f_ *>(in + (wbase - g0));
 #pragma unroll
                 for (int k = 0; k < SPT / 2; k++) { const v4f_ v = __builtin_nontemporal_load(p4 + lane + 64 * k); raw[k] = make_float4(v.x, v.y, v.z, v.w); }
-#else
+            } else if (FMT == 0) {
                 const float4 *p4 = reinterpret_cast<const float4 *>(in + (wbase - g0));
 #pragma unroll
                 for (int k = 0; k < SPT / 2; k++) raw[k] = p4[lane + 64 * k];
-#endif
             } else if (FMT == 1 || FMT == 2) {
                 const uint32_t *p1 = reinterpret_cast<const uint32_t *>(inb + (size_t)(wbase - g0) * BPS);
 #pragma unroll
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
     const int dc_unit = (lane & 3) * XS4 + 3 + (lane >> 2);     // this lane's column pair (24 + 2 l, 24 + 2 l + 1), row 0
     FMX_TICK(0);
 
-    for (int ti = wave; ti < NT; ti += 4) {
+    for (int ti = wave; ti < NT; ti += NW) {
         const int qt = ti * WCOLS;                    // first column of the tile
         const int wbase = qt * 12;
         // ---- scatter the raw samples into the image
@@ -343,9 +354,9 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
         __builtin_amdgcn_wave_barrier();              // LDS operations of one wave complete in order
         // ---- prefetch this wave's next tile as soon as the registers are free: the loads are in flight for the whole
         //      iteration (DC pass, hand-off, FIR), so every wave keeps 12 KB of HBM reads outstanding all the time
-        const bool more = (ti + 4 < NT);
+        const bool more = (ti + NW < NT);
 #if FMX_EARLY_PREFETCH
-        if (more) load_tile(ti + 4);
+        if (more) load_tile(ti + NW);
 #endif
         FMX_TICK(1);
         const int q = qt + 2 * lane;                  // this lane's first column
@@ -523,8 +534,8 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
         // ---- hand the 24 newest processed columns to the next tile: written straight into the next wave's image, once
         //      that wave is done with its previous tile (ti - 3), whose history / partial sums live there
         if (ti + 1 < NT) {
-            const int nw = (wave + 1) & 3;
-            if (ti >= 3) seq_wait(&free_seq[nw], ti - 2);
+            const int nw = (wave + 1) % NW;
+            if (ti + 1 >= NW) seq_wait(&free_seq[nw], ti + 2 - NW);
 #pragma unroll
             for (int k = 0; k < 3; k++)
                 if (k < 2 || lane < DECIM * 12 - 128) Xn[ho_dst[k]] = X4[ho_src[k]];
@@ -535,7 +546,7 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
         if (ti > 0) seq_wait(&hist_seq[wave], ti);
         FMX_TICK(3);
 #if !FMX_EARLY_PREFETCH
-        if (more) load_tile(ti + 4);                  // (A/B build) prefetch only in front of the FIR
+        if (more) load_tile(ti + NW);                 // (A/B build) prefetch only in front of the FIR
 #endif
 
         // ---- polyphase FIR  out[j] = sum_d sum_r Trd[r][d] * X[r][C_j - d]:  lane quarter rq sums rows 3 rq .. 3 rq + 2
@@ -616,10 +627,13 @@ __global__ __launch_bounds__(256, 2) FMX_WAVES_ATTR void front_kernel(DeviceTabl
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s) {
     switch (G.iq_format) {
-    case 1: hipLaunchKernelGGL(front_kernel<1>, dim3(channels), dim3(256), 0, s, T, B, G, iq); break;
-    case 2: hipLaunchKernelGGL(front_kernel<2>, dim3(channels), dim3(256), 0, s, T, B, G, iq); break;
-    case 3: hipLaunchKernelGGL(front_kernel<3>, dim3(channels), dim3(256), 0, s, T, B, G, iq); break;
-    default: hipLaunchKernelGGL(front_kernel<0>, dim3(channels), dim3(256), 0, s, T, B, G, iq); break;
+    case 1: hipLaunchKernelGGL((front_kernel<1, false>), dim3(channels), dim3(NTHR), 0, s, T, B, G, iq); break;
+    case 2: hipLaunchKernelGGL((front_kernel<2, false>), dim3(channels), dim3(NTHR), 0, s, T, B, G, iq); break;
+    case 3: hipLaunchKernelGGL((front_kernel<3, false>), dim3(channels), dim3(NTHR), 0, s, T, B, G, iq); break;
+    default:
+        if (G.streams_private) hipLaunchKernelGGL((front_kernel<0, true>), dim3(channels), dim3(NTHR), 0, s, T, B, G, iq);
+        else hipLaunchKernelGGL((front_kernel<0, false>), dim3(channels), dim3(NTHR), 0, s, T, B, G, iq);
+        break;
     }
 }
 

@@ -204,7 +204,7 @@ struct CallGeom {
     int32_t input_rate;
     int32_t pitch;       // row pitch (elements) of the sample-major work arrays: channels + pad, so that
                          // consecutive rows do not land on the same HBM channel/bank (power-of-two strides do)
-    int32_t pad_;
+    int32_t streams_private;   // every stream is read by exactly one channel (stage A then loads it nontemporally)
     int64_t stream_stride, pcm_stride;   // in complex samples / frames
     int32_t iq_format;   // fmx_iq_format of the input buffer
     float   iq_scale;    // 1/128 (U8, S8) or 1/denominator (S16)
