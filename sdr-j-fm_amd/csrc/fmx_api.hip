@@ -1464,7 +1464,7 @@ int fmx_debug_sync_dump(fmx_handle h, int32_t *out, int32_t capacity, int32_t *n
 }
 
 // diagnostics (not part of include/fmx.h): per-phase shader-cycle counters of front_kernel, summed over channels
-int fmx_debug_phase_cycles(fmx_handle h, int32_t enable, unsigned long long *out /*[DBG_SLOTS = 32], may be null*/) {
+int fmx_debug_phase_cycles(fmx_handle h, int32_t enable, unsigned long long *out /*[DBG_SLOTS = 96], may be null*/) {
     if (!h) return fail(FMX_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());

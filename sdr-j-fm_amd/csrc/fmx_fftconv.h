@@ -25,32 +25,52 @@ namespace fftc {
 constexpr int N = 2048, T = 256, LDS_N = N + 4 * (N >> 5);
 __host__ __device__ __forceinline__ int pad(int i) { return i + 4 * (i >> 5); }
 
-__host__ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__host__ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__host__ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__host__ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj (b)
+// Complex arithmetic on the native two-float vector, so that every operation is ONE packed instruction (v_pk_add_f32,
+// v_pk_mul_f32, v_pk_fma_f32; the (re, im) swaps and sign flips ride on their op_sel / neg modifiers).  The products are fused
+// multiply-adds -- on the host too (make_spectrum runs this very code), whatever -ffp-contract says.
+typedef float cf __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ cf V(float2 a) { cf r; r.x = a.x; r.y = a.y; return r; }
+__host__ __device__ __forceinline__ float2 F(cf a) { return make_float2(a.x, a.y); }
+__host__ __device__ __forceinline__ cf vfma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
+// SIGN j t as t.yx times (-SIGN, SIGN): the swap rides on the instruction's op_sel, so "base + SIGN j t" is one packed fma
+template <int SIGN> __host__ __device__ __forceinline__ cf jsign() { cf m; m.x = (float)-SIGN; m.y = (float)SIGN; return m; }
+template <int SIGN> __host__ __device__ __forceinline__ cf vmulj(cf a) { return a.yx * jsign<SIGN>(); }
+template <int SIGN> __host__ __device__ __forceinline__ cf add_j(cf base, cf t) { return vfma(t.yx, jsign<SIGN>(), base); }    // base + SIGN j t
+template <int SIGN> __host__ __device__ __forceinline__ cf sub_j(cf base, cf t) { return vfma(t.yx, jsign<-SIGN>(), base); }   // base - SIGN j t
+__host__ __device__ __forceinline__ cf vcmul(cf a, cf b) {                  // a b = a.x (b.x, b.y) + a.y (-b.y, b.x)
+    return vfma(a.yy, vmulj<+1>(b), a.xx * b);
+}
+__host__ __device__ __forceinline__ cf vcmulc(cf a, cf b) {                 // a conj (b) = b.x (a.x, a.y) + b.y (a.y, -a.x)
+    return vfma(b.yy, vmulj<-1>(a), b.xx * a);
+}
+__host__ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return F(V(a) + V(b)); }
+__host__ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return F(V(a) - V(b)); }
+__host__ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return F(vcmul(V(a), V(b))); }
+__host__ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return F(vcmulc(V(a), V(b))); }   // a * conj (b)
 // multiplication by SIGN * j
-template <int SIGN> __host__ __device__ __forceinline__ float2 mulj(float2 a) { return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+template <int SIGN> __host__ __device__ __forceinline__ float2 mulj(float2 a) { return F(vmulj<SIGN>(V(a))); }
 
 // X[q] = sum_p a[p] w^(p q), w = exp (SIGN * 2 pi i / 4)
-template <int SIGN> __host__ __device__ __forceinline__ void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
-    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = mulj<SIGN>(csub(a1, a3));
-    a0 = cadd(s02, s13); a2 = csub(s02, s13); a1 = cadd(d02, d13); a3 = csub(d02, d13);
+template <int SIGN> __host__ __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3) {
+    const cf s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13; a2 = s02 - s13; a1 = add_j<SIGN>(d02, d13); a3 = sub_j<SIGN>(d02, d13);
+}
+// the same with a2 standing for SIGN j a2 (the caller's rotation folded in)
+template <int SIGN> __host__ __device__ __forceinline__ void dft4_j2(cf &a0, cf &a1, cf &a2, cf &a3) {
+    const cf s02 = add_j<SIGN>(a0, a2), d02 = sub_j<SIGN>(a0, a2), s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13; a2 = s02 - s13; a1 = add_j<SIGN>(d02, d13); a3 = sub_j<SIGN>(d02, d13);
 }
 // X[q] = sum_p a[p] w^(p q), w = exp (SIGN * 2 pi i / 8), in place
 template <int SIGN> __host__ __device__ __forceinline__ void dft8(float2 *a) {
-    const float R = 0.70710678118654752440f;
-    float2 e0 = cadd(a[0], a[4]), e1 = cadd(a[1], a[5]), e2 = cadd(a[2], a[6]), e3 = cadd(a[3], a[7]);
-    float2 o0 = csub(a[0], a[4]), o1 = csub(a[1], a[5]), o2 = csub(a[2], a[6]), o3 = csub(a[3], a[7]);
-    {   // o_p *= w^p: w = (1 + SIGN j) / sqrt 2, w^2 = SIGN j, w^3 = (-1 + SIGN j) / sqrt 2
-        const float2 j1 = mulj<SIGN>(o1), j3 = mulj<SIGN>(o3);
-        o1 = make_float2((o1.x + j1.x) * R, (o1.y + j1.y) * R);
-        o2 = mulj<SIGN>(o2);
-        o3 = make_float2((j3.x - o3.x) * R, (j3.y - o3.y) * R);
-    }
+    const cf R = {0.70710678118654752440f, 0.70710678118654752440f};
+    cf e0 = V(a[0]) + V(a[4]), e1 = V(a[1]) + V(a[5]), e2 = V(a[2]) + V(a[6]), e3 = V(a[3]) + V(a[7]);
+    cf o0 = V(a[0]) - V(a[4]), o1 = V(a[1]) - V(a[5]), o2 = V(a[2]) - V(a[6]), o3 = V(a[3]) - V(a[7]);
+    // o_p *= w^p: w = (1 + SIGN j) / sqrt 2, w^2 = SIGN j (inside dft4_j2), w^3 = (-1 + SIGN j) / sqrt 2
+    o1 = add_j<SIGN>(o1, o1) * R;
+    o3 = add_j<SIGN>(-o3, o3) * R;
     dft4<SIGN>(e0, e1, e2, e3);          // X[0], X[2], X[4], X[6]
-    dft4<SIGN>(o0, o1, o2, o3);          // X[1], X[3], X[5], X[7]
-    a[0] = e0; a[2] = e1; a[4] = e2; a[6] = e3; a[1] = o0; a[3] = o1; a[5] = o2; a[7] = o3;
+    dft4_j2<SIGN>(o0, o1, o2, o3);       // X[1], X[3], X[5], X[7]
+    a[0] = F(e0); a[2] = F(e1); a[4] = F(e2); a[6] = F(e3); a[1] = F(o0); a[3] = F(o1); a[5] = F(o2); a[7] = F(o3);
 }
 
 // A radix-8 stage works on blocks of length L: the butterfly j of a block (j < S = L / 8) takes the points base + j + p S,
@@ -103,17 +123,33 @@ template <int L> __host__ __device__ __forceinline__ void store_q(const float2 *
 
 // The radix-4 stage across a quad: lane j (= t & 3) holds point j of a block of four.  Two exchanges (partner = lane ^ 2, then
 // lane ^ 1) leave (Y0, Y2, Y1, Y3) in lanes (0, 1, 2, 3); the backward pair undoes them (times 4).  `own` / `other` = this
-// lane's and the partner's value.
+// lane's and the partner's value; the lane-dependent sign is a multiplier (own * (+-1) + other: one packed fma), not a select.
 template <int SIGN> __host__ __device__ __forceinline__ float2 quad_f1(int j, float2 own, float2 other) {
-    const float2 s = (j & 2) ? csub(other, own) : cadd(own, other);
-    return j == 3 ? mulj<SIGN>(s) : s;
+    const float sg = (j & 2) ? -1.f : 1.f;
+    const cf sv = {sg, sg};
+    const cf s = vfma(V(own), sv, V(other));
+    const float k = (j == 3) ? 0.f : 1.f, r = (j == 3) ? (float)SIGN : 0.f;      // lane 3: times SIGN j, as s k + s.yx (-r, r)
+    const cf kv = {k, k}, rv = {-r, r};
+    return F(vfma(s.yx, rv, s * kv));
 }
-__host__ __device__ __forceinline__ float2 quad_f2(int j, float2 own, float2 other) { return (j & 1) ? csub(other, own) : cadd(own, other); }
+__host__ __device__ __forceinline__ float2 quad_f2(int j, float2 own, float2 other) {
+    const float sg = (j & 1) ? -1.f : 1.f;
+    const cf sv = {sg, sg};
+    return F(vfma(V(own), sv, V(other)));
+}
 template <int SIGN> __host__ __device__ __forceinline__ float2 quad_b1(int j, float2 own, float2 other) {
-    const float2 s = (j & 1) ? csub(other, own) : cadd(own, other);
-    return j == 3 ? mulj<-SIGN>(s) : s;
+    const float sg = (j & 1) ? -1.f : 1.f;
+    const cf sv = {sg, sg};
+    const cf s = vfma(V(own), sv, V(other));
+    const float k = (j == 3) ? 0.f : 1.f, r = (j == 3) ? (float)-SIGN : 0.f;     // lane 3: times -SIGN j
+    const cf kv = {k, k}, rv = {-r, r};
+    return F(vfma(s.yx, rv, s * kv));
 }
-__host__ __device__ __forceinline__ float2 quad_b2(int j, float2 own, float2 other) { return (j & 2) ? csub(other, own) : cadd(own, other); }
+__host__ __device__ __forceinline__ float2 quad_b2(int j, float2 own, float2 other) {
+    const float sg = (j & 2) ? -1.f : 1.f;
+    const cf sv = {sg, sg};
+    return F(vfma(V(own), sv, V(other)));
+}
 
 template <int CTRL> __device__ __forceinline__ float2 quad_get(float2 v) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -212,7 +212,7 @@ struct CallGeom {
     int32_t pad_gf;
 };
 
-constexpr int DBG_SLOTS = 32;
+constexpr int DBG_SLOTS = 96;
 struct DeviceBuffers {
     float2 *hist;        // [channels][DECIM][A_HIST_COLS]   input history (column layout): raw samples; DC-corrected and mixed ones for channels with an LO
     float2 *dcv_hist;    // [channels][DCV_SAVE] RfDC in front of the 13 columns before the next call's first column, and of that column

@@ -34,10 +34,19 @@
 #include "fmx_internal.h"
 #include "fmx_demod_math.h"
 #include "fmx_fftconv.h"
+#include <type_traits>
 
 namespace fmx {
 
 #define SB_TICK(k) do { if (dbg_on) { const unsigned long long now_ = clock64(); dbg_acc[k] += now_ - dbg_t; dbg_t = now_; } } while (0)
+// (diagnostic build SB_FINE_TICKS: cycles of thread 0 between ~40 points of a segment, accumulated in LDS; W = drain the memory counters first)
+#ifdef SB_FINE_TICKS
+#define SB_FT(k) do { if (ft_on) { const unsigned long long now_ = clock64(); atomicAdd(&ft_acc[k], now_ - ft_t); ft_t = now_; } } while (0)
+#define SB_FTW(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); SB_FT(k); } while (0)
+#else
+#define SB_FT(k) do { } while (0)
+#define SB_FTW(k) do { } while (0)
+#endif
 
 constexpr int FB_T = 256, FB_K = 6, FB_W = FB_T * FB_K;        // threads, samples per thread, segment length
 static_assert(FB_T == fftc::T, "the convolution is written for the workgroup size");
@@ -324,7 +333,14 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
     unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
 #define SB_TICK1(k) SB_TICK(k)
 #else
-#define SB_TICK1(k) asm volatile("; SB_PHASE_END " #k)           /* (a marker in the assembly listing: tools/isa_phases.py) */
+#define SB_TICK1(k) asm volatile("; SB_PHASE_END " #k " F%c0" :: "i"(SB_FASTFLAG))   /* (a marker in the assembly listing: tools/isa_phases.py) */
+#endif
+#ifdef SB_FINE_TICKS
+    __shared__ unsigned long long ft_acc[64];
+    const bool ft_on = (B.dbg != nullptr) && (threadIdx.x == 0);
+    if (threadIdx.x < 64) ft_acc[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long ft_t = ft_on ? clock64() : 0ull;
 #endif
     const bool stereo_possible = P.fm_mode != 2, auto_mono = P.auto_mono != 0, pss_active = P.pss_active != 0;
     const bool pss_on = stereo_possible && pss_active;
@@ -363,7 +379,13 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
     float2 zn[FB_K + 2];
     fetch((int)threadIdx.x * FB_K, 0, nj < FB_W ? nj : FB_W, zn);
     __syncthreads();
-    for (int seg0 = 0; seg0 < nj; seg0 += FB_W) {
+    // One segment.  FAST = a full segment (every thread has its six samples) that neither holds the metaData snapshot sample nor the
+    // call's first two samples: all the `i < nv` / `i == il` / `i == ix` guards of the general form fold away at compile time (they
+    // were a third of the kernel's VALU instructions: v_cndmask, exec-mask bookkeeping, SGPR spills).  The general form runs the
+    // ragged last segment of a call and the one segment in 62 that takes the snapshot.
+    auto segment = [&](auto fast_tag, const int seg0) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr int SB_FASTFLAG = FAST ? 1 : 0;
         // Everything below that only depends on the thread index (table addresses, twiddles, scan weights, the ramp) is
         // loop-invariant, and the compiler would keep it all in registers across the loop (346 VGPRs): the index is made opaque
         // per segment, so those values are recomputed / reloaded (L1 hits) where they are used.
@@ -372,20 +394,22 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         wg.tid = tid; wg.lane = tid & 63; wg.wv = tid >> 6;
         const int lane = wg.lane;
         const int j0 = tid * FB_K;                                   // segment-relative index of this thread's first sample
-        const int w = (nj - seg0) < FB_W ? (nj - seg0) : FB_W;
+        const int w = FAST ? FB_W : ((nj - seg0) < FB_W ? (nj - seg0) : FB_W);
         const bool lastseg = seg0 + FB_W >= nj;
-        const int nv = w - j0;                                       // sample i of this thread exists when i < nv
-        const bool owner = nv >= 1 && nv <= FB_K;                    // this thread owns the segment's last sample
-        const int il = nv - 1;                                       // ... at this position
-        const int ix = jx - seg0 - j0;                               // this thread's index of the metaData snapshot sample, if 0 .. K-1
+        const int nv = FAST ? FB_K : w - j0;                         // sample i of this thread exists when i < nv
+        const bool owner = FAST ? (tid == FB_T - 1) : (nv >= 1 && nv <= FB_K);   // this thread owns the segment's last sample
+        const int il = FAST ? FB_K - 1 : nv - 1;                     // ... at this position
+        const int ix = FAST ? -1 : jx - seg0 - j0;                   // this thread's index of the metaData snapshot sample, if 0 .. K-1
 
+        SB_FT(0); SB_FTW(1);      // 0: loop top bookkeeping, 1: wait for the prefetched ring entries
         // ================= limiter + discriminator (fm-demodulator.cpp:119-126, 168-189) =================
         float res[FB_K];
         {
             const int decoder = P.decoder;
             float2 lim[FB_K + 2];                                // limited samples j0-2 .. j0+K-1 (the two in front recomputed: cheaper
 #pragma unroll                                                   // than an exchange through LDS with its two barriers)
-            for (int t = 0; t < FB_K + 2; t++) lim[t] = (zn[t].x != zn[t].x) ? make_float2((float)0.01, (float)0.01) : limiter_fast(zn[t]);
+            for (int t = 0; t < FB_K + 2; t++) lim[t] = (!FAST && zn[t].x != zn[t].x) ? make_float2((float)0.01, (float)0.01) : limiter_fast(zn[t]);
+            SB_FT(2);
             // (one loop per decoder: the six table gathers of a thread are issued back to back, not one per branch arm)
             if (decoder == 5) {                                      // REAL_BB :174-182
                 int index[FB_K];
@@ -414,15 +438,18 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
                     arm[i] = atan_arm(Q * I1 - I * Q1, I * I1 + Q * Q1);
                 }
+                SB_FT(3);
                 float tv[FB_K];
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) tv[i] = T.atan_ppy[arm[i].idx];
+                SB_FTW(4);
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) res[i] = atan_finish(arm[i], tv[i]);
             }
 #pragma unroll
             for (int i = 0; i < FB_K; i++) res[i] = (i < nv) ? res[i] : 0.f;
         }
+        SB_FT(5);
         SB_ARGS_FRESH(); SB_TICK1(0);
 
         // ================= AFC + scaling (fm-demodulator.cpp:197-198) =================
@@ -446,6 +473,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             if (lastseg && owner) st->fm_afc = afc_end;
             if (tid == 0) cy.afc = afc_next;
         }
+        SB_FT(6);
         SB_ARGS_FRESH(); SB_TICK1(1);
 
         // ================= pilot PLL (pilot-recover.cpp:54-61) =================
@@ -529,6 +557,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     ph[i] = (j0 + i == 0) ? x0 : (v < P32 ? v : 0.f);
                 }
             }
+            SB_FT(7);
             // Every guess is x[j] = fl (x0 + P[j] + S[j]): P = the f64 prefix sum of the exact increments step (x) - x of the previous
             // guess (what Picard's iteration would take), S = the Newton correction, S[j+1] = (1 + c[j]) S[j] + c[j] d[j] with
             // c = g cos x, d = x0 + P - x -- a scan of affine maps in f32 (S is small).  One rounding per sample, none accumulated:
@@ -570,6 +599,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     e[i] = tot;
                     tot += (i < nv) ? (double)nx[i] - (double)phase : 0.0;
                 }
+                SB_FT(8);
                 int anyopen = 0;
                 double pre = 0.0;
                 if (!seq) {
@@ -587,6 +617,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     for (int v = 0; v < 3; v++) pre += (v < wg.wv) ? lds.wd[wg.sl][v][0] : 0.0;
                     wg.sl ^= 1;
                 }
+                SB_FT(9);
                 if (!anyopen) {
                     // (the evaluation just made is the final one)
 #pragma unroll
@@ -627,8 +658,10 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     }
                     S = fmaf(1.f + c[i], S, c[i] * d[i]);
                 }
+                SB_FT(10);
                 open_ = !(dmax < PLL_NEWTON_TOL);
             }
+            SB_FT(11);
             // (cur / osc are those of the last evaluation: of the trajectory the iteration ended on)
             if (owner) { const float xe = (nxl >= 0.f && nxl < P32) ? nxl : 0.f; cy.x0 = xe; if (lastseg) st->pil_phase = xe; }
             // the NCO sine in front of each thread's first sample; the last one behind a full segment
@@ -647,6 +680,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 st->pil_old = oe;
             }
         }
+        SB_FT(12);
         SB_ARGS_FRESH(); SB_TICK1(2);
 
         // ================= lock detector (pilot-recover.cpp:62-80) =================
@@ -670,6 +704,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             float Lt = 0.f;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) Lt = xq[i] + Lt * keepf;
+            SB_FT(13);
             float lock_next;
             const int locked0 = cy.locked, stable0 = cy.stable;
             float lock = wg.decay_incoming2(Lt, cy.lock, make_decay(T.lock_l2, lane), &lock_next);
@@ -682,6 +717,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 if (i == il) lock_end = lock;
                 if (i == ix) lock_x = lock;
             }
+            SB_FT(14);
             // locked[j] = no sample <= j below the threshold AND (locked before, or the run has lasted long enough)
             int cnt_dummy, tot_dummy, preF, totF;
             wg.excl_add_max_i(0, lastf, &cnt_dummy, &tot_dummy, &preF, &totF);
@@ -706,12 +742,14 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             if (lastseg && owner) { st->pil_lock = lock_end; st->pil_locked = nl; st->pil_stable = ns; }
             if (tid == 0) { cy.locked = nl; cy.stable = ns; cy.lock = lock_next; }
         }
+        SB_FT(15);
         {   // scope taps and the inputs of the RDS path: channel-major rows of this call
             const size_t lrow = (size_t)ch * B.lin_rows + seg0 + j0;
             float *wd = B.w_dem + lrow, *wc = B.w_cur + lrow;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) if (i < nv) { wd[i] = dem[i]; wc[i] = cur[i]; }
         }
+        SB_FT(16);
         SB_ARGS_FRESH(); SB_TICK1(3);
 
         // ================= PSS errors of the calls this segment can make: err[m] = Re (y) Im (y), y = low-pass of the s ring
@@ -728,7 +766,9 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 const int64_t idx = i0 - (PSS_DELAY + PSS_TAPS - 1) + n;
                 a[p] = (n < w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & smask] : make_float2(0.f, 0.f);
             }
+            SB_FT(17); SB_FTW(18);
             fftc::convolve(tid, a, X, T.fft_w, T.pss_hs);
+            SB_FT(19);
             __syncthreads();                   // (er overlays the buffer the last stage was read from)
 #pragma unroll
             for (int p = 0; p < 8; p++) {
@@ -737,6 +777,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             }
         }
         __syncthreads();
+        SB_FT(20);
         SB_ARGS_FRESH(); SB_TICK1(4);
 
         // ================= the PSS call index of every sample (fm-processor.cpp:704-718) =================
@@ -771,6 +812,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             wg.reduce_max4(firstU, firstZ, anyl, alll);
         }
 
+        SB_FT(21);
         // ================= PSS integrator (stereo-separation.cpp:84-109, fm-processor.cpp:699-718) =================
         float used[FB_K];                                            // pilotDelayPSS as used by each sample
         {
@@ -818,6 +860,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     aend = (float)(a0 + total);
                     changed = changed || (double)aend != a0 + total;
                 }
+                SB_FT(22);
                 // mean_error (1 / rate smoothing) and the "minimised" bookkeeping in closed form
                 const DecayW dw = make_decay(T.pssmean_l2, lane);
                 float Lt = 0.f;
@@ -839,6 +882,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     mean_next = Cc;
                     mean = fmaf(dw.dl, Cin, lane_prev_f(Z, 0.f));
                 }
+                SB_FT(23);
                 int rounds = 1;
                 if (changed) {
                     for (int it = 0; ; it++) {
@@ -868,6 +912,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                         if (!anych || it == PSS_MAX_ROUNDS - 1) break;
                     }
                 }
+                SB_FT(24);
                 if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 9] += rounds; B.dbg[(size_t)ch * DBG_SLOTS + 12] += 1; }
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) used[i] = (j0 + i == 0) ? s.pdp : a[i];
@@ -879,6 +924,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     if (i == il) mean_end = mean;
                     if (i == ix && i < nv) meta_snapshot(st, P, fminf(fmaxf(a[i] + xa[i], -c4), c4), mean, mz, true);   // (mz: no flip inside a steady segment)
                 }
+                SB_FT(25);
                 wg.reduce_max4(lastS, lastN, d3, d4);
                 e.mean = mean_next;                                  // (behind a full segment; the owner's own value replaces it below)
                 e.acc = aend; e.pdp = aend; e.minimized = mz;
@@ -924,6 +970,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 for (int i = 0; i < FB_K; i++) used[i] = (i < nv) ? er[j0 + i] : 0.f;
             }
         }
+        SB_FT(26);
         SB_ARGS_FRESH(); SB_TICK1(5);
 
         // ================= 38 kHz mix, PSS input, stereo matrix (fm-processor.cpp:707-730, 517-549) =================
@@ -955,6 +1002,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 }
                 sumv[i] = dem[i]; diffv[i] = dif;
             }
+            SB_FT(27);
             {   // scope tap (fmx_get_tap): channel-major rows of this call
                 float *wf = B.w_diff + (size_t)ch * B.lin_rows + seg0 + j0;
 #pragma unroll
@@ -978,18 +1026,21 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 x[i] = (i < nv) ? o : make_float2(0.f, 0.f);
             }
         }
+        SB_FT(28);
         SB_ARGS_FRESH(); SB_TICK1(6);
 
         // ================= de-emphasis (fm-processor.cpp:594-595) into the d ring =================
         // (the next segment's ring entries are requested here: they land under the de-emphasis, and are not in the way of the
         // register-hungry phases above)
         if (!lastseg) { const int wn = (nj - seg0 - FB_W) < FB_W ? (nj - seg0 - FB_W) : FB_W; fetch(j0, seg0 + FB_W, wn, zn); }
+        SB_FT(29);
         {
             const float a = P.deemph_alpha;
             const DecayW dw = make_decay(P.deemph_l2, lane);
             float Ll = 0.f, Lr = 0.f;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) { Ll = (x[i].x - Ll) * a + Ll; Lr = (x[i].y - Lr) * a + Lr; }
+            SB_FT(30);
             float yl, yr;
             {   // (both channels behind one barrier)
                 const float Zl = wscan_decay(Ll, dw), Zr = wscan_decay(Lr, dw);
@@ -1001,6 +1052,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 wg.sl ^= 1;
                 yl = fmaf(dw.dl, Cl, lane_prev_f(Zl, 0.f)); yr = fmaf(dw.dl, Cr, lane_prev_f(Zr, 0.f));
             }
+            SB_FT(31);
             if (tid == 0) cy.calls = calls_before + ncalls;          // (the mix above was the last reader; a barrier in between)
             const int dmask = G.dring_mask;
             float2 *dr = B.dring + (size_t)ch * (dmask + 1);
@@ -1016,7 +1068,12 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             // the state behind the segment's last sample, as its owner computed it (read again behind the next segment's barriers)
             if (owner) { cy.de_l = el; cy.de_r = er_; }
         }
+        SB_FT(32);
         SB_ARGS_FRESH(); SB_TICK1(7);
+    };
+    for (int seg0 = 0; seg0 < nj; seg0 += FB_W) {
+        const bool fast = (nj - seg0 >= FB_W) && !((unsigned)(jx - seg0) < (unsigned)FB_W) && (G.J0 + seg0 >= 2);
+        if (fast) segment(std::true_type{}, seg0); else segment(std::false_type{}, seg0);
     }
     // ================= bookkeeping behind the call =================
     __syncthreads();
@@ -1037,9 +1094,14 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         st->pss_count = pss_count0 + cy.calls;                   // the PSS filter time base advances by this call's process_sample calls
         st->pss_call_total = 0;
     }
+    constexpr int SB_FASTFLAG = 2;
     SB_TICK1(8);
 #ifdef SB_PHASE_CYCLES
     if (dbg_on) for (int k = 0; k < 9; k++) B.dbg[(size_t)ch * DBG_SLOTS + 16 + k] += dbg_acc[k];
+#endif
+#ifdef SB_FINE_TICKS
+    __syncthreads();
+    if (ft_on) for (int k = 0; k < 64; k++) B.dbg[(size_t)ch * DBG_SLOTS + 32 + k] += ft_acc[k];
 #endif
     if (B.dbg && threadIdx.x == 0) {
         B.dbg[(size_t)ch * DBG_SLOTS + 13] = __float_as_uint(cy.x0); B.dbg[(size_t)ch * DBG_SLOTS + 14] = __float_as_uint(cy.lock);   // (diagnostics: state behind the call)

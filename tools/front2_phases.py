@@ -18,7 +18,7 @@ L.fmx_debug_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_ulongl
 L.fmx_debug_phase_cycles(f.h, 1, None)
 K = 3
 for _ in range(K): f.process_device(iq.data_ptr(), n, n, pcm.data_ptr(), n // 48 + 96, hip_stream=s)
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 96)()
 L.fmx_debug_phase_cycles(f.h, 0, out)
 names = ["P: wait loads + scatter", "P: DC pass + write-back + post", "P: wait for consumer", "P: history write",
          "C: wait for producer", "C: matrix FIR + post", "C: exchange + store"]

@@ -18,7 +18,7 @@ L.fmx_debug_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_ulongl
 L.fmx_debug_phase_cycles(f.h, 1, None)
 K = 3
 for _ in range(K): f.process_device(iq.data_ptr(), n, n, pcm.data_ptr(), n // 48 + 96, hip_stream=s)
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 96)()
 L.fmx_debug_phase_cycles(f.h, 0, out)
 names = ["prologue+first load", "scatter to LDS", "DC removal (scan, carry wait) + mix", "history hand-off (waits)", "prefetch + FIR + partial sums", "reduce + store", "epilogue"]
 tiles = ch * K * (n / 1536.0 / 4)     # wave 0 of every workgroup handles a quarter of the 1536-sample tiles

@@ -32,7 +32,7 @@ for layout in ("chunked", "fused"):
     out = []
     import ctypes as C
     f.L.fmx_debug_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_ulonglong)]
-    dbg = (C.c_ulonglong * 32)()
+    dbg = (C.c_ulonglong * 96)()
     pos = 0
     for k in range(calls):
         f.L.fmx_debug_phase_cycles(f.h, 1, None)

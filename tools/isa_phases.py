@@ -15,7 +15,7 @@ rows = []
 label = "start"
 for line in s[a:b].split("\n"):
     t = line.strip()
-    mm = re.match(r"; SB_PHASE_END (\d+)", t)
+    mm = re.match(r"; SB_PHASE_END (\d+ ?F?\d?)", t)
     if mm:
         rows.append((label, cur)); cur = dict.fromkeys(cur, 0); label = "after %s" % mm.group(1)
         continue

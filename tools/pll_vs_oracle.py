@@ -28,7 +28,7 @@ f = pkg.Fmx(1, max_block=block)
 for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FM_MODE, 0)):
     f.set_param(pid, v)
 f.L.fmx_debug_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_ulonglong)]
-dbg = (C.c_ulonglong * 32)()
+dbg = (C.c_ulonglong * 96)()
 f.L.fmx_debug_phase_cycles(f.h, 1, None)
 for p in range(0, n, block):
     f.process_host(iq[p:p + block])

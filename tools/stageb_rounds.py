@@ -27,7 +27,7 @@ pcm = torch.zeros((ch, n // 48 + 96, 2), dtype=torch.float32, device=dev)
 st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
 L = f.L
 L.fmx_debug_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_ulonglong)]
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 96)()
 for k in range(calls):
     if k % 8 == 0:
         L.fmx_debug_phase_cycles(f.h, 1, None)
