@@ -163,15 +163,30 @@ template <int CTRL> __device__ __forceinline__ float2 quad_get(float2 v) {
 // X: LDS_N complex of LDS; W: twiddles; Hs: the spectrum in "slot" order (entry 8 t + q = what thread t holds in register q in
 // front of the multiplication, make_spectrum below), 1 / N included.
 // forward half: `a` = natural-order inputs t + 256 p on entry, slot values (register q of thread t) on return
-__device__ __forceinline__ void forward_slots(int t, float2 *a, float2 *X, const float2 *__restrict__ W) {
+// (hs / Hs: when given, the thread's eight spectrum entries Hs[8 t ..] are requested in front of the second barrier)
+__device__ __forceinline__ void forward_slots(int t, float2 *a, float2 *X, const float2 *__restrict__ W, float4 *hs = nullptr, const float2 *__restrict__ Hs = nullptr) {
+    // (every stage's twiddles are requested a stage ahead: their latency lands under the butterflies and the barrier in front)
     int base, j;
-    fwd8<2048>(a, t, W); store_q<2048>(a, X, 0, t);
-    __syncthreads();
+    float2 twa[7], twb[7];
+    load_tw<2048>(twa, t, W);
     geom8<256>(t, base, j);
-    load_p<256>(a, X, base, j); fwd8<256>(a, j, W); store_q<256>(a, X, base, j);
+    load_tw<256>(twb, j, W);
+    fwd8(a, twa); store_q<2048>(a, X, 0, t);
+    {
+        int b32, j32;
+        geom8<32>(t, b32, j32);
+        load_tw<32>(twa, j32, W);
+    }
+    __syncthreads();
+    load_p<256>(a, X, base, j); fwd8(a, twb); store_q<256>(a, X, base, j);
+    if (hs) {
+        const float4 *H4 = reinterpret_cast<const float4 *>(Hs + 8 * t);
+#pragma unroll
+        for (int q = 0; q < 4; q++) hs[q] = H4[q];
+    }
     __syncthreads();
     geom8<32>(t, base, j);
-    load_p<32>(a, X, base, j); fwd8<32>(a, j, W);
+    load_p<32>(a, X, base, j); fwd8(a, twa);
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         float2 v = a[q];
@@ -182,19 +197,27 @@ __device__ __forceinline__ void forward_slots(int t, float2 *a, float2 *X, const
 // backward half: slot values in, natural-order outputs t + 256 p out (times N)
 __device__ __forceinline__ void backward_slots(int t, float2 *a, float2 *X, const float2 *__restrict__ W) {
     int base, j;
+    float2 twa[7], twb[7];
     geom8<32>(t, base, j);
+    load_tw<32>(twa, j, W);
+    {
+        int b256, j256;
+        geom8<256>(t, b256, j256);
+        load_tw<256>(twb, j256, W);
+    }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         float2 v = a[q];
         v = quad_b1<-1>(j, v, quad_get<0xB1>(v));
         a[q] = quad_b2(j, v, quad_get<0x4E>(v));
     }
-    inv8<32>(a, j, W); store_p<32>(a, X, base, j);
+    inv8(a, twa); store_p<32>(a, X, base, j);
+    load_tw<2048>(twa, t, W);
     __syncthreads();
     geom8<256>(t, base, j);
-    load_q<256>(a, X, base, j); inv8<256>(a, j, W); store_p<256>(a, X, base, j);
+    load_q<256>(a, X, base, j); inv8(a, twb); store_p<256>(a, X, base, j);
     __syncthreads();
-    load_q<2048>(a, X, 0, t); inv8<2048>(a, t, W);
+    load_q<2048>(a, X, 0, t); inv8(a, twa);
 }
 // a[q] *= Hs[8 t + q]
 __device__ __forceinline__ void times_spectrum(int t, float2 *a, const float2 *__restrict__ Hs) {
@@ -205,8 +228,10 @@ __device__ __forceinline__ void times_spectrum(int t, float2 *a, const float2 *_
 // (the caller must put a barrier between the last LDS read of one transform and the first LDS write of the next: the end of
 // forward_slots and of backward_slots reads X)
 __device__ __forceinline__ void convolve(int t, float2 *a, float2 *X, const float2 *__restrict__ W, const float2 *__restrict__ Hs) {
-    forward_slots(t, a, X, W);
-    times_spectrum(t, a, Hs);
+    float4 hs[4];
+    forward_slots(t, a, X, W, hs, Hs);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { a[2 * q] = cmul(a[2 * q], make_float2(hs[q].x, hs[q].y)); a[2 * q + 1] = cmul(a[2 * q + 1], make_float2(hs[q].z, hs[q].w)); }
     backward_slots(t, a, X, W);
 }
 

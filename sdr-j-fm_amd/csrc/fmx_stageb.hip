@@ -353,6 +353,13 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         const int delay = T.front_sets[P.front_set].delay_fm;
         const float2 *zr = B.zring + (size_t)ch * (G.ring_mask + 1);
         const int64_t base = G.J0 + seg0;
+        if (w == FB_W && base - 2 - delay >= 0) {                // (the same for every thread) a full segment behind the filter latency:
+            const int rmask = G.ring_mask;                       // no clamp, no marker, no zero fill; ring positions in 32 bits
+            const int r0 = (int)((base - delay) & rmask) + j0 - 2;
+#pragma unroll
+            for (int t = 0; t < FB_K + 2; t++) z[t] = zr[(r0 + t) & rmask];
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < FB_K + 2; t++) {
             const int jr = j0 - 2 + t;
@@ -760,11 +767,20 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         if (pss_on) {
             const int64_t i0 = pss_count0 + calls_before;                            // call index of the segment's first output
             float2 a[8];
+            const int64_t first = i0 - (PSS_DELAY + PSS_TAPS - 1);                   // s index of window entry 0
+            if (FAST && first >= 0) {          // (the usual case: ring positions in 32 bits, only the last of a thread's eight entries can be padding)
+                const int r0 = (int)(first & smask) + tid;
 #pragma unroll
-            for (int p = 0; p < 8; p++) {      // window entry n <-> s index i0 - (1753 + 294) + n; entries past the segment's need are padding
-                const int n = tid + FB_T * p;
-                const int64_t idx = i0 - (PSS_DELAY + PSS_TAPS - 1) + n;
-                a[p] = (n < w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & smask] : make_float2(0.f, 0.f);
+                for (int p = 0; p < 7; p++) a[p] = sring[(r0 + FB_T * p) & smask];
+                static_assert(FB_T * 7 < FB_W + PSS_TAPS - 1 && FB_W + PSS_TAPS - 1 <= FB_T * 8, "which window entries are padding");
+                a[7] = (tid < FB_W + PSS_TAPS - 1 - FB_T * 7) ? sring[(r0 + FB_T * 7) & smask] : make_float2(0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 8; p++) {      // window entry n <-> s index i0 - (1753 + 294) + n; entries past the segment's need are padding
+                    const int n = tid + FB_T * p;
+                    const int64_t idx = first + n;
+                    a[p] = (n < w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & smask] : make_float2(0.f, 0.f);
+                }
             }
             SB_FT(17); SB_FTW(18);
             fftc::convolve(tid, a, X, T.fft_w, T.pss_hs);
@@ -978,7 +994,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         {
             constexpr double INV2PI = 1.0 / FMX_2PI;
             const int ssel = P.sound_sel; const float pano = (P.fm_mode == 1) ? P.panorama : 1.0f;
-            const int64_t ic = pss_count0 + calls_before;            // call index of the segment's first call
+            const int icl = (int)((pss_count0 + calls_before) & smask);   // ring position of the segment's first call
             const float P32 = 6.2831855f, C32 = T.wrap32_c;
             const bool wrap_ok = T.wrap32_ok != 0;
             float sumv[FB_K], diffv[FB_K];
@@ -996,7 +1012,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 sincos_idx_f32(idx, &e.y, &e.x);
                 float dif = 0.f;
                 if (tag[i] != -2) {
-                    if (tag[i] >= 0 && i < nv) sring[(ic + tag[i]) & smask] = make_float2(e.x * dem[i], e.y * dem[i]);
+                    if (tag[i] >= 0 && i < nv) sring[(icl + tag[i]) & smask] = make_float2(e.x * dem[i], e.y * dem[i]);
                     const float lut = (ssel == 6) ? e.y : e.x;       // S_LEFTminusRIGHT_Test mixes with the sine
                     dif = 2.0f * (lut * dem[i]);                     // (float)(2.0 * lut * demod): one rounding of the exact product either way
                 }
