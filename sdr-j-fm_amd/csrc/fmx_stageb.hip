@@ -596,41 +596,50 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                     for (int i = 0; i < FB_K; i++) ph[i] = (i < nv) ? er[FB_W + j0 + i] : 0.f;
                     __syncthreads();
                 }
-                double e[FB_K], tot = 0.0;
                 float nx[FB_K];
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) {
                     const float phase = into_range(ph[i]);
                     ph[i] = phase;
                     eval(i, phase, &nx[i]);
-                    e[i] = tot;
-                    tot += (i < nv) ? (double)nx[i] - (double)phase : 0.0;
                 }
                 SB_FT(8);
-                int anyopen = 0;
-                double pre = 0.0;
-                if (!seq) {
-                    // the increments' prefix sums; with the same barrier: has the previous round's update been small everywhere?
-                    const double inc = wscan_add_d(tot);
-                    {
-                        const int wopen = __any(open_) ? 1 : 0;
-                        if (lane == 63) lds.wd[wg.sl][wg.wv][0] = inc;
-                        if (lane == 0) lds.wi[wg.sl][wg.wv][1] = wopen;
-                    }
+                if (seq || it > 0) {
+                    // This evaluation is the final one unless the update in front of it was not small somewhere: that flag rides on the
+                    // barrier of the NCO-sine hand-off the lock detector needs anyway (the sine in front of each thread's first sample;
+                    // the last one behind a full segment is the next segment's `old`).
+                    const int wopen = (!seq && __any(open_)) ? 1 : 0;
+                    if (lane == 63) lds.wf[wg.sl][wg.wv][1] = osc[FB_K - 1];
+                    if (lane == 0) lds.wi[wg.sl][wg.wv][1] = wopen;
+                    const float cold = cy.old;
                     __syncthreads();
-                    anyopen = lds.wi[wg.sl][0][1] | lds.wi[wg.sl][1][1] | lds.wi[wg.sl][2][1] | lds.wi[wg.sl][3][1];
+                    const int anyopen = lds.wi[wg.sl][0][1] | lds.wi[wg.sl][1][1] | lds.wi[wg.sl][2][1] | lds.wi[wg.sl][3][1];
+                    const float from_prev_wave = lds.wf[wg.sl][(wg.wv + 3) & 3][1], old_next = lds.wf[wg.sl][3][1];
+                    wg.sl ^= 1;
+                    if (!anyopen) {
+                        osc_in = dppf<0x138, 0xf>(0.f, osc[FB_K - 1]);
+                        if (lane == 0) osc_in = wg.wv ? from_prev_wave : cold;
+                        if (tid == 0) cy.old = old_next;             // (read again behind the next segment's barriers)
+#pragma unroll
+                        for (int i = 0; i < FB_K; i++) if (i == il) nxl = nx[i];
+                        if (B.dbg && tid == 0 && !P.pll_seq) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; }
+                        break;
+                    }
+                }
+                SB_FT(9);
+                // the increments' prefix sums in f64
+                double e[FB_K], tot = 0.0;
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) { e[i] = tot; tot += (i < nv) ? (double)nx[i] - (double)ph[i] : 0.0; }
+                double pre;
+                {
+                    const double inc = wscan_add_d(tot);
+                    if (lane == 63) lds.wd[wg.sl][wg.wv][0] = inc;
+                    __syncthreads();
                     pre = inc - tot;
 #pragma unroll
                     for (int v = 0; v < 3; v++) pre += (v < wg.wv) ? lds.wd[wg.sl][v][0] : 0.0;
                     wg.sl ^= 1;
-                }
-                SB_FT(9);
-                if (!anyopen) {
-                    // (the evaluation just made is the final one)
-#pragma unroll
-                    for (int i = 0; i < FB_K; i++) if (i == il) nxl = nx[i];
-                    if (B.dbg && tid == 0 && !P.pll_seq) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; }
-                    break;
                 }
                 if (it == PLL_NEWTON_MAX - 1) { seq = true; continue; }       // not settled: sample by sample
                 // ---- the Newton correction
@@ -671,15 +680,6 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             SB_FT(11);
             // (cur / osc are those of the last evaluation: of the trajectory the iteration ended on)
             if (owner) { const float xe = (nxl >= 0.f && nxl < P32) ? nxl : 0.f; cy.x0 = xe; if (lastseg) st->pil_phase = xe; }
-            // the NCO sine in front of each thread's first sample; the last one behind a full segment
-            if (lane == 63) lds.wf[wg.sl][wg.wv][1] = osc[FB_K - 1];
-            const float cold = cy.old;
-            __syncthreads();
-            osc_in = dppf<0x138, 0xf>(0.f, osc[FB_K - 1]);
-            if (lane == 0) osc_in = wg.wv ? lds.wf[wg.sl][(wg.wv + 3) & 3][1] : cold;
-            const float old_next = lds.wf[wg.sl][3][1];
-            wg.sl ^= 1;
-            if (tid == 0) cy.old = old_next;
             if (lastseg && owner) {
                 float oe = 0.f;
 #pragma unroll
