@@ -181,8 +181,9 @@ int  fmx_get_peaks(fmx_handle h, int32_t channel, float *lr_db, int32_t capacity
 int  fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap_id, float *dst, int64_t n);
 /* What the reference's RDS classes tell the GUI through Qt signals (rds-groupdecoder.cpp:44-63, rds-blocksynchronizer.cpp:39-42):
  * setPiCode, setPTYCode, setStationLabel, setRadioText / clearRadioText, setAFDisplay, setMusicSpeechFlag, setGroup,
- * setRDSisSynchronized, setbitErrorRate, setCRCErrors, setSyncErrors.  Text fields hold the raw RDS (EBU Latin)
- * characters, NUL terminated; the EBU -> Unicode mapping stays with the adapter. */
+ * setRDSisSynchronized, setbitErrorRate, setCRCErrors, setSyncErrors.  station_label / radio_text hold the raw RDS characters, NUL
+ * terminated (the reference shows the label as QString (stationLabel), rds-groupdecoder.cpp:185-186); radio_text_ucs2 is the text as
+ * setRadioText receives it. */
 typedef struct fmx_rds_info {
     int32_t synchronized;      /* block synchroniser locked (A..C received without error) */
     int32_t pi_code;           /* block A of the last group; 0 until a group has been decoded */
@@ -196,6 +197,12 @@ typedef struct fmx_rds_info {
     int32_t af1_khz, af2_khz;  /* alternative frequencies of the last 0A group, 0 = none */
     int32_t music_speech;      /* -1 unknown, else the M/S flag */
     int32_t di_code;
+    /* the radio text as rdsGroupDecoder::prepareText hands it to setRadioText (rds-groupdecoder.cpp:298-315): walked pair by pair with
+     * the alphabet-switch pairs 0x0F0F / 0x0E0E / 0x1B6E handled as the reference handles them (the pair's second byte is emitted, the
+     * character behind it is not), every character through mapEBUtoUnicode (ebu-codetables.c:65-72), QString::trimmed; UTF-16 code
+     * units, 0 terminated */
+    uint16_t radio_text_ucs2[65];
+    int16_t  radio_text_ucs2_len;
 } fmx_rds_info;
 /* replaces rdsDecoder::processBit + rdsBlockSynchronizer + rdsGroupDecoder (rds-decoder.cpp:104-131,
  * rds-blocksynchronizer.cpp:114-336, rds-groupdecoder.cpp:100-290) on the host: feeds every bit the slicer has produced
@@ -205,6 +212,16 @@ int  fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info);
 /* the same decoder over a caller-supplied bit array, from a fresh state (host only, needs no device): what a
  * recorded bit stream decodes to */
 int  fmx_rds_decode_bits(const uint8_t *bits, int32_t n_bits, fmx_rds_info *info);
+/* The byte work behind the text signals, exactly as the reference does it (tests/test_rds_text.py pins all three against the
+ * reference's own code in oracle/_ref and tests/golden/ref_rds_tables.npz):
+ *   fmx_rds_pty_name      pty_table [pty][locale] (ebu-codetables.c:4-37; rds-groupdecoder.cpp:115), UTF-8; NULL outside 0..31 x 0..1
+ *   fmx_rds_map_char      mapEBUtoUnicode (alfabet, character) (ebu-codetables.c:65-72)
+ *   fmx_rds_prepare_text  rdsGroupDecoder::prepareText (v, length) (:298-315) with alfabetSwitcher / setAlfabetTo (:317-343): writes the
+ *                         trimmed text as UTF-16 code units (0 terminated when capacity allows) and returns their count; *alfabet is
+ *                         the decoder's theAlfabet (in / out, may be NULL) */
+const char *fmx_rds_pty_name(int32_t pty_code, int32_t pty_locale);
+uint16_t fmx_rds_map_char(uint8_t alfabet, uint8_t character);
+int32_t  fmx_rds_prepare_text(const uint8_t *v, int32_t length, uint8_t *alfabet, uint16_t *out, int32_t capacity);
 /* replaces rdsDecoder::doDecode's bit output (rds-decoder.cpp:69-104): pending RDS bits */
 int  fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity, int32_t *n_bits);
 /* replaces doDecode's second output (`*m`, rds-decoder-2.cpp:108-114), the constellation point every bit was decided on, which

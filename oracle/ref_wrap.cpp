@@ -9,7 +9,7 @@
 // Classes wrapped (all Qt-free): LowPassFIR, BandPassFIR, DecimatingFIR (fir-filters.h),
 // fftFilter, fftFilterHilbert (fft-filters.h), Fft_transform (fft-complex.h), SinCos, Oscillator,
 // compAtan, pllC, pilotRecovery, PerfectStereoSeparation, ShapingFilter, AGC, Costas, LowPassIIR, HighPassIIR, BandPassIIR,
-// PI_Constrain (fm-constants.h).  With -DFMREF_WITH_QT also fm_Demodulator (needs QString from
+// PI_Constrain (fm-constants.h), RDSGroup (rds-group.h) and the PTY / EBU tables of src/rds/ebu-codetables.c.  With -DFMREF_WITH_QT also fm_Demodulator (needs QString from
 // the image's conda QtCore; built only when those headers exist).
 //
 // NOT built: src/fm/fm-processor.cpp (needs portaudio.h, sndfile.h, samplerate.h, qwt and
@@ -35,6 +35,8 @@
 #include "agc.h"
 #include "costas.h"
 #include "iir-filters.h"
+#include "rds-group.h"          // RDSGroup (src/rds/rds-group.cpp, compiled with this file)
+#include "ebu-codetables.c"     // pty_table, EBU_E1, mapEBUtoUnicode: pulled in by #include, as rds-groupdecoder.cpp:43 does
 #ifdef FMREF_WITH_QT
 #include "fm-demodulator.h"
 #include "squelchClass.h"       // QObject + moc (oracle/Makefile runs the image's moc on the reference's header, output in _ref/)
@@ -367,4 +369,19 @@ void ref_squelch_run(void *p, const float *in, const float *carrier, float *out,
 #endif
 }
 
+
+// ---- RDS byte work: RDSGroup (rds-group.cpp:33-81) and the tables of ebu-codetables.c, which the reference itself
+// pulls in by #include (rds-groupdecoder.cpp:43) -- included from the reference tree in place at the top of this file
+void ref_rdsgroup_fields(const uint16_t *blk /*4*/, int32_t *out /*9*/) {
+    RDSGroup g;
+    g.setBlock(RDSGroup::BLOCK_A, blk[0]); g.setBlock(RDSGroup::BLOCK_B, blk[1]);
+    g.setBlock(RDSGroup::BLOCK_C, blk[2]); g.setBlock(RDSGroup::BLOCK_D, blk[3]);
+    out[0] = g.getBlock_A(); out[1] = g.getBlock_B(); out[2] = g.getBlock_C(); out[3] = g.getBlock_D();
+    out[4] = g.getPiCode(); out[5] = g.getGroupType(); out[6] = g.isTypeBGroup() ? 1 : 0; out[7] = g.isTpFlagSet() ? 1 : 0;
+    out[8] = g.getProgrammeType();
+    g.clear();
+    if (g.getBlock(RDSGroup::BLOCK_A) | g.getBlock(RDSGroup::BLOCK_B) | g.getBlock(RDSGroup::BLOCK_C) | g.getBlock(RDSGroup::BLOCK_D)) out[0] = -1;
+}
+uint16_t ref_map_ebu(uint8_t alfabet, uint8_t character) { return mapEBUtoUnicode(alfabet, character); }
+const char *ref_pty_name(int32_t pty, int32_t locale) { return pty_table[pty][locale]; }   // rds-groupdecoder.cpp:115
 }  // extern "C"

@@ -1367,6 +1367,13 @@ int fmx_rds_decode_bits(const uint8_t *bits, int32_t n_bits, fmx_rds_info *info)
     return FMX_OK;
 }
 
+const char *fmx_rds_pty_name(int32_t pty_code, int32_t pty_locale) { return fmx::rds_pty_name(pty_code, pty_locale); }
+uint16_t fmx_rds_map_char(uint8_t alfabet, uint8_t character) { return fmx::rds_map_char(alfabet, character); }
+int32_t fmx_rds_prepare_text(const uint8_t *v, int32_t length, uint8_t *alfabet, uint16_t *out, int32_t capacity) {
+    if (!v || !out || length < 0 || capacity < 0) { (void)fail(FMX_E_INVALID, "bad argument"); return -1; }
+    return fmx::rds_prepare_text(v, length, alfabet, out, capacity);
+}
+
 int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32_t capacity, int32_t *n) {
     if (!h || !dst || !n || channel < 0 || channel >= h->channels) return fail(FMX_E_INVALID, "bad argument");
     {   // the tap sets of the CURRENT settings; nothing is uploaded and no pending action is touched (introspection)

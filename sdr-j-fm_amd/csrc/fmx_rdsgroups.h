@@ -5,14 +5,46 @@
 //   RDSGroup                        src/rds/rds-group.cpp:33-81
 //   rdsGroupDecoder::decode & co.   src/rds/rds-groupdecoder.cpp:71-290
 // The Qt signals of those classes (setPiCode, setStationLabel, setRadioText, ...) become fields of fmx_rds_info, which
-// the adapter turns back into signals.  EBU -> Unicode mapping of the text (ebu-codetables.c) stays with the adapter:
-// the label and the radio text are handed over as the raw RDS characters.
+// the adapter turns back into signals.  The radio text goes through the reference's own character handling (prepareText with its
+// alphabet-switch pairs, mapEBUtoUnicode, rds-groupdecoder.cpp:298-343, ebu-codetables.c:65-72; tables in fmx_rds_tables.h) into
+// fmx_rds_info::radio_text_ucs2; the raw characters are handed over next to it.
 #pragma once
 #include <cstdint>
 #include <cstring>
 #include "../../include/fmx.h"
+#include "fmx_rds_tables.h"
 
 namespace fmx {
+
+// mapEBUtoUnicode (ebu-codetables.c:65-72): the alphabet is ignored there, control codes read as a blank
+inline uint16_t rds_map_char(uint8_t /*alfabet*/, uint8_t c) { return c < 0x20 ? (uint16_t)' ' : RDS_CHAR_UCS2[c - 0x20]; }
+inline const char *rds_pty_name(int pty, int locale) { return (pty < 0 || pty > 31 || locale < 0 || locale > 1) ? nullptr : RDS_PTY_NAME[locale][pty]; }
+// rdsGroupDecoder::prepareText (:298-315): the buffer is walked as (previous, current) pairs.  A pair that switches the alphabet
+// (alfabetSwitcher :317-325: 0x0F 0x0F, 0x0E 0x0E, 0x1B 0x6E) sets theAlfabet from its first byte (setAlfabetTo :331-343), makes its
+// SECOND byte the previous character and steps over the byte behind the pair; otherwise the previous character is emitted.  So the
+// last character of `length` never appears, a switch pair leaves its second byte in the text and swallows the character behind it.
+// Result trimmed as QString::trimmed does (the table holds no other white space than U+0020).  Returns the number of code units.
+inline int rds_prepare_text(const uint8_t *v, int length, uint8_t *alfabet, uint16_t *out, int cap) {
+    uint8_t alf = alfabet ? *alfabet : 0;
+    uint16_t tmp[256];
+    int n = 0;
+    if (length > 256) length = 256;
+    uint8_t prev = v[0];                                               // (read even when length is 0, as the reference does)
+    for (int i = 1; i < length; i++) {
+        const uint8_t cur = v[i];
+        const bool sw = (prev == 0x0F && cur == 0x0F) || (prev == 0x0E && cur == 0x0E) || (prev == 0x1B && cur == 0x6E);
+        if (sw) { alf = prev == 0x0E ? 1 : (prev == 0x1B ? 2 : 0); prev = v[i]; i++; }
+        else { tmp[n++] = rds_map_char(alf, prev); prev = cur; }
+    }
+    if (alfabet) *alfabet = alf;
+    int a = 0, e = n;
+    while (a < e && tmp[a] == ' ') a++;
+    while (e > a && tmp[e - 1] == ' ') e--;
+    int k = 0;
+    for (int i = a; i < e && k < cap; i++) out[k++] = tmp[i];
+    if (k < cap) out[k] = 0;
+    return e - a;
+}
 
 class RdsGroupDecoderHost {
 public:
@@ -111,14 +143,16 @@ private:
         std::memset(ps_, ' ', 8); ps_[8] = 0; ps_seg_ = 0; di_ = 0;
         std::memset(rt_, ' ', 64); rt_[64] = 0; rt_ab_ = -1; rt_seg_ = 0; rt_len_ = 0; rt_shown_[0] = 0;
         ms_ = -1; af1_ = af2_ = 0;
+        rt_u16_[0] = 0; rt_u16_len_ = 0;                               // clearRadioText (:95); theAlfabet is not touched by reset ()
     }
-    void show_text(int len) {                                          // prepareText :262-278, without the alphabet mapping
+    void show_text(int len) {                                          // prepareText :298-315; rt_shown_ = the same characters unmapped
         // the reference emits characters v[0 .. len-2] (it walks pairs, dropping the last one) and trims the result
         int n = len - 1; if (n < 0) n = 0;
         auto sp = [](char c) { return c == ' ' || (c >= 0x09 && c <= 0x0D); };     // QString::trimmed
         int a = 0; while (a < n && sp(rt_[a])) a++;
         int e = n; while (e > a && sp(rt_[e - 1])) e--;
         std::memcpy(rt_shown_, rt_ + a, (size_t)(e - a)); rt_shown_[e - a] = 0; rt_len_ = e - a;
+        rt_u16_len_ = rds_prepare_text(reinterpret_cast<const uint8_t *>(rt_), len, &alfabet_, rt_u16_, 65);
     }
     void decode_group() {                                              // decode :100-165
         groups_ok_++;
@@ -138,7 +172,7 @@ private:
             di_ |= ((blk_[1] >> 2) & 1) << seg;
         } else if (last_type_ == 2) {                                  // Handle_RadioText :222-281
             const int ab = (blk_[1] >> 4) & 1; const int seg = blk_[1] & 0xF;
-            if (rt_ab_ != ab) { rt_ab_ = ab; rt_seg_ = 0; std::memset(rt_, ' ', 64); rt_[64] = 0; rt_shown_[0] = 0; rt_len_ = 0; }
+            if (rt_ab_ != ab) { rt_ab_ = ab; rt_seg_ = 0; std::memset(rt_, ' ', 64); rt_[64] = 0; rt_shown_[0] = 0; rt_len_ = 0; rt_u16_[0] = 0; rt_u16_len_ = 0; }
             char *f = &rt_[4 * seg];
             f[0] = (char)(blk_[2] >> 8); f[1] = (char)(blk_[2] & 0xFF); f[2] = (char)(blk_[3] >> 8); f[3] = (char)(blk_[3] & 0xFF);
             rt_seg_ |= 1u << seg;
@@ -153,6 +187,7 @@ private:
         info_.groups_decoded = groups_ok_; info_.crc_errors = n_crc_err_; info_.sync_errors = n_sync_err_; info_.bit_error_rate = ber_;
         std::memcpy(info_.station_label, ps_, 9); std::memcpy(info_.radio_text, rt_shown_, 65);
         info_.af1_khz = af1_; info_.af2_khz = af2_; info_.music_speech = ms_; info_.di_code = di_;
+        std::memcpy(info_.radio_text_ucs2, rt_u16_, sizeof(rt_u16_)); info_.radio_text_ucs2_len = (int16_t)rt_u16_len_;
     }
     // synchroniser
     uint32_t stream_; bool synced_; int cur_; float ber_; uint32_t bits_in_blk_, bits_done_, bit_err_; int n_crc_err_, n_sync_err_;
@@ -160,6 +195,7 @@ private:
     // groups
     int32_t pi_, pty_, last_type_ = -1, groups_ok_ = 0, ms_, af1_, af2_; uint32_t ps_seg_, di_, rt_seg_; int rt_ab_, rt_len_;
     char ps_[9], rt_[65], rt_shown_[65];
+    uint16_t rt_u16_[65] = {0}; int rt_u16_len_ = 0; uint8_t alfabet_ = 0;
     fmx_rds_info info_;
 };
 

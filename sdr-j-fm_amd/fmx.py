@@ -30,7 +30,7 @@ EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
     "fmx_get_meta", "fmx_get_tap", "fmx_get_peaks",
-    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_last_rds_samples", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
+    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_last_rds_samples", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
 
@@ -63,7 +63,13 @@ class FmxRdsInfo(C.Structure):
     _fields_ = [("synchronized", C.c_int32), ("pi_code", C.c_int32), ("pty_code", C.c_int32), ("last_group_type", C.c_int32),
                 ("groups_decoded", C.c_int32), ("crc_errors", C.c_int32), ("sync_errors", C.c_int32), ("bit_error_rate", C.c_float),
                 ("station_label", C.c_char * 9), ("radio_text", C.c_char * 65), ("af1_khz", C.c_int32), ("af2_khz", C.c_int32),
-                ("music_speech", C.c_int32), ("di_code", C.c_int32)]
+                ("music_speech", C.c_int32), ("di_code", C.c_int32),
+                ("radio_text_ucs2", C.c_uint16 * 65), ("radio_text_ucs2_len", C.c_int16)]
+
+    @property
+    def radio_text_unicode(self):
+        """The radio text as the reference's setRadioText receives it (prepareText + mapEBUtoUnicode, trimmed)."""
+        return "".join(chr(v) for v in self.radio_text_ucs2[:self.radio_text_ucs2_len])
 
 
 class FmxProfile(C.Structure):
@@ -116,6 +122,12 @@ def load_library(path=None):
     L.fmx_rds_decode.argtypes = [vp, i32, C.POINTER(FmxRdsInfo)]
     L.fmx_rds_decode_bits.restype = C.c_int
     L.fmx_rds_decode_bits.argtypes = [C.POINTER(C.c_uint8), i32, C.POINTER(FmxRdsInfo)]
+    L.fmx_rds_pty_name.restype = C.c_char_p
+    L.fmx_rds_pty_name.argtypes = [i32, i32]
+    L.fmx_rds_map_char.restype = C.c_uint16
+    L.fmx_rds_map_char.argtypes = [C.c_uint8, C.c_uint8]
+    L.fmx_rds_prepare_text.restype = i32
+    L.fmx_rds_prepare_text.argtypes = [C.POINTER(C.c_uint8), i32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), i32]
     L.fmx_rds_bits.restype = C.c_int
     L.fmx_rds_bits.argtypes = [vp, i32, C.POINTER(C.c_uint8), i32, C.POINTER(i32)]
     L.fmx_rds_symbols.restype = C.c_int

@@ -215,9 +215,9 @@ void fmProcessor::feed_rds() {
     if (now.pi_code != (first ? 0 : was.pi_code)) emit setPiCode(now.pi_code);                                     // rds-groupdecoder.cpp:100-125
     if (now.pty_code >= 0 && (first || now.pty_code != was.pty_code)) emit setPTYCode(now.pty_code, pty_name(now.pty_code, I.core.get_ptyLocale()));
     if (first || std::memcmp(now.station_label, was.station_label, sizeof(now.station_label)) != 0)
-        if (now.station_label[0]) emit setStationLabel(ebu_latin_to_qstring(now.station_label));
-    if (first || std::strcmp(now.radio_text, was.radio_text) != 0) {
-        if (now.radio_text[0]) emit setRadioText(ebu_latin_to_qstring(now.radio_text));
+        if (now.station_label[0]) emit setStationLabel(QString(now.station_label));            // QString (stationLabel) rds-groupdecoder.cpp:185-186
+    if (first || now.radio_text_ucs2_len != was.radio_text_ucs2_len || std::memcmp(now.radio_text_ucs2, was.radio_text_ucs2, sizeof(now.radio_text_ucs2)) != 0) {
+        if (now.radio_text_ucs2_len > 0) emit setRadioText(radio_text_qstring(now));               // prepareText -> setRadioText (outString. trimmed ())
         else if (!first) emit clearRadioText();
     }
     if ((now.af1_khz || now.af2_khz) && (first || now.af1_khz != was.af1_khz || now.af2_khz != was.af2_khz)) emit setAFDisplay(now.af1_khz, now.af2_khz);
@@ -250,43 +250,14 @@ void fmProcessor::run() {
     }
 }
 
-// ---- RDS character set and programme type names ------------------------------------------------------------------
-QString ebu_latin_to_qstring(const char *s) {
-    // EN 50067 annex E, table E.1, codes 0x80 .. 0xFF (0x20 .. 0x7D are ISO 646 apart from the four listed below)
-    static const char16_t hi[128] = {
-        u'á', u'à', u'é', u'è', u'í', u'ì', u'ó', u'ò', u'ú', u'ù', u'Ñ', u'Ç', u'Ş', u'ß', u'¡', u'Ĳ',
-        u'â', u'ä', u'ê', u'ë', u'î', u'ï', u'ô', u'ö', u'û', u'ü', u'ñ', u'ç', u'ş', u'ǧ', u'ı', u'ĳ',
-        u'ª', u'α', u'©', u'‰', u'Ǧ', u'ě', u'ň', u'ő', u'π', u'€', u'£', u'$', u'←', u'↑', u'→', u'↓',
-        u'º', u'¹', u'²', u'³', u'±', u'İ', u'ń', u'ű', u'µ', u'¿', u'÷', u'°', u'¼', u'½', u'¾', u'§',
-        u'Á', u'À', u'É', u'È', u'Í', u'Ì', u'Ó', u'Ò', u'Ú', u'Ù', u'Ř', u'Č', u'Š', u'Ž', u'Ð', u'Ŀ',
-        u'Â', u'Ä', u'Ê', u'Ë', u'Î', u'Ï', u'Ô', u'Ö', u'Û', u'Ü', u'ř', u'č', u'š', u'ž', u'đ', u'ŀ',
-        u'Ã', u'Å', u'Æ', u'Œ', u'ŷ', u'Ý', u'Õ', u'Ø', u'Þ', u'Ŋ', u'Ŕ', u'Ć', u'Ś', u'Ź', u'Ŧ', u'ð',
-        u'ã', u'å', u'æ', u'œ', u'ŵ', u'ý', u'õ', u'ø', u'þ', u'ŋ', u'ŕ', u'ć', u'ś', u'ź', u'ŧ', u' ' };
-    QString out;
-    for (const unsigned char *p = reinterpret_cast<const unsigned char *>(s); *p; p++) {
-        const unsigned char c = *p;
-        if (c >= 0x80) out.append(QChar(hi[c - 0x80]));
-        else if (c == 0x24) out.append(QChar(0x00a4));      // currency sign
-        else if (c == 0x5e) out.append(QChar(0x2015));      // horizontal bar
-        else if (c == 0x60) out.append(QChar(0x2016));      // double vertical line
-        else if (c == 0x7e) out.append(QChar(0x00af));      // macron
-        else if (c < 0x20) out.append(QChar(' '));
-        else out.append(QChar(c));
-    }
-    return out;
+// ---- RDS text: the library does the reference's byte work (fmx_rds_pty_name = pty_table [pty][locale] ebu-codetables.c:4-37;
+// radio_text_ucs2 = prepareText + mapEBUtoUnicode, rds-groupdecoder.cpp:298-315); here only the QString wrapping -------------------
+QString radio_text_qstring(const fmx_rds_info &info) {
+    return QString::fromUtf16(reinterpret_cast<const char16_t *>(info.radio_text_ucs2), info.radio_text_ucs2_len);
 }
-
 QString pty_name(int pty, int ptyLocale) {
-    static const char *eu[32] = { "None", "News", "Current Affairs", "Information", "Sport", "Education", "Drama", "Culture", "Science",
-        "Varied", "Pop Music", "Rock Music", "Easy Listening", "Light Classical", "Serious Classical", "Other Music", "Weather", "Finance",
-        "Children's Programmes", "Social Affairs", "Religion", "Phone In", "Travel", "Leisure", "Jazz Music", "Country Music",
-        "National Music", "Oldies Music", "Folk Music", "Documentary", "Alarm Test", "Alarm" };
-    static const char *us[32] = { "None", "News", "Information", "Sports", "Talk", "Rock", "Classic Rock", "Adult Hits", "Soft Rock", "Top 40",
-        "Country", "Oldies", "Soft", "Nostalgia", "Jazz", "Classical", "Rhythm and Blues", "Soft Rhythm and Blues", "Foreign Language",
-        "Religious Music", "Religious Talk", "Personality", "Public", "College", "Spanish Talk", "Spanish Music", "Hip Hop", "Unassigned",
-        "Unassigned", "Weather", "Emergency Test", "Emergency" };
-    if (pty < 0 || pty > 31) return QString();
-    return QString::fromLatin1(ptyLocale == 1 ? us[pty] : eu[pty]);
+    const char *n = fmx_rds_pty_name(pty, ptyLocale);
+    return n ? QString(n) : QString();             // (QString (const char *) = fromUtf8, what setPTYCode (int, const QString &) receives)
 }
 
 }  // namespace fmx_qt

@@ -138,9 +138,9 @@ private:
     SMetaData metaData{};
 };
 
-// RDS characters (EN 50067 annex E, code table E.1: the basic EBU Latin set) as Unicode
-QString ebu_latin_to_qstring(const char *s);
-// programme type names (EN 50067 annex F; ptyLocale 1: the RBDS names)
+// the radio text as the reference's setRadioText receives it (fmx_rds_info::radio_text_ucs2)
+QString radio_text_qstring(const fmx_rds_info &info);
+// programme type names: the reference's pty_table [pty][ptyLocale] (fmx_rds_pty_name)
 QString pty_name(int pty, int ptyLocale);
 
 }  // namespace fmx_qt

@@ -230,6 +230,9 @@ def ref():
                                C.c_int, C.c_int, C.c_int]),
         "ref_chain_free": (None, [vp]),
         "ref_chain_run": (lng, [vp, c_float_p, lng, c_float_p, c_float_p, c_float_p, c_float_p]),
+        "ref_rdsgroup_fields": (None, [C.POINTER(C.c_uint16), C.POINTER(C.c_int32)]),
+        "ref_map_ebu": (C.c_uint16, [C.c_uint8, C.c_uint8]),
+        "ref_pty_name": (C.c_char_p, [i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

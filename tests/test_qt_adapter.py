@@ -92,10 +92,19 @@ def test_qt_adapter_run(tmp_path, ol, fmx_amd):
 @pytest.mark.gpu
 def test_qt_adapter_rds_signals(tmp_path, ol, fmx_amd):
     """RDS on: the decided symbols reach the IQ ring (iqBufferLoaded every 101), and the group decoder's picture arrives as the
-    reference's signals: PI 0xD3A1, PTY with its name, the PS name and the radio text of the generated programme."""
+    reference's signals: PI 0xD3A1, PTY with its name, the PS name and the radio text of the generated programme -- a text with
+    accented characters and an alphabet-switch pair (0x0F 0x0F), which must arrive as rdsGroupDecoder::prepareText would hand it to
+    setRadioText (rds-groupdecoder.cpp:298-315: the pair leaves a blank and swallows the character behind it; the reference's own
+    character table, tests/test_rds_text.py)."""
+    from test_rds_text import G as RDS_GOLD, prepare_text_reference_loop
     exe = build_demo(str(tmp_path))
-    nblocks = 520                                             # 3.7 s: block sync + a full pass over the 35-group programme
-    prog = dict(pi=0xD3A1, pty=10, ps="FMX-AMD ", text="HIP KERNELS ON MI355X - RDS OK")
+    nblocks = 520                                             # 3.7 s: block sync + a full pass over the programme's groups
+    raw = b"Caf\x82 \x0f\x0fM\x97nchen \x91 - RDS OK 5\xa9"
+    prog = dict(pi=0xD3A1, pty=10, ps="FMX-AMD ", text=raw.decode("latin1"))
+    padded = raw + b"\r"
+    padded += b" " * (-len(padded) % 4)
+    want_text, _ = prepare_text_reference_loop(list(padded + b" " * (64 - len(padded)) + b"\0"), 64, 0, lambda a, c: int(RDS_GOLD["ebu_map"][a][c]))
+    assert want_text == "Café  önchen ä - RDS OK 5X"
     bits = ol.rds_programme_bits(**prog)
     iq = ol.synth_iq(16384 * nblocks, rds=1, rdsLevel=0.05, rds_payload=bits)
     iq.tofile(str(tmp_path / "iq.f32"))
@@ -103,7 +112,7 @@ def test_qt_adapter_rds_signals(tmp_path, ol, fmx_amd):
     print("\n[qt adapter, RDS]", out.strip())
     kv, txt = parse(out)
     assert int(kv["rdssync"]) == 1 and int(kv["pi"]) == prog["pi"] and int(kv["pty"]) == prog["pty"]
-    assert txt["ptyname"] == "Pop Music" and txt["label"] == prog["ps"] and txt["text"].strip() == prog["text"]
+    assert txt["ptyname"] == "Pop Music" and txt["label"] == prog["ps"] and txt["text"] == want_text
     assert int(kv["groups"]) >= 20 and int(kv["crc"]) <= 2
     nsym = int(kv["iqring"])
     assert abs(nsym - 16384 * nblocks / 2304000.0 * 1187.5) < 30          # one constellation point per RDS bit
