@@ -202,8 +202,11 @@ __global__ void rds_collect(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, i
     const int64_t r = row0 + q, n = n0 + q;
     const float demod = B.w_dem[tap_idx(B, r, ch, G.pitch)];
     const float cur = B.w_cur[tap_idx(B, r, ch, G.pitch)];             // unconstrained pilot phase; PI_Constrain gives currentPilotPhase
-    Rb.in_blk[(size_t)ch * RBLK + (int)(n % RBLK)] = demod;
-    float c = cur;
+    // Channels 2p and 2p + 1 ride through the block transforms as the real and imaginary part of one row: a non-finite sample of one
+    // (the raw IQ formats cannot carry one, float32 input can) would turn the whole pair's spectrum into NaN and leave the
+    // neighbour's slicer state NaN for good.  It enters the block as zero instead.
+    Rb.in_blk[(size_t)ch * RBLK + (int)(n % RBLK)] = (fabsf(demod) < __builtin_inff()) ? demod : 0.f;
+    float c = (fabsf(cur) < __builtin_inff()) ? cur : 0.f;
     {   // PI_Constrain fm-constants.h:148-158 (arguments are within (-2pi, 4pi))
         const double v = (double)c;
         if (!(c >= 0.f && c < 6.2831855f)) c = (v >= 6.283185307179586) ? (float)(v - 6.283185307179586) : (float)(v + 6.283185307179586);

@@ -221,3 +221,40 @@ def test_newton_solver_batch_equals_single_and_reports_rounds(fmx_amd, ol):
           f"PCM of the two against each other {rms(out[4][0][0] - out[65][0][0]):.2e}")
     assert out[4][1] <= 2e-6
     assert out[65][1] <= 1e-4
+
+
+def test_non_finite_samples_of_one_rds_channel_leave_its_pair_partner_alone(fmx_amd, ol):
+    """channels 2p and 2p + 1 share one complex row of the RDS block transforms.  NaN / Inf bursts in the IQ stream
+    of channel 0 must not reach channel 1: its RDS bit stream and PCM equal those of a run without the bursts, bit for bit, and
+    channel 0 itself recovers (bits equal to the clean run's again once the burst has left its filters)."""
+    block = 16384 * 16
+    n = int(2.4 * 2304000) // block * block
+    payloads = [ol.rds_programme_bits(pi=0xD3A1, ps="FMX-AMD ", text="CHANNEL ZERO"), ol.rds_programme_bits(pi=0x2468, ps="CHAN TWO", text="SECOND STREAM")]
+    iqs = [ol.synth_iq(n, rds=1, rdsLevel=0.05, rds_payload=p) for p in payloads]
+    clean = np.stack(iqs)
+    dirty = clean.copy()
+    burst0 = int(0.9 * 2304000)
+    dirty[0, burst0:burst0 + 3000, 0] = np.nan
+    dirty[0, burst0 + 5000:burst0 + 5200, 1] = np.inf
+    dirty[0, burst0 + 9000:burst0 + 9100, :] = -np.inf
+
+    def run(iq):
+        f = fmx_amd.Fmx(2, streams=2, stream_of_channel=[0, 1], max_block=block)
+        gui_defaults(f)
+        f.set_param(M.P_RDS_MODE, 2)
+        f.set_param(M.P_DC_REMOVE, 0)          # (the RF DC estimate is a recurrence: a NaN sample would stay in it for good, in the reference too)
+        pcm = []
+        for i in range(0, n, block):
+            pcm.append(f.process_host(iq[:, i:i + block, :]))
+        bits = [f.rds_bits(c, 8192) for c in range(2)]
+        return np.concatenate(pcm, axis=1), bits
+
+    pcm_c, bits_c = run(clean)
+    pcm_d, bits_d = run(dirty)
+    assert len(bits_c[1]) > 2000 and np.array_equal(bits_c[1], bits_d[1])                  # the partner: untouched
+    assert np.array_equal(pcm_c[1], pcm_d[1])
+    assert np.isfinite(pcm_d[1]).all()
+    # the channel with the bursts: the same number of bits, equal again behind the burst (two 32000-sample block filters + slicer pull-in)
+    assert len(bits_d[0]) == len(bits_c[0])
+    tail = len(bits_c[0]) - 600
+    assert np.array_equal(bits_c[0][tail:], bits_d[0][tail:])
