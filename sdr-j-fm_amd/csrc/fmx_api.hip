@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -74,7 +75,9 @@ struct fmx_handle_s {
     std::vector<ChanUser> user;
     std::vector<ChanParams> params;          // host mirror
     bool params_dirty = true, sets_dirty = true;
-    bool gain_dirty = true;                                          // volume / balance set since the last call (and before the first): gain_fix_kernel runs
+    bool gain_dirty = true;                                          // volume / balance set since the last call (and before the first); under mtx
+    bool gain_pending = false;                                       // ... taken over by flush_mailbox together with the settings themselves (processing
+                                                                     // thread only): gain_fix_kernel runs in the first call that produces frames
     float *d_audio_lp = nullptr, *d_rs_taps = nullptr;
     float2 *d_audio_spec = nullptr;               // the audio low-pass and the resampler alone (gain_fix_kernel)
     // unique tap sets
@@ -106,6 +109,8 @@ struct fmx_handle_s {
     std::vector<int32_t> rds_read;          // per channel: bits already handed out by fmx_rds_bits
     std::vector<int32_t> rds_read_dec;      // ... and by fmx_rds_decode
     std::vector<int32_t> rds_read_sym;      // ... symbols handed out by fmx_rds_symbols
+    std::atomic<int32_t> rds_gen{0};        // counts rds_restart: a consumer that saw an older generation starts over (its own read position and,
+    std::vector<int32_t> rds_gen_dec, rds_gen_sym;   // for fmx_rds_decode, the channel's block synchroniser / group decoder), however late it polls
     std::vector<fmx::RdsGroupDecoderHost> rds_dec;
     int64_t last_m0 = 0, last_m1 = 0;       // 24 kS/s outputs of the last call
     std::vector<void *> rds_ptrs, tail_ptrs;
@@ -427,7 +432,8 @@ int rds_restart(fmx_handle h) {
     s0.c_limit = (float)(2 * design::kPi * (double)10.0f / (double)(float)24000);
     std::vector<RdsState> init(C, s0);
     HIPCHK(hipMemcpy(R.state, init.data(), sizeof(RdsState) * C, hipMemcpyHostToDevice));
-    h->rds_read.assign(C, 0);                       // the bit counters restart at 0 (fmx_rds_decode sees have < 0 and starts over)
+    h->rds_read.assign(C, 0);                       // the bit counters restart at 0
+    h->rds_gen.fetch_add(1);                        // fmx_rds_decode / fmx_rds_symbols start over too (their own threads: they compare generations)
     return FMX_OK;
 }
 
@@ -435,6 +441,7 @@ constexpr int PLL_SEQ_AUTO_MAX = 64;   // FMX_P_PLL_SOLVER = 0: handles up to th
 
 int flush_mailbox(fmx_handle h) {
     std::lock_guard<std::mutex> lk(h->mtx);
+    if (h->gain_dirty) { h->gain_pending = true; h->gain_dirty = false; }   // (a change arriving behind this point belongs to the next call, flag and value)
     if (h->sets_dirty) { int rc = ensure_sets(h); if (rc) return rc; h->params_dirty = true; }
     bool any_lo = false;
     for (auto &p : h->params) any_lo |= (p.lo_freq != 0);
@@ -617,7 +624,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         }
     }
     if (prof) HIPCHK(hipEventRecord(pr.e[2], s));
-    if (h->gain_dirty && G.M1 > G.M0) { G.gain_fix = 1; launch_gain_fix(h->T, h->B, G, h->channels, s); FMX_LAUNCHED(); h->gain_dirty = false; }
+    if (h->gain_pending && G.M1 > G.M0) { G.gain_fix = 1; launch_gain_fix(h->T, h->B, G, h->channels, s); FMX_LAUNCHED(); h->gain_pending = false; }
     if (!h->cv_nt) launch_audio(h->T, h->B, G, d_pcm, h->channels, s);
     else {
         // the audio stage writes its 48 kHz frames behind the converter's history; theConverter's output goes to the caller
@@ -1031,6 +1038,13 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     }
     std::lock_guard<std::mutex> lk(h->mtx);
     const int c0 = channel < 0 ? 0 : channel, c1 = channel < 0 ? h->channels : channel + 1;
+    if (id == FMX_P_RDS_MODE && iv != 0 && h->rds_start >= 0) {
+        // RDS already off everywhere (set since the last call, no call in between): that is "off everywhere first" -- the block phase
+        // ends now, this enable restarts the RDS path at the next call (what flush_mailbox would have done with a call in between)
+        bool any = false;
+        for (auto &p : h->params) any |= (p.rds_mode != 0);
+        if (!any) { h->rds_start = -1; h->rds_rearm = true; }
+    }
     if (id == FMX_P_RDS_MODE && iv != 0 && h->rds_start >= 0 && h->rds_start != h->g_total / DECIM) {
         // The two 32768-point overlap-add filters of the RDS front end run on ONE block phase for the whole batch (all three
         // decoders sit behind them): while other channels are decoding, a channel cannot join in the middle of a block run.
@@ -1295,8 +1309,11 @@ int fmx_rds_symbols(fmx_handle h, int32_t channel, float *iq, int32_t capacity, 
     RdsState st;
     HIPCHK(hipMemcpy(&st, h->R.state + channel, sizeof(st), hipMemcpyDeviceToHost));
     int32_t &rd = h->rds_read_sym[(size_t)channel];
+    if (h->rds_gen_sym.size() != (size_t)h->channels) h->rds_gen_sym.assign((size_t)h->channels, 0);
+    const int32_t gen = h->rds_gen.load();
+    if (h->rds_gen_sym[(size_t)channel] != gen) { h->rds_gen_sym[(size_t)channel] = gen; rd = 0; }   // the RDS path was restarted (rds_restart)
     int32_t have = st.nbits - rd;
-    if (have < 0) { rd = 0; have = st.nbits; }                                          // the RDS path was restarted
+    if (have < 0) { rd = 0; have = st.nbits; }
     if (have > RDS_SYM_CAP) { rd = st.nbits - RDS_SYM_CAP; have = RDS_SYM_CAP; }        // ring overrun: oldest symbols lost
     const int32_t take = have < capacity ? have : capacity;
     if (take > 0 && iq) {
@@ -1337,8 +1354,11 @@ int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {
         RdsState st;
         HIPCHK(hipMemcpy(&st, h->R.state + channel, sizeof(st), hipMemcpyDeviceToHost));
         int32_t &rd = h->rds_read_dec[(size_t)channel];
+        if (h->rds_gen_dec.size() != (size_t)h->channels) h->rds_gen_dec.assign((size_t)h->channels, 0);
+        const int32_t gen = h->rds_gen.load();
+        if (h->rds_gen_dec[(size_t)channel] != gen) { h->rds_gen_dec[(size_t)channel] = gen; rd = 0; D.reset_all(); }   // the RDS path was restarted (rds_restart)
         int32_t have = st.nbits - rd;
-        if (have < 0) { rd = 0; have = st.nbits; D.reset_all(); }                      // the RDS path was restarted (rds_restart): new bit count
+        if (have < 0) { rd = 0; have = st.nbits; D.reset_all(); }
         if (do_reset) {
             // rdsGroupDecoder::reset: PI / PTY / labels back to unknown.  The reference resets between two blocks of samples;
             // here the decoder runs behind the slicer, so the bits still pending belong to the time before the reset (the

@@ -78,26 +78,29 @@ private:
             if (std::fread(ck, 1, 8, file_) != 8) return false;
             const uint32_t size = u32(ck + 4);
             if (std::memcmp(ck, "fmt ", 4) == 0) {
+                if (size < 16 || size > 4096) return false;                       // (the header is not trusted: a fmt chunk is 16 .. 40 bytes)
                 std::vector<uint8_t> f(size);
-                if (size < 16 || std::fread(f.data(), 1, size, file_) != size) return false;
+                if (std::fread(f.data(), 1, size, file_) != size) return false;
                 tag = u16(&f[0]); ch = u16(&f[2]); inputRate_ = (int32_t)u32(&f[4]); bits = u16(&f[14]);
                 if (tag == 0xFFFE && size >= 26) tag = u16(&f[24]);              // WAVE_FORMAT_EXTENSIBLE: the sub-format's first word
                 have_fmt = true;
                 if (size & 1) std::fseek(file_, 1, SEEK_CUR);
             } else if (std::memcmp(ck, "data", 4) == 0) {
                 dataStart_ = std::ftell(file_);
-                std::fseek(file_, 0, SEEK_END);
+                if (dataStart_ < 0 || std::fseek(file_, 0, SEEK_END) != 0) return false;
                 const long end = std::ftell(file_);
+                if (end < dataStart_) return false;
                 dataBytes_ = std::min<int64_t>((int64_t)size, (int64_t)end - dataStart_);
                 break;
             } else if (std::fseek(file_, (long)size + (long)(size & 1), SEEK_CUR) != 0) return false;
         }
         if (!have_fmt || (ch != 1 && ch != 2)) return false;
+        if (inputRate_ <= 0 || inputRate_ > 100000000) return false;            // (a rate of 0 or beyond 2^31 would make the 10 ms period empty / negative)
         if (tag == 1 && bits == 16) fmt_ = 0; else if (tag == 1 && bits == 8) fmt_ = 1; else if (tag == 1 && bits == 32) fmt_ = 2;
         else if (tag == 3 && bits == 32) fmt_ = 3; else return false;
         channels_ = (int)ch; bytesPerValue_ = (int)bits / 8;
         frames_ = dataBytes_ / ((int64_t)bytesPerValue_ * channels_);
-        std::fseek(file_, dataStart_, SEEK_SET);
+        if (std::fseek(file_, dataStart_, SEEK_SET) != 0) return false;
         return frames_ > 0;
     }
     // filehulp.cpp:127-147: `length` floats wanted; returns the floats delivered; wraps to the start after a short read

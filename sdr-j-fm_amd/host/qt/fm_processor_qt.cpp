@@ -157,7 +157,8 @@ void fmProcessor::feed_lf_scope() {
     // RDS views: an entry per rdsDecimator output (RDS on) or a zero per fm sample (RDS off), :566-589
     std::vector<std::complex<float>> rdsv;
     int64_t nrds = 0;
-    if (rdsView && rdsMode.load() != 0) {
+    const bool rdsOn = rdsMode.load() != 0;          // read ONCE per block: the GUI thread may switch RDS off while the loop below runs
+    if (rdsView && rdsOn) {
         nrds = fmx_last_rds_samples(h);
         if (nrds > 0) {
             I.tapbuf.resize((size_t)(2 * nrds));
@@ -171,7 +172,7 @@ void fmProcessor::feed_lf_scope() {
     // the reference's counters, sample by sample
     int64_t rdsPushed = 0;
     for (int64_t k = 0; k < nfm; k++) {
-        if (rdsView && rdsMode.load() != 0) {
+        if (rdsView && rdsOn) {
             // the decimator delivers one output per eight fm samples: spread this block's outputs evenly over it
             const int64_t due = ((k + 1) * nrds) / nfm;
             while (rdsPushed < due) I.spectrumBuffer_lf.push_back(rdsv[(size_t)rdsPushed++]);

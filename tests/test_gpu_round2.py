@@ -163,6 +163,17 @@ def test_rds_off_everywhere_then_on_again(fmx_amd, ol):
         info = f.rds_decode(c)
         assert info.synchronized == 1 and info.pi_code == p["pi"] and info.station_label.decode() == p["ps"], c
         assert info.crc_errors <= 2
+    # off everywhere and on again with NO call in between (a paused device, a programmatic reconfiguration): the same restart, no
+    # error; a consumer that polls only at the very end still gets a fresh synchroniser / decoder picture
+    g_before = [f.rds_decode(c).groups_decoded for c in range(2)]
+    f.set_param(M.P_RDS_MODE, 0)
+    f.set_param(M.P_RDS_MODE, 2)
+    for i in range(0, n, block):
+        f.process_host(iq[i:i + block])
+    for c in range(2):
+        info = f.rds_decode(c)
+        assert info.synchronized == 1 and info.pi_code == p["pi"] and info.station_label.decode() == p["ps"], c
+        assert 8 <= info.groups_decoded < g_before[c] + 8 and info.crc_errors <= 2      # counted from the restart, not on top of the old run
 
 
 def _run_layout(fmx_amd, monkeypatch, layout, nch, iq, block, setup):
