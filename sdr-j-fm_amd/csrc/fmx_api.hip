@@ -599,6 +599,9 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         else launch_front(h->T, h->B, G, d_iq, h->channels, s);
     }
     FMX_LAUNCHED();
+    static const bool prof_double = getenv("FMX_PROF_DOUBLE") != nullptr;    // (diagnostic: a throw-away event in front of each boundary event)
+    hipEvent_t pdummy = nullptr;
+    if (prof && prof_double) { HIPCHK(hipEventCreate(&pdummy)); HIPCHK(hipEventRecord(pdummy, s)); }
     if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
     {
         static const bool serial = getenv("FMX_SERIAL_STAGE_B") != nullptr;     // diagnostics: no side streams
@@ -623,6 +626,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
             h->last_m0 = n0 / 8; h->last_m1 = (n0 + (G.J1 - G.J0)) / 8;
         }
     }
+    if (prof && prof_double) HIPCHK(hipEventRecord(pdummy, s));
     if (prof) HIPCHK(hipEventRecord(pr.e[2], s));
     if (h->gain_pending && G.M1 > G.M0) { G.gain_fix = 1; launch_gain_fix(h->T, h->B, G, h->channels, s); FMX_LAUNCHED(); h->gain_pending = false; }
     if (!h->cv_nt) launch_audio(h->T, h->B, G, d_pcm, h->channels, s);

@@ -240,7 +240,7 @@ struct WG {
 // one step of the PSS integrator and its state machines, every lane / thread in any state (fm-processor.cpp:699-718,
 // stereo-separation.cpp:84-109); the replay path runs it sample by sample
 // ---------------------------------------------------------------------------------------------------------------------
-struct PssSt { float acc, mean, pdp; int lock_cnt, unlock_cnt; bool minimized; };
+struct PssSt { float acc, mean, pdp; int lock_cnt, unlock_cnt; int minimized; };   // (minimized: 0 / 1; an int so that the struct has no padding bytes, which copies would move through scratch)
 __device__ __forceinline__ float pss_step(PssSt &s, float alpha, float la, float keep, bool locked, int tag, float err) {
     const bool rst = !locked;                      // unlocked: pilotDelayPSS = 0; pPSS.reset() (fm-processor.cpp:699-702)
     s.pdp = rst ? 0.f : s.pdp; s.acc = rst ? 0.f : s.acc; s.mean = rst ? 0.f : s.mean;
@@ -321,6 +321,9 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
     float *er = reinterpret_cast<float *>(X);                        // [FB_W] PSS error per call of the segment; replay paths: inputs in, results out
     int *pk = reinterpret_cast<int *>(X) + FB_W;                     // [FB_W] replay path: ((tag + 2) << 1) | locked per sample
     static_assert(2 * FB_W * 4 <= sizeof(float2) * fftc::LDS_N, "er and pk live in the convolution buffer");
+    // demod and pilot phase of the segment wait here while the convolution has the registers (they are not needed in it; kept in
+    // registers they pushed the kernel over its budget of 168: spills, i.e. scratch memory for every wave)
+    __shared__ __attribute__((aligned(8))) float park_dem[FB_W], park_cur[FB_W];
     const int ch = blockIdx.x;
     if (ch >= C) return;
     WG wg; wg.L = &lds; wg.tid = threadIdx.x; wg.lane = threadIdx.x & 63; wg.wv = threadIdx.x >> 6; wg.sl = 0;
@@ -765,6 +768,11 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
         const int smask = G.sring_mask;
         if (pss_on) {
+#pragma unroll
+            for (int i = 0; i < FB_K; i += 2) {
+                *reinterpret_cast<float2 *>(&park_dem[j0 + i]) = make_float2(dem[i], dem[i + 1]);
+                *reinterpret_cast<float2 *>(&park_cur[j0 + i]) = make_float2(cur[i], cur[i + 1]);
+            }
             const int64_t i0 = pss_count0 + calls_before;                            // call index of the segment's first output
             float2 a[8];
             const int64_t first = i0 - (PSS_DELAY + PSS_TAPS - 1);                   // s index of window entry 0
@@ -790,6 +798,11 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             for (int p = 0; p < 8; p++) {
                 const int m = tid + FB_T * p - (PSS_TAPS - 1);
                 if (m >= 0 && m < FB_W) er[m] = a[p].x * a[p].y;
+            }
+#pragma unroll
+            for (int i = 0; i < FB_K; i += 2) {
+                const float2 d2 = *reinterpret_cast<const float2 *>(&park_dem[j0 + i]), c2 = *reinterpret_cast<const float2 *>(&park_cur[j0 + i]);
+                dem[i] = d2.x; dem[i + 1] = d2.y; cur[i] = c2.x; cur[i + 1] = c2.y;
             }
         }
         __syncthreads();
@@ -942,13 +955,16 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 }
                 SB_FT(25);
                 wg.reduce_max4(lastS, lastN, d3, d4);
-                e.mean = mean_next;                                  // (behind a full segment; the owner's own value replaces it below)
-                e.acc = aend; e.pdp = aend; e.minimized = mz;
-                const bool all_small = lastN < 0, any_small = lastS >= 0;
-                if (mz) { e.lock_cnt = all_small ? s.lock_cnt : 0; e.unlock_cnt = any_small ? (w - 1 - lastS) : s.unlock_cnt + w; }
-                else { e.lock_cnt = all_small ? s.lock_cnt + w : (w - 1 - lastN); e.unlock_cnt = any_small ? 0 : s.unlock_cnt; }
-                // (reduce_max4's barrier: everybody has its copy of the state in front of the segment)
-                if (tid == 0) { cy.ps.acc = e.acc; cy.ps.pdp = e.pdp; cy.ps.minimized = e.minimized; cy.ps.lock_cnt = e.lock_cnt; cy.ps.unlock_cnt = e.unlock_cnt; }
+                // (reduce_max4's barrier: everybody has its copy of the state in front of the segment; the two counters are only carried
+                // by thread 0, which reads them again here instead of every thread keeping them in registers through the phase)
+                if (tid == 0) {
+                    const int lc0 = cy.ps.lock_cnt, uc0 = cy.ps.unlock_cnt;
+                    const bool all_small = lastN < 0, any_small = lastS >= 0;
+                    int lc, uc;
+                    if (mz) { lc = all_small ? lc0 : 0; uc = any_small ? (w - 1 - lastS) : uc0 + w; }
+                    else { lc = all_small ? lc0 + w : (w - 1 - lastN); uc = any_small ? 0 : uc0; }
+                    cy.ps.acc = aend; cy.ps.pdp = aend; cy.ps.minimized = mz ? 1 : 0; cy.ps.lock_cnt = lc; cy.ps.unlock_cnt = uc;
+                }
                 if (owner) cy.ps.mean = mean_end;
             } else if (nocall) {
                 // nobody calls process_sample: an unlocked sample clears everything, a stereo sample without PSS clears pilotDelayPSS
