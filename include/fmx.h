@@ -105,6 +105,8 @@ typedef struct {
     float   live_lock_strength;
     float   live_dc_if;
     int32_t squelch_active;    /* getSquelchState (:217-219): the level squelch is muting the demodulator output */
+    float   live_rf_dc_re, live_rf_dc_im;   /* RfDC (:423-446) behind the last sample processed: what a caller needs to reproduce the
+                                               DC-corrected block the reference dumps (:448-455) with the reference's own recurrence */
 } fmx_meta;
 
 typedef enum {

@@ -1185,6 +1185,7 @@ int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
     m->live_lock_strength = (h->params[channel].fm_mode != 2) ? st.pil_lock : 0.f;
     m->live_dc_if = st.fm_afc; m->squelch_active = (h->params[channel].squelch_mode != 0) ? st.sq_suppress : 0;
     m->fm_samples = h->g_total / DECIM; m->pcm_frames = conv2_out(h, 48 * ((h->g_total / DECIM) / 192));
+    m->live_rf_dc_re = st.dc_re; m->live_rf_dc_im = st.dc_im;
     return FMX_OK;
 }
 

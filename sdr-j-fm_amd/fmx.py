@@ -55,7 +55,7 @@ class FmxMeta(C.Structure):
         ("PssPhaseChange", C.c_float), ("PssState", C.c_int32), ("PilotPllLockStrength", C.c_float),
         ("PilotPllLocked", C.c_int32), ("fm_samples", C.c_int64), ("pcm_frames", C.c_int64),
         ("live_pilot_locked", C.c_int32), ("live_lock_strength", C.c_float), ("live_dc_if", C.c_float),
-        ("squelch_active", C.c_int32),
+        ("squelch_active", C.c_int32), ("live_rf_dc_re", C.c_float), ("live_rf_dc_im", C.c_float),
     ]
 
 

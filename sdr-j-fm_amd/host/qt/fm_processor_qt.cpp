@@ -41,6 +41,7 @@ struct fmProcessor::Impl {
     // LF scope (fm-processor.cpp:566-627, 650-660)
     std::vector<std::complex<float>> spectrumBuffer_lf;
     std::vector<float> tapbuf;
+    std::vector<std::complex<float>> dumped;
     int32_t lfCount = 0;
     // RDS (fm-processor.cpp:555-563 and the signals of the RDS objects)
     int iqCounter = 0;
@@ -101,12 +102,12 @@ void fmProcessor::setFMdecoder(const QString &name) { d->core.setFMdecoder(name.
 void fmProcessor::setSoundMode(uint8_t selector) { d->core.setSoundMode(selector); }
 void fmProcessor::setStereoPanorama(int16_t pan) { d->core.setStereoPanorama(pan); }
 void fmProcessor::setSoundBalance(int16_t balance) { d->core.setSoundBalance(balance); }
-void fmProcessor::setDeemphasis(float us) { d->core.setDeemphasis((int16_t)us); }
+void fmProcessor::setDeemphasis(int16_t us) { d->core.setDeemphasis(us); }
 void fmProcessor::setVolume(float gainDb) { d->core.setVolume(gainDb); }
 void fmProcessor::setlfcutoff(int32_t hz) { d->core.setlfcutoff(hz); }
 void fmProcessor::setBandwidth(const QString &f) { d->core.setBandwidth(f.toStdString()); }
 void fmProcessor::setAttenuation(float l, float r) { d->core.setAttenuation(l, r); }
-void fmProcessor::setfmRdsSelector(int mode) { rdsMode.store(mode); d->core.setfmRdsSelector(mode); }
+void fmProcessor::setfmRdsSelector(rdsDecoder::ERdsMode mode) { rdsMode.store((int)mode); d->core.setfmRdsSelector((int)mode); }
 void fmProcessor::triggerFrequencyChange() { d->core.triggerFrequencyChange(); }
 void fmProcessor::restartPssAnalyzer() { d->core.restartPssAnalyzer(); }
 void fmProcessor::resetRds() { d->core.resetRds(); }
@@ -115,7 +116,7 @@ void fmProcessor::set_squelchMode(ESqMode m) { d->core.set_squelchMode((int)m); 
 void fmProcessor::set_squelchValue(int16_t v) { d->core.set_squelchValue(v); }
 void fmProcessor::setAutoMonoMode(bool b) { d->core.setAutoMonoMode(b); }
 void fmProcessor::setPSSMode(bool b) { d->core.setPSSMode(b); }
-void fmProcessor::setDCRemove(bool b) { d->core.setDCRemove(b); }
+void fmProcessor::setDCRemove(bool b) { dcRemove.store(b); d->core.setDCRemove(b); }
 void fmProcessor::setTestTone(bool b) { d->core.setTestTone(b); }
 void fmProcessor::setDispDelay(int steps) { d->core.setDispDelay(steps); }
 void fmProcessor::set_ptyLocale(int l) { d->core.set_ptyLocale(l); }
@@ -234,11 +235,26 @@ void fmProcessor::run() {
     running.store(true);
     bool lastSquelch = false, first = true;
     while (running.load()) {
+        fmx_meta dcBefore{};
+        if (dumpFile.load()) (void)fmx_get_meta(I.core.handle(), 0, &dcBefore);             // RfDC in front of the block, for the dump
         if (!I.core.run_block()) { QThread::msleep(1); continue; }        // fewer than 16384 samples waiting (:388-391)
         const int32_t amount = I.core.lastAmount();
         if (I.hfBuffer) I.hfBuffer->putDataIntoBuffer(I.core.lastBlock(), amount);          // :420
         emit hfBufferLoaded();                                                              // :421
-        if (sf_private_tag *f = dumpFile.load()) if (dumpWriter) dumpWriter(f, reinterpret_cast<const float *>(I.core.lastBlock()), amount);   // :448-455
+        if (sf_private_tag *f = dumpFile.load()) if (dumpWriter) {                          // :448-455: the block behind the RF DC removal (:423-446)
+            std::complex<float> dc(dcBefore.live_rf_dc_re, dcBefore.live_rf_dc_im);
+            const float alpha = 1.0f / (float)I.dev.getRate(), lim = 0.01f;
+            I.dumped.resize((size_t)amount);
+            for (int32_t i = 0; i < amount; i++) {
+                std::complex<float> x = I.core.lastBlock()[i];
+                if (dcRemove.load()) {
+                    dc = (x - dc) * alpha + dc;
+                    x -= std::complex<float>(std::fmin(std::fmax(dc.real(), -lim), lim), std::fmin(std::fmax(dc.imag(), -lim), lim));
+                }
+                I.dumped[(size_t)i] = x;
+            }
+            dumpWriter(f, reinterpret_cast<const float *>(I.dumped.data()), amount);
+        }
         feed_rds();
         feed_lf_scope();
         I.core.poll_peaks([this](float l, float r) { emit showPeakLevel(l, r); });          // :645, 772-798

@@ -37,6 +37,9 @@ struct sf_private_tag;                     // sndfile.h: typedef struct sf_priva
 
 namespace fmx_qt {
 
+// the selector type of setfmRdsSelector (includes/rds/rds-decoder.h:60-65); in the reference tree this is the reference's own class
+struct rdsDecoder { enum class ERdsMode { RDS_OFF, RDS_1, RDS_2, RDS_3 }; };
+
 class fmProcessor : public QThread {
     Q_OBJECT
 public:
@@ -63,12 +66,12 @@ public:
     void setSoundMode(uint8_t selector);
     void setStereoPanorama(int16_t pan);
     void setSoundBalance(int16_t balance);
-    void setDeemphasis(float us);
+    void setDeemphasis(int16_t us);                                        // fm-processor.h:125
     void setVolume(float gainDb);
     void setlfcutoff(int32_t hz);
     void setBandwidth(const QString &f);
     void setAttenuation(float l, float r);
-    void setfmRdsSelector(int mode);
+    void setfmRdsSelector(rdsDecoder::ERdsMode mode);                      // fm-processor.h:134
     void triggerFrequencyChange();
     void restartPssAnalyzer();
     void resetRds();
@@ -90,7 +93,8 @@ public:
     void new_lfSpectrum() { lfBuffer_newFlag.store(true); }                // fm-processor.cpp:927-929
     // input dump (fm-processor.cpp:337-349, 448-455 write every block with sf_writef_float): the image has no libsndfile, so the
     // handle is passed through to `dumpWriter` (a one-line function around sf_writef_float in the reference tree).  The block is
-    // written as it came from the device; the reference writes it behind its RF DC removal, which runs on the GPU here.
+    // written behind the RF DC removal, as the reference writes it: the reference's own recurrence (:423-446) run over the block from
+    // the library's RfDC in front of it (fmx_meta::live_rf_dc_*).
     void startDumping(sf_private_tag *f) { dumpFile.store(f); }
     void stopDumping() { dumpFile.store(nullptr); }
     static void (*dumpWriter)(sf_private_tag *f, const float *interleaved_iq, int32_t frames);
@@ -132,6 +136,7 @@ private:
     std::unique_ptr<Impl> d;
     std::atomic<bool> running{false};
     std::atomic<int> lfPlot{0}, zoomFactor{1}, rdsMode{0};
+    std::atomic<bool> dcRemove{true};
     std::atomic<bool> squelchState{false}, showFullSpectrum{false}, lfBuffer_newFlag{true};
     std::atomic<sf_private_tag *> dumpFile{nullptr};
     int32_t fmRate, repeatRate, spectrumSize;

@@ -38,7 +38,7 @@ int main(int argc, char **argv) {
     p.setBandwidth("165kHz"); p.setlfcutoff(15000); p.setDeemphasis(50); p.setVolume(-6.0f);
     p.setAutoMonoMode(true); p.setPSSMode(true); p.setDCRemove(true);
     p.setlfPlotType(fmx_qt::fmProcessor::ELfPlot::DEMODULATOR);
-    if (rds) p.setfmRdsSelector(2);
+    if (rds) p.setfmRdsSelector(fmx_qt::rdsDecoder::ERdsMode::RDS_2);
     p.start();                                                     // QThread::start -> run()
     QTimer poll;
     QObject::connect(&poll, &QTimer::timeout, [&]() { if (dev.Samples() < 16384) { p.stop(); app.quit(); } });
