@@ -697,8 +697,19 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     if (!cfg || !out) return fail(FMX_E_INVALID, "null argument");
     if (cfg->struct_size != (int32_t)sizeof(fmx_config)) return fail(FMX_E_INVALID, "fmx_config.struct_size mismatch");
     if (cfg->channels < 1) return fail(FMX_E_INVALID, "channels must be >= 1");
-    if (cfg->inputRate != 2304000 || cfg->fmRate != 192000 || cfg->workingRate != 48000)
-        return fail(FMX_E_UNSUPPORTED, "this build implements inputRate 2304000 / fmRate 192000 / workingRate 48000");
+    if (cfg->fmRate != 192000 || cfg->workingRate != 48000)
+        return fail(FMX_E_UNSUPPORTED, "this build implements fmRate 192000 / workingRate 48000 (radio.cpp:68,231-233)");
+    {   // The reference derives its two decimators from inputRate (fm-processor.cpp:36,68-75): fmBand_1 always divides by 6, fmBand_2 by
+        // (inputRate / 6) / fmRate in INTEGER arithmetic -- whatever rate that leaves is then treated as fmRate.  Stage A is built for a
+        // total of 12 (fmx_internal.h DECIM): every input rate with (inputRate / 6) / fmRate == 2, i.e. 2 304 000 <= inputRate < 3 456 000
+        // (2.304, 2.4, 2.56, 2.88, 3.2 MS/s ...), with the filters, the LO table and the DC constant designed for the rate given.
+        if (cfg->inputRate < 1 || cfg->inputRate > 100000000) return fail(FMX_E_INVALID, "inputRate out of range");
+        const int32_t IRate = cfg->inputRate / 6;
+        const int64_t d2 = IRate / cfg->fmRate;
+        if (cfg->inputRate / cfg->fmRate <= 1 || d2 != 2 || 4 * (int64_t)cfg->inputRate / IRate + 1 != 25 || cfg->inputRate / IRate != 6)
+            return fail(FMX_E_UNSUPPORTED, "inputRate: this build implements the reference's decimation by 6 x 2 = 12, i.e. 2304000 <= inputRate < 3456000 "
+                                           "((inputRate / 6) / fmRate == 2, fm-processor.cpp:68-75); rates whose reference decimation is 1, 6 or 18+ are not built");
+    }
     std::vector<float> cv_taps; int cv_p = 1, cv_q = 1, cv_nt = 0;
     if (cfg->audioRate != cfg->workingRate) {
         if (cfg->audioRate < 8000 || cfg->audioRate > 192000 ||

@@ -317,9 +317,11 @@ class FmProcessor:
     DECODERS = {"AM": 1, "FM PLL Decoder": 2, "FM Mixed Demod": 3, "FM Complex Baseband Delay": 4,
                 "FM Real Baseband Delay": 5, "FM Difference Based": 6}      # fm-demodulator.cpp:36-43
 
-    def __init__(self, theDevice=None, mySink=None, inputRate=2304000, fmRate=192000, workingRate=48000,
+    def __init__(self, theDevice=None, mySink=None, inputRate=None, fmRate=192000, workingRate=48000,
                  audioRate=48000, fmx=None, channel=0, blockSize=16384):
         self.myRig, self.theSink = theDevice, mySink
+        if inputRate is None:                             # radio.cpp:836: inputRate = theDevice -> getRate ()
+            inputRate = theDevice.getRate() if hasattr(theDevice, "getRate") else 2304000
         self.fmx = fmx if fmx is not None else Fmx(1, max_block=blockSize, inputRate=inputRate, fmRate=fmRate,
                                                    workingRate=workingRate, audioRate=audioRate)
         self.channel = channel
