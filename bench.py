@@ -38,9 +38,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# libfmx's event-driven stage-B layout uses five HIP streams; ROCm maps streams onto 4 hardware queues by default, so two
-# of them would share one.  Must be set before the HIP runtime starts (i.e. before torch is imported).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 INPUT_RATE = 2304000

@@ -6,9 +6,6 @@ fmProcessor interface).  Import with ``importlib.import_module("sdr-j-fm_amd")``
 """
 import os as _os
 
-# five concurrent HIP streams in stage B want five hardware queues (ROCm default: 4); only effective if the HIP runtime
-# has not started yet in this process
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .fmx import (Fmx, FmProcessor, FmxError, load_library, EXPORTS, LIB_PATH)  # noqa: F401
 from . import fmx, shard  # noqa: F401

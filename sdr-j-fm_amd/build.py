@@ -14,7 +14,6 @@ LIB = os.path.join(LIBDIR, "libfmx.so")
 # expressions reproduce the reference's unfused arithmetic (SURVEY A.14 ii).
 SOURCES = [
     ("fmx_front.hip", []),
-    ("fmx_front2.hip", ["-fno-slp-vectorize"]),      # packed f32 VALU issues badly beside the matrix pipe: keep the scalar code scalar
     ("fmx_demod.hip", ["-ffp-contract=off"]),
     ("fmx_stageb.hip", ["-ffp-contract=off"]),
     ("fmx_audio.hip", []),

@@ -57,20 +57,11 @@ struct fmx_handle_s {
     int channels = 0, streams = 0;
     bool streams_private = false;                                    // no two channels listen to the same stream
     hipStream_t stream = nullptr;
-    hipStream_t s_side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams of the stage-B chunk pipeline
-    hipStream_t s_r = nullptr, s_t = nullptr;          // persistent layout of stage B: CU-masked streams
     int n_cus = 256; size_t lds_per_block = 65536;     // device limits the stage-A layout choice looks at
-    DemodSync *d_sync = nullptr;
-    int *h_stall = nullptr, *d_stall = nullptr;                      // host-mapped: set by the GPU when the persistent layout stalled
-    bool partitioned = false; int ev_next = 0;
-    bool never_fused = false;                                        // FMX_STAGE_B=chunked at fmx_create
-    bool fused = false;                                              // stage B runs as the fused per-channel kernel (fmx_stageb.hip)
-    bool last_lin = false;                                           // ... and did so in the last call (layout of the scope tap arrays)
-    bool stall_reported = false;                                     // the host-mapped stall word was turned into an error once
     std::vector<int32_t> act_up;                                     // one-shot action bits uploaded with the last parameter upload
     std::vector<uint8_t> rds_reset_req;                              // resetRds / triggerFrequencyChange asked for the group decoder's reset
     bool rds_rearm = false;                                          // every channel had RDS off: buffers and state restart at the next enable
-    std::vector<hipEvent_t> evs; hipEvent_t ev_join = nullptr, ev_in = nullptr;
+    hipEvent_t ev_in = nullptr;
     std::mutex mtx;                          // guards the mailbox (set_param from any thread)
     std::vector<ChanUser> user;
     std::vector<ChanParams> params;          // host mirror
@@ -255,7 +246,7 @@ int ensure_sets(fmx_handle h) {
             if (h->d_audio_spec) (void)hipFree(h->d_audio_spec);
             HIPCHK(hipMalloc(&h->d_audio_spec, sizeof(float2) * spec.size()));
             HIPCHK(hipMemcpy(h->d_audio_spec, spec.data(), sizeof(float2) * spec.size(), hipMemcpyHostToDevice));
-            h->T.audio_spec = (getenv("FMX_AUDIO_FIR") && std::string(getenv("FMX_AUDIO_FIR")) == "direct") ? nullptr : h->d_audio_spec;
+            h->T.audio_spec = h->d_audio_spec;
         }
     }
     h->sets_dirty = false;
@@ -463,11 +454,6 @@ int flush_mailbox(fmx_handle h) {
     for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0);     // pllC on the fm-rate IQ; |z| for the level squelch; the general AFC body for the noise squelch
     bool any_nsq = false;
     for (auto &p : h->params) any_nsq |= (p.squelch_mode == 1);
-    {   // The fused stage-B layout covers the memoryless discriminators without squelch (every BASELINE config); the PLL / AM
-        // decoders and the squelches -- recurrences of their own -- run on the chunked layouts of fmx_demod.hip.
-        // FMX_STAGE_B=chunked keeps the chunked layouts for everything (A/B runs, tests).
-        h->fused = !h->never_fused && !any_pll;
-    }
     if (any_nsq && !h->d_nsq) {
         // squelch ctor squelchClass.cpp:11-18 with mySquelch (1, 70000, fmRate / 20, fmRate) fm-processor.cpp:87
         const design::Iir hp = design::iir_chebyshev_lowhigh(true, 20, 70000 - 100, h->cfg.fmRate);
@@ -488,9 +474,12 @@ int flush_mailbox(fmx_handle h) {
         h->T.nsq_coef = h->d_nsq; h->tail_ptrs.push_back(h->d_nsq);
     }
     if (any_pll && !h->B.w_iq) {
+        // the tiled work arrays of the demodulator pre-pass (fmx_demod.hip): limited / unlimited samples in, demodulator output out
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMalloc(&h->B.w_iq, sizeof(float2) * (size_t)h->work_nj * h->pitch));
         HIPCHK(hipMemset(h->B.w_iq, 0, sizeof(float2) * (size_t)h->work_nj * h->pitch));
+        HIPCHK(hipMalloc(&h->B.w_osc, sizeof(float) * (size_t)h->work_nj * h->pitch));
+        HIPCHK(hipMemset(h->B.w_osc, 0, sizeof(float) * (size_t)h->work_nj * h->pitch));
     }
     for (int c = 0; c < h->channels; c++) {            // set_squelchValue takes effect at a block start, when it differs (fm-processor.cpp:410-413)
         ChanUser &u = h->user[c];
@@ -525,22 +514,6 @@ void actions_consumed(fmx_handle h, bool had_fm_samples) {
     }
 }
 
-// The persistent stage-B layout gives up a wait after ~2 s (fmx_demod.hip pb_wait) and raises a host-mapped word.  That
-// word is a STICKY error: the call it happened in produced invalid output and left the channel states half advanced.  It is
-// reported exactly once -- by the host entry point that ran the call, by fmx_synchronize, or by the next fmx_process_* call of
-// an asynchronous caller -- and the handle uses the event-driven layout from then on.
-int check_stall(fmx_handle h) {
-    if (!h->h_stall || *(volatile int *)h->h_stall == 0 || h->stall_reported) return FMX_OK;
-    h->stall_reported = true;
-    h->partitioned = false;
-    int info[4] = {0, 0, 0, 0};
-    if (h->d_sync) { (void)hipDeviceSynchronize(); (void)hipMemcpy(info, h->d_sync, sizeof(info), hipMemcpyDeviceToHost); (void)hipGetLastError(); }
-    char msg[256];
-    snprintf(msg, sizeof msg, "stage B pipeline stalled (waiter %d needed %d, saw %d): the output of the call it happened in is invalid "
-             "and that call's samples are lost to the demodulator; later calls use the event-driven layout", info[1], info[2], info[3]);
-    return fail(FMX_E_HIP, msg);
-}
-
 void frames_geom(const fmx_handle h, int64_t n, CallGeom *G) {
     G->g0 = h->g_total; G->n = n;
     G->J0 = h->g_total / DECIM; G->J1 = (h->g_total + n) / DECIM;
@@ -558,9 +531,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         if (!(s16_den >= 1.0f) || m != 0.5f) return fail(FMX_E_INVALID, "s16_denominator must be a power of two >= 1");
     }
     if (n <= 0 || n > h->cfg.max_block) return fail(FMX_E_TOO_LARGE, "n_complex must be in [1, max_block]");
-    int rc = check_stall(h);                      // an earlier asynchronous call stalled and nobody has been told yet
-    if (rc) return rc;
-    rc = flush_mailbox(h);
+    int rc = flush_mailbox(h);
     if (rc) return rc;
     CallGeom G{};
     frames_geom(h, n, &G);
@@ -578,43 +549,14 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         HIPCHK(hipEventRecord(pr.e[0], s));
     }
     g_launch_err = hipSuccess;
-    h->B.lin_rows = h->fused ? (int32_t)h->work_nj : 0;
-    {
-        // Stage A layout: four waves per channel with the packed-FMA FIR (fmx_front.hip).  FMX_FRONT=pairs selects the
-        // producer / consumer wave pairs with the FIR as f32 matrix instructions (fmx_front2.hip): parity-equal, measured
-        // slower (2.3 against 2.04 ms per launch at 4096 channels) because on gfx950 a wave streaming MFMAs leaves the other
-        // wave of its SIMD one VALU issue per matrix instruction (tools/ubench/mfma_valu_share.hip) -- DESIGN.md section 3.1.
-        const char *fe = getenv("FMX_FRONT");
-        bool pairs = fe ? std::string(fe) == "pairs" : false;             // (measured slower than the classic layout so far: opt-in)
-        int ntab = 1, lo_cap = 0;
-        if (pairs) {
-            for (int c = 0; c < h->channels; c++) {
-                if (h->params[c].front_set != h->params[0].front_set) ntab = 4;
-                if (h->params[c].lo_freq != 0) lo_cap = std::max(lo_cap, (int)h->params[c].lo_period);
-            }
-            if (front2_lds_bytes(ntab, lo_cap) > h->lds_per_block) lo_cap = 0;          // LO phases from the table in memory then
-            if (front2_lds_bytes(ntab, lo_cap) > h->lds_per_block) pairs = false;
-        }
-        if (pairs) note_hip(launch_front2(h->T, h->B, G, d_iq, h->channels, ntab, lo_cap, s));
-        else launch_front(h->T, h->B, G, d_iq, h->channels, s);
-    }
+    h->B.lin_rows = (int32_t)h->work_nj;
+    launch_front(h->T, h->B, G, d_iq, h->channels, s);   // stage A: four waves per channel, packed-FMA FIR (fmx_front.hip)
     FMX_LAUNCHED();
     static const bool prof_double = getenv("FMX_PROF_DOUBLE") != nullptr;    // (diagnostic: a throw-away event in front of each boundary event)
     hipEvent_t pdummy = nullptr;
     if (prof && prof_double) { HIPCHK(hipEventCreate(&pdummy)); HIPCHK(hipEventRecord(pdummy, s)); }
     if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
-    {
-        static const bool serial = getenv("FMX_SERIAL_STAGE_B") != nullptr;     // diagnostics: no side streams
-        DemodStreams DS{};
-        for (int i = 0; i < 4; i++) DS.side[i] = serial ? nullptr : h->s_side[i];
-        DS.ev = h->evs.data(); DS.nev = (int)h->evs.size(); DS.join = h->ev_join;
-        DS.rs = h->s_r; DS.ts = h->s_t; DS.sync = h->d_sync; DS.host_flag = h->d_stall;
-        DS.partitioned = (h->partitioned && !serial) ? 1 : 0; DS.ev_next = &h->ev_next;
-        h->B.lin_rows = h->fused ? (int32_t)h->work_nj : 0;
-        if (h->fused) launch_demod_fused(h->T, h->B, G, h->channels, s);
-        else launch_demod(h->T, h->B, G, h->channels, s, DS);
-        h->last_lin = h->fused;
-    }
+    launch_demod_fused(h->T, h->B, G, h->channels, s);      // (with its pre-pass for the PLL / AM decoders and the squelches)
     if (h->rds_alloc && h->rds_start >= 0) {
         bool any_rds = false;
         for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
@@ -728,7 +670,6 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     // every failure below goes through fmx_destroy: nothing of a half-built handle stays behind
     auto init = [&]() -> int {
     h->cfg = *cfg; h->cfg.stream_of_channel = nullptr;
-    h->never_fused = getenv("FMX_STAGE_B") && std::string(getenv("FMX_STAGE_B")) == "chunked";
     h->channels = cfg->channels;
     h->streams = cfg->streams > 0 ? cfg->streams : cfg->channels;
     if (cv_nt) {
@@ -768,53 +709,6 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         h->lds_per_block = std::max((size_t)dp.sharedMemPerBlock, (size_t)optin);
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (auto &ss : h->s_side) HIPCHK(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
-    {
-        // Persistent layout of stage B (fmx_demod.hip launch_demod_persistent) from FMX_PERSISTENT_MIN_CHANNELS channels on
-        // (default 1; 0 = never): the recurrence kernel gets a CU set of its own, big enough to hold all its wavefronts
-        // at once (they wait for each other), the time-parallel kernels the other CUs.  Mask bit i is CU i / 8 of XCD i % 8.
-        const char *e1 = getenv("FMX_PERSISTENT_MIN_CHANNELS");
-        const int minch = e1 ? atoi(e1) : 1;
-        hipDeviceProp_t prop{};
-        HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
-        const int ncu = prop.multiProcessorCount;
-        const int groups = (h->channels + 63) / 64;
-        // every wavefront of the recurrence kernel must be resident at once (they wait for each other): count five per CU
-        // (LDS and VGPRs allow eight; the dispatcher does not pack CUs completely), one spare CU per XCD, and check the runtime's own occupancy figure agrees
-        const int occ = recurrences_blocks_per_cu();
-        const char *e3 = getenv("FMX_RECURRENCE_WAVES_PER_CU");
-        // few waves per CU while that costs few CUs (the recurrences then run undisturbed), up to five when the channel
-        // count is large and the time-parallel kernels need the CUs more
-        const int want = std::max(2, std::min(5, (PB_ROLES * groups + 47) / 48));   // (7 of the 8 possible did not all become resident)
-        // From 2048 channels on stage B is bound by the time-parallel kernels' throughput, not by the recurrences' latency:
-        // they then run on every CU, and so do the recurrence waves, one or two to a CU (measured at 4096 channels with the
-        // time-parallel kernels switched off: the five roles of 64 groups take 4.0 ms three to a CU on 120 CUs, 3.4 ms two
-        // to a CU on 168 CUs, 2.9 ms spread over all 256 -- the roles slow each other in proportion to the waves per CU).
-        const bool t_everywhere = getenv("FMX_T_UNMASKED") ? atoi(getenv("FMX_T_UNMASKED")) != 0 : groups >= 32;
-        const int per_cu = std::min(occ, e3 ? std::max(1, atoi(e3)) : (t_everywhere ? 1 : want));
-        if (getenv("FMX_DEBUG_LAYOUT")) fprintf(stderr, "[fmx] recurrence kernel occupancy %d blocks/CU, %d groups\n", occ, groups);
-        if (minch > 0 && h->channels >= minch && ncu >= 64 && ncu <= 1024 && per_cu > 0) {
-            const int rwaves = PB_ROLES * groups;
-            int rcus = (rwaves + per_cu - 1) / per_cu;
-            rcus = std::max(16, (rcus + 7) / 8 * 8 + 8);
-            if (t_everywhere) rcus = std::min(rcus, ncu);      // (the time-parallel kernels run on every CU anyway)
-            if (rcus <= ncu * 3 / 4 || t_everywhere) {
-                std::vector<uint32_t> mr((ncu + 31) / 32, 0u), mt((ncu + 31) / 32, 0u);
-                for (int i = 0; i < ncu; i++) (i < rcus ? mr : mt)[i / 32] |= 1u << (i % 32);
-                if (t_everywhere) for (int i = 0; i < ncu; i++) mt[i / 32] |= 1u << (i % 32);
-                bool ok = hipExtStreamCreateWithCUMask(&h->s_r, (uint32_t)mr.size(), mr.data()) == hipSuccess;
-                ok = ok && hipExtStreamCreateWithCUMask(&h->s_t, (uint32_t)mt.size(), mt.data()) == hipSuccess;
-                ok = ok && hipMalloc(&h->d_sync, sizeof(DemodSync) + sizeof(int) * PB_ROLES * groups) == hipSuccess;
-                ok = ok && hipHostMalloc((void **)&h->h_stall, sizeof(int), hipHostMallocMapped) == hipSuccess;
-                if (ok) { *h->h_stall = 0; ok = hipHostGetDevicePointer((void **)&h->d_stall, h->h_stall, 0) == hipSuccess; }
-                (void)hipGetLastError();
-                h->partitioned = ok;             // otherwise the event-driven layout is used
-            }
-        }
-    }
-    h->evs.resize(512);
-    for (auto &e : h->evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
 
     // ---- tables -------------------------------------------------------------------------
@@ -894,7 +788,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMemcpy(h->d_fft_w, W.data(), sizeof(float2) * fftc::W_COUNT, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_pss_hs, Hs.data(), sizeof(float2) * fftc::N, hipMemcpyHostToDevice));
         h->T.fft_w = h->d_fft_w;
-        h->T.pss_hs = (getenv("FMX_PSS_FIR") && std::string(getenv("FMX_PSS_FIR")) == "direct") ? nullptr : h->d_pss_hs;
+        h->T.pss_hs = h->d_pss_hs;
     }
     h->T.sincos_C = fmRate / (2 * design::kPi);
     {   // fm_Demodulator ctor fm-demodulator.cpp:57-72
@@ -935,27 +829,14 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         const size_t C = (size_t)h->pitch;   // rows are padded (see CallGeom.pitch)
         HIPCHK(hipMalloc(&h->B.w_dem, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_cur, sizeof(float) * NJ * C));
-        HIPCHK(hipMalloc(&h->B.w_osc, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_diff, sizeof(float) * NJ * C));
-        HIPCHK(hipMalloc(&h->B.w_err, sizeof(float) * (size_t)(PSS_CHUNK + WT) * C));
-        HIPCHK(hipMalloc(&h->B.w_pdp, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.gfix, sizeof(float2) * GAIN_FIX_FRAMES * C));
         HIPCHK(hipMemset(h->B.gfix, 0, sizeof(float2) * GAIN_FIX_FRAMES * C));
-        h->B.lockm_stride = (int32_t)(NJ / 6 + 512);
-        HIPCHK(hipMalloc(&h->B.w_lockm, (size_t)h->B.lockm_stride * C));
-        HIPCHK(hipMemset(h->B.w_lockm, 0, (size_t)h->B.lockm_stride * C));
-        HIPCHK(hipMalloc(&h->B.w_tag, sizeof(int32_t) * NJ * C));
-        HIPCHK(hipMalloc(&h->B.w_x, sizeof(float2) * NJ * C));
         h->B.w_iq = nullptr;
         // the recurrence kernels move whole 64-channel row blocks, pad columns included: keep those finite
         HIPCHK(hipMemset(h->B.w_dem, 0, sizeof(float) * NJ * C));
         HIPCHK(hipMemset(h->B.w_cur, 0, sizeof(float) * NJ * C));
-        HIPCHK(hipMemset(h->B.w_osc, 0, sizeof(float) * NJ * C));
         HIPCHK(hipMemset(h->B.w_diff, 0, sizeof(float) * NJ * C));
-        HIPCHK(hipMemset(h->B.w_err, 0, sizeof(float) * (size_t)(PSS_CHUNK + WT) * C));
-        HIPCHK(hipMemset(h->B.w_pdp, 0, sizeof(float) * NJ * C));
-        HIPCHK(hipMemset(h->B.w_tag, 0, sizeof(int32_t) * NJ * C));
-        HIPCHK(hipMemset(h->B.w_x, 0, sizeof(float2) * NJ * C));
     }
     HIPCHK(hipMalloc(&h->B.state, sizeof(ChanState) * C));
     HIPCHK(hipMalloc(&h->d_params, sizeof(ChanParams) * C));
@@ -1006,18 +887,11 @@ int fmx_destroy(fmx_handle h) {
     void *ptrs[] = { h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
                      h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.dcv_hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
-                     h->B.w_osc, h->B.w_diff, h->B.w_err, h->B.w_pdp, h->B.w_tag, h->B.w_x, h->B.w_lockm, h->d_cv_taps, h->d_x48 };
+                     h->B.w_osc, h->B.w_diff, h->d_cv_taps, h->d_x48 };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
     for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);
-    for (auto &e : h->evs) (void)hipEventDestroy(e);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-    for (auto &ss : h->s_side) if (ss) (void)hipStreamDestroy(ss);
-    if (h->s_r) (void)hipStreamDestroy(h->s_r);
-    if (h->s_t) (void)hipStreamDestroy(h->s_t);
-    if (h->d_sync) (void)hipFree(h->d_sync);
-    if (h->h_stall) (void)hipHostFree(h->h_stall);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FMX_OK;
@@ -1169,7 +1043,7 @@ int fmx_process_host_raw(fmx_handle h, const void *iq, int32_t format, float s16
                                 h->channels, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (n_frames) *n_frames = got;
-    return check_stall(h);
+    return FMX_OK;
 }
 int fmx_process_host(fmx_handle h, const float *iq, int64_t stream_stride, int64_t n, float *pcm,
                      int64_t pcm_stride, int64_t *n_frames) {
@@ -1180,7 +1054,7 @@ int fmx_synchronize(fmx_handle h) {
     if (!h) return fail(FMX_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
-    return check_stall(h);                       // a stalled stage-B pipeline gives up instead of hanging (fmx_demod.hip pb_wait)
+    return FMX_OK;
 }
 
 int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
@@ -1241,10 +1115,10 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
     case FMX_TAP_FM_IQ: base = (const char *)(h->B.zring + (size_t)channel * h->ring); cap = h->ring; elem = sizeof(float2);
         delay = h->h_front_sets[h->params[channel].front_set].delay_fm; break;
     case FMX_TAP_DEMOD: case FMX_TAP_LR_RAW: case FMX_TAP_PILOT_PHASE: {
-        // these two taps are read back from the last call's work arrays (tiles of 16 rows: widx), rows [nj - n, nj)
+        // these taps are read back from the last call's work arrays (channel-major rows of the call), rows [nj - n, nj)
         const int64_t nj = h->last_J1 - h->last_J0, r0 = nj - n;
         if (n == 0) return FMX_OK;
-        if (h->last_lin) {           // fused layout: this call's rows are contiguous per channel
+        {                            // this call's rows are contiguous per channel
             const size_t off = (size_t)channel * (size_t)h->work_nj + (size_t)r0;
             std::vector<float> a((size_t)n), b;
             HIPCHK(hipMemcpy(a.data(), (tap == FMX_TAP_PILOT_PHASE ? h->B.w_cur : h->B.w_dem) + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
@@ -1253,18 +1127,6 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
                 HIPCHK(hipMemcpy(b.data(), h->B.w_diff + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
                 for (int64_t i = 0; i < n; i++) { dst[2 * i] = a[(size_t)i]; dst[2 * i + 1] = b[(size_t)i]; }
             } else std::memcpy(dst, a.data(), sizeof(float) * (size_t)n);
-            return FMX_OK;
-        }
-        const int64_t t0 = r0 / WT, t1 = (nj - 1) / WT + 1;
-        std::vector<float> a((size_t)(t1 - t0) * WT), b;
-        const size_t spitch = (size_t)h->pitch * WT * sizeof(float);
-        HIPCHK(hipMemcpy2D(a.data(), WT * sizeof(float), (tap == FMX_TAP_PILOT_PHASE ? h->B.w_cur : h->B.w_dem) + ((size_t)t0 * h->pitch + channel) * WT, spitch, WT * sizeof(float), (size_t)(t1 - t0), hipMemcpyDeviceToHost));
-        if (tap == FMX_TAP_LR_RAW) {
-            b.resize(a.size());
-            HIPCHK(hipMemcpy2D(b.data(), WT * sizeof(float), h->B.w_diff + ((size_t)t0 * h->pitch + channel) * WT, spitch, WT * sizeof(float), (size_t)(t1 - t0), hipMemcpyDeviceToHost));
-            for (int64_t i = 0; i < n; i++) { dst[2 * i] = a[(size_t)(r0 - t0 * WT + i)]; dst[2 * i + 1] = b[(size_t)(r0 - t0 * WT + i)]; }
-        } else {
-            std::memcpy(dst, a.data() + (r0 - t0 * WT), sizeof(float) * (size_t)n);
         }
         return FMX_OK; }
     case FMX_TAP_PRE_RESAMPLER: base = (const char *)(h->B.dring + (size_t)channel * h->dring); cap = h->dring; elem = sizeof(float2); break;
@@ -1488,21 +1350,6 @@ int fmx_debug_stream_bandwidth(int32_t device, int32_t mode, int64_t bytes, int3
     const double moved = mode == 0 ? 2.0 * n16 * 16 : n16 * 16 * (1.0 + 1.0 / 12);
     *gbps = moved * iters / (ms * 1e-3) * 1e-9;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(src); (void)hipFree(dst);
-    return FMX_OK;
-}
-
-// diagnostics (not part of include/fmx.h): the progress words of the persistent stage-B layout after a device synchronise
-int fmx_debug_sync_dump(fmx_handle h, int32_t *out, int32_t capacity, int32_t *n) {
-    if (!h || !out || !n) return fail(FMX_E_INVALID, "null argument");
-    *n = 0;
-    if (!h->partitioned || !h->d_sync) return FMX_OK;
-    HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipDeviceSynchronize());
-    const int groups = (h->channels + 63) / 64;
-    const int words = (int)(sizeof(DemodSync) / sizeof(int)) + PB_ROLES * groups;
-    const int m = std::min(words, (int)capacity);
-    HIPCHK(hipMemcpy(out, h->d_sync, sizeof(int) * m, hipMemcpyDeviceToHost));
-    *n = m;
     return FMX_OK;
 }
 

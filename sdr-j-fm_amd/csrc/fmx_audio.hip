@@ -19,171 +19,8 @@
 namespace fmx {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int CQ = C_TAPS_STRIDE / 4;                     // 224 tap columns per phase (zero padded)
-constexpr int NG3MAX = (CQ / 4 + 2) / 3 * 3;              // tap groups (four tap columns each) per phase, a multiple of three
-constexpr int AW = 4;                                     // waves per workgroup: AW adjacent 256-frame tiles share one window and the taps
-constexpr int CWC = AW * C_TILE + 4 * NG3MAX + 16;        // window columns per phase
-constexpr int FPT = 4;                                    // output frames a thread finishes (it computes half of eight)
 
-// One wave per (256-frame tile, channel), four adjacent tiles per workgroup (one window fill and one tap image for the four:
-// 44 KB of LDS for four waves, three waves per SIMD, one workgroup's fill -- pure memory latency -- under the others' FIR).
-// The window lives in LDS as four decimation phases (entry w of the window = fm index fbase + w is column w >> 2 of phase
-// w & 3), so output frame f reads column f + q of phase p for tap 4 q + p.  A thread computes EIGHT adjacent frames for TWO
-// of the four phases (lanes 0..31: phases 0, 1; lanes 32..63: phases 2, 3) through a twelve-column register ring: per four
-// taps two ds_read_b128 of data and one of taps feed 32 packed FMAs -- (L, R) ride in one v_pk_fma_f32 because the taps
-// are real.  (Four frames x four phases per thread needed the same three LDS reads per 16 FMAs and was LDS-bound.)  The two
-// half-sums meet through one cross-lane exchange, after which every lane finishes four frames.
-__global__ __launch_bounds__(64 * AW) void audio_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
-                                                   float2 *__restrict__ pcm) {
-    // X[p][plane][o] = the column pair of unit u = 4 o + plane (columns 2 u, 2 u + 1) of phase p: a thread's units start four
-    // after its neighbour's, so every ds_read_b128 of a half-wave reads consecutive 16-byte slots of one plane
-    __shared__ __attribute__((aligned(16))) float4 X[4][4][CWC / 8 + 1];
-    __shared__ __attribute__((aligned(16))) float tp[4][4 * NG3MAX];  // taps by phase: tp[p][q] = taps[4 q + p], zero padded
-    const int ch = blockIdx.y;
-    const int tb = threadIdx.x, t = tb & 63, wv = tb >> 6;
-    const int64_t mb = G.M0 + (int64_t)blockIdx.x * (AW * C_TILE);     // first frame of the workgroup, of this wave:
-    const int64_t m0 = mb + wv * C_TILE;
-    if (mb >= G.M1) return;
-    const ChanParams P = B.params[ch];
-    const AudioSet AS = T.audio_sets[P.audio_set];
-    const float *__restrict__ taps = T.audio_taps + (size_t)P.audio_set * C_TAPS_STRIDE;   // reversed order, zero padded
-    const float2 *__restrict__ dring = B.dring + (size_t)ch * (G.dring_mask + 1);
-    const int NC = AS.ntaps;
-    const int NG3 = ((NC + 15) / 16 + 2) / 3 * 3;           // groups of four tap columns per phase, a multiple of three
-    // window entry w <-> fm index fbase + w ; output frame f (0..255) reads w = 4 f + kk, kk = tap index
-    const int64_t fbase = 4 * mb + 3 - AS.delay - (NC - 1);
-    const int nfr = (int)((G.M1 - mb) < (int64_t)(AW * C_TILE) ? (G.M1 - mb) : (int64_t)(AW * C_TILE));   // frames of this workgroup
-    const int nw = 4 * (((nfr + C_TILE - 1) / C_TILE) * C_TILE + 4 * NG3 + 8);
-    // window and taps fill: the loads of a batch are issued together and only then written to LDS -- one memory round trip
-    // per batch instead of one per 64 entries (a wave has nothing else to do here: the fill is pure latency)
-    constexpr int FB = 8;
-    for (int w0 = 0; w0 < nw; w0 += 64 * AW * FB) {
-        float2 v[FB];
-#pragma unroll
-        for (int k = 0; k < FB; k++) {
-            const int w = w0 + 64 * AW * k + tb;
-            const int64_t f = fbase + w;
-            v[k] = make_float2(0.f, 0.f);
-            if (w < nw && f >= 0 && w < 4 * (nfr - 1) + NC) v[k] = dring[f & G.dring_mask];
-        }
-#pragma unroll
-        for (int k = 0; k < FB; k++) {
-            const int w = w0 + 64 * AW * k + tb;
-            const int col = w >> 2;
-            if (w < nw) reinterpret_cast<float2 *>(&X[w & 3][(col >> 1) & 3][col >> 3])[col & 1] = v[k];
-        }
-    }
-    {
-        static_assert(NG3MAX <= 64 * AW && C_TAPS_STRIDE / 4 <= 4 * NG3MAX, "one float4 of taps per thread");
-        const int i4 = tb;                                                   // float4 index: taps 4 i4 .. 4 i4 + 3 = column i4 of phases 0..3
-        if (i4 < 4 * NG3MAX) {
-            const float4 tv = i4 < C_TAPS_STRIDE / 4 ? reinterpret_cast<const float4 *>(taps)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            tp[0][i4] = tv.x; tp[1][i4] = tv.y; tp[2][i4] = tv.z; tp[3][i4] = tv.w;
-        }
-    }
-    __syncthreads();
-    if (m0 >= G.M1) return;
-    const int tl = t & 31, ph = t >> 5;
-    v2f a8[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) a8[j] = (v2f){0.f, 0.f};
-    const int mu = 32 * wv + tl;                                  // this thread's first window unit is 4 mu
-    for (int pp = 0; pp < 2; pp++) {
-        const int p = 2 * ph + pp;
-        const float4 *hr = reinterpret_cast<const float4 *>(&tp[p][0]);
-        v2f c[12];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {                             // ring = columns 8 mu .. 8 mu + 11 (units 4 mu .. 4 mu + 5)
-            const float4 v = X[p][k & 3][mu + (k >> 2)];
-            c[2 * k] = (v2f){v.x, v.y}; c[2 * k + 1] = (v2f){v.z, v.w};
-        }
-        for (int g3 = 0; g3 < NG3; g3 += 3) {
-#pragma unroll
-            for (int gg = 0; gg < 3; gg++) {                      // group g: tap columns 4 g .. 4 g + 3 on ring entries (4 gg + q + j) % 12
-                const int g = g3 + gg;
-                const float4 h4 = hr[g];
-                const float hq[4] = {h4.x, h4.y, h4.z, h4.w};
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) {
-                    const v2f w = (v2f){hq[qq], hq[qq]};
-#pragma unroll
-                    for (int j = 0; j < 8; j++) a8[j] = __builtin_elementwise_fma(w, c[(4 * gg + qq + j) % 12], a8[j]);
-                }
-                // columns 4 g + 12 .. 4 g + 15 replace the four oldest: units 4 mu + 2 g + 6, + 7
-                const int u0 = 2 * g + 6;
-                const float4 va = X[p][u0 & 3][mu + (u0 >> 2)], vb = X[p][(u0 + 1) & 3][mu + ((u0 + 1) >> 2)];
-                c[(4 * gg) % 12] = (v2f){va.x, va.y}; c[(4 * gg + 1) % 12] = (v2f){va.z, va.w};
-                c[(4 * gg + 2) % 12] = (v2f){vb.x, vb.y}; c[(4 * gg + 3) % 12] = (v2f){vb.z, vb.w};
-            }
-        }
-    }
-    // the other half-wave holds the other two phases of the same eight frames: lane (tl, ph) finishes frames 8 tl + 4 ph + j
-    v2f acc[FPT];
-#pragma unroll
-    for (int j = 0; j < FPT; j++) {
-        const v2f mine = ph ? a8[4 + j] : a8[j], give = ph ? a8[j] : a8[4 + j];
-        const float gx = __shfl_xor(give.x, 32), gy = __shfl_xor(give.y, 32);
-        acc[j] = ph ? (v2f){gx + mine.x, gy + mine.y} : (v2f){mine.x + gx, mine.y + gy};    // (phases 0, 1) + (phases 2, 3) in both
-    }
-    const int c0 = 8 * tl + FPT * ph;
-    // audioGainCorrection fm-processor.cpp:303-306: (volumeFactor * leftChannel) * sample.  Applied here, at
-    // the output of the folded FIR, so that a volume/balance change takes effect at the call boundary as in
-    // the reference (it sits behind the audio low-pass there) rather than one filter latency late; the reference
-    // multiplies in FRONT of the resampler, whose 128-sample memory blends old and new gain over 32 frames:
-    // gain_fix_kernel supplies that blend for the call in front of which a gain changed.
-    const float gl = P.volume * P.left_ch, gr = P.volume * P.right_ch;
-    const ChanState *__restrict__ st = &B.state[ch];
-    const int64_t F = st->fade_start_frame;
-    const int Max = 24000;                               // workingRate / 2
-    // peak meter: frame i of the call is frame cnt0 + i of the window that was open at the call's start; a 256-frame tile
-    // meets at most two 961-frame windows: maxima of the tile's first window in pk[0], pk[1], of its second in pk[2], pk[3]
-    const int cnt0 = st->pk_cnt, tt0 = st->tt_pos;
-    const int i_tile = (int)(m0 - G.M0);
-    const int w_first = (cnt0 + i_tile) / PK_WIN;
-    float pk[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < FPT; j++) {
-        const int64_t m = m0 + c0 + j;
-        if (m >= G.M1) break;
-        float al = acc[j].x * gl, ar = acc[j].y * gr;
-        if (G.gain_fix && m - G.M0 < GAIN_FIX_FRAMES) {      // the part of the resampler's memory that entered under the old gain
-            const float2 c = B.gfix[(size_t)ch * GAIN_FIX_FRAMES + (m - G.M0)];
-            al += c.x; ar += c.y;
-        }
-        // start-up fade fm-processor.cpp:638-642: factor = (Max - cnt)/Max with cnt = Max - (m - F)
-        const int64_t since = m - F;
-        if (since >= 0 && since < Max) {
-            const float cnt = (float)(Max - (int)since);
-            const float f = ((float)Max - cnt) / (float)Max;
-            al *= f; ar *= f;
-        }
-        const int i = (int)(m - G.M0);
-        if (P.test_tone) {
-            // insertTestTone fm-processor.cpp:800-823.  The counters make a fixed cycle -- 96001 attenuated frames, then a
-            // 1200-frame burst whose phase restarts at 0, so every burst is the same 1200 values (tabulated on the host
-            // with the reference's own recurrence); the cycle position only advances while the tone is enabled.
-#pragma clang fp contract(off)
-            const float level = 0.9f;
-            al = al * (1.0f - level); ar = ar * (1.0f - level);
-            const int pos = (int)(((int64_t)tt0 + i) % TT_CYCLE);
-            if (pos >= TT_SILENT) {
-                const float smpl = level * B.tone[pos - TT_SILENT];
-                al = al + smpl; ar = ar + smpl;
-            }
-        }
-        const bool second = (cnt0 + i) / PK_WIN != w_first;
-        pk[second ? 2 : 0] = fmaxf(pk[second ? 2 : 0], fabsf(al));
-        pk[second ? 3 : 1] = fmaxf(pk[second ? 3 : 1], fabsf(ar));
-        pcm[(size_t)ch * G.pcm_stride + (m - G.M0)] = make_float2(al, ar);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) pk[q] = fmaxf(pk[q], __shfl_xor(pk[q], d));
-    if (t == 0) B.pk_part[(size_t)ch * B.pk_tiles + AW * blockIdx.x + wv] = make_float4(pk[0], pk[1], pk[2], pk[3]);
-}
-
-// PCM tail bookkeeping, one thread per channel, after audio_kernel: folds the tiles' maxima into the open window, writes
+// PCM tail bookkeeping, one thread per channel, after audio_fft_kernel: folds the tiles' maxima into the open window, writes
 // the maxima of every window that closed in this call to the channel's ring (the host turns them into dB and runs the
 // display delay line: fmx_get_peaks), advances the test-tone cycle position.
 __global__ __launch_bounds__(64) void pcm_tail_kernel(DeviceBuffers B, CallGeom G, int channels) {
@@ -374,11 +211,7 @@ void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
                   int channels, hipStream_t s) {
     const int64_t frames = G.M1 - G.M0;
     if (frames <= 0) return;
-    if (T.audio_spec) hipLaunchKernelGGL(audio_fft_kernel, dim3((unsigned)((frames + AF_VALID - 1) / AF_VALID), channels), dim3(fftc::T), 0, s, T, B, G, pcm);
-    else {
-        const int tiles = (int)((frames + AW * C_TILE - 1) / (AW * C_TILE));
-        hipLaunchKernelGGL(audio_kernel, dim3(tiles, channels), dim3(64 * AW), 0, s, T, B, G, pcm);
-    }
+    hipLaunchKernelGGL(audio_fft_kernel, dim3((unsigned)((frames + AF_VALID - 1) / AF_VALID), channels), dim3(fftc::T), 0, s, T, B, G, pcm);
     hipLaunchKernelGGL(pcm_tail_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, B, G, channels);
 }
 

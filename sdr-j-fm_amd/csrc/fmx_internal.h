@@ -223,28 +223,26 @@ struct DeviceBuffers {
     const ChanParams *params;
     unsigned long long *dbg;   // optional [channels][DBG_SLOTS] diagnostics (null = off): 0-7 per-phase cycles of front_kernel, 8-12 path / round
                                // counters of stage B, 16-27 per-phase cycles of stageb_seg_kernel
-    // sample-major [fm sample of this call][channel] work arrays of stage B
-    float   *w_dem;      // discriminator output, then demod (in place)
-    float2  *w_iq;       // limiter output (only allocated when a channel uses the PLL decoder)
-    float   *w_cur;      // pilot phase (currentPilotPhase)
-    float   *w_osc;      // pilot NCO sine
-    float   *w_diff;     // [fm sample][channel] L-R difference before the matrix (LR scope tap, with w_dem)
-    float   *w_err;      // [PSS_CHUNK][channel] PSS error for the chunk's call indices
-    float   *w_pdp;      // pilotDelayPSS as used by each sample
-    int32_t *w_tag;      // -2 mono branch, -1 stereo without PSS, >= 0 PSS call index within the chunk
-    float2  *w_x;        // matrix output, then de-emphasised + gained stereo (in place)
+    // per-call work arrays of stage B
+    float   *w_dem;      // [channel][lin_rows] demodulator output of this call (DEMODULATOR scope tap; input of the RDS path)
+    float   *w_cur;      // [channel][lin_rows] pilot phase (currentPilotPhase; input of the RDS path)
+    float   *w_diff;     // [channel][lin_rows] L-R difference before the matrix (LR scope tap, with w_dem)
+    float2  *w_iq;       // demodulator pre-pass (fmx_demod.hip; allocated when a channel first needs it), 16-row tiles of widx(): limited
+                         // (PLL decoder) / unlimited (AM) samples, |z| for the level squelch of the other decoders
+    float   *w_osc;      // ... and its output: the demodulator output behind AFC, scaling and squelch
     float2  *gfix;       // [channels][GAIN_FIX_FRAMES] what a gain change adds to the first frames of the call (gain_fix_kernel)
-    uint8_t *w_lockm;    // fused layout: [channel][lockm_stride] pilot-lock flags of this call, one byte (six samples) per thread and segment
-    int32_t lockm_stride, pad_lm;
+    int32_t prepass;     // != 0: disc_kernel / afc_kernel<true> run as the pre-pass of the fused stage B (launch_demod_fused): only the channels
+                         // with a recurrence of their own in the demodulator (PLL / AM decoder, a squelch) are touched, their demodulator output
+                         // goes to the 16-row tiles of w_osc (given to them as w_dem), the metaData snapshot of the AFC value is taken there
+    int32_t pad_pp;
     // PCM tail (fmx_audio.hip)
     const float *tone;   // [TT_BURST] one test-tone burst (the same for every burst: phase restarts at 0)
     float4  *pk_part;    // [channels][pk_tiles] per audio tile: max |L|, |R| of the frames of the tile's first window, then of its second
     float2  *pk_ring;    // [channels][PK_RING] maxima of the finished windows
     int32_t pk_tiles;
-    int32_t lin_rows;    // != 0 (fused stage-B layout): w_dem / w_diff / w_cur hold this call's rows channel-major, [channel][lin_rows], and
-                         // w_err the PSS errors of one segment, [channel][1536]; 0: the 16-row tiles of widx()
+    int32_t lin_rows;    // rows per channel of w_dem / w_diff / w_cur; 0 inside the demodulator pre-pass: its arrays are the 16-row tiles of widx()
 };
-// element (row r, channel ch) of a per-call scope / RDS tap array in either layout
+// element (row r, channel ch) of a per-call work array in either layout
 __host__ __device__ __forceinline__ size_t tap_idx(const DeviceBuffers &B, int64_t r, int ch, int pitch) {
     return B.lin_rows ? (size_t)ch * (size_t)B.lin_rows + (size_t)r : widx(r, ch, pitch);
 }
@@ -304,42 +302,14 @@ void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G,
 
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s);
-// producer / consumer layout of stage A (fmx_front2.hip): four channels per 512-thread workgroup, FIR on the matrix pipe.
-// ntab = 1 when every channel uses the tap set of channel 0 (one tap image per workgroup), else 4; lo_cap = LDS entries per
-// channel for one LO period (0: none).  front2_lds_bytes = dynamic LDS the launch needs.
-size_t front2_lds_bytes(int ntab, int lo_cap);
-hipError_t launch_front2(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels,
-                         int ntab, int lo_cap, hipStream_t s);
-// side streams + events for the chunk pipeline of stage B (null streams = run everything on the caller's stream)
-// Streams of the stage-B chunk pipeline.  side[]: four unmasked side streams of the event-driven layout.
-// Persistent layout (partitioned != 0): rs / ts[] are bound to two disjoint CU sets (hipExtStreamCreateWithCUMask); ONE
-// persistent kernel on rs runs every recurrence of the call (roles AFC, PLL, lock, PSS integrator, de-emphasis), the
-// time-parallel kernels run chunk by chunk on ts (discriminator, PSS low-pass, mix), and the two
-// sides meet through progress words in `sync` (device memory) instead of stream events.
-constexpr int PB_MAX_CHUNKS = 64;      // chunks of one call in the persistent layout
-constexpr int PB_CHUNK = 864;          // its chunk length: <= PSS_DELAY / 2 and a multiple of the work-array tile
-constexpr int PB_ROLES = 5;
-struct DemodSync {                      // zeroed at the start of every call
-    int abort;                          // set when a wait ran out of patience (a stalled pipeline must not hang the GPU)
-    int info[3];                        // first waiter that gave up: id, value needed, value seen
-    int groups;
-    int started;                        // workgroups of the recurrence kernel that have begun (all of them must be resident)
-    int pad[8];
-    int *host_flag;                     // host-mapped word the first waiter that gives up also sets: the host then stops using this layout
-    int snap[64];                       // snapshot of the words below at that moment (diagnostics)
-    int cnt_disc[PB_MAX_CHUNKS], cnt_fir[PB_MAX_CHUNKS], cnt_mix[PB_MAX_CHUNKS];     // finished blocks of chunk c's kernel
-    int prog[PB_ROLES][1];              // [role][group]: chunks finished; really [PB_ROLES][groups] (allocated to size)
-};
-struct DemodStreams { hipStream_t side[4]; hipEvent_t *ev; int nev; hipEvent_t join; hipStream_t rs; hipStream_t ts;
-                      int partitioned; int *ev_next; DemodSync *sync; int *host_flag; };
-int recurrences_blocks_per_cu();
 // first HIP error of the launches / event calls of the current fmx_process_* call (they are enqueued by void helpers);
 // run_call clears it before the launches and turns it into FMX_E_HIP behind them
 extern thread_local hipError_t g_launch_err;
 inline void note_hip(hipError_t e) { if (e != hipSuccess && g_launch_err == hipSuccess) g_launch_err = e; }
 #define FMX_LAUNCHED() ::fmx::note_hip(hipGetLastError())
-void launch_demod(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s,
-                  const DemodStreams &DS);
+// the demodulators with a recurrence of their own (PLL / AM decoder, squelches), one lane per channel over the whole call, in front of
+// the fused kernel and on the same stream (fmx_demod.hip: disc_kernel + afc_kernel<true> with DeviceBuffers::prepass set)
+void launch_demod_prepass(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
 // stage B as one time-parallel workgroup per channel and segment (fmx_stageb.hip): everything on the caller's stream
 void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,

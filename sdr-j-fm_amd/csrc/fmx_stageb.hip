@@ -346,6 +346,11 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
     unsigned long long ft_t = ft_on ? clock64() : 0ull;
 #endif
     const bool stereo_possible = P.fm_mode != 2, auto_mono = P.auto_mono != 0, pss_active = P.pss_active != 0;
+    // A demodulator with a recurrence of its own -- pllC (PLL and AM decoders, fm-demodulator.cpp:133-166, 215-241, pllC.cpp:67-90), the
+    // squelches (squelchClass.cpp:47-113) -- has run before this kernel, one lane per channel (launch_demod_fused: disc_kernel and
+    // afc_kernel<true> of fmx_demod.hip over the whole call): its output, AFC / scaling / squelch applied, waits in the 16-row tiles of
+    // w_osc and this kernel starts behind the demodulator.
+    const bool special = P.decoder <= 2 || P.squelch_mode != 0;
     const bool pss_on = stereo_possible && pss_active;
     // the sample behind which the reference takes its metaData snapshot (++myCount > fmRate / 2, fm-processor.cpp:662-684), call-relative
     const int my_count0 = st->my_count;
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
     }
     const int64_t pss_count0 = st->pss_count;
     float2 zn[FB_K + 2];
-    fetch((int)threadIdx.x * FB_K, 0, nj < FB_W ? nj : FB_W, zn);
+    if (!special) fetch((int)threadIdx.x * FB_K, 0, nj < FB_W ? nj : FB_W, zn);
     __syncthreads();
     // One segment.  FAST = a full segment (every thread has its six samples) that neither holds the metaData snapshot sample nor the
     // call's first two samples: all the `i < nv` / `i == il` / `i == ix` guards of the general form fold away at compile time (they
@@ -412,6 +417,8 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         const int ix = FAST ? -1 : jx - seg0 - j0;                   // this thread's index of the metaData snapshot sample, if 0 .. K-1
 
         SB_FT(0); SB_FTW(1);      // 0: loop top bookkeeping, 1: wait for the prefetched ring entries
+        float dem[FB_K];
+        if (!special) {
         // ================= limiter + discriminator (fm-demodulator.cpp:119-126, 168-189) =================
         float res[FB_K];
         {
@@ -463,7 +470,6 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         SB_ARGS_FRESH(); SB_TICK1(0);
 
         // ================= AFC + scaling (fm-demodulator.cpp:197-198) =================
-        float dem[FB_K];
         {
             const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha;
             float Lt = 0.f;
@@ -482,6 +488,11 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             }
             if (lastseg && owner) st->fm_afc = afc_end;
             if (tid == 0) cy.afc = afc_next;
+        }
+        } else {
+            // (demodulator output of the pre-pass: row r of this call, channel ch, in the 16-row tiles of w_osc)
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) dem[i] = (i < nv) ? B.w_osc[widx((int64_t)(seg0 + j0 + i), ch, G.pitch)] : 0.f;
         }
         SB_FT(6);
         SB_ARGS_FRESH(); SB_TICK1(1);
@@ -1064,7 +1075,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         // ================= de-emphasis (fm-processor.cpp:594-595) into the d ring =================
         // (the next segment's ring entries are requested here: they land under the de-emphasis, and are not in the way of the
         // register-hungry phases above)
-        if (!lastseg) { const int wn = (nj - seg0 - FB_W) < FB_W ? (nj - seg0 - FB_W) : FB_W; fetch(j0, seg0 + FB_W, wn, zn); }
+        if (!lastseg && !special) { const int wn = (nj - seg0 - FB_W) < FB_W ? (nj - seg0 - FB_W) : FB_W; fetch(j0, seg0 + FB_W, wn, zn); }
         SB_FT(29);
         {
             const float a = P.deemph_alpha;
@@ -1145,6 +1156,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
 
 void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s) {
     if (G.J1 - G.J0 <= 0) return;
+    if (B.w_iq) launch_demod_prepass(T, B, G, C, s);     // some channel has (had) a PLL / AM decoder or a squelch: fmx_demod.hip
     StageBArgs A; A.T = T; A.B = B; A.G = G; A.C = C;
     hipLaunchKernelGGL(stageb_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
 }

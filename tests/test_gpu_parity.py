@@ -389,39 +389,46 @@ def test_level_squelch(fmx_amd, ol, decoder):
     assert rms(pcm_g[0][muted]) < 1e-6 and rms(pcm_g[1][muted]) > 1e-4      # muted vs noise of the weak carrier
 
 
-def test_stage_b_layouts_identical(fmx_amd, ol, monkeypatch):
-    """The two schedules of stage B (persistent recurrence kernel + progress words, and the event-driven five-stream
-    pipeline) run the same chunk bodies: PCM, taps and meta must be bit-identical.  130 channels = three 64-channel
-    groups, the last one nearly empty; mixed per-channel settings; four calls, so state crosses call boundaries in both."""
+def test_mixed_decoders_in_one_batch_equal_single_channel_runs(fmx_amd, ol):
+    """130 channels on one stream with mixed per-channel settings -- among them the PLL decoder, whose loop runs in the lane-per-channel
+    pre-pass in front of the fused stage-B kernel while its neighbours are demodulated inside it: channels with the same settings are
+    bit-identical, and one channel of every kind equals a single-channel handle with those settings bit for bit (state crosses four
+    call boundaries in both)."""
     nch, block = 130, 16384 * 6
     iq = ol.synth_iq(4 * block, stereo=1, noiseSigma=0.002)
-    outs = []
-    for minch in ("1", "0"):
-        monkeypatch.setenv("FMX_PERSISTENT_MIN_CHANNELS", minch)
-        f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block)
-        gui_defaults(f, 165000, True)
-        for c in range(0, nch, 7):
-            f.set_param(M.P_FM_DECODER, 2 + c % 5, c)
-        for c in range(3, nch, 11):
-            f.set_param(M.P_FM_MODE, 2, c)
-        for c in range(5, nch, 13):
-            f.set_param(M.P_PSS, 0, c)
-        pcm = run_blocks(f, iq, block)
-        f.synchronize()
-        outs.append((pcm, f.tap(M.TAP_DEMOD, block // 12, 64), f.tap(M.TAP_LR_RAW, block // 12, 129), f.tap(M.TAP_PRE_RESAMPLER, block // 12, 7),
-                     [f.meta(c).PilotPllLocked for c in (0, 64, 129)]))
-    assert np.array_equal(outs[0][0], outs[1][0])
-    for k in (1, 2, 3):
-        assert np.array_equal(outs[0][k], outs[1][k])
-    assert outs[0][4] == outs[1][4]
-    assert rms(outs[0][0][0]) > 0.01
+
+    def settings(c):
+        return (2 + c % 5 if c % 7 == 0 else 3, 2 if c % 11 == 3 else 0, 0 if c % 13 == 5 else 1)       # (decoder, fm mode, PSS)
+
+    def apply(f, c, to):
+        dec, mode, pss = settings(c)
+        f.set_param(M.P_FM_DECODER, dec, to); f.set_param(M.P_FM_MODE, mode, to); f.set_param(M.P_PSS, pss, to)
+
+    f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block)
+    gui_defaults(f, 165000, True)
+    for c in range(nch):
+        apply(f, c, c)
+    pcm = run_blocks(f, iq, block)
+    f.synchronize()
+    first = {}
+    for c in range(nch):
+        k = settings(c)
+        if k in first:
+            assert np.array_equal(pcm[c], pcm[first[k]]), (c, first[k])
+        else:
+            first[k] = c
+    assert len(first) >= 7 and any(k[0] == 2 for k in first)
+    for k, c in first.items():
+        g = fmx_amd.Fmx(1, max_block=block)
+        gui_defaults(g, 165000, True)
+        apply(g, c, 0)
+        assert np.array_equal(run_blocks(g, iq, block)[0], pcm[c]), k
+    assert rms(pcm[0]) > 0.01
 
 
 def test_large_batch_is_self_consistent(fmx_amd, ol):
-    """2112 channels (33 groups: the regime where the time-parallel kernels share the recurrence kernel's CUs) listening
-    to ONE stream with the same settings: every channel's PCM must be bit-identical to channel 0's, and channel 0 must
-    match the oracle.  A race between the persistent kernel's roles and the time-parallel kernels would show up as a
-    channel that differs."""
+    """2112 channels listening to ONE stream with the same settings: every channel's PCM must be bit-identical to channel 0's, and
+    channel 0 must match the oracle (a race anywhere in the stages would show up as a channel that differs)."""
     nch, block = 2112, 16384 * 6
     iq = ol.synth_iq(5 * block, stereo=1)
     o = ol.OracleChain(inputFilterBw=165000, fmMode=0)
