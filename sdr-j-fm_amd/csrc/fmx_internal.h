@@ -280,7 +280,9 @@ struct RdsBuffers {
     float  *phase_ring;  // [ch][RDS_PHASE_RING]
     float2 *U, *V;       // [ch][32768]     FFT scratch
     float2 *rds24;       // [ch][RDS24_RING]
-    float2 *mf;          // [rows][pitch]   matched-filter output of the call (sample-major)
+    float2 *mf;          // [rows][pitch]   RDS_1: matched-filter output of the call (sample-major)
+    float2 *mfc;         // [ch][mfc_stride] RDS_2: two AGC outputs of the previous call, then the call's matched-filter outputs, AGC'd in place
+    int64_t mfc_stride;
     RdsState *state;
     uint8_t *bits;       // [ch][RDS_BITS_CAP]
     float2 *sym;         // [ch][RDS_SYM_CAP] RDS_2: the sample every bit was decided on (rds-decoder-2.cpp:108-114, `*m = r`), index = bit count

@@ -242,7 +242,8 @@ __global__ void rds_mix_decim(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C,
     Rb.rds24[(size_t)ch * RDS24_RING + (int)(m & (RDS24_RING - 1))] = acc;
 }
 
-// ---- RRC matched filter (rds-decoder-2.cpp:83-98), time-parallel
+// ---- RRC matched filter (rds-decoder-2.cpp:83-98), time-parallel; output channel-major: mfc[ch][2 + q] (entries 0, 1 are the last
+//      two AGC outputs of the previous call, put there by rds_agc)
 __global__ void rds_matched(DeviceBuffers B, RdsBuffers Rb, int64_t m0, int nout) {
     const int ch = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -256,61 +257,104 @@ __global__ void rds_matched(DeviceBuffers B, RdsBuffers Rb, int64_t m0, int nout
         const float w = Rb.rrc[i];
         acc.x += v.x * w; acc.y += v.y * w;
     }
-    Rb.mf[(size_t)q * C_RDS_PITCH(Rb) + ch] = acc;
+    Rb.mfc[(size_t)ch * Rb.mfc_stride + 2 + q] = acc;
 }
 
-// ---- AGC -> Mueller&Mueller timing -> Costas -> slicer -> differential decode   [lane per channel]
-//      agc.h:14-18, rds-decoder-2.cpp:101-157, costas.h:21-33
-__global__ __launch_bounds__(64) void rds_slicer(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
+// The reference's rdsDecoder_2::doDecode runs AGC, Mueller & Mueller timing, Costas loop and slicer per 24 kS/s sample
+// (rds-decoder-2.cpp:101-157).  Only the AGC works on every sample; the rest acts once per symbol (every ~20.2 samples), on the last
+// three AGC outputs, and nothing of it feeds back into the AGC.  One lane per channel walking the samples with the symbol branch
+// inside -- round 1 / 2 -- made a wave pay for the branch at nearly every sample (64 lanes at unrelated symbol phases: some lane
+// is in it 96 % of the time; 0.87 ms per call at 2048 channels on 32 waves).  Two kernels instead:
+//   rds_agc      lane per channel over the samples, AGC only (agc.h:14-18), eight samples per step, in place in mfc;
+//   rds_symbols  lane per channel over the SYMBOLS: the sample a symbol falls on follows from the skip count in closed form
+//                (`++sampleCount >= skipNrSamples`), so a lane jumps from symbol to symbol and every lane is in the branch together.
+__global__ __launch_bounds__(64) void rds_agc(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C || B.params[ch].rds_mode != 2) return;
+    RdsState *sp = Rb.state + ch;
+    float gain = sp->gain;
+    float2 *row = Rb.mfc + (size_t)ch * Rb.mfc_stride;
+    float2 p1 = sp->sb1, p2 = sp->sb2, p0 = sp->sb0;
+    row[0] = p1; row[1] = p2;                                     // what the first symbols of this call may look back at
+    auto agc1 = [&](float2 v) -> float2 {                            // AGC (2e-3, 0.38, start 9): out = in * gain; gain += rate * (ref - |out|)
+        v = make_float2(v.x * gain, v.y * gain);
+        const float mag = (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);   // std::abs(complex) = hypotf
+        gain += 2e-3f * (0.38f - mag);
+        return v;
+    };
+    float4 *r4 = reinterpret_cast<float4 *>(row + 2);             // (row + 2 is 16-byte aligned: mfc_stride is even)
+    const int n8 = nout / 8;
+    for (int k = 0; k < n8; k++) {
+        float4 x[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = r4[4 * k + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float2 a = agc1(make_float2(x[i].x, x[i].y)), b = agc1(make_float2(x[i].z, x[i].w));
+            x[i] = make_float4(a.x, a.y, b.x, b.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) r4[4 * k + i] = x[i];
+    }
+    for (int q = 8 * n8; q < nout; q++) row[2 + q] = agc1(row[2 + q]);
+    // sampleBuffer [0..2] behind the call = the last three AGC outputs (rds-decoder-2.cpp:123-125)
+    if (nout >= 3) { p0 = row[2 + nout - 3]; p1 = row[2 + nout - 2]; p2 = row[2 + nout - 1]; }
+    else for (int q = 0; q < nout; q++) { p0 = p1; p1 = p2; p2 = row[2 + q]; }
+    sp->gain = gain; sp->sb0 = p0; sp->sb1 = p1; sp->sb2 = p2;
+}
+
+// ---- Mueller & Mueller timing -> Costas -> slicer -> differential decode, one step per symbol   [lane per channel]
+//      rds-decoder-2.cpp:120-157, costas.h:21-33
+__global__ __launch_bounds__(64) void rds_symbols(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= C || B.params[ch].rds_mode != 2) return;
     RdsState st = Rb.state[ch];
-    const int pitch = C_RDS_PITCH(Rb);
     const float sps = 24000.0f / 1187.5f;                   // samplesPerSymbol = rate / (float)RDS_BITCLK_HZ
     const float mm_alpha = (float)0.01;
     uint8_t *bits = Rb.bits + (size_t)ch * RDS_BITS_CAP;
-    for (int q = 0; q < nout; q++) {
-        float2 v = Rb.mf[(size_t)q * pitch + ch];
-        // AGC (2e-3, 0.38, start 9)
-        v = make_float2(v.x * st.gain, v.y * st.gain);
-        const float mag = (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);   // std::abs(complex) = hypotf
-        st.gain += 2e-3f * (0.38f - mag);
-        // process_sample rds-decoder-2.cpp:120-157
-        st.sb0 = st.sb1; st.sb1 = st.sb2; st.sb2 = v;
-        if (++st.sample_count >= st.skip) {
-            const float2 r0 = make_float2(st.sb0.x > 0.f ? 1.f : -1.f, st.sb0.y > 0.f ? 1.f : -1.f);
-            const float2 r1 = make_float2(st.sb1.x > 0.f ? 1.f : -1.f, st.sb1.y > 0.f ? 1.f : -1.f);
-            const float2 r2 = make_float2(st.sb2.x > 0.f ? 1.f : -1.f, st.sb2.y > 0.f ? 1.f : -1.f);
-            const float x = (r2.x - r0.x) * st.sb1.x + (r2.y - r0.y) * st.sb1.y;
-            const float y = (st.sb2.x - st.sb0.x) * r1.x + (st.sb2.y - st.sb0.y) * r1.y;
-            const float mm = y - x;
-            st.mu += sps + mm_alpha * mm;
-            st.skip = (int)st.mu;
-            st.mu -= (float)st.skip;
-            st.sample_count = 0;
-            // Costas (alpha 1, beta 0.02, limit 2*pi*10/24000)
-            const float2 e = make_float2(cosf(-st.c_phase), sinf(-st.c_phase));       // std::exp(complex(0, -phase))
-            const float2 r = cmulf(st.sb2, e);
-            const float err = r.x * r.y;
-            st.c_freq += 0.02f * err;
-            if (fabsf(st.c_freq) > st.c_limit) st.c_freq = 0.f;
-            st.c_phase += st.c_freq + 1.0f * err;
-            {   // PI_Constrain, generic form
-                const double pv = (double)st.c_phase;
-                if (!(0.0 <= pv && pv < 6.283185307179586)) {
-                    if (pv >= 6.283185307179586) st.c_phase = (float)fmod(pv, 6.283185307179586);
-                    else if (pv > -6.283185307179586) st.c_phase = (float)(pv + 6.283185307179586);
-                    else st.c_phase = (float)(6.283185307179586 - fmod(-pv, 6.283185307179586));
-                }
+    const float2 *v = Rb.mfc + (size_t)ch * Rb.mfc_stride + 2;     // v[q], q = -2 .. nout - 1: AGC outputs
+    // `if (++sampleCount >= skip)` at sample q of the call: sampleCount = count0 + q + 1
+    int q = st.skip - st.sample_count - 1;
+    q = q < 0 ? 0 : q;
+    int count = st.sample_count + nout;                     // (no symbol in this call)
+    while (q < nout) {
+        const float2 s0 = v[q - 2], s1 = v[q - 1], s2 = v[q];
+        const float2 r0 = make_float2(s0.x > 0.f ? 1.f : -1.f, s0.y > 0.f ? 1.f : -1.f);
+        const float2 r1 = make_float2(s1.x > 0.f ? 1.f : -1.f, s1.y > 0.f ? 1.f : -1.f);
+        const float2 r2 = make_float2(s2.x > 0.f ? 1.f : -1.f, s2.y > 0.f ? 1.f : -1.f);
+        const float x = (r2.x - r0.x) * s1.x + (r2.y - r0.y) * s1.y;
+        const float y = (s2.x - s0.x) * r1.x + (s2.y - s0.y) * r1.y;
+        const float mm = y - x;
+        st.mu += sps + mm_alpha * mm;
+        st.skip = (int)st.mu;
+        st.mu -= (float)st.skip;
+        // Costas (alpha 1, beta 0.02, limit 2*pi*10/24000)
+        const float2 e = make_float2(cosf(-st.c_phase), sinf(-st.c_phase));       // std::exp(complex(0, -phase))
+        const float2 r = cmulf(s2, e);
+        const float err = r.x * r.y;
+        st.c_freq += 0.02f * err;
+        if (fabsf(st.c_freq) > st.c_limit) st.c_freq = 0.f;
+        st.c_phase += st.c_freq + 1.0f * err;
+        {   // PI_Constrain, generic form
+            const double pv = (double)st.c_phase;
+            if (!(0.0 <= pv && pv < 6.283185307179586)) {
+                if (pv >= 6.283185307179586) st.c_phase = (float)fmod(pv, 6.283185307179586);
+                else if (pv > -6.283185307179586) st.c_phase = (float)(pv + 6.283185307179586);
+                else st.c_phase = (float)(6.283185307179586 - fmod(-pv, 6.283185307179586));
             }
-            const int bit = r.x >= 0.f ? 1 : 0;
-            bits[st.nbits & (RDS_BITS_CAP - 1)] = (uint8_t)(bit ^ st.prev_bit);
-            Rb.sym[(size_t)ch * RDS_SYM_CAP + (st.nbits & (RDS_SYM_CAP - 1))] = r;      // *m = r: what the IQ scope shows (fm-processor.cpp:555-563)
-            st.prev_bit = bit;
-            st.nbits++;
         }
+        const int bit = r.x >= 0.f ? 1 : 0;
+        bits[st.nbits & (RDS_BITS_CAP - 1)] = (uint8_t)(bit ^ st.prev_bit);
+        Rb.sym[(size_t)ch * RDS_SYM_CAP + (st.nbits & (RDS_SYM_CAP - 1))] = r;      // *m = r: what the IQ scope shows (fm-processor.cpp:555-563)
+        st.prev_bit = bit;
+        st.nbits++;
+        count = nout - 1 - q;                               // sampleCount behind the call, should this be its last symbol
+        q += st.skip < 1 ? 1 : st.skip;                     // the next sample with sampleCount >= skip (a skip below 1 fires at once)
     }
-    Rb.state[ch] = st;
+    st.sample_count = count;
+    RdsState *sp = Rb.state + ch;                           // (gain and the sample buffer are rds_agc's)
+    sp->mu = st.mu; sp->c_freq = st.c_freq; sp->c_phase = st.c_phase; sp->sample_count = st.sample_count; sp->skip = st.skip;
+    sp->prev_bit = st.prev_bit; sp->nbits = st.nbits;
 }
 
 
@@ -633,7 +677,8 @@ void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G,
     if (nout <= 0) return;
     if (modes & (1 << 2)) {
         hipLaunchKernelGGL(rds_matched, dim3((unsigned)((nout + 255) / 256), C), dim3(256), 0, s, B, Rb, mfirst, nout);
-        hipLaunchKernelGGL(rds_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
+        hipLaunchKernelGGL(rds_agc, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
+        hipLaunchKernelGGL(rds_symbols, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
     }
     if (modes & (1 << 1)) {          // (the mf rows of an RDS_1 channel are its own: the two slicers never share a channel)
         const dim3 gt((unsigned)((nout + 255) / 256), C);
