@@ -317,6 +317,7 @@ int ensure_rds_body(fmx_handle h) {
     if ((rc = dalloc((void **)&R.mf, sizeof(float2) * (size_t)(h->work_nj / 8 + 8) * h->pitch, false))) return rc;
     R.mfc_stride = ((h->work_nj / 8 + 8 + 2 + 7) / 8) * 8;
     if ((rc = dalloc((void **)&R.mfc, sizeof(float2) * (size_t)R.mfc_stride * C, true))) return rc;
+    if ((rc = dalloc((void **)&R.mfm, sizeof(float) * (size_t)R.mfc_stride * C, true))) return rc;
     if ((rc = dalloc((void **)&R.bits, C * RDS_BITS_CAP, true))) return rc;
     if ((rc = dalloc((void **)&R.sym, sizeof(float2) * C * RDS_SYM_CAP, true))) return rc;
     {   // rdsDecoder_2 / AGC / Costas constructor state (rds-decoder-2.cpp:44-78, rds-decoder.cpp:41-43)

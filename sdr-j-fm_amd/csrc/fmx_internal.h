@@ -282,6 +282,7 @@ struct RdsBuffers {
     float2 *rds24;       // [ch][RDS24_RING]
     float2 *mf;          // [rows][pitch]   RDS_1: matched-filter output of the call (sample-major)
     float2 *mfc;         // [ch][mfc_stride] RDS_2: two AGC outputs of the previous call, then the call's matched-filter outputs, AGC'd in place
+    float  *mfm;         // [ch][mfc_stride] RDS_2: |matched-filter output| (same indexing)
     int64_t mfc_stride;
     RdsState *state;
     uint8_t *bits;       // [ch][RDS_BITS_CAP]

@@ -221,18 +221,28 @@ __global__ void rds_mix_decim(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C,
     if (q >= nout || B.params[ch].rds_mode == 0) return;
     const int64_t m = m0 + q;
     float2 acc = make_float2(0.f, 0.f);
+    // block and position of the newest input (one 64-bit division per thread; the ten older inputs follow by counting down)
+    const int64_t n_hi = 8 * m + 7;
+    const int64_t blk_hi = n_hi / RBLK; const int inp_hi = (int)(n_hi - blk_hi * RBLK);
+    const float2 *hil = Rb.hil + (size_t)ch * 2 * RBLK;
+    const float *pring = Rb.phase_ring + (size_t)ch * RDS_PHASE_RING;
+#pragma unroll
     for (int i = 0; i < 11; i++) {                           // newest -> oldest, kernel[0] * newest (fir-filters.cpp:409-418)
-        const int64_t n = 8 * m + 7 - i;
+        const int64_t n = n_hi - i;
         float2 x = make_float2(0.f, 0.f);
         if (n >= 0) {
-            const int64_t blk = n / RBLK; const int inp = (int)(n - blk * RBLK);
+            int inp = inp_hi - i; int64_t blk = blk_hi;
+            if (inp < 0) { inp += RBLK; blk -= 1; }
             // during block blk the Hilbert filter returns the result of block blk-1 (zeros for the first block)
             float2 hv = make_float2(0.f, 0.f);
-            if (blk >= 1) hv = Rb.hil[((size_t)ch * 2 + ((blk - 1) & 1)) * RBLK + inp];
+            if (blk >= 1) hv = hil[(size_t)((blk - 1) & 1) * RBLK + inp];
             float th = 0.f;
-            if (n >= 2 * RBLK) th = Rb.phase_ring[(size_t)ch * RDS_PHASE_RING + (int)((n - 2 * RBLK) & (RDS_PHASE_RING - 1))];
+            if (n >= 2 * RBLK) th = pring[(int)((n - 2 * RBLK) & (RDS_PHASE_RING - 1))];
             th = 3 * th;                                     // thePhase = 3 * rdsPhaseBuffer[idx]  (:744)
-            const float2 osc = make_float2(cosf(th), -sinf(th));
+            // cos / sin (thePhase) (:749-750) from the hardware's sine unit: thePhase lies in [0, 6 pi), the unit takes turns and is good to
+            // ~5e-7 absolute -- on a sub-carrier of 0.07 that is 4e-8, forty times below what the block filters' own rounding leaves
+            const float turns = th * 0.15915494309189535f;
+            const float2 osc = make_float2(__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns));
             x = cmulf(osc, hv);                              // *rdsValueCmpl = oscValue * rdsBaseHilb  (:754)
         }
         const float2 k = Rb.dec_taps[i];
@@ -258,6 +268,8 @@ __global__ void rds_matched(DeviceBuffers B, RdsBuffers Rb, int64_t m0, int nout
         acc.x += v.x * w; acc.y += v.y * w;
     }
     Rb.mfc[(size_t)ch * Rb.mfc_stride + 2 + q] = acc;
+    // |x| for the AGC (std::abs (complex) = hypotf: f64 square root of the f64 sum of squares), taken here where it is time-parallel
+    Rb.mfm[(size_t)ch * Rb.mfc_stride + 2 + q] = (float)sqrt((double)acc.x * (double)acc.x + (double)acc.y * (double)acc.y);
 }
 
 // The reference's rdsDecoder_2::doDecode runs AGC, Mueller & Mueller timing, Costas loop and slicer per 24 kS/s sample
@@ -265,42 +277,77 @@ __global__ void rds_matched(DeviceBuffers B, RdsBuffers Rb, int64_t m0, int nout
 // three AGC outputs, and nothing of it feeds back into the AGC.  One lane per channel walking the samples with the symbol branch
 // inside -- round 1 / 2 -- made a wave pay for the branch at nearly every sample (64 lanes at unrelated symbol phases: some lane
 // is in it 96 % of the time; 0.87 ms per call at 2048 channels on 32 waves).  Two kernels instead:
-//   rds_agc      lane per channel over the samples, AGC only (agc.h:14-18), eight samples per step, in place in mfc;
+//   rds_agc      the AGC (agc.h:14-18) of every sample, in place in mfc: a workgroup per channel, the gain by a scan (see there);
 //   rds_symbols  lane per channel over the SYMBOLS: the sample a symbol falls on follows from the skip count in closed form
 //                (`++sampleCount >= skipNrSamples`), so a lane jumps from symbol to symbol and every lane is in the branch together.
-__global__ __launch_bounds__(64) void rds_agc(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
+constexpr int AGC_T = 256, AGC_K = 10;                         // threads per channel, samples per thread (2400 outputs per 0.1 s call)
+__global__ __launch_bounds__(AGC_T) void rds_agc(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
+    // AGC (2e-3, 0.38, start 9), agc.h:14-18: out = in * gain; gain += rate * (ref - |out|).  |out| = |in * gain| is taken as gain * |in|
+    // with |in| from rds_matched (the same value to an ulp), which makes the gain an AFFINE recurrence, gain' = gain (1 - rate |in|) +
+    // rate ref: one workgroup per channel, every thread composes the maps of its AGC_K adjacent samples in f64, a scan over the
+    // workgroup gives the gain in front of each thread, and the thread then runs its own samples in the reference's f32 expression.
+    // (Lane per channel over the samples -- the first form of this kernel -- had 64 lanes walking 64 rows in 64 different pages:
+    // 0.16-0.2 ms per call at 2048 channels, all of it address translation and load latency.)
+    const int ch = blockIdx.x;
     if (ch >= C || B.params[ch].rds_mode != 2) return;
+    __shared__ double sA[4], sB[4];
+    __shared__ float2 sLast[3];
+    __shared__ float sGain;                                        // the gain behind a round of AGC_T * AGC_K samples
     RdsState *sp = Rb.state + ch;
-    float gain = sp->gain;
+    const float g0 = sp->gain;
     float2 *row = Rb.mfc + (size_t)ch * Rb.mfc_stride;
-    float2 p1 = sp->sb1, p2 = sp->sb2, p0 = sp->sb0;
-    row[0] = p1; row[1] = p2;                                     // what the first symbols of this call may look back at
-    auto agc1 = [&](float2 v) -> float2 {                            // AGC (2e-3, 0.38, start 9): out = in * gain; gain += rate * (ref - |out|)
-        v = make_float2(v.x * gain, v.y * gain);
-        const float mag = (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);   // std::abs(complex) = hypotf
-        gain += 2e-3f * (0.38f - mag);
-        return v;
-    };
-    float4 *r4 = reinterpret_cast<float4 *>(row + 2);             // (row + 2 is 16-byte aligned: mfc_stride is even)
-    const int n8 = nout / 8;
-    for (int k = 0; k < n8; k++) {
-        float4 x[4];
+    const float *mrow = Rb.mfm + (size_t)ch * Rb.mfc_stride + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float2 p0 = sp->sb0, p1 = sp->sb1, p2 = sp->sb2;
+    __syncthreads();                                               // (everybody has read the state the last thread rewrites below)
+    if (tid == 0) { row[0] = p1; row[1] = p2; }                   // what the first symbols of this call may look back at
+    for (int base = 0; base < nout; base += AGC_T * AGC_K) {       // (one round for calls of up to 2560 outputs)
+        const int q0 = base + tid * AGC_K;
+        float a[AGC_K]; float2 x[AGC_K];
+        double A = 1.0, Bv = 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) x[i] = r4[4 * k + i];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float2 a = agc1(make_float2(x[i].x, x[i].y)), b = agc1(make_float2(x[i].z, x[i].w));
-            x[i] = make_float4(a.x, a.y, b.x, b.y);
+        for (int i = 0; i < AGC_K; i++) {
+            const bool ok = q0 + i < nout;
+            a[i] = ok ? mrow[q0 + i] : 0.f; x[i] = ok ? row[2 + q0 + i] : make_float2(0.f, 0.f);
+            if (ok) { const double m = 1.0 - (double)2e-3f * (double)a[i]; A *= m; Bv = Bv * m + (double)2e-3f * (double)0.38f; }
         }
+        // inclusive scan of the maps g -> A g + B over the wave, then over the four waves
+        double cA = A, cB = Bv;
 #pragma unroll
-        for (int i = 0; i < 4; i++) r4[4 * k + i] = x[i];
+        for (int o = 1; o < 64; o <<= 1) {
+            const double pA = __shfl_up(cA, o, 64), pB = __shfl_up(cB, o, 64);
+            if (lane >= o) { cB = cA * pB + cB; cA = cA * pA; }
+        }
+        if (lane == 63) { sA[wv] = cA; sB[wv] = cB; }
+        __syncthreads();
+        double gin = (double)((base == 0) ? g0 : sGain);
+        for (int v = 0; v < wv; v++) gin = sA[v] * gin + sB[v];      // gain behind the waves in front
+        {
+            const double eA = __shfl_up(cA, 1, 64), eB = __shfl_up(cB, 1, 64);
+            if (lane > 0) gin = eA * gin + eB;                          // ... and behind the lanes in front
+        }
+        float gain = (float)gin;
+#pragma unroll
+        for (int i = 0; i < AGC_K; i++) {
+            if (q0 + i < nout) {
+                const float2 v = make_float2(x[i].x * gain, x[i].y * gain);
+                gain += 2e-3f * (0.38f - gain * a[i]);
+                row[2 + q0 + i] = v;
+                if (q0 + i >= nout - 3) sLast[q0 + i - (nout - 3)] = v;
+            }
+        }
+        __syncthreads();                                           // (everybody has taken the last round's gain)
+        if (q0 < nout && q0 + AGC_K >= nout) sp->gain = gain;       // the thread that owns the call's last sample
+        if (tid == AGC_T - 1) sGain = gain;                         // (a further round starts from here)
+        __syncthreads();
     }
-    for (int q = 8 * n8; q < nout; q++) row[2 + q] = agc1(row[2 + q]);
     // sampleBuffer [0..2] behind the call = the last three AGC outputs (rds-decoder-2.cpp:123-125)
-    if (nout >= 3) { p0 = row[2 + nout - 3]; p1 = row[2 + nout - 2]; p2 = row[2 + nout - 1]; }
-    else for (int q = 0; q < nout; q++) { p0 = p1; p1 = p2; p2 = row[2 + q]; }
-    sp->gain = gain; sp->sb0 = p0; sp->sb1 = p1; sp->sb2 = p2;
+    if (tid == 0) {
+        float2 n0 = p0, n1 = p1, n2 = p2;
+        if (nout >= 3) { n0 = sLast[0]; n1 = sLast[1]; n2 = sLast[2]; }
+        else for (int q = 0; q < nout; q++) { n0 = n1; n1 = n2; n2 = row[2 + q]; }
+        sp->sb0 = n0; sp->sb1 = n1; sp->sb2 = n2;
+    }
 }
 
 // ---- Mueller & Mueller timing -> Costas -> slicer -> differential decode, one step per symbol   [lane per channel]
@@ -677,7 +724,7 @@ void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G,
     if (nout <= 0) return;
     if (modes & (1 << 2)) {
         hipLaunchKernelGGL(rds_matched, dim3((unsigned)((nout + 255) / 256), C), dim3(256), 0, s, B, Rb, mfirst, nout);
-        hipLaunchKernelGGL(rds_agc, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
+        hipLaunchKernelGGL(rds_agc, dim3((unsigned)C), dim3(AGC_T), 0, s, B, Rb, C, nout);
         hipLaunchKernelGGL(rds_symbols, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
     }
     if (modes & (1 << 1)) {          // (the mf rows of an RDS_1 channel are its own: the two slicers never share a channel)
