@@ -47,9 +47,10 @@ typedef struct {
     int32_t streams;           /* number of distinct IQ input streams; 0 => one per channel */
     const int32_t *stream_of_channel; /* [channels] or NULL (identity); several channels may share a
                                   wide-band stream and differ in set_localOscillator (BASELINE config 3) */
-    int32_t inputRate;         /* the device's rate (deviceHandler::getRate, radio.cpp:836): 2304000 (fm-constants.h:35) or any rate the reference
-                                  decimates by 6 x 2 = 12, 2304000 <= inputRate < 3456000 (fm-processor.cpp:68-75; what that leaves is treated
-                                  as fmRate, as in the reference); other rates: FMX_E_UNSUPPORTED */
+    int32_t inputRate;         /* the device's rate (deviceHandler::getRate, radio.cpp:836): 2304000 (fm-constants.h:35), or any rate the reference
+                                  decimates by 12 (2304000 <= inputRate < 3456000), by 6 (1152000 <= inputRate < 2304000: its second decimator
+                                  then only filters) or not at all (inputRate / fmRate <= 1: the 192 kS/s devices) -- fm-processor.cpp:68-75,
+                                  :471; what the decimation leaves is treated as fmRate, as in the reference.  Other rates: FMX_E_UNSUPPORTED */
     int32_t fmRate;            /* 192000 */
     int32_t workingRate;       /* 48000 */
     int32_t audioRate;         /* 48000 = workingRate: sendSampletoOutput's direct path (:826-829); any other rate in 8000 .. 192000

@@ -85,6 +85,7 @@ struct fmx_handle_s {
     ChanParams *d_params = nullptr;
     DeviceTables T{}; DeviceBuffers B{};
     int ring = 0, dring = 0, sring = 0;
+    int decim = DECIM, twins = 1;            // the reference's total decimation for cfg.inputRate (12, 6 or 1) and 12 / decim (CallGeom::twins)
     int64_t g_total = 0;                     // input samples consumed per stream
     int64_t work_nj = 0;                     // rows of the sample-major work arrays
     int pitch = 0;                           // their row pitch in elements
@@ -110,17 +111,25 @@ struct fmx_handle_s {
 namespace {
 
 // ---- tap-set construction -----------------------------------------------------------------
-// Front end = inputFilter (optional) * fmBand_1 * fmBand_2 folded into one real /12 polyphase FIR.
-void build_front_set(int32_t bw, int32_t inputRate, int32_t fmRate, float *taps /*A_TAPS_STRIDE*/, FrontSet *fs) {
-    const int32_t IRate = inputRate / 6;                                       // fm-processor.cpp:36
-    design::DecimKernel k1 = design::decim(4 * inputRate / IRate + 1, fmRate / 2, inputRate);   // :68-71
-    design::DecimKernel k2 = design::decim(IRate / fmRate + 1, fmRate / 2, IRate);              // :72-75
-    const int D1 = inputRate / IRate;                                          // 6
-    // y[m] = sum k1[l] x[6m+5-l]; z[j] = sum k2[i] y[2j+1-i]  (fir-filters.cpp:397-424)
-    //  => z[j] = sum_k g[k] x[12j+11-k],  g[k] = sum_{D1*i+l=k} h2[i] h1[l]
-    std::vector<double> g((size_t)(D1 * (k2.hn.size() - 1) + k1.hn.size()), 0.0);
-    for (size_t i = 0; i < k2.hn.size(); i++)
-        for (size_t l = 0; l < k1.hn.size(); l++) g[D1 * i + l] += (double)k2.hn[i] * (double)k1.hn[l];
+// Front end = inputFilter (optional) * fmBand_1 * fmBand_2 folded into one real polyphase FIR evaluated by stage A's /12 kernel.
+// `decim` = the reference's total decimation at this input rate (12: both decimators; 6: fmBand_2 does not decimate; 1: no decimators
+// at all, fm-processor.cpp:471), `twins` = 12 / decim, `p` = which of the twins this set is for: twin p computes the outputs
+// j = twins * m + p, whose newest input decim * j + decim - 1 - L = 12 (m - delay_p) + off_p.  Returns delay_p.
+int build_front_set(int32_t bw, int32_t inputRate, int32_t fmRate, int decim, int p, float *taps /*A_TAPS_STRIDE*/, FrontSet *fs) {
+    std::vector<double> g(1, 1.0);
+    double S1 = 0.0, S2 = 0.0;
+    if (decim > 1) {
+        const int32_t IRate = inputRate / 6;                                       // fm-processor.cpp:36
+        design::DecimKernel k1 = design::decim(4 * inputRate / IRate + 1, fmRate / 2, inputRate);   // :68-71
+        design::DecimKernel k2 = design::decim(IRate / fmRate + 1, fmRate / 2, IRate);              // :72-75 (decimation IRate / fmRate: 2 or 1)
+        const int D1 = inputRate / IRate;                                          // 6
+        // y[m] = sum k1[l] x[6m+5-l]; z[j] = sum k2[i] y[D2 j + D2 - 1 - i]  (fir-filters.cpp:397-424)
+        //  => z[j] = sum_k g[k] x[decim j + decim - 1 - k],  g[k] = sum_{D1*i+l=k} h2[i] h1[l]
+        g.assign((size_t)(D1 * (k2.hn.size() - 1) + k1.hn.size()), 0.0);
+        for (size_t i = 0; i < k2.hn.size(); i++)
+            for (size_t l = 0; l < k1.hn.size(); l++) g[D1 * i + l] += (double)k2.hn[i] * (double)k1.hn[l];
+        S1 = k1.sum; S2 = k2.sum;
+    }
     int L = 0;                                                                 // overlap-add latency in input samples
     if (bw > 0) {
         // inputFilter.setLowPass(fmBandwidth / 2, inputRate), fftFilter(2*32768, 251) (:77,398)
@@ -129,10 +138,11 @@ void build_front_set(int32_t bw, int32_t inputRate, int32_t fmRate, float *taps 
         L = 2 * 32768 - 251;                                                   // NumofSamples fft-filters.cpp:34
     }
     const int NT = (int)g.size();
-    // z[j] = sum_k g[k] x'[12 j + 11 - L - k]  ->  off = 11 - (L mod 12), delay = L div 12 (+ carry)
-    int off = 11 - (L % 12), delay = L / 12;
-    if (off < 0) { off += 12; delay += 1; }
-    fs->off = off; fs->delay_fm = delay;
+    // newest input of this twin's output column m: 12 (m - delay) + off
+    const int64_t e = (int64_t)decim * p + decim - 1 - L;
+    int64_t delay = -(e >= 0 ? e / 12 : -((-e + 11) / 12));
+    const int off = (int)(e + 12 * delay);
+    fs->off = off; fs->delay_fm = (int32_t)delay; fs->zshift = 0;
     int nd = 0;
     std::fill(taps, taps + A_TAPS_STRIDE, 0.f);
     for (int d = 0; d < A_MAX_ND; d++)
@@ -141,8 +151,7 @@ void build_front_set(int32_t bw, int32_t inputRate, int32_t fmRate, float *taps 
             if (k >= 0 && k < NT) { taps[(d + 1) * DECIM + r] = (float)g[k]; nd = d + 1; }
         }
     fs->nd = nd;
-    // complex gain of the (h/sum, h) kernels: (1 + j S1)(1 + j S2)  (fir-filters.cpp:345-346)
-    const double S1 = k1.sum, S2 = k2.sum;
+    // complex gain of the (h/sum, h) kernels: (1 + j S1)(1 + j S2)  (fir-filters.cpp:345-346); 1 without the decimators
     fs->gain_re = (float)(1.0 - S1 * S2); fs->gain_im = (float)(S1 + S2);
     // the FIR's response to the slowly moving RfDC value: sum of the taps (as the kernel sums them: f32 taps) times the value at
     // the taps' centre of mass.  Output column q has its newest input at sample 12 q + off; "RfDC applied to sample s" is the state
@@ -156,7 +165,8 @@ void build_front_set(int32_t bw, int32_t inputRate, int32_t fmRate, float *taps 
     fs->hsum = (float)hs;
     const double q0 = (double)off - mk / hs + 1.0;
     const int K = -(int)std::floor(q0 / 12.0);
-    fs->dc_k = K; fs->dc_w = (float)((q0 + 12.0 * K) / 12.0); fs->pad_ = 0;
+    fs->dc_k = K; fs->dc_w = (float)((q0 + 12.0 * K) / 12.0);
+    return (int)delay;
 }
 
 void build_audio_set(int32_t lf, int32_t fmRate, const std::vector<float> &rs, float *taps /*C_TAPS_STRIDE*/, AudioSet *as) {
@@ -180,31 +190,40 @@ int ensure_sets(fmx_handle h) {
         int32_t b = h->user[c].bandwidth, l = h->user[c].lf_cutoff > 0 ? h->user[c].lf_cutoff : 0;
         auto it = std::find(fk.begin(), fk.end(), b);
         if (it == fk.end()) { fk.push_back(b); it = fk.end() - 1; }
-        h->params[c].front_set = (int)(it - fk.begin());
+        h->params[c].front_set = (int)(it - fk.begin()) * h->twins;          // (index of the channel's first twin set)
         auto ia = std::find(ak.begin(), ak.end(), l);
         if (ia == ak.end()) { ak.push_back(l); ia = ak.end() - 1; }
         h->params[c].audio_set = (int)(ia - ak.begin());
     }
     if (fk != h->front_keys) {
         h->front_keys = fk;
-        h->h_front_taps.assign(fk.size() * A_TAPS_STRIDE, 0.f);
-        h->h_front_sets.resize(fk.size());
-        for (size_t i = 0; i < fk.size(); i++)
-            build_front_set(fk[i], h->cfg.inputRate, h->cfg.fmRate, &h->h_front_taps[i * A_TAPS_STRIDE], &h->h_front_sets[i]);
-        if ((int)fk.size() > h->front_cap) {
+        const size_t TW = (size_t)h->twins, NS = fk.size() * TW;              // one tap set per bandwidth value and twin
+        h->h_front_taps.assign(NS * A_TAPS_STRIDE, 0.f);
+        h->h_front_sets.resize(NS);
+        for (size_t i = 0; i < fk.size(); i++) {
+            int dmin = 0x7fffffff;
+            std::vector<int> dl(TW);
+            for (size_t p = 0; p < TW; p++) {
+                dl[p] = build_front_set(fk[i], h->cfg.inputRate, h->cfg.fmRate, h->decim, (int)p, &h->h_front_taps[(i * TW + p) * A_TAPS_STRIDE], &h->h_front_sets[i * TW + p]);
+                dmin = std::min(dmin, dl[p]);
+            }
+            // fm sample j sits at ring position j - delay_fm: twin p's column m is j = TW (m + delay_p) + p
+            for (size_t p = 0; p < TW; p++) { h->h_front_sets[i * TW + p].zshift = dl[p] - dmin; h->h_front_sets[i * TW + p].delay_fm = (int32_t)(TW * (size_t)dmin); }
+        }
+        if ((int)NS > h->front_cap) {
             if (h->d_front_taps) { (void)hipFree(h->d_front_taps); (void)hipFree(h->d_front_sets); }
-            h->front_cap = std::max<int>((int)fk.size(), 4);
+            h->front_cap = std::max<int>((int)NS, 4);
             HIPCHK(hipMalloc(&h->d_front_taps, sizeof(float) * A_TAPS_DEV * h->front_cap));
             HIPCHK(hipMalloc(&h->d_front_sets, sizeof(FrontSet) * h->front_cap));
         }
         HIPCHK(hipDeviceSynchronize());
-        std::vector<float> dev(fk.size() * A_TAPS_DEV, 0.f);             // device image: [set][r][d]
-        for (size_t i = 0; i < fk.size(); i++)
+        std::vector<float> dev(NS * A_TAPS_DEV, 0.f);                    // device image: [set][r][d]
+        for (size_t i = 0; i < NS; i++)
             for (int d = 0; d < A_MAX_ND; d++)
                 for (int r = 0; r < DECIM; r++)
                     dev[i * A_TAPS_DEV + r * A_TAPS_ROW + d] = h->h_front_taps[i * A_TAPS_STRIDE + (d + 1) * DECIM + r];
         HIPCHK(hipMemcpy(h->d_front_taps, dev.data(), sizeof(float) * dev.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->d_front_sets, h->h_front_sets.data(), sizeof(FrontSet) * fk.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_front_sets, h->h_front_sets.data(), sizeof(FrontSet) * NS, hipMemcpyHostToDevice));
         h->T.front_taps = h->d_front_taps; h->T.front_sets = h->d_front_sets;
     }
     if (ak != h->audio_keys) {
@@ -446,7 +465,7 @@ int flush_mailbox(fmx_handle h) {
         int rc = ensure_rds(h); if (rc) return rc;
         if (h->rds_start < 0) {
             if (h->rds_rearm) { rc = rds_restart(h); if (rc) return rc; h->rds_rearm = false; }
-            h->rds_start = h->g_total / DECIM;       // the RDS filters start counting here (all channels)
+            h->rds_start = h->g_total / h->decim;    // the RDS filters start counting here (all channels)
         }
     } else if (h->rds_start >= 0) {
         // nobody listens any more: the shared overlap-add block phase ends here; the next enable starts from fresh filters,
@@ -519,7 +538,7 @@ void actions_consumed(fmx_handle h, bool had_fm_samples) {
 
 void frames_geom(const fmx_handle h, int64_t n, CallGeom *G) {
     G->g0 = h->g_total; G->n = n;
-    G->J0 = h->g_total / DECIM; G->J1 = (h->g_total + n) / DECIM;
+    G->J0 = h->g_total / h->decim; G->J1 = (h->g_total + n) / h->decim;
     // newConverter: 192 frames in -> 48 out (newconverter.cpp:55-80, inputLimit = fmRate/1000)
     G->M0 = 48 * (G->J0 / 192); G->M1 = 48 * (G->J1 / 192);
 }
@@ -539,7 +558,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     CallGeom G{};
     frames_geom(h, n, &G);
     G.ring_mask = h->ring - 1; G.dring_mask = h->dring - 1; G.sring_mask = h->sring - 1;
-    G.input_rate = h->cfg.inputRate; G.pitch = h->pitch; G.streams_private = h->streams_private ? 1 : 0; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
+    G.input_rate = h->cfg.inputRate; G.pitch = h->pitch; G.streams_private = (h->streams_private && h->twins == 1) ? 1 : 0; G.twins = h->twins; G.channels = h->channels; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
     G.iq_format = fmt; G.iq_scale = (fmt == 3) ? 1.0f / s16_den : 1.0f / 128.0f;
     const int64_t frames = conv2_out(h, G.M1) - conv2_out(h, G.M0);
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
@@ -644,16 +663,22 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     if (cfg->channels < 1) return fail(FMX_E_INVALID, "channels must be >= 1");
     if (cfg->fmRate != 192000 || cfg->workingRate != 48000)
         return fail(FMX_E_UNSUPPORTED, "this build implements fmRate 192000 / workingRate 48000 (radio.cpp:68,231-233)");
+    int decim = DECIM;
     {   // The reference derives its two decimators from inputRate (fm-processor.cpp:36,68-75): fmBand_1 always divides by 6, fmBand_2 by
-        // (inputRate / 6) / fmRate in INTEGER arithmetic -- whatever rate that leaves is then treated as fmRate.  Stage A is built for a
-        // total of 12 (fmx_internal.h DECIM): every input rate with (inputRate / 6) / fmRate == 2, i.e. 2 304 000 <= inputRate < 3 456 000
-        // (2.304, 2.4, 2.56, 2.88, 3.2 MS/s ...), with the filters, the LO table and the DC constant designed for the rate given.
+        // (inputRate / 6) / fmRate in INTEGER arithmetic, and with inputRate / fmRate <= 1 there are no decimators at all (:471) -- whatever
+        // rate that leaves is then treated as fmRate.  Stage A's kernel decimates by 12; a total of 6 or 1 runs it as 2 or 12 "twins" per
+        // channel, one per output phase (CallGeom::twins).  Filters, LO table and DC constant are designed for the rate given.
         if (cfg->inputRate < 1 || cfg->inputRate > 100000000) return fail(FMX_E_INVALID, "inputRate out of range");
-        const int32_t IRate = cfg->inputRate / 6;
-        const int64_t d2 = IRate / cfg->fmRate;
-        if (cfg->inputRate / cfg->fmRate <= 1 || d2 != 2 || 4 * (int64_t)cfg->inputRate / IRate + 1 != 25 || cfg->inputRate / IRate != 6)
-            return fail(FMX_E_UNSUPPORTED, "inputRate: this build implements the reference's decimation by 6 x 2 = 12, i.e. 2304000 <= inputRate < 3456000 "
-                                           "((inputRate / 6) / fmRate == 2, fm-processor.cpp:68-75); rates whose reference decimation is 1, 6 or 18+ are not built");
+        if (cfg->inputRate / cfg->fmRate <= 1) decim = 1;
+        else {
+            const int32_t IRate = cfg->inputRate / 6;
+            const int64_t d2 = IRate / cfg->fmRate;
+            if ((d2 != 1 && d2 != 2) || 4 * (int64_t)cfg->inputRate / IRate + 1 != 25 || cfg->inputRate / IRate != 6)
+                return fail(FMX_E_UNSUPPORTED, "inputRate: built are the rates the reference decimates by 12 (2304000 <= inputRate < 3456000), by 6 "
+                                               "(1152000 <= inputRate < 2304000) and not at all (inputRate < 384000); below 1152000 the reference's "
+                                               "second decimator has one tap and a zero gain (fir-filters.cpp:327-347), from 3456000 on it divides by 3+");
+            decim = 6 * (int)d2;
+        }
     }
     std::vector<float> cv_taps; int cv_p = 1, cv_q = 1, cv_nt = 0;
     if (cfg->audioRate != cfg->workingRate) {
@@ -673,11 +698,12 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     // every failure below goes through fmx_destroy: nothing of a half-built handle stays behind
     auto init = [&]() -> int {
     h->cfg = *cfg; h->cfg.stream_of_channel = nullptr;
+    h->decim = decim; h->twins = DECIM / decim;
     h->channels = cfg->channels;
     h->streams = cfg->streams > 0 ? cfg->streams : cfg->channels;
     if (cv_nt) {
         h->cv_p = cv_p; h->cv_q = cv_q; h->cv_nt = cv_nt;
-        h->x48_stride = cv_nt + cfg->max_block / 48 + 96;
+        h->x48_stride = cv_nt + cfg->max_block / (4 * h->decim) + 96;
         HIPCHK(hipMalloc(&h->d_cv_taps, sizeof(float) * cv_taps.size()));
         HIPCHK(hipMemcpy(h->d_cv_taps, cv_taps.data(), sizeof(float) * cv_taps.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMalloc(&h->d_x48, sizeof(float2) * (size_t)h->channels * h->x48_stride));
@@ -814,14 +840,20 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     h->T.pssmean_l2 = (float)std::log2((double)(1.0f - h->T.pss_lock_alpha));          // stereo-separation.cpp:90 (1.0f - lockAlpha)
 
     // ---- per-channel buffers ------------------------------------------------------------
-    const int64_t fm_per_call = cfg->max_block / DECIM + 2;
-    h->ring = next_pow2(5440 + fm_per_call + 512);
+    const int64_t fm_per_call = cfg->max_block / h->decim + 2;
+    h->ring = next_pow2((2 * 32768 - 251) / h->decim + 1 + fm_per_call + 512);      // the input filter's latency in fm samples + a call
     h->dring = next_pow2(AUDIO_DELAY + C_MAX_TAPS + fm_per_call + 192 + 4 * C_TILE);
     h->sring = 4096;
     const size_t C = (size_t)h->channels;
-    HIPCHK(hipMalloc(&h->B.hist, sizeof(float2) * C * DECIM * A_HIST_COLS));
-    HIPCHK(hipMalloc(&h->B.dcv_hist, sizeof(float2) * C * DCV_SAVE));
-    HIPCHK(hipMemset(h->B.dcv_hist, 0, sizeof(float2) * C * DCV_SAVE));
+    const size_t CT = C * (size_t)h->twins;                    // stage-A workgroups: `twins` per channel
+    HIPCHK(hipMalloc(&h->B.hist, sizeof(float2) * CT * DECIM * A_HIST_COLS));
+    HIPCHK(hipMalloc(&h->B.dcv_hist, sizeof(float2) * CT * DCV_SAVE));
+    HIPCHK(hipMemset(h->B.dcv_hist, 0, sizeof(float2) * CT * DCV_SAVE));
+    if (h->twins > 1) {
+        HIPCHK(hipMalloc(&h->B.state_tw, sizeof(ChanState) * C * (size_t)(h->twins - 1)));
+        HIPCHK(hipMemset(h->B.state_tw, 0, sizeof(ChanState) * C * (size_t)(h->twins - 1)));
+        h->tail_ptrs.push_back(h->B.state_tw);
+    }
     HIPCHK(hipMalloc(&h->B.zring, sizeof(float2) * C * h->ring));
     HIPCHK(hipMalloc(&h->B.sring, sizeof(float2) * C * h->sring));
     HIPCHK(hipMalloc(&h->B.dring, sizeof(float2) * C * h->dring));
@@ -856,14 +888,14 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMalloc(&d_tone, sizeof(float) * TT_BURST));
         HIPCHK(hipMemcpy(d_tone, tone.data(), sizeof(float) * TT_BURST, hipMemcpyHostToDevice));
         h->B.tone = d_tone; h->tail_ptrs.push_back(d_tone);
-        h->B.pk_tiles = (int32_t)((cfg->max_block / 48 + 96) / C_TILE + 8);
+        h->B.pk_tiles = (int32_t)((cfg->max_block / (4 * h->decim) + 96) / C_TILE + 8);
         HIPCHK(hipMalloc(&h->B.pk_part, sizeof(float4) * C * h->B.pk_tiles));
         HIPCHK(hipMalloc(&h->B.pk_ring, sizeof(float2) * C * PK_RING));
         HIPCHK(hipMemset(h->B.pk_part, 0, sizeof(float4) * C * h->B.pk_tiles));
         HIPCHK(hipMemset(h->B.pk_ring, 0, sizeof(float2) * C * PK_RING));
         h->tail_ptrs.push_back(h->B.pk_part); h->tail_ptrs.push_back(h->B.pk_ring);
     }
-    HIPCHK(hipMemset(h->B.hist, 0, sizeof(float2) * C * DECIM * A_HIST_COLS));
+    HIPCHK(hipMemset(h->B.hist, 0, sizeof(float2) * CT * DECIM * A_HIST_COLS));
     HIPCHK(hipMemset(h->B.zring, 0, sizeof(float2) * C * h->ring));
     HIPCHK(hipMemset(h->B.sring, 0, sizeof(float2) * C * h->sring));
     HIPCHK(hipMemset(h->B.dring, 0, sizeof(float2) * C * h->dring));
@@ -937,7 +969,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         for (auto &p : h->params) any |= (p.rds_mode != 0);
         if (!any) { h->rds_start = -1; h->rds_rearm = true; }
     }
-    if (id == FMX_P_RDS_MODE && iv != 0 && h->rds_start >= 0 && h->rds_start != h->g_total / DECIM) {
+    if (id == FMX_P_RDS_MODE && iv != 0 && h->rds_start >= 0 && h->rds_start != h->g_total / h->decim) {
         // The two 32768-point overlap-add filters of the RDS front end run on ONE block phase for the whole batch (all three
         // decoders sit behind them): while other channels are decoding, a channel cannot join in the middle of a block run.
         for (int c = c0; c < c1; c++)
@@ -1027,7 +1059,7 @@ int fmx_process_host_raw(fmx_handle h, const void *iq, int32_t format, float s16
     if (stream_stride < n) return fail(FMX_E_INVALID, "stream_stride < n_complex");
     if (n <= 0 || n > h->cfg.max_block) return fail(FMX_E_TOO_LARGE, "n_complex must be in [1, max_block]");
     HIPCHK(hipSetDevice(h->cfg.device));
-    const int64_t cap = conv2_out(h, h->cfg.max_block / 48 + 96) + 2;
+    const int64_t cap = conv2_out(h, h->cfg.max_block / (4 * h->decim) + 96) + 2;
     if (!h->d_iq) {
         HIPCHK(hipMalloc(&h->d_iq, sizeof(float2) * (size_t)h->streams * h->cfg.max_block));    // sized for the widest format
         HIPCHK(hipMalloc(&h->d_pcm, sizeof(float2) * (size_t)h->channels * cap));
@@ -1072,7 +1104,7 @@ int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
     m->live_pilot_locked = (h->params[channel].fm_mode != 2) ? st.pil_locked : 0;
     m->live_lock_strength = (h->params[channel].fm_mode != 2) ? st.pil_lock : 0.f;
     m->live_dc_if = st.fm_afc; m->squelch_active = (h->params[channel].squelch_mode != 0) ? st.sq_suppress : 0;
-    m->fm_samples = h->g_total / DECIM; m->pcm_frames = conv2_out(h, 48 * ((h->g_total / DECIM) / 192));
+    m->fm_samples = h->g_total / h->decim; m->pcm_frames = conv2_out(h, 48 * ((h->g_total / h->decim) / 192));
     m->live_rf_dc_re = st.dc_re; m->live_rf_dc_im = st.dc_im;
     return FMX_OK;
 }
@@ -1109,7 +1141,7 @@ int fmx_get_peaks(fmx_handle h, int32_t channel, float *lr_db, int32_t capacity,
 
 int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t n) {
     if (!h || !dst || channel < 0 || channel >= h->channels || n < 0) return fail(FMX_E_INVALID, "bad argument");
-    const int64_t J1 = h->g_total / DECIM;
+    const int64_t J1 = h->g_total / h->decim;
     if (tap != 4 && (n > J1 || n > (h->last_J1 - h->last_J0))) return fail(FMX_E_INVALID, "n exceeds the samples produced by the last call");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());

@@ -146,18 +146,22 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     __shared__ int carry_seq;                                              // tiles whose carry is published
     __shared__ int hist_seq[NW], free_seq[NW];                               // per wave image: history of tile (n-1) is in / tile (n-1) is done
 
-    const int ch = blockIdx.x;
+    // (twins: G.twins workgroups per channel, twin tw computes the outputs of phase tw -- see CallGeom::twins)
+    const int vc = blockIdx.x;
+    const int TW = G.twins;
+    const int ch = TW == 1 ? vc : vc / TW;
+    const int tw = vc - ch * TW;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     float4 *X4 = Xall[wave];
     float2 *X2 = reinterpret_cast<float2 *>(X4);
     const ChanParams P = B.params[ch];
-    const FrontSet FS = T.front_sets[P.front_set];
+    const FrontSet FS = T.front_sets[P.front_set + tw];
     const char *__restrict__ inb = reinterpret_cast<const char *>(iq_raw) + (size_t)P.stream * G.stream_stride * BPS;
     const float2 *__restrict__ in = reinterpret_cast<const float2 *>(inb);       // FMT == 0
     const float qs = G.iq_scale;
-    ChanState *st = B.state + ch;
-    float2 *hist = B.hist + (size_t)ch * DECIM * A_HIST_COLS;
+    ChanState *st = tw == 0 ? B.state + ch : B.state_tw + (size_t)(tw - 1) * G.channels + ch;
+    float2 *hist = B.hist + (size_t)vc * DECIM * A_HIST_COLS;
     float2 *zring = B.zring + (size_t)ch * (G.ring_mask + 1);
 
     const int off = FS.off, nd = FS.nd;
@@ -169,9 +173,9 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     const int jb = (int)((G.g0 + G.n - off + 11) / 12 - qa);      // one past the last
     const int qb = (gend - 1) / 12;                   // column holding the last fresh sample
     const int NT = qb / WCOLS + 1;                    // wave tiles in this call
-    const int zr0 = (int)(qa & (int64_t)G.ring_mask);
+    const int zr0 = (int)(((qa + FS.zshift) * TW + tw) & (int64_t)G.ring_mask);      // ring position of this twin's output column qa
 
-    for (int i = t; i < A_TAPS_DEV; i += NTHR) sT[i] = T.front_taps[(size_t)P.front_set * A_TAPS_DEV + i];
+    for (int i = t; i < A_TAPS_DEV; i += NTHR) sT[i] = T.front_taps[(size_t)(P.front_set + tw) * A_TAPS_DEV + i];
     if (t == 0) { carry_seq = 0; for (int i = 0; i < NW; i++) { hist_seq[i] = 0; free_seq[i] = 0; } }
     // ---- history -> the image of tile 0 (wave 0): columns qa-24 .. qa-1 at C 0..23, partial column qa at C 24
     const bool hist_convert = (P.lo_freq != 0) && (T.lo_table != nullptr) && (st->hist_fmt == 0) && (P.dc_remove != 0 || P.att_l != 1.0f || P.att_r != 1.0f);
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
                 // samples DC-corrected and balanced (mixed with the LO of their time: none) -- RfDC of their column from the saved
                 // boundaries (the oldest one for the columns in front of them)
                 const int tb = c - HL + 13;
-                const float2 d = B.dcv_hist[(size_t)ch * DCV_SAVE + (tb < 0 ? 0 : tb)];
+                const float2 d = B.dcv_hist[(size_t)vc * DCV_SAVE + (tb < 0 ? 0 : tb)];
                 v.x = (v.x - __builtin_amdgcn_fmed3f(d.x, -0.01f, 0.01f)) * P.att_l;
                 v.y = (v.y - __builtin_amdgcn_fmed3f(d.y, -0.01f, 0.01f)) * P.att_r;
             }
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
         }
     }
     // RfDC in front of the 13 columns before this call's first column and of that column itself (ring slots -13 .. 0)
-    if (t < 14 && !(P.lo_freq != 0 && T.lo_table != nullptr)) dcv[(t - 13) & (DCV_N - 1)] = B.dcv_hist[(size_t)ch * DCV_SAVE + t];
+    if (t < 14 && !(P.lo_freq != 0 && T.lo_table != nullptr)) dcv[(t - 13) & (DCV_N - 1)] = B.dcv_hist[(size_t)vc * DCV_SAVE + t];
     // per-channel state is read by every wave BEFORE the barrier (the wave that ends the call rewrites it)
     const int lo_phase0 = st->lo_phase;
     const bool dc_rst = (P.actions & ACT_DC_RESET) != 0;          // setDCRemove zeroes RfDC (:922-925)
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
                     // call when the call ends on a column boundary; zero history when DC removal is off)
                     if ((gend % 12) == 0 && lane == 0) dcv[qn & (DCV_N - 1)] = make_float2(dcr ? c_out_r : dc0r, dcr ? c_out_i : dc0i);
                     __builtin_amdgcn_wave_barrier();
-                    if (lane < 14) B.dcv_hist[(size_t)ch * DCV_SAVE + lane] = dcr ? dcv[(qn - 13 + lane) & (DCV_N - 1)] : make_float2(dc0r, dc0i);
+                    if (lane < 14) B.dcv_hist[(size_t)vc * DCV_SAVE + lane] = dcr ? dcv[(qn - 13 + lane) & (DCV_N - 1)] : make_float2(dc0r, dc0i);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -606,16 +610,16 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
             }
             if (fast && (Lg != 1.0f || Rg != 1.0f)) { aA.x *= Lg; aA.y *= Rg; aB.x *= Lg; aB.y *= Rg; }      // IQ balance :462-464
             if (q >= ja && q < jb)
-                zring[(zr0 + q) & G.ring_mask] = make_float2(aA.x * FS.gain_re - aA.y * FS.gain_im, aA.x * FS.gain_im + aA.y * FS.gain_re);
+                zring[(zr0 + q * TW) & G.ring_mask] = make_float2(aA.x * FS.gain_re - aA.y * FS.gain_im, aA.x * FS.gain_im + aA.y * FS.gain_re);
             if (q + 1 >= ja && q + 1 < jb)
-                zring[(zr0 + q + 1) & G.ring_mask] = make_float2(aB.x * FS.gain_re - aB.y * FS.gain_im, aB.x * FS.gain_im + aB.y * FS.gain_re);
+                zring[(zr0 + (q + 1) * TW) & G.ring_mask] = make_float2(aB.x * FS.gain_re - aB.y * FS.gain_im, aB.x * FS.gain_im + aB.y * FS.gain_re);
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) seq_post(&free_seq[wave], ti + 1);          // this image may receive the history of tile ti + 3
         FMX_TICK(5);
     }
     FMX_TICK(6);
-    if (dbg_on) for (int k = 0; k < 8; k++) B.dbg[(size_t)ch * DBG_SLOTS + k] += dbg_acc[k];
+    if (dbg_on && tw == 0) for (int k = 0; k < 8; k++) B.dbg[(size_t)ch * DBG_SLOTS + k] += dbg_acc[k];
     if (t == 0 && lo != 0) {
         long long m = ((long long)G.n * (long long)lo) % (long long)R;
         int ph = (int)(((long long)lo_phase0 - m) % (long long)R);
@@ -627,12 +631,12 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s) {
     switch (G.iq_format) {
-    case 1: hipLaunchKernelGGL((front_kernel<1, false>), dim3(channels), dim3(NTHR), 0, s, T, B, G, iq); break;
-    case 2: hipLaunchKernelGGL((front_kernel<2, false>), dim3(channels), dim3(NTHR), 0, s, T, B, G, iq); break;
-    case 3: hipLaunchKernelGGL((front_kernel<3, false>), dim3(channels), dim3(NTHR), 0, s, T, B, G, iq); break;
+    case 1: hipLaunchKernelGGL((front_kernel<1, false>), dim3(channels * G.twins), dim3(NTHR), 0, s, T, B, G, iq); break;
+    case 2: hipLaunchKernelGGL((front_kernel<2, false>), dim3(channels * G.twins), dim3(NTHR), 0, s, T, B, G, iq); break;
+    case 3: hipLaunchKernelGGL((front_kernel<3, false>), dim3(channels * G.twins), dim3(NTHR), 0, s, T, B, G, iq); break;
     default:
-        if (G.streams_private) hipLaunchKernelGGL((front_kernel<0, true>), dim3(channels), dim3(NTHR), 0, s, T, B, G, iq);
-        else hipLaunchKernelGGL((front_kernel<0, false>), dim3(channels), dim3(NTHR), 0, s, T, B, G, iq);
+        if (G.streams_private) hipLaunchKernelGGL((front_kernel<0, true>), dim3(channels * G.twins), dim3(NTHR), 0, s, T, B, G, iq);
+        else hipLaunchKernelGGL((front_kernel<0, false>), dim3(channels * G.twins), dim3(NTHR), 0, s, T, B, G, iq);
         break;
     }
 }

@@ -44,7 +44,8 @@ struct FrontSet {
     // RF DC removal applied BEHIND the FIR (channels without LO mix, fmx_front.hip): the taps' sum, and where the RfDC value an
     // output takes sits -- the taps' centre of mass: boundary column = output column - dc_k, weight dc_w towards the next one
     float   hsum, dc_w;
-    int32_t dc_k, pad_;
+    int32_t dc_k;
+    int32_t zshift;      // twins (CallGeom::twins > 1): output column q of this twin is fm sample twins * (q + zshift) + twin index of the ring
 };
 constexpr int DCV_SAVE = 16;           // RfDC boundary values kept per channel between calls (14 used)
 
@@ -209,17 +210,20 @@ struct CallGeom {
     int32_t iq_format;   // fmx_iq_format of the input buffer
     float   iq_scale;    // 1/128 (U8, S8) or 1/denominator (S16)
     int32_t gain_fix;    // the call's first GAIN_FIX_FRAMES frames take a correction from B.gfix (a volume / balance change, fmx_audio.hip)
-    int32_t pad_gf;
+    int32_t twins;       // stage A always decimates by 12; an input rate the reference decimates by 12 / twins (6: twins = 2, 1: twins = 12) runs
+                         // `twins` workgroups per channel, twin p with the tap alignment of output phase p, interleaved in the fm-rate ring
+    int32_t channels, pad_gf;
 };
 
 constexpr int DBG_SLOTS = 96;
 struct DeviceBuffers {
-    float2 *hist;        // [channels][DECIM][A_HIST_COLS]   input history (column layout): raw samples; DC-corrected and mixed ones for channels with an LO
-    float2 *dcv_hist;    // [channels][DCV_SAVE] RfDC in front of the 13 columns before the next call's first column, and of that column
+    float2 *hist;        // [channels * twins][DECIM][A_HIST_COLS]   input history (column layout): raw samples; DC-corrected and mixed ones for channels with an LO
+    float2 *dcv_hist;    // [channels * twins][DCV_SAVE] RfDC in front of the 13 columns before the next call's first column, and of that column
     float2 *zring;       // [channels][ring]  front-end output v[j]
     float2 *sring;       // [channels][sring] PSS filter input history
     float2 *dring;       // [channels][dring] de-emphasised, gained stereo @ fmRate
     ChanState *state;
+    ChanState *state_tw; // [twins - 1][channels] stage-A state (RfDC, LO phase, history format) of the twins p > 0 (null when twins == 1)
     const ChanParams *params;
     unsigned long long *dbg;   // optional [channels][DBG_SLOTS] diagnostics (null = off): 0-7 per-phase cycles of front_kernel, 8-12 path / round
                                // counters of stage B, 16-27 per-phase cycles of stageb_seg_kernel

@@ -59,7 +59,9 @@ public:
         c.max_block = bufferSize;
         check(fmx_create(&c, &h));
         inBuf.resize(bufferSize);
-        outBuf.resize((size_t)((int64_t)(bufferSize / 48 + 64) * std::max(audioRate, workingRate) / workingRate + 8));   // second converter: audioRate / workingRate frames per 48 kHz frame
+        // one PCM frame per 4 fm samples; an input rate the reference does not decimate (192 kS/s devices) gives bufferSize fm samples per
+        // block; the second converter makes audioRate / workingRate frames of every 48 kHz frame
+        outBuf.resize((size_t)((int64_t)(bufferSize / 4 + 64) * std::max(audioRate, workingRate) / workingRate + 8));
     }
     ~FmProcessor() { stop(); if (h) fmx_destroy(h); }
     FmProcessor(const FmProcessor &) = delete;
@@ -121,7 +123,7 @@ public:
                                     reinterpret_cast<float *>(outBuf.data()), (int64_t)outBuf.size(), &frames)))
             return false;
         if (frames > 0 && theSink) theSink->putSamples(outBuf.data(), (int32_t)frames);
-        fmCount += amount / 12;
+        fmCount += fmx_last_fm_samples(h);                                    // (amount / the reference's decimation at this input rate)
         return true;
     }
     // QThread::run() equivalent; stop() as fm-processor.cpp:204-211

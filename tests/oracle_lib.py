@@ -363,7 +363,8 @@ class OracleChain:
     def process(self, iq):
         iq = np.ascontiguousarray(iq, np.float32).reshape(-1, 2)
         n = iq.shape[0]
-        cap = n // 48 + 64 + 16384 // 48 + 2              # (the chain works in the reference's 16384-sample blocks: up to one block may be pending)
+        dec = 12 if self.cfg.inputRate >= 2304000 else (6 if self.cfg.inputRate // self.cfg.fmRate > 1 else 1)      # fm-processor.cpp:68-75, 471
+        cap = n // (4 * dec) + 64 + 16384 // (4 * dec) + 2  # (the chain works in the reference's 16384-sample blocks: up to one block may be pending)
         cap = cap * max(self.cfg.audioRate, self.cfg.workingRate) // self.cfg.workingRate + 8      # second converter (audioRate != workingRate)
         pcm = np.zeros((cap, 2), np.float32)
         got = self.L.fmo_chain_process(self.h, fptr(iq), n, fptr(pcm), cap)

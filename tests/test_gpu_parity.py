@@ -553,7 +553,7 @@ def test_error_behaviour(fmx_amd):
     with pytest.raises(fmx_amd.FmxError):
         f.set_param(M.P_VOLUME_DB, 0.0, channel=2)       # channel out of range
     with pytest.raises(fmx_amd.FmxError):
-        fmx_amd.Fmx(1, inputRate=192000)                 # only 2304000 is built
+        fmx_amd.Fmx(1, inputRate=1000000)                # a rate at which the reference's own second decimator degenerates
 
 
 # ------------------------------------------------------------------------------------------------
