@@ -193,4 +193,27 @@ __host__ __device__ __forceinline__ void sincos_idx_f32(int idx, float *sn, floa
     *cs = (((q >> 1) ^ (q >> 2)) & 1) ? -c : c;
 }
 
+// The same table entries from the hardware sine unit (v_sin_f32 / v_cos_f32 take turns): the index is folded into the first quadrant in
+// integers (exact), so the argument is at most a quarter turn and carries 2^-26 turns of rounding; measured against the table for all
+// 192000 entries (tools/ubench/hwsin.hip on gfx950): worst |error| 1.19e-7 (one ulp at 1), rms 4.1e-8 -- inside the polynomials'
+// 1.5e-7 -- at a third of their instructions.
+__device__ __forceinline__ float sin_idx_hw(int idx) {
+    constexpr int QUAD = SINCOS_N / 4;
+    const int q = (int)(((unsigned)(idx >> 7) * 2797u) >> 20);          // idx / 48000 for idx < 384000
+    const int r = idx - q * QUAD;
+    const int rr = (q & 1) ? QUAD - r : r;
+    const float s = __builtin_amdgcn_sinf((float)rr * (1.0f / (float)SINCOS_N));
+    return (q & 2) ? -s : s;
+}
+__device__ __forceinline__ void sincos_idx_hw(int idx, float *sn, float *cs) {      // idx < 192000
+    constexpr int QUAD = SINCOS_N / 4;
+    const int q = (int)(((unsigned)(idx >> 7) * 2797u) >> 20);
+    const int r = idx - q * QUAD;
+    const int rr = (q & 1) ? QUAD - r : r;
+    const float t = (float)rr * (1.0f / (float)SINCOS_N);
+    const float s = __builtin_amdgcn_sinf(t), c = __builtin_amdgcn_cosf(t);
+    *sn = (q & 2) ? -s : s;
+    *cs = ((q + 1) & 2) ? -c : c;
+}
+
 }  // namespace fmx

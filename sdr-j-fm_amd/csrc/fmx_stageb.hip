@@ -357,12 +357,17 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
     const int jx = (SINCOS_N >> 1) - my_count0;
     // ring entries of the samples j0 - 2 .. j0 + K - 1 of the segment at seg0 (clamped to the call's last sample: never past what
     // stage A wrote; zero until the filter latency has elapsed; the marker NaN where the reference's start values 0.01 apply)
+    // (loop-invariant scalars of the prefetch and of the segment dispatch, read once: through the kernarg pointer they would cost a chain
+    // of three dependent scalar loads per segment, 1.5 k cycles of a wave's 58 k)
+    const int zdelay = special ? 0 : T.front_sets[P.front_set].delay_fm;
+    const float2 *const zr = B.zring + (size_t)ch * (G.ring_mask + 1);
+    const int64_t callJ0 = G.J0;
+    const int zmask = G.ring_mask;
     auto fetch = [&](int j0, int seg0, int w, float2 *z) {
-        const int delay = T.front_sets[P.front_set].delay_fm;
-        const float2 *zr = B.zring + (size_t)ch * (G.ring_mask + 1);
-        const int64_t base = G.J0 + seg0;
+        const int delay = zdelay;
+        const int64_t base = callJ0 + seg0;
         if (w == FB_W && base - 2 - delay >= 0) {                // (the same for every thread) a full segment behind the filter latency:
-            const int rmask = G.ring_mask;                       // no clamp, no marker, no zero fill; ring positions in 32 bits
+            const int rmask = zmask;                             // no clamp, no marker, no zero fill; ring positions in 32 bits
             const int r0 = (int)((base - delay) & rmask) + j0 - 2;
 #pragma unroll
             for (int t = 0; t < FB_K + 2; t++) z[t] = zr[(r0 + t) & rmask];
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             const int jr = j0 - 2 + t;
             const int64_t jj = base + (jr < w ? jr : w - 1);
             const int64_t s = jj - delay;
-            z[t] = jj < 0 ? make_float2(__builtin_nanf(""), 0.f) : (s >= 0 ? zr[s & G.ring_mask] : make_float2(0.f, 0.f));
+            z[t] = jj < 0 ? make_float2(__builtin_nanf(""), 0.f) : (s >= 0 ? zr[s & zmask] : make_float2(0.f, 0.f));
         }
     };
     if (threadIdx.x == 0) {
@@ -528,10 +533,14 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
             float ph[FB_K];
             // the reference's step on one guess: table index in f64 as sincos.cpp:81-85 computes it, everything else in f32
             float nxl = 0.f;                                     // step result of this thread's last evaluated sample `il` (the owner's: the next segment's start)
+            bool seq = P.pll_seq != 0;                           // this pass evaluates the loop sample by sample (the same in every thread)
             auto eval = [&](int i, float phase, float *nx_out) {
                 int idx = (int)((double)phase * SC64);           // SinCos::getSin sincos.cpp:81-85 for phase >= 0: entry (int)(phase * C) % Rate
                 idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
-                const float o = sin_idx_f32(idx);
+                // (table value: Newton's method from the hardware sine unit, 1.2e-7, a third of the instructions; the sample-by-sample
+                // solver -- the one that is asked for the reference's trajectory -- keeps the polynomial, whose errors are half as large)
+                float o;
+                if (seq) o = sin_idx_f32(idx); else o = sin_idx_hw(idx);
                 const float perr = (5 * dem[i]) * o;             // pilot-recover.cpp:56-58 (pilot = 5 * demod fm-processor.cpp:696)
                 const float t = phase + perr * gain;
                 const float val = t + omega;
@@ -552,7 +561,6 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 }
                 return phase;
             };
-            bool seq = P.pll_seq != 0;                           // this pass evaluates the loop sample by sample (the same in every thread)
             if (!seq) {   // ---- the first guess
                 float rv[FB_K];                                  // the ramp x0 + j omega in turns, fraction
                 const double tb = ((double)x0 + (double)j0 * (double)omega) * (1.0 / FMX_2PI);
@@ -1036,7 +1044,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
                 int idx = (int)(u * (double)SINCOS_N);               // SinCos::getComplex sincos.cpp:93-97
                 idx = idx >= SINCOS_N ? SINCOS_N - 1 : idx;
                 float2 e;
-                sincos_idx_f32(idx, &e.y, &e.x);
+                sincos_idx_hw(idx, &e.y, &e.x);
                 float dif = 0.f;
                 if (tag[i] != -2) {
                     if (tag[i] >= 0 && i < nv) sring[(icl + tag[i]) & smask] = make_float2(e.x * dem[i], e.y * dem[i]);
@@ -1115,7 +1123,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         SB_ARGS_FRESH(); SB_TICK1(7);
     };
     for (int seg0 = 0; seg0 < nj; seg0 += FB_W) {
-        const bool fast = (nj - seg0 >= FB_W) && !((unsigned)(jx - seg0) < (unsigned)FB_W) && (G.J0 + seg0 >= 2);
+        const bool fast = (nj - seg0 >= FB_W) && !((unsigned)(jx - seg0) < (unsigned)FB_W) && (callJ0 + seg0 >= 2);
         if (fast) segment(std::true_type{}, seg0); else segment(std::false_type{}, seg0);
     }
     // ================= bookkeeping behind the call =================
