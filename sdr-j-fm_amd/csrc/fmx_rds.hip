@@ -33,9 +33,12 @@ __global__ __launch_bounds__(256) void rds_fft_step1(const float2 *__restrict__ 
                                                      size_t pair_stride = 0, int C = 0) {
     __shared__ float2 s[16][RN1 + 1];
     __shared__ float2 tw[RN1 / 2];
+    __shared__ float2 twA[RN1], twB[RN2];                  // W_128^a, W_32768^b
     const int tid = threadIdx.x;
     const int ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
     const int c0 = blockIdx.x * 16;
+    if (tid < RN1) { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN1, &sn, &cs); twA[tid] = make_float2(cs, sn); }
+    { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN, &sn, &cs); twB[tid] = make_float2(cs, sn); }
     const float2 *x = in + (size_t)ch * RN;
     float2 *a = out + (size_t)ch * RN;
     if (tid < RN1 / 2) { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN1, &sn, &cs); tw[tid] = make_float2(cs, sn); }
@@ -71,11 +74,13 @@ __global__ __launch_bounds__(256) void rds_fft_step1(const float2 *__restrict__ 
             __syncthreads();
         }
     }
+    // twiddle W_N^(n2 k1): the exponent m = n2 k1 mod N split as 256 a + b, W_N^m = W_128^a W_N^b from two small tables in LDS
+    // (384 sincospif per workgroup instead of 2048: the libm call was most of this kernel's instructions)
     for (int i = tid; i < RN1 * 16; i += 256) {
         const int k1 = i >> 4, c = i & 15, n2 = c0 + c;
-        float sn, cs;
-        sincospif(-2.0f * (float)((k1 * n2) & (RN - 1)) / (float)RN, &sn, &cs);
-        a[k1 * RN2 + n2] = cmulf(s[c][k1], make_float2(cs, sn));
+        const int m = (k1 * n2) & (RN - 1);
+        const float2 w = cmulf(twA[m >> 8], twB[m & 255]);
+        a[k1 * RN2 + n2] = cmulf(s[c][k1], w);
     }
 }
 // ---- step 2: 128 row FFTs of length 256, 16 rows per workgroup; X[k1 + 128 k2] = sum_n2 a[k1][n2] W_256^(n2 k2)
