@@ -15,6 +15,7 @@
 // Everything downstream of them is cheap: the mix + decimator is time-parallel (each 24 kS/s output recomputes its
 // 11 inputs), the matched filter is time-parallel, and only AGC / M&M / Costas run as a lane-per-channel recurrence.
 #include "fmx_internal.h"
+#include "fmx_fftconv.h"
 
 namespace fmx {
 
@@ -24,66 +25,79 @@ constexpr int RDEG = 768;
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// ---- four-step FFT, step 1: 256 column FFTs of length 128 (+ twiddle), 16 columns per workgroup.
+// ---- 16-point DFT in registers (two 8-point DFTs of fmx_fftconv.h + the 16th roots of unity), natural order in and out
+__device__ __forceinline__ void dft16_fwd(float2 *v) {
+    float2 e[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    fftc::dft8<-1>(e); fftc::dft8<-1>(o);
+    // exp (-2 pi i k / 16), k = 0 .. 7
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, r2 = 0.70710678118654752440f;
+    const float2 w[8] = { make_float2(1.f, 0.f), make_float2(c1, -s1), make_float2(r2, -r2), make_float2(s1, -c1),
+                          make_float2(0.f, -1.f), make_float2(-s1, -c1), make_float2(-r2, -r2), make_float2(-c1, -s1) };
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float2 t = k == 0 ? o[0] : fftc::cmul(o[k], w[k]);
+        v[k] = fftc::cadd(e[k], t); v[k + 8] = fftc::csub(e[k], t);
+    }
+}
+
+// ---- four-step FFT, step 1: 256 column FFTs of length 128 (+ twiddle), 32 columns per workgroup (256-byte row segments in HBM).
 //      in  : x[n], n = 256*n1 + n2          out : a[k1*256 + n2] = W_N^(n2 k1) * sum_n1 x[256 n1 + n2] W_128^(n1 k1)
+// Eight threads per column, sixteen points per thread, 128 = 16 x 8: n1 = 8 p + t, k1 = q + 16 u,
+//      X[q + 16 u] = sum_t W_8^(t u) W_128^(t q) sum_p x[8 p + t] W_16^(p q)
+// -- a 16-point DFT in registers, one exchange through LDS, an 8-point DFT in registers.  (Rounds 1-2: radix 2 in LDS, seven passes with
+// a barrier each: LDS bound at 2.4-2.9 TB/s of HBM traffic.)
 // pair_src != null: the row is not read from `in` but built on the fly from two real 32000-sample blocks, channels 2 p and 2 p + 1 as
 // real and imaginary part, zero padded (rds_load_real_pair fused into the transform's first pass)
+constexpr int S1C = 32;
 __global__ __launch_bounds__(256) void rds_fft_step1(const float2 *__restrict__ in, float2 *__restrict__ out, int nch,
                                                      const int *__restrict__ chlist, const float *__restrict__ pair_src = nullptr,
                                                      size_t pair_stride = 0, int C = 0) {
-    __shared__ float2 s[16][RN1 + 1];
-    __shared__ float2 tw[RN1 / 2];
+    __shared__ __attribute__((aligned(16))) float2 sx[S1C][RN1 + 2];     // [column][q * 8 + t]; the pad keeps the 16-byte reads of adjacent columns apart
     __shared__ float2 twA[RN1], twB[RN2];                  // W_128^a, W_32768^b
     const int tid = threadIdx.x;
     const int ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
-    const int c0 = blockIdx.x * 16;
-    if (tid < RN1) { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN1, &sn, &cs); twA[tid] = make_float2(cs, sn); }
-    { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN, &sn, &cs); twB[tid] = make_float2(cs, sn); }
+    const int c0 = blockIdx.x * S1C;
     const float2 *x = in + (size_t)ch * RN;
     float2 *a = out + (size_t)ch * RN;
-    if (tid < RN1 / 2) { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN1, &sn, &cs); tw[tid] = make_float2(cs, sn); }
+    if (tid < RN1) { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN1, &sn, &cs); twA[tid] = make_float2(cs, sn); }
+    { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN, &sn, &cs); twB[tid] = make_float2(cs, sn); }
+    const int col = tid & (S1C - 1), t = tid >> 5, n2 = c0 + col;
+    float2 v[16];
     if (pair_src) {
         const float *pa = pair_src + (size_t)(2 * ch) * pair_stride, *pb = pair_src + (size_t)(2 * ch + 1) * pair_stride;
         const bool hb = 2 * ch + 1 < C;
-        for (int i = tid; i < RN1 * 16; i += 256) {
-            const int n1 = i >> 4, c = i & 15, n = n1 * RN2 + c0 + c;
-            s[c][n1] = make_float2(n < RBLK ? pa[n] : 0.f, (n < RBLK && hb) ? pb[n] : 0.f);
-        }
-    } else
-    for (int i = tid; i < RN1 * 16; i += 256) { const int n1 = i >> 4, c = i & 15; s[c][n1] = x[n1 * RN2 + c0 + c]; }
-    __syncthreads();
-    // 16 independent FFT-128, 16 threads each
-    {
-        const int f = tid >> 4, lt = tid & 15;
-        float2 *v = s[f];
-        for (int i = lt; i < RN1; i += 16) {
-            const int j = (int)(__brev((unsigned)i) >> 25);
-            if (j > i) { const float2 t = v[i]; v[i] = v[j]; v[j] = t; }
-        }
-        __syncthreads();
-        for (int size = 2, step = RN1 / 2; size <= RN1; size <<= 1, step >>= 1) {
-            const int half = size >> 1;
-            for (int b = lt; b < RN1 / 2; b += 16) {
-                const int grp = b / half, k = b - grp * half;
-                const int j = grp * size + k, l = j + half;
-                const float2 t = cmulf(v[l], tw[k * step]);
-                const float2 u = v[j];
-                v[l] = make_float2(u.x - t.x, u.y - t.y);
-                v[j] = make_float2(u.x + t.x, u.y + t.y);
-            }
-            __syncthreads();
-        }
+#pragma unroll
+        for (int p = 0; p < 16; p++) { const int n = (8 * p + t) * RN2 + n2; v[p] = make_float2(n < RBLK ? pa[n] : 0.f, (n < RBLK && hb) ? pb[n] : 0.f); }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 16; p++) v[p] = x[(8 * p + t) * RN2 + n2];
     }
-    // twiddle W_N^(n2 k1): the exponent m = n2 k1 mod N split as 256 a + b, W_N^m = W_128^a W_N^b from two small tables in LDS
-    // (384 sincospif per workgroup instead of 2048: the libm call was most of this kernel's instructions)
-    for (int i = tid; i < RN1 * 16; i += 256) {
-        const int k1 = i >> 4, c = i & 15, n2 = c0 + c;
-        const int m = (k1 * n2) & (RN - 1);
-        const float2 w = cmulf(twA[m >> 8], twB[m & 255]);
-        a[k1 * RN2 + n2] = cmulf(s[c][k1], w);
+    __syncthreads();                                       // (the twiddle tables)
+    dft16_fwd(v);
+#pragma unroll
+    for (int q = 0; q < 16; q++) sx[col][q * 8 + t] = q == 0 ? v[0] : fftc::cmul(v[q], twA[t * q]);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int q = t + 8 * h;
+        float2 w[8];
+        const float4 *r4 = reinterpret_cast<const float4 *>(&sx[col][q * 8]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 f = r4[i]; w[2 * i] = make_float2(f.x, f.y); w[2 * i + 1] = make_float2(f.z, f.w); }
+        fftc::dft8<-1>(w);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k1 = q + 16 * u;
+            const int m = (k1 * n2) & (RN - 1);            // twiddle W_N^(n2 k1): the exponent split as 256 a + b
+            a[k1 * RN2 + n2] = fftc::cmul(w[u], fftc::cmul(twA[m >> 8], twB[m & 255]));
+        }
     }
 }
-// ---- step 2: 128 row FFTs of length 256, 16 rows per workgroup; X[k1 + 128 k2] = sum_n2 a[k1][n2] W_256^(n2 k2)
+// ---- step 2: 128 row FFTs of length 256, 16 rows per workgroup; X[k1 + 128 k2] = sum_n2 a[k1][n2] W_256^(n2 k2).
+// Sixteen threads per row, sixteen points per thread, 256 = 16 x 16: n2 = 16 p + t, k2 = q + 16 u, two 16-point DFTs in registers around
+// one exchange through LDS (the second one with the threads regrouped so that adjacent lanes hold adjacent k1: 128-byte segments out).
 // EPI: what happens to the transform's result on its way out (the element-wise passes of the block filters fused into the
 // transform's last pass): 0 stored as it is; 1 times the filter vector S (and `scale`), conjugated (rds_spectrum); 2 band-pass
 // pair behind the second transform -- conj / N, overlap add, the two real block results, the two new tails (rds_finish_pair +
@@ -97,57 +111,54 @@ struct RdsEpi {
 template <int EPI>
 __global__ __launch_bounds__(256) void rds_fft_step2(const float2 *__restrict__ in, float2 *__restrict__ out, int nch,
                                                      const int *__restrict__ chlist, RdsEpi E) {
-    __shared__ float2 s[16][RN2 + 1];
-    __shared__ float2 tw[RN2 / 2];
+    constexpr int QS = 18, RS = 16 * QS + 2;               // [row][q * 18 + t]: strides that keep both sides' LDS accesses conflict-free
+    __shared__ __attribute__((aligned(16))) float2 sy[16][RS];
+    __shared__ float2 tw[RN2];                             // W_256^i
     const int tid = threadIdx.x;
     const int ch = chlist ? chlist[blockIdx.y] : blockIdx.y;
     const int k10 = blockIdx.x * 16;
     const float2 *a = in + (size_t)ch * RN;
     float2 *X = out + (size_t)ch * RN;
-    if (tid < RN2 / 2) { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN2, &sn, &cs); tw[tid] = make_float2(cs, sn); }
-    for (int i = tid; i < RN2 * 16; i += 256) { const int r = i >> 8, n2 = i & 255; s[r][n2] = a[(k10 + r) * RN2 + n2]; }
-    __syncthreads();
+    { float sn, cs; sincospif(-2.0f * (float)tid / (float)RN2, &sn, &cs); tw[tid] = make_float2(cs, sn); }
+    float2 v[16];
     {
-        const int f = tid >> 4, lt = tid & 15;
-        float2 *v = s[f];
-        for (int i = lt; i < RN2; i += 16) {
-            const int j = (int)(__brev((unsigned)i) >> 24);
-            if (j > i) { const float2 t = v[i]; v[i] = v[j]; v[j] = t; }
-        }
-        __syncthreads();
-        for (int size = 2, step = RN2 / 2; size <= RN2; size <<= 1, step >>= 1) {
-            const int half = size >> 1;
-            for (int b = lt; b < RN2 / 2; b += 16) {
-                const int grp = b / half, k = b - grp * half;
-                const int j = grp * size + k, l = j + half;
-                const float2 t = cmulf(v[l], tw[k * step]);
-                const float2 u = v[j];
-                v[l] = make_float2(u.x - t.x, u.y - t.y);
-                v[j] = make_float2(u.x + t.x, u.y + t.y);
-            }
-            __syncthreads();
-        }
+        const int row = tid >> 4, t = tid & 15;
+#pragma unroll
+        for (int p = 0; p < 16; p++) v[p] = a[(k10 + row) * RN2 + 16 * p + t];
+        __syncthreads();                                   // (the twiddle table)
+        dft16_fwd(v);
+#pragma unroll
+        for (int q = 0; q < 16; q++) sy[row][q * QS + t] = q == 0 ? v[0] : fftc::cmul(v[q], tw[t * q]);
     }
-    for (int i = tid; i < RN2 * 16; i += 256) {
-        const int k2 = i >> 4, r = i & 15, k = (k10 + r) + RN1 * k2;
-        const float2 v = s[r][k2];
-        if (EPI == 0) X[k] = v;
-        else if (EPI == 1) { float2 w = cmulf(v, E.S[k]); X[k] = make_float2(w.x * E.scale, -(w.y * E.scale)); }
+    __syncthreads();
+    const int r = tid & 15, q = tid >> 4;
+    {
+        const float4 *r4 = reinterpret_cast<const float4 *>(&sy[r][q * QS]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const float4 f = r4[i]; v[2 * i] = make_float2(f.x, f.y); v[2 * i + 1] = make_float2(f.z, f.w); }
+        dft16_fwd(v);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int k2 = q + 16 * u, k = (k10 + r) + RN1 * k2;
+        const float2 vv = v[u];
+        if (EPI == 0) X[k] = vv;
+        else if (EPI == 1) { float2 w = cmulf(vv, E.S[k]); X[k] = make_float2(w.x * E.scale, -(w.y * E.scale)); }
         else if (EPI == 2) {
-            const int a = 2 * ch, b = 2 * ch + 1;
-            const bool hb = b < E.C;
+            const int ca = 2 * ch, cb = 2 * ch + 1;
+            const bool hb = cb < E.C;
             const float f = 1.0f / (float)RN;
-            float va = v.x * f, vb = -v.y * f;
+            float va = vv.x * f, vb = -vv.y * f;
             if (k < RBLK) {
-                if (k < RDEG) { va += E.over_old[(size_t)a * RDEG + k].x; if (hb) vb += E.over_old[(size_t)b * RDEG + k].x; }
-                E.out_real[(size_t)a * E.out_stride + k] = va; if (hb) E.out_real[(size_t)b * E.out_stride + k] = vb;
+                if (k < RDEG) { va += E.over_old[(size_t)ca * RDEG + k].x; if (hb) vb += E.over_old[(size_t)cb * RDEG + k].x; }
+                E.out_real[(size_t)ca * E.out_stride + k] = va; if (hb) E.out_real[(size_t)cb * E.out_stride + k] = vb;
             } else {
-                E.over_new[(size_t)a * RDEG + (k - RBLK)] = make_float2(va, 0.f);
-                if (hb) E.over_new[(size_t)b * RDEG + (k - RBLK)] = make_float2(vb, 0.f);
+                E.over_new[(size_t)ca * RDEG + (k - RBLK)] = make_float2(va, 0.f);
+                if (hb) E.over_new[(size_t)cb * RDEG + (k - RBLK)] = make_float2(vb, 0.f);
             }
         } else {
             const float f = 1.0f / (float)RN;
-            float2 w = make_float2(v.x * f, -v.y * f);
+            float2 w = make_float2(vv.x * f, -vv.y * f);
             if (k < RBLK) {
                 if (k < RDEG) { const float2 o = E.over_old[(size_t)ch * RDEG + k]; w.x += o.x; w.y += o.y; }
                 E.out_cplx[(size_t)ch * E.out_stride + k] = w;
@@ -627,13 +638,13 @@ __global__ __launch_bounds__(64) void rds3_slicer(DeviceBuffers B, RdsBuffers Rb
 }
 
 static void fft_fwd(const RdsBuffers &Rb, int nch, const int *chlist, hipStream_t s) {
-    hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nch), dim3(256), 0, s, Rb.U, Rb.V, nch, chlist, (const float *)nullptr, (size_t)0, 0);
+    hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / S1C, nch), dim3(256), 0, s, Rb.U, Rb.V, nch, chlist, (const float *)nullptr, (size_t)0, 0);
     hipLaunchKernelGGL(rds_fft_step2<0>, dim3(RN1 / 16, nch), dim3(256), 0, s, Rb.V, Rb.U, nch, chlist, RdsEpi{});
 }
 // the transform of `nrows` rows: first pass A -> Bs (or from the real pair source), last pass Bs -> A with the epilogue
 template <int EPI>
 static void fft_rows(float2 *A, float2 *Bs, int nrows, const RdsEpi &E, hipStream_t s, const float *pair_src = nullptr, size_t pair_stride = 0, int C = 0) {
-    hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / 16, nrows), dim3(256), 0, s, A, Bs, nrows, (const int *)nullptr, pair_src, pair_stride, C);
+    hipLaunchKernelGGL(rds_fft_step1, dim3(RN2 / S1C, nrows), dim3(256), 0, s, A, Bs, nrows, (const int *)nullptr, pair_src, pair_stride, C);
     hipLaunchKernelGGL(rds_fft_step2<EPI>, dim3(RN1 / 16, nrows), dim3(256), 0, s, Bs, A, nrows, (const int *)nullptr, E);
 }
 
