@@ -89,6 +89,10 @@ typedef enum {
                                   bit for bit (about 45 us per 1536 fm samples and channel); 2 = all samples of a segment at once by
                                   Newton's method -- the trajectory to ~1e-5 rad (the loop's own f32 rounding noise, integrated), what
                                   large batches need; 0 = automatic: 1 up to 64 channels per handle, 2 above (default) */
+    FMX_P_STAGEB_FORM = 22,    /* (handle-wide: the channel argument is ignored) stage B -- limiter .. de-emphasis -- as 1 = one kernel per call,
+                                  2 = two kernels (limiter .. lock detector, then PSS .. de-emphasis: four workgroups per CU instead of
+                                  three); 0 = automatic (default): whichever wastes less of its last round of workgroups for the
+                                  handle's channel count.  The results of the two forms are bit-identical. */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */

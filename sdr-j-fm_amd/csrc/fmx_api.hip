@@ -106,6 +106,7 @@ struct fmx_handle_s {
     std::vector<fmx::RdsGroupDecoderHost> rds_dec;
     int64_t last_m0 = 0, last_m1 = 0;       // 24 kS/s outputs of the last call
     std::vector<void *> rds_ptrs, tail_ptrs;
+    std::atomic<int> stageb_form{0};     // FMX_P_STAGEB_FORM
 };
 
 namespace {
@@ -578,6 +579,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     hipEvent_t pdummy = nullptr;
     if (prof && prof_double) { HIPCHK(hipEventCreate(&pdummy)); HIPCHK(hipEventRecord(pdummy, s)); }
     if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
+    G.stageb_form = h->stageb_form.load();
     launch_demod_fused(h->T, h->B, G, h->channels, s);      // (with its pre-pass for the PLL / AM decoders and the squelches)
     if (h->rds_alloc && h->rds_start >= 0) {
         bool any_rds = false;
@@ -865,6 +867,10 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMalloc(&h->B.w_dem, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_cur, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_diff, sizeof(float) * NJ * C));
+        h->B.lockm_stride = (int32_t)(NJ / 6 + 512);
+        HIPCHK(hipMalloc(&h->B.w_lockm, (size_t)h->B.lockm_stride * C));
+        HIPCHK(hipMemset(h->B.w_lockm, 0, (size_t)h->B.lockm_stride * C));
+        h->tail_ptrs.push_back(h->B.w_lockm);
         HIPCHK(hipMalloc(&h->B.gfix, sizeof(float2) * GAIN_FIX_FRAMES * C));
         HIPCHK(hipMemset(h->B.gfix, 0, sizeof(float2) * GAIN_FIX_FRAMES * C));
         h->B.w_iq = nullptr;
@@ -953,6 +959,9 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "squelch mode must be 0 (off), 1 (noise squelch) or 2 (level squelch)"); break;
     case FMX_P_SQUELCH_VALUE: if (iv < 0 || iv > 100) return fail(FMX_E_INVALID, "squelch value must be 0..100"); break;
     case FMX_P_PLL_SOLVER: if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "PLL solver must be 0 (automatic), 1 (sequential) or 2 (parallel)"); break;
+    case FMX_P_STAGEB_FORM:
+        if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "stage B form must be 0 (automatic), 1 (one kernel) or 2 (two kernels)");
+        h->stageb_form.store(iv); return FMX_OK;
     case FMX_P_DISP_DELAY: if (iv < 0 || iv > 100000) return fail(FMX_E_INVALID, "display delay must be 0..100000 steps"); break;
     case FMX_P_TEST_TONE:
     case FMX_P_VOLUME_DB: case FMX_P_LF_CUTOFF: case FMX_P_ATTENUATION_L: case FMX_P_ATTENUATION_R:

@@ -210,6 +210,7 @@ struct CallGeom {
     int32_t iq_format;   // fmx_iq_format of the input buffer
     float   iq_scale;    // 1/128 (U8, S8) or 1/denominator (S16)
     int32_t gain_fix;    // the call's first GAIN_FIX_FRAMES frames take a correction from B.gfix (a volume / balance change, fmx_audio.hip)
+    int32_t stageb_form; // FMX_P_STAGEB_FORM (host side only: launch_demod_fused)
     int32_t twins;       // stage A always decimates by 12; an input rate the reference decimates by 12 / twins (6: twins = 2, 1: twins = 12) runs
                          // `twins` workgroups per channel, twin p with the tap alignment of output phase p, interleaved in the fm-rate ring
     int32_t channels, pad_gf;
@@ -235,10 +236,12 @@ struct DeviceBuffers {
                          // (PLL decoder) / unlimited (AM) samples, |z| for the level squelch of the other decoders
     float   *w_osc;      // ... and its output: the demodulator output behind AFC, scaling and squelch
     float2  *gfix;       // [channels][GAIN_FIX_FRAMES] what a gain change adds to the first frames of the call (gain_fix_kernel)
+    uint8_t *w_lockm;    // [channel][lockm_stride] stage B as two kernels: the pilot-lock flags of this call, one byte (six samples + the
+                         // whole segment's) per thread and segment
+    int32_t lockm_stride;
     int32_t prepass;     // != 0: disc_kernel / afc_kernel<true> run as the pre-pass of the fused stage B (launch_demod_fused): only the channels
                          // with a recurrence of their own in the demodulator (PLL / AM decoder, a squelch) are touched, their demodulator output
                          // goes to the 16-row tiles of w_osc (given to them as w_dem), the metaData snapshot of the AFC value is taken there
-    int32_t pad_pp;
     // PCM tail (fmx_audio.hip)
     const float *tone;   // [TT_BURST] one test-tone burst (the same for every burst: phase restarts at 0)
     float4  *pk_part;    // [channels][pk_tiles] per audio tile: max |L|, |R| of the frames of the tile's first window, then of its second

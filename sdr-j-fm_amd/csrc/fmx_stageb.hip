@@ -307,7 +307,14 @@ constexpr float PLL_NEWTON_TOL = SB_NEWTON_TOL;   // a Newton round whose larges
                                           // 0.5 sum |g| d^2 < 2e-6 rad over a segment (g = 5 demod gain, sum |g| < 1 for programme material)
 constexpr int PLL_NEWTON_MAX = 10;        // rounds before the segment is replayed sample by sample (ChanState::pll_replays counts those)
 
-__global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs by_value_never_touched) {
+// PART 0: the whole of stage B in one kernel (handles of few channels: one launch, the channel's latency is what counts).
+// PART 1 / 2: the same code as TWO kernels -- limiter .. lock detector, then PSS .. de-emphasis -- for large batches: each half needs
+// at most 128 VGPRs without a spill (the whole needs 168), so FOUR workgroups share a CU instead of three, and the kernel is bound by the
+// latency of its dependent chains, not by throughput.  The halves meet in the per-call rows they write anyway (w_dem, w_cur: the scope
+// taps and the RDS path's inputs) plus one byte of lock flags per thread and segment (w_lockm).  Nothing in the first half depends on
+// the second.
+template <int PART>
+__global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_kernel(StageBArgs by_value_never_touched) {
     StageBArgsP ka = (StageBArgsP)__builtin_amdgcn_kernarg_segment_ptr();
 #define T (ka->T)
 #define B (ka->B)
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
     }
     const int64_t pss_count0 = st->pss_count;
     float2 zn[FB_K + 2];
-    if (!special) fetch((int)threadIdx.x * FB_K, 0, nj < FB_W ? nj : FB_W, zn);
+    if (PART != 2 && !special) fetch((int)threadIdx.x * FB_K, 0, nj < FB_W ? nj : FB_W, zn);
     __syncthreads();
     // One segment.  FAST = a full segment (every thread has its six samples) that neither holds the metaData snapshot sample nor the
     // call's first two samples: all the `i < nv` / `i == il` / `i == ix` guards of the general form fold away at compile time (they
@@ -422,7 +429,12 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         const int ix = FAST ? -1 : jx - seg0 - j0;                   // this thread's index of the metaData snapshot sample, if 0 .. K-1
 
         SB_FT(0); SB_FTW(1);      // 0: loop top bookkeeping, 1: wait for the prefetched ring entries
-        float dem[FB_K];
+        // what the second half takes over from the first
+        float dem[FB_K], cur[FB_K];
+        bool locked[FB_K];
+        bool all_locked;                                         // every sample of the segment (the same in every thread)
+        uint8_t *const lockm = B.w_lockm + (size_t)ch * B.lockm_stride + (size_t)(seg0 / FB_W) * FB_T + tid;
+        if constexpr (PART != 2) {
         if (!special) {
         // ================= limiter + discriminator (fm-demodulator.cpp:119-126, 168-189) =================
         float res[FB_K];
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         //    guess a few ulps off rounds differently at every sample -- the result wanders around the reference's trajectory by
         //    ~1.5e-5 rad RMS whatever the number of rounds (tools/pll_fixed_point.py; the Picard iteration of round 2 did the same).
         //    A segment that does not settle in PLL_NEWTON_MAX rounds is evaluated sequentially (ChanState::pll_replays counts them).
-        float cur[FB_K], osc[FB_K];
+        float osc[FB_K];
         float osc_in;                                            // NCO sine of the sample in front of this thread's first
         {
             const float gain = T.pil_gain, omega = T.pil_omega;
@@ -713,8 +725,6 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         SB_ARGS_FRESH(); SB_TICK1(2);
 
         // ================= lock detector (pilot-recover.cpp:62-80) =================
-        bool locked[FB_K];
-        bool all_locked;                                         // every sample of the segment (the same in every thread)
         {
             const float lockA = 1.0f / 3000.0f;
             const double keep = 1.0 - (double)lockA;
@@ -780,6 +790,25 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         }
         SB_FT(16);
         SB_ARGS_FRESH(); SB_TICK1(3);
+        if constexpr (PART == 1) {
+            // hand-over to the second kernel: lock flags of this thread's samples (bits 0 .. 5) and of the whole segment (bit 7); the next
+            // segment's ring entries are requested here (the whole kernel does that under its de-emphasis)
+            unsigned m = all_locked ? 0x80u : 0u;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) m |= locked[i] ? (1u << i) : 0u;
+            *lockm = (uint8_t)m;
+            if (!lastseg && !special) { const int wn = (nj - seg0 - FB_W) < FB_W ? (nj - seg0 - FB_W) : FB_W; fetch(j0, seg0 + FB_W, wn, zn); }
+        }
+        } else {
+            // second kernel: demodulator output, pilot phase and lock flags as the first one left them
+            const size_t lrow = (size_t)ch * B.lin_rows + seg0 + j0;
+            const float *wd = B.w_dem + lrow, *wc = B.w_cur + lrow;
+            const unsigned m = *lockm;
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) { dem[i] = (i < nv) ? wd[i] : 0.f; cur[i] = (i < nv) ? wc[i] : 0.f; locked[i] = ((m >> i) & 1u) != 0; }
+            all_locked = (m & 0x80u) != 0;
+        }
+        if constexpr (PART != 1) {
 
         // ================= PSS errors of the calls this segment can make: err[m] = Re (y) Im (y), y = low-pass of the s ring
         // (stereo-separation.cpp:60-83), m = call index within the segment, into er =================
@@ -1121,6 +1150,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
         }
         SB_FT(32);
         SB_ARGS_FRESH(); SB_TICK1(7);
+        }   // PART != 1
     };
     for (int seg0 = 0; seg0 < nj; seg0 += FB_W) {
         const bool fast = (nj - seg0 >= FB_W) && !((unsigned)(jx - seg0) < (unsigned)FB_W) && (callJ0 + seg0 >= 2);
@@ -1128,7 +1158,7 @@ __global__ __launch_bounds__(FB_T, SB_WG_PER_SIMD) void stageb_kernel(StageBArgs
     }
     // ================= bookkeeping behind the call =================
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (PART != 1 && threadIdx.x == 0) {
         const PssSt ps = cy.ps;
         st->pss_acc = ps.acc; st->pss_mean = ps.mean; st->pilot_delay_pss = ps.pdp;
         st->pss_lock_cnt = ps.lock_cnt; st->pss_unlock_cnt = ps.unlock_cnt; st->pss_minimized = ps.minimized ? 1 : 0;
@@ -1166,7 +1196,23 @@ void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const Cal
     if (G.J1 - G.J0 <= 0) return;
     if (B.w_iq) launch_demod_prepass(T, B, G, C, s);     // some channel has (had) a PLL / AM decoder or a squelch: fmx_demod.hip
     StageBArgs A; A.T = T; A.B = B; A.G = G; A.C = C;
-    hipLaunchKernelGGL(stageb_kernel, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
+    // One kernel or two?  Per channel both forms cost the same (measured, 256 ... 4096 channels: the kernel is bound by instruction
+    // issue, a fourth workgroup per CU adds nothing), what differs is the tail: the whole kernel runs 3 workgroups per CU, its halves 4,
+    // and a batch that does not fill the last round of either leaves CUs idle.  The form whose rounds waste less wins; a tie goes to
+    // the single launch.  (4096 channels on 256 CUs: 5.33 rounds of 768 against 4 of 1024 -- 2.05 against 1.91 ms.)
+    // FMX_P_STAGEB_FORM (tests) or the environment (FMX_STAGEB_SPLIT=0 / 1: A/B runs of the bench) force either form.
+    static const int env = getenv("FMX_STAGEB_SPLIT") ? atoi(getenv("FMX_STAGEB_SPLIT")) : -1;
+    const int force = G.stageb_form ? G.stageb_form - 1 : env;
+    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const long whole = (long)((C + SB_WG_PER_SIMD * cus - 1) / (SB_WG_PER_SIMD * cus)) * SB_WG_PER_SIMD * 100;
+    const long halves = (long)((C + 4 * cus - 1) / (4 * cus)) * 4 * 102;          // (two launches, the hand-over through HBM: 2 %)
+    const bool split = force >= 0 ? force != 0 : halves < whole;
+    if (split) {
+        hipLaunchKernelGGL(stageb_kernel<1>, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
+        hipLaunchKernelGGL(stageb_kernel<2>, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
+    } else {
+        hipLaunchKernelGGL(stageb_kernel<0>, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
+    }
 }
 
 }  // namespace fmx

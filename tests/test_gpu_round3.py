@@ -298,3 +298,46 @@ def test_input_rates_not_built_are_refused(fmx_amd):
     for rate in (1000000, 400000, 3456000):
         with pytest.raises(fmx_amd.FmxError):
             fmx_amd.Fmx(1, max_block=16384, inputRate=rate)
+
+
+def test_stage_b_as_one_kernel_and_as_two_give_identical_results(fmx_amd, ol):
+    """FMX_P_STAGEB_FORM: stage B as one kernel per call (handles up to 768 channels and the counts that fill its rounds of 3
+    workgroups per CU) and as two (limiter .. lock detector | PSS .. de-emphasis, 4 workgroups per CU: what 4096 channels run) meet
+    in the demodulator-output / pilot-phase rows and a byte of lock flags.  Same arithmetic: PCM, taps, metaData and RDS bits are
+    bit-identical, over ragged calls, for every kind of channel (Newton and sequential PLL solver, PLL decoder and level squelch through
+    the pre-pass, mono, PSS off) -- and the PCM equals the oracle's."""
+    blocks = (BLOCKS * 4)[:22]                               # 1.2 s: through pilot lock, uneven, crossing segment boundaries
+    iq = ol.synth_iq(sum(blocks), rds=1, rdsLevel=0.05, rds_payload=ol.rds_programme_bits(pi=0xD3A1, ps="FMX-AMD ", text="TWO KERNELS"))
+    nch = 6
+
+    def run(form):
+        f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=max(blocks))
+        gui_defaults(f)
+        f.set_param(M.P_STAGEB_FORM, form)
+        f.set_param(M.P_RDS_MODE, 2)
+        f.set_param(M.P_PLL_SOLVER, 2)
+        f.set_param(M.P_PLL_SOLVER, 1, channel=1)
+        f.set_param(M.P_FM_DECODER, 2, channel=2)
+        f.set_param(M.P_SQUELCH_MODE, 2, channel=3); f.set_param(M.P_SQUELCH_VALUE, 30, channel=3)
+        f.set_param(M.P_FM_MODE, 2, channel=4)
+        f.set_param(M.P_PSS, 0, channel=5)
+        pcm, metas, pos = [], [], 0
+        for b in blocks:
+            pcm.append(f.process_host(iq[pos:pos + b])); pos += b
+            metas.append([(m.PilotPllLocked, m.PssState, m.PilotPllLockStrength, m.DcValIf, m.live_lock_strength) for m in (f.meta(c) for c in range(nch))])
+        nt = blocks[-1] // 12
+        taps = [f.tap(t, nt, c) for t in (M.TAP_PILOT_PHASE, M.TAP_DEMOD) for c in range(nch)]
+        bits = [f.rds_bits(c, 8192) for c in range(nch)]
+        return np.concatenate(pcm, axis=1), metas, taps, bits
+
+    one, two = run(1), run(2)
+    assert np.array_equal(one[0], two[0])
+    assert one[1] == two[1]
+    for a, b in zip(one[2], two[2]):
+        assert np.array_equal(a, b)
+    for a, b in zip(one[3], two[3]):
+        assert len(a) > 800 and np.array_equal(a, b)
+    po = ol.OracleChain(inputFilterBw=165000).process(iq)
+    assert rms(two[0][0] - po) <= PCM_RMS_TOL
+    with pytest.raises(Exception):
+        fmx_amd.Fmx(1, max_block=16384).set_param(M.P_STAGEB_FORM, 3)
