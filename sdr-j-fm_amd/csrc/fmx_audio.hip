@@ -59,7 +59,10 @@ constexpr int AF_HIST = (C_MAX_TAPS + 3) / 4 - 1;        // 220 frames of histor
 constexpr int AF_VALID = 7 * C_TILE;                     // frames a block delivers
 static_assert(AF_HIST + AF_VALID <= fftc::N, "block + history fit one transform");
 static_assert(AUDIO_DELAY % 4 == 0, "the four phases of a frame are one aligned group of four ring entries");
-__global__ __launch_bounds__(fftc::T) void audio_fft_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, float2 *__restrict__ pcm) {
+#ifndef AF_WAVES_PER_SIMD
+#define AF_WAVES_PER_SIMD 3
+#endif
+__global__ __launch_bounds__(fftc::T, AF_WAVES_PER_SIMD) void audio_fft_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, float2 *__restrict__ pcm) {
     __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];
     __shared__ int pkt[7][4];
     const int ch = blockIdx.y, t = threadIdx.x, lane = t & 63;
@@ -76,20 +79,24 @@ __global__ __launch_bounds__(fftc::T) void audio_fft_kernel(DeviceTables T, Devi
     float2 acc[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) acc[q] = make_float2(0.f, 0.f);
-#pragma unroll 1
-    for (int p = 0; p < 4; p++) {
-        float2 a[8];
+    auto load_phase = [&](int p, float2 *a) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int64_t fr = mb - AF_HIST + t + fftc::T * k;
             const int64_t f0 = 4 * fr - AS.delay;
             a[k] = (f0 >= 0 && fr < G.M1) ? dring[(f0 + 3 - p) & G.dring_mask] : make_float2(0.f, 0.f);     // (frames past the call's last are never used)
         }
+    };
+    float2 a[8];
+    load_phase(0, a);
+#pragma unroll 1
+    for (int p = 0; p < 4; p++) {
         __syncthreads();                                  // (the previous transform's last reads of X are done)
         fftc::forward_slots(t, a, X, T.fft_w);
         fftc::times_spectrum(t, a, Gs + (size_t)p * fftc::N);
 #pragma unroll
         for (int q = 0; q < 8; q++) { acc[q].x += a[q].x; acc[q].y += a[q].y; }
+        if (p < 3) load_phase(p + 1, a);                  // (a second register set that lands under the transform spills: measured, slower)
     }
     __syncthreads();
     fftc::backward_slots(t, acc, X, T.fft_w);

@@ -178,26 +178,50 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     for (int i = t; i < A_TAPS_DEV; i += NTHR) sT[i] = T.front_taps[(size_t)(P.front_set + tw) * A_TAPS_DEV + i];
     if (t == 0) { carry_seq = 0; for (int i = 0; i < NW; i++) { hist_seq[i] = 0; free_seq[i] = 0; } }
     // ---- history -> the image of tile 0 (wave 0): columns qa-24 .. qa-1 at C 0..23, partial column qa at C 24
-    const bool hist_convert = (P.lo_freq != 0) && (T.lo_table != nullptr) && (st->hist_fmt == 0) && (P.dc_remove != 0 || P.att_l != 1.0f || P.att_r != 1.0f);
+    // The history a call finds is in the format the last call left (ChanState::hist_fmt): raw for a channel without an LO (RfDC and IQ
+    // balance are applied behind the FIR), DC-corrected, balanced and mixed for a channel with one.  Where the format -- or the RfDC value
+    // the raw format is read with -- changes between two calls, the history is converted on load, so that the filter memory holds what
+    // the reference's holds (its memory always has the processed samples of their own time):
+    //  * LO switched on (raw -> processed): RfDC of each column from the saved boundaries, then the balance, then R0;
+    //  * LO switched off (processed -> raw): the sample the output-side correction (sum h) clamp (RfDC), the balance and R0 take back to
+    //    the processed one, r = conj (R0) v / att + clamp (RfDC now) (RfDC moves by < 1e-6 over the history's 288 samples);
+    //  * setDCRemove (raw, RfDC zeroed at this call, fm-processor.cpp:922-925): the memory holds samples corrected with the OLD value,
+    //    the output-side correction will use the new one: r = raw - clamp (old RfDC of the column) + clamp (0).
+    // In the last two cases the boundaries in front of the call's first column are those of the new value.
+    // R0: an oscillator set back to 0 Hz keeps its phase (Oscillator::nextValue oscillator.cpp:49-58 goes on reading the table entry it
+    // stopped at), so the reference multiplies every sample by that constant -- which commutes with the real-tap filters and rides with
+    // the complex output gain here.
+    const bool lo_on = (P.lo_freq != 0) && (T.lo_table != nullptr);
+    const float2 R0 = (!lo_on && T.lo_table != nullptr && st->lo_phase != 0) ? T.lo_table[st->lo_phase] : make_float2(1.f, 0.f);
+    const bool dc_rst0 = (P.actions & ACT_DC_RESET) != 0;
+    const float2 R0h = (lo_on && st->hist_fmt == 0 && st->lo_phase != 0) ? T.lo_table[st->lo_phase] : make_float2(1.f, 0.f);   // (what the raw history was read with)
+    const bool hist_convert = lo_on && (st->hist_fmt == 0) && (P.dc_remove != 0 || P.att_l != 1.0f || P.att_r != 1.0f || dc_rst0 || st->lo_phase != 0);
+    const bool hist_to_raw = !lo_on && (st->hist_fmt == 1);
+    const bool hist_rst = !lo_on && (st->hist_fmt == 0) && dc_rst0;
+    const float2 dc_now = (dc_rst0 || P.dc_remove == 0) ? make_float2(0.f, 0.f)
+                                                        : make_float2(__builtin_amdgcn_fmed3f(st->dc_re, -0.01f, 0.01f), __builtin_amdgcn_fmed3f(st->dc_im, -0.01f, 0.01f));
     if (wave == 0) {
         for (int i = lane; i < DECIM * A_HIST_COLS; i += 64) {
             int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;
             float2 v = hist[i];
             if (c == HL && r >= r0) v = make_float2(0.f, 0.f);
-            else if (hist_convert) {
-                // the LO was switched on since the last call: the history is still raw, the reference's filter memory holds these
-                // samples DC-corrected and balanced (mixed with the LO of their time: none) -- RfDC of their column from the saved
-                // boundaries (the oldest one for the columns in front of them)
+            else if (hist_convert || hist_rst) {
                 const int tb = c - HL + 13;
                 const float2 d = B.dcv_hist[(size_t)vc * DCV_SAVE + (tb < 0 ? 0 : tb)];
-                v.x = (v.x - __builtin_amdgcn_fmed3f(d.x, -0.01f, 0.01f)) * P.att_l;
-                v.y = (v.y - __builtin_amdgcn_fmed3f(d.y, -0.01f, 0.01f)) * P.att_r;
+                v.x -= __builtin_amdgcn_fmed3f(d.x, -0.01f, 0.01f);
+                v.y -= __builtin_amdgcn_fmed3f(d.y, -0.01f, 0.01f);
+                if (hist_convert) { v.x *= P.att_l; v.y *= P.att_r; v = make_float2(v.x * R0h.x - v.y * R0h.y, v.x * R0h.y + v.y * R0h.x); }
+            } else if (hist_to_raw) {
+                v = make_float2(v.x * R0.x + v.y * R0.y, v.y * R0.x - v.x * R0.y);
+                v.x = (P.att_l != 0.f ? v.x / P.att_l : 0.f) + dc_now.x;
+                v.y = (P.att_r != 0.f ? v.y / P.att_r : 0.f) + dc_now.y;
             }
             X2[xidx(r, c)] = v;
         }
     }
     // RfDC in front of the 13 columns before this call's first column and of that column itself (ring slots -13 .. 0)
-    if (t < 14 && !(P.lo_freq != 0 && T.lo_table != nullptr)) dcv[(t - 13) & (DCV_N - 1)] = B.dcv_hist[(size_t)vc * DCV_SAVE + t];
+    if (t < 14 && !lo_on) dcv[(t - 13) & (DCV_N - 1)] = (hist_to_raw || hist_rst) ? make_float2(dc_rst0 ? 0.f : st->dc_re, dc_rst0 ? 0.f : st->dc_im)
+                                                                                 : B.dcv_hist[(size_t)vc * DCV_SAVE + t];
     // per-channel state is read by every wave BEFORE the barrier (the wave that ends the call rewrites it)
     const int lo_phase0 = st->lo_phase;
     const bool dc_rst = (P.actions & ACT_DC_RESET) != 0;          // setDCRemove zeroes RfDC (:922-925)
@@ -214,6 +238,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     }
     __syncthreads();                                  // the only workgroup barrier: tables and counters are set up
 
+    const float cg_re = FS.gain_re * R0.x - FS.gain_im * R0.y, cg_im = FS.gain_re * R0.y + FS.gain_im * R0.x;     // complex output gain x R0
     const bool dcr = P.dc_remove != 0;
     const int lo = P.lo_freq;
     const bool mix = (lo != 0) && (T.lo_table != nullptr);
@@ -610,9 +635,9 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
             }
             if (fast && (Lg != 1.0f || Rg != 1.0f)) { aA.x *= Lg; aA.y *= Rg; aB.x *= Lg; aB.y *= Rg; }      // IQ balance :462-464
             if (q >= ja && q < jb)
-                zring[(zr0 + q * TW) & G.ring_mask] = make_float2(aA.x * FS.gain_re - aA.y * FS.gain_im, aA.x * FS.gain_im + aA.y * FS.gain_re);
+                zring[(zr0 + q * TW) & G.ring_mask] = make_float2(aA.x * cg_re - aA.y * cg_im, aA.x * cg_im + aA.y * cg_re);
             if (q + 1 >= ja && q + 1 < jb)
-                zring[(zr0 + (q + 1) * TW) & G.ring_mask] = make_float2(aB.x * FS.gain_re - aB.y * FS.gain_im, aB.x * FS.gain_im + aB.y * FS.gain_re);
+                zring[(zr0 + (q + 1) * TW) & G.ring_mask] = make_float2(aB.x * cg_re - aB.y * cg_im, aB.x * cg_im + aB.y * cg_re);
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) seq_post(&free_seq[wave], ti + 1);          // this image may receive the history of tile ti + 3

@@ -341,3 +341,40 @@ def test_stage_b_as_one_kernel_and_as_two_give_identical_results(fmx_amd, ol):
     assert rms(two[0][0] - po) <= PCM_RMS_TOL
     with pytest.raises(Exception):
         fmx_amd.Fmx(1, max_block=16384).set_param(M.P_STAGEB_FORM, 3)
+
+
+@pytest.mark.parametrize("bw", [165000, 0])
+def test_stage_a_history_follows_lo_off_and_dc_removal_toggles(fmx_amd, ol, bw):
+    """ADVICE r2 (low #1).  Stage A keeps a channel's FIR history raw while it has no local oscillator (RfDC and the IQ balance are applied
+    behind the FIR) and processed while it has one; the reference's filter memory always holds processed samples of their own time
+    (fm-processor.cpp:423-470).  Every change in between is a conversion of the 24 history columns on load: LO on, LO back to 0,
+    setDCRemove off / on (which zeroes RfDC, :922-925) with and without an LO.  A stream with a DC offset and an unbalanced IQ pair, the
+    fm-rate IQ of the call behind every switch against the oracle's (a history taken in the wrong format shows as up to 5e-3 over the
+    first 24 samples), and the PCM over everything."""
+    block = 16384 * 3                                       # 4096 fm samples per call
+    switches = {4: dict(loFrequency=3000), 8: dict(loFrequency=0), 11: dict(dcRemove=0), 14: dict(dcRemove=1),
+                17: dict(loFrequency=-2500), 19: dict(dcRemove=0), 21: dict(loFrequency=0), 23: dict(dcRemove=1)}
+    nb = 26
+    iq = ol.synth_iq(nb * block)
+    iq[:, 0] += 0.007; iq[:, 1] -= 0.005
+    o = ol.OracleChain(inputFilterBw=bw, attL=0.9, attR=1.1, taps=[ol.TAP_FM_IQ], tap_seconds=4.0)
+    f = fmx_amd.Fmx(1, max_block=block)
+    gui_defaults(f, bw)
+    f.set_param(M.P_ATTENUATION_L, 0.9); f.set_param(M.P_ATTENUATION_R, 1.1)
+    ids = dict(loFrequency=M.P_LOCAL_OSCILLATOR, dcRemove=M.P_DC_REMOVE)
+    nt = block // 12
+    po, pg, worst = [], [], {}
+    for b in range(nb):
+        for k, v in switches.get(b, {}).items():
+            o.configure(**{k: v}); f.set_param(ids[k], v)
+        x = iq[b * block:(b + 1) * block]
+        po.append(o.process(x)); pg.append(f.process_host(x)[0])
+        z_g, z_o = f.tap(M.TAP_FM_IQ, nt), o.tap(ol.TAP_FM_IQ)[b * nt:(b + 1) * nt]
+        d = np.abs(z_g - z_o).max(axis=1)
+        if b in switches or b - 1 in switches:
+            worst[b] = (float(d[:64].max()), float(d.max()))
+        assert d.max() <= 2e-5, (b, float(d.max()), int(d.argmax()))
+    po, pg = np.concatenate(po), np.concatenate(pg)
+    print(f"\n[stage A history, input filter {bw}] fm-rate IQ max |diff| in the calls behind a switch (first 64 samples, whole call): "
+          + ", ".join(f"{b}: {a:.1e}/{w:.1e}" for b, (a, w) in sorted(worst.items())) + f"; PCM rms {rms(pg - po):.2e}")
+    assert po.shape == pg.shape and rms(pg - po) <= PCM_RMS_TOL
