@@ -300,6 +300,9 @@ __device__ __forceinline__ Aff wscan_aff(Aff v) {
     return v;
 }
 
+#ifndef SB_SEED_ROUNDS
+#define SB_SEED_ROUNDS 2
+#endif
 #ifndef SB_NEWTON_TOL
 #define SB_NEWTON_TOL 2e-3f
 #endif
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 float cor[FB_K];                                 // sum of the corrections in front of each sample (rad)
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) cor[i] = 0.f;
-                for (int round = 0; round < 2; round++) {
+                for (int round = 0; round < SB_SEED_ROUNDS; round++) {
                     float c[FB_K], run = 0.f;
 #pragma unroll
                     for (int i = 0; i < FB_K; i++) { c[i] = run; run += g[i] * __builtin_amdgcn_sinf(rv[i] + cor[i] * INV2PI32); }

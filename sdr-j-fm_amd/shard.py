@@ -31,9 +31,18 @@ def init(backend=None):
     return rank, world
 
 
+def _collectives_on():
+    """Collectives run when a process group exists and has more than one rank -- or when FMX_SHARD_FORCE_COLLECTIVES is set: a
+    one-rank group still goes through the backend (communicator set-up, the collective's kernels), which is how the RCCL path is
+    exercised on a one-GPU box (tests/test_gpu_round3.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or bool(os.environ.get("FMX_SHARD_FORCE_COLLECTIVES"))
+
+
 def max_over_ranks(value, device="cpu"):
     """bench.py's timing rule: the slowest rank defines the step time."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -44,7 +53,7 @@ def gather_pcm(pcm_local, total_channels, dst=0):
     """Gather per-rank PCM [channels_local, frames, 2] onto `dst` as [total_channels, frames, 2]
     (384 kB/s per channel: far below one xGMI link, so a plain gather is the right collective).
     Returns the full tensor on dst, None elsewhere."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return pcm_local
     world, rank = dist.get_world_size(), dist.get_rank()
     base = (total_channels + world - 1) // world                # pad every shard to the largest one
@@ -65,6 +74,6 @@ def gather_pcm(pcm_local, total_channels, dst=0):
 def broadcast_stream(iq, src=0):
     """Fan-out of a shared wide-band IQ stream (BASELINE configs[2]): every rank demodulates its own
     carriers out of the same samples.  18.4 MB/s per stream."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         dist.broadcast(iq, src=src)
     return iq

@@ -378,3 +378,46 @@ def test_stage_a_history_follows_lo_off_and_dc_removal_toggles(fmx_amd, ol, bw):
     print(f"\n[stage A history, input filter {bw}] fm-rate IQ max |diff| in the calls behind a switch (first 64 samples, whole call): "
           + ", ".join(f"{b}: {a:.1e}/{w:.1e}" for b, (a, w) in sorted(worst.items())) + f"; PCM rms {rms(pg - po):.2e}")
     assert po.shape == pg.shape and rms(pg - po) <= PCM_RMS_TOL
+
+
+def test_shard_collectives_over_rccl_one_rank(fmx_amd, ol, tmp_path):
+    """SURVEY 8e / VERDICT r2 ("RCCL has never been exercised"): the gather / broadcast / max-over-ranks helpers of shard.py -- what
+    bench.py --gpus N uses either side of the path -- over backend "nccl" (= RCCL) on the GPU box.  One GPU allows one rank (RCCL
+    refuses two ranks on a device), so this is a one-rank group with the collectives forced on: communicator set-up and the
+    collectives' kernels run on device tensors produced by the library; the two-rank logic is covered on gloo
+    (test_distributed_cpu.py)."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = tmp_path / "w.py"
+    worker.write_text(textwrap.dedent('''
+        import importlib, os, sys
+        import numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        import bench
+        pkg = importlib.import_module("sdr-j-fm_amd"); m = pkg.fmx; shard = pkg.shard
+        dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        assert dist.get_backend() == "nccl"
+        ch, n = 5, 16384 * 6
+        f = pkg.Fmx(ch, max_block=n)
+        for pid, v in ((m.P_BANDWIDTH, 165000), (m.P_LF_CUTOFF, 15000), (m.P_DEEMPHASIS, 50), (m.P_VOLUME_DB, -6.0), (m.P_FM_MODE, 0)):
+            f.set_param(pid, v)
+        iq = bench.synth_device(torch, ch, n, dev)
+        iq = shard.broadcast_stream(iq, src=0)
+        pcm = torch.zeros((ch, n // 48 + 96, 2), dtype=torch.float32, device=dev)
+        fr = 0
+        for _ in range(3):
+            fr = f.process_device(iq.data_ptr(), n, n, pcm.data_ptr(), pcm.shape[1], hip_stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        loc = pcm[:, :fr].contiguous()
+        full = shard.gather_pcm(loc, ch, dst=0)
+        torch.cuda.synchronize()
+        assert full.data_ptr() != loc.data_ptr() and torch.equal(full, loc) and float(loc.abs().max()) > 0.01
+        assert shard.max_over_ranks(3.25, device=dev) == 3.25
+        t = torch.tensor([float(fr)], device=dev); dist.all_reduce(t); assert int(t.item()) == fr
+        dist.barrier(); dist.destroy_process_group()
+        print("RCCL_OK", fr, tuple(full.shape))
+    ''' % root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", FMX_SHARD_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(worker)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
