@@ -1,4 +1,5 @@
-// fmx_stageb.hip -- stage B time-parallel, one workgroup per channel, ONE kernel per call.  COMPILED WITH -ffp-contract=off.
+// fmx_stageb.hip -- stage B time-parallel, one workgroup per channel, ONE kernel per call (or the same code as two, see stageb_kernel).
+// COMPILED WITH -ffp-contract=off.
 //
 // Replaces per channel, like fmx_demod.hip:
 //   fm_Demodulator::demodulate        fm-demodulator.cpp:111-205 (memoryless decoders: Mixed / ComplexBB / RealBB / Diff)
