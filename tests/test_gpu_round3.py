@@ -322,7 +322,9 @@ def test_stage_b_as_one_kernel_and_as_two_give_identical_results(fmx_amd, ol):
         f.set_param(M.P_FM_MODE, 2, channel=4)
         f.set_param(M.P_PSS, 0, channel=5)
         pcm, metas, pos = [], [], 0
-        for b in blocks:
+        for k, b in enumerate(blocks):
+            if form == 0:                                    # (the form may change from call to call: the state is the same)
+                f.set_param(M.P_STAGEB_FORM, 1 + (k * 7 // 3) % 2)
             pcm.append(f.process_host(iq[pos:pos + b])); pos += b
             metas.append([(m.PilotPllLocked, m.PssState, m.PilotPllLockStrength, m.DcValIf, m.live_lock_strength) for m in (f.meta(c) for c in range(nch))])
         nt = blocks[-1] // 12
@@ -330,13 +332,14 @@ def test_stage_b_as_one_kernel_and_as_two_give_identical_results(fmx_amd, ol):
         bits = [f.rds_bits(c, 8192) for c in range(nch)]
         return np.concatenate(pcm, axis=1), metas, taps, bits
 
-    one, two = run(1), run(2)
-    assert np.array_equal(one[0], two[0])
-    assert one[1] == two[1]
-    for a, b in zip(one[2], two[2]):
-        assert np.array_equal(a, b)
-    for a, b in zip(one[3], two[3]):
-        assert len(a) > 800 and np.array_equal(a, b)
+    one, two, mixed = run(1), run(2), run(0)
+    for other in (two, mixed):
+        assert np.array_equal(one[0], other[0])
+        assert one[1] == other[1]
+        for a, b in zip(one[2], other[2]):
+            assert np.array_equal(a, b)
+        for a, b in zip(one[3], other[3]):
+            assert len(a) > 800 and np.array_equal(a, b)
     po = ol.OracleChain(inputFilterBw=165000).process(iq)
     assert rms(two[0][0] - po) <= PCM_RMS_TOL
     with pytest.raises(Exception):
