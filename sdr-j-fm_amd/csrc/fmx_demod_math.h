@@ -197,23 +197,25 @@ __host__ __device__ __forceinline__ void sincos_idx_f32(int idx, float *sn, floa
 // integers (exact), so the argument is at most a quarter turn and carries 2^-26 turns of rounding; measured against the table for all
 // 192000 entries (tools/ubench/hwsin.hip on gfx950): worst |error| 1.19e-7 (one ulp at 1), rms 4.1e-8 -- inside the polynomials'
 // 1.5e-7 -- at a third of their instructions.
-__device__ __forceinline__ float sin_idx_hw(int idx) {
-    constexpr int QUAD = SINCOS_N / 4;
-    const int q = (int)(((unsigned)(idx >> 7) * 2797u) >> 20);          // idx / 48000 for idx < 384000
-    const int r = idx - q * QUAD;
-    const int rr = (q & 1) ? QUAD - r : r;
+// (the fold without a division: h = idx mod N/2 by an unsigned minimum, then its mirror image about the quarter turn; the same rr and
+// the same signs as q = idx / (N/4), r = idx - q N/4, rr = q odd ? N/4 - r : r, sine negative for q >= 2, cosine for q = 1, 2)
+__device__ __forceinline__ float sin_idx_hw(int idx) {            // 0 <= idx < 192000
+    constexpr unsigned HALF = SINCOS_N / 2;
+    const unsigned u = (unsigned)idx;
+    const unsigned h = min(u, u - HALF);                           // (u - HALF wraps to a huge value when u < HALF)
+    const unsigned rr = min(h, HALF - h);
     const float s = __builtin_amdgcn_sinf((float)rr * (1.0f / (float)SINCOS_N));
-    return (q & 2) ? -s : s;
+    return (u >= HALF) ? -s : s;
 }
-__device__ __forceinline__ void sincos_idx_hw(int idx, float *sn, float *cs) {      // idx < 192000
-    constexpr int QUAD = SINCOS_N / 4;
-    const int q = (int)(((unsigned)(idx >> 7) * 2797u) >> 20);
-    const int r = idx - q * QUAD;
-    const int rr = (q & 1) ? QUAD - r : r;
+__device__ __forceinline__ void sincos_idx_hw(int idx, float *sn, float *cs) {      // 0 <= idx < 192000
+    constexpr unsigned HALF = SINCOS_N / 2, QUAD = SINCOS_N / 4;
+    const unsigned u = (unsigned)idx;
+    const unsigned h = min(u, u - HALF);
+    const unsigned rr = min(h, HALF - h);
     const float t = (float)rr * (1.0f / (float)SINCOS_N);
     const float s = __builtin_amdgcn_sinf(t), c = __builtin_amdgcn_cosf(t);
-    *sn = (q & 2) ? -s : s;
-    *cs = ((q + 1) & 2) ? -c : c;
+    *sn = (u >= HALF) ? -s : s;
+    *cs = (u - QUAD < HALF) ? -c : c;                              // N/4 <= idx < 3N/4
 }
 
 }  // namespace fmx

@@ -550,9 +550,9 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             // the reference's step on one guess: table index in f64 as sincos.cpp:81-85 computes it, everything else in f32
             float nxl = 0.f;                                     // step result of this thread's last evaluated sample `il` (the owner's: the next segment's start)
             bool seq = P.pll_seq != 0;                           // this pass evaluates the loop sample by sample (the same in every thread)
-            auto eval = [&](int i, float phase, float *nx_out) {
+            auto eval = [&](int i, float phase, float *nx_out, float *val_out) {
                 int idx = (int)((double)phase * SC64);           // SinCos::getSin sincos.cpp:81-85 for phase >= 0: entry (int)(phase * C) % Rate
-                idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+                idx = (int)min((unsigned)idx, (unsigned)idx - (unsigned)SINCOS_N);       // (0 <= idx < 2 N: the wrap as an unsigned minimum)
                 // (table value: Newton's method from the hardware sine unit, 1.2e-7, a third of the instructions; the sample-by-sample
                 // solver -- the one that is asked for the reference's trajectory -- keeps the polynomial, whose errors are half as large)
                 float o;
@@ -561,21 +561,26 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 const float t = phase + perr * gain;
                 const float val = t + omega;
                 const float wrapped = wrap_ok ? (val - P32) + C32 : (float)((double)val - FMX_2PI);
-                float nx = (val < P32) ? val : wrapped;          // PI_Constrain fm-constants.h:148-158
-                // (a correction of more than a turn: the DIFF decoder's spike where the limiter output jumps from its 0.001 floor
-                // to the unit circle at signal onset -- the general PI_Constrain, wave-uniformly skipped otherwise)
-                if (__any(!(val >= 0.f && val < 2.f * P32))) nx = pi_constrain(val);
+                // PI_Constrain fm-constants.h:148-158 for 0 <= val < 4 pi (anything else -- a correction of more than a turn: the DIFF
+                // decoder's spike where the limiter output jumps from its 0.001 floor to the unit circle at signal onset -- is seen by
+                // the caller's check of all six values at once and takes the general form there)
                 cur[i] = t; osc[i] = o;
-                *nx_out = nx;
+                *val_out = val;
+                *nx_out = (val < P32) ? val : wrapped;
+            };
+            // 0 <= v < limit for all six values in one comparison: non-negative floats order like their bit patterns, and a negative value
+            // or a NaN has a larger pattern than any limit used here
+            auto all_in = [&](const float *v, float limit) {
+                unsigned m = __float_as_uint(v[0]);
+#pragma unroll
+                for (int i = 1; i < FB_K; i++) m = max(m, __float_as_uint(v[i]));
+                return m < __float_as_uint(limit);
             };
             // a guess outside [0, 2 pi) (unfinished rounds only) is taken modulo 2 pi
             auto into_range = [&](float phase) {
-                if (__any(!(phase >= 0.f && phase < P32))) {
-                    const double pd = (double)phase;
-                    const float pw = (float)(pd - floor(pd * (1.0 / FMX_2PI)) * FMX_2PI);
-                    phase = (phase >= 0.f && phase < P32) ? phase : ((pw >= 0.f && pw < P32) ? pw : 0.f);
-                }
-                return phase;
+                const double pd = (double)phase;
+                const float pw = (float)(pd - floor(pd * (1.0 / FMX_2PI)) * FMX_2PI);
+                return (phase >= 0.f && phase < P32) ? phase : ((pw >= 0.f && pw < P32) ? pw : 0.f);
             };
             if (!seq) {   // ---- the first guess
                 float rv[FB_K];                                  // the ramp x0 + j omega in turns, fraction
@@ -634,12 +639,16 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                     for (int i = 0; i < FB_K; i++) ph[i] = (i < nv) ? er[FB_W + j0 + i] : 0.f;
                     __syncthreads();
                 }
-                float nx[FB_K];
+                float nx[FB_K], val[FB_K];
+                if (__any(!all_in(ph, P32))) {
 #pragma unroll
-                for (int i = 0; i < FB_K; i++) {
-                    const float phase = into_range(ph[i]);
-                    ph[i] = phase;
-                    eval(i, phase, &nx[i]);
+                    for (int i = 0; i < FB_K; i++) ph[i] = into_range(ph[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < FB_K; i++) eval(i, ph[i], &nx[i], &val[i]);
+                if (__any(!all_in(val, 2.f * P32))) {
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) nx[i] = pi_constrain(val[i]);
                 }
                 SB_FT(8);
                 if (seq || it > 0) {
@@ -684,10 +693,21 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 float d[FB_K], c[FB_K];
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) {
-                    double dd = (x0d + (pre + e[i])) - (double)ph[i];
-                    dd = dd > 3.14159265358979323846 ? dd - FMX_2PI : (dd < -3.14159265358979323846 ? dd + FMX_2PI : dd);   // (a wrap that sits one sample apart in guess and step)
-                    d[i] = (i < nv) ? (float)dd : 0.f;
+                    d[i] = (i < nv) ? (float)((x0d + (pre + e[i])) - (double)ph[i]) : 0.f;
                     c[i] = g[i] * __builtin_amdgcn_cosf(ph[i] * INV2PI32);
+                }
+                {   // (a wrap that sits one sample apart in guess and step shows as a residual of a whole turn: rare, looked for once)
+                    unsigned m = __float_as_uint(d[0]) & 0x7fffffffu;
+#pragma unroll
+                    for (int i = 1; i < FB_K; i++) m = max(m, __float_as_uint(d[i]) & 0x7fffffffu);
+                    if (__any(!(m < __float_as_uint(3.0f)))) {
+#pragma unroll
+                        for (int i = 0; i < FB_K; i++) {
+                            double dd = (x0d + (pre + e[i])) - (double)ph[i];
+                            dd = dd > 3.14159265358979323846 ? dd - FMX_2PI : (dd < -3.14159265358979323846 ? dd + FMX_2PI : dd);
+                            d[i] = (i < nv) ? (float)dd : 0.f;
+                        }
+                    }
                 }
                 Aff m; m.A = 1.f; m.Bv = 0.f;
 #pragma unroll
