@@ -288,6 +288,15 @@ struct StageBArgs { DeviceTables T; DeviceBuffers B; CallGeom G; int C; };
 typedef const StageBArgs __attribute__((address_space(4))) *StageBArgsP;
 #define SB_ARGS_FRESH() asm volatile("" : "+s"(ka))
 
+// 0 <= v < limit for all of a thread's six values in one comparison: non-negative floats order like their bit patterns, and a negative
+// value or a NaN has a larger pattern than any limit used here
+__device__ __forceinline__ bool all_in(const float *v, float limit) {
+    unsigned m = __float_as_uint(v[0]);
+#pragma unroll
+    for (int i = 1; i < FB_K; i++) m = max(m, __float_as_uint(v[i]));
+    return m < __float_as_uint(limit);
+}
+
 // inclusive wave scan of affine maps d -> A d + Bv (composition: the later map after the earlier one)
 struct Aff { float A, Bv; };
 template <int CTRL, int RM> __device__ __forceinline__ Aff aff_step(Aff c) {
@@ -568,14 +577,6 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 *val_out = val;
                 *nx_out = (val < P32) ? val : wrapped;
             };
-            // 0 <= v < limit for all six values in one comparison: non-negative floats order like their bit patterns, and a negative value
-            // or a NaN has a larger pattern than any limit used here
-            auto all_in = [&](const float *v, float limit) {
-                unsigned m = __float_as_uint(v[0]);
-#pragma unroll
-                for (int i = 1; i < FB_K; i++) m = max(m, __float_as_uint(v[i]));
-                return m < __float_as_uint(limit);
-            };
             // a guess outside [0, 2 pi) (unfinished rounds only) is taken modulo 2 pi
             auto into_range = [&](float phase) {
                 const double pd = (double)phase;
@@ -591,10 +592,14 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 float cor[FB_K];                                 // sum of the corrections in front of each sample (rad)
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) cor[i] = 0.f;
-                for (int round = 0; round < SB_SEED_ROUNDS; round++) {
-                    float c[FB_K], run = 0.f;
 #pragma unroll
-                    for (int i = 0; i < FB_K; i++) { c[i] = run; run += g[i] * __builtin_amdgcn_sinf(rv[i] + cor[i] * INV2PI32); }
+                for (int round = 0; round < SB_SEED_ROUNDS; round++) {
+                    float c[FB_K], run;
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) {             // (x + 0 is not x to the compiler: the first round and the first term spelled out)
+                        const float sv = g[i] * __builtin_amdgcn_sinf(round == 0 ? rv[i] : rv[i] + cor[i] * INV2PI32);
+                        if (i == 0) { c[i] = 0.f; run = sv; } else { c[i] = run; run += sv; }
+                    }
                     float total;
                     const float pre = wg.excl_add_f(run, &total);
 #pragma unroll
@@ -1086,12 +1091,13 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             const float P32 = 6.2831855f, C32 = T.wrap32_c;
             const bool wrap_ok = T.wrap32_ok != 0;
             float sumv[FB_K], diffv[FB_K];
+            const bool wide = __any(!all_in(cur, P32 + 0.5f)) || !wrap_ok;     // (some phase of the wave outside [0, 2 pi + 0.5): the general PI_Constrain)
 #pragma unroll
             for (int i = 0; i < FB_K; i++) {
                 // phaseforLRDiff fm-processor.cpp:707-714: 2 (currentPilotPhase + pi/4) - pilotDelayPSS lies in (0, 4 pi + 2.4), so the
                 // "< -2 pi" branch never runs and fmod (., 2 pi) is the fraction of the turn count
                 float cc = (cur[i] < P32) ? cur[i] : (cur[i] - P32) + C32;                   // PI_Constrain of [0, 2 pi + 0.7), see the pilot PLL
-                if (__any(!(cur[i] >= 0.f && cur[i] < P32 + 0.5f) || !wrap_ok)) cc = pi_constrain(cur[i]);
+                if (wide) cc = pi_constrain(cur[i]);
                 const float p = (float)(2 * ((double)cc + FMX_PI_4 + 0) - (double)used[i]);
                 const double u = __builtin_amdgcn_fract((double)p * INV2PI);
                 int idx = (int)(u * (double)SINCOS_N);               // SinCos::getComplex sincos.cpp:93-97
