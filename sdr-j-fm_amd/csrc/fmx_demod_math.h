@@ -146,6 +146,26 @@ __device__ __forceinline__ float atan_finish(const AtanArm &a, float tv) {
     const float r = a.A + ((a.flags & 1u) ? -tv : tv);
     return (a.flags & 2u) ? a.special : r;
 }
+// The same for finite arguments with x != 0 (everything but the corners Xtan2.cpp:56-68 handles first): no special value to carry.
+// `odd` collects the arguments that are not of that kind (one v_cmp_class each); the caller looks at it once for all its samples and
+// takes the general form above when it is set anywhere in the wave.
+struct AtanArmF { int idx; float A; bool neg; };
+__device__ __forceinline__ AtanArmF atan_arm_plain(float y, float x, bool *odd) {
+    const float St = (float)3.14159265358979323846, Sh = St * 0.5f;
+    // v_cmp_class masks: 0x001 sNaN 0x002 qNaN 0x004 -inf 0x010 -denormal 0x020 -0 0x040 +0 0x080 +denormal 0x200 +inf (denormal x: to the general form, whatever the denormal mode makes of it)
+    *odd = *odd || __builtin_amdgcn_classf(x, 0x2f7) || __builtin_amdgcn_classf(y, 0x207);
+    const bool xpos = x > 0.f, ypos = y >= 0.f;
+    const bool swap = !(fabsf(x) >= fabsf(y));
+    const bool same = xpos == ypos;
+    const float size = same ? (float)ATAN_N : -(float)ATAN_N;
+    const float num = swap ? x : y, den = swap ? y : x;
+    int idx = (int)(fdiv_fast(size * num, den) + 0.5f);
+    AtanArmF a;
+    a.idx = idx < 0 ? 0 : (idx > ATAN_N ? ATAN_N : idx);
+    a.A = swap ? (ypos ? Sh : -Sh) : (xpos ? 0.f : (ypos ? St : -St));
+    a.neg = same == swap;
+    return a;
+}
 __device__ __forceinline__ float lut_atan2_fast(const float *__restrict__ ppy, float y, float x) {
     const AtanArm a = atan_arm(y, x);
     return atan_finish(a, ppy[a.idx]);

@@ -479,11 +479,12 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                     res[i] = fdiv_fast(r, (I1 * I1 + Q1 * Q1) * Scaler);
                 }
             } else {                                                 // MIXED :168-172 (COMPLEX_BB is bitwise the same)
-                AtanArm arm[FB_K];
+                AtanArmF arm[FB_K];
+                bool odd = false;                                    // an argument pair compAtan::atan2 answers without its table
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) {
                     const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
-                    arm[i] = atan_arm(Q * I1 - I * Q1, I * I1 + Q * Q1);
+                    arm[i] = atan_arm_plain(Q * I1 - I * Q1, I * I1 + Q * Q1, &odd);
                 }
                 SB_FT(3);
                 float tv[FB_K];
@@ -491,7 +492,14 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 for (int i = 0; i < FB_K; i++) tv[i] = T.atan_ppy[arm[i].idx];
                 SB_FTW(4);
 #pragma unroll
-                for (int i = 0; i < FB_K; i++) res[i] = atan_finish(arm[i], tv[i]);
+                for (int i = 0; i < FB_K; i++) res[i] = arm[i].A + (arm[i].neg ? -tv[i] : tv[i]);
+                if (__any(odd)) {                                    // (x = 0, an infinity, a NaN: the general form for the thread's samples)
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) {
+                        const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
+                        res[i] = lut_atan2_fast(T.atan_ppy, Q * I1 - I * Q1, I * I1 + Q * Q1);
+                    }
+                }
             }
 #pragma unroll
             for (int i = 0; i < FB_K; i++) res[i] = (i < nv) ? res[i] : 0.f;

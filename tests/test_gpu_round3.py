@@ -424,3 +424,40 @@ def test_shard_collectives_over_rccl_one_rank(fmx_amd, ol, tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", FMX_SHARD_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(worker)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_discriminator_corner_arguments_of_the_atan_table(fmx_amd, ol):
+    """compAtan::atan2 (Xtan2.cpp:56-68) answers x = 0 without its table (+-pi/2, 0 for y = 0).  The kernel computes the table arm of a
+    thread's six samples without those corners and looks for them once per wave (v_cmp_class), taking the general form when one turns
+    up.  A 192 kS/s stream (no decimators: the samples reach the limiter as they are) that steps by exactly 90 degrees, flips by 180,
+    repeats samples and falls to zero for stretches makes x = 0, y = 0 and the limiter's 0.001 floor appear in every combination, in
+    some segments only: demodulator output and PCM against the oracle."""
+    rng = np.random.default_rng(7)
+    block = 16384
+    nb = 30
+    n = block * nb
+    steps = rng.choice([0, 1, 1, 1, 2, 3], size=n)            # quarter turns per sample
+    k = np.cumsum(steps) % 4
+    unit = np.array([[1, 0], [0, 1], [-1, 0], [0, -1]], np.float32)
+    iq = 0.5 * unit[k]
+    smooth = ol.synth_iq(n)[:, :]                             # an ordinary stereo signal (its time base does not matter here)
+    use_smooth = (np.arange(n) // 3000) % 3 == 0              # ordinary stretches in between: segments without a corner
+    iq[use_smooth] = smooth[use_smooth]
+    zero = (np.arange(n) // 1777) % 7 == 3
+    iq[zero] = 0.0
+    for dec in (3, 4):
+        f = fmx_amd.Fmx(1, max_block=block, inputRate=192000)
+        gui_defaults(f, 0)
+        f.set_param(M.P_DC_REMOVE, 0); f.set_param(M.P_FM_DECODER, dec)
+        o = ol.OracleChain(inputRate=192000, inputFilterBw=0, dcRemove=0, decoder=dec, taps=[ol.TAP_DEMOD], tap_seconds=3.0)
+        pg, po, worst = [], [], 0.0
+        for b in range(nb):
+            x = iq[b * block:(b + 1) * block]
+            pg.append(f.process_host(x)[0]); po.append(o.process(x))
+            d_g, d_o = f.tap(M.TAP_DEMOD, block), o.tap(ol.TAP_DEMOD)[b * block:(b + 1) * block]
+            worst = max(worst, float(np.abs(d_g - d_o).max()))
+        pg, po = np.concatenate(pg), np.concatenate(po)
+        print(f"\n[atan corners, decoder {dec}] demodulator output max |diff| {worst:.2e} (full scale {np.abs(o.tap(ol.TAP_DEMOD)).max():.2f}), PCM rms {rms(pg - po):.2e}")
+        # (a wrong corner would be off by pi/2 or more = 2.4 of the demodulator's scale; what is left is the AFC average of this heavily
+        # biased signal -- |afc| ~ 1 rad -- summed in another order by the time-parallel scan: ~6e-6 rad, 1e-5 .. 1e-4 after the scaling)
+        assert worst <= 3e-4 and rms(pg - po) <= PCM_RMS_TOL
