@@ -310,6 +310,10 @@ __device__ __forceinline__ Aff wscan_aff(Aff v) {
     return v;
 }
 
+#ifndef SB_ABLATE
+#define SB_ABLATE 0      /* diagnostic builds only (tools/diag/valu_phases.sh): bit 0 no discriminator, 1 no AFC, 2 no pilot PLL, 3 no lock
+                            detector -- for instruction counts per phase; the results are wrong by construction */
+#endif
 #ifndef SB_SEED_ROUNDS
 #define SB_SEED_ROUNDS 2
 #endif
@@ -451,7 +455,10 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         if (!special) {
         // ================= limiter + discriminator (fm-demodulator.cpp:119-126, 168-189) =================
         float res[FB_K];
-        {
+        if (SB_ABLATE & 1) {
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) res[i] = zn[i + 2].x;
+        } else {
             const int decoder = P.decoder;
             float2 lim[FB_K + 2];                                // limited samples j0-2 .. j0+K-1 (the two in front recomputed: cheaper
 #pragma unroll                                                   // than an exchange through LDS with its two barriers)
@@ -508,7 +515,10 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         SB_ARGS_FRESH(); SB_TICK1(0);
 
         // ================= AFC + scaling (fm-demodulator.cpp:197-198) =================
-        {
+        if (SB_ABLATE & 2) {
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) dem[i] = res[i];
+        } else {
             const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha;
             float Lt = 0.f;
 #pragma unroll
@@ -553,7 +563,11 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         //    A segment that does not settle in PLL_NEWTON_MAX rounds is evaluated sequentially (ChanState::pll_replays counts them).
         float osc[FB_K];
         float osc_in;                                            // NCO sine of the sample in front of this thread's first
-        {
+        if (SB_ABLATE & 4) {
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) { cur[i] = dem[i]; osc[i] = dem[i]; }
+            osc_in = dem[0];
+        } else {
             const float gain = T.pil_gain, omega = T.pil_omega;
             const double SC64 = T.sincos_C;
             const float P32 = 6.2831855f, C32 = T.wrap32_c, INV2PI32 = 0.159154943f;
@@ -762,7 +776,11 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         SB_ARGS_FRESH(); SB_TICK1(2);
 
         // ================= lock detector (pilot-recover.cpp:62-80) =================
-        {
+        if (SB_ABLATE & 8) {
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) locked[i] = osc[i] > 0.f;
+            all_locked = osc_in > 0.f;
+        } else {
             const float lockA = 1.0f / 3000.0f;
             const double keep = 1.0 - (double)lockA;
             const float keepf = (float)keep;
@@ -795,8 +813,17 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             }
             SB_FT(14);
             // locked[j] = no sample <= j below the threshold AND (locked before, or the run has lasted long enough)
-            int cnt_dummy, tot_dummy, preF, totF;
-            wg.excl_add_max_i(0, lastf, &cnt_dummy, &tot_dummy, &preF, &totF);
+            // (a pilot in lock has no such sample: one flag per wave through the barrier instead of the maximum's scan, which follows
+            // behind a second barrier where a sample did fall below)
+            int preF = -1, totF = -1;
+            {
+                const int wlow = __any(lastf >= 0) ? 1 : 0;
+                if (lane == 0) lds.wi[wg.sl][wg.wv][2] = wlow;
+                __syncthreads();
+                const int anylow = lds.wi[wg.sl][0][2] | lds.wi[wg.sl][1][2] | lds.wi[wg.sl][2][2] | lds.wi[wg.sl][3][2];
+                wg.sl ^= 1;
+                if (anylow) { int cnt_dummy, tot_dummy; wg.excl_add_max_i(0, lastf, &cnt_dummy, &tot_dummy, &preF, &totF); }
+            }
             {
                 int F = preF;
 #pragma unroll
@@ -1106,7 +1133,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 // "< -2 pi" branch never runs and fmod (., 2 pi) is the fraction of the turn count
                 float cc = (cur[i] < P32) ? cur[i] : (cur[i] - P32) + C32;                   // PI_Constrain of [0, 2 pi + 0.7), see the pilot PLL
                 if (wide) cc = pi_constrain(cur[i]);
-                const float p = (float)(2 * ((double)cc + FMX_PI_4 + 0) - (double)used[i]);
+                const float p = (float)(2 * ((double)cc + FMX_PI_4) - (double)used[i]);      // (+ PILOTTESTDELAY = 0, fm-processor.cpp:42: x + 0 = x for x > 0)
                 const double u = __builtin_amdgcn_fract((double)p * INV2PI);
                 int idx = (int)(u * (double)SINCOS_N);               // SinCos::getComplex sincos.cpp:93-97
                 idx = idx >= SINCOS_N ? SINCOS_N - 1 : idx;
@@ -1150,7 +1177,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         // ================= de-emphasis (fm-processor.cpp:594-595) into the d ring =================
         // (the next segment's ring entries are requested here: they land under the de-emphasis, and are not in the way of the
         // register-hungry phases above)
-        if (!lastseg && !special) { const int wn = (nj - seg0 - FB_W) < FB_W ? (nj - seg0 - FB_W) : FB_W; fetch(j0, seg0 + FB_W, wn, zn); }
+        if (PART == 0 && !lastseg && !special) { const int wn = (nj - seg0 - FB_W) < FB_W ? (nj - seg0 - FB_W) : FB_W; fetch(j0, seg0 + FB_W, wn, zn); }
         SB_FT(29);
         {
             const float a = P.deemph_alpha;
