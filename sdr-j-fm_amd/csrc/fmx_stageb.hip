@@ -103,13 +103,26 @@ struct DecayW { float m1, m2, m4, m8, mA, mB, dl, d64; };
 // to 1536 must not carry the 3e-8 of a rounded base); v_exp_f32 is good to an ulp, like the f32 the weights are stored in
 __device__ __forceinline__ DecayW make_decay(float l2, int lane) {
     DecayW w;
-#ifndef SB_HOIST_DECAY
-    asm volatile("" : "+v"(l2));        // opaque: the eight weights are recomputed where they are used (hoisted out of the segment loop they
-#endif                                  // would occupy 8 VGPRs per recurrence for the whole kernel)
     const float L = l2 * (float)FB_K;                            // log2 of D = d^FB_K
     w.m1 = __builtin_amdgcn_exp2f(L); w.m2 = __builtin_amdgcn_exp2f(2 * L); w.m4 = __builtin_amdgcn_exp2f(4 * L); w.m8 = __builtin_amdgcn_exp2f(8 * L);
     w.mA = __builtin_amdgcn_exp2f((float)((lane & 15) + 1) * L); w.mB = __builtin_amdgcn_exp2f((float)((lane & 31) + 1) * L);
     w.dl = __builtin_amdgcn_exp2f((float)lane * L); w.d64 = __builtin_amdgcn_exp2f(64 * L);
+    return w;
+}
+// The weights of the kernel's four one-pole scans (AFC, lock metric, PSS mean error, de-emphasis) per lane, in LDS: computed once per
+// launch, read back with two 16-byte LDS reads where a scan needs them.  (Kept in registers they would occupy 8 VGPRs per scan for the
+// whole kernel; recomputed per segment -- what was done before -- they cost eight quarter-rate v_exp_f32 and as many multiplies per scan
+// and segment: 5 % of the first kernel's VALU time.)
+enum { DEC_AFC = 0, DEC_LOCK = 1, DEC_PSSMEAN = 2, DEC_DEEMPH = 3 };
+template <int NSCANS> struct DecayTab { float4 w[NSCANS][64][2]; };      // (a half of the kernel holds its own two scans: which & 1)
+template <int NSCANS> __device__ __forceinline__ void store_decay(DecayTab<NSCANS> *tab, int which, float l2, int lane) {
+    const DecayW w = make_decay(l2, lane);
+    tab->w[which % NSCANS][lane][0] = make_float4(w.m1, w.m2, w.m4, w.m8);
+    tab->w[which % NSCANS][lane][1] = make_float4(w.mA, w.mB, w.dl, w.d64);
+}
+template <int NSCANS> __device__ __forceinline__ DecayW load_decay(const DecayTab<NSCANS> *tab, int which, int lane) {
+    const float4 a = tab->w[which % NSCANS][lane][0], b = tab->w[which % NSCANS][lane][1];
+    DecayW w; w.m1 = a.x; w.m2 = a.y; w.m4 = a.z; w.m8 = a.w; w.mA = b.x; w.mB = b.y; w.dl = b.z; w.d64 = b.w;
     return w;
 }
 // inclusive over the wave: Z[t] = D Z[t-1] + L[t]
@@ -348,6 +361,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     // demod and pilot phase of the segment wait here while the convolution has the registers (they are not needed in it; kept in
     // registers they pushed the kernel over its budget of 168: spills, i.e. scratch memory for every wave)
     __shared__ __attribute__((aligned(8))) float park_dem[FB_W], park_cur[FB_W];
+    __shared__ __attribute__((aligned(16))) DecayTab<(PART == 0 ? 4 : 2)> dtab;
     const int ch = blockIdx.x;
     if (ch >= C) return;
     WG wg; wg.L = &lds; wg.tid = threadIdx.x; wg.lane = threadIdx.x & 63; wg.wv = threadIdx.x >> 6; wg.sl = 0;
@@ -420,6 +434,10 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         cy.calls = 0;                                            // process_sample calls of this call's earlier segments
     }
     const int64_t pss_count0 = st->pss_count;
+    if (threadIdx.x < 64) {
+        if (PART != 2) { store_decay(&dtab, DEC_AFC, T.afc_l2, threadIdx.x); store_decay(&dtab, DEC_LOCK, T.lock_l2, threadIdx.x); }
+        if (PART != 1) { store_decay(&dtab, DEC_PSSMEAN, T.pssmean_l2, threadIdx.x); store_decay(&dtab, DEC_DEEMPH, P.deemph_l2, threadIdx.x); }
+    }
     float2 zn[FB_K + 2];
     if (PART != 2 && !special) fetch((int)threadIdx.x * FB_K, 0, nj < FB_W ? nj : FB_W, zn);
     __syncthreads();
@@ -524,7 +542,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
 #pragma unroll
             for (int i = 0; i < FB_K; i++) Lt = c1 * Lt + fmDcAlpha * res[i];
             float afc_next;
-            float afc = wg.decay_incoming2(Lt, cy.afc, make_decay(T.afc_l2, lane), &afc_next);
+            float afc = wg.decay_incoming2(Lt, cy.afc, load_decay(&dtab, DEC_AFC, lane), &afc_next);
             float afc_end = 0.f;
             const float K_FM = T.K_FM, K_FM_rcp = T.K_FM_rcp;
 #pragma unroll
@@ -801,7 +819,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             SB_FT(13);
             float lock_next;
             const int locked0 = cy.locked, stable0 = cy.stable;
-            float lock = wg.decay_incoming2(Lt, cy.lock, make_decay(T.lock_l2, lane), &lock_next);
+            float lock = wg.decay_incoming2(Lt, cy.lock, load_decay(&dtab, DEC_LOCK, lane), &lock_next);
             bool hi[FB_K]; int lastf = -1; float lock_end = 0.f, lock_x = 0.f;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) {
@@ -1003,7 +1021,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 }
                 SB_FT(22);
                 // mean_error (1 / rate smoothing) and the "minimised" bookkeeping in closed form
-                const DecayW dw = make_decay(T.pssmean_l2, lane);
+                const DecayW dw = load_decay(&dtab, DEC_PSSMEAN, lane);
                 float Lt = 0.f;
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) Lt = ((i < nv) ? la * er10[i] : 0.f) + Lt * keep;
@@ -1181,7 +1199,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         SB_FT(29);
         {
             const float a = P.deemph_alpha;
-            const DecayW dw = make_decay(P.deemph_l2, lane);
+            const DecayW dw = load_decay(&dtab, DEC_DEEMPH, lane);
             float Ll = 0.f, Lr = 0.f;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) { Ll = (x[i].x - Ll) * a + Ll; Lr = (x[i].y - Lr) * a + Lr; }
