@@ -407,6 +407,14 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         if (w == FB_W && base - 2 - delay >= 0) {                // (the same for every thread) a full segment behind the filter latency:
             const int rmask = zmask;                             // no clamp, no marker, no zero fill; ring positions in 32 bits
             const int r0 = (int)((base - delay) & rmask) + j0 - 2;
+            // (eight consecutive entries: where no lane's run crosses the ring's end -- the same for the whole wave -- one address
+            // and eight immediate offsets instead of eight masked indices)
+            if (!__any(r0 < 0 || r0 + FB_K + 1 > rmask)) {
+                const float2 *p = zr + r0;
+#pragma unroll
+                for (int t = 0; t < FB_K + 2; t++) z[t] = p[t];
+                return;
+            }
 #pragma unroll
             for (int t = 0; t < FB_K + 2; t++) z[t] = zr[(r0 + t) & rmask];
             return;
