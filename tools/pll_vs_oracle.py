@@ -27,6 +27,8 @@ ch.process(iq)
 f = pkg.Fmx(1, max_block=block)
 for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FM_MODE, 0)):
     f.set_param(pid, v)
+if os.environ.get("PLL_SOLVER"):                           # 1 sequential, 2 Newton (a one-channel handle takes the sequential one by itself)
+    f.set_param(M.P_PLL_SOLVER, int(os.environ["PLL_SOLVER"]))
 f.L.fmx_debug_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_ulonglong)]
 dbg = (C.c_ulonglong * 96)()
 f.L.fmx_debug_phase_cycles(f.h, 1, None)
