@@ -23,7 +23,10 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 1
+/* 2: fmx_meta and fmx_rds_info grew (live_rf_dc_*, radio_text_ucs2*), FMX_P_PLL_SOLVER 3, fmx_pll_exact_segments.  The output
+ * structs are caller-allocated and carry no size field: a caller built against another version must not call in -- the adapters
+ * compare fmx_abi_version () with the FMX_ABI_VERSION they were compiled with when they load the library. */
+#define FMX_ABI_VERSION 2
 
 typedef struct fmx_handle_s *fmx_handle;
 
@@ -85,10 +88,15 @@ typedef enum {
     FMX_P_DISP_DELAY = 20,     /* setDispDelay (:935-937): steps of the peak-level delay line; applies to the windows
                                   fmx_get_peaks has not handed out yet */
     FMX_P_PLL_SOLVER = 21,     /* how stage B evaluates the pilot PLL loop of pilot-recover.cpp:54-61 (no counterpart in the reference, whose
-                                  loop runs sample by sample): 1 = sequentially, one thread per channel -- the reference's f32 trajectory
-                                  bit for bit (about 45 us per 1536 fm samples and channel); 2 = all samples of a segment at once by
-                                  Newton's method -- the trajectory to ~1e-5 rad (the loop's own f32 rounding noise, integrated), what
-                                  large batches need; 0 = automatic: 1 up to 64 channels per handle, 2 above (default) */
+                                  loop runs sample by sample): 1 = sequentially in every segment -- the reference's f32 trajectory (one thread
+                                  per channel walks the recurrence, the table arithmetic is prepared by all); 2 = all samples of a segment at
+                                  once by Newton's method (the trajectory to ~1e-5 rad: the loop's own f32 rounding noise, integrated) WHILE
+                                  THE PILOT IS COMFORTABLY IN LOCK, sequentially otherwise -- during acquisition and whenever the lock metric
+                                  came within 0.05 of its threshold in the previous segment, so that every lock decision
+                                  (pilot-recover.cpp:62-80) is taken on the reference's own trajectory: what large batches use;
+                                  3 = Newton's method always (diagnostic: lock decisions may then fall a few samples apart from the
+                                  reference's when the metric creeps through its threshold); 0 = automatic: 1 up to 64 channels per
+                                  handle, 2 above (default) */
     FMX_P_STAGEB_FORM = 22,    /* (handle-wide: the channel argument is ignored) stage B -- limiter .. de-emphasis -- as 1 = one kernel per call,
                                   2 = two kernels (limiter .. lock detector, then PSS .. de-emphasis: four workgroups per CU instead of
                                   three); 0 = automatic (default): whichever wastes less of its last round of workgroups for the
@@ -237,7 +245,7 @@ int  fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity
  * fmProcessor::run pushes into the IQ scope ring (fm-processor.cpp:555-563): pending symbols as interleaved (I, Q), oldest
  * first, own read position.  RDS_2 only; the library keeps the last 1024. */
 int  fmx_rds_symbols(fmx_handle h, int32_t channel, float *iq, int32_t capacity, int32_t *n_symbols);
-/* fm-rate samples (inputRate / 12) the last fmx_process_* call produced per channel: the n that fmx_get_tap accepts for the
+/* fm-rate samples (inputRate / the reference's decimation: 12, 6 or 1) the last fmx_process_* call produced per channel: the n that fmx_get_tap accepts for the
  * fm-rate taps, and the number of entries the reference's run() pushed into its LF scope vector for the same block */
 int64_t fmx_last_fm_samples(fmx_handle h);
 /* Health counter of the pilot PLL (no counterpart in the reference, whose loop is sequential): stage B finds the loop's
@@ -245,6 +253,9 @@ int64_t fmx_last_fm_samples(fmx_handle h);
  * round limit is replayed sample by sample by one thread -- correct, only slower.  Returns the number of such segments
  * of `channel` since fmx_create (channel < 0: summed over all channels), or a negative fmx error code. */
 int64_t fmx_pll_replays(fmx_handle h, int32_t channel);
+/* Segments (of up to 1536 fm samples) that FMX_P_PLL_SOLVER = 2 evaluated sequentially because the pilot was not comfortably in lock,
+ * of `channel` since fmx_create (channel < 0: summed over all channels), or a negative fmx error code: what the guard costs. */
+int64_t fmx_pll_exact_segments(fmx_handle h, int32_t channel);
 /* ... and 24 kS/s RDS samples (rdsDecimator outputs, fm-processor.cpp:553): the n that fmx_get_tap accepts for FMX_TAP_RDS_IQ */
 int64_t fmx_last_rds_samples(fmx_handle h);
 

@@ -958,7 +958,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_SQUELCH_MODE:
         if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "squelch mode must be 0 (off), 1 (noise squelch) or 2 (level squelch)"); break;
     case FMX_P_SQUELCH_VALUE: if (iv < 0 || iv > 100) return fail(FMX_E_INVALID, "squelch value must be 0..100"); break;
-    case FMX_P_PLL_SOLVER: if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "PLL solver must be 0 (automatic), 1 (sequential) or 2 (parallel)"); break;
+    case FMX_P_PLL_SOLVER: if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "PLL solver must be 0 (automatic), 1 (sequential), 2 (Newton, sequential around lock decisions) or 3 (Newton always)"); break;
     case FMX_P_STAGEB_FORM:
         if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "stage B form must be 0 (automatic), 1 (one kernel) or 2 (two kernels)");
         h->stageb_form.store(iv); return FMX_OK;
@@ -1018,7 +1018,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         case FMX_P_SQUELCH_MODE: p.squelch_mode = iv; break;
         case FMX_P_SQUELCH_VALUE: u.squelch_value = iv; break;
         case FMX_P_TEST_TONE: p.test_tone = iv != 0; break;
-        case FMX_P_PLL_SOLVER: p.pll_seq = (iv == 1 || (iv == 0 && h->channels <= PLL_SEQ_AUTO_MAX)) ? 1 : 0; break;
+        case FMX_P_PLL_SOLVER: p.pll_seq = (iv == 1 || (iv == 0 && h->channels <= PLL_SEQ_AUTO_MAX)) ? 1 : (iv == 3 ? 2 : 0); break;
         case FMX_P_DISP_DELAY:                       // DelayLine::set_delay_steps fm-processor.h:60-63: resize keeps what is there
             u.delay.resize((size_t)iv + 1, make_float2(-40.0f, -40.0f)); u.delay_idx = 0; break;
         case FMX_P_DC_REMOVE: p.dc_remove = iv != 0; p.actions |= ACT_DC_RESET; break;
@@ -1257,6 +1257,16 @@ int64_t fmx_pll_replays(fmx_handle h, int32_t channel) {
     if (hipMemcpy(st.data(), h->B.state + c0, sizeof(ChanState) * st.size(), hipMemcpyDeviceToHost) != hipSuccess) return (int64_t)fail(FMX_E_HIP, "device error");
     int64_t n = 0;
     for (auto &s : st) n += s.pll_replays;
+    return n;
+}
+int64_t fmx_pll_exact_segments(fmx_handle h, int32_t channel) {
+    if (!h || channel >= h->channels) return (int64_t)fail(FMX_E_INVALID, "bad argument");
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return (int64_t)fail(FMX_E_HIP, "device error");
+    const int c0 = channel < 0 ? 0 : channel, c1 = channel < 0 ? h->channels : channel + 1;
+    std::vector<ChanState> st((size_t)(c1 - c0));
+    if (hipMemcpy(st.data(), h->B.state + c0, sizeof(ChanState) * st.size(), hipMemcpyDeviceToHost) != hipSuccess) return (int64_t)fail(FMX_E_HIP, "device error");
+    int64_t n = 0;
+    for (auto &s : st) n += s.pll_exact_segs;
     return n;
 }
 int64_t fmx_last_rds_samples(fmx_handle h) { return (h && h->rds_alloc) ? (int64_t)(h->last_m1 - h->last_m0) : 0; }

@@ -69,7 +69,9 @@ struct ChanParams {
     int32_t test_tone;      // setTestTone fm-processor.cpp:931-933
     float   squelch_nthr;   // noiseSquelchThreshold squelchClass.cpp:36
     float   deemph_l2;      // log2 (1.0f - deemph_alpha) (fused stage B: scan weights)
-    int32_t pll_seq;        // the pilot PLL of this channel is evaluated sample by sample (FMX_P_PLL_SOLVER resolved on the host)
+    int32_t pll_seq;        // FMX_P_PLL_SOLVER resolved on the host: 1 the pilot PLL of this channel is evaluated sample by sample in every segment;
+                            // 0 Newton's method on the segment while the pilot is comfortably in lock, sample by sample otherwise (PLL_GUARD in
+                            // fmx_stageb.hip: the lock decisions are then taken on the reference's own trajectory); 2 Newton's method always (diagnostic)
 };
 enum { ACT_TRIGGER_FREQ = 1, ACT_RESTART_PSS = 2, ACT_DC_RESET = 4 };
 
@@ -116,7 +118,11 @@ struct ChanState {
     float   sq_avg_hi, sq_avg_lo;
     float   sq_m[2][NSQ_QUADS][2];
     // segments of the pilot PLL that did not settle and were replayed sample by sample (fmx_stageb.hip), since fmx_create
-    int32_t pll_replays, pad_r;
+    int32_t pll_replays;
+    // ChanParams::pll_seq == 0: the next segment may use Newton's method (the pilot was in lock behind the last segment and the lock metric stayed
+    // above PLL_GUARD throughout it); 0 after fmx_create: the acquisition runs sample by sample
+    int32_t pll_newton_ok;
+    int32_t pll_exact_segs, pad_x;   // segments the guard sent through the sample-by-sample evaluation, since fmx_create
 };
 
 // Work arrays of stage B (w_*): element (row r, channel ch) lives at ((r / 16) * pitch + ch) * 16 + r % 16 -- tiles of 16

@@ -335,6 +335,8 @@ __device__ __forceinline__ Aff wscan_aff(Aff v) {
 #endif
 constexpr float PLL_NEWTON_TOL = SB_NEWTON_TOL;   // a Newton round whose largest update is below this ends the iteration: what it leaves is of second order,
                                           // 0.5 sum |g| d^2 < 2e-6 rad over a segment (g = 5 demod gain, sum |g| < 1 for programme material)
+constexpr float PLL_GUARD = 0.12f;        // ChanParams::pll_seq == 0: Newton's method needs the lock metric above this through the whole previous segment (threshold 0.07;
+                                          // a pilot of 8 % of the deviation settles at 0.28, one of 3 % at 0.105)
 constexpr int PLL_NEWTON_MAX = 10;        // rounds before the segment is replayed sample by sample (ChanState::pll_replays counts those)
 
 // PART 0: the whole of stage B in one kernel (handles of few channels: one launch, the channel's latency is what counts).
@@ -353,14 +355,22 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     __shared__ ScanLds lds;
     // the recurrences' states in front of the next segment: the same for every thread, so they live in LDS, not in everybody's registers
     // (written by one thread behind a phase, read by all in front of the same phase of the next segment: barriers in between)
-    __shared__ struct { float afc, x0, old, lock; int locked, stable; PssSt ps; float de_l, de_r; int calls; } cy;
-    __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];     // the convolution's buffer, afterwards er / pk:
-    float *er = reinterpret_cast<float *>(X);                        // [FB_W] PSS error per call of the segment; replay paths: inputs in, results out
-    int *pk = reinterpret_cast<int *>(X) + FB_W;                     // [FB_W] replay path: ((tag + 2) << 1) | locked per sample
-    static_assert(2 * FB_W * 4 <= sizeof(float2) * fftc::LDS_N, "er and pk live in the convolution buffer");
-    // demod and pilot phase of the segment wait here while the convolution has the registers (they are not needed in it; kept in
-    // registers they pushed the kernel over its budget of 168: spills, i.e. scratch memory for every wave)
-    __shared__ __attribute__((aligned(8))) float park_dem[FB_W], park_cur[FB_W];
+    __shared__ struct { float afc, x0, old, lock; int locked, stable; PssSt ps; float de_l, de_r; int calls; int newton_ok; } cy;
+    // One block of LDS: the convolution's buffer X (afterwards er / pk), then the two rows in which demod and pilot phase of the segment
+    // wait while the convolution has the registers (they are not needed in it; kept in registers they pushed the kernel over its budget of
+    // 168: spills, i.e. scratch memory for every wave).  The sample-by-sample pass of the pilot PLL, which runs while all of that is
+    // free, takes the whole block: FB_W candidate records of 16 bytes and FB_W phases (SpecRec below).
+    constexpr int XF = 2 * fftc::LDS_N;                              // floats of X
+    __shared__ __attribute__((aligned(16))) float big[XF + 2 * FB_W];
+    float2 *const X = reinterpret_cast<float2 *>(big);
+    float *er = big;                                                 // [FB_W] PSS error per call of the segment; replay paths: inputs in, results out
+    int *pk = reinterpret_cast<int *>(big) + FB_W;                   // [FB_W] replay path: ((tag + 2) << 1) | locked per sample
+    static_assert(2 * FB_W <= XF, "er and pk live in the convolution buffer");
+    float *const park_dem = big + XF, *const park_cur = big + XF + FB_W;
+    float4 *const spec4 = reinterpret_cast<float4 *>(big);           // [FB_W] {c(idx - 1), c(idx), c(idx + 1), idx} of the guess, see the pilot PLL
+    float *const pout = big + 4 * FB_W;                              // [FB_W] the phases the sample-by-sample pass found
+    static_assert(5 * FB_W <= XF + 2 * FB_W && (XF % 4) == 0, "candidate records and phases fit the block");
+    __shared__ int spec_bad;
     __shared__ __attribute__((aligned(16))) DecayTab<(PART == 0 ? 4 : 2)> dtab;
     const int ch = blockIdx.x;
     if (ch >= C) return;
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     };
     if (threadIdx.x == 0) {
         cy.afc = st->fm_afc; cy.x0 = st->pil_phase; cy.old = st->pil_old; cy.lock = st->pil_lock;
-        cy.locked = st->pil_locked; cy.stable = st->pil_stable;
+        cy.locked = st->pil_locked; cy.stable = st->pil_stable; cy.newton_ok = st->pll_newton_ok;
         PssSt ps;
         ps.acc = st->pss_acc; ps.mean = st->pss_mean; ps.pdp = st->pilot_delay_pss;
         ps.lock_cnt = st->pss_lock_cnt; ps.unlock_cnt = st->pss_unlock_cnt; ps.minimized = st->pss_minimized != 0;
@@ -606,7 +616,17 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             float ph[FB_K];
             // the reference's step on one guess: table index in f64 as sincos.cpp:81-85 computes it, everything else in f32
             float nxl = 0.f;                                     // step result of this thread's last evaluated sample `il` (the owner's: the next segment's start)
-            bool seq = P.pll_seq != 0;                           // this pass evaluates the loop sample by sample (the same in every thread)
+            // Which segments are evaluated sample by sample (the same decision in every thread).  pll_seq 1: all of them.  pll_seq 0 (large
+            // batches): the segments in which a lock decision can fall -- Newton's trajectory carries the rounding noise of ~1e-5 rad
+            // described above, which moves the lock metric by ~1e-6, enough to shift the sample at which the metric crosses its threshold
+            // (and, half a second later, the sample at which the stereo decoder switches) when it crosses slowly.  So Newton's method only
+            // runs while the pilot is in lock AND the metric stayed above PLL_GUARD through the whole previous segment; the acquisition and
+            // every approach of the threshold run on the reference's own trajectory (cy.newton_ok, set by the lock detector below).
+            const int pll_mode = P.pll_seq;
+            bool exact_pending = pll_mode == 1 || (pll_mode == 0 && stereo_possible && !cy.newton_ok);
+            const bool guard_seg = pll_mode == 0 && exact_pending;
+            bool seq = false;                                    // this pass evaluates the loop sample by sample (the same in every thread)
+            bool failsafe = false;                               // ... because Newton's iteration did not settle
             auto eval = [&](int i, float phase, float *nx_out, float *val_out) {
                 int idx = (int)((double)phase * SC64);           // SinCos::getSin sincos.cpp:81-85 for phase >= 0: entry (int)(phase * C) % Rate
                 idx = (int)min((unsigned)idx, (unsigned)idx - (unsigned)SINCOS_N);       // (0 <= idx < 2 N: the wrap as an unsigned minimum)
@@ -631,7 +651,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 const float pw = (float)(pd - floor(pd * (1.0 / FMX_2PI)) * FMX_2PI);
                 return (phase >= 0.f && phase < P32) ? phase : ((pw >= 0.f && pw < P32) ? pw : 0.f);
             };
-            if (!seq) {   // ---- the first guess
+            {   // ---- the first guess
                 float rv[FB_K];                                  // the ramp x0 + j omega in turns, fraction
                 const double tb = ((double)x0 + (double)j0 * (double)omega) * (1.0 / FMX_2PI);
                 const float tbf = (float)(tb - floor(tb));
@@ -670,27 +690,84 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             const double x0d = (double)x0;
             for (int it = 0; ; it++) {
                 if (seq) {
-                    // the loop sample by sample: one thread, operands through LDS (the convolution's buffer is free here)
+                    // The loop sample by sample: one thread, operands through LDS (the block is free here).  What makes the reference's step
+                    // slow as a dependent chain is its table look-up; the recurrence itself is two additions and the wrap.  The guess at hand
+                    // (Newton's, good to a few 1e-6 rad; a table step is 3.3e-5) tells which entry each sample will read, give or take one: all
+                    // threads tabulate the correction 5 demod sin (.) gain for the guess's entry and its two neighbours (the f32 expressions of
+                    // the step, the same table values the final evaluation uses), and the serial pass only computes the index of ITS phase,
+                    // picks one of the three, adds and wraps.  A sample whose index is not one of the three (or a step result outside
+                    // [0, 4 pi)) sends the segment through the plain loop below: the result is the sequential f32 trajectory either way.
                     __syncthreads();
 #pragma unroll
-                    for (int i = 0; i < FB_K; i++) if (i < nv) er[j0 + i] = dem[i];
-                    __syncthreads();
-                    if (tid == 0) {
-                        float phase = x0;
-                        for (int j = 0; j < w; j++) {
-                            const float d5 = 5 * er[j];
-                            er[FB_W + j] = phase;
-                            int idx = (int)((double)phase * SC64);
-                            idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
-                            const float val = (phase + (d5 * sin_idx_f32(idx)) * gain) + omega;
-                            phase = (val >= 0.f && val < P32) ? val : pi_constrain(val);
+                    for (int i = 0; i < FB_K; i++) {
+                        float4 rec = make_float4(0.f, 0.f, 0.f, __int_as_float(-4));
+                        if (i < nv && !failsafe) {
+                            int idx = (int)((double)ph[i] * SC64);
+                            idx = (int)min((unsigned)idx, (unsigned)idx - (unsigned)SINCOS_N);
+                            idx = (unsigned)idx < (unsigned)SINCOS_N ? idx : 0;              // (a guess outside [0, 2 pi): the serial pass will not find its index here)
+                            const int im = idx == 0 ? SINCOS_N - 1 : idx - 1, ip = idx == SINCOS_N - 1 ? 0 : idx + 1;
+                            const float d5 = 5 * dem[i];
+                            rec = make_float4((d5 * sin_idx_f32(im)) * gain, (d5 * sin_idx_f32(idx)) * gain, (d5 * sin_idx_f32(ip)) * gain, __int_as_float(idx));
                         }
-                        if (it > 0) st->pll_replays += 1;        // (a Newton iteration that did not settle)
+                        spec4[j0 + i] = rec;
                     }
+                    if (tid == 0) spec_bad = failsafe ? 1 : 0;
+                    SB_FT(33);
                     __syncthreads();
+                    SB_FT(34);
+                    if (tid == 0 && !failsafe) {
+                        float x = x0;
+                        int bad = 0;
+                        auto one = [&](const float4 r, const bool valid) {
+                            const float xin = x;
+                            const int k = (int)((double)xin * SC64) - __float_as_int(r.w);
+                            const float c = k == 0 ? r.y : (k < 0 ? r.x : r.z);
+                            const float val = (xin + c) + omega;
+                            const float wrapped = wrap_ok ? (val - P32) + C32 : (float)((double)val - FMX_2PI);
+                            bad |= (valid && ((unsigned)(k + 1) > 2u || !(val >= 0.f && val < 2.f * P32))) ? 1 : 0;
+                            x = (val < P32) ? val : wrapped;
+                            return xin;
+                        };
+                        float4 r0 = spec4[0], r1 = spec4[1], r2 = spec4[2], r3 = spec4[3];
+                        for (int j = 0; j < w; j += 4) {
+                            const int jn = (j + 4 < FB_W) ? j + 4 : j;                        // (the next four records are requested before this block's store)
+                            const float4 n0 = spec4[jn], n1 = spec4[jn + 1], n2 = spec4[jn + 2], n3 = spec4[jn + 3];
+                            float4 o;
+                            o.x = one(r0, j < w); o.y = one(r1, j + 1 < w); o.z = one(r2, j + 2 < w); o.w = one(r3, j + 3 < w);
+                            *reinterpret_cast<float4 *>(&pout[j]) = o;
+                            r0 = n0; r1 = n1; r2 = n2; r3 = n3;
+                        }
+                        spec_bad = bad;
+                    }
+                    SB_FT(35);
+                    __syncthreads();
+                    if (spec_bad) {                              // (the same in every thread) the plain loop: every sample looks its table value up itself
+                        __syncthreads();
 #pragma unroll
-                    for (int i = 0; i < FB_K; i++) ph[i] = (i < nv) ? er[FB_W + j0 + i] : 0.f;
+                        for (int i = 0; i < FB_K; i++) if (i < nv) er[j0 + i] = dem[i];
+                        __syncthreads();
+                        if (tid == 0) {
+                            float phase = x0;
+                            for (int j = 0; j < w; j++) {
+                                const float d5 = 5 * er[j];
+                                pout[j] = phase;
+                                int idx = (int)((double)phase * SC64);
+                                idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+                                const float val = (phase + (d5 * sin_idx_f32(idx)) * gain) + omega;
+                                phase = (val >= 0.f && val < P32) ? val : pi_constrain(val);
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    if (tid == 0) {
+                        if (failsafe) st->pll_replays += 1;      // (a Newton iteration that did not settle)
+                        else if (guard_seg) st->pll_exact_segs += 1;
+                        if (B.dbg && spec_bad && !failsafe) B.dbg[(size_t)ch * DBG_SLOTS + 15] += 1;
+                    }
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) ph[i] = (i < nv) ? pout[j0 + i] : 0.f;
                     __syncthreads();
+                    SB_FT(36);
                 }
                 float nx[FB_K], val[FB_K];
                 if (__any(!all_in(ph, P32))) {
@@ -722,7 +799,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                         if (tid == 0) cy.old = old_next;             // (read again behind the next segment's barriers)
 #pragma unroll
                         for (int i = 0; i < FB_K; i++) if (i == il) nxl = nx[i];
-                        if (B.dbg && tid == 0 && !P.pll_seq) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; }
+                        if (B.dbg && tid == 0 && !seq) { B.dbg[(size_t)ch * DBG_SLOTS + 8] += it; B.dbg[(size_t)ch * DBG_SLOTS + 11] += 1; }
                         break;
                     }
                 }
@@ -741,7 +818,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                     for (int v = 0; v < 3; v++) pre += (v < wg.wv) ? lds.wd[wg.sl][v][0] : 0.0;
                     wg.sl ^= 1;
                 }
-                if (it == PLL_NEWTON_MAX - 1) { seq = true; continue; }       // not settled: sample by sample
+                if (it == PLL_NEWTON_MAX - 1) { seq = true; failsafe = true; continue; }       // not settled: sample by sample
                 // ---- the Newton correction
                 float d[FB_K], c[FB_K];
 #pragma unroll
@@ -787,6 +864,8 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 }
                 SB_FT(10);
                 open_ = !(dmax < PLL_NEWTON_TOL);
+                // a segment that is to be evaluated sample by sample takes the corrected guess as it is: the serial pass checks it
+                if (exact_pending) { seq = true; exact_pending = false; }
             }
             SB_FT(11);
             // (cur / osc are those of the last evaluation: of the trajectory the iteration ended on)
@@ -829,10 +908,12 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             const int locked0 = cy.locked, stable0 = cy.stable;
             float lock = wg.decay_incoming2(Lt, cy.lock, load_decay(&dtab, DEC_LOCK, lane), &lock_next);
             bool hi[FB_K]; int lastf = -1; float lock_end = 0.f, lock_x = 0.f;
+            float lock_min = 1.0f;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) {
                 lock = (float)((double)xq[i] + (double)lock * keep);
                 hi[i] = lock > 0.07f;
+                lock_min = (i < nv) ? fminf(lock_min, lock) : lock_min;
                 if (i < nv && !hi[i]) lastf = j0 + i;
                 if (i == il) lock_end = lock;
                 if (i == ix) lock_x = lock;
@@ -842,11 +923,14 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             // (a pilot in lock has no such sample: one flag per wave through the barrier instead of the maximum's scan, which follows
             // behind a second barrier where a sample did fall below)
             int preF = -1, totF = -1;
+            bool anynear;                                        // some sample's metric not above PLL_GUARD (NaN counts)
             {
-                const int wlow = __any(lastf >= 0) ? 1 : 0;
+                const int wlow = (__any(lastf >= 0) ? 1 : 0) | (__any(!(lock_min > PLL_GUARD)) ? 2 : 0);
                 if (lane == 0) lds.wi[wg.sl][wg.wv][2] = wlow;
                 __syncthreads();
-                const int anylow = lds.wi[wg.sl][0][2] | lds.wi[wg.sl][1][2] | lds.wi[wg.sl][2][2] | lds.wi[wg.sl][3][2];
+                const int anyw = lds.wi[wg.sl][0][2] | lds.wi[wg.sl][1][2] | lds.wi[wg.sl][2][2] | lds.wi[wg.sl][3][2];
+                const int anylow = anyw & 1;
+                anynear = (anyw & 2) != 0;
                 wg.sl ^= 1;
                 if (anylow) { int cnt_dummy, tot_dummy; wg.excl_add_max_i(0, lastf, &cnt_dummy, &tot_dummy, &preF, &totF); }
             }
@@ -868,8 +952,9 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             if (totF < 0) { nl = (locked0 != 0 || stable0 + w > (SINCOS_N >> 1)) ? 1 : 0;
                             ns = locked0 ? stable0 : (stable0 + w < (SINCOS_N >> 1) + 1 ? stable0 + w : (SINCOS_N >> 1) + 1); }
             else { nl = 0; ns = w - 1 - totF; }
-            if (lastseg && owner) { st->pil_lock = lock_end; st->pil_locked = nl; st->pil_stable = ns; }
-            if (tid == 0) { cy.locked = nl; cy.stable = ns; cy.lock = lock_next; }
+            const int nok = (nl && !anynear) ? 1 : 0;
+            if (lastseg && owner) { st->pil_lock = lock_end; st->pil_locked = nl; st->pil_stable = ns; st->pll_newton_ok = nok; }
+            if (tid == 0) { cy.locked = nl; cy.stable = ns; cy.lock = lock_next; cy.newton_ok = nok; }
         }
         SB_FT(15);
         {   // scope taps and the inputs of the RDS path: channel-major rows of this call

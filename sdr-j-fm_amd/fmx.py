@@ -16,12 +16,13 @@ LIB_PATH = os.environ.get("FMX_LIB") or os.path.join(HERE, "lib", "libfmx.so")  
 FMX_OK, FMX_E_INVALID, FMX_E_UNSUPPORTED, FMX_E_NO_DEVICE, FMX_E_HIP, FMX_E_NOMEM, FMX_E_TOO_LARGE = 0, -1, -2, -3, -4, -5, -6
 
 # parameter ids (include/fmx.h fmx_param_id)
+ABI_VERSION = 2               # FMX_ABI_VERSION of include/fmx.h this mirror follows
 P_FM_MODE, P_FM_DECODER, P_SOUND_MODE, P_STEREO_PANORAMA, P_SOUND_BALANCE, P_DEEMPHASIS = 1, 2, 3, 4, 5, 6
 P_VOLUME_DB, P_LF_CUTOFF, P_BANDWIDTH, P_ATTENUATION_L, P_ATTENUATION_R, P_RDS_MODE = 7, 8, 9, 10, 11, 12
 P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE, P_SQUELCH_VALUE = 13, 14, 15, 16, 17, 18, 19
 P_DISP_DELAY = 20
 P_STAGEB_FORM = 22            # handle-wide: 0 automatic, 1 stage B as one kernel per call, 2 as two (bit-identical results)
-P_PLL_SOLVER = 21             # 0 automatic, 1 sequential (the reference's trajectory bit for bit), 2 parallel (Newton)
+P_PLL_SOLVER = 21             # 0 automatic, 1 sequential (the reference's trajectory), 2 Newton while in lock + sequential around lock decisions, 3 Newton always
 A_TRIGGER_FREQUENCY_CHANGE, A_RESTART_PSS, A_RESET_RDS = 100, 101, 102
 
 TAP_FM_IQ, TAP_DEMOD, TAP_LR_RAW, TAP_PRE_RESAMPLER, TAP_RDS_IQ, TAP_PILOT_PHASE = 0, 1, 2, 3, 4, 5
@@ -31,7 +32,7 @@ EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
     "fmx_get_meta", "fmx_get_tap", "fmx_get_peaks",
-    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_last_rds_samples", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
+    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_pll_exact_segments", "fmx_last_rds_samples", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
 
@@ -93,6 +94,8 @@ def load_library(path=None):
     vp, i32, i64, f32p = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_float)
     L.fmx_abi_version.restype = C.c_int
     L.fmx_abi_version.argtypes = []
+    if L.fmx_abi_version() != ABI_VERSION:     # the output structs (FmxMeta, FmxRdsInfo) carry no size field: refuse a library of another layout
+        raise FmxError(FMX_E_INVALID, "%s has ABI version %d, this binding was written for %d" % (p, L.fmx_abi_version(), ABI_VERSION))
     L.fmx_last_error.restype = C.c_char_p
     L.fmx_last_error.argtypes = []
     L.fmx_create.restype = C.c_int
@@ -137,6 +140,8 @@ def load_library(path=None):
     L.fmx_last_fm_samples.argtypes = [vp]
     L.fmx_pll_replays.restype = C.c_int64
     L.fmx_pll_replays.argtypes = [vp, C.c_int32]
+    L.fmx_pll_exact_segments.restype = C.c_int64
+    L.fmx_pll_exact_segments.argtypes = [vp, C.c_int32]
     L.fmx_last_rds_samples.restype = C.c_int64
     L.fmx_last_rds_samples.argtypes = [vp]
     L.fmx_get_taps.restype = C.c_int
@@ -280,6 +285,13 @@ class Fmx:
     def pll_replays(self, channel=-1):
         """Segments of the pilot PLL that were replayed sequentially (fmx_pll_replays)."""
         n = int(self.L.fmx_pll_replays(self.h, channel))
+        if n < 0:
+            self._check(n)
+        return n
+
+    def pll_exact_segments(self, channel=-1):
+        """Segments FMX_P_PLL_SOLVER = 2 evaluated sequentially because the pilot was not comfortably in lock (fmx_pll_exact_segments)."""
+        n = int(self.L.fmx_pll_exact_segments(self.h, channel))
         if n < 0:
             self._check(n)
         return n

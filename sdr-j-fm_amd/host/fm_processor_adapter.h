@@ -57,6 +57,7 @@ public:
         c.struct_size = (int32_t)sizeof(c); c.device = device; c.channels = 1; c.streams = 0; c.stream_of_channel = nullptr;
         c.inputRate = inputRate; c.fmRate = fmRate; c.workingRate = workingRate; c.audioRate = audioRate;
         c.max_block = bufferSize;
+        if (fmx_abi_version() != FMX_ABI_VERSION) { err = "libfmx has another ABI version than this adapter was built for"; h = nullptr; return; }
         check(fmx_create(&c, &h));
         inBuf.resize(bufferSize);
         // one PCM frame per 4 fm samples; an input rate the reference does not decimate (192 kS/s devices) gives bufferSize fm samples per

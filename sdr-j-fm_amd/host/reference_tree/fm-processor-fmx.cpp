@@ -80,9 +80,16 @@ fmProcessor::fmProcessor(deviceHandler *theDevice, RadioInterface *RI, audioSink
     cfg.struct_size = (int32_t)sizeof cfg; cfg.device = 0; cfg.channels = 1;
     cfg.inputRate = inputRate_; cfg.fmRate = fmRate_; cfg.workingRate = workingRate_; cfg.audioRate = audioRate_;
     cfg.max_block = kBlock;
+    if (fmx_abi_version() != FMX_ABI_VERSION) qFatal("fmx: libfmx has ABI version %d, this binding was built for %d", fmx_abi_version(), FMX_ABI_VERSION);
     if (fmx_create(&cfg, &c->h) != FMX_OK) qFatal("fmx: %s", fmx_last_error());
     c->in.resize(kBlock); c->dumped.resize(kBlock);
-    c->pcm.resize((size_t)((int64_t)(kBlock / 48 + 64) * std::max(audioRate_, workingRate_) / workingRate_ + 8));
+    // PCM frames of one block: the reference decimates inputRate by 12, 6 or not at all (fm-processor.cpp:68-75,471), four fm samples make
+    // one 48 kHz frame, the second converter makes audioRate / workingRate of those -- a 192 kS/s device yields 4096 frames per block, not
+    // 341.  Sized from what the library itself says the largest call produces (fmx_frames_for follows rate and block phase), plus slack.
+    {
+        const int64_t per_block = std::max<int64_t>(fmx_frames_for(c->h, kBlock), 0);
+        c->pcm.resize((size_t)(per_block + (int64_t)(64 * std::max(audioRate_, workingRate_) / workingRate_) + 64));
+    }
     { std::lock_guard<std::mutex> lk(g_mtx); g_core[this] = c; }
 
     // by name, exactly the connections of fm-processor.cpp:179-192

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(fmx_amd):
     L = fmx_amd.load_library()
     for n in header_functions():
         assert hasattr(L, n), n
-    assert L.fmx_abi_version() == 1
+    assert L.fmx_abi_version() == 2
 
 
 def test_no_oracle_dependency_in_product():

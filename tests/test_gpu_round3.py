@@ -1,7 +1,7 @@
 """Round-3 GPU tests: stage B as one kernel per call (fmx_stageb.hip) where its iterations can fail -- noise-only input, low CNR,
 no pilot, a pilot that flaps across the lock threshold, a DC offset that crosses the RF limiter inside a call -- with both
-solvers of the pilot PLL (FMX_P_PLL_SOLVER: 1 = sample by sample, 2 = Newton's method on the segment), against the oracle
-through the C ABI.  The bar everywhere: PCM <= 1e-5 RMS, lock / PSS flags equal call by call, the fallback counter reported."""
+solvers of the pilot PLL (FMX_P_PLL_SOLVER: 1 = sample by sample, 2 = what large batches run: Newton's method on the segment while
+the pilot is comfortably in lock, sample by sample around every lock decision), against the oracle through the C ABI.  The bar everywhere: PCM <= 1e-5 RMS, lock / PSS flags equal call by call, the fallback counter reported."""
 import numpy as np
 import pytest
 
@@ -129,33 +129,71 @@ def test_pilot_flapping_across_the_lock_threshold(fmx_amd, ol, solver):
         res[auto_mono] = e
 
 
-@pytest.mark.parametrize("solver", [1, 2])
+def creeping_pilot_iq(n, phase=-0.5, period=1.6, rate=2304000):
+    t = np.arange(n) / rate
+    pil = 0.036 + 0.024 * np.sin(2 * np.pi * t / period + phase)
+    lft, rgt = 0.5 * np.sin(2 * np.pi * 1000 * t), 0.5 * np.sin(2 * np.pi * 400 * t)
+    p19 = 2 * np.pi * 19000 * t
+    return fm_modulate(0.45 * (lft + rgt) + pil * np.sin(p19) + 0.45 * (lft - rgt) * np.sin(2 * p19))
+
+
+@pytest.mark.parametrize("solver", [1, 2, 3])
 def test_pilot_creeping_through_the_lock_threshold(fmx_amd, ol, solver):
     """The pilot level moves sinusoidally between 1.2 % and 6 % with a 1.6 s period, so the lock metric creeps through its threshold
     at ~1e-6 per sample and the sample at which it crosses depends on the seventh digit of the metric.  The decision itself is the
-    reference's (pilot-recover.cpp:62-80); with the sequential PLL the library takes it at the reference's sample.  With Newton's
-    method the NCO sine differs by ~1e-5, the crossing may land a few samples apart, and 0.5 s later (the persistence counter) the
-    stereo decoder switches on those few samples apart: a click of a few frames in the call that contains it (measured: one call
-    at 3e-4 RMS, 1.6e-2 peak in L-R, everything else below 1e-6).  Stated with its own bound: at most one such call per lock
-    acquisition, none above 1e-3."""
-    rate = 2304000
+    reference's (pilot-recover.cpp:62-80); on the sequential trajectory the library takes it at the reference's sample (metric 2e-7
+    from the oracle's).  Newton's method on a segment leaves the NCO phase ~2e-5 rad from the reference's and the metric 1.5e-6: the
+    crossing then lands a pilot period later, and 0.5 s later (the persistence counter) the stereo decoder switches on ten samples late
+    -- a click in one call (3e-4 RMS, 1.6e-2 peak in L-R).  Solver 2, what every large batch runs, therefore evaluates the segments
+    around a lock decision sequentially (fmx_stageb.hip PLL_GUARD): no call above the tolerance.  Solver 3 (Newton
+    always, a diagnostic) keeps the old bound: at most one such call per lock acquisition, none above 1e-3."""
     blocks = BLOCKS * 8
-    n = sum(blocks)
-    t = np.arange(n) / rate
-    pil = 0.036 + 0.024 * np.sin(2 * np.pi * t / 1.6 - 0.5)
-    lft, rgt = 0.5 * np.sin(2 * np.pi * 1000 * t), 0.5 * np.sin(2 * np.pi * 400 * t)
-    p19 = 2 * np.pi * 19000 * t
-    iq = fm_modulate(0.45 * (lft + rgt) + pil * np.sin(p19) + 0.45 * (lft - rgt) * np.sin(2 * p19))
+    iq = creeping_pilot_iq(sum(blocks))
     pg, po, fg, fo, f = run_against_oracle(fmx_amd, ol, iq, blocks, solver)
     locks = f.live_locks
     ups = sum(1 for a, b in zip(locks, locks[1:]) if b > a)
     over = [v for v in f.per_call_rms if v > PCM_RMS_TOL]
-    print(f"\n[creeping pilot, solver {solver}] PCM rms diff {rms(pg - po):.3e}, lock acquired {ups} times, calls above 1e-5: {['%.1e' % v for v in over]}")
+    print(f"\n[creeping pilot, solver {solver}] PCM rms diff {rms(pg - po):.3e}, lock acquired {ups} times, calls above 1e-5: {['%.1e' % v for v in over]}, "
+          f"segments evaluated sequentially by the guard: {f.pll_exact_segments()} of {sum(-(-(b // 12) // 1536) for b in blocks)}")
     assert fg == fo and ups >= 2
-    if solver == 1:
+    if solver != 3:
         assert not over
     else:
         assert len(over) <= ups and all(v <= 1e-3 for v in over)
+    assert (f.pll_exact_segments() > 0) == (solver == 2)
+
+
+def test_creeping_pilots_at_batch_scale(fmx_amd, ol):
+    """the creeping-pilot case on the DEFAULT path of a large batch -- 4096 channels, four streams whose pilot levels
+    creep through the threshold at different times (channel c listens to stream c % 4), the handle's automatic solver (above 64
+    channels: Newton's method while in lock, sequential around the lock decisions).  Channels 0 .. 3 against their oracle chains call by
+    call (no call above 1e-5, flags equal), every other channel bit-identical to channel c % 4."""
+    nch, nst = 4096, 4
+    blocks = BLOCKS * 8
+    n = sum(blocks)
+    iqs = np.stack([creeping_pilot_iq(n, phase=-0.5 + 0.9 * k, period=1.6 - 0.13 * k) for k in range(nst)])
+    f = fmx_amd.Fmx(nch, streams=nst, stream_of_channel=[c % nst for c in range(nch)], max_block=max(blocks))
+    gui_defaults(f)
+    chains = [ol.OracleChain(inputFilterBw=165000) for _ in range(nst)]
+    worst, ups, pos, prev = [0.0] * nst, [0] * nst, 0, [0] * nst
+    for b in blocks:
+        x = iqs[:, pos:pos + b]; pos += b
+        pg = f.process_host(x)
+        for k in range(nst):
+            po = chains[k].process(x[k])
+            assert pg[k].shape == po.shape
+            worst[k] = max(worst[k], rms(pg[k] - po))
+            a, m = f.meta(k), chains[k].meta()
+            assert (a.PilotPllLocked, a.PssState) == (m.pilotLocked, m.pssState)
+            ups[k] += 1 if a.live_pilot_locked > prev[k] else 0
+            prev[k] = a.live_pilot_locked
+        ref4 = pg[:nst]
+        assert np.array_equal(pg.reshape(nch // nst, nst, -1, 2), np.broadcast_to(ref4, (nch // nst,) + ref4.shape))
+    ex = f.pll_exact_segments()
+    print(f"\n[creeping pilots, {nch} channels] worst call per stream: {' '.join('%.1e' % v for v in worst)}; lock acquisitions {ups}; "
+          f"guard: {ex / nch:.0f} of {sum(-(-(b // 12) // 1536) for b in blocks)} segments per channel sequential; fail-safe replays {f.pll_replays()}")
+    assert max(worst) <= PCM_RMS_TOL and sum(ups) >= 4
+    assert f.pll_replays() == 0 and 0 < ex < nch * sum(-(-(b // 12) // 1536) for b in blocks)
 
 
 @pytest.mark.parametrize("solver", [1, 2])

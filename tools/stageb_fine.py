@@ -31,14 +31,16 @@ names = {0: "top", 1: "wait zn", 2: "limiter", 3: "atan arm", 4: "atan gather(W)
          9: "pll f64 scan", 10: "pll newton", 11: "pll (loop exit)", 12: "pll osc handoff", 13: "lock local", 14: "lock scan+run", 15: "lock flags scan",
          16: "taps store", 17: "sring addr+issue", 18: "sring wait(W)", 19: "fft convolve", 20: "er write+barrier", 21: "tags", 22: "integr scan",
          23: "mean scan", 24: "integr rounds", 25: "mean run", 26: "pss tail", 27: "mix sincos", 28: "matrix", 29: "fetch issue", 30: "deemph local",
-         31: "deemph scan", 32: "deemph store"}
+         31: "deemph scan", 32: "deemph store", 33: "seq candidates", 34: "seq barrier", 35: "seq serial pass", 36: "seq fallback + read"}
+if os.environ.get("PLL_SOLVER"):
+    f.set_param(m.P_PLL_SOLVER, int(os.environ["PLL_SOLVER"]))
 for k in range(calls):
     if k == calls - 8:
         L.fmx_debug_phase_cycles(f.h, 1, None)
     f.process_device(iq.data_ptr(), n, n, pcm.data_ptr(), pcm.shape[1], hip_stream=st.cuda_stream)
 L.fmx_debug_phase_cycles(f.h, 1, out)
 v = list(out)
-segs = max(v[11], 1)
+segs = max((calls - (calls - 8)) * -(-(n // 12) // 1536) * ch, 1)
 tot = sum(v[32:96])
 print("channels %d: %d segments, %.0f cycles per segment (thread 0)" % (ch, segs, tot / segs))
 for i in range(64):
