@@ -367,10 +367,11 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     int *pk = reinterpret_cast<int *>(big) + FB_W;                   // [FB_W] replay path: ((tag + 2) << 1) | locked per sample
     static_assert(2 * FB_W <= XF, "er and pk live in the convolution buffer");
     float *const park_dem = big + XF, *const park_cur = big + XF + FB_W;
-    float4 *const spec4 = reinterpret_cast<float4 *>(big);           // [FB_W] {c(idx - 1), c(idx), c(idx + 1), idx} of the guess, see the pilot PLL
-    float *const pout = big + 4 * FB_W;                              // [FB_W] the phases the sample-by-sample pass found
-    static_assert(5 * FB_W <= XF + 2 * FB_W && (XF % 4) == 0, "candidate records and phases fit the block");
-    __shared__ int spec_bad;
+    // the sample-by-sample pass of the pilot PLL: five rows of FB_W floats -- the corrections for the two table entries next to the guess, the
+    // phase at which the entry changes, and the two addends of the wrap; the phases the pass finds replace the first row
+    float *const sq_lo = big, *const sq_hi = big + FB_W, *const sq_b = big + 2 * FB_W, *const sq_wa = big + 3 * FB_W, *const sq_wb = big + 4 * FB_W;
+    float *const pout = sq_lo;
+    static_assert(5 * FB_W <= XF + 2 * FB_W && (FB_W % 4) == 0, "the rows fit the block");
     __shared__ __attribute__((aligned(16))) DecayTab<(PART == 0 ? 4 : 2)> dtab;
     const int ch = blockIdx.x;
     if (ch >= C) return;
@@ -627,6 +628,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             const bool guard_seg = pll_mode == 0 && exact_pending;
             bool seq = false;                                    // this pass evaluates the loop sample by sample (the same in every thread)
             bool failsafe = false;                               // ... because Newton's iteration did not settle
+            bool force_plain = false;                            // ... again, without the predictions of the first pass, which did not hold
             auto eval = [&](int i, float phase, float *nx_out, float *val_out) {
                 int idx = (int)((double)phase * SC64);           // SinCos::getSin sincos.cpp:81-85 for phase >= 0: entry (int)(phase * C) % Rate
                 idx = (int)min((unsigned)idx, (unsigned)idx - (unsigned)SINCOS_N);       // (0 <= idx < 2 N: the wrap as an unsigned minimum)
@@ -689,83 +691,95 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             bool open_ = true;                                   // this thread's last update was not small yet
             const double x0d = (double)x0;
             for (int it = 0; ; it++) {
+                float ph_next = 0.f;                             // (sample-by-sample pass) the phase behind this thread's last sample
                 if (seq) {
-                    // The loop sample by sample: one thread, operands through LDS (the block is free here).  What makes the reference's step
-                    // slow as a dependent chain is its table look-up; the recurrence itself is two additions and the wrap.  The guess at hand
-                    // (Newton's, good to a few 1e-6 rad; a table step is 3.3e-5) tells which entry each sample will read, give or take one: all
-                    // threads tabulate the correction 5 demod sin (.) gain for the guess's entry and its two neighbours (the f32 expressions of
-                    // the step, the same table values the final evaluation uses), and the serial pass only computes the index of ITS phase,
-                    // picks one of the three, adds and wraps.  A sample whose index is not one of the three (or a step result outside
-                    // [0, 4 pi)) sends the segment through the plain loop below: the result is the sequential f32 trajectory either way.
+                    // The loop sample by sample: one thread, operands through LDS (the block is free here).  A lone wave issues an instruction
+                    // -- of any kind -- every 4 to 5 cycles at best, and the reference's step with its table look-up is ~25 of them plus
+                    // branches: 220-240 cycles per sample measured.  But the guess at hand (Newton's, good to a few 1e-6 rad; a table step is
+                    // 3.3e-5) already tells which table entry each sample will read, give or take one, and whether its step will wrap.  So all
+                    // threads tabulate, per sample: the correction 5 demod sin (.) gain for the two entries next to the guess (the f32
+                    // expressions of the step, the same table values the final evaluation uses), the phase at which the entry changes, and the
+                    // two addends of the wrap (0, 0 or -P32, C32).  The serial pass is then compare, select and four additions per sample --
+                    // x' = (((x + c) + omega) + A) + B is the reference's  t = phase + corr; val = t + omega; PI_Constrain (val)  where the
+                    // prediction holds.  Whether it held is checked by the evaluation that follows anyway: the exact step of every phase found
+                    // must be the next phase found, bit for bit (a trajectory with that property that starts at x0 IS the sequential one); a
+                    // segment that fails the check -- or whose Newton iteration failed -- takes the plain loop below.
                     __syncthreads();
+                    const bool plain = failsafe || force_plain || !wrap_ok;
+                    if (!plain) {
+                        constexpr double INVC = FMX_2PI / SINCOS_N;
 #pragma unroll
-                    for (int i = 0; i < FB_K; i++) {
-                        float4 rec = make_float4(0.f, 0.f, 0.f, __int_as_float(-4));
-                        if (i < nv && !failsafe) {
-                            int idx = (int)((double)ph[i] * SC64);
-                            idx = (int)min((unsigned)idx, (unsigned)idx - (unsigned)SINCOS_N);
-                            idx = (unsigned)idx < (unsigned)SINCOS_N ? idx : 0;              // (a guess outside [0, 2 pi): the serial pass will not find its index here)
-                            const int im = idx == 0 ? SINCOS_N - 1 : idx - 1, ip = idx == SINCOS_N - 1 ? 0 : idx + 1;
-                            const float d5 = 5 * dem[i];
-                            rec = make_float4((d5 * sin_idx_f32(im)) * gain, (d5 * sin_idx_f32(idx)) * gain, (d5 * sin_idx_f32(ip)) * gain, __int_as_float(idx));
+                        for (int i = 0; i < FB_K; i++) {
+                            float clo = 0.f, chi = 0.f, bb = 0.f, wa = 0.f, wb = 0.f;
+                            if (i < nv) {
+                                int idx = (int)((double)ph[i] * SC64);
+                                idx = (int)min((unsigned)idx, (unsigned)idx - (unsigned)SINCOS_N);
+                                idx = (unsigned)idx < (unsigned)SINCOS_N ? idx : 0;              // (a guess outside [0, 2 pi): the check will see what comes of it)
+                                // the two entries: the guess's own and the one on the side of the cell the guess sits in
+                                const bool lower = (double)ph[i] < ((double)idx + 0.5) * INVC;
+                                int klo = lower ? idx - 1 : idx;
+                                klo = klo < 0 ? 0 : (klo > SINCOS_N - 2 ? SINCOS_N - 2 : klo);
+                                const float d5 = 5 * dem[i];
+                                clo = (d5 * sin_idx_f32(klo)) * gain; chi = (d5 * sin_idx_f32(klo + 1)) * gain;
+                                // the smallest f32 phase whose index (int) ((double) phase * C) reaches klo + 1: the f32 nearest (klo + 1) / C, or the one above it
+                                const float bh = (float)((double)(klo + 1) * INVC);
+                                bb = ((int)((double)bh * SC64) >= klo + 1) ? bh : __int_as_float(__float_as_int(bh) + 1);
+                                const float vg = (ph[i] + (idx == klo ? clo : chi)) + omega;
+                                const bool wr = !(vg < P32);
+                                wa = wr ? -P32 : 0.f; wb = wr ? C32 : 0.f;
+                            }
+                            sq_lo[j0 + i] = clo; sq_hi[j0 + i] = chi; sq_b[j0 + i] = bb; sq_wa[j0 + i] = wa; sq_wb[j0 + i] = wb;
                         }
-                        spec4[j0 + i] = rec;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < FB_K; i++) if (i < nv) sq_hi[j0 + i] = dem[i];
                     }
-                    if (tid == 0) spec_bad = failsafe ? 1 : 0;
                     SB_FT(33);
                     __syncthreads();
                     SB_FT(34);
-                    if (tid == 0 && !failsafe) {
+                    if (tid == 0 && !plain) {
                         float x = x0;
-                        int bad = 0;
-                        auto one = [&](const float4 r, const bool valid) {
+                        auto one = [&](float clo, float chi, float bb, float wa, float wb) {
                             const float xin = x;
-                            const int k = (int)((double)xin * SC64) - __float_as_int(r.w);
-                            const float c = k == 0 ? r.y : (k < 0 ? r.x : r.z);
-                            const float val = (xin + c) + omega;
-                            const float wrapped = wrap_ok ? (val - P32) + C32 : (float)((double)val - FMX_2PI);
-                            bad |= (valid && ((unsigned)(k + 1) > 2u || !(val >= 0.f && val < 2.f * P32))) ? 1 : 0;
-                            x = (val < P32) ? val : wrapped;
+                            const float c = (xin < bb) ? clo : chi;
+                            x = (((xin + c) + omega) + wa) + wb;
                             return xin;
                         };
-                        float4 r0 = spec4[0], r1 = spec4[1], r2 = spec4[2], r3 = spec4[3];
-                        for (int j = 0; j < w; j += 4) {
-                            const int jn = (j + 4 < FB_W) ? j + 4 : j;                        // (the next four records are requested before this block's store)
-                            const float4 n0 = spec4[jn], n1 = spec4[jn + 1], n2 = spec4[jn + 2], n3 = spec4[jn + 3];
+                        const float4 *qlo = reinterpret_cast<const float4 *>(sq_lo), *qhi = reinterpret_cast<const float4 *>(sq_hi), *qb = reinterpret_cast<const float4 *>(sq_b),
+                                     *qwa = reinterpret_cast<const float4 *>(sq_wa), *qwb = reinterpret_cast<const float4 *>(sq_wb);
+                        float4 r0 = qlo[0], r1 = qhi[0], r2 = qb[0], r3 = qwa[0], r4 = qwb[0];
+                        const int nq = (w + 3) >> 2;
+                        for (int q = 0; q < nq; q++) {
+                            const int qn = (q + 1 < FB_W / 4) ? q + 1 : q;                    // (the next four are requested before these four are stored)
+                            const float4 n0 = qlo[qn], n1 = qhi[qn], n2 = qb[qn], n3 = qwa[qn], n4 = qwb[qn];
                             float4 o;
-                            o.x = one(r0, j < w); o.y = one(r1, j + 1 < w); o.z = one(r2, j + 2 < w); o.w = one(r3, j + 3 < w);
-                            *reinterpret_cast<float4 *>(&pout[j]) = o;
-                            r0 = n0; r1 = n1; r2 = n2; r3 = n3;
+                            o.x = one(r0.x, r1.x, r2.x, r3.x, r4.x); o.y = one(r0.y, r1.y, r2.y, r3.y, r4.y);
+                            o.z = one(r0.z, r1.z, r2.z, r3.z, r4.z); o.w = one(r0.w, r1.w, r2.w, r3.w, r4.w);
+                            reinterpret_cast<float4 *>(pout)[q] = o;
+                            r0 = n0; r1 = n1; r2 = n2; r3 = n3; r4 = n4;
                         }
-                        spec_bad = bad;
                     }
-                    SB_FT(35);
-                    __syncthreads();
-                    if (spec_bad) {                              // (the same in every thread) the plain loop: every sample looks its table value up itself
-                        __syncthreads();
-#pragma unroll
-                        for (int i = 0; i < FB_K; i++) if (i < nv) er[j0 + i] = dem[i];
-                        __syncthreads();
-                        if (tid == 0) {
-                            float phase = x0;
-                            for (int j = 0; j < w; j++) {
-                                const float d5 = 5 * er[j];
-                                pout[j] = phase;
-                                int idx = (int)((double)phase * SC64);
-                                idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
-                                const float val = (phase + (d5 * sin_idx_f32(idx)) * gain) + omega;
-                                phase = (val >= 0.f && val < P32) ? val : pi_constrain(val);
-                            }
+                    if (tid == 0 && plain) {                     // the plain loop: every sample looks its table value up itself
+                        float phase = x0;
+                        for (int j = 0; j < w; j++) {
+                            const float d5 = 5 * sq_hi[j];
+                            pout[j] = phase;
+                            int idx = (int)((double)phase * SC64);
+                            idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+                            const float val = (phase + (d5 * sin_idx_f32(idx)) * gain) + omega;
+                            phase = (val >= 0.f && val < P32) ? val : pi_constrain(val);
                         }
-                        __syncthreads();
                     }
                     if (tid == 0) {
                         if (failsafe) st->pll_replays += 1;      // (a Newton iteration that did not settle)
-                        else if (guard_seg) st->pll_exact_segs += 1;
-                        if (B.dbg && spec_bad && !failsafe) B.dbg[(size_t)ch * DBG_SLOTS + 15] += 1;
+                        else if (guard_seg && !force_plain) st->pll_exact_segs += 1;
+                        if (B.dbg && force_plain) B.dbg[(size_t)ch * DBG_SLOTS + 15] += 1;
                     }
+                    SB_FT(35);
+                    __syncthreads();
 #pragma unroll
                     for (int i = 0; i < FB_K; i++) ph[i] = (i < nv) ? pout[j0 + i] : 0.f;
+                    ph_next = (j0 + FB_K < w) ? pout[j0 + FB_K] : 0.f;
                     __syncthreads();
                     SB_FT(36);
                 }
@@ -785,7 +799,15 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                     // This evaluation is the final one unless the update in front of it was not small somewhere: that flag rides on the
                     // barrier of the NCO-sine hand-off the lock detector needs anyway (the sine in front of each thread's first sample;
                     // the last one behind a full segment is the next segment's `old`).
-                    const int wopen = (!seq && __any(open_)) ? 1 : 0;
+                    int wopen = (!seq && __any(open_)) ? 1 : 0;
+                    if (seq && !failsafe && !force_plain) {
+                        // the pass that relied on predictions: every phase's exact step must be the next phase
+                        bool defect = false;
+#pragma unroll
+                        for (int i = 0; i < FB_K; i++)
+                            defect = defect || (j0 + i + 1 < w && __float_as_int(nx[i]) != __float_as_int(i + 1 < FB_K ? ph[i + 1 < FB_K ? i + 1 : i] : ph_next));
+                        wopen |= __any(defect) ? 2 : 0;
+                    }
                     if (lane == 63) lds.wf[wg.sl][wg.wv][1] = osc[FB_K - 1];
                     if (lane == 0) lds.wi[wg.sl][wg.wv][1] = wopen;
                     const float cold = cy.old;
@@ -793,6 +815,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                     const int anyopen = lds.wi[wg.sl][0][1] | lds.wi[wg.sl][1][1] | lds.wi[wg.sl][2][1] | lds.wi[wg.sl][3][1];
                     const float from_prev_wave = lds.wf[wg.sl][(wg.wv + 3) & 3][1], old_next = lds.wf[wg.sl][3][1];
                     wg.sl ^= 1;
+                    if (anyopen & 2) { force_plain = true; continue; }
                     if (!anyopen) {
                         osc_in = dppf<0x138, 0xf>(0.f, osc[FB_K - 1]);
                         if (lane == 0) osc_in = wg.wv ? from_prev_wave : cold;
