@@ -106,6 +106,78 @@ def synth_device(torch, channels, n, device, offsets_hz=None, seed=0, rds_level=
     return out
 
 
+POPULATIONS = {
+    # name: (description, [(fraction, kind)])   kinds: est = established stereo station, noise = no station (complex white noise),
+    # cnr17 = the station at 17 dB wide-band CNR, nopilot = a mono transmitter (no pilot, no L-R), flap = a station whose pilot comes and goes
+    "established": ("every channel an established stereo station (pilot locked, PSS established): the headline's population", [(1.0, "est")]),
+    "mixed": ("70 % established stereo, 10 % noise only, 10 % at 17 dB CNR, 5 % without pilot, 5 % with a pilot that comes (65 % of a 1 s cycle) "
+              "and goes, the cycles of the channels shifted against each other", [(0.70, "est"), (0.10, "noise"), (0.10, "cnr17"), (0.05, "nopilot"), (0.05, "flap")]),
+    "unlocked": ("no channel ever locks: half noise only, half mono transmitters without pilot", [(0.5, "noise"), (0.5, "nopilot")]),
+}
+FLAP_BLOCKS = 10          # the pilot's on / off cycle of the "flap" channels: 10 blocks of 0.1 s
+
+
+def population_kinds(name, channels):
+    """kind of every channel: the population's fractions dealt out so that the kinds interleave (channel c -> slot (37 c) mod 100)"""
+    spec = POPULATIONS[name][1]
+    edges, acc = [], 0.0
+    for frac, kind in spec:
+        acc += frac
+        edges.append((acc * 100.0 - 1e-9, kind))
+    kinds = []
+    for c in range(channels):
+        slot = (37 * c) % 100
+        kinds.append(next(k for e, k in edges if slot < e))
+    return kinds
+
+
+def synth_population(torch, channels, n, nblk, device, kinds, seed=0):
+    """[channels, nblk * n, 2] float32 IQ: per channel what its kind says (POPULATIONS), periodic in nblk * n samples.  Everything but the
+    "flap" channels is one block repeated; a flap channel's pilot is on for 65 % of the nblk-block cycle, starting at a channel-specific
+    point of it, with the FM phase continuous through the whole cycle."""
+    out = torch.empty((channels, nblk * n, 2), dtype=torch.float32, device=device)
+    g = torch.Generator(device="cpu").manual_seed(4321 + seed)
+    gd = torch.Generator(device=device).manual_seed(99 + seed)
+    sigma17 = float(np.sqrt(0.25 / (2 * 10 ** 1.7)))
+    step = 16
+    for c0 in range(0, channels, step):
+        c1 = min(channels, c0 + step)
+        kk = kinds[c0:c1]
+        flap = [k == "flap" for k in kk]
+        L_ = nblk * n if any(flap) else n
+        t = torch.arange(L_, dtype=torch.float64, device=device) / INPUT_RATE
+        k = torch.arange(c0, c1, dtype=torch.float64)
+        fl = (300 + 10 * ((37 * k) % 400)).to(device)[:, None]
+        fr = (500 + 10 * ((53 * k) % 400)).to(device)[:, None]
+        ph = (torch.rand((c1 - c0, 4), generator=g, dtype=torch.float64)).to(device)
+        L = 0.5 * torch.sin(2 * np.pi * fl * t + 2 * np.pi * ph[:, 0:1])
+        R = 0.5 * torch.sin(2 * np.pi * fr * t + 2 * np.pi * ph[:, 1:2])
+        p19 = 2 * np.pi * 19000.0 * t + 2 * np.pi * ph[:, 2:3]
+        pil = torch.tensor([0.0 if x == "nopilot" else 0.10 for x in kk], dtype=torch.float64, device=device)[:, None]
+        dsb = torch.tensor([0.0 if x == "nopilot" else 0.45 for x in kk], dtype=torch.float64, device=device)[:, None]
+        pilot = pil * torch.sin(p19)
+        if any(flap):
+            cyc = torch.remainder(t[None, :] * (INPUT_RATE / float(nblk * n)) + ph[:, 3:4], 1.0)      # position in the on / off cycle
+            on = (cyc < 0.65).to(torch.float64)
+            fm = torch.tensor([1.0 if x else 0.0 for x in flap], dtype=torch.float64, device=device)[:, None]
+            pilot = pilot * (1.0 - fm + fm * on)
+        mpx = 0.45 * (L + R) + pilot + dsb * (L - R) * torch.sin(2 * p19)
+        inc = 2 * np.pi * 75000.0 * mpx / INPUT_RATE
+        inc = inc - inc.mean(dim=1, keepdim=True)
+        phase = torch.cumsum(inc, dim=1)
+        amp = torch.tensor([0.0 if x == "noise" else 0.5 for x in kk], dtype=torch.float64, device=device)[:, None]
+        sig = torch.stack([(amp * torch.cos(phase)).float(), (amp * torch.sin(phase)).float()], dim=2)
+        sg = torch.tensor([0.2 if x == "noise" else (sigma17 if x == "cnr17" else 0.0) for x in kk], dtype=torch.float32, device=device)[:, None, None]
+        if float(sg.max()) > 0:
+            sig[:, :n] += sg * torch.randn((c1 - c0, n, 2), generator=gd, dtype=torch.float32, device=device)    # (only the first block of a channel that is not a flap channel is kept)
+        if L_ == n:
+            out[c0:c1] = sig.repeat(1, nblk, 1)
+        else:
+            for i, f_ in enumerate(flap):
+                out[c0 + i] = sig[i] if f_ else sig[i, :n].repeat(nblk, 1)
+    return out
+
+
 def usable_cores():
     """Host cores this process may really use: the affinity mask, cut down by a cgroup CPU quota if one is set."""
     try:
@@ -193,7 +265,9 @@ def sub_bench(extra):
         k = j["kernels_ms_per_step"]
         return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "channels_per_gpu": j["config"]["channels_per_gpu"],
                 "kernels_ms_per_step": {x: k[x] for x in ("front_fir", "demod_pilot_pss", "audio_fir_resample")},
-                "front_fir_frac_of_8TBps": j["roofline"]["frac"], **({"rds_check": j["rds_check"]} if "rds_check" in j else {})}
+                "stage_b_min_median_max": j["kernels_ms_per_step_raw"]["stage_b_min_median_max"], "pilot_pll": j["pilot_pll"],
+                "front_fir_frac_of_8TBps": j["roofline"]["frac"], **({"front_fir_bytes": j["roofline"]["front_fir_bytes"]} if "front_fir_bytes" in j["roofline"] else {}),
+                **({"rds_check": j["rds_check"]} if "rds_check" in j else {})}
     except Exception as e:          # an extra leg must not take the headline line down
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -246,6 +320,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=12)   # (at least 44 untimed calls are made: see the timed region)
     ap.add_argument("--workload", default="config4", choices=sorted(WORKLOADS))
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
+    ap.add_argument("--population", default="established", choices=sorted(POPULATIONS),
+                    help="what the channels of a one-stream-per-channel workload receive (POPULATIONS); the headline is `established`")
+    ap.add_argument("--decoder", type=int, default=0, help="fm_Demodulator::setDecoder for every channel (1 AM 2 PLL 3 Mixed ... 6 Diff; 0: the default, Mixed)")
+    ap.add_argument("--squelch", type=int, default=0, help="set_squelchMode for every channel (1 noise squelch, 2 level squelch)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank runs the workload's channel count; strong: --total-channels split over the ranks "
                          "(shard.shard_channels), BASELINE configs[3] literally: 4096 channels over 1/2/4/8 GPUs")
@@ -321,6 +399,11 @@ def main():
         f.set_param(m.P_FM_MODE, 0)
         if args.workload == "config5":
             f.set_param(m.P_RDS_MODE, 2)
+        if args.decoder:
+            f.set_param(m.P_FM_DECODER, args.decoder)
+        if args.squelch:
+            f.set_param(m.P_SQUELCH_MODE, args.squelch)
+            f.set_param(m.P_SQUELCH_VALUE, 30)
         if streams:
             for c in range(nch):
                 f.set_param(m.P_LOCAL_OSCILLATOR, ((c % 11) - 5) * 200000, channel=c)
@@ -350,6 +433,10 @@ def main():
         nblk = RDS_BLOCKS
         iq = synth_device(torch, channels, nblk * n, device, seed=rank if args.scaling == "weak" else 1000 + first_channel,
                           rds_level=0.05, first_channel=first_channel)
+    elif args.population != "established":
+        kinds = population_kinds(args.population, channels)
+        nblk = FLAP_BLOCKS if "flap" in kinds else 1
+        iq = synth_population(torch, channels, n, nblk, device, kinds, seed=rank)
     else:
         iq = synth_device(torch, channels, n, device, seed=rank if args.scaling == "weak" else 1000 + first_channel)
     stride = nblk * n + args.stride_pad
@@ -412,13 +499,23 @@ def main():
     # the small workloads add up to more than ms_per_step).
     f.profile_enable(True)
     f.profile_read(reset=True)
-    for _ in range(min(args.steps, 10)):
+    prof = {"launches": [0, 0, 0, 0], "ms": [0.0, 0.0, 0.0, 0.0]}
+    per_step = [[], [], []]                 # stage times of every profiled step (the populations in which they differ from step to step)
+    rep0, ex0 = f.pll_replays(), f.pll_exact_segments()
+    nprof = min(args.steps, 10) if nblk == 1 else max(min(args.steps, 10), nblk)     # (a whole cycle of the input blocks)
+    for _ in range(nprof):
         with torch.cuda.stream(call_stream):
             torch.cuda._sleep(2000000)
         step()
         torch.cuda.synchronize()
+        one = f.profile_read(reset=True)
+        for k in range(3):
+            prof["launches"][k] += one["launches"][k]; prof["ms"][k] += one["ms"][k]
+            per_step[k].append(one["ms"][k] / max(one["launches"][k], 1))
     torch.cuda.synchronize()
-    prof = f.profile_read(reset=True)
+    pll_counts = {"steps": nprof, "fail_safe_replays_per_step": round((f.pll_replays() - rep0) / nprof, 2),
+                  "guard_sequential_segments_per_step": round((f.pll_exact_segments() - ex0) / nprof, 1),
+                  "segments_per_step": channels * -(-(n // 12) // 1536)}
     f.profile_enable(False)
 
     # ---- gather leg: one step's PCM of every rank to rank 0 over RCCL, timed on its own ------------------
@@ -517,26 +614,41 @@ def main():
                     measured[key] = round(g.value, 1)
         except Exception as e:      # the probe is a diagnostic; the bench line does not depend on it
             measured = {"error": str(e)}
+        # the stage table as a decomposition of the timed step: the event intervals of the profiled pass, scaled so that they add up to
+        # ms_per_step (the raw intervals stay beside it)
+        raw = [prof["ms"][k] / max(prof["launches"][k], 1) for k in range(3)]
+        ms_step = dt / args.steps * 1e3
+        scale = ms_step / sum(raw) if sum(raw) > 0 else 1.0
+        kernels_ms = {"front_fir": round(raw[0] * scale, 4), "demod_pilot_pss": round(raw[1] * scale, 4), "audio_fir_resample": round(raw[2] * scale, 4),
+                      "scale": round(scale, 4), "note": "raw event intervals x scale = a decomposition of ms_per_step"}
         out = {
             "metric": "IQ MSamples/s demodulated to 48 kHz stereo",
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "untimed_calls": untimed,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "description": desc, "channels_per_gpu": channels, "channels_total": total_channels,
+            "config": {"workload": args.workload, "description": desc, "population": args.population, "population_description": POPULATIONS[args.population][0],
+                       "channels_per_gpu": channels, "channels_total": total_channels,
                        "streams_per_gpu": nstreams, "block_samples_per_channel": n,
                        "realtime_channels_equiv": round(value / 2.304, 1),
                        "pcm_frames_per_channel_per_step": frames // max(args.steps, 1), "parallelism": "channels sharded, 1 rank/GPU"},
             "roofline": {"bound": "hbm", "kernel": "fmx::front_kernel (input FIR stage)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "frac_read_only": round(achieved * (8.0 / ALG_BYTES_STAGE_A) / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "avg_launch_ms": round(ms_a, 4),
+                         # both byte counts: what the channels consume (every channel reads its stream) and what is unique in HBM
+                         # (a stream several channels listen to is read once from HBM, then from the caches)
+                         "front_fir_bytes": {"per_channel_sample": alg_bytes, "unique_stream": 8.0 * nstreams * n + (8.0 / 12.0) * channels * n,
+                                             "frac_unique_stream": round((8.0 * nstreams * n + (8.0 / 12.0) * channels * n) / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_a > 0 else None},
                          "algorithmic_bytes_per_launch": alg_bytes, "measured_stream_bandwidth": measured,
                          "frac_of_measured": (round(achieved / measured["read12_write1_GBps"], 4)
                                               if measured.get("read12_write1_GBps") else None)},
-            "kernels_ms_per_step": {"front_fir": round(prof["ms"][0] / launches, 4),
-                                    "demod_pilot_pss": round(prof["ms"][1] / launches, 4),
-                                    "audio_fir_resample": round(prof["ms"][2] / launches, 4),
-                                    "note": "HIP events of a separate untimed pass of %d steps" % launches},
+            "kernels_ms_per_step": kernels_ms,
+            "kernels_ms_per_step_raw": {"front_fir": round(raw[0], 4), "demod_pilot_pss": round(raw[1], 4), "audio_fir_resample": round(raw[2], 4),
+                                        "stage_b_min_median_max": [round(float(v), 4) for v in (np.min(per_step[1]), np.median(per_step[1]), np.max(per_step[1]))],
+                                        "note": "HIP-event intervals of a separate untimed pass of %d steps, each enqueued behind a spin kernel; their sum "
+                                                "exceeds the timed step by the events' own cost" % launches},
+            "pilot_pll": pll_counts,
             "per_rank_value": [round(rank_channels[r] * n * args.steps / t / 1e6, 3) for r, t in enumerate(per_rank)],
         }
         if rds_check: out["rds_check"] = rds_check
@@ -556,13 +668,20 @@ def main():
             if sustained:
                 out["cpu_baseline"]["note"] = ("the port is ~10 %% faster than the reference's own classes; GPU/CPU ratio of "
                                                "the headline value = %.0f" % (out["value"] / out["cpu_baseline"]["value"]))
-        if world == 1 and not args.no_extra_workloads and args.workload == "config4" and args.channels == 0 and args.scaling == "weak":
+        if (world == 1 and not args.no_extra_workloads and args.workload == "config4" and args.channels == 0 and args.scaling == "weak"
+                and args.population == "established" and not args.decoder and not args.squelch):
             # the other BASELINE configs as one-liners (so that the driver's record carries every config), and the shard sizes of
             # configs[3] split 2 / 4 / 8 ways: what strong scaling of 4096 channels comes to per GPU, before any RCCL cost (there is
             # no collective on the data path; `python bench.py --gpus N --scaling strong --total-channels 4096` measures it for real)
             out["other_workloads"] = {"configs[1] (1 channel)": sub_bench(["--workload", "config2"]),
                                       "configs[2] (256 carriers on 24 shared streams)": sub_bench(["--workload", "config3"]),
-                                      "configs[4] shard (2048 channels, RDS on)": sub_bench(["--workload", "config5"])}
+                                      "configs[4] shard (2048 channels, RDS on)": sub_bench(["--workload", "config5"]),
+                                      # the path where it is slow: populations that are not all established, and the decoders /
+                                      # squelch that run one lane per channel (fmx_demod.hip)
+                                      "configs[3], mixed population": sub_bench(["--population", "mixed"]),
+                                      "configs[3], no channel locked": sub_bench(["--population", "unlocked"]),
+                                      "configs[3], PLL decoder on every channel": sub_bench(["--decoder", "2"]),
+                                      "configs[3], noise squelch on every channel": sub_bench(["--squelch", "1"])}
             proj = {"1": {"channels_per_gpu": channels, "per_gpu_value": out["value"], "efficiency": 1.0}}
             for g in (2, 4, 8):
                 r = sub_bench(["--channels", str(channels // g)])
