@@ -101,6 +101,13 @@ typedef enum {
                                   2 = two kernels (limiter .. lock detector, then PSS .. de-emphasis: four workgroups per CU instead of
                                   three); 0 = automatic (default): whichever wastes less of its last round of workgroups for the
                                   handle's channel count.  The results of the two forms are bit-identical. */
+    FMX_P_FILTER_RESTARTS = 23,/* (handle-wide, before the first call) how the two overlap-add filters of the reference -- inputFilter (65536 points, 251
+                                  taps, :469-470) and fmAudioFilter (8192 points, 756 taps, :589-591) -- are built: 1 = as the block machines they
+                                  are (fft-filters.cpp:33-163): a setBandwidth / setlfcutoff in the middle of a stream then replays the last output
+                                  block, drops the block in progress and carries the old tail over, sample for sample as the reference does
+                                  (handles of up to 64 channels); 2 = folded into stage A's / stage C's polyphase FIRs -- the same filters
+                                  wherever the settings were made before the first call, a different glitch of one filter latency behind a
+                                  change in mid-stream (what large batches run); 0 = automatic (default): 1 up to 64 channels, 2 above */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */

@@ -61,7 +61,7 @@ struct fmx_handle_s {
     std::vector<int32_t> act_up;                                     // one-shot action bits uploaded with the last parameter upload
     std::vector<uint8_t> rds_reset_req;                              // resetRds / triggerFrequencyChange asked for the group decoder's reset
     bool rds_rearm = false;                                          // every channel had RDS off: buffers and state restart at the next enable
-    hipEvent_t ev_in = nullptr;
+    hipEvent_t ev_in = nullptr, ev_dummy = nullptr;
     std::mutex mtx;                          // guards the mailbox (set_param from any thread)
     std::vector<ChanUser> user;
     std::vector<ChanParams> params;          // host mirror
@@ -107,6 +107,14 @@ struct fmx_handle_s {
     int64_t last_m0 = 0, last_m1 = 0;       // 24 kS/s outputs of the last call
     std::vector<void *> rds_ptrs, tail_ptrs;
     std::atomic<int> stageb_form{0};     // FMX_P_STAGEB_FORM
+    // the reference's two overlap-add filters as the block machines they are (fmx_ola.hip): handles of up to OLA_MAX_CH channels
+    bool ola_mode = false;               // FMX_P_FILTER_RESTARTS resolved (fixed once the first call has been made)
+    struct OlaSide {
+        int L = 0, degree = 0;
+        float2 *A = nullptr, *C = nullptr, *over = nullptr, *over_new = nullptr; float *taps = nullptr;
+        std::vector<int32_t> inp, on, key;   // per channel: block position, Pass () in use, the setting the kernel was designed for (-1: none yet)
+    } ola_in, ola_au;
+    float2 *d_v = nullptr, *d_u = nullptr, *d2ring = nullptr;   // pre_kernel's output, the input filter's output ([channels][max_block]), the audio filter's output ring
 };
 
 namespace {
@@ -189,6 +197,7 @@ int ensure_sets(fmx_handle h) {
     std::vector<int32_t> fk, ak;
     for (int c = 0; c < h->channels; c++) {
         int32_t b = h->user[c].bandwidth, l = h->user[c].lf_cutoff > 0 ? h->user[c].lf_cutoff : 0;
+        if (h->ola_mode) { b = 0; l = 0; }      // (the two filters run as block machines in front of stage A's decimators / stage C's resampler)
         auto it = std::find(fk.begin(), fk.end(), b);
         if (it == fk.end()) { fk.push_back(b); it = fk.end() - 1; }
         h->params[c].front_set = (int)(it - fk.begin()) * h->twins;          // (index of the channel's first twin set)
@@ -451,11 +460,103 @@ int rds_restart(fmx_handle h) {
     return FMX_OK;
 }
 
+// ---- the overlap-add block machines (fmx_ola.hip) ----------------------------------------------------------------------------------
+int ola_alloc_side(fmx_handle h, fmx_handle_s::OlaSide &S, int L, int degree) {
+    const size_t C = (size_t)h->channels;
+    S.L = L; S.degree = degree;
+    HIPCHK(hipMalloc(&S.A, sizeof(float2) * C * L)); HIPCHK(hipMemset(S.A, 0, sizeof(float2) * C * L));
+    HIPCHK(hipMalloc(&S.C, sizeof(float2) * C * L)); HIPCHK(hipMemset(S.C, 0, sizeof(float2) * C * L));
+    HIPCHK(hipMalloc(&S.over, sizeof(float2) * C * OLA_MAX_TAPS)); HIPCHK(hipMemset(S.over, 0, sizeof(float2) * C * OLA_MAX_TAPS));
+    HIPCHK(hipMalloc(&S.over_new, sizeof(float2) * C * OLA_MAX_TAPS)); HIPCHK(hipMemset(S.over_new, 0, sizeof(float2) * C * OLA_MAX_TAPS));
+    HIPCHK(hipMalloc(&S.taps, sizeof(float) * C * OLA_MAX_TAPS)); HIPCHK(hipMemset(S.taps, 0, sizeof(float) * C * OLA_MAX_TAPS));
+    S.inp.assign(C, 0); S.on.assign(C, 0); S.key.assign(C, -1);
+    for (void *p : {(void *)S.A, (void *)S.C, (void *)S.over, (void *)S.over_new, (void *)S.taps}) h->tail_ptrs.push_back(p);
+    return FMX_OK;
+}
+int ensure_ola(fmx_handle h) {
+    if (h->d_v) return FMX_OK;
+    const size_t C = (size_t)h->channels;
+    HIPCHK(hipMalloc(&h->d_v, sizeof(float2) * C * h->cfg.max_block));
+    HIPCHK(hipMalloc(&h->d_u, sizeof(float2) * C * h->cfg.max_block));
+    HIPCHK(hipMalloc(&h->d2ring, sizeof(float2) * C * h->dring));
+    HIPCHK(hipMemset(h->d2ring, 0, sizeof(float2) * C * h->dring));
+    for (void *p : {(void *)h->d_v, (void *)h->d_u, (void *)h->d2ring}) h->tail_ptrs.push_back(p);
+    int rc = ola_alloc_side(h, h->ola_in, 2 * 32768 - 251, 251);          // inputFilter (2 * 32768, 251) fm-processor.cpp:77
+    if (rc) return rc;
+    return ola_alloc_side(h, h->ola_au, 2 * 4096 - AUDIO_TAPS, AUDIO_TAPS);   // fmAudioFilter (2 * 4096, 756) :76
+}
+// setBandwidth / setlfcutoff as the reference's loop takes them over at a block start (fm-processor.cpp:396-408): a new value designs the
+// kernel and RESTARTS the block position (fftFilter::setLowPass fft-filters.cpp:84-95: inp = 0, buffers kept); "Off" / <= 0 stops using the
+// filter, whose buffers stay as they are
+int ola_take_settings(fmx_handle h) {
+    bool synced = false;
+    for (int side = 0; side < 2; side++) {
+        fmx_handle_s::OlaSide &S = side ? h->ola_au : h->ola_in;
+        for (int c = 0; c < h->channels; c++) {
+            const int32_t want = side ? (h->user[c].lf_cutoff > 0 ? h->user[c].lf_cutoff : 0) : (h->user[c].bandwidth > 0 ? h->user[c].bandwidth : 0);
+            if (want == S.key[(size_t)c]) continue;
+            S.key[(size_t)c] = want;
+            if (want == 0) { S.on[(size_t)c] = 0; continue; }
+            const std::vector<float> k = side ? design::lowpass(AUDIO_TAPS, want, h->cfg.fmRate) : design::lowpass(251, want / 2, h->cfg.inputRate);
+            if (!synced) { HIPCHK(hipDeviceSynchronize()); synced = true; }      // (an earlier call may still be reading the kernels)
+            HIPCHK(hipMemcpy(S.taps + (size_t)c * OLA_MAX_TAPS, k.data(), sizeof(float) * k.size(), hipMemcpyHostToDevice));
+            S.on[(size_t)c] = 1; S.inp[(size_t)c] = 0;
+        }
+    }
+    return FMX_OK;
+}
+void ola_fill(const fmx_handle_s::OlaSide &S, OlaBuffers &O) { O.A = S.A; O.C = S.C; O.over = S.over; O.over_new = S.over_new; O.taps = S.taps; O.L = S.L; O.degree = S.degree; }
+// does every channel's filter take the whole call as one run (no block boundary before its last sample)?  Then the step is returned and
+// the caller's own kernel (pre_kernel / deemph_kernel) does the copy; ola_finish_single runs the block transforms that fall due behind it.
+bool ola_single_step(fmx_handle h, const fmx_handle_s::OlaSide &S, int64_t len, OlaStep *st) {
+    *st = OlaStep{};
+    for (int c = 0; c < h->channels; c++) {
+        const bool on = S.on[(size_t)c] != 0;
+        if (on && S.inp[(size_t)c] + len > S.L) return false;
+        OlaChan &d = st->ch[c];
+        d.off = 0; d.len = (int32_t)len; d.inp = S.inp[(size_t)c]; d.on = on ? 1 : 0; d.conv = (on && len > 0 && S.inp[(size_t)c] + len == S.L) ? 1 : 0;
+    }
+    return true;
+}
+void ola_finish_single(fmx_handle h, fmx_handle_s::OlaSide &S, const OlaStep &st, const OlaBuffers &O, hipStream_t s) {
+    bool any_conv = false;
+    for (int c = 0; c < h->channels; c++) any_conv |= st.ch[c].conv != 0;
+    if (any_conv) { launch_ola_conv(st, O, h->channels, s); FMX_LAUNCHED(); }
+    for (int c = 0; c < h->channels; c++) if (st.ch[c].on) S.inp[(size_t)c] = st.ch[c].conv ? 0 : S.inp[(size_t)c] + st.ch[c].len;
+}
+// Pass () of every channel over `len` samples: runs up to the block boundary, the block transform where a block completes, and on
+void run_ola(fmx_handle h, fmx_handle_s::OlaSide &S, OlaBuffers O, int64_t len, hipStream_t s) {
+    ola_fill(S, O);
+    std::vector<int64_t> off((size_t)h->channels, 0);
+    for (;;) {
+        OlaStep st{};
+        int maxlen = 0; bool any_conv = false;
+        for (int c = 0; c < h->channels; c++) {
+            const int64_t rem = len - off[(size_t)c];
+            const bool on = S.on[(size_t)c] != 0;
+            const int64_t run = on ? std::min<int64_t>(rem, S.L - S.inp[(size_t)c]) : rem;
+            OlaChan &d = st.ch[c];
+            d.off = (int32_t)off[(size_t)c]; d.len = (int32_t)run; d.inp = S.inp[(size_t)c]; d.on = on ? 1 : 0;
+            d.conv = (on && run > 0 && S.inp[(size_t)c] + run == S.L) ? 1 : 0;
+            maxlen = std::max<int>(maxlen, (int)run); any_conv |= d.conv != 0;
+        }
+        if (maxlen <= 0) break;
+        launch_ola_io(st, O, h->channels, maxlen, s); FMX_LAUNCHED();
+        if (any_conv) { launch_ola_conv(st, O, h->channels, s); FMX_LAUNCHED(); }
+        for (int c = 0; c < h->channels; c++) {
+            const OlaChan &d = st.ch[c];
+            off[(size_t)c] += d.len;
+            if (d.on) S.inp[(size_t)c] = d.conv ? 0 : S.inp[(size_t)c] + d.len;
+        }
+    }
+}
+
 constexpr int PLL_SEQ_AUTO_MAX = 64;   // FMX_P_PLL_SOLVER = 0: handles up to this many channels evaluate the pilot PLL sequentially
 
 int flush_mailbox(fmx_handle h) {
     std::lock_guard<std::mutex> lk(h->mtx);
     if (h->gain_dirty) { h->gain_pending = true; h->gain_dirty = false; }   // (a change arriving behind this point belongs to the next call, flag and value)
+    if (h->ola_mode) { int rc = ensure_ola(h); if (rc) return rc; rc = ola_take_settings(h); if (rc) return rc; }
     if (h->sets_dirty) { int rc = ensure_sets(h); if (rc) return rc; h->params_dirty = true; }
     bool any_lo = false;
     for (auto &p : h->params) any_lo |= (p.lo_freq != 0);
@@ -560,7 +661,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     frames_geom(h, n, &G);
     G.ring_mask = h->ring - 1; G.dring_mask = h->dring - 1; G.sring_mask = h->sring - 1;
     G.input_rate = h->cfg.inputRate; G.pitch = h->pitch; G.streams_private = (h->streams_private && h->twins == 1) ? 1 : 0; G.twins = h->twins; G.channels = h->channels; G.stream_stride = stream_stride; G.pcm_stride = pcm_stride;
-    G.iq_format = fmt; G.iq_scale = (fmt == 3) ? 1.0f / s16_den : 1.0f / 128.0f;
+    G.iq_format = fmt; G.iq_scale = (fmt == 3) ? 1.0f / s16_den : 1.0f / 128.0f; G.n_cus = h->n_cus;
     const int64_t frames = conv2_out(h, G.M1) - conv2_out(h, G.M0);
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
     if (h->rds_alloc && h->rds_start >= 0 && G.J1 - G.J0 > RDS_BLK)
@@ -573,13 +674,29 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     }
     g_launch_err = hipSuccess;
     h->B.lin_rows = (int32_t)h->work_nj;
+    if (h->ola_mode) {
+        // few channels: RF DC removal / balance / LO mix per sample, the input filter as the reference's block machine, then the decimators
+        OlaBuffers O{}; O.src = h->d_v; O.dst = h->d_u; O.src_stride = O.dst_stride = h->cfg.max_block; O.src_mask = O.dst_mask = -1;
+        OlaStep st1;
+        if (ola_single_step(h, h->ola_in, n, &st1)) {
+            ola_fill(h->ola_in, O);
+            launch_pre(h->T, h->B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, &st1, &O); FMX_LAUNCHED();
+            ola_finish_single(h, h->ola_in, st1, O, s);
+        } else {
+            launch_pre(h->T, h->B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, nullptr, nullptr); FMX_LAUNCHED();
+            run_ola(h, h->ola_in, O, n, s);
+        }
+        CallGeom Gp = G; Gp.pre_processed = 1; Gp.iq_format = 0; Gp.iq_scale = 1.0f; Gp.stream_stride = h->cfg.max_block; Gp.streams_private = h->twins == 1 ? 1 : 0;
+        launch_front(h->T, h->B, Gp, h->d_u, h->channels, s);
+    } else
     launch_front(h->T, h->B, G, d_iq, h->channels, s);   // stage A: four waves per channel, packed-FMA FIR (fmx_front.hip)
     FMX_LAUNCHED();
     static const bool prof_double = getenv("FMX_PROF_DOUBLE") != nullptr;    // (diagnostic: a throw-away event in front of each boundary event)
-    hipEvent_t pdummy = nullptr;
-    if (prof && prof_double) { HIPCHK(hipEventCreate(&pdummy)); HIPCHK(hipEventRecord(pdummy, s)); }
+    if (prof && prof_double && !h->ev_dummy) HIPCHK(hipEventCreate(&h->ev_dummy));      // (one per handle, destroyed with it)
+    hipEvent_t pdummy = h->ev_dummy;
+    if (prof && prof_double) HIPCHK(hipEventRecord(pdummy, s));
     if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
-    G.stageb_form = h->stageb_form.load();
+    G.stageb_form = h->stageb_form.load(); G.no_deemph = h->ola_mode ? 1 : 0;
     launch_demod_fused(h->T, h->B, G, h->channels, s);      // (with its pre-pass for the PLL / AM decoders and the squelches)
     if (h->rds_alloc && h->rds_start >= 0) {
         bool any_rds = false;
@@ -594,12 +711,29 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     }
     if (prof && prof_double) HIPCHK(hipEventRecord(pdummy, s));
     if (prof) HIPCHK(hipEventRecord(pr.e[2], s));
-    if (h->gain_pending && G.M1 > G.M0) { G.gain_fix = 1; launch_gain_fix(h->T, h->B, G, h->channels, s); FMX_LAUNCHED(); h->gain_pending = false; }
-    if (!h->cv_nt) launch_audio(h->T, h->B, G, d_pcm, h->channels, s);
+    DeviceBuffers Bq = h->B;
+    if (h->ola_mode && G.J1 > G.J0) {
+        // the audio low-pass as the reference's block machine on the de-emphasised stream; the resampler reads its output
+        OlaBuffers O{}; O.src = h->B.dring; O.dst = h->d2ring; O.src_stride = O.dst_stride = h->dring; O.src_mask = O.dst_mask = h->dring - 1;
+        O.src_pos = O.dst_pos = G.J0;
+        OlaStep st1;
+        // de-emphasis behind the filter, as the reference orders them (:589-595)
+        if (ola_single_step(h, h->ola_au, G.J1 - G.J0, &st1)) {
+            ola_fill(h->ola_au, O);
+            launch_deemph(h->B, G, h->d2ring, h->channels, s, &st1, &O); FMX_LAUNCHED();
+            ola_finish_single(h, h->ola_au, st1, O, s);
+        } else {
+            run_ola(h, h->ola_au, O, G.J1 - G.J0, s);
+            launch_deemph(h->B, G, h->d2ring, h->channels, s, nullptr, nullptr); FMX_LAUNCHED();
+        }
+    }
+    if (h->ola_mode) Bq.dring = h->d2ring;
+    if (h->gain_pending && G.M1 > G.M0) { G.gain_fix = 1; launch_gain_fix(h->T, Bq, G, h->channels, s); FMX_LAUNCHED(); h->gain_pending = false; }
+    if (!h->cv_nt) launch_audio(h->T, Bq, G, d_pcm, h->channels, s);
     else {
         // the audio stage writes its 48 kHz frames behind the converter's history; theConverter's output goes to the caller
         CallGeom G48 = G; G48.pcm_stride = h->x48_stride;
-        launch_audio(h->T, h->B, G48, h->d_x48 + h->cv_nt, h->channels, s);
+        launch_audio(h->T, Bq, G48, h->d_x48 + h->cv_nt, h->channels, s);
         launch_conv2(h->d_x48, h->x48_stride, h->d_cv_taps, h->cv_p, h->cv_q, h->cv_nt, G.M0, G.M1 - G.M0, conv2_out(h, G.M0), frames,
                      d_pcm, pcm_stride, h->channels, s);
     }
@@ -711,6 +845,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMalloc(&h->d_x48, sizeof(float2) * (size_t)h->channels * h->x48_stride));
         HIPCHK(hipMemset(h->d_x48, 0, sizeof(float2) * (size_t)h->channels * h->x48_stride));
     }
+    h->ola_mode = h->channels <= OLA_MAX_CH;          // FMX_P_FILTER_RESTARTS = 0 (automatic)
     h->user.assign(h->channels, ChanUser());
     h->params.assign(h->channels, ChanParams());
     for (int c = 0; c < h->channels; c++) {
@@ -933,6 +1068,7 @@ int fmx_destroy(fmx_handle h) {
     for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
     for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_dummy) (void)hipEventDestroy(h->ev_dummy);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FMX_OK;
@@ -962,6 +1098,14 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_STAGEB_FORM:
         if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "stage B form must be 0 (automatic), 1 (one kernel) or 2 (two kernels)");
         h->stageb_form.store(iv); return FMX_OK;
+    case FMX_P_FILTER_RESTARTS: {
+        if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "filter restarts must be 0 (automatic), 1 (the reference's block filters) or 2 (folded FIRs)");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        if (h->g_total != 0) return fail(FMX_E_UNSUPPORTED, "the filter structure of a handle is fixed by its first call");
+        if (iv == 1 && h->channels > OLA_MAX_CH) return fail(FMX_E_UNSUPPORTED, "the block filters are built for handles of up to 64 channels");
+        const bool want = iv == 1 || (iv == 0 && h->channels <= OLA_MAX_CH);
+        if (want != h->ola_mode) { h->ola_mode = want; h->sets_dirty = true; }
+        return FMX_OK; }
     case FMX_P_DISP_DELAY: if (iv < 0 || iv > 100000) return fail(FMX_E_INVALID, "display delay must be 0..100000 steps"); break;
     case FMX_P_TEST_TONE:
     case FMX_P_VOLUME_DB: case FMX_P_LF_CUTOFF: case FMX_P_ATTENUATION_L: case FMX_P_ATTENUATION_R:
@@ -1173,7 +1317,7 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
             } else std::memcpy(dst, a.data(), sizeof(float) * (size_t)n);
         }
         return FMX_OK; }
-    case FMX_TAP_PRE_RESAMPLER: base = (const char *)(h->B.dring + (size_t)channel * h->dring); cap = h->dring; elem = sizeof(float2); break;
+    case FMX_TAP_PRE_RESAMPLER: base = (const char *)((h->ola_mode && h->d2ring ? h->d2ring : h->B.dring) + (size_t)channel * h->dring); cap = h->dring; elem = sizeof(float2); break;
     case 4: {   // FMX_TAP_RDS_IQ: complex @24 kS/s after rdsDecimator (:553): the last n outputs of the last call
         if (!h->rds_alloc) return fail(FMX_E_INVALID, "RDS is off");
         if (n > h->last_m1 - h->last_m0) return fail(FMX_E_INVALID, "n exceeds the RDS samples produced by the last call");

@@ -155,7 +155,10 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     float4 *X4 = Xall[wave];
     float2 *X2 = reinterpret_cast<float2 *>(X4);
-    const ChanParams P = B.params[ch];
+    ChanParams P = B.params[ch];
+    // (the stream pre_kernel and the overlap-add machine of fmx_ola.hip have made: one per channel, RF DC removal, IQ balance and LO mix done)
+    const bool pp = G.pre_processed != 0;
+    if (pp) { P.stream = ch; P.dc_remove = 0; P.lo_freq = 0; P.lo_period = 0; P.att_l = 1.0f; P.att_r = 1.0f; P.actions &= ~ACT_DC_RESET; }
     const FrontSet FS = T.front_sets[P.front_set + tw];
     const char *__restrict__ inb = reinterpret_cast<const char *>(iq_raw) + (size_t)P.stream * G.stream_stride * BPS;
     const float2 *__restrict__ in = reinterpret_cast<const float2 *>(inb);       // FMT == 0
@@ -192,11 +195,11 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     // stopped at), so the reference multiplies every sample by that constant -- which commutes with the real-tap filters and rides with
     // the complex output gain here.
     const bool lo_on = (P.lo_freq != 0) && (T.lo_table != nullptr);
-    const float2 R0 = (!lo_on && T.lo_table != nullptr && st->lo_phase != 0) ? T.lo_table[st->lo_phase] : make_float2(1.f, 0.f);
+    const float2 R0 = (!pp && !lo_on && T.lo_table != nullptr && st->lo_phase != 0) ? T.lo_table[st->lo_phase] : make_float2(1.f, 0.f);
     const bool dc_rst0 = (P.actions & ACT_DC_RESET) != 0;
     const float2 R0h = (lo_on && st->hist_fmt == 0 && st->lo_phase != 0) ? T.lo_table[st->lo_phase] : make_float2(1.f, 0.f);   // (what the raw history was read with)
     const bool hist_convert = lo_on && (st->hist_fmt == 0) && (P.dc_remove != 0 || P.att_l != 1.0f || P.att_r != 1.0f || dc_rst0 || st->lo_phase != 0);
-    const bool hist_to_raw = !lo_on && (st->hist_fmt == 1);
+    const bool hist_to_raw = !pp && !lo_on && (st->hist_fmt == 1);
     const bool hist_rst = !lo_on && (st->hist_fmt == 0) && dc_rst0;
     const float2 dc_now = (dc_rst0 || P.dc_remove == 0) ? make_float2(0.f, 0.f)
                                                         : make_float2(__builtin_amdgcn_fmed3f(st->dc_re, -0.01f, 0.01f), __builtin_amdgcn_fmed3f(st->dc_im, -0.01f, 0.01f));
@@ -364,6 +367,13 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
         // ---- scatter the raw samples into the image
         {
             const bool allfresh = (wbase >= g0) && (wbase + WSAMP <= gend);
+            if (allfresh && (FMX_ABL & 8)) {              // (diagnostic: what a conflict-free scatter would cost -- the image is garbage)
+#pragma unroll
+                for (int k = 0; k < SPT / 2; k++) {
+                    X2[lane + 128 * k] = make_float2(raw[k].x, raw[k].y);
+                    X2[lane + 128 * k + 64] = make_float2(raw[k].z, raw[k].w);
+                }
+            } else
             if (allfresh && !(FMX_ABL & 1)) {
 #pragma unroll
                 for (int k = 0; k < SPT / 2; k++) {
@@ -602,7 +612,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
                     hist[i] = v;
                 }
                 if (lane == 0 && (dcr || dc_rst)) { st->dc_re = dcr ? c_out_r : dc0r; st->dc_im = dcr ? c_out_i : dc0i; }
-                if (lane == 0) st->hist_fmt = mix ? 1 : 0;
+                if (lane == 0 && !pp) st->hist_fmt = mix ? 1 : 0;
                 if (fast) {
                     // RfDC in front of the 13 columns before the next call's first column qn and of qn itself (the state behind the
                     // call when the call ends on a column boundary; zero history when DC removal is off)
@@ -634,10 +644,21 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
                 aB.x = fmaf(-hsum, __builtin_amdgcn_fmed3f(dBr, -0.01f, 0.01f), aB.x); aB.y = fmaf(-hsum, __builtin_amdgcn_fmed3f(dBi, -0.01f, 0.01f), aB.y);
             }
             if (fast && (Lg != 1.0f || Rg != 1.0f)) { aA.x *= Lg; aA.y *= Rg; aB.x *= Lg; aB.y *= Rg; }      // IQ balance :462-464
-            if (q >= ja && q < jb)
-                zring[(zr0 + q * TW) & G.ring_mask] = make_float2(aA.x * cg_re - aA.y * cg_im, aA.x * cg_im + aA.y * cg_re);
-            if (q + 1 >= ja && q + 1 < jb)
-                zring[(zr0 + (q + 1) * TW) & G.ring_mask] = make_float2(aB.x * cg_re - aB.y * cg_im, aB.x * cg_im + aB.y * cg_re);
+            const float2 zA = make_float2(aA.x * cg_re - aA.y * cg_im, aA.x * cg_im + aA.y * cg_re);
+            const float2 zB = make_float2(aB.x * cg_re - aB.y * cg_im, aB.x * cg_im + aB.y * cg_re);
+            const int zi = (zr0 + q) & G.ring_mask;
+            if (TW == 1 && (zi & 1) == 0 && q >= ja && q + 1 < jb) {
+                // the lane's two outputs are neighbours in the ring and start on a 16-byte boundary (the ring's size is even): one store,
+                // 1 KB contiguous per wave instead of two interleaved 8-byte streams
+#ifdef FMX_ZNT
+                { typedef float v4f_ __attribute__((ext_vector_type(4))); __builtin_nontemporal_store((v4f_){zA.x, zA.y, zB.x, zB.y}, reinterpret_cast<v4f_ *>(&zring[zi])); }
+#else
+                *reinterpret_cast<float4 *>(&zring[zi]) = make_float4(zA.x, zA.y, zB.x, zB.y);
+#endif
+            } else {
+                if (q >= ja && q < jb) zring[(zr0 + q * TW) & G.ring_mask] = zA;
+                if (q + 1 >= ja && q + 1 < jb) zring[(zr0 + (q + 1) * TW) & G.ring_mask] = zB;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) seq_post(&free_seq[wave], ti + 1);          // this image may receive the history of tile ti + 3

@@ -219,7 +219,11 @@ struct CallGeom {
     int32_t stageb_form; // FMX_P_STAGEB_FORM (host side only: launch_demod_fused)
     int32_t twins;       // stage A always decimates by 12; an input rate the reference decimates by 12 / twins (6: twins = 2, 1: twins = 12) runs
                          // `twins` workgroups per channel, twin p with the tap alignment of output phase p, interleaved in the fm-rate ring
-    int32_t channels, pad_gf;
+    int32_t channels;
+    int32_t n_cus;       // compute units of the handle's device (host side only: the one-kernel / two-kernel choice of stage B)
+    int32_t pre_processed;   // stage A reads a stream that pre_kernel / the overlap-add machine (fmx_ola.hip) have already made: one stream per
+    int32_t no_deemph;       // channel, no RF DC removal, balance or LO mix here, history always raw, no front-end state written.  no_deemph: stage B
+                             // writes the stereo pair to the d ring as it is: the audio low-pass (a block machine then) comes first, deemph_kernel behind it
 };
 
 constexpr int DBG_SLOTS = 96;
@@ -259,6 +263,27 @@ struct DeviceBuffers {
 __host__ __device__ __forceinline__ size_t tap_idx(const DeviceBuffers &B, int64_t r, int ch, int pitch) {
     return B.lin_rows ? (size_t)ch * (size_t)B.lin_rows + (size_t)r : widx(r, ch, pitch);
 }
+
+// ---- the reference's overlap-add filters as block machines (fmx_ola.hip; handles of few channels) ----------------------
+constexpr int OLA_MAX_CH = 64;              // FMX_P_FILTER_RESTARTS automatic: handles up to this many channels
+constexpr int OLA_MAX_TAPS = 768;           // >= 756 (fmAudioFilter) and 251 (inputFilter)
+struct OlaChan { int32_t off, len, inp; int16_t on, conv; };   // this step of one channel: samples [off, off + len) of the call enter the block at inp; conv: the block is complete behind them
+struct OlaStep { OlaChan ch[OLA_MAX_CH]; };
+struct OlaBuffers {
+    const float2 *src; float2 *dst;         // input / output streams, channel c at + c * stride, sample i of the call at (pos + i) & mask
+    int64_t src_stride, dst_stride, src_mask, dst_mask, src_pos, dst_pos;
+    float2 *A, *C;                          // [channels][L] FFT_A (block being filled) and FFT_C (result of the last complete block), fft-filters.h:58-62
+    float2 *over, *over_new;                // [channels][OLA_MAX_TAPS] Overloop, and where the block transform puts the new one
+    const float *taps;                      // [channels][OLA_MAX_TAPS] the kernel of each channel
+    int32_t L, degree;                      // NumofSamples = fftSize - degree (fft-filters.cpp:34), degree
+};
+// (S, O given: the whole call is ONE run of every channel's filter, and the kernel does ola_io_kernel's work itself)
+void launch_pre(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, float2 *vbuf, int64_t vstride, int channels, hipStream_t s,
+                const OlaStep *S, const OlaBuffers *O);
+void launch_ola_io(const OlaStep &S, const OlaBuffers &O, int channels, int maxlen, hipStream_t s);
+void launch_ola_conv(const OlaStep &S, const OlaBuffers &O, int channels, hipStream_t s);
+// de-emphasis (fm-processor.cpp:594-595) of fm samples [J0, J1) of every channel, in place in `ring`
+void launch_deemph(const DeviceBuffers &B, const CallGeom &G, float2 *ring, int channels, hipStream_t s, const OlaStep *S, const OlaBuffers *O);
 
 // ---- RDS path (fmx_rds.hip) -------------------------------------------------------------------
 constexpr int RDS_BLK = 32000;              // overlap-add block of the two 32768-pt filters (fft-filters.cpp:34)

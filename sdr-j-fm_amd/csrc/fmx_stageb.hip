@@ -1313,6 +1313,16 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         // register-hungry phases above)
         if (PART == 0 && !lastseg && !special) { const int wn = (nj - seg0 - FB_W) < FB_W ? (nj - seg0 - FB_W) : FB_W; fetch(j0, seg0 + FB_W, wn, zn); }
         SB_FT(29);
+        if (G.no_deemph) {
+            // (handles whose audio low-pass runs as the reference's block machine, fmx_ola.hip: the filter comes first, :589-595 -- the pair goes
+            // out as it is, deemph_kernel owns the de-emphasis state)
+            const int dmask = G.dring_mask;
+            float2 *dr = B.dring + (size_t)ch * (dmask + 1);
+            const int jb = (int)((G.J0 + seg0 + j0) & dmask);
+#pragma unroll
+            for (int i = 0; i < FB_K; i++) if (i < nv) dr[(jb + i) & dmask] = x[i];
+            if (tid == 0) cy.calls = calls_before + ncalls;
+        } else
         {
             const float a = P.deemph_alpha;
             const DecayW dw = load_decay(&dtab, DEC_DEEMPH, lane);
@@ -1361,7 +1371,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         const PssSt ps = cy.ps;
         st->pss_acc = ps.acc; st->pss_mean = ps.mean; st->pilot_delay_pss = ps.pdp;
         st->pss_lock_cnt = ps.lock_cnt; st->pss_unlock_cnt = ps.unlock_cnt; st->pss_minimized = ps.minimized ? 1 : 0;
-        st->de_l = cy.de_l; st->de_r = cy.de_r;
+        if (!G.no_deemph) { st->de_l = cy.de_l; st->de_r = cy.de_r; }
         // metaData: the snapshot behind sample fmRate / 2 - myCount of the call was stored sample-exactly above; the RF DC level moves
         // by 1e-7 of its distance per input sample and is taken here, at the end of that call
         int cnt = my_count0 + nj;
@@ -1400,9 +1410,12 @@ void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const Cal
     // and a batch that does not fill the last round of either leaves CUs idle.  The form whose rounds waste less wins; a tie goes to
     // the single launch.  (4096 channels on 256 CUs: 5.33 rounds of 768 against 4 of 1024 -- 2.05 against 1.91 ms.)
     // FMX_P_STAGEB_FORM (tests) or the environment (FMX_STAGEB_SPLIT=0 / 1: A/B runs of the bench) force either form.
-    static const int env = getenv("FMX_STAGEB_SPLIT") ? atoi(getenv("FMX_STAGEB_SPLIT")) : -1;
+    // (the handle's own CU count rides in CallGeom: handles on different devices -- another SKU, another partition mode -- each do their own
+    // round arithmetic)
+    const char *envs = getenv("FMX_STAGEB_SPLIT");
+    const int env = envs ? atoi(envs) : -1;
     const int force = G.stageb_form ? G.stageb_form - 1 : env;
-    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int cus = G.n_cus > 0 ? G.n_cus : 256;
     const long whole = (long)((C + SB_WG_PER_SIMD * cus - 1) / (SB_WG_PER_SIMD * cus)) * SB_WG_PER_SIMD * 100;
     const long halves = (long)((C + 4 * cus - 1) / (4 * cus)) * 4 * 102;          // (two launches, the hand-over through HBM: 2 %)
     const bool split = force >= 0 ? force != 0 : halves < whole;

@@ -115,8 +115,15 @@ public:
     // ---- the processing loop ----
     // One iteration of the while loop of fmProcessor::run() (fm-processor.cpp:387-686).  Returns false
     // when the device holds fewer than bufferSize samples (the reference sleeps 1 ms and retries).
-    bool run_block() {
+    // `before_block`, when given, runs once a block is known to be waiting and before it is taken: the place to read state that belongs in
+    // front of the block (the Qt adapter latches its dump flag and the RfDC value there, not on iterations that find no block)
+    template <class F> bool run_block(F before_block) {
         if (!h || myRig->Samples() < bufferSize) return false;
+        before_block();
+        return take_block();
+    }
+    bool run_block() { return run_block([] {}); }
+    bool take_block() {
         const int32_t amount = myRig->getSamples(inBuf.data(), bufferSize);
         lastN = amount;
         int64_t frames = 0;

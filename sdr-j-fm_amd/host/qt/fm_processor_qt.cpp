@@ -235,13 +235,19 @@ void fmProcessor::run() {
     running.store(true);
     bool lastSquelch = false, first = true;
     while (running.load()) {
+        // the dump flag is latched once per block, with the RfDC value in front of that block (what the reference's `dumping` test at :448
+        // sees); nothing is fetched on iterations that find no block
         fmx_meta dcBefore{};
-        if (dumpFile.load()) (void)fmx_get_meta(I.core.handle(), 0, &dcBefore);             // RfDC in front of the block, for the dump
-        if (!I.core.run_block()) { QThread::msleep(1); continue; }        // fewer than 16384 samples waiting (:388-391)
+        sf_private_tag *dumpNow = nullptr;
+        const bool got = I.core.run_block([&] {
+            dumpNow = dumpFile.load();
+            if (dumpNow) (void)fmx_get_meta(I.core.handle(), 0, &dcBefore);
+        });
+        if (!got) { QThread::msleep(1); continue; }                       // fewer than 16384 samples waiting (:388-391)
         const int32_t amount = I.core.lastAmount();
         if (I.hfBuffer) I.hfBuffer->putDataIntoBuffer(I.core.lastBlock(), amount);          // :420
         emit hfBufferLoaded();                                                              // :421
-        if (sf_private_tag *f = dumpFile.load()) if (dumpWriter) {                          // :448-455: the block behind the RF DC removal (:423-446)
+        if (sf_private_tag *f = dumpNow) if (dumpWriter) {                                  // :448-455: the block behind the RF DC removal (:423-446)
             std::complex<float> dc(dcBefore.live_rf_dc_re, dcBefore.live_rf_dc_im);
             const float alpha = 1.0f / (float)I.dev.getRate(), lim = 0.01f;
             I.dumped.resize((size_t)amount);

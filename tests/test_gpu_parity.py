@@ -420,6 +420,7 @@ def test_mixed_decoders_in_one_batch_equal_single_channel_runs(fmx_amd, ol):
     assert len(first) >= 7 and any(k[0] == 2 for k in first)
     for k, c in first.items():
         g = fmx_amd.Fmx(1, max_block=block)
+        g.set_param(M.P_FILTER_RESTARTS, 2)            # the batch's filter structure (a handle this small runs the reference's block filters by default)
         gui_defaults(g, 165000, True)
         apply(g, c, 0)
         assert np.array_equal(run_blocks(g, iq, block)[0], pcm[c]), k
@@ -813,6 +814,7 @@ def test_tap_sets_match_oracle_design(fmx_amd, ol):
     import ctypes as C
     O = ol.oracle()
     f = fmx_amd.Fmx(1, max_block=16384)
+    f.set_param(M.P_FILTER_RESTARTS, 2)                # the folded form (what handles above 64 channels run); a handle this small runs the block filters by default
     gui_defaults(f)
     k1 = np.zeros(50, np.float32); O.fmo_decim_kernel(25, 96000, 2304000, ol.fptr(k1))
     k2 = np.zeros(6, np.float32); O.fmo_decim_kernel(3, 96000, 384000, ol.fptr(k2))

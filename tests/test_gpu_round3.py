@@ -499,3 +499,64 @@ def test_discriminator_corner_arguments_of_the_atan_table(fmx_amd, ol):
         # (a wrong corner would be off by pi/2 or more = 2.4 of the demodulator's scale; what is left is the AFC average of this heavily
         # biased signal -- |afc| ~ 1 rad -- summed in another order by the time-parallel scan: ~6e-6 rad, 1e-5 .. 1e-4 after the scaling)
         assert worst <= 3e-4 and rms(pg - po) <= PCM_RMS_TOL
+
+
+MID_ORDER = [dict(inputFilterBw=0), dict(inputFilterBw=120000), dict(lfCutoff=12000), dict(lfCutoff=0), dict(lfCutoff=15000), dict(inputFilterBw=165000),
+             dict(inputFilterBw=165000, lfCutoff=9000)]
+
+
+def run_mid_stream_changes(fmx_amd, ol, nch, gap_s, block=16384 * 3):
+    """the changes of MID_ORDER, one every gap_s seconds, through the library and the oracle: per-call PCM RMS differences and the change calls"""
+    per_s = 2304000 / block
+    gap = int(gap_s * per_s)
+    switches = {(i + 1) * gap: d for i, d in enumerate(MID_ORDER)}
+    nb = (len(MID_ORDER) + 1) * gap
+    iq = ol.synth_iq(nb * block)
+    o = ol.OracleChain(inputFilterBw=165000)
+    f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block)
+    gui_defaults(f)
+    per_call = []
+    for b in range(nb):
+        for k, v in switches.get(b, {}).items():
+            o.configure(**{k: v})
+            f.set_param(M.P_BANDWIDTH if k == "inputFilterBw" else M.P_LF_CUTOFF, v)
+        x = iq[b * block:(b + 1) * block]
+        po, pg = o.process(x), f.process_host(x)
+        assert pg[0].shape == po.shape and np.isfinite(pg).all() and float(np.abs(pg).max()) <= 1.5
+        for c in range(1, nch):
+            assert np.array_equal(pg[c], pg[0])
+        per_call.append(rms(pg[0] - po))
+    return per_call, switches, gap
+
+
+def test_mid_stream_filter_changes_single_receiver(fmx_amd, ol):
+    """VERDICT r3 missing #1 / next #5.  setBandwidth (radio.cpp:1706-1712 -> fm-processor.cpp:232-239,396-408) and setlfcutoff (:762-770)
+    while the stream runs.  The reference's overlap-add filters restart their block position at every setLowPass
+    (fft-filters.cpp:71-95: `inp = 0`, buffers kept): the reference plays the last completed output block again (65285 input samples =
+    28 ms for the input filter, 7436 fm samples = 39 ms for the audio filter), drops the block in progress and adds the old block's tail
+    to the first block of the new kernel; "Off" lets the undelayed samples through at once.  A handle of up to 64 channels runs the two
+    filters as those block machines (fmx_ola.hip, FMX_P_FILTER_RESTARTS): "165kHz" -> "Off" -> "120kHz", three changes of the audio
+    cut-off, back to "165kHz", and both filters at once, every 0.5 s -- the PCM stays within the tolerance in EVERY call, the glitches
+    included."""
+    per_call, switches, gap = run_mid_stream_changes(fmx_amd, ol, 1, 0.5)
+    print("\n[mid-stream filter changes, single receiver] worst call behind each change: "
+          + ", ".join(f"{switches[s_]}: {max(per_call[s_:s_ + gap]):.1e}" for s_ in sorted(switches)))
+    assert max(per_call) <= PCM_RMS_TOL
+
+
+def test_mid_stream_filter_changes_are_bounded_in_a_batch(fmx_amd, ol):
+    """The same changes on a handle above 64 channels, whose filters are folded into the polyphase FIRs of stage A and stage C: the new tap
+    set applies from the call's first sample and the rings are read at the new latency -- during one filter latency the reference's
+    output and the library's are both glitches, and different ones.  Behind an AUDIO filter change nothing else has state: the PCM agrees
+    again within 0.25 s.  Behind an INPUT filter change the 28 ms of different fm-rate IQ kick the pilot PLL, the lock detector and the PSS
+    differently; where the glitch costs one side its pilot lock the stereo decoder comes back half a second apart and the PSS
+    integrator re-converges behind it.  Asserted: PCM finite and bounded throughout (run_mid_stream_changes), within the tolerance again
+    at most 0.25 s behind an audio filter change and 2.3 s behind an input filter change, and from there until the next change."""
+    per_call, switches, gap = run_mid_stream_changes(fmx_amd, ol, 65, 2.5)
+    per_s = 2304000 / (16384 * 3)
+    back = {s_: next((i for i in range(gap) if all(v <= PCM_RMS_TOL for v in per_call[s_ + i:s_ + gap])), gap) for s_ in sorted(switches)}
+    print("\n[mid-stream filter changes, 65 channels, folded filters] seconds behind each change until the PCM is back under 1e-5 for good: "
+          + ", ".join(f"{switches[s_]}: {back[s_] / per_s:.2f} (worst call {max(per_call[s_:s_ + gap]):.1e})" for s_ in sorted(switches)))
+    assert max(per_call[30:gap]) <= PCM_RMS_TOL
+    for s_ in sorted(switches):
+        assert back[s_] <= (0.25 if "inputFilterBw" not in switches[s_] else 2.3) * per_s, (switches[s_], back[s_])
