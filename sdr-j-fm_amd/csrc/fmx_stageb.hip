@@ -487,6 +487,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         float dem[FB_K], cur[FB_K];
         bool locked[FB_K];
         bool all_locked;                                         // every sample of the segment (the same in every thread)
+        bool none_locked = false;                                // surely no sample of the segment (the same in every thread): the PSS filter has no call to serve
         uint8_t *const lockm = B.w_lockm + (size_t)ch * B.lockm_stride + (size_t)(seg0 / FB_W) * FB_T + tid;
         if constexpr (PART != 2) {
         if (!special) {
@@ -741,8 +742,9 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                         float x = x0;
                         auto one = [&](float clo, float chi, float bb, float wa, float wb) {
                             const float xin = x;
-                            const float c = (xin < bb) ? clo : chi;
-                            x = (((xin + c) + omega) + wa) + wb;
+                            // (both candidates side by side and the choice last: the dependent chain is four additions and a select)
+                            const float xl = (((xin + clo) + omega) + wa) + wb, xh = (((xin + chi) + omega) + wa) + wb;
+                            x = (xin < bb) ? xl : xh;
                             return xin;
                         };
                         const float4 *qlo = reinterpret_cast<const float4 *>(sq_lo), *qhi = reinterpret_cast<const float4 *>(sq_hi), *qb = reinterpret_cast<const float4 *>(sq_b),
@@ -971,6 +973,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 }
             }
             all_locked = totF < 0 && (locked0 != 0 || stable0 + 1 > (SINCOS_N >> 1));
+            none_locked = locked0 == 0 && !(stable0 + w > (SINCOS_N >> 1));      // (not in lock in front of the segment and the run cannot get long enough inside it)
             int nl, ns;
             if (totF < 0) { nl = (locked0 != 0 || stable0 + w > (SINCOS_N >> 1)) ? 1 : 0;
                             ns = locked0 ? stable0 : (stable0 + w < (SINCOS_N >> 1) + 1 ? stable0 + w : (SINCOS_N >> 1) + 1); }
@@ -991,7 +994,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         if constexpr (PART == 1) {
             // hand-over to the second kernel: lock flags of this thread's samples (bits 0 .. 5) and of the whole segment (bit 7); the next
             // segment's ring entries are requested here (the whole kernel does that under its de-emphasis)
-            unsigned m = all_locked ? 0x80u : 0u;
+            unsigned m = (all_locked ? 0x80u : 0u) | (none_locked ? 0x40u : 0u);
 #pragma unroll
             for (int i = 0; i < FB_K; i++) m |= locked[i] ? (1u << i) : 0u;
             *lockm = (uint8_t)m;
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             const unsigned m = *lockm;
 #pragma unroll
             for (int i = 0; i < FB_K; i++) { dem[i] = (i < nv) ? wd[i] : 0.f; cur[i] = (i < nv) ? wc[i] : 0.f; locked[i] = ((m >> i) & 1u) != 0; }
-            all_locked = (m & 0x80u) != 0;
+            all_locked = (m & 0x80u) != 0; none_locked = (m & 0x40u) != 0;
         }
         if constexpr (PART != 1) {
 
@@ -1013,7 +1016,9 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         const int calls_before = cy.calls;
         float2 *sring = B.sring + (size_t)ch * (G.sring_mask + 1);
         const int smask = G.sring_mask;
-        if (pss_on) {
+        // (a segment without a sample in lock makes no process_sample call when autoMono is on, :704: the low-pass has nobody to serve --
+        // what unlocked channels, which pay for the sample-by-sample PLL, save here)
+        if (pss_on && !(auto_mono && none_locked)) {
 #pragma unroll
             for (int i = 0; i < FB_K; i += 2) {
                 *reinterpret_cast<float2 *>(&park_dem[j0 + i]) = make_float2(dem[i], dem[i + 1]);
