@@ -119,9 +119,6 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
 // (6-bit vmcnt) and on gfx9 stores count too: the loads of the next batch are issued right behind the stores of the
 // last one, so (loads + stores) per batch must stay below that or every batch stalls for a store round trip.
 constexpr int SEQ_UB = WT;
-// LDS of the wave: the forty filter memories of every lane's noise squelch, and the staging of a tile's outputs in front of it
-constexpr int REC_LDS_BYTES = (4 * NSQ_QUADS + SEQ_UB) * 64 * 4;
-__shared__ __attribute__((aligned(16))) char g_rec_lds[REC_LDS_BYTES];
 // a few wavefronts whose run time is pure instruction latency: the issue arbiter must not make them wait behind other kernels' waves
 #ifndef FMX_RECURRENCE_PRIO
 #define FMX_RECURRENCE_PRIO() __builtin_amdgcn_s_setprio(3)
@@ -210,18 +207,7 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     const float sq_thr = B.params[ch].squelch_thr;
     int sq_cnt = st->sq_count; bool sq_sup = st->sq_suppress != 0;
     float am = st->am_carr;
-    // noise squelch (squelch::do_noise_squelch squelchClass.cpp:47-87): |high-pass 69.9 kHz| against |low-pass 70 kHz| of the
-    // demodulator output, two order-20 Chebyshev cascades (Basic_IIR::Pass iir-filters.h:89-103, same f32 operation order)
-    const bool nsq = PLLDEC && (B.params[ch].squelch_mode == 1) && T.nsq_coef != nullptr;
-    const float nsq_thr = B.params[ch].squelch_nthr;
-    // (the forty filter memories of a lane live in LDS, [memory][lane]: the AFC role has the wave's LDS buffer to itself, and
-    // forty more live registers would push the PLL-decoder / AM / level-squelch paths of this body into scratch)
-    float *nmem = reinterpret_cast<float *>(g_rec_lds) + threadIdx.x;
-    float avg_hi = 0.f, avg_lo = 0.f;
-    if (PLLDEC && nsq) {
-        for (int k = 0; k < 4 * NSQ_QUADS; k++) nmem[64 * k] = (&st->sq_m[0][0][0])[k];
-        avg_hi = st->sq_avg_hi; avg_lo = st->sq_avg_lo;
-    }
+    // (the noise squelch, squelchClass.cpp:47-87, is a pass of its own behind this kernel: nsq_kernel below)
     const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha, K = T.K_FM, rK = T.K_FM_rcp;
     const double SC = T.sincos_C;
     float afc = st->fm_afc, nco_phase = st->nco_phase, incr = st->phase_incr;
@@ -267,38 +253,6 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
         }
         return r;
     };
-    // the noise squelch of one demodulator output (a pass of its own behind `step`, in rolled loops: inlined sixteen times
-    // into the unrolled tile body it pushed every path of this body into scratch memory)
-    auto nsq1 = [&](float r) __attribute__((always_inline)) -> float {
-        float val[2];
-#pragma unroll
-        for (int f = 0; f < 2; f++) {
-            const float *cf = T.nsq_coef + f * NSQ_QUADS * 4;
-            float o = r * T.nsq_coef[2 * NSQ_QUADS * 4 + f];
-#pragma unroll 1
-            for (int i = 0; i < NSQ_QUADS; i++) {
-                float *m = nmem + 64 * 2 * (f * NSQ_QUADS + i);               // (m1, m2) of this biquad
-                const float rm1 = m[0], rm2 = m[64];
-                const float w = o - rm1 * cf[4 * i + 2] - rm2 * cf[4 * i + 3];
-                o = w + rm1 * cf[4 * i] + rm2 * cf[4 * i + 1];
-                m[64] = rm1; m[0] = w;
-            }
-            val[f] = fabsf(o);
-        }
-        // decayingAverage squelchClass.cpp:40-45, weight = sampleRate / 100, evaluated in double
-        const double k1 = 1.0 / (double)(float)(SINCOS_N / 100), k2 = 1.0 - k1;
-        avg_hi = (float)((double)val[0] * k1 + (double)avg_hi * k2);
-        avg_lo = (float)((double)val[1] * k1 + (double)avg_lo * k2);
-        if (++sq_cnt >= SINCOS_N / 20) {
-            sq_cnt = 0;
-            if (nsq_thr < 0.001f) sq_sup = true;                                   // SQUELCH_HYSTERESIS_NSQ = 0.001
-            else if (avg_hi < avg_lo * nsq_thr - 0.001f) sq_sup = false;
-            else if (avg_hi >= avg_lo * nsq_thr + 0.001f) sq_sup = true;
-        }
-        return sq_sup ? r * 0.000f : r;
-    };
-    const bool nsq_wave = PLLDEC && __any(nsq);
-    float *nsx = reinterpret_cast<float *>(g_rec_lds) + 64 * 4 * NSQ_QUADS + threadIdx.x;      // [16][lane] staging of a tile's outputs
     constexpr int UB = SEQ_UB;
     const int nfull = chunk_len / UB;
     const int TS = UB * CP;                                       // elements from one tile of this channel to the next
@@ -324,16 +278,6 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
                 x[k] = step(x[k], xq[k]);
                 if (PLLDEC && (int64_t)tb * UB + k == snap_row) st->meta_dc_if = afc;          // get_demodDcComponent () at the snapshot
             }
-            if (PLLDEC && nsq_wave) {
-#pragma unroll
-                for (int k = 0; k < UB; k++) nsx[64 * k] = x[k];
-                if (nsq) {
-#pragma unroll 1
-                    for (int k = 0; k < UB; k++) nsx[64 * k] = nsq1(nsx[64 * k]);
-                }
-#pragma unroll
-                for (int k = 0; k < UB; k++) x[k] = nsx[64 * k];
-            }
             wst(wd + tb * TS, x);
         });
     {
@@ -342,21 +286,105 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
         {
             float r = step(wdt[k], PLLDEC ? wiqt[k] : make_float2(0.f, 0.f));
             if (PLLDEC && (int64_t)nfull * UB + k == snap_row) st->meta_dc_if = afc;
-            if (PLLDEC && nsq) r = nsq1(r);
             wdt[k] = r;
         }
     }
     st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr; st->am_carr = am;
-    if (PLLDEC) { st->sq_count = sq_cnt; st->sq_suppress = sq_sup ? 1 : 0; }
-    if (PLLDEC && nsq) {
-        st->sq_avg_hi = avg_hi; st->sq_avg_lo = avg_lo;
-        for (int k = 0; k < 4 * NSQ_QUADS; k++) (&st->sq_m[0][0][0])[k] = nmem[64 * k];
-    }
+    if (PLLDEC && lsq) { st->sq_count = sq_cnt; st->sq_suppress = sq_sup ? 1 : 0; }
 }
 template <bool PLLDEC>
 __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len) {
     FMX_RECURRENCE_PRIO();
     afc_body<PLLDEC>(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// =================================================================================================
+// nsq_kernel: squelch::do_noise_squelch (squelchClass.cpp:47-87) behind afc_kernel -- |high-pass 69.9 kHz| against |low-pass 70 kHz| of the
+// demodulator output, two order-20 Chebyshev cascades of ten biquads each (Basic_IIR::Pass iir-filters.h:89-103), decaying averages,
+// a decision every fmRate / 20 samples, the output muted while the squelch is closed.
+// One lane per channel (rounds 2-3) walked twenty dependent biquads per sample with their forty memories in LDS: 40 ms per step at 4096
+// channels.  A cascade is a PIPELINE: here one lane is ONE BIQUAD -- lanes 20 k .. 20 k + 9 the high-pass of the wave's k-th channel, 20 k +
+// 10 .. 20 k + 19 its low-pass, three channels per wave -- with its two memories and four coefficients in registers; at step s lane i of
+// a cascade works on sample s - i and hands its output one lane up (DPP wave_shr:1).  Every biquad does the reference's own f32
+// operations in the reference's order on the reference's inputs: the results are the sequential ones bit for bit, the dependent chain per
+// step is one biquad instead of twenty.  The cascades' last lanes keep the decaying averages (f64 expressions as decayingAverage
+// computes them), meet at the decision points, and the low-pass's last lane writes the muted output back in place, nine samples behind.
+// =================================================================================================
+constexpr int NSQ_CH_PER_WAVE = 3, NSQ_LANES = 2 * NSQ_QUADS;
+__global__ __launch_bounds__(64) void nsq_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int nrows) {
+    const int lane = threadIdx.x;
+    const int k = lane / NSQ_LANES, li = lane - k * NSQ_LANES;           // channel of the wave, lane of its pair of cascades
+    const int ch = blockIdx.x * NSQ_CH_PER_WAVE + k;
+    const bool mine = k < NSQ_CH_PER_WAVE && ch < C && B.params[ch < C ? ch : 0].squelch_mode == 1 && T.nsq_coef != nullptr;
+    if (!__any(mine)) return;
+    const int chs = mine ? ch : 0;
+    const int f = li >= NSQ_QUADS ? 1 : 0, q = li - f * NSQ_QUADS;        // which filter (0 high-pass, 1 low-pass), which biquad of it
+    ChanState *st = B.state + chs;
+    const float *cf = T.nsq_coef + (f * NSQ_QUADS + q) * 4;
+    const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+    const float gain = T.nsq_coef[2 * NSQ_QUADS * 4 + f];
+    float m1 = mine ? st->sq_m[f][q][0] : 0.f, m2 = mine ? st->sq_m[f][q][1] : 0.f;
+    const bool first = q == 0, last = q == NSQ_QUADS - 1;
+    float avg = (f == 0) ? st->sq_avg_hi : st->sq_avg_lo;                   // (kept by the cascade's last lane)
+    int sq_cnt = st->sq_count; bool sq_sup = st->sq_suppress != 0;
+    const float thr = B.params[chs].squelch_nthr;
+    const int CP = G.pitch;
+    float *wd = B.w_dem + widx(0, chs, CP);                                 // (prepass: w_dem = w_osc, 16-row tiles; tile t of this channel at + t * 16 * CP)
+    const int TS = WT * CP;
+    const double k1 = 1.0 / (double)(float)(SINCOS_N / 100), k2 = 1.0 - k1;   // decayingAverage squelchClass.cpp:40-45, weight = sampleRate / 100, in double
+    float xin[WT], xout[WT], xtail[WT];                                      // the tile the first lanes feed from; the tile the last lane is muting
+#pragma unroll
+    for (int i = 0; i < WT; i++) { xin[i] = 0.f; xout[i] = 0.f; xtail[i] = 0.f; }
+    float o = 0.f;                                                         // this lane's output of the previous step
+    const int nsteps = nrows + NSQ_QUADS - 1;
+    for (int s0 = 0; s0 < nsteps + WT; s0 += WT) {
+        // the first lanes take tile s0 / 16 of the input; the last low-pass lane takes the tile whose samples it will mute in these steps
+        if (mine && first && s0 < nrows) wld(xin, wd + (s0 / WT) * TS);
+#pragma unroll
+        for (int i = 0; i < WT; i++) {
+            const int s = s0 + i;
+            const int n = s - q;                                           // the sample this lane works on in this step
+            const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o), 0x138, 0xf, 0xf, false));     // the lane below, previous step
+            const bool act = mine && n >= 0 && n < nrows;
+            if (act) {
+                const float in = first ? xin[i] * gain : up;                // Basic_IIR::Pass: o = in * gain, then the quads
+                const float w = in - m1 * c2 - m2 * c3;
+                o = w + m1 * c0 + m2 * c1;
+                m2 = m1; m1 = w;
+            }
+            const bool tail = act && last;
+            if (tail) avg = (float)((double)fabsf(o) * k1 + (double)avg * k2);
+            // the two cascades' last lanes work on the same sample in the same step and count it; at a decision point (squelchClass.cpp:60-75:
+            // every fmRate / 20 samples) they exchange their averages -- only then -- and both take the decision
+            bool hit = false;
+            if (tail) { hit = ++sq_cnt >= SINCOS_N / 20; sq_cnt = hit ? 0 : sq_cnt; }
+            if (__any(hit)) {
+                const float other = __shfl(avg, lane + (f ? -NSQ_QUADS : NSQ_QUADS), 64);
+                if (hit) {
+                    const float avg_hi = f ? other : avg, avg_lo = f ? avg : other;
+                    if (thr < 0.001f) sq_sup = true;                       // SQUELCH_HYSTERESIS_NSQ = 0.001
+                    else if (avg_hi < avg_lo * thr - 0.001f) sq_sup = false;
+                    else if (avg_hi >= avg_lo * thr + 0.001f) sq_sup = true;
+                }
+            }
+            if (tail) {
+                if (f == 1) {
+                    // (sample n = s - 9 sits at place (i + 7) mod 16 of tile n / 16 -- a constant of the unrolled step: xtail holds that tile's
+                    // input, xout collects the muted values; rows of the last tile behind the call's last sample are nobody's)
+                    constexpr int LAG = NSQ_QUADS - 1;
+                    const int ti = (i + WT - LAG) & (WT - 1);
+                    if (ti == 0) wld(xtail, wd + (n / WT) * TS);
+                    const float r = sq_sup ? xtail[ti] * 0.000f : xtail[ti];
+                    xout[ti] = r;
+                    if (ti == WT - 1 || n == nrows - 1) wst(wd + (n / WT) * TS, xout);
+                }
+            }
+        }
+    }
+    if (mine) { st->sq_m[f][q][0] = m1; st->sq_m[f][q][1] = m2; }
+    if (mine && last) {
+        if (f == 0) st->sq_avg_hi = avg; else { st->sq_avg_lo = avg; st->sq_count = sq_cnt; st->sq_suppress = sq_sup ? 1 : 0; }
+    }
 }
 
 void launch_demod_prepass(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s) {
@@ -366,6 +394,9 @@ void launch_demod_prepass(const DeviceTables &T, const DeviceBuffers &B, const C
     Bp.prepass = 1; Bp.lin_rows = 0; Bp.w_dem = B.w_osc;          // (the tiled work arrays of the two kernels: w_osc takes the demodulator output)
     hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((nj + DISC_ROWS - 1) / DISC_ROWS), (unsigned)((C + DISC_CH - 1) / DISC_CH)), dim3(256), 0, s, T, Bp, G, C, (int64_t)0, (int)nj); FMX_LAUNCHED();
     hipLaunchKernelGGL(afc_kernel<true>, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, T, Bp, G, C, (int64_t)0, (int)nj); FMX_LAUNCHED();
+    if (T.nsq_coef) {        // (some channel has, or had, the noise squelch on: fmx_api.hip uploads the coefficients then)
+        hipLaunchKernelGGL(nsq_kernel, dim3((unsigned)((C + NSQ_CH_PER_WAVE - 1) / NSQ_CH_PER_WAVE)), dim3(64), 0, s, T, Bp, G, C, (int)nj); FMX_LAUNCHED();
+    }
 }
 
 }  // namespace fmx
