@@ -464,8 +464,12 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     // call's first two samples: all the `i < nv` / `i == il` / `i == ix` guards of the general form fold away at compile time (they
     // were a third of the kernel's VALU instructions: v_cndmask, exec-mask bookkeeping, SGPR spills).  The general form runs the
     // ragged last segment of a call and the one segment in 62 that takes the snapshot.
-    auto segment = [&](auto fast_tag, const int seg0) {
+    // EXACT = this segment's pilot PLL is evaluated on the sequential trajectory (see the pilot PLL below): an instantiation of its own,
+    // so that the registers its solvers need do not press on the segments that run Newton's method (spill code sits where the pressure is).
+    bool newton_ok_next = st->pll_newton_ok != 0;                     // (the same value in every thread: set by the lock detector from workgroup-wide results)
+    auto segment = [&](auto fast_tag, auto exact_tag, const int seg0) {
         constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr bool EXACT = decltype(exact_tag)::value;
         constexpr int SB_FASTFLAG = FAST ? 1 : 0;
         // Everything below that only depends on the thread index (table addresses, twiddles, scan weights, the ramp) is
         // loop-invariant, and the compiler would keep it all in registers across the loop (346 VGPRs): the index is made opaque
@@ -625,8 +629,8 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             // runs while the pilot is in lock AND the metric stayed above PLL_GUARD through the whole previous segment; the acquisition and
             // every approach of the threshold run on the reference's own trajectory (cy.newton_ok, set by the lock detector below).
             const int pll_mode = P.pll_seq;
-            bool exact_pending = pll_mode == 1 || (pll_mode == 0 && stereo_possible && !cy.newton_ok);
-            const bool guard_seg = pll_mode == 0 && exact_pending;
+            bool exact_pending = EXACT;                          // (the dispatch below decides: pll_mode 1, or pll_mode 0 and not newton_ok)
+            const bool guard_seg = pll_mode == 0 && EXACT;
             bool seq = false;                                    // this pass evaluates the loop sample by sample (the same in every thread)
             bool failsafe = false;                               // ... because Newton's iteration did not settle
             bool force_plain = false;                            // ... again, without the predictions of the first pass, which did not hold
@@ -706,8 +710,85 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                     // must be the next phase found, bit for bit (a trajectory with that property that starts at x0 IS the sequential one); a
                     // segment that fails the check -- or whose Newton iteration failed -- takes the plain loop below.
                     __syncthreads();
-                    const bool plain = failsafe || force_plain || !wrap_ok;
+                    const bool plain = !EXACT || failsafe || force_plain || !wrap_ok;
+                    // ---- first: the pilot periods of the segment side by side.  Once per period (~10.1 samples) the phase enters [4, 8),
+                    // where every f32 is a multiple of U = 2^-21 -- and U is a multiple of every ulp the phase has anywhere in [0, 2 pi).  Two
+                    // trajectories that differ by k U at such an ANCHOR and make the same decisions afterwards (table entry of every sample,
+                    // where the step wraps, where a binade is crossed) differ by exactly k U at every later sample: the rounding of an
+                    // addition commutes with a shift by a multiple of its grid.  So the ~152 runs from anchor to anchor of the GUESS are
+                    // evaluated by as many threads at once, each with the reference's own step, ten or eleven samples deep; a run's end misses
+                    // the next run's start by an integer d_c (in U); the prefix sums of the d_c are the shifts K_c of the true trajectory
+                    // against the guess -- provided no decision changes under the shift, which the next pass, started from the shifted
+                    // anchors, shows: passes are repeated until every run ends on the next run's start.  A chain with that property that
+                    // starts at x0 IS the sequential trajectory (tools/pll_cycle_sim.py: 3-5 passes, bit-identical on every segment tried).
+                    // Anything outside the assumptions (a run that is too long, an end off the grid, no agreement in CYC_MAXPASS passes)
+                    // leaves the segment to the single-thread pass below; the evaluation behind this block checks the result either way.
+                    bool cyc_ok = false;
+                    if constexpr (EXACT) {
                     if (!plain) {
+                        constexpr int CYC_LMAX = 12, CYC_MAXPASS = 10, CYC_RUNS = FB_T;
+                        float *const cg = big + 2 * FB_W, *const cd = big + 3 * FB_W;         // the guess, and 5 demod, per sample
+                        int *const canc = reinterpret_cast<int *>(big + 4 * FB_W), *const cK = canc + CYC_RUNS + 8;   // anchors (sample indices), shifts
+#pragma unroll
+                        for (int i = 0; i < FB_K; i++) if (i < nv) { cg[j0 + i] = ph[i]; cd[j0 + i] = 5 * dem[i]; }
+                        __syncthreads();
+                        bool af[FB_K]; int cnt = 0;
+                        {
+                            float prev = (j0 > 0 && nv > 0) ? cg[j0 - 1] : 0.f;
+#pragma unroll
+                            for (int i = 0; i < FB_K; i++) {
+                                af[i] = i < nv && (j0 + i == 0 || (ph[i] >= 4.0f && prev < 4.0f));
+                                cnt += af[i] ? 1 : 0; prev = ph[i];
+                            }
+                        }
+                        int pre, nc, dm1, dm2;
+                        wg.excl_add_max_i(cnt, 0, &pre, &nc, &dm1, &dm2);
+#pragma unroll
+                        for (int i = 0; i < FB_K; i++) if (af[i]) { if (pre < CYC_RUNS) canc[pre] = j0 + i; pre++; }
+                        if (tid == 0) canc[nc < CYC_RUNS ? nc : CYC_RUNS] = w;
+                        cK[tid] = 0;
+                        __syncthreads();
+                        const int c = tid;
+                        const bool runner = c < nc && nc <= CYC_RUNS;
+                        const int s_ = runner ? canc[c] : 0, len = runner ? canc[c + 1] - s_ : 0;
+                        const bool has_next = runner && c + 1 < nc;
+                        const float gs = runner ? cg[s_] : 4.0f, ge = has_next ? cg[s_ + len] : 4.0f;
+                        bool fail = nc > CYC_RUNS || (runner && (len > CYC_LMAX || len < 1));
+                        constexpr float Uq = 4.76837158203125e-07f;                             // 2^-21
+                        int passes = 0;
+                        for (; passes < CYC_MAXPASS; passes++) {
+                            const int Kc = cK[c], Kn = (c + 1 < CYC_RUNS) ? cK[c + 1] : 0;
+                            float x = (c == 0) ? x0 : gs + (float)Kc * Uq;
+                            if (runner && c > 0 && !(x >= 4.0f && x < 8.0f)) fail = true;
+                            for (int i = 0; i < CYC_LMAX; i++) {
+                                if (runner && i < len) {
+                                    pout[s_ + i] = x;
+                                    int idx = (int)((double)x * SC64);
+                                    idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+                                    const float val = (x + (cd[s_ + i] * sin_idx_f32(idx)) * gain) + omega;
+                                    x = (val >= 0.f && val < P32) ? val : pi_constrain(val);
+                                }
+                            }
+                            int d = 0;
+                            if (has_next && !fail) {
+                                const float dq = (x - (ge + (float)Kn * Uq)) * 2097152.0f;          // in U (exact: both on the grid of [4, 8))
+                                const float dr = rintf(dq);
+                                if (!(dq == dr) || !(fabsf(dr) < 4096.f)) fail = true; else d = (int)dr;
+                            }
+                            int preD, totD, preM, totM;
+                            wg.excl_add_max_i(d, (d != 0 ? 1 : 0) | (fail ? 2 : 0), &preD, &totD, &preM, &totM);
+                            if (totM >= 2) break;
+                            if (totM == 0) { cyc_ok = true; break; }
+                            cK[c] = Kc + preD;
+                            __syncthreads();
+                        }
+                        if (B.dbg && tid == 0) { B.dbg[(size_t)ch * DBG_SLOTS + 28] += passes + 1; B.dbg[(size_t)ch * DBG_SLOTS + 29] += 1; B.dbg[(size_t)ch * DBG_SLOTS + 30] += cyc_ok ? 0 : 1; }
+                        __syncthreads();
+                    }
+                    }
+                    const bool spec = EXACT && !plain && !cyc_ok;    // ---- second: one thread, its table arithmetic prepared by all
+                    if constexpr (EXACT) {
+                    if (spec) {
                         constexpr double INVC = FMX_2PI / SINCOS_N;
 #pragma unroll
                         for (int i = 0; i < FB_K; i++) {
@@ -731,14 +812,17 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                             }
                             sq_lo[j0 + i] = clo; sq_hi[j0 + i] = chi; sq_b[j0 + i] = bb; sq_wa[j0 + i] = wa; sq_wb[j0 + i] = wb;
                         }
-                    } else {
+                    }
+                    }
+                    if (plain) {
 #pragma unroll
                         for (int i = 0; i < FB_K; i++) if (i < nv) sq_hi[j0 + i] = dem[i];
                     }
                     SB_FT(33);
                     __syncthreads();
                     SB_FT(34);
-                    if (tid == 0 && !plain) {
+                    if constexpr (EXACT)
+                    if (tid == 0 && spec) {
                         float x = x0;
                         auto one = [&](float clo, float chi, float bb, float wa, float wb) {
                             const float xin = x;
@@ -979,6 +1063,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                             ns = locked0 ? stable0 : (stable0 + w < (SINCOS_N >> 1) + 1 ? stable0 + w : (SINCOS_N >> 1) + 1); }
             else { nl = 0; ns = w - 1 - totF; }
             const int nok = (nl && !anynear) ? 1 : 0;
+            newton_ok_next = nok != 0;
             if (lastseg && owner) { st->pil_lock = lock_end; st->pil_locked = nl; st->pil_stable = ns; st->pll_newton_ok = nok; }
             if (tid == 0) { cy.locked = nl; cy.stable = ns; cy.lock = lock_next; cy.newton_ok = nok; }
         }
@@ -1368,7 +1453,10 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     };
     for (int seg0 = 0; seg0 < nj; seg0 += FB_W) {
         const bool fast = (nj - seg0 >= FB_W) && !((unsigned)(jx - seg0) < (unsigned)FB_W) && (callJ0 + seg0 >= 2);
-        if (fast) segment(std::true_type{}, seg0); else segment(std::false_type{}, seg0);
+        // (the pilot PLL of this segment on the sequential trajectory?  pll_seq 1: always; 0: unless the pilot is comfortably in lock, PLL_GUARD)
+        const bool exact = PART != 2 && (P.pll_seq == 1 || (P.pll_seq == 0 && stereo_possible && !newton_ok_next));
+        if (fast) { if (exact) segment(std::true_type{}, std::true_type{}, seg0); else segment(std::true_type{}, std::false_type{}, seg0); }
+        else { if (exact) segment(std::false_type{}, std::true_type{}, seg0); else segment(std::false_type{}, std::false_type{}, seg0); }
     }
     // ================= bookkeeping behind the call =================
     __syncthreads();
