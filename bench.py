@@ -323,6 +323,7 @@ def main():
     ap.add_argument("--population", default="established", choices=sorted(POPULATIONS),
                     help="what the channels of a one-stream-per-channel workload receive (POPULATIONS); the headline is `established`")
     ap.add_argument("--decoder", type=int, default=0, help="fm_Demodulator::setDecoder for every channel (1 AM 2 PLL 3 Mixed ... 6 Diff; 0: the default, Mixed)")
+    ap.add_argument("--pll-solver", type=int, default=0, help="FMX_P_PLL_SOLVER for every channel (0: the handle's default)")
     ap.add_argument("--squelch", type=int, default=0, help="set_squelchMode for every channel (1 noise squelch, 2 level squelch)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank runs the workload's channel count; strong: --total-channels split over the ranks "
@@ -399,6 +400,8 @@ def main():
         f.set_param(m.P_FM_MODE, 0)
         if args.workload == "config5":
             f.set_param(m.P_RDS_MODE, 2)
+        if args.pll_solver:
+            f.set_param(m.P_PLL_SOLVER, args.pll_solver)
         if args.decoder:
             f.set_param(m.P_FM_DECODER, args.decoder)
         if args.squelch:

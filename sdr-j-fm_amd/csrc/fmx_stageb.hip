@@ -637,10 +637,11 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             auto eval = [&](int i, float phase, float *nx_out, float *val_out) {
                 int idx = (int)((double)phase * SC64);           // SinCos::getSin sincos.cpp:81-85 for phase >= 0: entry (int)(phase * C) % Rate
                 idx = (int)min((unsigned)idx, (unsigned)idx - (unsigned)SINCOS_N);       // (0 <= idx < 2 N: the wrap as an unsigned minimum)
-                // (table value: Newton's method from the hardware sine unit, 1.2e-7, a third of the instructions; the sample-by-sample
-                // solver -- the one that is asked for the reference's trajectory -- keeps the polynomial, whose errors are half as large)
-                float o;
-                if (seq) o = sin_idx_f32(idx); else o = sin_idx_hw(idx);
+                // (table value: from the hardware sine unit on the index folded into the first quadrant, within 1.2e-7 of the reference's entry
+                // -- every evaluation of the step in this kernel, whichever solver asks: the runs of the exact solvers and this evaluation,
+                // which verifies them, must read the same values.  Round 3's polynomial for the sample-by-sample solver was half as far
+                // from the table and three times the instructions; the pilot phase agrees with the oracle's to 7e-7 rad rms either way.)
+                const float o = sin_idx_hw(idx);
                 const float perr = (5 * dem[i]) * o;             // pilot-recover.cpp:56-58 (pilot = 5 * demod fm-processor.cpp:696)
                 const float t = phase + perr * gain;
                 const float val = t + omega;
@@ -765,8 +766,10 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                                     pout[s_ + i] = x;
                                     int idx = (int)((double)x * SC64);
                                     idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
-                                    const float val = (x + (cd[s_ + i] * sin_idx_f32(idx)) * gain) + omega;
-                                    x = (val >= 0.f && val < P32) ? val : pi_constrain(val);
+                                    const float val = (x + (cd[s_ + i] * sin_idx_hw(idx)) * gain) + omega;
+                                    // (PI_Constrain of [0, 4 pi) without a branch -- some run wraps in nearly every step; anything else ends this way)
+                                    fail = fail || !(__float_as_uint(val) < __float_as_uint(2.f * P32));
+                                    x = (val < P32) ? val : (val - P32) + C32;
                                 }
                             }
                             int d = 0;
@@ -802,7 +805,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                                 int klo = lower ? idx - 1 : idx;
                                 klo = klo < 0 ? 0 : (klo > SINCOS_N - 2 ? SINCOS_N - 2 : klo);
                                 const float d5 = 5 * dem[i];
-                                clo = (d5 * sin_idx_f32(klo)) * gain; chi = (d5 * sin_idx_f32(klo + 1)) * gain;
+                                clo = (d5 * sin_idx_hw(klo)) * gain; chi = (d5 * sin_idx_hw(klo + 1)) * gain;
                                 // the smallest f32 phase whose index (int) ((double) phase * C) reaches klo + 1: the f32 nearest (klo + 1) / C, or the one above it
                                 const float bh = (float)((double)(klo + 1) * INVC);
                                 bb = ((int)((double)bh * SC64) >= klo + 1) ? bh : __int_as_float(__float_as_int(bh) + 1);
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                             pout[j] = phase;
                             int idx = (int)((double)phase * SC64);
                             idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
-                            const float val = (phase + (d5 * sin_idx_f32(idx)) * gain) + omega;
+                            const float val = (phase + (d5 * sin_idx_hw(idx)) * gain) + omega;
                             phase = (val >= 0.f && val < P32) ? val : pi_constrain(val);
                         }
                     }
