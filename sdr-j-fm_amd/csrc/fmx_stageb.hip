@@ -16,12 +16,14 @@
 //   * linear recurrences with a constant decay (AFC, lock metric, PSS mean error, de-emphasis): a weighted wave scan in DPP
 //     carries the state ACROSS threads, each thread then re-runs its own six samples in the reference's exact f32 / f64
 //     expression.  The cross-thread carry differs from the sequential evaluation by rounding (1e-7 relative);
-//   * the pilot PLL -- non-linear: the phase feeds the sine look-up that corrects it -- by Newton's method on the f32
-//     trajectory of the whole segment (large batches), or sample by sample by one thread (few channels, and as the
-//     fail-safe): see the kernel.  The step evaluated is always the reference's own f32 step: its roundings are not noise
-//     but a pattern (adding the f32 omega to a phase in [4, 8) adds omega rounded to that binade's grid), a frequency
-//     offset of ~1e-7 rad per sample that the loop turns into a standing phase offset of ~5e-4 rad -- an evaluation in
-//     higher precision misses the reference by that much (tools/pll_fixed_point.py);
+//   * the pilot PLL -- non-linear: the phase feeds the sine look-up that corrects it -- by Newton's method on the f32 trajectory of the
+//     whole segment while the pilot is comfortably in lock, and on the reference's own sequential trajectory everywhere a lock decision
+//     can fall (and everywhere for handles of few channels): found without a 1536-step chain by evaluating the segment's pilot periods
+//     side by side from their anchors in [4, 8) -- where every f32 is a multiple of 2^-21, itself a multiple of every ulp of the phase --
+//     and prefix-summing the integer misses of their end points until every run ends on the next run's start (see the kernel).  The step
+//     evaluated is always the reference's own f32 step: its roundings are not noise but a pattern (adding the f32 omega to a phase in
+//     [4, 8) adds omega rounded to that binade's grid), a frequency offset of ~1e-7 rad per sample that the loop turns into a standing
+//     phase offset of ~5e-4 rad -- an evaluation in higher precision misses the reference by that much (tools/pll_fixed_point.py);
 //   * the PSS phase integrator (whose increments are often smaller than half an ulp of the accumulator, so they must be
 //     absorbed exactly as the reference absorbs them): increments evaluated at the segment's first value and summed in
 //     f64, verified against the values found; a segment where that is not yet the trajectory iterates to the EXACT fixed
@@ -375,6 +377,12 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     __shared__ __attribute__((aligned(16))) DecayTab<(PART == 0 ? 4 : 2)> dtab;
     const int ch = blockIdx.x;
     if (ch >= C) return;
+#ifdef SB_POISON_LDS
+    // (diagnostic build: every LDS word a NaN pattern before anything is written -- a read of a word nobody wrote shows in the results)
+    for (int i = threadIdx.x; i < XF + 2 * FB_W; i += FB_T) big[i] = __int_as_float(0x7fc0dead);
+    for (int i = threadIdx.x; i < (int)(sizeof(lds) / 4); i += FB_T) reinterpret_cast<int *>(&lds)[i] = 0x7fc0dead;
+    __syncthreads();
+#endif
     WG wg; wg.L = &lds; wg.tid = threadIdx.x; wg.lane = threadIdx.x & 63; wg.wv = threadIdx.x >> 6; wg.sl = 0;
     const ChanParams &P = B.params[ch];
     ChanState *st = B.state + ch;
@@ -505,6 +513,17 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             float2 lim[FB_K + 2];                                // limited samples j0-2 .. j0+K-1 (the two in front recomputed: cheaper
 #pragma unroll                                                   // than an exchange through LDS with its two barriers)
             for (int t = 0; t < FB_K + 2; t++) lim[t] = (!FAST && zn[t].x != zn[t].x) ? make_float2((float)0.01, (float)0.01) : limiter_fast(zn[t]);
+            // Handles that are asked for the reference's own values (pll_seq 1: up to 64 channels) take the limiter and the discriminators with
+            // the reference's divisions and its f64 square root: the short forms above agree with them to an ulp, which moves a table index by
+            // one entry in one sample of some ten thousand (7.9e-5 of the demodulator's scale at that sample).
+            bool exact_disc = false;
+            if constexpr (EXACT) {
+                exact_disc = P.pll_seq == 1;
+                if (exact_disc) {
+#pragma unroll
+                    for (int t = 0; t < FB_K + 2; t++) lim[t] = (!FAST && zn[t].x != zn[t].x) ? make_float2((float)0.01, (float)0.01) : limiter(zn[t]);
+                }
+            }
             SB_FT(2);
             // (one loop per decoder: the six table gathers of a thread are issued back to back, not one per branch arm)
             if (decoder == 5) {                                      // REAL_BB :174-182
@@ -525,7 +544,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                     const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
                     const float Scaler = (float)1.4142135623730951;
                     const float r = (I1 * (Q - lim[i].y) - Q1 * (I - lim[i].x));
-                    res[i] = fdiv_fast(r, (I1 * I1 + Q1 * Q1) * Scaler);
+                    res[i] = exact_disc ? r / ((I1 * I1 + Q1 * Q1) * Scaler) : fdiv_fast(r, (I1 * I1 + Q1 * Q1) * Scaler);
                 }
             } else {                                                 // MIXED :168-172 (COMPLEX_BB is bitwise the same)
                 AtanArmF arm[FB_K];
@@ -542,6 +561,13 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 SB_FTW(4);
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) res[i] = arm[i].A + (arm[i].neg ? -tv[i] : tv[i]);
+                if (exact_disc) {                                    // (compAtan::atan2 with the reference's division, Xtan2.cpp:56-100)
+#pragma unroll
+                    for (int i = 0; i < FB_K; i++) {
+                        const float I = lim[i + 2].x, Q = lim[i + 2].y, I1 = lim[i + 1].x, Q1 = lim[i + 1].y;
+                        res[i] = lut_atan2(T.atan_ppy, Q * I1 - I * Q1, I * I1 + Q * Q1);
+                    }
+                } else
                 if (__any(odd)) {                                    // (x = 0, an infinity, a NaN: the general form for the thread's samples)
 #pragma unroll
                     for (int i = 0; i < FB_K; i++) {
@@ -567,6 +593,34 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             for (int i = 0; i < FB_K; i++) Lt = c1 * Lt + fmDcAlpha * res[i];
             float afc_next;
             float afc = wg.decay_incoming2(Lt, cy.afc, load_decay(&dtab, DEC_AFC, lane), &afc_next);
+            bool afc_exact = false;
+            if constexpr (EXACT) {
+                // Handles that are asked for the reference's trajectories (pll_seq 1: up to 64 channels): the scan above gives the state in
+                // front of this thread's six samples to ~1e-7 of it, summed in another order than the reference's sample-by-sample walk --
+                // 6e-6 x |afc| of wander, 1e-4 of the demodulator's scale for a signal whose mean phase step is ~1 rad.
+                // The recurrence forgets a shift of its state at 1e-4 per sample, i.e. a shift by a few ulps rides through a thread's six
+                // samples unchanged (unless it flips a rounding: 6e-4 per ulp and run): every thread runs its samples from its incoming
+                // value, the end values' misses against the next threads' incoming values are prefix-summed into corrections, and the
+                // passes repeat until every run ends on the next run's start -- the chain from the exact cy.afc is then the sequential one.
+                if (P.pll_seq == 1) {
+                    const float afc0 = cy.afc;
+                    for (int pass = 0; pass < 8; pass++) {
+                        float o = afc;
+#pragma unroll
+                        for (int i = 0; i < FB_K; i++) if (i < nv) o = c1 * o + fmDcAlpha * res[i];
+                        float po = dppf<0x138, 0xf>(0.f, o);
+                        if (lane == 63) lds.wf[wg.sl][wg.wv][2] = o;
+                        __syncthreads();
+                        if (lane == 0) po = wg.wv ? lds.wf[wg.sl][(wg.wv + 3) & 3][2] : afc0;
+                        wg.sl ^= 1;
+                        const double d = (nv >= 1) ? (double)po - (double)afc : 0.0;
+                        double total; bool any;
+                        const double pre = wg.excl_add_d(d, &total, d != 0.0, &any);
+                        if (!any) { afc_exact = true; break; }
+                        afc = (float)((double)afc + (pre + d));
+                    }
+                }
+            }
             float afc_end = 0.f;
             const float K_FM = T.K_FM, K_FM_rcp = T.K_FM_rcp;
 #pragma unroll
@@ -577,7 +631,8 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 if (i == ix && i < nv) st->meta_dc_if = afc;                 // get_demodDcComponent () at the snapshot
             }
             if (lastseg && owner) st->fm_afc = afc_end;
-            if (tid == 0) cy.afc = afc_next;
+            if (afc_exact) { if (owner) cy.afc = afc_end; }          // (the chain's own end value: read again behind the next segment's barriers)
+            else if (tid == 0) cy.afc = afc_next;
         }
         } else {
             // (demodulator output of the pre-pass: row r of this call, channel ch, in the 16-row tiles of w_osc)

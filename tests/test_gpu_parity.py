@@ -421,6 +421,7 @@ def test_mixed_decoders_in_one_batch_equal_single_channel_runs(fmx_amd, ol):
     for k, c in first.items():
         g = fmx_amd.Fmx(1, max_block=block)
         g.set_param(M.P_FILTER_RESTARTS, 2)            # the batch's filter structure (a handle this small runs the reference's block filters by default)
+        g.set_param(M.P_PLL_SOLVER, 2)                 # ... and the batch's solvers (a handle this small walks the PLL and the AFC as the reference does)
         gui_defaults(g, 165000, True)
         apply(g, c, 0)
         assert np.array_equal(run_blocks(g, iq, block)[0], pcm[c]), k

@@ -188,7 +188,19 @@ def test_creeping_pilots_at_batch_scale(fmx_amd, ol):
             ups[k] += 1 if a.live_pilot_locked > prev[k] else 0
             prev[k] = a.live_pilot_locked
         ref4 = pg[:nst]
-        assert np.array_equal(pg.reshape(nch // nst, nst, -1, 2), np.broadcast_to(ref4, (nch // nst,) + ref4.shape))
+        same = (pg.reshape(nch // nst, nst, -1) == ref4.reshape(1, nst, -1)).all(axis=2)
+        if not same.all():                                   # (say where: a channel that differs from its twin is a race or a stray read)
+            bad = np.argwhere(~same)
+            c = int(bad[0][0] * nst + bad[0][1])
+            nt = f.last_fm_samples()
+            where = []
+            for name, tap in (("fm IQ", M.TAP_FM_IQ), ("demod", M.TAP_DEMOD), ("pilot phase", M.TAP_PILOT_PHASE), ("LR raw", M.TAP_LR_RAW)):
+                ta, tb = f.tap(tap, nt, c), f.tap(tap, nt, c % nst)
+                wz = np.flatnonzero((ta != tb).reshape(nt, -1).any(axis=1))
+                where.append("%s %s" % (name, "same" if len(wz) == 0 else "first at fm sample %d of %d (%d differ, max %.2e)" % (wz[0], nt, len(wz), float(np.abs(ta - tb).max()))))
+            wf = np.flatnonzero((pg[c] != pg[c % nst]).any(axis=1))
+            raise AssertionError("call %d: %d channels differ from their twins, e.g. %d vs %d: PCM frames %d..%d; %s; channels %s"
+                                 % (len(worst) and blocks.index(b), len(bad), c, c % nst, wf[0], wf[-1], "; ".join(where), [int(x[0] * nst + x[1]) for x in bad[:12]]))
     ex = f.pll_exact_segments()
     print(f"\n[creeping pilots, {nch} channels] worst call per stream: {' '.join('%.1e' % v for v in worst)}; lock acquisitions {ups}; "
           f"guard: {ex / nch:.0f} of {sum(-(-(b // 12) // 1536) for b in blocks)} segments per channel sequential; fail-safe replays {f.pll_replays()}")
