@@ -19,7 +19,7 @@ Extra legs on rank 0 at N = 1 (reported as extra keys; the headline `value` stay
   sustained      the same step loop for >= --sustain seconds
   host_ingest    raw uint8 / float32 IQ from PINNED host memory, double-buffered: the copy of step k+1 overlaps the
                  processing of step k (PCIe-inclusive rates)
-  host_call      latency of the single-receiver drop-in call: 1 channel, 16384 samples, fmx_process_host
+  host_call      latency of the single-receiver drop-in call: 1 channel, 16384 samples, fmx_process_host (in a process of its own)
   cpu_baseline   the oracle (a port) on the host cores; with oracle/_ref present also the reference's own leaf classes
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config4|shard512|config2|config3|config5]
@@ -338,7 +338,12 @@ def main():
     ap.add_argument("--stride-pad", type=int, default=0,
                     help="complex samples of padding between consecutive streams in the IQ buffer (even)")
     ap.add_argument("--selftest-spawn", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--host-call-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.host_call_only:                      # the host_call leg's own process: a receiver's, nothing else on the device
+        import importlib
+        print(json.dumps(host_call_latency(importlib.import_module("sdr-j-fm_amd"), int(os.environ.get("LOCAL_RANK", "0")))))
+        return
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.quick:
@@ -664,7 +669,7 @@ def main():
         del f
         torch.cuda.empty_cache()
         out["host_ingest"] = host_ingest_legs(torch, fmx_amd, configure, args, device, local_rank, n, streams, smap)
-        out["host_call"] = host_call_latency(fmx_amd, local_rank)
+        out["host_call"] = host_call_leg(fmx_amd, local_rank)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
@@ -761,6 +766,22 @@ def host_ingest_legs(torch, fmx_amd, configure, args, device, local_rank, n, str
             res[name] = {"error": str(e)[:200]}
     res["what"] = ("pinned host IQ -> H2D copy on one stream, fmx_process_device_raw on another, two device buffers "
                    "(copy of step k+1 overlaps step k); PCIe-inclusive, never the headline value")
+    return res
+
+
+def host_call_leg(fmx_amd, local_rank):
+    """host_call_latency in a process of its own -- what a receiver is: one handle, one stream, no other work on the device -- and, beside it,
+    in this process, where the batch handles' streams and PyTorch's are alive (every copy and wait of the call then negotiates with them)."""
+    here = host_call_latency(fmx_amd, local_rank)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-call-only"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, LOCAL_RANK=str(local_rank)))
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return dict(here, note="own-process run failed: %s" % str(e)[:120])
+    if "error" not in res:
+        res["process"] = "its own (one handle, nothing else on the device: the receiver's situation)"
+        res["ms_median_inside_the_bench_process"] = here.get("ms_median")
     return res
 
 

@@ -508,9 +508,11 @@ def test_discriminator_corner_arguments_of_the_atan_table(fmx_amd, ol):
             worst = max(worst, float(np.abs(d_g - d_o).max()))
         pg, po = np.concatenate(pg), np.concatenate(po)
         print(f"\n[atan corners, decoder {dec}] demodulator output max |diff| {worst:.2e} (full scale {np.abs(o.tap(ol.TAP_DEMOD)).max():.2f}), PCM rms {rms(pg - po):.2e}")
-        # (a wrong corner would be off by pi/2 or more = 2.4 of the demodulator's scale; what is left is the AFC average of this heavily
-        # biased signal -- |afc| ~ 1 rad -- summed in another order by the time-parallel scan: ~6e-6 rad, 1e-5 .. 1e-4 after the scaling)
-        assert worst <= 3e-4 and rms(pg - po) <= PCM_RMS_TOL
+        # (a wrong corner would be off by pi/2 or more = 2.4 of the demodulator's scale.  Round 3 allowed 3e-4 here: the AFC average of this
+        # heavily biased signal -- |afc| ~ 1 rad -- was summed in another order by the time-parallel scan (~6e-6 rad, 1e-4 after the scaling),
+        # and the short forms of the limiter / table-index divisions moved a table index by one entry in a sample of some ten thousand (7.9e-5).
+        # A handle this small now walks the AFC as the reference does and takes the reference's divisions: measured 0.0 -- bit-identical.)
+        assert worst <= 2e-5 and rms(pg - po) <= PCM_RMS_TOL
 
 
 MID_ORDER = [dict(inputFilterBw=0), dict(inputFilterBw=120000), dict(lfCutoff=12000), dict(lfCutoff=0), dict(lfCutoff=15000), dict(inputFilterBw=165000),
