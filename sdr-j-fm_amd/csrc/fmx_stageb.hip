@@ -1234,6 +1234,10 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             }
             wg.reduce_max4(firstU, firstZ, anyl, alll);
         }
+        // (every thread read cy.calls in front of the barrier above; the next segment reads it again at its very top -- in the second
+        // kernel with no barrier in front of that read, so the count is stored HERE, with the integrator's barriers still to come, and
+        // not behind the segment's last barrier, where a wave that runs ahead into the next segment could still see the old one)
+        if (tid == 0) cy.calls = calls_before + ncalls;
 
         SB_FT(21);
         // ================= PSS integrator (stereo-separation.cpp:84-109, fm-processor.cpp:699-718) =================
@@ -1469,7 +1473,6 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             const int jb = (int)((G.J0 + seg0 + j0) & dmask);
 #pragma unroll
             for (int i = 0; i < FB_K; i++) if (i < nv) dr[(jb + i) & dmask] = x[i];
-            if (tid == 0) cy.calls = calls_before + ncalls;
         } else
         {
             const float a = P.deemph_alpha;
@@ -1490,7 +1493,6 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 yl = fmaf(dw.dl, Cl, lane_prev_f(Zl, 0.f)); yr = fmaf(dw.dl, Cr, lane_prev_f(Zr, 0.f));
             }
             SB_FT(31);
-            if (tid == 0) cy.calls = calls_before + ncalls;          // (the mix above was the last reader; a barrier in between)
             const int dmask = G.dring_mask;
             float2 *dr = B.dring + (size_t)ch * (dmask + 1);
             const int jb = (int)((G.J0 + seg0 + j0) & dmask);
