@@ -3,7 +3,7 @@
 fmx_process_device as tests/test_gpu_parity.py::test_full_size_config4_device_path), handles created and destroyed in a loop, each run
 through pilot acquisition; every call every channel's PCM is compared with channel c % 4's on the device.  On a mismatch: channel, call,
 and the first tap (fm IQ / demodulator / pilot phase / L-R raw / pre-resampler) in which the channel differs from its twin.
-usage: python tools/diag/flake_hunt.py [runs] [calls per run] [block]"""
+usage: python tools/diag/flake_hunt.py [runs] [calls per run] [block] [channels] [rds 0|1] [stage-B form 0 auto|1 one kernel|2 two]"""
 import importlib, os, sys, time
 import numpy as np
 import torch
@@ -14,9 +14,11 @@ pkg = importlib.import_module("sdr-j-fm_amd"); M = pkg.fmx
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 block = int(sys.argv[3]) if len(sys.argv) > 3 else 230400
-C = 4096
+C = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+rds = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+form = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 dev = torch.device("cuda", 0)
-base = np.stack([ol.synth_iq(block * calls, leftHz=300.0 + 370 * j, rightHz=500.0 + 530 * j) for j in range(4)])
+base = np.stack([ol.synth_iq(block * calls, leftHz=300.0 + 370 * j, rightHz=500.0 + 530 * j, **(dict(rds=1, rdsLevel=0.05, rdsBitsSeed=12345 + j) if rds else {})) for j in range(4)])
 d_base = torch.from_numpy(base).to(dev)
 cap = block // 48 + 96
 d_pcm = torch.zeros((C, cap, 2), dtype=torch.float32, device=dev)
@@ -27,6 +29,8 @@ for r in range(runs):
     f = pkg.Fmx(C, max_block=block, device=0)
     for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FM_MODE, 0), (M.P_FM_DECODER, 3)):
         f.set_param(pid, v)
+    if rds: f.set_param(M.P_RDS_MODE, 2)
+    if form: f.set_param(M.P_STAGEB_FORM, form)
     for i in range(calls):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -51,5 +55,11 @@ for r in range(runs):
             w = np.flatnonzero((pa != pb).any(axis=1))
             print("run %d call %d: %d channels differ %s; channel %d: PCM frames %d..%d (%d), max %.2e; %s; exact segs %d replays %d"
                   % (r, i, nb, chans, c, w[0], w[-1], len(w), float(np.abs(pa - pb).max()), "; ".join(msg), f.pll_exact_segments(), f.pll_replays()), flush=True)
+    if rds:
+        bits = [f.rds_bits(c, 8192) for c in range(C)]
+        badb = [c for c in range(4, C) if not np.array_equal(bits[c], bits[c % 4])]
+        if badb:
+            bad_total += len(badb)
+            print("run %d: RDS bits of %d channels differ from their twins: %s (lengths %s vs %d)" % (r, len(badb), badb[:12], [len(bits[c]) for c in badb[:4]], len(bits[0])), flush=True)
     del f
 print("runs %d, calls %d each, %.0f s: (channel, call) pairs with a mismatch: %d" % (runs, calls, time.time() - t0, bad_total))
