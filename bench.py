@@ -341,7 +341,6 @@ def main():
     ap.add_argument("--host-call-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.host_call_only:                      # the host_call leg's own process: a receiver's, nothing else on the device
-        import importlib
         print(json.dumps(host_call_latency(importlib.import_module("sdr-j-fm_amd"), int(os.environ.get("LOCAL_RANK", "0")))))
         return
     if args.gpus < 1:

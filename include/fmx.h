@@ -108,6 +108,10 @@ typedef enum {
                                   (handles of up to 64 channels); 2 = folded into stage A's / stage C's polyphase FIRs -- the same filters
                                   wherever the settings were made before the first call, a different glitch of one filter latency behind a
                                   change in mid-stream (what large batches run); 0 = automatic (default): 1 up to 64 channels, 2 above */
+    FMX_P_FRONT_PARTS = 24,    /* (handle-wide: the channel argument is ignored) the input-filter stage runs one workgroup per channel; a handle with
+                                  fewer channels than the GPU has workgroup slots splits every channel's call in time over several workgroups
+                                  (each later one recomputes one 1536-sample tile to get its filter history): 0 = automatic (default), 1 = never,
+                                  2..32 = that many parts wherever a call is long enough.  The results are bit-identical. */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */

@@ -107,6 +107,7 @@ struct fmx_handle_s {
     int64_t last_m0 = 0, last_m1 = 0;       // 24 kS/s outputs of the last call
     std::vector<void *> rds_ptrs, tail_ptrs;
     std::atomic<int> stageb_form{0};     // FMX_P_STAGEB_FORM
+    std::atomic<int> front_parts{0};     // FMX_P_FRONT_PARTS
     // the reference's two overlap-add filters as the block machines they are (fmx_ola.hip): handles of up to OLA_MAX_CH channels
     bool ola_mode = false;               // FMX_P_FILTER_RESTARTS resolved (fixed once the first call has been made)
     struct OlaSide {
@@ -647,6 +648,37 @@ void frames_geom(const fmx_handle h, int64_t n, CallGeom *G) {
 // frames the second converter has put out after `in` frames at the working rate: outputs m with m q < in p
 int64_t conv2_out(const fmx_handle h, int64_t in) { return h->cv_nt ? (in * h->cv_p + h->cv_q - 1) / h->cv_q : in; }
 
+// Stage A runs one workgroup per channel, two per CU: a handle with fewer channels than that leaves compute units idle while each workgroup
+// walks its channel's tiles one after the other.  Such a call splits every channel in time (fmx_front.hip, CallGeom::parts): as many parts as
+// fill the chip, none shorter than FRONT_MIN_PART_TILES tiles (every later part computes one tile twice).  The results are the same bit for bit.
+constexpr int FRONT_MIN_PART_TILES = 6, FRONT_MAX_PARTS = 32, FRONT_TILE = 128 * DECIM;
+int front_parts_for(fmx_handle h, CallGeom &G) {
+    G.parts = 1; G.part_tiles = 0; G.streams = h->streams;
+    const int want = h->front_parts.load();
+    if (h->twins != 1 || want == 1) return FMX_OK;
+    const int64_t r0 = G.g0 % DECIM;
+    const int NT = (int)((r0 + G.n - 1) / FRONT_TILE) + 1;
+    int parts = want > 1 ? want : (2 * h->n_cus) / h->channels;
+    if (want <= 1 && parts > NT / FRONT_MIN_PART_TILES) parts = NT / FRONT_MIN_PART_TILES;
+    if (parts > FRONT_MAX_PARTS) parts = FRONT_MAX_PARTS;
+    if (parts > NT / 2) parts = NT / 2;              // (forced: at least two tiles per part)
+    if (parts < 2) return FMX_OK;
+    const int pt = (NT + parts - 1) / parts;
+    parts = (NT + pt - 1) / pt;
+    if (parts < 2) return FMX_OK;
+    if (!h->B.fsnap) {
+        const size_t C = (size_t)h->channels;
+        h->B.dc_pitch = (int32_t)(h->cfg.max_block / FRONT_TILE + 2);
+        HIPCHK(hipMalloc(&h->B.dc_tiles, sizeof(float4) * 2 * (size_t)h->streams * h->B.dc_pitch));
+        HIPCHK(hipMalloc(&h->B.fsnap, sizeof(FrontSnap) * C));
+        HIPCHK(hipMalloc(&h->B.hist_snap, sizeof(float2) * C * DECIM * A_HIST_COLS));
+        HIPCHK(hipMalloc(&h->B.dcv_snap, sizeof(float2) * C * DCV_SAVE));
+        for (void *p : {(void *)h->B.dc_tiles, (void *)h->B.fsnap, (void *)h->B.hist_snap, (void *)h->B.dcv_snap}) h->tail_ptrs.push_back(p);
+    }
+    G.parts = parts; G.part_tiles = pt;
+    return FMX_OK;
+}
+
 int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
              int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
     if (fmt < 0 || fmt > 3) return fail(FMX_E_INVALID, "unknown IQ format");
@@ -674,6 +706,8 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
     }
     g_launch_err = hipSuccess;
     h->B.lin_rows = (int32_t)h->work_nj;
+    rc = front_parts_for(h, G);
+    if (rc) return rc;
     if (h->ola_mode) {
         // few channels: RF DC removal / balance / LO mix per sample, the input filter as the reference's block machine, then the decimators
         OlaBuffers O{}; O.src = h->d_v; O.dst = h->d_u; O.src_stride = O.dst_stride = h->cfg.max_block; O.src_mask = O.dst_mask = -1;
@@ -1095,6 +1129,9 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "squelch mode must be 0 (off), 1 (noise squelch) or 2 (level squelch)"); break;
     case FMX_P_SQUELCH_VALUE: if (iv < 0 || iv > 100) return fail(FMX_E_INVALID, "squelch value must be 0..100"); break;
     case FMX_P_PLL_SOLVER: if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "PLL solver must be 0 (automatic), 1 (sequential), 2 (Newton, sequential around lock decisions) or 3 (Newton always)"); break;
+    case FMX_P_FRONT_PARTS:
+        if (iv < 0 || iv > 32) return fail(FMX_E_INVALID, "front parts must be 0 (automatic), 1 (one workgroup per channel) or 2..32");
+        h->front_parts.store(iv); return FMX_OK;
     case FMX_P_STAGEB_FORM:
         if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "stage B form must be 0 (automatic), 1 (one kernel) or 2 (two kernels)");
         h->stageb_form.store(iv); return FMX_OK;

@@ -68,6 +68,112 @@ __device__ __forceinline__ Aff aff_then(const Aff &f, const Aff &g) {      // ap
     return o;
 }
 
+// one tile's map applied to the state in front of it (the same expression wherever the chain is walked: the workgroup that owns the tile,
+// and the workgroups of later parts of a channel that is split in time, which walk the maps of the tiles in front of their own)
+__device__ __forceinline__ float dc_chain(float c, float tu, float ta) { return fmaf(-c, tu, c) + ta; }
+
+#ifndef FMX_WAVE_SHR
+#define FMX_WAVE_SHR 1   /* 0: ds_bpermute (__shfl_up) for the one-lane shift of the scan (A/B builds) */
+#endif
+// constants of the wave scan of full tiles: every lane's run of 24 samples has the same u, so the scan of u is known in advance -- u_exc = u of
+// `lane` runs, u_tile = u of 64 runs -- and only the `a` parts are scanned: a <- a + a_earlier * m with m = (1 - u)^(runs the lane's partial
+// result covers), a constant per scan step (m1, m2, m4, m8) or per lane (mA, mB)
+struct DcK { float alpha, u_full, m1, m2, m4, m8, u_exc, u_tile, mA, mB; };
+__device__ __forceinline__ DcK dc_consts(float alpha, int lane) {
+    DcK K; K.alpha = alpha;
+    float u_full = 0.f;                               // u of a full 24-sample run (the same for every such lane)
+    for (int k = 0; k < 2 * DECIM; k++) u_full = (1.0f - u_full) * alpha + u_full;
+    K.u_full = u_full;
+    K.m1 = 1.0f - u_full; K.m2 = K.m1 * K.m1; K.m4 = K.m2 * K.m2; K.m8 = K.m4 * K.m4;
+    float u_exc = 0.f, u_tile = 0.f, mA = 1.f, mB = 1.f;
+    for (int i = 0; i < 64; i++) {
+        if (i < lane) u_exc = u_exc + u_full - u_exc * u_full;
+        u_tile = u_tile + u_full - u_tile * u_full;
+        if (i < (lane & 15) + 1) mA *= K.m1;
+        if (i < (lane & 31) + 1) mB *= K.m1;
+    }
+    K.u_exc = u_exc; K.u_tile = u_tile; K.mA = mA; K.mB = mB;
+    return K;
+}
+// The RF DC recurrence (fm-processor.cpp:423-446) over one tile as an affine map: the lane's run over its 24 samples x[first .. lastp1), the wave
+// scan of the runs; pre = the map of the lanes in front of this one, (tu, tar, tai) = the whole tile's, sA = the sum of the lane's first column
+// (channels without an LO, full tiles).  One function for the kernel and for front_pre_kernel, which tabulates the maps of a stream's tiles.
+struct DcMap { Aff pre; float tu, tar, tai; v2f sA; };
+__device__ __forceinline__ DcMap dc_tile_map(const v2f *x, int first, int lastp1, bool wave_full, bool fast, const DcK &K, int lane) {
+    constexpr int SPT_ = 2 * DECIM;
+    DcMap M;
+    const float alpha = K.alpha, u_full = K.u_full;
+    Aff a; a.u = 0.f;
+    v2f aa = (v2f){0.f, 0.f};
+    const v2f al = (v2f){alpha, alpha};
+    v2f sA = (v2f){0.f, 0.f};                 // fast path: sum of the lane's first column
+    if (wave_full && fast) {
+        v2f t4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) t4[j] = (x[6 * j] + x[6 * j + 1]) + (x[6 * j + 2] + x[6 * j + 3]) + (x[6 * j + 4] + x[6 * j + 5]);
+        sA = t4[0] + t4[1];
+        aa = al * (sA + (t4[2] + t4[3]));
+        a.u = u_full;
+    } else if (wave_full) {
+#pragma unroll
+        for (int k = 0; k < SPT_; k++) aa = __builtin_elementwise_fma(x[k] - aa, al, aa);
+        a.u = u_full;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SPT_; k++) {
+            if (k >= first && k < lastp1) {
+                a.u = (1.0f - a.u) * alpha + a.u;
+                aa = __builtin_elementwise_fma(x[k] - aa, al, aa);
+            }
+        }
+    }
+    Aff pre;                                  // exclusive prefix within the tile
+    float tu, tar, tai;                       // the whole tile's map
+    if (wave_full) {
+        // inclusive scan of the a parts with DPP: four steps inside the 16-lane rows, then the row totals
+        // ride row_bcast:15 (into rows 1, 3) and row_bcast:31 (into rows 2, 3)
+        float sr = aa.x, si = aa.y;
+#define FMX_SCAN_STEP(ctrl, rmask, mm)                                                                                       \
+        {                                                                                                        \
+            const float er = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), ctrl, rmask, 0xf, false)); \
+            const float ei = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), ctrl, rmask, 0xf, false)); \
+            sr = fmaf(er, mm, sr); si = fmaf(ei, mm, si);                                                        \
+        }
+        FMX_SCAN_STEP(0x111, 0xf, K.m1)
+        FMX_SCAN_STEP(0x112, 0xf, K.m2)
+        FMX_SCAN_STEP(0x114, 0xf, K.m4)
+        FMX_SCAN_STEP(0x118, 0xf, K.m8)
+        FMX_SCAN_STEP(0x142, 0xa, K.mA)
+        FMX_SCAN_STEP(0x143, 0xc, K.mB)
+#undef FMX_SCAN_STEP
+#if FMX_WAVE_SHR
+        // exclusive prefix = the inclusive one of the lane to the left: wave_shr:1 (DPP, lane 0 gets the zero of `old`)
+        pre.ar = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x138, 0xf, 0xf, false));
+        pre.ai = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x138, 0xf, 0xf, false));
+#else
+        pre.ar = __shfl_up(sr, 1, 64); pre.ai = __shfl_up(si, 1, 64);
+        if (lane == 0) { pre.ar = 0.f; pre.ai = 0.f; }
+#endif
+        pre.u = K.u_exc;
+        tu = K.u_tile;
+        tar = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sr), 63));
+        tai = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(si), 63));
+    } else {
+        a.ar = aa.x; a.ai = aa.y;
+        Aff inc = a;                          // general inclusive scan (first / last tile of a call)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            Aff o; o.u = __shfl_up(inc.u, d, 64); o.ar = __shfl_up(inc.ar, d, 64); o.ai = __shfl_up(inc.ai, d, 64);
+            if (lane >= d) inc = aff_then(o, inc);
+        }
+        pre.u = __shfl_up(inc.u, 1, 64); pre.ar = __shfl_up(inc.ar, 1, 64); pre.ai = __shfl_up(inc.ai, 1, 64);
+        if (lane == 0) { pre.u = 0.f; pre.ar = 0.f; pre.ai = 0.f; }
+        tu = __shfl(inc.u, 63, 64); tar = __shfl(inc.ar, 63, 64); tai = __shfl(inc.ai, 63, 64);
+    }
+    M.pre = pre; M.tu = tu; M.tar = tar; M.tai = tai; M.sA = sA;
+    return M;
+}
+
 #ifndef FMX_EARLY_PREFETCH
 #define FMX_EARLY_PREFETCH 1
 #endif
@@ -77,9 +183,6 @@ __device__ __forceinline__ Aff aff_then(const Aff &f, const Aff &g) {      // ap
 #endif
 #ifndef FMX_WG_PER_CU
 #define FMX_WG_PER_CU 2
-#endif
-#ifndef FMX_WAVE_SHR
-#define FMX_WAVE_SHR 1   /* 0: ds_bpermute (__shfl_up) for the one-lane shift of the scan (A/B builds) */
 #endif
 #ifndef FMX_ABL
 #define FMX_ABL 0      /* diagnostic builds only (tools/ablate_front.sh): bit 0 no scatter, 1 no DC/mix pass, 2 no FIR */
@@ -148,6 +251,10 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
 
     // (twins: G.twins workgroups per channel, twin tw computes the outputs of phase tw -- see CallGeom::twins)
     const int vc = blockIdx.x;
+    // (a channel split in time, CallGeom::parts: workgroup `part` of the channel stores the outputs of tiles tA .. t_end - 1; a part behind the
+    // first begins one tile early -- a warm-up tile whose outputs nobody stores: its DC-corrected / mixed columns are the history of tile tA,
+    // its RfDC boundaries the ones tile tA's outputs look back to --, with the DC state the maps of front_pre_kernel give it)
+    const int NP = (G.parts > 1 && G.twins == 1) ? G.parts : 1, part = NP > 1 ? (int)blockIdx.y : 0;
     const int TW = G.twins;
     const int ch = TW == 1 ? vc : vc / TW;
     const int tw = vc - ch * TW;
@@ -165,6 +272,11 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     const float qs = G.iq_scale;
     ChanState *st = tw == 0 ? B.state + ch : B.state_tw + (size_t)(tw - 1) * G.channels + ch;
     float2 *hist = B.hist + (size_t)vc * DECIM * A_HIST_COLS;
+    // the state in front of the call: the live one, or -- when the channel's last part may rewrite it before this part has started -- its snapshot
+    FrontSnap sn;
+    if (NP > 1) sn = B.fsnap[vc]; else { sn.lo_phase = st->lo_phase; sn.hist_fmt = st->hist_fmt; sn.dc_re = st->dc_re; sn.dc_im = st->dc_im; }
+    const float2 *histR = NP > 1 ? B.hist_snap + (size_t)vc * DECIM * A_HIST_COLS : hist;
+    const float2 *dcvR = (NP > 1 ? B.dcv_snap : B.dcv_hist) + (size_t)vc * DCV_SAVE;
     float2 *zring = B.zring + (size_t)ch * (G.ring_mask + 1);
 
     const int off = FS.off, nd = FS.nd;
@@ -176,6 +288,8 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     const int jb = (int)((G.g0 + G.n - off + 11) / 12 - qa);      // one past the last
     const int qb = (gend - 1) / 12;                   // column holding the last fresh sample
     const int NT = qb / WCOLS + 1;                    // wave tiles in this call
+    const int tA = part * G.part_tiles, t_first = part > 0 ? tA - 1 : 0;
+    const int t_end = (part + 1 == NP) ? NT : (tA + G.part_tiles < NT ? tA + G.part_tiles : NT);
     const int zr0 = (int)(((qa + FS.zshift) * TW + tw) & (int64_t)G.ring_mask);      // ring position of this twin's output column qa
 
     for (int i = t; i < A_TAPS_DEV; i += NTHR) sT[i] = T.front_taps[(size_t)(P.front_set + tw) * A_TAPS_DEV + i];
@@ -195,22 +309,22 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     // stopped at), so the reference multiplies every sample by that constant -- which commutes with the real-tap filters and rides with
     // the complex output gain here.
     const bool lo_on = (P.lo_freq != 0) && (T.lo_table != nullptr);
-    const float2 R0 = (!pp && !lo_on && T.lo_table != nullptr && st->lo_phase != 0) ? T.lo_table[st->lo_phase] : make_float2(1.f, 0.f);
+    const float2 R0 = (!pp && !lo_on && T.lo_table != nullptr && sn.lo_phase != 0) ? T.lo_table[sn.lo_phase] : make_float2(1.f, 0.f);
     const bool dc_rst0 = (P.actions & ACT_DC_RESET) != 0;
-    const float2 R0h = (lo_on && st->hist_fmt == 0 && st->lo_phase != 0) ? T.lo_table[st->lo_phase] : make_float2(1.f, 0.f);   // (what the raw history was read with)
-    const bool hist_convert = lo_on && (st->hist_fmt == 0) && (P.dc_remove != 0 || P.att_l != 1.0f || P.att_r != 1.0f || dc_rst0 || st->lo_phase != 0);
-    const bool hist_to_raw = !pp && !lo_on && (st->hist_fmt == 1);
-    const bool hist_rst = !lo_on && (st->hist_fmt == 0) && dc_rst0;
+    const float2 R0h = (lo_on && sn.hist_fmt == 0 && sn.lo_phase != 0) ? T.lo_table[sn.lo_phase] : make_float2(1.f, 0.f);   // (what the raw history was read with)
+    const bool hist_convert = lo_on && (sn.hist_fmt == 0) && (P.dc_remove != 0 || P.att_l != 1.0f || P.att_r != 1.0f || dc_rst0 || sn.lo_phase != 0);
+    const bool hist_to_raw = !pp && !lo_on && (sn.hist_fmt == 1);
+    const bool hist_rst = !lo_on && (sn.hist_fmt == 0) && dc_rst0;
     const float2 dc_now = (dc_rst0 || P.dc_remove == 0) ? make_float2(0.f, 0.f)
-                                                        : make_float2(__builtin_amdgcn_fmed3f(st->dc_re, -0.01f, 0.01f), __builtin_amdgcn_fmed3f(st->dc_im, -0.01f, 0.01f));
-    if (wave == 0) {
+                                                        : make_float2(__builtin_amdgcn_fmed3f(sn.dc_re, -0.01f, 0.01f), __builtin_amdgcn_fmed3f(sn.dc_im, -0.01f, 0.01f));
+    if (wave == 0 && part == 0) {
         for (int i = lane; i < DECIM * A_HIST_COLS; i += 64) {
             int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;
-            float2 v = hist[i];
+            float2 v = histR[i];
             if (c == HL && r >= r0) v = make_float2(0.f, 0.f);
             else if (hist_convert || hist_rst) {
                 const int tb = c - HL + 13;
-                const float2 d = B.dcv_hist[(size_t)vc * DCV_SAVE + (tb < 0 ? 0 : tb)];
+                const float2 d = dcvR[tb < 0 ? 0 : tb];
                 v.x -= __builtin_amdgcn_fmed3f(d.x, -0.01f, 0.01f);
                 v.y -= __builtin_amdgcn_fmed3f(d.y, -0.01f, 0.01f);
                 if (hist_convert) { v.x *= P.att_l; v.y *= P.att_r; v = make_float2(v.x * R0h.x - v.y * R0h.y, v.x * R0h.y + v.y * R0h.x); }
@@ -223,12 +337,28 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
         }
     }
     // RfDC in front of the 13 columns before this call's first column and of that column itself (ring slots -13 .. 0)
-    if (t < 14 && !lo_on) dcv[(t - 13) & (DCV_N - 1)] = (hist_to_raw || hist_rst) ? make_float2(dc_rst0 ? 0.f : st->dc_re, dc_rst0 ? 0.f : st->dc_im)
-                                                                                 : B.dcv_hist[(size_t)vc * DCV_SAVE + t];
+    if (t < 14 && !lo_on && part == 0) dcv[(t - 13) & (DCV_N - 1)] = (hist_to_raw || hist_rst) ? make_float2(dc_rst0 ? 0.f : sn.dc_re, dc_rst0 ? 0.f : sn.dc_im)
+                                                                                              : dcvR[t];
     // per-channel state is read by every wave BEFORE the barrier (the wave that ends the call rewrites it)
-    const int lo_phase0 = st->lo_phase;
+    const int lo_phase0 = sn.lo_phase;
     const bool dc_rst = (P.actions & ACT_DC_RESET) != 0;          // setDCRemove zeroes RfDC (:922-925)
-    const float dc0r = dc_rst ? 0.f : st->dc_re, dc0i = dc_rst ? 0.f : st->dc_im;
+    const float dc0r = dc_rst ? 0.f : sn.dc_re, dc0i = dc_rst ? 0.f : sn.dc_im;
+    // a later part: the DC state in front of its warm-up tile = the maps of the stream's tiles 0 .. t_first - 1 applied to the call's, one
+    // after the other as the workgroup of one part walks them (the values are the same bit for bit)
+    if (part > 0 && P.dc_remove != 0 && wave == 0) {
+        const float4 *mp = B.dc_tiles + (size_t)P.stream * B.dc_pitch * 2 + (lo_on ? 1 : 0);
+        float cr = dc0r, ci = dc0i;
+        for (int b = 0; b < t_first; b += 64) {
+            const float4 m = (b + lane < t_first) ? mp[2 * (b + lane)] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int cnt = t_first - b < 64 ? t_first - b : 64;
+            for (int k = 0; k < cnt; k++) {
+                const float tu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.x), k));
+                cr = dc_chain(cr, tu, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.y), k)));
+                ci = dc_chain(ci, tu, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.z), k)));
+            }
+        }
+        if (lane == 0) { carry[(t_first - 1) & 7][0] = cr; carry[(t_first - 1) & 7][1] = ci; carry_seq = t_first; }
+    }
     // ---- LO mix table: LOPhase after sample i of the call is (P0 - (i+1) lo) mod R; when lo / R has a short period p
     //      (channels on a raster: 200 kHz at 2.304 MS/s gives p = 288) the p table entries the call will use sit in LDS,
     //      sLO[m] = T[(P0 - m lo) mod R] with m = (i + 1) mod p, instead of 24 scattered reads of the 18 MB table per lane
@@ -271,19 +401,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
         const int16_t *p = reinterpret_cast<const int16_t *>(inb) + 2 * (size_t)i;
         return make_float2((float)p[0] * qs, (float)p[1] * qs);
     };
-    float u_full = 0.f;                               // u of a full 24-sample run (the same for every such lane)
-    for (int k = 0; k < SPT; k++) u_full = (1.0f - u_full) * alpha + u_full;
-    // Full tiles: every lane's run has the same u, so the scan of u is known in advance -- u_exc = u of `lane` runs,
-    // u_tile = u of 64 runs -- and only the `a` parts are scanned: a <- a + a_earlier * m with m = (1 - u)^(runs the lane's
-    // partial result covers), which is a constant per scan step (m1, m2, m4, m8) or per lane (mA, mB) (DPP scan below).
-    const float m1 = 1.0f - u_full, m2 = m1 * m1, m4 = m2 * m2, m8 = m4 * m4;
-    float u_exc = 0.f, u_tile = 0.f, mA = 1.f, mB = 1.f;
-    for (int i = 0; i < 64; i++) {
-        if (i < lane) u_exc = u_exc + u_full - u_exc * u_full;
-        u_tile = u_tile + u_full - u_tile * u_full;
-        if (i < (lane & 15) + 1) mA *= m1;
-        if (i < (lane & 31) + 1) mB *= m1;
-    }
+    const DcK DK = dc_consts(alpha, lane);
     // history hand-off: the 24 newest columns of this image go straight into the next wave's image (144 float4 units)
     float4 *Xn = Xall[(wave + 1) % NW];
     int ho_src[3], ho_dst[3];
@@ -357,11 +475,11 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     const bool dbg_on = (B.dbg != nullptr) && (t == 0);
     unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
-    if (wave < NT) load_tile(wave);
+    if (t_first + wave < t_end) load_tile(t_first + wave);
     const int dc_unit = (lane & 3) * XS4 + 3 + (lane >> 2);     // this lane's column pair (24 + 2 l, 24 + 2 l + 1), row 0
     FMX_TICK(0);
 
-    for (int ti = wave; ti < NT; ti += NW) {
+    for (int ti = t_first + wave; ti < t_end; ti += NW) {
         const int qt = ti * WCOLS;                    // first column of the tile
         const int wbase = qt * 12;
         // ---- scatter the raw samples into the image
@@ -393,7 +511,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
         __builtin_amdgcn_wave_barrier();              // LDS operations of one wave complete in order
         // ---- prefetch this wave's next tile as soon as the registers are free: the loads are in flight for the whole
         //      iteration (DC pass, hand-off, FIR), so every wave keeps 12 KB of HBM reads outstanding all the time
-        const bool more = (ti + NW < NT);
+        const bool more = (ti + NW < t_end);
 #if FMX_EARLY_PREFETCH
         if (more) load_tile(ti + NW);
 #endif
@@ -418,80 +536,18 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
             //      the previous tile from the mailbox, then the reference's own f32 recurrence
             //      RfDC = (x - RfDC)*alpha + RfDC from the scanned prefix.
             if (dcr) {
-                Aff a; a.u = 0.f;
-                v2f aa = (v2f){0.f, 0.f};
                 const v2f al = (v2f){alpha, alpha};
-                v2f sA = (v2f){0.f, 0.f};                 // fast path: sum of the lane's first column
-                if (wave_full && fast) {
-                    v2f t4[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) t4[j] = (x[6 * j] + x[6 * j + 1]) + (x[6 * j + 2] + x[6 * j + 3]) + (x[6 * j + 4] + x[6 * j + 5]);
-                    sA = t4[0] + t4[1];
-                    aa = al * (sA + (t4[2] + t4[3]));
-                    a.u = u_full;
-                } else if (wave_full) {
-#pragma unroll
-                    for (int k = 0; k < SPT; k++) aa = __builtin_elementwise_fma(x[k] - aa, al, aa);
-                    a.u = u_full;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < SPT; k++) {
-                        if (k >= first && k < lastp1) {
-                            a.u = (1.0f - a.u) * alpha + a.u;
-                            aa = __builtin_elementwise_fma(x[k] - aa, al, aa);
-                        }
-                    }
-                }
-                Aff pre;                                  // exclusive prefix within the tile
-                float tu, tar, tai;                       // the whole tile's map
-                if (wave_full) {
-                    // inclusive scan of the a parts with DPP: four steps inside the 16-lane rows, then the row totals
-                    // ride row_bcast:15 (into rows 1, 3) and row_bcast:31 (into rows 2, 3)
-                    float sr = aa.x, si = aa.y;
-#define FMX_SCAN_STEP(ctrl, rmask, mm)                                                                                       \
-                    {                                                                                                        \
-                        const float er = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), ctrl, rmask, 0xf, false)); \
-                        const float ei = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), ctrl, rmask, 0xf, false)); \
-                        sr = fmaf(er, mm, sr); si = fmaf(ei, mm, si);                                                        \
-                    }
-                    FMX_SCAN_STEP(0x111, 0xf, m1)
-                    FMX_SCAN_STEP(0x112, 0xf, m2)
-                    FMX_SCAN_STEP(0x114, 0xf, m4)
-                    FMX_SCAN_STEP(0x118, 0xf, m8)
-                    FMX_SCAN_STEP(0x142, 0xa, mA)
-                    FMX_SCAN_STEP(0x143, 0xc, mB)
-#undef FMX_SCAN_STEP
-#if FMX_WAVE_SHR
-                    // exclusive prefix = the inclusive one of the lane to the left: wave_shr:1 (DPP, lane 0 gets the zero of `old`)
-                    pre.ar = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x138, 0xf, 0xf, false));
-                    pre.ai = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x138, 0xf, 0xf, false));
-#else
-                    pre.ar = __shfl_up(sr, 1, 64); pre.ai = __shfl_up(si, 1, 64);
-                    if (lane == 0) { pre.ar = 0.f; pre.ai = 0.f; }
-#endif
-                    pre.u = u_exc;
-                    tu = u_tile;
-                    tar = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sr), 63));
-                    tai = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(si), 63));
-                } else {
-                    a.ar = aa.x; a.ai = aa.y;
-                    Aff inc = a;                          // general inclusive scan (first / last tile of a call)
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        Aff o; o.u = __shfl_up(inc.u, d, 64); o.ar = __shfl_up(inc.ar, d, 64); o.ai = __shfl_up(inc.ai, d, 64);
-                        if (lane >= d) inc = aff_then(o, inc);
-                    }
-                    pre.u = __shfl_up(inc.u, 1, 64); pre.ar = __shfl_up(inc.ar, 1, 64); pre.ai = __shfl_up(inc.ai, 1, 64);
-                    if (lane == 0) { pre.u = 0.f; pre.ar = 0.f; pre.ai = 0.f; }
-                    tu = __shfl(inc.u, 63, 64); tar = __shfl(inc.ar, 63, 64); tai = __shfl(inc.ai, 63, 64);
-                }
+                const DcMap DM = dc_tile_map(x, first, lastp1, wave_full, fast, DK, lane);
+                const Aff pre = DM.pre;
+                const float tu = DM.tu, tar = DM.tar, tai = DM.tai;
+                const v2f sA = DM.sA;
                 // carry in: the DC state at the tile's first sample
                 float c0 = dc0r, c1 = dc0i;
                 if (ti > 0) {
                     seq_wait(&carry_seq, ti);
                     c0 = carry[(ti - 1) & 7][0]; c1 = carry[(ti - 1) & 7][1];
                 }
-                c_out_r = c0 - c0 * tu + tar; c_out_i = c1 - c1 * tu + tai;
+                c_out_r = dc_chain(c0, tu, tar); c_out_i = dc_chain(c1, tu, tai);
                 if (lane == 0) { carry[ti & 7][0] = c_out_r; carry[ti & 7][1] = c_out_i; }
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) seq_post(&carry_seq, ti + 1);              // look-back hand-off, before this wave's pass 2
@@ -572,9 +628,9 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
         FMX_TICK(2);
         // ---- hand the 24 newest processed columns to the next tile: written straight into the next wave's image, once
         //      that wave is done with its previous tile (ti - 3), whose history / partial sums live there
-        if (ti + 1 < NT) {
+        if (ti + 1 < t_end) {
             const int nw = (wave + 1) % NW;
-            if (ti + 1 >= NW) seq_wait(&free_seq[nw], ti + 2 - NW);
+            if (ti + 1 - NW >= t_first) seq_wait(&free_seq[nw], ti + 2 - NW);
 #pragma unroll
             for (int k = 0; k < 3; k++)
                 if (k < 2 || lane < DECIM * 12 - 128) Xn[ho_dst[k]] = X4[ho_src[k]];
@@ -582,7 +638,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
             if (lane == 0) seq_post(&hist_seq[nw], ti + 1);
         }
         // ---- and wait for the previous tile's (tile 0 got the call's history from HBM)
-        if (ti > 0) seq_wait(&hist_seq[wave], ti);
+        if (ti > t_first) seq_wait(&hist_seq[wave], ti);
         FMX_TICK(3);
 #if !FMX_EARLY_PREFETCH
         if (more) load_tile(ti + NW);                 // (A/B build) prefetch only in front of the FIR
@@ -647,7 +703,8 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
             const float2 zA = make_float2(aA.x * cg_re - aA.y * cg_im, aA.x * cg_im + aA.y * cg_re);
             const float2 zB = make_float2(aB.x * cg_re - aB.y * cg_im, aB.x * cg_im + aB.y * cg_re);
             const int zi = (zr0 + q) & G.ring_mask;
-            if (TW == 1 && (zi & 1) == 0 && q >= ja && q + 1 < jb) {
+            if (ti < tA) { /* the warm-up tile of a later part: its outputs are the previous part's */ }
+            else if (TW == 1 && (zi & 1) == 0 && q >= ja && q + 1 < jb) {
                 // the lane's two outputs are neighbours in the ring and start on a 16-byte boundary (the ring's size is even): one store,
                 // 1 KB contiguous per wave instead of two interleaved 8-byte streams
 #ifdef FMX_ZNT
@@ -665,8 +722,8 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
         FMX_TICK(5);
     }
     FMX_TICK(6);
-    if (dbg_on && tw == 0) for (int k = 0; k < 8; k++) B.dbg[(size_t)ch * DBG_SLOTS + k] += dbg_acc[k];
-    if (t == 0 && lo != 0) {
+    if (dbg_on && tw == 0 && part == 0) for (int k = 0; k < 8; k++) B.dbg[(size_t)ch * DBG_SLOTS + k] += dbg_acc[k];
+    if (t == 0 && lo != 0 && part + 1 == NP) {
         long long m = ((long long)G.n * (long long)lo) % (long long)R;
         int ph = (int)(((long long)lo_phase0 - m) % (long long)R);
         if (ph < 0) ph += R;
@@ -674,15 +731,80 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     }
 }
 
+// In front of a launch that splits channels in time (CallGeom::parts > 1).  Workgroups 0 .. streams * n_tiles - 1: the RF DC recurrence over tile
+// (x % n_tiles) of stream (x / n_tiles) as an affine map, computed exactly as the owner of the tile computes it in front_kernel (dc_tile_map:
+// the same runs, the same scan), in both forms -- [0] channels without an LO (full tiles: sums), [1] channels with one (the recurrence).  The
+// workgroups behind them: one per channel, the snapshot of what front_kernel reads of the channel's state, history and saved boundaries.
+template <int FMT>
+__global__ __launch_bounds__(64) void front_pre_kernel(DeviceBuffers B, CallGeom G, const void *__restrict__ iq_raw, int n_tiles, int streams) {
+    constexpr int BPS = (FMT == 0) ? 8 : (FMT == 3 ? 4 : 2);
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x;
+    if (x >= streams * n_tiles) {
+        const int vc = x - streams * n_tiles;
+        const ChanState *st = B.state + vc;
+        if (lane == 0) { FrontSnap sn; sn.lo_phase = st->lo_phase; sn.hist_fmt = st->hist_fmt; sn.dc_re = st->dc_re; sn.dc_im = st->dc_im; B.fsnap[vc] = sn; }
+        for (int i = lane; i < DECIM * A_HIST_COLS; i += 64) B.hist_snap[(size_t)vc * DECIM * A_HIST_COLS + i] = B.hist[(size_t)vc * DECIM * A_HIST_COLS + i];
+        if (lane < DCV_SAVE) B.dcv_snap[(size_t)vc * DCV_SAVE + lane] = B.dcv_hist[(size_t)vc * DCV_SAVE + lane];
+        return;
+    }
+    const int sidx = x / n_tiles, ti = x - sidx * n_tiles;
+    const char *__restrict__ inb = reinterpret_cast<const char *>(iq_raw) + (size_t)sidx * G.stream_stride * BPS;
+    const float qs = G.iq_scale;
+    const int64_t qa = G.g0 / 12;
+    const int g0 = (int)(G.g0 - qa * 12), gend = g0 + (int)G.n;
+    const float alpha = 1.0f / (float)G.input_rate;
+    const DcK DK = dc_consts(alpha, lane);
+    const int base = (ti * WCOLS + 2 * lane) * 12;
+    int first = (base >= g0) ? 0 : ((g0 - base) < SPT ? (g0 - base) : SPT);
+    int lastp1 = (base + SPT <= gend) ? SPT : ((gend - base) > 0 ? (gend - base) : 0);
+    if (lastp1 < first) lastp1 = first;
+    const bool wave_full = __all(first == 0 && lastp1 == SPT);
+    v2f xs[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        float2 v = make_float2(0.f, 0.f);
+        if (k >= first && k < lastp1) {
+            const size_t i = (size_t)(base + k - g0);
+            if (FMT == 0) v = reinterpret_cast<const float2 *>(inb)[i];
+            else if (FMT == 1) { const uint8_t *p = reinterpret_cast<const uint8_t *>(inb) + 2 * i; v = make_float2((float)((int)p[0] - 127) * qs, (float)((int)p[1] - 127) * qs); }
+            else if (FMT == 2) { const int8_t *p = reinterpret_cast<const int8_t *>(inb) + 2 * i; v = make_float2((float)p[0] * qs, (float)p[1] * qs); }
+            else { const int16_t *p = reinterpret_cast<const int16_t *>(inb) + 2 * i; v = make_float2((float)p[0] * qs, (float)p[1] * qs); }
+        }
+        xs[k] = (v2f){v.x, v.y};
+    }
+    float4 *out = B.dc_tiles + ((size_t)sidx * B.dc_pitch + ti) * 2;
+    const DcMap M1 = dc_tile_map(xs, first, lastp1, wave_full, false, DK, lane);
+    if (wave_full) {
+        const DcMap M0 = dc_tile_map(xs, first, lastp1, true, true, DK, lane);
+        if (lane == 0) out[0] = make_float4(M0.tu, M0.tar, M0.tai, 0.f);
+    } else if (lane == 0) out[0] = make_float4(M1.tu, M1.tar, M1.tai, 0.f);      // (a tile that is not full: one form for both)
+    if (lane == 0) out[1] = make_float4(M1.tu, M1.tar, M1.tai, 0.f);
+}
+
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s) {
+    const int parts = (G.parts > 1 && G.twins == 1) ? G.parts : 1;
+    if (parts > 1) {
+        // (the maps of the tiles in front of the last part's warm-up tile; a stream that pre_kernel has made carries no RF DC removal here)
+        const int n_tiles = G.pre_processed ? 0 : (parts - 1) * G.part_tiles - 1;
+        const int streams = n_tiles > 0 ? G.streams : 0;
+        const dim3 pg(streams * n_tiles + channels);
+        switch (G.iq_format) {
+        case 1: hipLaunchKernelGGL((front_pre_kernel<1>), pg, dim3(64), 0, s, B, G, iq, n_tiles, streams); break;
+        case 2: hipLaunchKernelGGL((front_pre_kernel<2>), pg, dim3(64), 0, s, B, G, iq, n_tiles, streams); break;
+        case 3: hipLaunchKernelGGL((front_pre_kernel<3>), pg, dim3(64), 0, s, B, G, iq, n_tiles, streams); break;
+        default: hipLaunchKernelGGL((front_pre_kernel<0>), pg, dim3(64), 0, s, B, G, iq, n_tiles, streams); break;
+        }
+    }
+    const dim3 grid(channels * G.twins, parts);
     switch (G.iq_format) {
-    case 1: hipLaunchKernelGGL((front_kernel<1, false>), dim3(channels * G.twins), dim3(NTHR), 0, s, T, B, G, iq); break;
-    case 2: hipLaunchKernelGGL((front_kernel<2, false>), dim3(channels * G.twins), dim3(NTHR), 0, s, T, B, G, iq); break;
-    case 3: hipLaunchKernelGGL((front_kernel<3, false>), dim3(channels * G.twins), dim3(NTHR), 0, s, T, B, G, iq); break;
+    case 1: hipLaunchKernelGGL((front_kernel<1, false>), grid, dim3(NTHR), 0, s, T, B, G, iq); break;
+    case 2: hipLaunchKernelGGL((front_kernel<2, false>), grid, dim3(NTHR), 0, s, T, B, G, iq); break;
+    case 3: hipLaunchKernelGGL((front_kernel<3, false>), grid, dim3(NTHR), 0, s, T, B, G, iq); break;
     default:
-        if (G.streams_private) hipLaunchKernelGGL((front_kernel<0, true>), dim3(channels * G.twins), dim3(NTHR), 0, s, T, B, G, iq);
-        else hipLaunchKernelGGL((front_kernel<0, false>), dim3(channels * G.twins), dim3(NTHR), 0, s, T, B, G, iq);
+        if (G.streams_private) hipLaunchKernelGGL((front_kernel<0, true>), grid, dim3(NTHR), 0, s, T, B, G, iq);
+        else hipLaunchKernelGGL((front_kernel<0, false>), grid, dim3(NTHR), 0, s, T, B, G, iq);
         break;
     }
 }

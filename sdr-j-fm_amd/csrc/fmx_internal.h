@@ -224,7 +224,13 @@ struct CallGeom {
     int32_t pre_processed;   // stage A reads a stream that pre_kernel / the overlap-add machine (fmx_ola.hip) have already made: one stream per
     int32_t no_deemph;       // channel, no RF DC removal, balance or LO mix here, history always raw, no front-end state written.  no_deemph: stage B
                              // writes the stereo pair to the d ring as it is: the audio low-pass (a block machine then) comes first, deemph_kernel behind it
+    int32_t streams;         // IQ streams of the handle
+    int32_t parts, part_tiles;   // stage A, handles that leave the chip empty (one workgroup per channel, few channels): a channel's tiles are
+                             // split in time over `parts` workgroups of `part_tiles` tiles each (FMX_P_FRONT_PARTS); parts <= 1: one per channel
 };
+// what a workgroup of stage A reads of its channel's state when the channel is split in time (the workgroup of the last part rewrites the
+// live state while others may not have started): taken by front_pre_kernel in front of the launch
+struct FrontSnap { int32_t lo_phase, hist_fmt; float dc_re, dc_im; };
 
 constexpr int DBG_SLOTS = 96;
 struct DeviceBuffers {
@@ -258,6 +264,13 @@ struct DeviceBuffers {
     float2  *pk_ring;    // [channels][PK_RING] maxima of the finished windows
     int32_t pk_tiles;
     int32_t lin_rows;    // rows per channel of w_dem / w_diff / w_cur; 0 inside the demodulator pre-pass: its arrays are the 16-row tiles of widx()
+    // stage A split in time (CallGeom::parts > 1; allocated when first needed)
+    float4  *dc_tiles;   // [streams][dc_pitch][2] the RF DC recurrence over tile t of a stream as the map r -> r (1 - u) + a: (u, a.re, a.im, -), [0] as the
+                         // channels without an LO compute it (sums), [1] as the ones with an LO do (the recurrence itself)
+    int32_t dc_pitch;
+    FrontSnap *fsnap;    // [channels] front-end state in front of the call
+    float2  *hist_snap;  // [channels][DECIM][A_HIST_COLS] ... and the history,
+    float2  *dcv_snap;   // [channels][DCV_SAVE] ... and the saved RfDC boundaries
 };
 // element (row r, channel ch) of a per-call work array in either layout
 __host__ __device__ __forceinline__ size_t tap_idx(const DeviceBuffers &B, int64_t r, int ch, int pitch) {

@@ -1,0 +1,76 @@
+"""Round-4 GPU tests: stage A with its channels split in time (FMX_P_FRONT_PARTS, fmx_front.hip): the results must not depend on the split."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+M = importlib.import_module("sdr-j-fm_amd").fmx
+
+
+def _handle(fmx_amd, nch, nst, max_block, parts, restarts, lo, dc_remove=1):
+    f = fmx_amd.Fmx(nch, streams=nst, stream_of_channel=[c % nst for c in range(nch)], max_block=max_block)
+    for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FM_MODE, 0)):
+        f.set_param(pid, v)
+    f.set_param(M.P_FILTER_RESTARTS, restarts)
+    f.set_param(M.P_FRONT_PARTS, parts)
+    f.set_param(M.P_DC_REMOVE, dc_remove)
+    for c, o in enumerate(lo):
+        if o:
+            f.set_param(M.P_LOCAL_OSCILLATOR, int(o), c)
+    return f
+
+
+@pytest.mark.parametrize("restarts", [2, 1])
+def test_front_parts_give_identical_results(fmx_amd, ol, restarts):
+    """Five channels on two streams (a DC offset on the streams, local oscillators on two channels -- the per-sample pass with its RF DC chain --,
+    RF DC removal behind the FIR on the others), calls of uneven lengths that are not multiples of 12 or of the 1536-sample tile: one workgroup per
+    channel against the automatic split against a forced split into 5 and into 32 parts -- PCM, fm-rate IQ and the RF DC value bit for bit.
+    restarts 2: the folded filters (stage A does RF DC removal, balance and mix itself); 1: the block machines of handles up to 64 channels
+    (stage A reads the streams pre_kernel has made)."""
+    blocks = [230400, 16384 * 3 + 7, 100001, 230400, 1536 * 9, 20000, 230399]
+    n = sum(blocks)
+    iq = np.stack([ol.synth_iq(n, leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k) for k in range(2)])
+    iq[0] += np.array([0.004, -0.003], np.float32)
+    iq[1] += np.array([-0.02, 0.015], np.float32)             # (beyond the +-0.01 limiter)
+    lo = [0, 200000, 0, -400000, 0]
+    outs = []
+    for parts in (1, 0, 5, 32):
+        f = _handle(fmx_amd, 5, 2, max(blocks), parts, restarts, lo)
+        pcm, taps, dcs = [], [], []
+        pos = 0
+        for b in blocks:
+            pcm.append(f.process_host(iq[:, pos:pos + b])); pos += b
+            nt = f.last_fm_samples()
+            taps.append(np.stack([f.tap(M.TAP_FM_IQ, nt, c) for c in range(5)]))
+            dcs.append([f.meta(c).DcValRf for c in range(5)])
+        outs.append((np.concatenate(pcm, axis=1), np.concatenate(taps, axis=1), np.array(dcs)))
+        del f
+    ref = outs[0]
+    assert np.isfinite(ref[0]).all() and float(np.abs(ref[0]).max()) > 0.01
+    for k, o in enumerate(outs[1:]):
+        assert np.array_equal(o[1], ref[1]), "fm-rate IQ differs (variant %d)" % (k + 1)
+        assert np.array_equal(o[0], ref[0]), "PCM differs (variant %d)" % (k + 1)
+        assert np.array_equal(o[2], ref[2]), "RF DC value differs (variant %d)" % (k + 1)
+
+
+@pytest.mark.parametrize("fmt", ["u8", "s16"])
+def test_front_parts_raw_formats(fmx_amd, ol, fmt):
+    """Raw integer samples (converted while stage A loads them; the tile maps of the split convert them the same way)."""
+    blocks = [230400, 100000, 230400]
+    n = sum(blocks)
+    x = ol.synth_iq(n)
+    if fmt == "u8":
+        raw = np.clip(np.round(x * 100.0 + 127.4), 0, 255).astype(np.uint8); code = M.IQ_U8
+    else:
+        raw = np.clip(np.round(x * 1500.0 + 9.0), -32768, 32767).astype(np.int16); code = M.IQ_S16
+    outs = []
+    for parts in (1, 0, 7):
+        f = _handle(fmx_amd, 2, 1, max(blocks), parts, 2, [0, 250000])
+        pcm, pos = [], 0
+        for b in blocks:
+            pcm.append(f.process_host_raw(raw[None, pos:pos + b], code)); pos += b
+        outs.append(np.concatenate(pcm, axis=1))
+        del f
+    assert float(np.abs(outs[0]).max()) > 0.01
+    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
