@@ -30,3 +30,26 @@ def test_gpus_flag_spawns_ranks():
 def test_world_size_mismatch_fails_loudly():
     p = _run(["--gpus", "4", "--selftest-spawn"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
+
+
+def test_bench_main_has_no_local_that_shadows_a_module_import():
+    """A function-level `import x` makes x local to the whole function: every earlier use of the module-level x then raises
+    UnboundLocalError -- at run time only, on the GPU box (it happened to main() once).  No function of bench.py may import a
+    name the module already imports."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    top = set()
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            top |= {(a.asname or a.name).split(".")[0] for a in node.names}
+    clashes = []
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]:
+        for node in ast.walk(fn):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                clashes += [(fn.name, (a.asname or a.name).split(".")[0]) for a in node.names if (a.asname or a.name).split(".")[0] in top]
+    assert clashes == [], clashes
+
+
+def test_bench_without_a_gpu_fails_loudly_not_with_a_python_error():
+    p = _run(["--quick"])
+    assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout) and "Traceback" not in p.stderr
