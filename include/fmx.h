@@ -205,7 +205,8 @@ int  fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *meta);
  * the last 256 windows (5 s) per channel. */
 int  fmx_get_peaks(fmx_handle h, int32_t channel, float *lr_db, int32_t capacity, int32_t *n_events);
 /* replaces the hf/lf/iq scope ring feeds: copies the most recent n samples of a tap
- * (n * 1 or 2 floats) to host memory; n <= samples produced by the last call */
+ * (n * 1 or 2 floats) to host memory; n <= samples produced by the last call (fmx_last_fm_samples / fmx_last_rds_samples: while a channel
+ * decodes RDS, a call of more than 383988 input samples is made in pieces of that length, and the taps hold the last piece) */
 int  fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap_id, float *dst, int64_t n);
 /* What the reference's RDS classes tell the GUI through Qt signals (rds-groupdecoder.cpp:44-63, rds-blocksynchronizer.cpp:39-42):
  * setPiCode, setPTYCode, setStationLabel, setRadioText / clearRadioText, setAFDisplay, setMusicSpeechFlag, setGroup,

@@ -679,8 +679,35 @@ int front_parts_for(fmx_handle h, CallGeom &G) {
     return FMX_OK;
 }
 
+int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
+                 int64_t pcm_stride, int64_t *n_frames, hipStream_t s);
+// One call of the boundary.  The RDS front end works on blocks of RDS_BLK fm samples, one block phase for the handle, and one launch sequence covers
+// at most one block: while a channel decodes RDS, a longer call is made in pieces (the chain is invariant to how a stream is cut into calls).
 int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
              int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
+    constexpr int64_t PIECE = (int64_t)(RDS_BLK - 1) * DECIM;      // (J1 - J0 <= RDS_BLK whatever the call's phase in the fm-rate grid)
+    bool any_rds = false;
+    { std::lock_guard<std::mutex> lk(h->mtx); for (auto &p : h->params) any_rds |= (p.rds_mode != 0); }
+    if (!any_rds || n <= PIECE || fmt < 0 || fmt > 3 || n > h->cfg.max_block) return run_call_one(h, d_iq, fmt, s16_den, stream_stride, n, d_pcm, pcm_stride, n_frames, s);
+    {
+        CallGeom G{}; frames_geom(h, n, &G);
+        if (conv2_out(h, G.M1) - conv2_out(h, G.M0) > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
+    }
+    const int64_t bps = (fmt == 0) ? 8 : (fmt == 3 ? 4 : 2);
+    int64_t total = 0;
+    for (int64_t pos = 0; pos < n; pos += PIECE) {
+        int64_t got = 0;
+        const int rc = run_call_one(h, reinterpret_cast<const char *>(d_iq) + pos * bps, fmt, s16_den, stream_stride, (n - pos < PIECE) ? n - pos : PIECE,
+                                    d_pcm + total, pcm_stride, &got, s);
+        if (rc) return rc;
+        total += got;
+    }
+    if (n_frames) *n_frames = total;
+    return FMX_OK;
+}
+
+int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
+                 int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
     if (fmt < 0 || fmt > 3) return fail(FMX_E_INVALID, "unknown IQ format");
     if (fmt == 3) {
         int ex = 0; const float m = std::frexp(s16_den, &ex);

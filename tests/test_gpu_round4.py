@@ -74,3 +74,26 @@ def test_front_parts_raw_formats(fmx_amd, ol, fmt):
         del f
     assert float(np.abs(outs[0]).max()) > 0.01
     assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
+
+
+def test_long_calls_with_rds_on_are_made_in_pieces(fmx_amd, ol):
+    """One launch sequence of the RDS front end covers one 32000-sample block of its filters (384000 input samples); a longer call is made in
+    pieces inside the library (VERDICT r3 missing #4).  Two channels, RDS_2 on, 0.4 s in calls of 230400 samples for both handles (the
+    slicer's loops pull in: the first ~450 bits are decided on a constellation that is still turning, where 1e-7 decides); then one handle
+    takes the next 0.4 s in ONE call of 921600 samples, the other in four of 230400: the same PCM (to the chain's block-size invariance,
+    2e-7) and the same RDS bits."""
+    n = 921600
+    iq = np.stack([ol.synth_iq(2 * n, rds=1, rdsLevel=0.05, rdsBitsSeed=sd) for sd in (5, 6)])
+    res = []
+    for blocks in ([230400] * 4 + [n], [230400] * 8):
+        f = _handle(fmx_amd, 2, 2, n, 0, 2, [0, 0])
+        f.set_param(M.P_RDS_MODE, 2)
+        pcm, pos = [], 0
+        for b in blocks:
+            pcm.append(f.process_host(iq[:, pos:pos + b])); pos += b
+        res.append((np.concatenate(pcm, axis=1), [f.rds_bits(c, 8192) for c in range(2)], f.last_fm_samples()))
+        del f
+    (p1, b1, l1), (p4, b4, l4) = res
+    assert p1.shape == p4.shape and float(np.sqrt(np.mean((p1.astype(np.float64) - p4) ** 2))) <= 2e-7
+    assert all(len(a) > 900 and len(a) == len(b) and np.array_equal(a, b) for a, b in zip(b1, b4))
+    assert l1 == (n - 2 * 383988) // 12 and l4 == 19200            # (the taps of the long call hold its last piece)
