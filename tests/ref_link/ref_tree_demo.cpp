@@ -4,10 +4,11 @@
 // reference's headers; a deviceHandler subclass plays a raw IQ file, the GUI stand-in (radio.h next to this file) records the signals.
 // The fmProcessor thread runs fm-processor-fmx.cpp: libfmx demodulates and slices, the bits come back through the C ABI and go through the
 // reference's own block synchroniser and group decoder, whose Qt signals arrive in the stand-in.  Prints what arrived.
-//   ref_tree_demo <iq.f32> <seconds> <pcm-out.f32>
+//   ref_tree_demo <iq.f32> <seconds> <pcm-out.f32> [device rate, default 2304000] [bandwidth, default 165kHz]
 #include <QCoreApplication>
 #include <QThread>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <vector>
@@ -36,8 +37,8 @@ sf_count_t sf_writef_float(SNDFILE *, const float *, sf_count_t n) { return n; }
 // ---- the device: a file of interleaved float32 (I, Q) at 2.304 MS/s, handed out as fast as the processor asks
 class fileDevice : public deviceHandler {
 public:
-    std::vector<std::complex<float>> data; size_t pos = 0;
-    int32_t getRate() override { return 2304000; }
+    std::vector<std::complex<float>> data; size_t pos = 0; int32_t rate = 2304000;
+    int32_t getRate() override { return rate; }
     int32_t Samples() override { return (int32_t)std::min<size_t>(data.size() - pos, 1 << 20); }
     int32_t getSamples(std::complex<float> *v, int32_t n) override { return getSamples(v, n, 0); }
     int32_t getSamples(std::complex<float> *v, int32_t n, uint8_t) override {
@@ -51,6 +52,7 @@ int main(int argc, char **argv) {
     QCoreApplication app(argc, argv);
     if (argc < 4) { std::fprintf(stderr, "usage: ref_tree_demo <iq.f32> <seconds> <pcm-out.f32>\n"); return 2; }
     fileDevice dev;
+    if (argc > 4) dev.rate = std::atoi(argv[4]);         // (the rates the reference decimates by 6 or not at all: ADVICE r3 medium)
     {
         std::ifstream f(argv[1], std::ios::binary | std::ios::ate);
         if (!f) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
@@ -62,8 +64,8 @@ int main(int argc, char **argv) {
     audioSink sink;
     fm_Demodulator demod(192000);                    // (the GUI owns this object, radio.cpp:905; the binding reads the decoder choice from it)
     RingBuffer<std::complex<float>> hf(32768), lf(32768), iq(32768);
-    fmProcessor proc(&dev, &gui, &sink, &demod, 2304000, 192000, 48000, 48000, 1024, 1024, 10, 0, &hf, &lf, &iq, 20);
-    proc.setBandwidth("165kHz"); proc.setlfcutoff(15000); proc.setDeemphasis(50); proc.setVolume(-6.0f);
+    fmProcessor proc(&dev, &gui, &sink, &demod, dev.rate, 192000, 48000, 48000, 1024, 1024, 10, 0, &hf, &lf, &iq, 20);
+    proc.setBandwidth(argc > 5 ? argv[5] : "165kHz"); proc.setlfcutoff(15000); proc.setDeemphasis(50); proc.setVolume(-6.0f);
     proc.setfmMode(fmProcessor::FM_Mode::Stereo); proc.setfmRdsSelector(rdsDecoder::ERdsMode::RDS_2);
     proc.start();
     while (dev.pos < dev.data.size() - 16384) { QCoreApplication::processEvents(); QThread::msleep(2); }

@@ -117,3 +117,27 @@ def test_binding_runs_the_reference_rds_classes_on_gpu_bits(tmp_path, ol, fmx_am
     po = ol.OracleChain(inputFilterBw=165000, rdsMode=2).process(iq)
     m = min(len(pcm), len(po))
     assert m >= len(po) - 400 and float(np.sqrt(np.mean((pcm[:m].astype(np.float64) - po[:m]) ** 2))) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate,bw", [(2048000, "165kHz"), (192000, "Off")])
+def test_binding_runs_at_the_rates_decimated_by_6_and_by_1(tmp_path, ol, fmx_amd, rate, bw):
+    """the reference-tree fmProcessor at a device rate the reference decimates by 6 (rtl-sdr's 2.048 MS/s: 683 PCM frames
+    per 16384-sample block) and at one it does not decimate (192 kS/s: 4096 frames per block) -- its PCM buffer is sized by fmx_frames_for,
+    every block reaches the audioSink, and the PCM equals the oracle's chain built for that rate."""
+    import numpy as np
+    exe = DEMO.OUT
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_tree_demo was not built (python oracle/build_ref_tree_demo.py where the reference tree is)")
+    decim = 1 if rate // 192000 <= 1 else 6 * ((rate // 6) // 192000)
+    n = 16384 * (60 if decim > 1 else 12)
+    iq = ol.synth_iq(n)                              # (generator time base 2.304 MS/s; the receivers are told `rate`)
+    (tmp_path / "iq.f32").write_bytes(np.ascontiguousarray(iq, np.float32).tobytes())
+    r = subprocess.run([exe, str(tmp_path / "iq.f32"), "0", str(tmp_path / "pcm.f32"), str(rate), bw], env=RUN_ENV, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "pcm_stride" not in r.stderr, (r.stdout[-1500:], r.stderr[-3000:])
+    pcm = np.frombuffer((tmp_path / "pcm.f32").read_bytes(), np.float32).reshape(-1, 2)
+    po = ol.OracleChain(inputRate=rate, inputFilterBw=0 if bw == "Off" else 165000, rdsMode=2).process(iq)
+    m = min(len(pcm), len(po))
+    print("\n[reference-tree binding at %d S/s] frames %d (oracle %d)" % (rate, len(pcm), len(po)))
+    assert m >= len(po) - 16384 // decim // 4 - 8 and m > 0.9 * (n // decim // 4)
+    assert float(np.sqrt(np.mean((pcm[:m].astype(np.float64) - po[:m]) ** 2))) <= 1e-5
