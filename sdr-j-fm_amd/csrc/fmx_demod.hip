@@ -190,13 +190,27 @@ __device__ __forceinline__ void tile_pipeline(int nfull, LoadF load, BodyF body)
 
 // ---- B2
 template <bool PLLDEC>
-__device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y) {
+__device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y, float *atan_lds) {
     constexpr int PDA = PLLDEC ? 2 : 4;
     const int CP = G.pitch;
     const int ch = bid_x * 64 + threadIdx.x;
+    const int decoder0 = ch < C ? B.params[ch].decoder : 3;
+    if (PLLDEC) {
+        // pllC's loop is one dependent chain per sample and a lone wave waits out every latency on it: the two table look-ups of a step must
+        // not be trips to memory (they were 2 x ~350 ns of the step's 900).  The arc-tangent table (32 KB, Xtan2.cpp:28-31) is copied into LDS by
+        // the wave that has a lane on the PLL or AM decoder; the NCO's table entry comes from the sine unit (sincos_idx_hw, as in stage B).
+        if (__any(decoder0 == 1 || decoder0 == 2)) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(T.atan_ppy);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(atan_lds);
+            for (int i = threadIdx.x; i < ATAN_N / 4; i += 64) dst[i] = src[i];
+            if (threadIdx.x == 0) atan_lds[ATAN_N] = T.atan_ppy[ATAN_N];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0);          // (one wave per workgroup: its own LDS stores are in order; the wait is for the compiler's sake)
+    }
     if (ch >= C) return;
     ChanState *st = B.state + ch;
-    const int decoder = B.params[ch].decoder;
+    const int decoder = decoder0;
     if (B.prepass && !(decoder <= 2 || B.params[ch].squelch_mode != 0)) return;      // (the fused kernel does this channel's demodulator itself)
     const bool use_pll = PLLDEC && (decoder == 2), use_am = PLLDEC && (decoder == 1);
     // the sample behind which the reference takes its metaData snapshot (++myCount > fmRate / 2, fm-processor.cpp:662-684), row of this chunk
@@ -214,42 +228,60 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     const size_t ro = widx(rc0, ch, CP);              // rc0 is a multiple of the tile height
     float *wd = B.w_dem + ro;
     const float2 *wiq = PLLDEC ? B.w_iq + ro : nullptr;
-    auto demod1 = [&](float res, float2 sig) -> float {
+    // One sample.  A lone wave issues an instruction every 4-5 cycles whatever it is, and a divergent branch is half a dozen of them: the
+    // step is written with selects; what only some handles need (the AM decoder's division, the level squelch) sits behind wave-uniform flags,
+    // and what the loop never reaches in practice (an NCO phase outside [0, 2 pi]: the update below cannot leave one) behind a wave-uniform test.
+    const bool any_pll = PLLDEC && __any(use_pll || use_am), any_am = PLLDEC && __any(use_am), any_lsq = PLLDEC && __any(lsq);
+    const bool on_pll = use_pll || use_am;
+    const float beta = T.pll_beta, omb = 1 - T.pll_beta, plo = T.pll_lo, phi = T.pll_hi, pce = T.pll_center;
+    auto step = [&](float res, float2 sig) -> float {
+        float r_am = 0.f;
         if (PLLDEC) {
             // |z| arrives in the demod array for the AM and PLL decoders, in the first half of the IQ array otherwise (disc_kernel)
-            if (use_am || lsq) am = (1.0f - 0.0010f) * am + 0.0010f * (decoder <= 2 ? res : sig.x);      // am_carr_ampl, carrierAlpha (fm-demodulator.cpp:117,130-131)
-            if (use_pll || use_am) {                 // pllC::do_pll pllC.cpp:67-90 (AM: on the unlimited sample, :222)
-                const float2 nco = sc_complex(T.sincos, SC, nco_phase);
+            if (any_am || any_lsq) {
+                const float am2 = (1.0f - 0.0010f) * am + 0.0010f * (decoder <= 2 ? res : sig.x);      // am_carr_ampl, carrierAlpha (fm-demodulator.cpp:117,130-131)
+                am = (use_am || lsq) ? am2 : am;
+            }
+            if (any_pll) {                               // pllC::do_pll pllC.cpp:67-90 (AM: on the unlimited sample, :222)
+                // The NCO phase is in [0, 2 pi] (as f32: the update below leaves nothing else, starting from the constructor's 0) and the
+                // loop's increment is limited to +-0.95 pi (NcoLLimit / NcoHLimit): SinCos::getComplex's table entry is one multiplication
+                // away, and the reference's wrap loops (pllC.cpp:84-89) are at most one turn either way.
+                int idx = (int)((double)nco_phase * SC);
+                idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+                float2 nco;
+                sincos_idx_hw(idx, &nco.y, &nco.x);
                 const float dre = nco.x * sig.x - (-nco.y) * sig.y;      // conj(nco) * signal
                 const float dim = nco.x * sig.y + (-nco.y) * sig.x;
-                const float perr = lut_atan2(T.atan_ppy, dim, dre);
-                incr = (1 - T.pll_beta) * perr + T.pll_beta * incr;
-                if (incr < T.pll_lo || incr > T.pll_hi) incr = T.pll_center;
-                nco_phase += incr;
-                if ((double)nco_phase >= FMX_2PI) nco_phase = (float)fmod_2pi((double)nco_phase);
-                else while (nco_phase < 0) nco_phase = (float)((double)nco_phase + FMX_2PI);
-                if (use_am) {                        // decodeAM fm-demodulator.cpp:215-241
-                    afc = c1 * afc + fmDcAlpha * incr;
+                const float perr = lut_atan2(atan_lds, dim, dre);
+                float inc2 = omb * perr + beta * incr;
+                inc2 = (inc2 < plo || inc2 > phi) ? pce : inc2;
+                const float ph = nco_phase + inc2;
+                const bool over = ph >= 6.2831855f, under = ph < 0.f;                  // ((double) ph >= 2 pi  <=>  ph >= 6.2831855f)
+                const double turn = over ? -FMX_2PI : FMX_2PI;                         // (x - 2 pi is fmod (x, 2 pi) for 2 pi <= x < 4 pi)
+                const float moved = (float)((double)ph + turn);
+                const float phw = (over || under) ? moved : ph;
+                incr = on_pll ? inc2 : incr;
+                nco_phase = on_pll ? phw : nco_phase;
+                if (any_am) {                            // decodeAM fm-demodulator.cpp:215-241
                     const float gainLimit = 0.01f;
                     float r = (res - am) / (am < gainLimit ? gainLimit : am);
-                    if (r > 1.0f) r = 1.0f; else if (r < -1.0f) r = -1.0f;
-                    return r;
+                    r = (r > 1.0f) ? 1.0f : (r < -1.0f ? -1.0f : r);
+                    r_am = r;
                 }
-                res = incr;
+                res = use_pll ? incr : res;
             }
         }
-        afc = c1 * afc + fmDcAlpha * res;            // fm-demodulator.cpp:197
-        return fdiv_const(20.0f * (res - afc) * 1.0f, K, rK);      // :198
-    };
-    auto step = [&](float res, float2 sig) -> float {
-        float r = demod1(res, sig);
-        if (PLLDEC && lsq) {
-            if (++sq_cnt >= SINCOS_N / 20) {         // holdPeriod = fmRate / 20 (fm-processor.cpp:87)
-                sq_cnt = 0;
-                if (am < sq_thr - 0.000f) sq_sup = true;             // SQUELCH_HYSTERESIS_LSQ = 0
-                else if (am >= sq_thr + 0.000f) sq_sup = false;
-            }
-            r = sq_sup ? r * 0.000f : r;             // LEVELREDUCTIONFACTOR = 0
+        afc = c1 * afc + fmDcAlpha * ((PLLDEC && use_am) ? incr : res);     // fm-demodulator.cpp:197 (AM: of the loop's increment, :232)
+        float r = fdiv_const(20.0f * (res - afc) * 1.0f, K, rK);            // :198
+        r = (PLLDEC && use_am) ? r_am : r;
+        if (PLLDEC && any_lsq) {
+            // (squelch::do_level_squelch squelchClass.cpp:89-113)
+            const int c2 = sq_cnt + 1;
+            const bool hold = c2 >= SINCOS_N / 20;           // holdPeriod = fmRate / 20 (fm-processor.cpp:87)
+            const bool sup2 = hold ? (am < sq_thr - 0.000f ? true : (am >= sq_thr + 0.000f ? false : sq_sup)) : sq_sup;   // SQUELCH_HYSTERESIS_LSQ = 0
+            sq_cnt = lsq ? (hold ? 0 : c2) : sq_cnt;
+            sq_sup = lsq ? sup2 : sq_sup;
+            r = (lsq && sq_sup) ? r * 0.000f : r;            // LEVELREDUCTIONFACTOR = 0
         }
         return r;
     };
@@ -273,10 +305,12 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
                         : (k < UB / 2 ? make_float2(nqa[ss][uu][2 * k], nqa[ss][uu][2 * k + 1])
                                       : make_float2(nqb[ss][uu][(2 * k) % UB], nqb[ss][uu][(2 * k) % UB + 1]));
             }
+            // (the metaData snapshot falls into one tile in 750: looked for once per tile, for the whole wave)
+            const bool snap_here = PLLDEC && __any(snap_row >= (int64_t)tb * UB && snap_row < (int64_t)(tb + 1) * UB);
 #pragma unroll
             for (int k = 0; k < UB; k++) {
                 x[k] = step(x[k], xq[k]);
-                if (PLLDEC && (int64_t)tb * UB + k == snap_row) st->meta_dc_if = afc;          // get_demodDcComponent () at the snapshot
+                if (snap_here && (int64_t)tb * UB + k == snap_row) st->meta_dc_if = afc;       // get_demodDcComponent () at the snapshot
             }
             wst(wd + tb * TS, x);
         });
@@ -295,7 +329,8 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
 template <bool PLLDEC>
 __global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len) {
     FMX_RECURRENCE_PRIO();
-    afc_body<PLLDEC>(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y);
+    __shared__ __attribute__((aligned(16))) float atan_lds[PLLDEC ? ATAN_N + 4 : 4];
+    afc_body<PLLDEC>(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y, atan_lds);
 }
 
 // =================================================================================================

@@ -89,13 +89,13 @@ __device__ __forceinline__ float lut_atan2(const float *__restrict__ ppy, float 
     int idx = at_idx(size, num, special ? 1.f : den);
     idx = special ? 0 : idx;
     const float tv = ppy[idx];
-    const float A = swap ? (ypos ? Sh : -Sh) : (xpos ? 0.f : (ypos ? St : -St));
+    const float ys = ypos ? 1.0f : -1.0f;                      // (+-1 times a constant is exact: selects, not a tree of branches)
+    const float A = swap ? Sh * ys : (xpos ? 0.f : St * ys);
     const float r = A + ((same == swap) ? -tv : tv);
-    if (special) {
-        if (x == 0.f && y != 0.f && !isnan(y) && !isinf(y)) return y > 0.f ? (float)(3.14159265358979323846 / 2) : (float)(-3.14159265358979323846 / 2);
-        return 0.f;
-    }
-    return r;
+    // (selects, not branches: the callers walk recurrences on lone waves, where a divergent branch costs more than both arms)
+    const bool axis = x == 0.f && y != 0.f && !isnan(y) && !isinf(y);
+    const float rs = axis ? (y > 0.f ? (float)(3.14159265358979323846 / 2) : (float)(-3.14159265358979323846 / 2)) : 0.f;
+    return special ? rs : r;
 }
 // ---- limiter fm-demodulator.cpp:119-126 (std::abs(complex<float>) == hypotf == f64 sqrt of f64 sum)
 __device__ __forceinline__ float2 limiter(float2 z) {
