@@ -188,6 +188,12 @@ __device__ __forceinline__ DcMap dc_tile_map(const v2f *x, int first, int lastp1
 #define FMX_ABL 0      /* diagnostic builds only (tools/ablate_front.sh): bit 0 no scatter, 1 no DC/mix pass, 2 no FIR */
 #endif
 #define FMX_TICK(k) do { if (dbg_on) { unsigned long long now_ = clock64(); dbg_acc[k] += now_ - dbg_t; dbg_t = now_; } } while (0)
+/* (diagnostics: the cycles wave 0 spends waiting for another wave's sequence counter, by counter, into slot 7 and the stage-B slots 13-15 nobody uses here) */
+#ifdef FMX_WAIT_TICKS   /* (a diagnostic build, tools/build_variant.sh: the three counters cost registers the kernel does not have) */
+#define FMX_WAIT(k, call) do { if (dbg_on) { const unsigned long long w0_ = clock64(); call; dbg_wait[k] += clock64() - w0_; } else { call; } } while (0)
+#else
+#define FMX_WAIT(k, call) do { call; } while (0)
+#endif
 
 // mailbox counters between the waves of a workgroup (LDS, workgroup scope)
 __device__ __forceinline__ void seq_wait(int *p, int need) {
@@ -474,6 +480,9 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     };
     const bool dbg_on = (B.dbg != nullptr) && (t == 0);
     unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef FMX_WAIT_TICKS
+    unsigned long long dbg_wait[3] = {0, 0, 0};
+#endif
     unsigned long long dbg_t = dbg_on ? clock64() : 0ull;
     if (t_first + wave < t_end) load_tile(t_first + wave);
     const int dc_unit = (lane & 3) * XS4 + 3 + (lane >> 2);     // this lane's column pair (24 + 2 l, 24 + 2 l + 1), row 0
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
                 // carry in: the DC state at the tile's first sample
                 float c0 = dc0r, c1 = dc0i;
                 if (ti > 0) {
-                    seq_wait(&carry_seq, ti);
+                    FMX_WAIT(0, seq_wait(&carry_seq, ti));
                     c0 = carry[(ti - 1) & 7][0]; c1 = carry[(ti - 1) & 7][1];
                 }
                 c_out_r = dc_chain(c0, tu, tar); c_out_i = dc_chain(c1, tu, tai);
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
         //      that wave is done with its previous tile (ti - 3), whose history / partial sums live there
         if (ti + 1 < t_end) {
             const int nw = (wave + 1) % NW;
-            if (ti + 1 - NW >= t_first) seq_wait(&free_seq[nw], ti + 2 - NW);
+            if (ti + 1 - NW >= t_first) FMX_WAIT(1, seq_wait(&free_seq[nw], ti + 2 - NW));
 #pragma unroll
             for (int k = 0; k < 3; k++)
                 if (k < 2 || lane < DECIM * 12 - 128) Xn[ho_dst[k]] = X4[ho_src[k]];
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
             if (lane == 0) seq_post(&hist_seq[nw], ti + 1);
         }
         // ---- and wait for the previous tile's (tile 0 got the call's history from HBM)
-        if (ti > t_first) seq_wait(&hist_seq[wave], ti);
+        if (ti > t_first) FMX_WAIT(2, seq_wait(&hist_seq[wave], ti));
         FMX_TICK(3);
 #if !FMX_EARLY_PREFETCH
         if (more) load_tile(ti + NW);                 // (A/B build) prefetch only in front of the FIR
@@ -722,7 +731,12 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
         FMX_TICK(5);
     }
     FMX_TICK(6);
-    if (dbg_on && tw == 0 && part == 0) for (int k = 0; k < 8; k++) B.dbg[(size_t)ch * DBG_SLOTS + k] += dbg_acc[k];
+    if (dbg_on && tw == 0 && part == 0) {
+        for (int k = 0; k < 8; k++) B.dbg[(size_t)ch * DBG_SLOTS + k] += dbg_acc[k];
+#ifdef FMX_WAIT_TICKS
+        for (int k = 0; k < 3; k++) B.dbg[(size_t)ch * DBG_SLOTS + 40 + k] += dbg_wait[k];
+#endif
+    }
     if (t == 0 && lo != 0 && part + 1 == NP) {
         long long m = ((long long)G.n * (long long)lo) % (long long)R;
         int ph = (int)(((long long)lo_phase0 - m) % (long long)R);

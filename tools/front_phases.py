@@ -1,6 +1,6 @@
 """Per-phase shader cycles of fmx::front_kernel (diagnostic hook fmx_debug_phase_cycles)."""
 import importlib, ctypes as C, sys, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 pkg = importlib.import_module("sdr-j-fm_amd"); m = pkg.fmx
 ch = int(sys.argv[1]) if len(sys.argv) > 1 else 512
@@ -26,4 +26,5 @@ tot = sum(out[:8])
 for k, nm in enumerate(names):
     print(f"{nm:24s} {out[k]/tiles:9.0f} cycles/tile  {100*out[k]/tot:5.1f}%")
 print("total cycles/tile", tot / tiles)
+print("of which waiting for another wave: RF DC carry %.0f, next image free %.0f, history in %.0f cycles/tile" % (out[40] / tiles, out[41] / tiles, out[42] / tiles))
 print("stage-B block paths: pss_acc steady/idle/replay =", out[8], out[9], out[10], " lock closed-form/replay =", out[11], out[12])
