@@ -3,7 +3,9 @@
 fmx_process_device as tests/test_gpu_parity.py::test_full_size_config4_device_path), handles created and destroyed in a loop, each run
 through pilot acquisition; every call every channel's PCM is compared with channel c % 4's on the device.  On a mismatch: channel, call,
 and the first tap (fm IQ / demodulator / pilot phase / L-R raw / pre-resampler) in which the channel differs from its twin.
-usage: python tools/diag/flake_hunt.py [runs] [calls per run] [block] [channels] [rds 0|1] [stage-B form 0 auto|1 one kernel|2 two]"""
+usage: python tools/diag/flake_hunt.py [runs] [calls per run] [block] [channels] [rds 0|1] [stage-B form 0 auto|1 one kernel|2 two] [signals 0|1]
+signals 1: the four programmes are a pilot flapping across the lock threshold, one creeping through it, noise only, and a station with
+a DC offset and a local oscillator -- lock transitions, PSS replays, the guard's sequential segments and the per-sample DC / mix pass in every call."""
 import importlib, os, sys, time
 import numpy as np
 import torch
@@ -17,8 +19,20 @@ block = int(sys.argv[3]) if len(sys.argv) > 3 else 230400
 C = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 rds = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 form = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+hard = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 dev = torch.device("cuda", 0)
 base = np.stack([ol.synth_iq(block * calls, leftHz=300.0 + 370 * j, rightHz=500.0 + 530 * j, **(dict(rds=1, rdsLevel=0.05, rdsBitsSeed=12345 + j) if rds else {})) for j in range(4)])
+if hard:
+    import test_gpu_round3 as T3
+    n = block * calls
+    t = np.arange(n) / 2304000.0
+    pil = np.where(np.mod(t, 0.35) < 0.22, 0.06, 0.01) * (1 + 0.2 * np.sin(2 * np.pi * t / 0.31))
+    lft, rgt = 0.5 * np.sin(2 * np.pi * 1000 * t), 0.5 * np.sin(2 * np.pi * 400 * t)
+    p19 = 2 * np.pi * 19000 * t
+    base[0] = T3.fm_modulate(0.45 * (lft + rgt) + pil * np.sin(p19) + 0.45 * (lft - rgt) * np.sin(2 * p19))
+    base[1] = T3.creeping_pilot_iq(n, phase=-0.5, period=0.5)
+    base[2] = ol.synth_iq(n, carrierAmp=0.0, noiseSeed=9, noiseSigma=0.3)
+    base[3] = ol.synth_iq(n, offsetHz=200000.0, dcI=0.004, dcQ=-0.02)
 d_base = torch.from_numpy(base).to(dev)
 cap = block // 48 + 96
 d_pcm = torch.zeros((C, cap, 2), dtype=torch.float32, device=dev)
@@ -31,6 +45,8 @@ for r in range(runs):
         f.set_param(pid, v)
     if rds: f.set_param(M.P_RDS_MODE, 2)
     if form: f.set_param(M.P_STAGEB_FORM, form)
+    if hard:
+        for c in range(3, C, 4): f.set_param(M.P_LOCAL_OSCILLATOR, 200000, c)
     for i in range(calls):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
