@@ -102,6 +102,9 @@ struct fmx_handle_s {
     std::vector<int32_t> rds_read_dec;      // ... and by fmx_rds_decode
     std::vector<int32_t> rds_read_sym;      // ... symbols handed out by fmx_rds_symbols
     std::atomic<int32_t> rds_gen{0};        // counts rds_restart: a consumer that saw an older generation starts over (its own read position and,
+    std::vector<int32_t> rds_gen_ch;        // ... and per channel: counts the channel's own restarts (its decoder switched on while others were decoding)
+    std::vector<uint8_t> rds_was_on;        // per channel: the decoder was on in the last call
+    std::vector<int32_t> rds_fresh;         // channels whose slicer state the next call clears in front of its kernels
     std::vector<int32_t> rds_gen_dec, rds_gen_sym;   // for fmx_rds_decode, the channel's block synchroniser / group decoder), however late it polls
     std::vector<fmx::RdsGroupDecoderHost> rds_dec;
     int64_t last_m0 = 0, last_m1 = 0;       // 24 kS/s outputs of the last call
@@ -457,6 +460,7 @@ int rds_restart(fmx_handle h) {
     std::vector<RdsState> init(C, s0);
     HIPCHK(hipMemcpy(R.state, init.data(), sizeof(RdsState) * C, hipMemcpyHostToDevice));
     h->rds_read.assign(C, 0);                       // the bit counters restart at 0
+    h->rds_fresh.clear();
     h->rds_gen.fetch_add(1);                        // fmx_rds_decode / fmx_rds_symbols start over too (their own threads: they compare generations)
     return FMX_OK;
 }
@@ -564,16 +568,26 @@ int flush_mailbox(fmx_handle h) {
     if (any_lo) { int rc = ensure_lo_table(h); if (rc) return rc; }
     bool any_rds = false;
     for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
+    if (h->rds_was_on.size() != h->params.size()) { h->rds_was_on.assign(h->params.size(), 0); h->rds_gen_ch.assign(h->params.size(), 0); }
     if (any_rds) {
         int rc = ensure_rds(h); if (rc) return rc;
-        if (h->rds_start < 0) {
+        const bool first = h->rds_start < 0;
+        if (first) {
             if (h->rds_rearm) { rc = rds_restart(h); if (rc) return rc; h->rds_rearm = false; }
             h->rds_start = h->g_total / h->decim;    // the RDS filters start counting here (all channels)
+        }
+        // a channel that joins while others are decoding: its filters have been running on zeros (rds_collect), its slicer starts from the
+        // constructor's state in this call, its bit counters from 0
+        for (size_t c = 0; c < h->params.size(); c++) {
+            const bool on = h->params[c].rds_mode != 0;
+            if (on && !h->rds_was_on[c] && !first) { h->rds_fresh.push_back((int32_t)c); h->rds_read[c] = 0; h->rds_gen_ch[c] += 1; }
+            h->rds_was_on[c] = on ? 1 : 0;
         }
     } else if (h->rds_start >= 0) {
         // nobody listens any more: the shared overlap-add block phase ends here; the next enable starts from fresh filters,
         // rings and slicer states (calls in between are not seen by the RDS path at all)
         h->rds_start = -1; h->rds_rearm = true;
+        std::fill(h->rds_was_on.begin(), h->rds_was_on.end(), 0);
     }
     bool any_pll = false;
     for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0);     // pllC on the fm-rate IQ; |z| for the level squelch; the general AFC body for the noise squelch
@@ -763,6 +777,22 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         bool any_rds = false;
         for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
         if (any_rds) {
+            if (!h->rds_fresh.empty()) {
+                std::lock_guard<std::mutex> lk(h->mtx);
+                RdsState s0; std::memset(&s0, 0, sizeof(s0));
+                s0.gain = 9.0f; s0.mu = 0.f; s0.skip = 3; s0.sample_count = 0;
+                s0.c_limit = (float)(2 * design::kPi * (double)10.0f / (double)(float)24000);
+                for (int32_t c : h->rds_fresh) {
+                    HIPCHK(hipMemcpyAsync(h->R.state + c, &s0, sizeof(s0), hipMemcpyHostToDevice, s));
+                    HIPCHK(hipMemsetAsync(h->R.state1 + c, 0, sizeof(Rds1State), s));
+                    HIPCHK(hipMemsetAsync(h->R.state3 + c, 0, sizeof(Rds3State), s));
+                    HIPCHK(hipMemsetAsync(h->R.mfc + (size_t)c * h->R.mfc_stride, 0, 2 * sizeof(float2), s));
+                    HIPCHK(hipMemsetAsync(h->R.c_ring + (size_t)c * RDS24_RING, 0, sizeof(float) * RDS24_RING, s));
+                    HIPCHK(hipMemsetAsync(h->R.f_ring + (size_t)c * RDS24_RING, 0, sizeof(float) * RDS24_RING, s));
+                }
+                HIPCHK(hipStreamSynchronize(s));         // (s0 is on this stack; a join is a rare event)
+                h->rds_fresh.clear();
+            }
             const int64_t n0 = G.J0 - h->rds_start;
             int modes = 0;
             for (auto &p : h->params) modes |= 1 << p.rds_mode;
@@ -1186,14 +1216,6 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         for (auto &p : h->params) any |= (p.rds_mode != 0);
         if (!any) { h->rds_start = -1; h->rds_rearm = true; }
     }
-    if (id == FMX_P_RDS_MODE && iv != 0 && h->rds_start >= 0 && h->rds_start != h->g_total / h->decim) {
-        // The two 32768-point overlap-add filters of the RDS front end run on ONE block phase for the whole batch (all three
-        // decoders sit behind them): while other channels are decoding, a channel cannot join in the middle of a block run.
-        for (int c = c0; c < c1; c++)
-            if (h->params[(size_t)c].rds_mode == 0)
-                return fail(FMX_E_UNSUPPORTED, "switch RDS on for all channels in the same call (shared overlap-add block phase); "
-                                               "or switch it off everywhere first: the next enable restarts the RDS path");
-    }
     if (id == FMX_A_RESET_RDS || id == FMX_A_TRIGGER_FREQUENCY_CHANGE) {
         if (h->rds_reset_req.size() != (size_t)h->channels) h->rds_reset_req.assign((size_t)h->channels, 0);
         for (int c = c0; c < c1; c++) h->rds_reset_req[(size_t)c] = 1;      // resetRds (:862-864); triggerFrequencyChange calls it (:852)
@@ -1440,7 +1462,7 @@ int fmx_rds_symbols(fmx_handle h, int32_t channel, float *iq, int32_t capacity, 
     HIPCHK(hipMemcpy(&st, h->R.state + channel, sizeof(st), hipMemcpyDeviceToHost));
     int32_t &rd = h->rds_read_sym[(size_t)channel];
     if (h->rds_gen_sym.size() != (size_t)h->channels) h->rds_gen_sym.assign((size_t)h->channels, 0);
-    const int32_t gen = h->rds_gen.load();
+    const int32_t gen = h->rds_gen.load() + (h->rds_gen_ch.size() == (size_t)h->channels ? h->rds_gen_ch[(size_t)channel] : 0);
     if (h->rds_gen_sym[(size_t)channel] != gen) { h->rds_gen_sym[(size_t)channel] = gen; rd = 0; }   // the RDS path was restarted (rds_restart)
     int32_t have = st.nbits - rd;
     if (have < 0) { rd = 0; have = st.nbits; }
@@ -1495,7 +1517,7 @@ int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {
         HIPCHK(hipMemcpy(&st, h->R.state + channel, sizeof(st), hipMemcpyDeviceToHost));
         int32_t &rd = h->rds_read_dec[(size_t)channel];
         if (h->rds_gen_dec.size() != (size_t)h->channels) h->rds_gen_dec.assign((size_t)h->channels, 0);
-        const int32_t gen = h->rds_gen.load();
+        const int32_t gen = h->rds_gen.load() + (h->rds_gen_ch.size() == (size_t)h->channels ? h->rds_gen_ch[(size_t)channel] : 0);
         if (h->rds_gen_dec[(size_t)channel] != gen) { h->rds_gen_dec[(size_t)channel] = gen; rd = 0; D.reset_all(); }   // the RDS path was restarted (rds_restart)
         int32_t have = st.nbits - rd;
         if (have < 0) { rd = 0; have = st.nbits; D.reset_all(); }

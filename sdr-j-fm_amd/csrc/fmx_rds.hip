@@ -214,10 +214,15 @@ __global__ void rds_save_tail(const float2 *__restrict__ U, float2 *__restrict__
 __global__ void rds_collect(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, int64_t row0, int nrows, int64_t n0 /* rds index of row0 */) {
     const int ch = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nrows || B.params[ch].rds_mode == 0) return;
+    if (q >= nrows) return;
     const int64_t r = row0 + q, n = n0 + q;
-    const float demod = B.w_dem[tap_idx(B, r, ch, G.pitch)];
-    const float cur = B.w_cur[tap_idx(B, r, ch, G.pitch)];             // unconstrained pilot phase; PI_Constrain gives currentPilotPhase
+    // A channel whose RDS decoder is off takes ZEROS into the block filters and the phase delay (round 4): the filters of the batch run on
+    // one block phase, so a channel that switches its decoder on in a later call than the others cannot start machines of its own -- but a
+    // linear filter that has been fed zeros IS one that starts from cleared buffers (fftFilter's constructor, fft-filters.cpp:33-52), and the
+    // delayed pilot phase of the first 64000 samples is the cleared rdsPhaseBuffer's 0 (fm-processor.cpp:744).
+    const bool on = B.params[ch].rds_mode != 0;
+    const float demod = on ? B.w_dem[tap_idx(B, r, ch, G.pitch)] : 0.f;
+    const float cur = on ? B.w_cur[tap_idx(B, r, ch, G.pitch)] : 0.f;   // unconstrained pilot phase; PI_Constrain gives currentPilotPhase
     // Channels 2p and 2p + 1 ride through the block transforms as the real and imaginary part of one row: a non-finite sample of one
     // (the raw IQ formats cannot carry one, float32 input can) would turn the whole pair's spectrum into NaN and leave the
     // neighbour's slicer state NaN for good.  It enters the block as zero instead.
@@ -234,7 +239,7 @@ __global__ void rds_collect(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, i
 __global__ void rds_mix_decim(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, int64_t m0, int nout) {
     const int ch = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nout || B.params[ch].rds_mode == 0) return;
+    if (q >= nout) return;                                   // (every channel: one that is off mixes zeros, see rds_collect)
     const int64_t m = m0 + q;
     float2 acc = make_float2(0.f, 0.f);
     // block and position of the newest input (one 64-bit division per thread; the ten older inputs follow by counting down)

@@ -284,6 +284,10 @@ class Fmx:
     def last_fm_samples(self):
         return int(self.L.fmx_last_fm_samples(self.h))
 
+    def last_rds_samples(self):
+        """24 kS/s RDS samples the last call produced (fmx_last_rds_samples): the n that tap(TAP_RDS_IQ, n) accepts."""
+        return int(self.L.fmx_last_rds_samples(self.h))
+
     def pll_replays(self, channel=-1):
         """Segments of the pilot PLL that were replayed sequentially (fmx_pll_replays)."""
         n = int(self.L.fmx_pll_replays(self.h, channel))
