@@ -1162,11 +1162,6 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
         // (a segment without a sample in lock makes no process_sample call when autoMono is on, :704: the low-pass has nobody to serve --
         // what unlocked channels, which pay for the sample-by-sample PLL, save here)
         if (pss_on && !(auto_mono && none_locked)) {
-#pragma unroll
-            for (int i = 0; i < FB_K; i += 2) {
-                *reinterpret_cast<float2 *>(&park_dem[j0 + i]) = make_float2(dem[i], dem[i + 1]);
-                *reinterpret_cast<float2 *>(&park_cur[j0 + i]) = make_float2(cur[i], cur[i + 1]);
-            }
             const int64_t i0 = pss_count0 + calls_before;                            // call index of the segment's first output
             float2 a[8];
             const int64_t first = i0 - (PSS_DELAY + PSS_TAPS - 1);                   // s index of window entry 0
@@ -1183,6 +1178,13 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                     const int64_t idx = first + n;
                     a[p] = (n < w + PSS_TAPS - 1 && idx >= 0) ? sring[idx & smask] : make_float2(0.f, 0.f);
                 }
+            }
+            // (the window's loads are in flight before the first use of what the second kernel loaded at the segment's top -- one trip to
+            // memory for both instead of one after the other)
+#pragma unroll
+            for (int i = 0; i < FB_K; i += 2) {
+                *reinterpret_cast<float2 *>(&park_dem[j0 + i]) = make_float2(dem[i], dem[i + 1]);
+                *reinterpret_cast<float2 *>(&park_cur[j0 + i]) = make_float2(cur[i], cur[i + 1]);
             }
             SB_FT(17); SB_FTW(18);
             fftc::convolve(tid, a, X, T.fft_w, T.pss_hs);
