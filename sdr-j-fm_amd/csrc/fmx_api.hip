@@ -111,6 +111,7 @@ struct fmx_handle_s {
     std::vector<void *> rds_ptrs, tail_ptrs;
     std::atomic<int> stageb_form{0};     // FMX_P_STAGEB_FORM
     std::atomic<int> front_parts{0};     // FMX_P_FRONT_PARTS
+    void *hp_iq = nullptr; float2 *hp_pcm = nullptr; size_t hp_iq_bytes = 0; int64_t hp_pcm_cap = 0;   // fmx_process_host: pinned, device-visible staging of small calls
     // the reference's two overlap-add filters as the block machines they are (fmx_ola.hip): handles of up to OLA_MAX_CH channels
     bool ola_mode = false;               // FMX_P_FILTER_RESTARTS resolved (fixed once the first call has been made)
     struct OlaSide {
@@ -1158,6 +1159,8 @@ int fmx_destroy(fmx_handle h) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
     for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);
+    if (h->hp_iq) (void)hipHostFree(h->hp_iq);
+    if (h->hp_pcm) (void)hipHostFree(h->hp_pcm);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_dummy) (void)hipEventDestroy(h->ev_dummy);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1307,6 +1310,28 @@ int fmx_process_host_raw(fmx_handle h, const void *iq, int32_t format, float s16
     const int64_t frames = fmx_frames_for(h, n);
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
     const size_t bps = (size_t)bytes_per_sample(format);
+    // The single receiver's call (one stream, 16384 samples: 128 KB in, 2.7 KB out) spends a third of its time in the two copies' fixed costs
+    // (a pageable buffer is staged by the runtime, each copy is a submission of its own).  Small calls go through pinned, device-visible
+    // memory instead: the samples are copied there by the CPU and READ BY STAGE A over the bus, the PCM is written there by stage C.
+    static const bool zc_env = !(getenv("FMX_HOST_ZEROCOPY") && atoi(getenv("FMX_HOST_ZEROCOPY")) == 0);
+    constexpr size_t ZC_MAX_IN = (size_t)1 << 20;
+    const size_t in_bytes = bps * (size_t)n * (size_t)h->streams;
+    if (zc_env && in_bytes <= ZC_MAX_IN && (size_t)h->channels * (size_t)cap * sizeof(float2) <= ZC_MAX_IN) {
+        if (!h->hp_pcm) {
+            HIPCHK(hipHostMalloc(&h->hp_iq, ZC_MAX_IN, hipHostMallocDefault)); h->hp_iq_bytes = ZC_MAX_IN;
+            HIPCHK(hipHostMalloc((void **)&h->hp_pcm, sizeof(float2) * (size_t)h->channels * cap, hipHostMallocDefault)); h->hp_pcm_cap = cap;
+        }
+        for (int sidx = 0; sidx < h->streams; sidx++)
+            std::memcpy((char *)h->hp_iq + (size_t)sidx * bps * n, (const char *)iq + (size_t)sidx * bps * stream_stride, bps * (size_t)n);
+        int64_t got = 0;
+        int rc = run_call(h, h->hp_iq, format, s16_den, n, n, h->hp_pcm, cap, &got, h->stream);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int c = 0; c < h->channels && got > 0; c++)
+            std::memcpy(pcm + 2 * (size_t)c * pcm_stride, h->hp_pcm + (size_t)c * cap, sizeof(float2) * (size_t)got);
+        if (n_frames) *n_frames = got;
+        return FMX_OK;
+    }
     HIPCHK(hipMemcpy2DAsync(h->d_iq, bps * h->cfg.max_block, iq, bps * stream_stride, bps * n, h->streams,
                             hipMemcpyHostToDevice, h->stream));
     int64_t got = 0;
