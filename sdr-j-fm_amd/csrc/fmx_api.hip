@@ -111,6 +111,7 @@ struct fmx_handle_s {
     std::vector<void *> rds_ptrs, tail_ptrs;
     std::atomic<int> stageb_form{0};     // FMX_P_STAGEB_FORM
     std::atomic<int> front_parts{0};     // FMX_P_FRONT_PARTS
+    PreLook pre_look{};                  // pre_kernel's look-back buffers (ensure_ola)
     void *hp_iq = nullptr; float2 *hp_pcm = nullptr; size_t hp_iq_bytes = 0; int64_t hp_pcm_cap = 0;   // fmx_process_host: pinned, device-visible staging of small calls
     // the reference's two overlap-add filters as the block machines they are (fmx_ola.hip): handles of up to OLA_MAX_CH channels
     bool ola_mode = false;               // FMX_P_FILTER_RESTARTS resolved (fixed once the first call has been made)
@@ -487,6 +488,11 @@ int ensure_ola(fmx_handle h) {
     HIPCHK(hipMalloc(&h->d2ring, sizeof(float2) * C * h->dring));
     HIPCHK(hipMemset(h->d2ring, 0, sizeof(float2) * C * h->dring));
     for (void *p : {(void *)h->d_v, (void *)h->d_u, (void *)h->d2ring}) h->tail_ptrs.push_back(p);
+    h->pre_look.max_tiles = (int32_t)(h->cfg.max_block / PRE_TILE_SAMPLES + 1);
+    HIPCHK(hipMalloc(&h->pre_look.maps, sizeof(float4) * C * h->pre_look.max_tiles));
+    HIPCHK(hipMalloc(&h->pre_look.flags, sizeof(int32_t) * C * h->pre_look.max_tiles));
+    HIPCHK(hipMemset(h->pre_look.flags, 0, sizeof(int32_t) * C * h->pre_look.max_tiles));
+    h->tail_ptrs.push_back(h->pre_look.maps); h->tail_ptrs.push_back(h->pre_look.flags);
     int rc = ola_alloc_side(h, h->ola_in, 2 * 32768 - 251, 251);          // inputFilter (2 * 32768, 251) fm-processor.cpp:77
     if (rc) return rc;
     return ola_alloc_side(h, h->ola_au, 2 * 4096 - AUDIO_TAPS, AUDIO_TAPS);   // fmAudioFilter (2 * 4096, 756) :76
@@ -756,10 +762,12 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         OlaStep st1;
         if (ola_single_step(h, h->ola_in, n, &st1)) {
             ola_fill(h->ola_in, O);
-            launch_pre(h->T, h->B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, &st1, &O); FMX_LAUNCHED();
+            h->pre_look.epoch += 1;
+            launch_pre(h->T, h->B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, &st1, &O, h->pre_look); FMX_LAUNCHED();
             ola_finish_single(h, h->ola_in, st1, O, s);
         } else {
-            launch_pre(h->T, h->B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, nullptr, nullptr); FMX_LAUNCHED();
+            h->pre_look.epoch += 1;
+            launch_pre(h->T, h->B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, nullptr, nullptr, h->pre_look); FMX_LAUNCHED();
             run_ola(h, h->ola_in, O, n, s);
         }
         CallGeom Gp = G; Gp.pre_processed = 1; Gp.iq_format = 0; Gp.iq_scale = 1.0f; Gp.stream_stride = h->cfg.max_block; Gp.streams_private = h->twins == 1 ? 1 : 0;

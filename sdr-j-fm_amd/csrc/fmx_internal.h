@@ -290,9 +290,13 @@ struct OlaBuffers {
     const float *taps;                      // [channels][OLA_MAX_TAPS] the kernel of each channel
     int32_t L, degree;                      // NumofSamples = fftSize - degree (fft-filters.cpp:34), degree
 };
+// pre_kernel's look-back between the tiles of a channel: the tiles' RF DC maps and "published in launch `epoch`" flags (zeroed once; the
+// epoch counts the handle's launches, so nothing is ever reset)
+struct PreLook { float4 *maps; int32_t *flags; int32_t max_tiles, epoch; };
+constexpr int PRE_TILE_SAMPLES = 8192;
 // (S, O given: the whole call is ONE run of every channel's filter, and the kernel does ola_io_kernel's work itself)
 void launch_pre(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, float2 *vbuf, int64_t vstride, int channels, hipStream_t s,
-                const OlaStep *S, const OlaBuffers *O);
+                const OlaStep *S, const OlaBuffers *O, const PreLook &LB);
 void launch_ola_io(const OlaStep &S, const OlaBuffers &O, int channels, int maxlen, hipStream_t s);
 void launch_ola_conv(const OlaStep &S, const OlaBuffers &O, int channels, hipStream_t s);
 // de-emphasis (fm-processor.cpp:594-595) of fm samples [J0, J1) of every channel, in place in `ring`
