@@ -145,10 +145,14 @@ __global__ __launch_bounds__(fftc::T, AF_WAVES_PER_SIMD) void audio_fft_kernel(D
         if (t < 192) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                float v = pv[q];
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-                if (lane == 0 && k >= 1) atomicMax(&pkt[k - 1][q], __float_as_int(v));
+                // (the wave's maximum of four non-negative values per step k: 32 reductions per thread -- as DPP moves on the vector pipe, not
+                // as 192 ds_bpermute that queue up with the transforms' exchanges; non-negative floats order like their bit patterns)
+                int v = __float_as_int(pv[q]);
+#define AF_MAX_STEP(ctrl, rmask) v = max(v, __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false))
+                AF_MAX_STEP(0x111, 0xf); AF_MAX_STEP(0x112, 0xf); AF_MAX_STEP(0x114, 0xf); AF_MAX_STEP(0x118, 0xf);   // row_shr 1, 2, 4, 8: lane 15 of a row has the row's
+                AF_MAX_STEP(0x142, 0xa); AF_MAX_STEP(0x143, 0xc);                                                     // row_bcast 15 / 31: lane 63 has the wave's
+#undef AF_MAX_STEP
+                if (lane == 63 && k >= 1) atomicMax(&pkt[k - 1][q], v);
             }
         } else if (live) {
 #pragma unroll
