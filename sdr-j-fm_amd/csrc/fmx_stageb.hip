@@ -219,13 +219,12 @@ struct WG {
     }
     // max-reduction of four ints over the workgroup
     __device__ __forceinline__ void reduce_max4(int &a, int &b, int &c, int &d) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const int xa = __shfl_xor(a, o, 64), xb = __shfl_xor(b, o, 64), xc = __shfl_xor(c, o, 64), xd = __shfl_xor(d, o, 64);
-            a = xa > a ? xa : a; b = xb > b ? xb : b; c = xc > c ? xc : c; d = xd > d ? xd : d;
-        }
-        if (lane == 0) { L->wi[sl][wv][0] = a; L->wi[sl][wv][1] = b; L->wi[sl][wv][2] = c; L->wi[sl][wv][3] = d; }
+        // (the wave's maxima in lane 63 by DPP moves on the vector pipe -- 24 ds_bpermute per thread and segment before, a fifth of the second
+        // kernel's LDS instructions)
+        a = wscan_max_i(a); b = wscan_max_i(b); c = wscan_max_i(c); d = wscan_max_i(d);
+        if (lane == 63) { L->wi[sl][wv][0] = a; L->wi[sl][wv][1] = b; L->wi[sl][wv][2] = c; L->wi[sl][wv][3] = d; }
         __syncthreads();
+        a = b = c = d = IMIN;
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const int xa = L->wi[sl][v][0], xb = L->wi[sl][v][1], xc = L->wi[sl][v][2], xd = L->wi[sl][v][3];
