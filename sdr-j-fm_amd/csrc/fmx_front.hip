@@ -184,6 +184,12 @@ __device__ __forceinline__ DcMap dc_tile_map(const v2f *x, int first, int lastp1
 #ifndef FMX_WG_PER_CU
 #define FMX_WG_PER_CU 2
 #endif
+#ifndef FMX_FIR_PRIO
+#define FMX_FIR_PRIO -1   /* diagnostic builds: s_setprio inside the FIR phase (FMX_REST_PRIO outside); -1: none */
+#endif
+#ifndef FMX_REST_PRIO
+#define FMX_REST_PRIO 0
+#endif
 #ifndef FMX_ABL
 #define FMX_ABL 0      /* diagnostic builds only (tools/ablate_front.sh): bit 0 no scatter, 1 no DC/mix pass, 2 no FIR */
 #endif
@@ -653,6 +659,9 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
         if (more) load_tile(ti + NW);                 // (A/B build) prefetch only in front of the FIR
 #endif
 
+#if FMX_FIR_PRIO >= 0
+        __builtin_amdgcn_s_setprio(FMX_FIR_PRIO);      // (A/B builds: the FIR's packed FMAs against the other wave's loads, LDS traffic and stores)
+#endif
         // ---- polyphase FIR  out[j] = sum_d sum_r Trd[r][d] * X[r][C_j - d]:  lane quarter rq sums rows 3 rq .. 3 rq + 2
         //      for eight adjacent outputs per lane; the four partial sums meet in LDS (on top of the image, which is
         //      dead by then)
@@ -692,6 +701,9 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
                 X4[(rq * 16 + cg) * 4 + ((k + (cg >> 1)) & 3)] = make_float4(acc[2 * k].x, acc[2 * k].y, acc[2 * k + 1].x, acc[2 * k + 1].y);
         }
         __builtin_amdgcn_wave_barrier();
+#if FMX_FIR_PRIO >= 0
+        __builtin_amdgcn_s_setprio(FMX_REST_PRIO);
+#endif
         FMX_TICK(4);
         {
             // outputs 2 l, 2 l + 1 = pair (l & 3) of column group l >> 2
