@@ -184,6 +184,9 @@ __device__ __forceinline__ DcMap dc_tile_map(const v2f *x, int first, int lastp1
 #ifndef FMX_WG_PER_CU
 #define FMX_WG_PER_CU 2
 #endif
+#ifndef FMX_FIR_ROT
+#define FMX_FIR_ROT 1   /* 0: the plain row loop (A/B builds) */
+#endif
 #ifndef FMX_FIR_PRIO
 #define FMX_FIR_PRIO -1   /* diagnostic builds: s_setprio inside the FIR phase (FMX_REST_PRIO outside); -1: none */
 #endif
@@ -239,6 +242,67 @@ __device__ __forceinline__ void fir_rows(const float4 *__restrict__ X4, int cg, 
 #pragma unroll
             for (int k = 0; k < FCOLS; k++) acc[k] = __builtin_elementwise_fma(w, W[HL + k - d], acc[k]);
         }
+    }
+}
+
+// The same sums with the LDS latency under the FMAs (25 tap columns only).  Tap d of a row reads window entries 24 - d .. 31 - d: taps 0 .. 8 touch
+// only the window's newer half (entries 16 .. 31), taps 16 .. 24 only its older half -- and tap d is used at step d alone.  So while taps 0 .. 15
+// run, the older half and the taps 16 .. 27 of the row arrive; while taps 16 .. 24 run, the NEXT row's newer half and taps 0 .. 15 arrive in the
+// registers that have just gone dead.  Only the first row's first loads are waited for (a wave has the SIMD to itself for much of a tile -- two
+// waves per SIMD --, so a stall of the FIR is a stall of the tile: 1600 of the FIR's 4000 cycles were such stalls).
+__device__ __forceinline__ void fir_rows_rot(const float4 *__restrict__ X4, int cg, int r0, const float4 *__restrict__ tp, v2f acc[FCOLS]) {
+    constexpr int ND = A_MAX_ND;
+    static_assert(ND == 25 && HL == 24 && FCOLS == 8, "the halves of the window are worked out for this shape");
+    v2f Wn[16], Wo[16];                  // window entries 16 .. 31 and 0 .. 15
+    float tlo[16], thi[12];              // taps 0 .. 15 and 16 .. 27
+    auto load_new = [&](int row) {
+#pragma unroll
+        for (int j = 3; j >= 2; j--)
+#pragma unroll
+            for (int kp = 0; kp < 4; kp++) {
+                const float4 v = X4[row * XRS + kp * XS4 + cg + j];
+                Wn[8 * (j - 2) + 2 * kp] = (v2f){v.x, v.y}; Wn[8 * (j - 2) + 2 * kp + 1] = (v2f){v.z, v.w};
+            }
+    };
+    auto load_old = [&](int row) {
+#pragma unroll
+        for (int j = 1; j >= 0; j--)
+#pragma unroll
+            for (int kp = 0; kp < 4; kp++) {
+                const float4 v = X4[row * XRS + kp * XS4 + cg + j];
+                Wo[8 * j + 2 * kp] = (v2f){v.x, v.y}; Wo[8 * j + 2 * kp + 1] = (v2f){v.z, v.w};
+            }
+    };
+    auto taps_lo = [&](int rr) {
+#pragma unroll
+        for (int d4 = 0; d4 < 4; d4++) { const float4 v = tp[rr * (A_TAPS_ROW / 4) + d4]; tlo[4 * d4] = v.x; tlo[4 * d4 + 1] = v.y; tlo[4 * d4 + 2] = v.z; tlo[4 * d4 + 3] = v.w; }
+    };
+    auto taps_hi = [&](int rr) {
+#pragma unroll
+        for (int d4 = 0; d4 < 3; d4++) { const float4 v = tp[rr * (A_TAPS_ROW / 4) + 4 + d4]; thi[4 * d4] = v.x; thi[4 * d4 + 1] = v.y; thi[4 * d4 + 2] = v.z; thi[4 * d4 + 3] = v.w; }
+    };
+    auto W = [&](int i) -> v2f { return i >= 16 ? Wn[i - 16] : Wo[i]; };
+    taps_lo(0); load_new(r0);
+#pragma unroll
+    for (int rr = 0; rr < RPQ; rr++) {
+        taps_hi(rr); load_old(r0 + rr);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            const v2f w = (v2f){tlo[d], tlo[d]};
+#pragma unroll
+            for (int k = 0; k < FCOLS; k++) acc[k] = __builtin_elementwise_fma(w, W(HL + k - d), acc[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (rr + 1 < RPQ) { taps_lo(rr + 1); load_new(r0 + rr + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 16; d < ND; d++) {
+            const v2f w = (v2f){thi[d - 16], thi[d - 16]};
+#pragma unroll
+            for (int k = 0; k < FCOLS; k++) acc[k] = __builtin_elementwise_fma(w, W(HL + k - d), acc[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -671,7 +735,11 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
             for (int k = 0; k < FCOLS; k++) acc[k] = (v2f){0.f, 0.f};
             if (FMX_ABL & 4) { acc[0] = (v2f){(float)cg, 1.f}; }
             else if (nd <= 4) fir_rows<4>(X4, cg, RPQ * rq, tp, acc);
+#if FMX_FIR_ROT
+            else fir_rows_rot(X4, cg, RPQ * rq, tp, acc);
+#else
             else fir_rows<A_MAX_ND>(X4, cg, RPQ * rq, tp, acc);
+#endif
             __builtin_amdgcn_wave_barrier();
             // save the columns the call-end history needs before the image is overwritten (last tile only: below)
             if (ti == NT - 1) {
