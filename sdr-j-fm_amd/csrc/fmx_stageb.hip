@@ -1073,6 +1073,32 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             float lock_next;
             const int locked0 = cy.locked, stable0 = cy.stable;
             float lock = wg.decay_incoming2(Lt, cy.lock, load_decay(&dtab, DEC_LOCK, lane), &lock_next);
+            bool lock_exact = false;
+            if constexpr (EXACT) {
+                // Handles that are asked for the reference's trajectories (pll_seq 1): the lock metric as the AFC above -- every thread runs its
+                // samples from its incoming value in the reference's own expression (pilot-recover.cpp:62-66: f64 product and sum, rounded to f32
+                // per sample), the misses of the end values against the next threads' incoming values are prefix-summed into corrections, until
+                // every run ends on the next run's start: the chain from the exact cy.lock is the sequential one (the metric forgets a shift at
+                // 1 / 3000 per sample).  The lock decisions then sit on the reference's metric, not within 1e-7 of it.
+                if (P.pll_seq == 1) {
+                    const float lock0 = cy.lock;
+                    for (int pass = 0; pass < 8; pass++) {
+                        float o = lock;
+#pragma unroll
+                        for (int i = 0; i < FB_K; i++) if (i < nv) o = (float)((double)xq[i] + (double)o * keep);
+                        float po = dppf<0x138, 0xf>(0.f, o);
+                        if (lane == 63) lds.wf[wg.sl][wg.wv][2] = o;
+                        __syncthreads();
+                        if (lane == 0) po = wg.wv ? lds.wf[wg.sl][(wg.wv + 3) & 3][2] : lock0;
+                        wg.sl ^= 1;
+                        const double d = (nv >= 1) ? (double)po - (double)lock : 0.0;
+                        double total; bool any;
+                        const double pre = wg.excl_add_d(d, &total, d != 0.0, &any);
+                        if (!any) { lock_exact = true; break; }
+                        lock = (float)((double)lock + (pre + d));
+                    }
+                }
+            }
             bool hi[FB_K]; int lastf = -1; float lock_end = 0.f, lock_x = 0.f;
             float lock_min = 1.0f;
 #pragma unroll
@@ -1122,7 +1148,8 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             const int nok = (nl && !anynear) ? 1 : 0;
             newton_ok_next = nok != 0;
             if (lastseg && owner) { st->pil_lock = lock_end; st->pil_locked = nl; st->pil_stable = ns; st->pll_newton_ok = nok; }
-            if (tid == 0) { cy.locked = nl; cy.stable = ns; cy.lock = lock_next; cy.newton_ok = nok; }
+            if (tid == 0) { cy.locked = nl; cy.stable = ns; cy.newton_ok = nok; if (!lock_exact) cy.lock = lock_next; }
+            if (lock_exact && owner) cy.lock = lock_end;             // (the chain's own end value: read again behind the next segment's barriers)
         }
         SB_FT(15);
         {   // scope taps and the inputs of the RDS path: channel-major rows of this call
