@@ -30,5 +30,6 @@ for k in range(calls):
 L.fmx_debug_phase_cycles(f.h, 0, out)
 v = list(out)
 segs = 10 * -(-(n // 12) // 1536) * ch
+print("PSS integrator: steady segments %d (rounds %.2f), replayed by one thread %d" % (v[12], v[9] / max(v[12], 1), v[10]))
 print("segments %d; cycle solver ran on %d (%.1f %%): passes per segment %.2f, not settled by it %d; plain replays %d; Newton rounds per Newton segment %.2f"
       % (segs, v[29], 100.0 * v[29] / segs, v[28] / max(v[29], 1), v[30], v[15], v[8] / max(v[11], 1)))
