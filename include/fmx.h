@@ -112,6 +112,11 @@ typedef enum {
                                   fewer channels than the GPU has workgroup slots splits every channel's call in time over several workgroups
                                   (each later one recomputes one 1536-sample tile to get its filter history): 0 = automatic (default), 1 = never,
                                   2..32 = that many parts wherever a call is long enough.  The results are bit-identical. */
+    FMX_P_FRONT_KERNEL = 25,   /* (handle-wide: the channel argument is ignored) which kernel runs the input-filter stage: 1 = four waves per channel, two
+                                  workgroups per CU, for every call; 2 = six waves per channel, three per SIMD (fmx_front3.hip), for the whole
+                                  1536-sample tiles of every call it can take -- float32 samples, no local oscillator on any channel, the
+                                  input filter on everywhere, a call that starts on a multiple of 12 samples -- and kernel 1 for the rest;
+                                  0 = automatic (default): kernel 1 (the faster one where measured).  The results are bit-identical. */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */
@@ -206,7 +211,8 @@ int  fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *meta);
 int  fmx_get_peaks(fmx_handle h, int32_t channel, float *lr_db, int32_t capacity, int32_t *n_events);
 /* replaces the hf/lf/iq scope ring feeds: copies the most recent n samples of a tap
  * (n * 1 or 2 floats) to host memory; n <= samples produced by the last call (fmx_last_fm_samples / fmx_last_rds_samples: while a channel
- * decodes RDS, a call of more than 383988 input samples is made in pieces of that length, and the taps hold the last piece) */
+ * decodes RDS, a call of more than 31999 fm samples -- 383988 input samples at the rates the reference decimates by 12, 191994 at those it
+ * decimates by 6, 31999 where it does not decimate -- is made in pieces of that length, and the taps hold the last piece) */
 int  fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap_id, float *dst, int64_t n);
 /* What the reference's RDS classes tell the GUI through Qt signals (rds-groupdecoder.cpp:44-63, rds-blocksynchronizer.cpp:39-42):
  * setPiCode, setPTYCode, setStationLabel, setRadioText / clearRadioText, setAFDisplay, setMusicSpeechFlag, setGroup,

@@ -111,6 +111,8 @@ struct fmx_handle_s {
     std::vector<void *> rds_ptrs, tail_ptrs;
     std::atomic<int> stageb_form{0};     // FMX_P_STAGEB_FORM
     std::atomic<int> front_parts{0};     // FMX_P_FRONT_PARTS
+    std::atomic<int> front_kernel{0};    // FMX_P_FRONT_KERNEL
+    bool front3_ok = false;              // every channel qualifies for front3_kernel (flush_mailbox)
     PreLook pre_look{};                  // pre_kernel's look-back buffers (ensure_ola)
     void *hp_iq = nullptr; float2 *hp_pcm = nullptr; size_t hp_iq_bytes = 0; int64_t hp_pcm_cap = 0;   // fmx_process_host: pinned, device-visible staging of small calls
     // the reference's two overlap-add filters as the block machines they are (fmx_ola.hip): handles of up to OLA_MAX_CH channels
@@ -573,6 +575,16 @@ int flush_mailbox(fmx_handle h) {
     bool any_lo = false;
     for (auto &p : h->params) any_lo |= (p.lo_freq != 0);
     if (any_lo) { int rc = ensure_lo_table(h); if (rc) return rc; }
+    {
+        // stage A on three waves per SIMD (fmx_front3.hip): no LO on any channel, every tap set the long fold (RfDC taken 1 .. 13 columns back)
+        bool ok = !any_lo && h->twins == 1 && !h->ola_mode;
+        for (auto &p : h->params) {
+            if (!ok) break;
+            const FrontSet &fs = h->h_front_sets[(size_t)p.front_set];
+            ok = fs.nd > 4 && fs.dc_k >= 1 && fs.dc_k <= 13;
+        }
+        h->front3_ok = ok;
+    }
     bool any_rds = false;
     for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
     if (h->rds_was_on.size() != h->params.size()) { h->rds_was_on.assign(h->params.size(), 0); h->rds_gen_ch.assign(h->params.size(), 0); }
@@ -706,7 +718,8 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
 // at most one block: while a channel decodes RDS, a longer call is made in pieces (the chain is invariant to how a stream is cut into calls).
 int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
              int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
-    constexpr int64_t PIECE = (int64_t)(RDS_BLK - 1) * DECIM;      // (J1 - J0 <= RDS_BLK whatever the call's phase in the fm-rate grid)
+    const int64_t PIECE = (int64_t)(RDS_BLK - 1) * h->decim;       // (J1 - J0 <= RDS_BLK whatever the call's phase in the fm-rate grid; decim: input samples per
+                                                                   // fm sample at this handle's rate -- 12, 6 or 1 as the reference decimates)
     bool any_rds = false;
     { std::lock_guard<std::mutex> lk(h->mtx); for (auto &p : h->params) any_rds |= (p.rds_mode != 0); }
     if (!any_rds || n <= PIECE || fmt < 0 || fmt > 3 || n > h->cfg.max_block) return run_call_one(h, d_iq, fmt, s16_den, stream_stride, n, d_pcm, pcm_stride, n_frames, s);
@@ -756,6 +769,13 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     h->B.lin_rows = (int32_t)h->work_nj;
     rc = front_parts_for(h, G);
     if (rc) return rc;
+    {
+        static const int fk_env = getenv("FMX_FRONT_KERNEL") ? atoi(getenv("FMX_FRONT_KERNEL")) : 0;     // (diagnostic: A/B runs of one build)
+        const int fk = h->front_kernel.load() ? h->front_kernel.load() : fk_env;
+        // (automatic = the four-wave kernel: measured on one box, 4096 channels, the six-wave kernel takes 1.84 ms per launch against 1.71 -- both sit at
+        // the packed-FMA power limit, DESIGN 3.1, and the six-wave kernel issues 17 % more VALU instructions)
+        if (h->front3_ok && fk == 2) { G.parts = 1; G.front3 = 1; }
+    }
     if (h->ola_mode) {
         // few channels: RF DC removal / balance / LO mix per sample, the input filter as the reference's block machine, then the decimators
         OlaBuffers O{}; O.src = h->d_v; O.dst = h->d_u; O.src_stride = O.dst_stride = h->cfg.max_block; O.src_mask = O.dst_mask = -1;
@@ -1197,6 +1217,9 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "squelch mode must be 0 (off), 1 (noise squelch) or 2 (level squelch)"); break;
     case FMX_P_SQUELCH_VALUE: if (iv < 0 || iv > 100) return fail(FMX_E_INVALID, "squelch value must be 0..100"); break;
     case FMX_P_PLL_SOLVER: if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "PLL solver must be 0 (automatic), 1 (sequential), 2 (Newton, sequential around lock decisions) or 3 (Newton always)"); break;
+    case FMX_P_FRONT_KERNEL:
+        if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "front kernel must be 0 (automatic), 1 (four waves per channel) or 2 (six waves per channel where it applies)");
+        h->front_kernel.store(iv); return FMX_OK;
     case FMX_P_FRONT_PARTS:
         if (iv < 0 || iv > 32) return fail(FMX_E_INVALID, "front parts must be 0 (automatic), 1 (one workgroup per channel) or 2..32");
         h->front_parts.store(iv); return FMX_OK;

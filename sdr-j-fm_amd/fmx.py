@@ -22,6 +22,7 @@ P_VOLUME_DB, P_LF_CUTOFF, P_BANDWIDTH, P_ATTENUATION_L, P_ATTENUATION_R, P_RDS_M
 P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE, P_SQUELCH_VALUE = 13, 14, 15, 16, 17, 18, 19
 P_DISP_DELAY = 20
 P_STAGEB_FORM = 22            # handle-wide: 0 automatic, 1 stage B as one kernel per call, 2 as two (bit-identical results)
+P_FRONT_KERNEL = 25           # handle-wide: 0 automatic, 1 four waves per channel (fmx_front.hip), 2 six waves per channel where it applies (fmx_front3.hip)
 P_FRONT_PARTS = 24            # handle-wide: 0 automatic, 1 one workgroup per channel, 2..32 parts in time per channel (bit-identical results)
 P_FILTER_RESTARTS = 23        # handle-wide, before the first call: 0 automatic, 1 the reference's block filters (<= 64 channels), 2 folded FIRs
 P_PLL_SOLVER = 21             # 0 automatic, 1 sequential (the reference's trajectory), 2 Newton while in lock + sequential around lock decisions, 3 Newton always

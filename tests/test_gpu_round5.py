@@ -1,0 +1,133 @@
+"""Round-5 GPU tests.  Stage A on three waves per SIMD (FMX_P_FRONT_KERNEL, csrc/fmx_front3.hip): the kernel takes the whole 1536-sample tiles of
+a call, front_kernel the rest -- the results must be front_kernel's bit for bit."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+M = importlib.import_module("sdr-j-fm_amd").fmx
+
+NCH, NST = 8, 3
+
+
+def _handle(fmx_amd, kernel, max_block, nch=NCH, nst=NST):
+    f = fmx_amd.Fmx(nch, streams=nst, stream_of_channel=[c % nst for c in range(nch)], max_block=max_block)
+    for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FM_MODE, 0)):
+        f.set_param(pid, v)
+    f.set_param(M.P_FILTER_RESTARTS, 2)          # (the folded filters: what batches run; the block machines of small handles have a stage A of their own)
+    f.set_param(M.P_FRONT_KERNEL, kernel)
+    f.set_param(M.P_FRONT_PARTS, 1)
+    # per-channel variety: another bandwidth (another tap set), IQ balance, RF DC removal off
+    f.set_param(M.P_BANDWIDTH, 120000, 1)
+    f.set_param(M.P_BANDWIDTH, 200000, 5)
+    f.set_param(M.P_ATTENUATION_L, 0.9, 2); f.set_param(M.P_ATTENUATION_R, 1.1, 2)
+    f.set_param(M.P_DC_REMOVE, 0, 3)
+    return f
+
+
+def _streams(ol, n):
+    iq = np.stack([ol.synth_iq(n, leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k) for k in range(NST)])
+    iq[0] += np.array([0.004, -0.003], np.float32)
+    iq[1] += np.array([-0.02, 0.015], np.float32)             # (beyond the +-0.01 limiter)
+    return iq
+
+
+def _run(f, iq, blocks, events=None):
+    """blocks: list of call lengths, or of tuples of lengths -- a tuple's samples are one stretch of the stream, made in that many calls"""
+    pcm, taps, dcs, pos = [], [], [], 0
+    for bi, b in enumerate(blocks):
+        if events and bi in events:
+            for pid, v, c in events[bi]:
+                f.set_param(pid, v, c)
+        for part in (b if isinstance(b, tuple) else (b,)):
+            pcm.append(f.process_host(iq[:, pos:pos + part])); pos += part
+            nt = f.last_fm_samples()
+            taps.append(np.stack([f.tap(M.TAP_FM_IQ, nt, c) for c in range(NCH)]))
+        dcs.append([(f.meta(c).live_rf_dc_re, f.meta(c).live_rf_dc_im) for c in range(NCH)])
+    return np.concatenate(pcm, axis=1), np.concatenate(taps, axis=1), np.array(dcs)
+
+
+def test_front3_whole_tiles_bit_identical(fmx_amd, ol):
+    """Calls of whole tiles (1 .. 150 of them: fewer tiles than the workgroup has waves, more, a multiple, not a multiple): six waves per channel
+    against four -- PCM, the fm-rate IQ and the RF DC state bit for bit; a setDCRemove in mid-stream (its reset of RfDC) on the way."""
+    blocks = [1536 * 10, 1536 * 150, 1536 * 1, 1536 * 7, 1536 * 6, 1536 * 5, 1536 * 13]
+    iq = _streams(ol, sum(blocks))
+    ev = {3: [(M.P_DC_REMOVE, 1, 3), (M.P_DC_REMOVE, 0, 4)], 5: [(M.P_DC_REMOVE, 1, 4)]}
+    outs = []
+    for kernel in (1, 2):
+        f = _handle(fmx_amd, kernel, max(blocks))
+        outs.append(_run(f, iq, blocks, ev))
+        del f
+    a, b = outs
+    assert np.isfinite(a[0]).all() and float(np.abs(a[0]).max()) > 0.01
+    assert np.array_equal(a[1], b[1]), "fm-rate IQ differs"
+    assert np.array_equal(a[2], b[2]), "RF DC state differs"
+    assert np.array_equal(a[0], b[0]), "PCM differs"
+
+
+def test_front3_remainders_and_fallbacks(fmx_amd, ol):
+    """Calls that are not whole tiles: the six-wave kernel takes the tiles, front_kernel the remainder as a call of its own -- so a handle on
+    front_kernel alone that is given the same stretches in two calls (tiles, remainder) must agree bit for bit in the fm-rate IQ.  Calls shorter
+    than a tile, calls that leave the 12-sample column grid (everything behind them is front_kernel's), a local oscillator switched on (the
+    handle falls back) and off again (the six-wave kernel finds a history of mixed samples and converts it)."""
+    T = 1536
+    stretches = [(3 * T, 480), (600,), (9 * T, 36), (2 * T, 1500), (7 * T,), (T, 12), (4 * T, 7), (5 * T,), (2 * T + 100,)]
+    n = sum(sum(s) for s in stretches)
+    iq = _streams(ol, n)
+    ev = {4: [(M.P_LOCAL_OSCILLATOR, 200000, 6)], 5: [(M.P_LOCAL_OSCILLATOR, 0, 6)]}
+    fa = _handle(fmx_amd, 1, 16 * T)
+    a = _run(fa, iq, stretches, ev)
+    del fa
+    fb = _handle(fmx_amd, 2, 16 * T)
+    b = _run(fb, iq, [sum(s) for s in stretches], ev)
+    del fb
+    assert np.array_equal(a[1], b[1]), "fm-rate IQ differs"
+    assert np.array_equal(a[2], b[2]), "RF DC state differs"
+    # the stages behind are invariant to the cut to rounding only
+    assert float(np.abs(a[0] - b[0]).max()) < 2e-6
+
+
+def test_front3_against_oracle_in_a_batch(fmx_amd, ol):
+    """600 channels on 4 streams, six waves per channel (two channels per workgroup, an even count), three calls -- whole tiles,
+    tiles and a remainder twice --, every 152nd channel against the oracle chain on its stream."""
+    nch, nst, T = 600, 4, 1536
+    blocks = [T * 100, T * 50 + 300, T * 42 - 300]          # (18 of the oracle's 16384-sample blocks)
+    n = sum(blocks)
+    iq = np.stack([ol.synth_iq(n, leftHz=500.0 + 250 * k, rightHz=900.0 + 150 * k) for k in range(nst)])
+    f = fmx_amd.Fmx(nch, streams=nst, stream_of_channel=[c % nst for c in range(nch)], max_block=max(blocks))
+    for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FRONT_KERNEL, 2)):
+        f.set_param(pid, v)
+    pcm, pos = [], 0
+    for b in blocks:
+        pcm.append(f.process_host(iq[:, pos:pos + b])); pos += b
+    pcm = np.concatenate(pcm, axis=1)
+    for k in range(nst):
+        ch = ol.OracleChain(inputFilterBw=165000)
+        ref = ch.process(iq[k])
+        for c in range(k, nch, 152):
+            assert pcm[c].shape == ref.shape, (pcm[c].shape, ref.shape)
+            err = float(np.sqrt(np.mean((pcm[c].astype(np.float64) - ref) ** 2)))
+            assert err <= 1e-5, (c, err)
+
+
+def test_long_rds_calls_in_pieces_at_a_rate_decimated_by_six(fmx_amd, ol):
+    """the pieces a long call is made in while a channel decodes RDS are 31999 FM samples -- 191994 input samples at 2.048 MS/s, which
+    the reference decimates by 6, not the 383988 of 2.304 MS/s.  One call of 921600 samples (153600 fm samples) against four of 230400 (each of
+    which is itself made in pieces: 38400 fm samples): the same PCM to the chain's block-size invariance, the same bits."""
+    rate, n = 2048000, 921600
+    iq = np.stack([ol.synth_iq(2 * n, inputRate=rate, rds=1, rdsLevel=0.05, rdsBitsSeed=sd) for sd in (5, 6)])
+    res = []
+    for blocks in ([230400] * 4 + [n], [230400] * 8):
+        f = fmx_amd.Fmx(2, max_block=n, inputRate=rate)
+        for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FILTER_RESTARTS, 2), (M.P_RDS_MODE, 2)):
+            f.set_param(pid, v)
+        pcm, pos = [], 0
+        for b in blocks:
+            pcm.append(f.process_host(iq[:, pos:pos + b])); pos += b
+        res.append((np.concatenate(pcm, axis=1), [f.rds_bits(c, 8192) for c in range(2)], f.last_fm_samples()))
+        del f
+    (p1, b1, l1), (p4, b4, l4) = res
+    assert p1.shape == p4.shape and float(np.sqrt(np.mean((p1.astype(np.float64) - p4) ** 2))) <= 2e-7
+    assert all(len(a) == len(b) and np.array_equal(a, b) for a, b in zip(b1, b4))
+    assert l1 == (n - 4 * 191994) // 6 and l4 == (230400 - 191994) // 6        # (the taps hold the last piece)
