@@ -307,6 +307,7 @@ def selftest_spawn(args):
     if rank == 0:
         assert full.shape[0] == world * ch and all(float(full[r * ch, 0, 0]) == r for r in range(world))
         print(json.dumps({"selftest": True, "metric": "IQ MSamples/s demodulated to 48 kHz stereo", "value": None, "n_gpus": world,
+                          "rccl_ranks": dist.get_world_size(), "rccl_backend": dist.get_backend(),
                           "steps": args.steps, "warmup": args.warmup, "max_dt": dt, "scaling": "weak",
                           "per_rank": [float(v.item()) for v in vals], "gather": {"ms": round(g_ms, 3)}}))
     dist.barrier()
@@ -631,6 +632,8 @@ def main():
         out = {
             "metric": "IQ MSamples/s demodulated to 48 kHz stereo",
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # what the process group saw, not what the environment said (1 / none without a process group): the evidence that N ranks joined
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "rccl_backend": dist.get_backend() if world > 1 else None,
             "untimed_calls": untimed,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

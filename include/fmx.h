@@ -96,7 +96,11 @@ typedef enum {
                                   (pilot-recover.cpp:62-80) is taken on the reference's own trajectory: what large batches use;
                                   3 = Newton's method always (diagnostic: lock decisions may then fall a few samples apart from the
                                   reference's when the metric creeps through its threshold); 0 = automatic: 1 up to 64 channels per
-                                  handle, 2 above (default) */
+                                  handle, 2 above (default).  "The reference's trajectory" to this bound: every evaluation of the loop step,
+                                  the sequential one included, takes the NCO sine from the GPU's sine unit, within 1.2e-7 of the
+                                  reference's table entry (not that entry bit for bit, and the unit's rounding is this architecture's);
+                                  the lock decisions were equal to the oracle's in every tested case, which a metric creeping at 1e-6
+                                  per sample through its threshold does not guarantee to the sample. */
     FMX_P_STAGEB_FORM = 22,    /* (handle-wide: the channel argument is ignored) stage B -- limiter .. de-emphasis -- as 1 = one kernel per call,
                                   2 = two kernels (limiter .. lock detector, then PSS .. de-emphasis: four workgroups per CU instead of
                                   three); 0 = automatic (default): whichever wastes less of its last round of workgroups for the

@@ -1254,13 +1254,14 @@ static void delay_set_steps(fmo_chain *ch, uint32_t steps);
 static void apply_settings(fmo_chain *ch, const fmo_config *c, int initial) {
     const fmo_config old = ch->cfg;
     ch->cfg = *c;
+    ch->cfg.touchInputFilter = 0; ch->cfg.touchLfCutoff = 0;
     /* setBandwidth fm-processor.cpp:232-239 */
-    if (initial || c->inputFilterBw != old.inputFilterBw) {
+    if (initial || c->inputFilterBw != old.inputFilterBw || c->touchInputFilter) {
         if (c->inputFilterBw <= 0) ch->inputFilterOn = 0;
         else { ch->fmBandwidth = c->inputFilterBw; ch->newInputFilter = 1; }
     }
     /* setlfcutoff :762-770 */
-    if (initial || c->lfCutoff != old.lfCutoff) {
+    if (initial || c->lfCutoff != old.lfCutoff || c->touchLfCutoff) {
         if (c->lfCutoff > 0) { ch->lowPassFrequency = c->lfCutoff; ch->newAudioFilter = 1; }
         else ch->audioFilterActive = 0;
     }

@@ -202,6 +202,9 @@ typedef struct {
     int32_t squelchValue;     /* set_squelchValue 0..100: applied at a block start when it differs from the last one (:410-413) */
     int32_t testTone;         /* setTestTone (fm-processor.cpp:931-933): 1 kHz bursts of 25 ms every 2 s mixed into the PCM (:800-823) */
     int32_t dispDelay;        /* setDispDelay (:935-937): steps of the peak-level delay line */
+    /* one-shot, consumed by fmo_chain_configure: the setter was CALLED, whatever the value -- setBandwidth (:232-239) / setlfcutoff (:762-770) set
+     * newInputFilter / newAudioFilter even when the current value is selected again, and the loop then restarts the filter's block (:396-408) */
+    int32_t touchInputFilter, touchLfCutoff;
 } fmo_config;
 
 void fmo_config_defaults(fmo_config *);   /* GUI-effective defaults, SURVEY 3.3 */

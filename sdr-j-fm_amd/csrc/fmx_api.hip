@@ -37,6 +37,8 @@ int next_pow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return (int)p; 
 struct ChanUser {
     int32_t bandwidth = 0;       // 0 = Off.  NB ctor default: inputFilterOn=false (fm-processor.cpp:149)
     int32_t lf_cutoff = 0;       // <=0 = off. ctor default fmAudioFilterActive=false (:164)
+    bool bw_event = false, lf_event = false;   // setBandwidth / setlfcutoff CALLED with a value since the last call: the reference sets newInputFilter /
+                                 // newAudioFilter whatever the value (:232-239, :762-770), and its loop restarts the filter's block (:396-408)
     int32_t deemph_us = 0;       // 0 = ctor default alpha (:174)
     bool    ctor_volume = true;  // volumeFactor = 0.5f (:127) until setVolume
     float   volume_db = 0.f;
@@ -508,7 +510,10 @@ int ola_take_settings(fmx_handle h) {
         fmx_handle_s::OlaSide &S = side ? h->ola_au : h->ola_in;
         for (int c = 0; c < h->channels; c++) {
             const int32_t want = side ? (h->user[c].lf_cutoff > 0 ? h->user[c].lf_cutoff : 0) : (h->user[c].bandwidth > 0 ? h->user[c].bandwidth : 0);
-            if (want == S.key[(size_t)c]) continue;
+            bool &ev = side ? h->user[c].lf_event : h->user[c].bw_event;
+            const bool again = ev && want != 0 && S.key[(size_t)c] >= 0;        // (the value in use selected again: the block restarts, the kernel stays)
+            ev = false;
+            if (want == S.key[(size_t)c]) { if (again) { S.on[(size_t)c] = 1; S.inp[(size_t)c] = 0; } continue; }
             S.key[(size_t)c] = want;
             if (want == 0) { S.on[(size_t)c] = 0; continue; }
             const std::vector<float> k = side ? design::lowpass(AUDIO_TAPS, want, h->cfg.fmRate) : design::lowpass(251, want / 2, h->cfg.inputRate);
@@ -1264,8 +1269,8 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         case FMX_P_SOUND_BALANCE: u.balance = iv; h->gain_dirty = true; break;
         case FMX_P_DEEMPHASIS: u.deemph_us = iv; break;
         case FMX_P_VOLUME_DB: u.volume_db = (float)value; u.ctor_volume = false; h->gain_dirty = true; break;
-        case FMX_P_LF_CUTOFF: u.lf_cutoff = iv > 0 ? iv : 0; h->sets_dirty = true; break;
-        case FMX_P_BANDWIDTH: u.bandwidth = iv; h->sets_dirty = true; break;
+        case FMX_P_LF_CUTOFF: u.lf_cutoff = iv > 0 ? iv : 0; u.lf_event = iv > 0; h->sets_dirty = true; break;
+        case FMX_P_BANDWIDTH: u.bandwidth = iv; u.bw_event = iv > 0; h->sets_dirty = true; break;
         case FMX_P_ATTENUATION_L: p.att_l = (float)value; break;
         case FMX_P_ATTENUATION_R: p.att_r = (float)value; break;
         case FMX_P_RDS_MODE: p.rds_mode = iv; break;

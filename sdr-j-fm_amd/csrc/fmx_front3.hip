@@ -237,6 +237,21 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
         F3_TICK(9);
         if (!(F3_ABL & 16) && ti - NW + 1 >= 0) seq_wait(&fir_seq[nw], ti - NW + 2);
         F3_TICK(0);
+        if (F3_ABL & 64) {
+            // (diagnostic: the scatter of the f16-split form -- per sample pair two scalings, hi parts, remainders, lo parts, four 4-byte LDS writes)
+            float *Xf = reinterpret_cast<float *>(X4);
+#pragma unroll
+            for (int k = 0; k < SPT / 2; k++) {
+                const float4 r = raw[k];
+                const float x0 = r.x * 4096.f, y0 = r.y * 4096.f, x1 = r.z * 4096.f, y1 = r.w * 4096.f;
+                typedef __fp16 v2h __attribute__((ext_vector_type(2)));
+                const v2h hr = __builtin_amdgcn_cvt_pkrtz(x0, x1), hi = __builtin_amdgcn_cvt_pkrtz(y0, y1);
+                const float dx0 = x0 - (float)hr.x, dx1 = x1 - (float)hr.y, dy0 = y0 - (float)hi.x, dy1 = y1 - (float)hi.y;
+                const v2h lr = __builtin_amdgcn_cvt_pkrtz(dx0, dx1), li = __builtin_amdgcn_cvt_pkrtz(dy0, dy1);
+                Xf[lane + 64 * k] = __builtin_bit_cast(float, hr); Xf[768 + lane + 64 * k] = __builtin_bit_cast(float, hi);
+                Xf[1536 + lane + 64 * k] = __builtin_bit_cast(float, lr); Xf[2304 + lane + 64 * k] = __builtin_bit_cast(float, li);
+            }
+        } else
         if (F3_ABL & 1) { asm volatile("" :: "v"(raw[0].x), "v"(raw[1].x), "v"(raw[2].x), "v"(raw[3].x), "v"(raw[4].x), "v"(raw[5].x), "v"(raw[6].x), "v"(raw[7].x), "v"(raw[8].x), "v"(raw[9].x), "v"(raw[10].x), "v"(raw[11].x)); }
         else
 #pragma unroll
@@ -264,6 +279,28 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
         v2f acc[FCOLS];
 #pragma unroll
         for (int k = 0; k < FCOLS; k++) acc[k] = (v2f){0.f, 0.f};
+        if (F3_ABL & 32) {
+            // (diagnostic: the shape of an f16-split FIR on the matrix pipe -- 15 K-steps of two operand pairs and three v_mfma_f32_16x16x32_f16, then
+            // 6 steps of column sums with two each; operands from the image as it is: the results are garbage)
+            typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+            typedef float v4f_ __attribute__((ext_vector_type(4)));
+            v4f_ am = (v4f_){0.f, 0.f, 0.f, 0.f}, as = am;
+            const float4 *pa = reinterpret_cast<const float4 *>(sT) + (lane & 15);
+            const float4 *pb = X4 + lane;
+#pragma unroll
+            for (int j = 0; j < 15; j++) {
+                const float4 a0 = pa[(j & 3) * 16], a1 = pa[((j + 1) & 3) * 16], b0 = pb[j * 48], b1 = pb[j * 48 + 24];
+                const v8h ah = __builtin_bit_cast(v8h, a0), al = __builtin_bit_cast(v8h, a1), bh = __builtin_bit_cast(v8h, b0), bl = __builtin_bit_cast(v8h, b1);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, am, 0, 0, 0);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, am, 0, 0, 0);
+                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, am, 0, 0, 0);
+                if (j >= 9) {
+                    as = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, as, 0, 0, 0);
+                    as = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bl, as, 0, 0, 0);
+                }
+            }
+            acc[0] = (v2f){am.x + as.x, am.y + as.y}; acc[1] = (v2f){am.z + as.z, am.w + as.w};
+        } else
         if (F3_ABL & 4) { acc[0] = (v2f){(float)cg, 1.f}; }
         else {
             float4 WP[3][16], TQ[3][7];

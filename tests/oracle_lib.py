@@ -37,6 +37,7 @@ class FmoConfig(C.Structure):
         ("attL", C.c_float), ("attR", C.c_float), ("loFrequency", C.c_int32),
         ("dcRemove", C.c_int32), ("autoMono", C.c_int32), ("pssActive", C.c_int32), ("rdsMode", C.c_int32),
         ("squelchMode", C.c_int32), ("squelchValue", C.c_int32), ("testTone", C.c_int32), ("dispDelay", C.c_int32),
+        ("touchInputFilter", C.c_int32), ("touchLfCutoff", C.c_int32),
     ]
 
 
@@ -358,7 +359,11 @@ class OracleChain:
     def configure(self, **kw):
         for k, v in kw.items():
             setattr(self.cfg, k, v)
+        # a keyword given = the reference's setter called: setBandwidth / setlfcutoff restart their filter even when the value is the current one
+        self.cfg.touchInputFilter = 1 if "inputFilterBw" in kw else 0
+        self.cfg.touchLfCutoff = 1 if "lfCutoff" in kw else 0
         self.L.fmo_chain_configure(self.h, C.byref(self.cfg))
+        self.cfg.touchInputFilter = 0; self.cfg.touchLfCutoff = 0
 
     def process(self, iq):
         iq = np.ascontiguousarray(iq, np.float32).reshape(-1, 2)

@@ -25,6 +25,8 @@ def test_gpus_flag_spawns_ranks():
     out = json.loads(lines[0])
     assert out["selftest"] is True and out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
     assert out["max_dt"] == 0.75 and out["per_rank"] == [0.0, 1.0] and out["scaling"] == "weak"
+    # what the process group itself reports (n_gpus alone only repeats the environment) and the gather leg
+    assert out["rccl_ranks"] == 2 and out["rccl_backend"] == "gloo" and out["gather"]["ms"] >= 0
 
 
 def test_world_size_mismatch_fails_loudly():
