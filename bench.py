@@ -596,6 +596,7 @@ def main():
         value = total / dt / 1e6
         launches = max(prof["launches"][0], 1)
         ms_a = prof["ms"][0] / launches
+        front_kernel_used = f.last_front_kernel()       # which of the three stage-A kernels the handle ran (include/fmx.h: FMX_P_FRONT_KERNEL)
         # algorithmic bytes of ONE front-end launch: every channel reads its n samples (8 B) and writes n/12 (8 B)
         alg_bytes = ALG_BYTES_STAGE_A * channels * n
         achieved = alg_bytes / (ms_a * 1e-3) / 1e9 if ms_a > 0 else 0.0
@@ -642,7 +643,8 @@ def main():
                        "streams_per_gpu": nstreams, "block_samples_per_channel": n,
                        "realtime_channels_equiv": round(value / 2.304, 1),
                        "pcm_frames_per_channel_per_step": frames // max(args.steps, 1), "parallelism": "channels sharded, 1 rank/GPU"},
-            "roofline": {"bound": "hbm", "kernel": "fmx::front_kernel (input FIR stage)", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": {1: "fmx::front_kernel", 2: "fmx::f3::front3_kernel", 3: "fmx::f4::front4_kernel"}.get(front_kernel_used, "?") + " (input FIR stage)",
+                         "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_read_only": round(achieved * (8.0 / ALG_BYTES_STAGE_A) / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "avg_launch_ms": round(ms_a, 4),

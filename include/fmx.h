@@ -116,11 +116,18 @@ typedef enum {
                                   fewer channels than the GPU has workgroup slots splits every channel's call in time over several workgroups
                                   (each later one recomputes one 1536-sample tile to get its filter history): 0 = automatic (default), 1 = never,
                                   2..32 = that many parts wherever a call is long enough.  The results are bit-identical. */
-    FMX_P_FRONT_KERNEL = 25,   /* (handle-wide: the channel argument is ignored) which kernel runs the input-filter stage: 1 = four waves per channel, two
-                                  workgroups per CU, for every call; 2 = six waves per channel, three per SIMD (fmx_front3.hip), for the whole
-                                  1536-sample tiles of every call it can take -- float32 samples, no local oscillator on any channel, the
-                                  input filter on everywhere, a call that starts on a multiple of 12 samples -- and kernel 1 for the rest;
-                                  0 = automatic (default): kernel 1 (the faster one where measured).  The results are bit-identical. */
+    FMX_P_FRONT_KERNEL = 25,   /* (handle-wide: the channel argument is ignored) which kernel runs the input-filter stage.
+                                  1 = fmx_front.hip: four waves per channel, the folded filter as packed f32 FMAs; every input format, local
+                                  oscillators, any call.
+                                  2 = fmx_front3.hip: the same arithmetic on six waves per channel (bit-identical results; measured slower).
+                                  3 = fmx_front4.hip: the filter on the matrix pipe -- samples and taps split into two f16 halves each, their
+                                  products exact in the f32 accumulator, the remainders' roundings at 2^-22 of a product: the fm-rate IQ
+                                  agrees with kernel 1's to 5e-7 of its amplitude, PCM against the oracle is unchanged.  THE SAMPLES MUST
+                                  STAY BELOW 16 IN MAGNITUDE (the reference's devices deliver +-1); larger ones overflow f16.
+                                  2 and 3 take the whole 1536-sample tiles of the calls they can -- float32 samples, no local oscillator on
+                                  any channel, the input filter on everywhere, a call that starts on a multiple of 12 samples -- and leave
+                                  the rest to kernel 1.
+                                  0 = automatic (default): 3 where a handle qualifies and has the channels to fill the GPU, else 1. */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */
@@ -278,6 +285,9 @@ int64_t fmx_pll_replays(fmx_handle h, int32_t channel);
 /* Segments (of up to 1536 fm samples) that FMX_P_PLL_SOLVER = 2 evaluated sequentially because the pilot was not comfortably in lock,
  * of `channel` since fmx_create (channel < 0: summed over all channels), or a negative fmx error code: what the guard costs. */
 int64_t fmx_pll_exact_segments(fmx_handle h, int32_t channel);
+/* Which kernel the last fmx_process_* call gave its input-filter stage to (FMX_P_FRONT_KERNEL's numbering: 1, 2 or 3; the remainder of a call
+ * that is not whole 1536-sample tiles always goes to kernel 1): what a benchmark names beside its number. */
+int32_t fmx_last_front_kernel(fmx_handle h);
 /* ... and 24 kS/s RDS samples (rdsDecimator outputs, fm-processor.cpp:553): the n that fmx_get_tap accepts for FMX_TAP_RDS_IQ */
 int64_t fmx_last_rds_samples(fmx_handle h);
 

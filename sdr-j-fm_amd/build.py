@@ -15,6 +15,7 @@ LIB = os.path.join(LIBDIR, "libfmx.so")
 SOURCES = [
     ("fmx_front.hip", []),
     ("fmx_front3.hip", []),
+    ("fmx_front4.hip", []),
     ("fmx_demod.hip", ["-ffp-contract=off"]),
     ("fmx_stageb.hip", ["-ffp-contract=off"]),
     ("fmx_audio.hip", []),

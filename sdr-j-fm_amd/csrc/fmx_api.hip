@@ -115,6 +115,8 @@ struct fmx_handle_s {
     std::atomic<int> front_parts{0};     // FMX_P_FRONT_PARTS
     std::atomic<int> front_kernel{0};    // FMX_P_FRONT_KERNEL
     bool front3_ok = false;              // every channel qualifies for front3_kernel (flush_mailbox)
+    bool front4_ok = false;              // ... and for front4_kernel
+    int last_front_kernel = 1;           // what the last call's stage A was given (FMX_P_FRONT_KERNEL numbering): fmx_last_front_kernel
     PreLook pre_look{};                  // pre_kernel's look-back buffers (ensure_ola)
     void *hp_iq = nullptr; float2 *hp_pcm = nullptr; size_t hp_iq_bytes = 0; int64_t hp_pcm_cap = 0;   // fmx_process_host: pinned, device-visible staging of small calls
     // the reference's two overlap-add filters as the block machines they are (fmx_ola.hip): handles of up to OLA_MAX_CH channels
@@ -589,6 +591,8 @@ int flush_mailbox(fmx_handle h) {
             ok = fs.nd > 4 && fs.dc_k >= 1 && fs.dc_k <= 13;
         }
         h->front3_ok = ok;
+        for (auto &p : h->params) { if (!ok) break; ok = h->h_front_sets[(size_t)p.front_set].dc_k == 12; }
+        h->front4_ok = ok;
     }
     bool any_rds = false;
     for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
@@ -777,9 +781,12 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     {
         static const int fk_env = getenv("FMX_FRONT_KERNEL") ? atoi(getenv("FMX_FRONT_KERNEL")) : 0;     // (diagnostic: A/B runs of one build)
         const int fk = h->front_kernel.load() ? h->front_kernel.load() : fk_env;
-        // (automatic = the four-wave kernel: measured on one box, 4096 channels, the six-wave kernel takes 1.84 ms per launch against 1.71 -- both sit at
-        // the packed-FMA power limit, DESIGN 3.1, and the six-wave kernel issues 17 % more VALU instructions)
+        // automatic: the filter on the matrix pipe wherever a handle qualifies and has the channels to fill the chip without splitting them in time
+        // (measured at 4096 channels on one box: 1.52 ms per launch against 1.75 for the four-wave kernel and 1.84 for the six-wave VALU kernel, which
+        // both sit at the packed-FMA power limit)
         if (h->front3_ok && fk == 2) { G.parts = 1; G.front3 = 1; }
+        if (h->front4_ok && (fk == 3 || (fk == 0 && G.parts <= 1))) { G.parts = 1; G.front3 = 2; }
+        h->last_front_kernel = G.front3 == 2 ? 3 : (G.front3 == 1 ? 2 : 1);
     }
     if (h->ola_mode) {
         // few channels: RF DC removal / balance / LO mix per sample, the input filter as the reference's block machine, then the decimators
@@ -1223,7 +1230,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_SQUELCH_VALUE: if (iv < 0 || iv > 100) return fail(FMX_E_INVALID, "squelch value must be 0..100"); break;
     case FMX_P_PLL_SOLVER: if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "PLL solver must be 0 (automatic), 1 (sequential), 2 (Newton, sequential around lock decisions) or 3 (Newton always)"); break;
     case FMX_P_FRONT_KERNEL:
-        if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "front kernel must be 0 (automatic), 1 (four waves per channel) or 2 (six waves per channel where it applies)");
+        if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "front kernel must be 0 (automatic), 1 (four waves per channel), 2 (six waves per channel) or 3 (the filter on the matrix pipe)");
         h->front_kernel.store(iv); return FMX_OK;
     case FMX_P_FRONT_PARTS:
         if (iv < 0 || iv > 32) return fail(FMX_E_INVALID, "front parts must be 0 (automatic), 1 (one workgroup per channel) or 2..32");
@@ -1560,6 +1567,7 @@ int64_t fmx_pll_exact_segments(fmx_handle h, int32_t channel) {
     for (auto &s : st) n += s.pll_exact_segs;
     return n;
 }
+int32_t fmx_last_front_kernel(fmx_handle h) { return h ? h->last_front_kernel : 0; }
 int64_t fmx_last_rds_samples(fmx_handle h) { return (h && h->rds_alloc) ? (int64_t)(h->last_m1 - h->last_m0) : 0; }
 
 int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {

@@ -757,10 +757,10 @@ void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
     if (G.front3) {
         // batches that fill the chip: the call's whole tiles on three waves per SIMD, what is left of it (less than a tile) behind them as a
         // call of its own -- the chain is invariant to how a stream is cut into calls
-        const int k = front3_tiles(G, iq);
+        const int k = G.front3 == 2 ? front4_tiles(G, iq) : front3_tiles(G, iq);
         if (k > 0) {
             CallGeom G3 = G; G3.n = (int64_t)k * WSAMP; G3.parts = 1;
-            launch_front3(T, B, G3, iq, channels, s);
+            if (G.front3 == 2) launch_front4(T, B, G3, iq, channels, s); else launch_front3(T, B, G3, iq, channels, s);
             if (G3.n == G.n) return;
             CallGeom G2 = G; G2.front3 = 0; G2.cont = 1; G2.parts = 1; G2.g0 = G.g0 + G3.n; G2.n = G.n - G3.n;
             launch_front(T, B, G2, reinterpret_cast<const char *>(iq) + (size_t)G3.n * sizeof(float2), channels, s);

@@ -1,0 +1,402 @@
+// fmx_front4.hip -- stage A for the batches that fill the chip, the input FIR on the MATRIX pipe.
+//
+// Replaces, per channel and per call (as front_kernel does):
+//   RF DC removal            fm-processor.cpp:423-446   (applied behind the filter, fmx_front.hip)
+//   IQ balance               fm-processor.cpp:462-464
+//   inputFilter (251 taps)   fm-processor.cpp:469-470, fft-filters.cpp:132-163
+//   fmBand_1 (25 taps, /6)   fm-processor.cpp:472,  fir-filters.cpp:397-424
+//   fmBand_2 (3 taps, /2)    fm-processor.cpp:474
+//
+// Why.  front_kernel (and its six-wave sibling fmx_front3.hip) spend 600 v_pk_fma_f32 per 1536-sample tile on the folded 287-tap filter, and a
+// kernel of packed FMAs runs this GPU into its power limit: 93 TFLOP/s sustained of the nominal 157 (tools/ubench/pkfma_clock.hip).  With
+// every load compiled out front3_kernel takes 1.67 ms per launch at 4096 channels, with everything BUT the loads compiled out 1.49 ms
+// (tools/diag/f3_ablate.sh): the stage sits at the vector ALU's power limit, not at the HBM stream's.  The f32 matrix instruction is no way
+// out (round 2, fmx_front2.hip: the Toeplitz form wastes 38 % of its multiplies, and it runs on the same f32 data path).  The f16 matrix
+// instruction is: sixteen times the rate, so the filter can afford both the Toeplitz zeros and a SPLIT of every operand into two halves --
+//     x * 2^12 = xh + xl,   t * 2^14 = th + tl      (xh, th: the value rounded to f16; xl, tl: the remainder rounded to f16)
+//     sum t x  ~  2^-26 sum (th xh + th xl + tl xh)  (+ tl xl with FMX_F4_TERMS = 4)
+// -- products of f16 values are exact in the f32 accumulator, so what is lost is the rounding of the remainders and the dropped tl xl: 2^-21
+// of a product, the same order as the f32 filter's own rounding (measured against front_kernel: tests/test_gpu_round5.py).  The pre-scales keep
+// the remainders of every sample above 1e-8 and of every tap above 4e-9 out of f16's subnormals.  |x| must stay below 16 (the reference's
+// devices deliver +-1).
+//
+// Layout.  K of the matrix product is TIME: the Toeplitz matrix A[i][k] = G[12 i + off + 288 - k] of the folded taps G (16 adjacent outputs i
+// against the 480 samples k of their 40-column window) times B[k][n] = the window of column block b, component comp, n = 2 b + comp.  So the
+// LDS image is simply the de-interleaved stream -- four linear planes of f16 (hi re, hi im, lo re, lo im) over a RING of the channel's last six
+// tiles: a tile's filter reads its 288 history samples in place in front of its own, the scatter is four linear 4-byte writes per sample pair
+// (one address register), a lane's operand is 16 consecutive bytes of a plane (one address register for all of a tile's 30 reads).  The column
+// sums the RF DC recurrence needs come off the same operands: two more matrix instructions per K-step with a boxcar of ones for A.
+//   per tile and wave: 45 + 12 v_mfma_f32_16x16x32_f16, 66 LDS operand reads, ~300 plain VALU instructions (conversion, DC scan, epilogue)
+// instead of 600 packed FMAs and ~370 others.
+// Six waves per channel, two channels per workgroup, one workgroup per CU, the waves of a channel staggered through its tiles as in
+// fmx_front3.hip (scatter, prefetch of the wave's next tile, filter, DC recurrence through a mailbox, output).
+#include "fmx_internal.h"
+#include "fmx_front_dc.h"
+
+namespace fmx {
+namespace f4 {
+
+constexpr int NW = 6;                          // waves (= ring slots) per channel
+constexpr int CPW = 2;                         // channels per workgroup
+constexpr int NTHR = 64 * NW * CPW;
+constexpr int WCOLS = 128;                     // columns (= outputs) per tile
+constexpr int WSAMP = WCOLS * DECIM;           // 1536 input samples per tile
+constexpr int SPT = 2 * DECIM;                 // 24 samples per lane per tile
+constexpr int HL = A_HIST_COLS - 1;            // 24 history columns in front of a tile
+constexpr int HS = HL * DECIM;                 // = 288 samples
+constexpr int PL = NW * WSAMP + HS;            // samples per plane: the ring, and in front of it a mirror of its last 288 samples (slot 0's history)
+constexpr int PLB = PL * 2;                    // bytes per plane (19008)
+constexpr int KSTEPS = (HL + 16) * DECIM / 32; // 15 K-steps of 32 samples over the 480-sample window
+constexpr int KSUM0 = HS / 32;                 // the block's own 16 columns begin at K-step 9
+constexpr int TA_N = 664;                      // entries of a reversed tap table: u = 32 j + 8 kg + e + 180 - 12 i in [0, 660)
+constexpr int MB_N = 16;                       // mailbox slot: [0..12] RfDC in front of columns -13 .. -1 of the next tile, [13] in front of its column 0 (= the carry)
+#ifndef FMX_F4_TERMS
+#define FMX_F4_TERMS 3
+#endif
+constexpr float XSC = 4096.f, TSC = 16384.f;   // pre-scales of the samples and of the taps
+constexpr float OSC = 1.0f / (4096.f * 16384.f);
+static_assert(HS % 32 == 0 && KSTEPS == 15 && PLB % 16 == 0 && (TA_N * 2) % 16 == 0, "geometry");
+
+typedef _Float16 h16;
+typedef h16 v8h __attribute__((ext_vector_type(8)));
+typedef h16 v2h __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bperm(int src_lane, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
+__device__ __forceinline__ float dpp_swap1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)); }   // quad_perm [1,0,3,2]
+template <int SH> __device__ __forceinline__ float dpp_row_shr(float v) {        // lanes shifted right by SH within their row of 16, zeros shifted in
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + SH, 0xf, 0xf, true));
+}
+// a sample pair of one component, scaled: the two f16 roundings and the two f16 remainders, packed
+__device__ __forceinline__ void split2(float a, float b, uint32_t *hi, uint32_t *lo) {
+    const h16 ha = (h16)a, hb = (h16)b;
+    const h16 la = (h16)(a - (float)ha), lb = (h16)(b - (float)hb);
+    *hi = __builtin_bit_cast(uint32_t, (v2h){ha, hb});
+    *lo = __builtin_bit_cast(uint32_t, (v2h){la, lb});
+}
+
+#ifndef F4_ABL
+#define F4_ABL 0      /* diagnostic builds only: bit 0 no scatter, 1 no DC pass, 2 no matrix FIR, 3 no tile loads behind the first (garbage results) */
+#endif
+
+template <bool NTL>
+__global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3))) void front4_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
+                                                                                                       const float2 *__restrict__ iq) {
+    struct ChanLds {
+        h16 pl[4][PL];                     // hi re, hi im, lo re, lo im of the channel's newest six tiles (and the mirror)
+        h16 ta[3][TA_N];                   // reversed tap table: hi, lo, and the boxcar of ones that sums a column
+        float2 mb[8][MB_N];                // RfDC boundaries behind tile ti, slot = ti & 7
+        int carry_seq;                     // tiles whose mailbox slot is published
+        int scat_seq[NW], fir_seq[NW];     // per wave: tiles scattered / tiles whose filter has read everything, + 1
+        int pad_[3];
+    };
+    __shared__ __attribute__((aligned(16))) ChanLds Lall[CPW];
+
+    const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (64 * NW));
+    const int ch_raw = (int)blockIdx.x * CPW + half;
+    const bool active = ch_raw < G.channels;                               // (an odd channel count: the last workgroup's second half has nothing to do)
+    const int ch = active ? ch_raw : G.channels - 1;
+    const int t = (int)threadIdx.x - half * (64 * NW);                     // thread index within the channel's six waves
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    ChanLds &L = Lall[half];
+    float2 (&mb)[8][MB_N] = L.mb;
+    int &carry_seq = L.carry_seq;
+    int (&scat_seq)[NW] = L.scat_seq;
+    int (&fir_seq)[NW] = L.fir_seq;
+    char *const plc = reinterpret_cast<char *>(&L.pl[0][0]);
+    const char *const tac = reinterpret_cast<const char *>(&L.ta[0][0]);
+    const ChanParams P = B.params[ch];
+    const FrontSet FS = T.front_sets[P.front_set];
+    const float2 *__restrict__ in = iq + (size_t)P.stream * G.stream_stride;
+    ChanState *st = B.state + ch;
+    float2 *hist = B.hist + (size_t)ch * DECIM * A_HIST_COLS;
+    float2 *zring = B.zring + (size_t)ch * (G.ring_mask + 1);
+
+    // Call-local geometry (front_kernel's, with the call starting on a column boundary and ending on a tile boundary)
+    const int64_t qa = G.g0 / 12;
+    const int NT = (int)(G.n / WSAMP);
+    const int off = FS.off;
+    const int ja = (int)((G.g0 - off + 11) / 12 - qa);              // first output completed by this call
+    const int jb = (int)((G.g0 + G.n - off + 11) / 12 - qa);        // one past the last
+    const int zr0 = (int)((qa + FS.zshift) & (int64_t)G.ring_mask);
+
+    // ---- tap tables: entry u holds G[M0 - u], G the folded filter in time order (G[12 d + off - r] = Trd[r][d])
+    {
+        const int M0 = off + 468;
+        for (int u = t; u < TA_N; u += 64 * NW) {
+            const int m = M0 - u;
+            float g = 0.f;
+            if (m >= 0) {
+                const int r = ((off - m) % DECIM + DECIM) % DECIM, d = (m - off + r) / DECIM;
+                if (d < A_MAX_ND) g = T.front_taps[(size_t)P.front_set * A_TAPS_DEV + r * A_TAPS_ROW + d];
+            }
+            const float gs = g * TSC;
+            const h16 gh = (h16)gs;
+            L.ta[0][u] = gh;
+            L.ta[1][u] = (h16)(gs - (float)gh);
+            L.ta[2][u] = (m >= off - (DECIM - 1) && m <= off) ? (h16)1.0f : (h16)0.0f;      // the 12 samples of the output's own column
+        }
+    }
+    if (t == 0) { carry_seq = 0; for (int i = 0; i < NW; i++) { scat_seq[i] = 0; fir_seq[i] = 0; } }
+    // ---- the call's history (raw samples, or what front_kernel's conversions make of them: see there) -> the mirror in front of ring slot 0
+    const bool dc_rst = (P.actions & ACT_DC_RESET) != 0;           // setDCRemove zeroes RfDC (:922-925)
+    const int hist_fmt0 = st->hist_fmt, lo_phase0 = st->lo_phase;
+    const float st_dc_re = st->dc_re, st_dc_im = st->dc_im;
+    const float2 R0 = (T.lo_table != nullptr && lo_phase0 != 0) ? T.lo_table[lo_phase0] : make_float2(1.f, 0.f);   // an oscillator set back to 0 Hz keeps its phase
+    const bool hist_to_raw = (hist_fmt0 == 1);                     // the LO was switched off in front of this call
+    const bool hist_rst = (hist_fmt0 == 0) && dc_rst;
+    const bool dcr = P.dc_remove != 0;
+    const float2 dc_now = (dc_rst || !dcr) ? make_float2(0.f, 0.f)
+                                           : make_float2(__builtin_amdgcn_fmed3f(st_dc_re, -0.01f, 0.01f), __builtin_amdgcn_fmed3f(st_dc_im, -0.01f, 0.01f));
+    const float2 *dcvR = B.dcv_hist + (size_t)ch * DCV_SAVE;
+    if (wave == 0) {
+        for (int i = lane; i < DECIM * A_HIST_COLS; i += 64) {
+            const int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;
+            if (c == HL) continue;                                 // (the partial column of a call that starts inside one: never here)
+            float2 v = hist[i];
+            if (hist_rst) {
+                const int tb = c - HL + 13;
+                const float2 d = dcvR[tb < 0 ? 0 : tb];
+                v.x -= __builtin_amdgcn_fmed3f(d.x, -0.01f, 0.01f);
+                v.y -= __builtin_amdgcn_fmed3f(d.y, -0.01f, 0.01f);
+            } else if (hist_to_raw) {
+                v = make_float2(v.x * R0.x + v.y * R0.y, v.y * R0.x - v.x * R0.y);
+                v.x = (P.att_l != 0.f ? v.x / P.att_l : 0.f) + dc_now.x;
+                v.y = (P.att_r != 0.f ? v.y / P.att_r : 0.f) + dc_now.y;
+            }
+            const int s = DECIM * c + r;                           // sample of the 288 in front of the call
+            const float xr = v.x * XSC, xi = v.y * XSC;
+            const h16 hr = (h16)xr, hi = (h16)xi;
+            L.pl[0][s] = hr; L.pl[1][s] = hi;
+            L.pl[2][s] = (h16)(xr - (float)hr); L.pl[3][s] = (h16)(xi - (float)hi);
+        }
+    }
+    // RfDC in front of the 13 columns before this call's first column and of that column itself
+    if (t < 14) mb[7][t] = (hist_to_raw || hist_rst) ? make_float2(dc_rst ? 0.f : st_dc_re, dc_rst ? 0.f : st_dc_im) : dcvR[t];
+    const float dc0r = dc_rst ? 0.f : st_dc_re, dc0i = dc_rst ? 0.f : st_dc_im;
+    __syncthreads();                                  // the only workgroup barrier: tables, history and counters are set up
+
+    // ---- per-lane constants.  Accumulator layout of the 16 x 16 matrix instruction: the lane holds rows 4 kg + v (v = 0..3) of column n.
+    const int kg = lane >> 4, n = lane & 15, blk = n >> 1, comp = n & 1;
+    const int c0col = 16 * blk + 4 * kg;              // the lane's first output column in the tile
+    const float alpha = 1.0f / (float)G.input_rate;   // rfDcAlpha fm-processor.cpp:379
+    const float cg_re = (FS.gain_re * R0.x - FS.gain_im * R0.y), cg_im = (FS.gain_re * R0.y + FS.gain_im * R0.x);     // complex output gain x R0
+    const float kown = cg_re, kpar = comp ? cg_im : -cg_im;       // z = a_own kown + a_partner kpar
+    const float bal = comp ? P.att_r : P.att_l;                   // IQ balance :462-464
+    const float hsum = FS.hsum, dcw = FS.dc_w;
+    // the RF DC recurrence over a tile (first order in alpha inside it, as front_kernel's fast path; the decay of the state over the tile and of
+    // the samples' weights towards its end to third / second order: relative errors below 1e-10)
+    const float ut = 1536.0f * alpha, u_tile = ut - 0.5f * ut * ut + (1.0f / 6.0f) * ut * ut * ut;       // 1 - (1 - alpha)^1536
+    float wv[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) { const float x = (float)(DECIM * (WCOLS - 1 - (c0col + v)) + 6) * alpha; wv[v] = 1.0f - x + 0.5f * x * x; }   // (1 - alpha)^(samples behind the column's middle)
+    const int pw = (wave + NW - 1) % NW, nw = (wave + 1) % NW;
+    // operand addresses: B = 16 bytes of a plane at sample 1536 wave - 288 + 192 blk + 32 j + 8 kg; A = 16 bytes (8-byte aligned) of a tap table
+    const char *const bB = plc + comp * PLB + 3072 * wave + 384 * blk + 16 * kg;
+    const char *const aB = tac + 16 * kg + 360 - 24 * (lane & 15);
+    char *const scW = plc + 2 * HS + 3072 * wave + 4 * lane;          // the lane's dword of sample pair lane (+ 256 k) of plane 0
+    char *const scM = plc + 4 * lane - 192;                            // ... of the mirror, for the pairs 624 + (lane - 48) (+ 256 (k - 9))
+    // RfDC boundaries the lane's outputs take: columns c0col - dck + (0..4), dck = 12: four values of lane srcA, one of srcB, or the previous tile's
+    const bool prevA = (blk == 0 && kg < 3), prevB = (blk == 0 && kg < 2);
+    const int srcA = (kg == 3) ? n : 16 * (kg + 1) + n - 2;
+    const int srcB = (kg >= 2) ? 16 * (kg - 2) + n : 16 * (kg + 2) + n - 2;
+    const int mbe = 4 * kg + 1;                                        // mailbox entry of column 4 kg - 12 of the tile
+
+    float4 raw[SPT / 2];
+    auto load_tile = [&](int ti) {
+        if (NTL) {
+            typedef float v4f_ __attribute__((ext_vector_type(4)));
+            const v4f_ *p4 = reinterpret_cast<const v4f_ *>(in + (size_t)ti * WSAMP);
+#pragma unroll
+            for (int k = 0; k < SPT / 2; k++) { const v4f_ v = __builtin_nontemporal_load(p4 + lane + 64 * k); raw[k] = make_float4(v.x, v.y, v.z, v.w); }
+        } else {
+            const float4 *p4 = reinterpret_cast<const float4 *>(in + (size_t)ti * WSAMP);
+#pragma unroll
+            for (int k = 0; k < SPT / 2; k++) raw[k] = p4[lane + 64 * k];
+        }
+    };
+    const int NTa = active ? NT : 0;
+    if (wave < NTa) load_tile(wave);
+
+    for (int ti = wave; ti < NTa; ti += NW) {
+        const int qt = ti * WCOLS;                    // first column of the tile
+        // ---- split the samples and put them into the ring, once the next tile's filter (the wave behind this one) has read its history from
+        //      what the slot held
+        if (ti - NW + 1 >= 0) seq_wait(&fir_seq[nw], ti - NW + 2);
+        if (!(F4_ABL & 1)) {
+#pragma unroll
+            for (int k = 0; k < SPT / 2; k++) {
+                uint32_t hr, lr, hi, li;
+                split2(raw[k].x * XSC, raw[k].z * XSC, &hr, &lr);
+                split2(raw[k].y * XSC, raw[k].w * XSC, &hi, &li);
+                *reinterpret_cast<uint32_t *>(scW + 256 * k) = hr;
+                *reinterpret_cast<uint32_t *>(scW + 256 * k + PLB) = hi;
+                *reinterpret_cast<uint32_t *>(scW + 256 * k + 2 * PLB) = lr;
+                *reinterpret_cast<uint32_t *>(scW + 256 * k + 3 * PLB) = li;
+                if (wave == NW - 1 && k >= 9 && (k > 9 || lane >= 48)) {      // the ring's last 288 samples once more in front of slot 0
+                    *reinterpret_cast<uint32_t *>(scM + 256 * (k - 9)) = hr;
+                    *reinterpret_cast<uint32_t *>(scM + 256 * (k - 9) + PLB) = hi;
+                    *reinterpret_cast<uint32_t *>(scM + 256 * (k - 9) + 2 * PLB) = lr;
+                    *reinterpret_cast<uint32_t *>(scM + 256 * (k - 9) + 3 * PLB) = li;
+                }
+            }
+        }
+        // last tile: the 24 newest columns are the next call's history -- the raw samples as they came (front_kernel's format: [r][c], an empty
+        // partial column behind them)
+        if (ti == NT - 1) {
+#pragma unroll
+            for (int k = 9; k < SPT / 2; k++) {
+                const int s = 2 * (lane + 64 * k) - (WSAMP - HS);          // sample of the 288, even
+                if (s >= 0) {
+                    const int c = s / DECIM, r = s - DECIM * c;
+                    hist[r * A_HIST_COLS + c] = make_float2(raw[k].x, raw[k].y);
+                    hist[(r + 1) * A_HIST_COLS + c] = make_float2(raw[k].z, raw[k].w);
+                }
+            }
+            if (lane < DECIM) hist[lane * A_HIST_COLS + HL] = make_float2(0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();              // LDS operations of one wave complete in order
+        if (lane == 0) seq_post(&scat_seq[wave], ti + 1);
+        // ---- prefetch this wave's next tile as soon as the registers are free: the loads are in flight for the whole iteration
+        if (ti + NW < NT && !(F4_ABL & 8)) load_tile(ti + NW);
+        // ---- the previous tile's newest 288 samples are this tile's history (tile 0: the call's, put there in front of the barrier)
+        if (ti > 0) seq_wait(&scat_seq[pw], ti);
+
+        // ---- the filter: D[i][n] += A[i][k] B[k][n] over the 480 samples of the window, three (four) f16 terms; the column sums beside it
+        v4f ahh = (v4f){0.f, 0.f, 0.f, 0.f}, ahl = ahh, alh = ahh, asum = ahh;
+        if (!(F4_ABL & 4)) {
+#pragma unroll
+            for (int j = 0; j < KSTEPS; j++) {
+                const u32x4 bh = *reinterpret_cast<const u32x4 *>(bB + 64 * j), bl = *reinterpret_cast<const u32x4 *>(bB + 64 * j + 2 * PLB);
+                const u32x2 a0 = *reinterpret_cast<const u32x2 *>(aB + 64 * j), a1 = *reinterpret_cast<const u32x2 *>(aB + 64 * j + 8);
+                const u32x2 l0 = *reinterpret_cast<const u32x2 *>(aB + 64 * j + 2 * TA_N), l1 = *reinterpret_cast<const u32x2 *>(aB + 64 * j + 2 * TA_N + 8);
+                const v8h Bh = __builtin_bit_cast(v8h, bh), Bl = __builtin_bit_cast(v8h, bl);
+                const v8h Ah = __builtin_bit_cast(v8h, (u32x4){a0.x, a0.y, a1.x, a1.y}), Al = __builtin_bit_cast(v8h, (u32x4){l0.x, l0.y, l1.x, l1.y});
+                ahh = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, ahh, 0, 0, 0);
+                ahl = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, ahl, 0, 0, 0);
+                alh = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, alh, 0, 0, 0);
+#if FMX_F4_TERMS >= 4
+                ahl = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bl, ahl, 0, 0, 0);
+#endif
+                if (dcr && j >= KSUM0 && !(F4_ABL & 2)) {
+                    const u32x2 o0 = *reinterpret_cast<const u32x2 *>(aB + 64 * j + 4 * TA_N), o1 = *reinterpret_cast<const u32x2 *>(aB + 64 * j + 4 * TA_N + 8);
+                    const v8h Ao = __builtin_bit_cast(v8h, (u32x4){o0.x, o0.y, o1.x, o1.y});
+                    asum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ao, Bh, asum, 0, 0, 0);
+                    asum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ao, Bl, asum, 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) seq_post(&fir_seq[wave], ti + 1);           // this slot's predecessor may take its owner's next tile
+        float a[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) a[v] = (ahh[v] + (ahl[v] + alh[v])) * OSC;
+
+        // ---- RF DC removal (fm-processor.cpp:423-446) behind the filter, as front_kernel does it for channels without an LO -- here in the
+        //      accumulator layout: the lane has the sums of its four columns (of its component), the exclusive prefix over the tile's 128 columns
+        //      comes from two cross-row exchanges and a three-step row scan, the state in front of the tile from the previous tile's mailbox slot
+        float c_out_r = dc0r, c_out_i = dc0i;
+        if (dcr && !(F4_ABL & 2)) {
+            const float S0 = asum[0] * (1.0f / XSC), S1 = asum[1] * (1.0f / XSC), S2 = asum[2] * (1.0f / XSC), S3 = asum[3] * (1.0f / XSC);
+            const float e2 = S0 + S1, e3 = e2 + S2, tot = e3 + S3;
+            const float p16 = bperm(lane ^ 16, tot), x1 = tot + p16;
+            const float p32 = bperm(lane ^ 32, x1), bt = x1 + p32;                                  // the block's 16 columns
+            const float exk = ((kg & 1) ? p16 : 0.f) + ((kg & 2) ? p32 : 0.f);                      // the block's columns in front of the lane's
+            float inc = bt;
+            inc += dpp_row_shr<2>(inc); inc += dpp_row_shr<4>(inc); inc += dpp_row_shr<8>(inc);   // blocks 0 .. blk (same component)
+            const float pre0 = (inc - bt) + exk;                                                    // columns 0 .. c0col - 1
+            // the tile's weighted sum (what is left of each column's samples at the tile's end), both components to every lane
+            float ws = (S0 * wv[0] + S1 * wv[1]) + (S2 * wv[2] + S3 * wv[3]);
+            ws += dpp_row_shr<2>(ws); ws += dpp_row_shr<4>(ws); ws += dpp_row_shr<8>(ws);
+            const float w16 = bperm(lane ^ 16, ws), ws2 = ws + w16;
+            const float w32 = bperm(lane ^ 32, ws2), ws3 = ws2 + w32;
+            const float W_re = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ws3), 14));
+            const float W_im = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ws3), 15));
+            // the state in front of the tile, and what the lanes at the tile's head need of the previous tile's boundaries
+            const float2 *mp = mb[(ti - 1) & 7];
+            if (ti > 0) seq_wait(&carry_seq, ti);
+            float pv[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { const float2 e = mp[(mbe + k) > 13 ? 13 : mbe + k]; pv[k] = comp ? e.y : e.x; }
+            float c0r = dc0r, c0i = dc0i;
+            if (ti > 0) { const float2 cc = mp[13]; c0r = cc.x; c0i = cc.y; }
+            c_out_r = dc_chain(c0r, u_tile, alpha * W_re); c_out_i = dc_chain(c0i, u_tile, alpha * W_im);
+            const float c0 = comp ? c0i : c0r;
+            // RfDC in front of the lane's four columns
+            float rr[4];
+            {
+                const float P0 = pre0, P1 = pre0 + S0, P2 = pre0 + e2, P3 = pre0 + e3;
+                const float base = (float)(DECIM * c0col) * alpha;
+                rr[0] = fmaf(alpha, P0, fmaf(-c0, base, c0));
+                rr[1] = fmaf(alpha, P1, fmaf(-c0, base + 12.0f * alpha, c0));
+                rr[2] = fmaf(alpha, P2, fmaf(-c0, base + 24.0f * alpha, c0));
+                rr[3] = fmaf(alpha, P3, fmaf(-c0, base + 36.0f * alpha, c0));
+            }
+            // the next tile's slot: columns 115 .. 127 of this tile, then the state behind it
+            float *mn = reinterpret_cast<float *>(mb[ti & 7]);
+            if (blk == 7) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) { const int e = 4 * kg + v - 3; if (e >= 0) mn[2 * e + comp] = rr[v]; }
+            }
+            if (lane == 0) mb[ti & 7][13] = make_float2(c_out_r, c_out_i);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) seq_post(&carry_seq, ti + 1);             // (every read of the previous slot is in front of this release)
+            // RfDC at the five boundaries the lane's outputs interpolate between (columns c0col - 12 .. c0col - 8)
+            float E[5];
+#pragma unroll
+            for (int v = 0; v < 4; v++) { const float f = bperm(srcA, rr[v]); E[v] = prevA ? pv[v] : f; }
+            { const float f = bperm(srcB, rr[0]); E[4] = prevB ? pv[4] : f; }
+            // what the FIR makes of the RfDC values the reference subtracts in front of it (limited to +-0.01, DCRlimit :429-442)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const float d = fmaf(dcw, E[v + 1] - E[v], E[v]);
+                a[v] = fmaf(-hsum, __builtin_amdgcn_fmed3f(d, -0.01f, 0.01f), a[v]);
+            }
+        }
+        // ---- IQ balance (:462-464), the decimators' complex gain, the fm-rate ring: the lane of the real part stores the quad's first two outputs,
+        //      the lane of the imaginary part the other two
+        float z[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) a[v] *= bal;
+#pragma unroll
+        for (int v = 0; v < 4; v++) z[v] = fmaf(dpp_swap1(a[v]), kpar, a[v] * kown);
+        const float k0 = comp ? z[2] : z[0], k1 = comp ? z[3] : z[1];       // what the lane keeps ...
+        const float g0 = comp ? z[0] : z[2], g1 = comp ? z[1] : z[3];       // ... and what its partner stores
+        const float r0 = dpp_swap1(g0), r1 = dpp_swap1(g1);
+        const float4 o4 = comp ? make_float4(r0, k0, r1, k1) : make_float4(k0, r0, k1, r1);
+        const int qc = qt + c0col + 2 * comp;         // the lane's first output column
+        const int zi = (zr0 + qc) & G.ring_mask;
+        if ((zi & 1) == 0 && qc >= ja && qc + 1 < jb) {
+            *reinterpret_cast<float4 *>(&zring[zi]) = o4;
+        } else {
+            if (qc >= ja && qc < jb) zring[(zr0 + qc) & G.ring_mask] = make_float2(o4.x, o4.y);
+            if (qc + 1 >= ja && qc + 1 < jb) zring[(zr0 + qc + 1) & G.ring_mask] = make_float2(o4.z, o4.w);
+        }
+        // ---- last tile: the state the next call finds (front_kernel's format)
+        if (ti == NT - 1) {
+            if (lane == 0 && (dcr || dc_rst)) { st->dc_re = c_out_r; st->dc_im = c_out_i; }
+            if (lane == 0) st->hist_fmt = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 14) B.dcv_hist[(size_t)ch * DCV_SAVE + lane] = dcr ? mb[ti & 7][lane] : make_float2(dc0r, dc0i);
+        }
+    }
+}
+
+}  // namespace f4
+
+// The calls front4_kernel takes (launch_front asks): whole tiles, on a column boundary, float32 samples 16-byte aligned.  The per-channel
+// conditions -- no LO anywhere, every tap set the long fold with its RfDC taken 12 columns back, one twin -- are the handle's (fmx_api.hip).
+int front4_tiles(const CallGeom &G, const void *iq) {
+    if (G.iq_format != 0 || G.twins != 1 || G.pre_processed || G.parts > 1) return 0;
+    if ((G.g0 % DECIM) != 0 || (G.stream_stride & 1) != 0 || (reinterpret_cast<uintptr_t>(iq) & 15) != 0) return 0;
+    return (int)(G.n / f4::WSAMP);
+}
+void launch_front4(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels, hipStream_t s) {
+    const dim3 grid((channels + f4::CPW - 1) / f4::CPW);
+    if (G.streams_private) hipLaunchKernelGGL((f4::front4_kernel<true>), grid, dim3(f4::NTHR), 0, s, T, B, G, reinterpret_cast<const float2 *>(iq));
+    else hipLaunchKernelGGL((f4::front4_kernel<false>), grid, dim3(f4::NTHR), 0, s, T, B, G, reinterpret_cast<const float2 *>(iq));
+}
+
+}  // namespace fmx

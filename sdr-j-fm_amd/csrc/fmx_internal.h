@@ -225,7 +225,8 @@ struct CallGeom {
     int32_t no_deemph;       // channel, no RF DC removal, balance or LO mix here, history always raw, no front-end state written.  no_deemph: stage B
                              // writes the stereo pair to the d ring as it is: the audio low-pass (a block machine then) comes first, deemph_kernel behind it
     int32_t streams;         // IQ streams of the handle
-    int32_t front3;          // stage A: the handle qualifies for front3_kernel (fmx_front3.hip: no LO anywhere, every tap set the long fold); launch_front
+    int32_t front3;          // stage A: 1 the handle runs front3_kernel (fmx_front3.hip: no LO anywhere, every tap set the long fold), 2 front4_kernel
+                             // (fmx_front4.hip: the filter on the matrix pipe; RfDC taken 12 columns back in every tap set as well); launch_front
                              // gives it the whole tiles of a call that starts on a column boundary, front_kernel the remainder and everything else
     int32_t cont;            // front_kernel: this launch continues a call whose head another launch has made (the one-shot actions are done)
     int32_t parts, part_tiles;   // stage A, handles that leave the chip empty (one workgroup per channel, few channels): a channel's tiles are
@@ -366,6 +367,9 @@ void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
 // fmx_front3.hip: whole tiles of the call front3_kernel can take (0: none), and its launch over that many
 int front3_tiles(const CallGeom &G, const void *iq);
 void launch_front3(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels, hipStream_t s);
+// fmx_front4.hip: the same for front4_kernel (the filter on the matrix pipe; CallGeom::front3 == 2)
+int front4_tiles(const CallGeom &G, const void *iq);
+void launch_front4(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels, hipStream_t s);
 // first HIP error of the launches / event calls of the current fmx_process_* call (they are enqueued by void helpers);
 // run_call clears it before the launches and turns it into FMX_E_HIP behind them
 extern thread_local hipError_t g_launch_err;

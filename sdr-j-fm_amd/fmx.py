@@ -22,7 +22,7 @@ P_VOLUME_DB, P_LF_CUTOFF, P_BANDWIDTH, P_ATTENUATION_L, P_ATTENUATION_R, P_RDS_M
 P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE, P_SQUELCH_VALUE = 13, 14, 15, 16, 17, 18, 19
 P_DISP_DELAY = 20
 P_STAGEB_FORM = 22            # handle-wide: 0 automatic, 1 stage B as one kernel per call, 2 as two (bit-identical results)
-P_FRONT_KERNEL = 25           # handle-wide: 0 automatic, 1 four waves per channel (fmx_front.hip), 2 six waves per channel where it applies (fmx_front3.hip)
+P_FRONT_KERNEL = 25           # handle-wide: 0 automatic, 1 fmx_front.hip (packed f32 FMAs), 2 fmx_front3.hip (the same on six waves), 3 fmx_front4.hip (f16-split matrix FIR)
 P_FRONT_PARTS = 24            # handle-wide: 0 automatic, 1 one workgroup per channel, 2..32 parts in time per channel (bit-identical results)
 P_FILTER_RESTARTS = 23        # handle-wide, before the first call: 0 automatic, 1 the reference's block filters (<= 64 channels), 2 folded FIRs
 P_PLL_SOLVER = 21             # 0 automatic, 1 sequential (the reference's trajectory), 2 Newton while in lock + sequential around lock decisions, 3 Newton always
@@ -35,7 +35,7 @@ EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
     "fmx_get_meta", "fmx_get_tap", "fmx_get_peaks",
-    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_pll_exact_segments", "fmx_last_rds_samples", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
+    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_pll_exact_segments", "fmx_last_front_kernel", "fmx_last_rds_samples", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
 
@@ -144,6 +144,8 @@ def load_library(path=None):
     L.fmx_pll_replays.restype = C.c_int64
     L.fmx_pll_replays.argtypes = [vp, C.c_int32]
     L.fmx_pll_exact_segments.restype = C.c_int64
+    L.fmx_last_front_kernel.restype = C.c_int32
+    L.fmx_last_front_kernel.argtypes = [vp]
     L.fmx_pll_exact_segments.argtypes = [vp, C.c_int32]
     L.fmx_last_rds_samples.restype = C.c_int64
     L.fmx_last_rds_samples.argtypes = [vp]
@@ -284,6 +286,10 @@ class Fmx:
 
     def last_fm_samples(self):
         return int(self.L.fmx_last_fm_samples(self.h))
+
+    def last_front_kernel(self):
+        """Which kernel ran the input-filter stage of the last call (fmx_last_front_kernel: FMX_P_FRONT_KERNEL's numbering)."""
+        return int(self.L.fmx_last_front_kernel(self.h))
 
     def last_rds_samples(self):
         """24 kS/s RDS samples the last call produced (fmx_last_rds_samples): the n that tap(TAP_RDS_IQ, n) accepts."""

@@ -48,47 +48,66 @@ def _run(f, iq, blocks, events=None):
     return np.concatenate(pcm, axis=1), np.concatenate(taps, axis=1), np.array(dcs)
 
 
-def test_front3_whole_tiles_bit_identical(fmx_amd, ol):
+def _close(a, b, kernel, what):
+    """kernel 2 (the same f32 arithmetic in another order of waves): equal to the last bit.  kernel 3 (the filter on the matrix pipe, operands split
+    into two f16 halves, products exact, the remainders' roundings at 2^-22 of a product; the RF DC recurrence with its sums taken in another
+    order): the fm-rate IQ to 4e-7 of its amplitude at the worst sample (the f32 filter's own rounding is 1e-7), RfDC to 2e-8, PCM to 2e-6."""
+    if kernel == 2:
+        assert np.array_equal(a, b), what + " differs"
+        return
+    tol = {"fm-rate IQ": 8e-7 * float(np.abs(a).max()), "RF DC state": 2e-8, "PCM": 2e-6}[what]
+    err = float(np.abs(a.astype(np.float64) - b).max())
+    print("\n[front kernel 3 against 1] %s: max |diff| %.2e (bound %.1e, full scale %.2f)" % (what, err, tol, float(np.abs(a).max())))
+    assert err <= tol, (what, err, tol)
+
+
+@pytest.mark.parametrize("kernel", [2, 3])
+def test_front3_whole_tiles_bit_identical(fmx_amd, ol, kernel):
     """Calls of whole tiles (1 .. 150 of them: fewer tiles than the workgroup has waves, more, a multiple, not a multiple): six waves per channel
-    against four -- PCM, the fm-rate IQ and the RF DC state bit for bit; a setDCRemove in mid-stream (its reset of RfDC) on the way."""
+    against four -- PCM, the fm-rate IQ and the RF DC state bit for bit; a setDCRemove in mid-stream (its reset of RfDC) on the way.  And the
+    filter on the matrix pipe (kernel 3) against the same, to the bounds of _close."""
     blocks = [1536 * 10, 1536 * 150, 1536 * 1, 1536 * 7, 1536 * 6, 1536 * 5, 1536 * 13]
     iq = _streams(ol, sum(blocks))
     ev = {3: [(M.P_DC_REMOVE, 1, 3), (M.P_DC_REMOVE, 0, 4)], 5: [(M.P_DC_REMOVE, 1, 4)]}
     outs = []
-    for kernel in (1, 2):
-        f = _handle(fmx_amd, kernel, max(blocks))
+    for kn in (1, kernel):
+        f = _handle(fmx_amd, kn, max(blocks))
         outs.append(_run(f, iq, blocks, ev))
         del f
     a, b = outs
     assert np.isfinite(a[0]).all() and float(np.abs(a[0]).max()) > 0.01
-    assert np.array_equal(a[1], b[1]), "fm-rate IQ differs"
-    assert np.array_equal(a[2], b[2]), "RF DC state differs"
-    assert np.array_equal(a[0], b[0]), "PCM differs"
+    _close(a[1], b[1], kernel, "fm-rate IQ")
+    _close(a[2], b[2], kernel, "RF DC state")
+    _close(a[0], b[0], kernel, "PCM")
 
 
-def test_front3_remainders_and_fallbacks(fmx_amd, ol):
+@pytest.mark.parametrize("kernel", [2, 3])
+def test_front3_remainders_and_fallbacks(fmx_amd, ol, kernel):
     """Calls that are not whole tiles: the six-wave kernel takes the tiles, front_kernel the remainder as a call of its own -- so a handle on
     front_kernel alone that is given the same stretches in two calls (tiles, remainder) must agree bit for bit in the fm-rate IQ.  Calls shorter
     than a tile, calls that leave the 12-sample column grid (everything behind them is front_kernel's), a local oscillator switched on (the
     handle falls back) and off again (the six-wave kernel finds a history of mixed samples and converts it)."""
     T = 1536
-    stretches = [(3 * T, 480), (600,), (9 * T, 36), (2 * T, 1500), (7 * T,), (T, 12), (4 * T, 7), (5 * T,), (2 * T + 100,)]
+    # (the first stretch carries the stream past the input filter's latency of 65285 samples: everything in front of it is zeros at the fm rate)
+    stretches = [(50 * T, 480), (600,), (9 * T, 36), (2 * T, 1500), (7 * T,), (T, 12), (4 * T, 7), (5 * T,), (2 * T + 100,)]
     n = sum(sum(s) for s in stretches)
     iq = _streams(ol, n)
     ev = {4: [(M.P_LOCAL_OSCILLATOR, 200000, 6)], 5: [(M.P_LOCAL_OSCILLATOR, 0, 6)]}
-    fa = _handle(fmx_amd, 1, 16 * T)
+    fa = _handle(fmx_amd, 1, 64 * T)
     a = _run(fa, iq, stretches, ev)
     del fa
-    fb = _handle(fmx_amd, 2, 16 * T)
+    fb = _handle(fmx_amd, kernel, 64 * T)
     b = _run(fb, iq, [sum(s) for s in stretches], ev)
     del fb
-    assert np.array_equal(a[1], b[1]), "fm-rate IQ differs"
-    assert np.array_equal(a[2], b[2]), "RF DC state differs"
+    assert float(np.abs(a[1]).max()) > 0.1
+    _close(a[1], b[1], kernel, "fm-rate IQ")
+    _close(a[2], b[2], kernel, "RF DC state")
     # the stages behind are invariant to the cut to rounding only
     assert float(np.abs(a[0] - b[0]).max()) < 2e-6
 
 
-def test_front3_against_oracle_in_a_batch(fmx_amd, ol):
+@pytest.mark.parametrize("kernel", [2, 3])
+def test_front3_against_oracle_in_a_batch(fmx_amd, ol, kernel):
     """600 channels on 4 streams, six waves per channel (two channels per workgroup, an even count), three calls -- whole tiles,
     tiles and a remainder twice --, every 152nd channel against the oracle chain on its stream."""
     nch, nst, T = 600, 4, 1536
@@ -96,7 +115,7 @@ def test_front3_against_oracle_in_a_batch(fmx_amd, ol):
     n = sum(blocks)
     iq = np.stack([ol.synth_iq(n, leftHz=500.0 + 250 * k, rightHz=900.0 + 150 * k) for k in range(nst)])
     f = fmx_amd.Fmx(nch, streams=nst, stream_of_channel=[c % nst for c in range(nch)], max_block=max(blocks))
-    for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FRONT_KERNEL, 2)):
+    for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FRONT_KERNEL, kernel)):
         f.set_param(pid, v)
     pcm, pos = [], 0
     for b in blocks:
@@ -108,6 +127,8 @@ def test_front3_against_oracle_in_a_batch(fmx_amd, ol):
         for c in range(k, nch, 152):
             assert pcm[c].shape == ref.shape, (pcm[c].shape, ref.shape)
             err = float(np.sqrt(np.mean((pcm[c].astype(np.float64) - ref) ** 2)))
+            if c < nst:
+                print("\n[front kernel %d, 600 channels] channel %d PCM rms against the oracle %.2e" % (kernel, c, err))
             assert err <= 1e-5, (c, err)
 
 
