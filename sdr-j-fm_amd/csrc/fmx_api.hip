@@ -72,6 +72,7 @@ struct fmx_handle_s {
     bool gain_pending = false;                                       // ... taken over by flush_mailbox together with the settings themselves (processing
                                                                      // thread only): gain_fix_kernel runs in the first call that produces frames
     float *d_audio_lp = nullptr, *d_rs_taps = nullptr;
+    uint16_t *d_audio_mtab = nullptr;
     float2 *d_audio_spec = nullptr;               // the audio low-pass and the resampler alone (gain_fix_kernel)
     // unique tap sets
     std::vector<int32_t> front_keys, audio_keys;
@@ -288,6 +289,24 @@ int ensure_sets(fmx_handle h) {
             HIPCHK(hipMalloc(&h->d_audio_spec, sizeof(float2) * spec.size()));
             HIPCHK(hipMemcpy(h->d_audio_spec, spec.data(), sizeof(float2) * spec.size(), hipMemcpyHostToDevice));
             h->T.audio_spec = h->d_audio_spec;
+            // ... and the same taps as audio_mfma_kernel wants them: two f16 halves of g * 2^14, reversed, shifted by the window's parity
+            std::vector<uint16_t> mt(ak.size() * 4 * AM_TAB, 0);
+            for (size_t i = 0; i < ak.size(); i++) {
+                const int nt = h->h_audio_sets[i].ntaps;
+                const float *rev = &h->h_audio_taps[i * C_TAPS_STRIDE];
+                for (int sh = 0; sh < 2; sh++)
+                    for (int u = 0; u < AM_TAB; u++) {
+                        const int kk = u - 124 - sh;
+                        const float gs = (kk >= 0 && kk < nt) ? rev[kk] * 16384.0f : 0.f;
+                        const _Float16 gh = (_Float16)gs, gl = (_Float16)(gs - (float)gh);
+                        std::memcpy(&mt[((i * 2 + sh) * 2 + 0) * AM_TAB + u], &gh, 2);
+                        std::memcpy(&mt[((i * 2 + sh) * 2 + 1) * AM_TAB + u], &gl, 2);
+                    }
+            }
+            if (h->d_audio_mtab) (void)hipFree(h->d_audio_mtab);
+            HIPCHK(hipMalloc(&h->d_audio_mtab, sizeof(uint16_t) * mt.size()));
+            HIPCHK(hipMemcpy(h->d_audio_mtab, mt.data(), sizeof(uint16_t) * mt.size(), hipMemcpyHostToDevice));
+            h->T.audio_mtab = h->d_audio_mtab;
         }
     }
     h->sets_dirty = false;
@@ -1192,7 +1211,7 @@ int fmx_destroy(fmx_handle h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &pr : h->prof) for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
-    void *ptrs[] = { h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
+    void *ptrs[] = { h->d_audio_mtab, h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
                      h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.dcv_hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
                      h->B.w_osc, h->B.w_diff, h->d_cv_taps, h->d_x48 };

@@ -763,7 +763,8 @@ void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
             if (G.front3 == 2) launch_front4(T, B, G3, iq, channels, s); else launch_front3(T, B, G3, iq, channels, s);
             if (G3.n == G.n) return;
             CallGeom G2 = G; G2.front3 = 0; G2.cont = 1; G2.parts = 1; G2.g0 = G.g0 + G3.n; G2.n = G.n - G3.n;
-            launch_front(T, B, G2, reinterpret_cast<const char *>(iq) + (size_t)G3.n * sizeof(float2), channels, s);
+            const size_t bps = (G.iq_format == 0) ? 8 : (G.iq_format == 3 ? 4 : 2);
+            launch_front(T, B, G2, reinterpret_cast<const char *>(iq) + (size_t)G3.n * bps, channels, s);
             return;
         }
     }

@@ -81,9 +81,12 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t *hi, uint32_t 
 #define F4_ABL 0      /* diagnostic builds only: bit 0 no scatter, 1 no DC pass, 2 no matrix FIR, 3 no tile loads behind the first (garbage results) */
 #endif
 
-template <bool NTL>
+// FMT: fmx_iq_format of the input (include/fmx.h).  Raw integer samples are converted while they are loaded -- (u8 - 127) / 128, s8 / 128,
+// s16 / denominator, all exact as in the reference's device handlers (rtlsdr-handler.cpp:291, hackrf-handler.cpp:364, lime-handler.cpp:250).
+template <int FMT, bool NTL>
 __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3))) void front4_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
-                                                                                                       const float2 *__restrict__ iq) {
+                                                                                                       const void *__restrict__ iq_raw) {
+    constexpr int BPS = (FMT == 0) ? 8 : (FMT == 3 ? 4 : 2);          // bytes per complex sample
     struct ChanLds {
         h16 pl[4][PL];                     // hi re, hi im, lo re, lo im of the channel's newest six tiles (and the mirror)
         h16 ta[3][TA_N];                   // reversed tap table: hi, lo, and the boxcar of ones that sums a column
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const char *const tac = reinterpret_cast<const char *>(&L.ta[0][0]);
     const ChanParams P = B.params[ch];
     const FrontSet FS = T.front_sets[P.front_set];
-    const float2 *__restrict__ in = iq + (size_t)P.stream * G.stream_stride;
+    const char *__restrict__ inb = reinterpret_cast<const char *>(iq_raw) + (size_t)P.stream * G.stream_stride * BPS;
+    const float qs = G.iq_scale;
     ChanState *st = B.state + ch;
     float2 *hist = B.hist + (size_t)ch * DECIM * A_HIST_COLS;
     float2 *zring = B.zring + (size_t)ch * (G.ring_mask + 1);
@@ -206,15 +210,36 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
 
     float4 raw[SPT / 2];
     auto load_tile = [&](int ti) {
-        if (NTL) {
+        const char *tb = inb + (size_t)ti * WSAMP * BPS;
+        if (FMT == 0 && NTL) {
             typedef float v4f_ __attribute__((ext_vector_type(4)));
-            const v4f_ *p4 = reinterpret_cast<const v4f_ *>(in + (size_t)ti * WSAMP);
+            const v4f_ *p4 = reinterpret_cast<const v4f_ *>(tb);
 #pragma unroll
             for (int k = 0; k < SPT / 2; k++) { const v4f_ v = __builtin_nontemporal_load(p4 + lane + 64 * k); raw[k] = make_float4(v.x, v.y, v.z, v.w); }
-        } else {
-            const float4 *p4 = reinterpret_cast<const float4 *>(in + (size_t)ti * WSAMP);
+        } else if (FMT == 0) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(tb);
 #pragma unroll
             for (int k = 0; k < SPT / 2; k++) raw[k] = p4[lane + 64 * k];
+        } else if (FMT == 1 || FMT == 2) {
+            const uint32_t *p1 = reinterpret_cast<const uint32_t *>(tb);
+#pragma unroll
+            for (int k = 0; k < SPT / 2; k++) {
+                const uint32_t w = p1[lane + 64 * k];                 // I0 Q0 I1 Q1
+                if (FMT == 1)
+                    raw[k] = make_float4((float)((int)(w & 255u) - 127) * qs, (float)((int)((w >> 8) & 255u) - 127) * qs,
+                                         (float)((int)((w >> 16) & 255u) - 127) * qs, (float)((int)(w >> 24) - 127) * qs);
+                else
+                    raw[k] = make_float4((float)(int8_t)(w & 255u) * qs, (float)(int8_t)((w >> 8) & 255u) * qs,
+                                         (float)(int8_t)((w >> 16) & 255u) * qs, (float)(int8_t)(w >> 24) * qs);
+            }
+        } else {
+            const uint2 *p2 = reinterpret_cast<const uint2 *>(tb);
+#pragma unroll
+            for (int k = 0; k < SPT / 2; k++) {
+                const uint2 w = p2[lane + 64 * k];                    // (I0 Q0) (I1 Q1)
+                raw[k] = make_float4((float)(int16_t)(w.x & 0xffffu) * qs, (float)(int16_t)(w.x >> 16) * qs,
+                                     (float)(int16_t)(w.y & 0xffffu) * qs, (float)(int16_t)(w.y >> 16) * qs);
+            }
         }
     };
     const int NTa = active ? NT : 0;
@@ -389,14 +414,23 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
 // The calls front4_kernel takes (launch_front asks): whole tiles, on a column boundary, float32 samples 16-byte aligned.  The per-channel
 // conditions -- no LO anywhere, every tap set the long fold with its RfDC taken 12 columns back, one twin -- are the handle's (fmx_api.hip).
 int front4_tiles(const CallGeom &G, const void *iq) {
-    if (G.iq_format != 0 || G.twins != 1 || G.pre_processed || G.parts > 1) return 0;
-    if ((G.g0 % DECIM) != 0 || (G.stream_stride & 1) != 0 || (reinterpret_cast<uintptr_t>(iq) & 15) != 0) return 0;
+    if (G.iq_format < 0 || G.iq_format > 3 || G.twins != 1 || G.pre_processed || G.parts > 1) return 0;
+    const int bps = (G.iq_format == 0) ? 8 : (G.iq_format == 3 ? 4 : 2);
+    // (a lane's sample PAIR is one 16 / 4 / 8 byte load)
+    if ((G.g0 % DECIM) != 0 || (G.stream_stride & 1) != 0 || (reinterpret_cast<uintptr_t>(iq) & (uintptr_t)(2 * bps - 1)) != 0) return 0;
     return (int)(G.n / f4::WSAMP);
 }
 void launch_front4(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels, hipStream_t s) {
     const dim3 grid((channels + f4::CPW - 1) / f4::CPW);
-    if (G.streams_private) hipLaunchKernelGGL((f4::front4_kernel<true>), grid, dim3(f4::NTHR), 0, s, T, B, G, reinterpret_cast<const float2 *>(iq));
-    else hipLaunchKernelGGL((f4::front4_kernel<false>), grid, dim3(f4::NTHR), 0, s, T, B, G, reinterpret_cast<const float2 *>(iq));
+    switch (G.iq_format) {
+    case 1: hipLaunchKernelGGL((f4::front4_kernel<1, false>), grid, dim3(f4::NTHR), 0, s, T, B, G, iq); break;
+    case 2: hipLaunchKernelGGL((f4::front4_kernel<2, false>), grid, dim3(f4::NTHR), 0, s, T, B, G, iq); break;
+    case 3: hipLaunchKernelGGL((f4::front4_kernel<3, false>), grid, dim3(f4::NTHR), 0, s, T, B, G, iq); break;
+    default:
+        if (G.streams_private) hipLaunchKernelGGL((f4::front4_kernel<0, true>), grid, dim3(f4::NTHR), 0, s, T, B, G, iq);
+        else hipLaunchKernelGGL((f4::front4_kernel<0, false>), grid, dim3(f4::NTHR), 0, s, T, B, G, iq);
+        break;
+    }
 }
 
 }  // namespace fmx

@@ -21,6 +21,7 @@ constexpr int AUDIO_DELAY = 8192 - 756;
 constexpr int C_MAX_TAPS = AUDIO_TAPS + RS_TAPS - 1;   // 883
 constexpr int C_TAPS_STRIDE = 896;     // padded
 constexpr int C_TILE = 256;            // PCM frames per audio-FIR tile
+constexpr int AM_TAB = 1152;           // entries of a tap table of audio_mfma_kernel (fmx_audio.hip)
 constexpr int GAIN_FIX_FRAMES = RS_TAPS / 4;   // PCM frames whose resampler memory straddles a gain change (32)
 constexpr int NSQ_QUADS = 10;          // ((20 + 1) & 0176) / 2 biquads per filter (iir-filters.cpp:454)
 constexpr int TT_SILENT = 96001;       // ++TimePeriodCounter > workingRate * 2.0f fires on the 96001st silent frame (fm-processor.cpp:816-817)
@@ -189,6 +190,8 @@ struct DeviceTables {
     const float2 *audio_spec;    // [sets][4][2048] spectra of the folded FIR's four decimation phases, slot order of fmx_fftconv.h, 1 / N
                                  // included; null: the direct form (FMX_AUDIO_FIR=direct)
     const AudioSet *audio_sets;
+    const uint16_t *audio_mtab;  // [sets][2][2][AM_TAB] audio_mfma_kernel's tap tables as f16 bit patterns: window parity sh, (hi, lo) half, entry u = the folded
+                                 // FIR's reversed tap u - 124 - sh times 2^14 (zero outside the filter); null: the fast convolution
     double  sincos_C;            // Rate / (2*M_PI)  (sincos.cpp:42)
     float   K_FM, K_FM_rcp, pil_omega_rcp;   // rcp = RN(1/c) for fdiv_const
     float   pil_omega, pil_gain, pss_alpha, pss_lock_alpha;

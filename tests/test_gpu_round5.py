@@ -168,3 +168,65 @@ def test_twins_at_batch_scale_flake_hunt(rds, form, hard):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     last = r.stdout.strip().splitlines()[-1]
     assert last.endswith("mismatch: 0"), r.stdout[-3000:]
+
+
+def test_audio_fir_on_the_matrix_pipe_matches_the_fast_convolution(fmx_amd, ol):
+    """Stage C's folded 883-tap FIR as a Toeplitz product of f16 halves on the matrix pipe (FMX_AUDIO_MFMA=1, csrc/fmx_audio.hip audio_mfma_kernel;
+    an opt-in: measured slower than the fast convolution) against the default: the same PCM to 2e-7 (two processes: the switch is read once)."""
+    import os, subprocess, sys, textwrap, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = textwrap.dedent('''
+        import sys, importlib, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+        import oracle_lib as ol
+        pkg = importlib.import_module("sdr-j-fm_amd"); M = pkg.fmx
+        blocks = [230400, 100001, 16384, 230400]
+        iq = np.stack([ol.synth_iq(sum(blocks), leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k) for k in range(2)])
+        f = pkg.Fmx(70, streams=2, stream_of_channel=[c %% 2 for c in range(70)], max_block=max(blocks))
+        for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0)): f.set_param(pid, v)
+        f.set_param(M.P_LF_CUTOFF, 0, 3); f.set_param(M.P_TEST_TONE, 1, 5)
+        out, pos = [], 0
+        for b in blocks:
+            out.append(f.process_host(iq[:, pos:pos + b])); pos += b
+        np.save(sys.argv[1], np.concatenate(out, axis=1))
+    ''' % (root, root))
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("0", "1"):
+            path = os.path.join(td, "pcm%s.npy" % flag)
+            r = subprocess.run([sys.executable, "-c", prog, path], env=dict(os.environ, FMX_AUDIO_MFMA=flag), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res.append(np.load(path))
+    a, b = res
+    assert a.shape == b.shape and float(np.abs(a).max()) > 0.01
+    assert float(np.abs(a - b).max()) <= 2e-7, float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("fmt", ["u8", "s8", "s16"])
+def test_front4_raw_formats(fmx_amd, ol, fmt):
+    """Raw integer samples through the matrix-pipe kernel (converted while they are loaded, as the reference's device handlers convert them):
+    against front_kernel on the same calls -- whole tiles, tiles and a remainder -- to the bounds of _close."""
+    T = 1536
+    blocks = [150 * T, 40 * T + 600, 60 * T]
+    n = sum(blocks)
+    x = ol.synth_iq(n)
+    if fmt == "u8":
+        raw = np.clip(np.round(x * 100.0 + 127.4), 0, 255).astype(np.uint8); code = M.IQ_U8
+    elif fmt == "s8":
+        raw = np.clip(np.round(x * 100.0 + 0.4), -128, 127).astype(np.int8); code = M.IQ_S8
+    else:
+        raw = np.clip(np.round(x * 1500.0 + 9.0), -32768, 32767).astype(np.int16); code = M.IQ_S16
+    outs = []
+    for kernel in (1, 3):
+        f = _handle(fmx_amd, kernel, max(blocks), nch=NCH, nst=1)
+        pcm, taps, pos = [], [], 0
+        for b in blocks:
+            pcm.append(f.process_host_raw(raw[None, pos:pos + b], code)); pos += b
+            assert f.last_front_kernel() == kernel
+            taps.append(np.stack([f.tap(M.TAP_FM_IQ, f.last_fm_samples(), c) for c in range(NCH)]))
+        outs.append((np.concatenate(pcm, axis=1), np.concatenate(taps, axis=1)))
+        del f
+    (pa, ta), (pb, tb) = outs
+    assert float(np.abs(ta).max()) > 0.1 and float(np.abs(pa).max()) > 0.01
+    _close(ta, tb, 3, "fm-rate IQ")
+    _close(pa, pb, 3, "PCM")
