@@ -175,14 +175,14 @@ __global__ __launch_bounds__(fftc::T, AF_WAVES_PER_SIMD) void audio_fft_kernel(D
 // K is TIME, so the LDS image is the de-interleaved d ring of the workgroup's 1024 frames -- four linear f16 planes (hi L, hi R, lo L, lo R) --
 // and a lane's operand 16 consecutive bytes of a plane; the taps sit reversed in a table per half.  The 32 x 32 tile because the operands come
 // from LDS: 12 multiply-adds per operand byte (the 16 x 16 tile: 6, and the LDS, not the matrix pipe, set the time -- measured, 0.43 ms against
-// 0.41 for the fast convolution).  A block's window begins 128 samples = 256 bytes behind its neighbour's -- sixteen blocks on ONE of the
+// 0.41 for the fast convolution).  Two waves share a group's 63 K-steps and exchange halves of their sums through LDS (four waves per workgroup).  A block's window begins 128 samples = 256 bytes behind its neighbour's -- sixteen blocks on ONE of the
 // sixteen 16-byte bank slots --, so every 256 bytes of a plane are followed by 16 bytes of padding (block stride 17 slots) and the planes of L
 // and R sit 8 slots apart: the operand reads are conflict-free.  One 128-thread workgroup per 1024 frames and channel; 63 K-steps of three
 // matrix instructions per wave; the per-frame epilogue (gain, fade-in, test tone, peak maxima) is the fast convolution's.
 namespace am {
-constexpr int WV = 2;                            // waves per workgroup
-constexpr int FRW = 512;                         // frames per wave: 16 blocks of 32
-constexpr int FR = WV * FRW;                     // frames per workgroup
+constexpr int WV = 4;                            // waves per workgroup: two per group of 512 frames, each with half of the K-steps
+constexpr int FRW = 512;                         // frames per group: 16 blocks of 32
+constexpr int FR = 2 * FRW;                      // frames per workgroup
 constexpr int KMAX = 1024;                       // >= 124 + 883 + 1, a multiple of 16
 constexpr int TAB = AM_TAB;                      // entries of a tap table: u = k - 4 i + 124 in [0, KMAX + 124)
 constexpr int PLN = 4 * FR - 128 + KMAX;         // samples per plane: the last block's window ends here (4992)
@@ -210,7 +210,8 @@ __global__ __launch_bounds__(64 * am::WV) void audio_mfma_kernel(DeviceTables T,
     __shared__ __attribute__((aligned(16))) char pl[4 * PLB];             // hi L, hi R, lo L, lo R (padded: pad256)
     __shared__ __attribute__((aligned(16))) h16 ta[2][TAB];
     __shared__ int pkt[FR / C_TILE][4];
-    const int ch = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ch = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wave = wv >> 1, kh = wv & 1;            // group of 512 frames, half of the K-steps
     const int64_t mb = G.M0 + (int64_t)blockIdx.x * FR;
     if (mb >= G.M1) return;
     const ChanParams P = B.params[ch];
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(64 * am::WV) void audio_mfma_kernel(DeviceTables T,
         const u32x2 l0 = *reinterpret_cast<const u32x2 *>(aB + 32 * j + 2 * TAB), l1 = *reinterpret_cast<const u32x2 *>(aB + 32 * j + 2 * TAB + 8);
         *ah = (u32x4){a0.x, a0.y, a1.x, a1.y}; *al = (u32x4){l0.x, l0.y, l1.x, l1.y};
     };
-    // four operand sets in rotation: a step's operands are requested two steps ahead (the workgroup is two waves, a CU holds six: nobody else
-    // hides the LDS latency), pinned there against the scheduler, which would sink the loads to their use
+    // operand sets in rotation: a step's operands are requested two steps ahead, pinned there against the scheduler, which would sink the
+    // loads to their use
     u32x4 bh[4], bl[4], ah[4], al[4];
     auto mm = [&](int k) {
         const v8h Bh = __builtin_bit_cast(v8h, bh[k]), Bl = __builtin_bit_cast(v8h, bl[k]), Ah = __builtin_bit_cast(v8h, ah[k]), Al = __builtin_bit_cast(v8h, al[k]);
@@ -281,10 +282,12 @@ __global__ __launch_bounds__(64 * am::WV) void audio_mfma_kernel(DeviceTables T,
         ahl = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, ahl, 0, 0, 0);
         alh = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, alh, 0, 0, 0);
     };
-    ldB(0, &bh[0], &bl[0]); ldA(0, &ah[0], &al[0]);
-    ldB(1, &bh[1], &bl[1]); ldA(1, &ah[1], &al[1]);
-    for (int j = 0; j < nsteps; j += 4) {
-        const int j2 = j + 2, j3 = j + 3, j4 = j + 4 < nsteps ? j + 4 : j, j5 = j + 5 < nsteps ? j + 5 : j;     // (the last round's look-ahead: any valid step)
+    const int jA = kh * (nsteps >> 1), jE = jA + (nsteps >> 1);           // this wave's K-steps (nsteps is a multiple of four: an even half)
+    ldB(jA, &bh[0], &bl[0]); ldA(jA, &ah[0], &al[0]);
+    ldB(jA + 1, &bh[1], &bl[1]); ldA(jA + 1, &ah[1], &al[1]);
+    for (int j = jA; j < jE; j += 2) {
+        const int j2 = j + 2 < jE ? j + 2 : j, j3 = j + 3 < jE ? j + 3 : j;           // (the last round's look-ahead: any valid step)
+        __builtin_amdgcn_sched_barrier(0);
         ldB(j2, &bh[2], &bl[2]); ldA(j2, &ah[2], &al[2]);
         __builtin_amdgcn_sched_barrier(0);
         mm(0);
@@ -293,14 +296,21 @@ __global__ __launch_bounds__(64 * am::WV) void audio_mfma_kernel(DeviceTables T,
         __builtin_amdgcn_sched_barrier(0);
         mm(1);
         __builtin_amdgcn_sched_barrier(0);
-        ldB(j4, &bh[0], &bl[0]); ldA(j4, &ah[0], &al[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(2);
-        __builtin_amdgcn_sched_barrier(0);
-        ldB(j5, &bh[1], &bl[1]); ldA(j5, &ah[1], &al[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(3);
-        __builtin_amdgcn_sched_barrier(0);
+        bh[0] = bh[2]; bl[0] = bl[2]; ah[0] = ah[2]; al[0] = al[2];
+        bh[1] = bh[3]; bl[1] = bl[3]; ah[1] = ah[3]; al[1] = al[3];
+    }
+    // the two waves of a group exchange halves of their sums through LDS (on top of the planes, which nobody reads any more): the wave of the
+    // first K-half finishes accumulator registers 0 .. 7 (frames 8 q + 4 kgr + r of a block, q = 0, 1), the other one 8 .. 15 (q = 2, 3)
+    float acc[8];
+    {
+        __syncthreads();
+        float *xs = reinterpret_cast<float *>(pl) + (size_t)(2 * wave + (kh ^ 1)) * 8 * 64;       // what the partner will read
+#pragma unroll
+        for (int v = 0; v < 8; v++) { const int r = 8 * (kh ^ 1) + v; xs[v * 64 + lane] = ahh[r] + (ahl[r] + alh[r]); }
+        __syncthreads();
+        const float *xr = reinterpret_cast<const float *>(pl) + (size_t)(2 * wave + kh) * 8 * 64;
+#pragma unroll
+        for (int v = 0; v < 8; v++) { const int r = 8 * kh + v; acc[v] = ((ahh[r] + (ahl[r] + alh[r])) + xr[v * 64 + lane]) * OSC; }
     }
     // ---- per frame: gain, fade, test tone, peaks, store (as audio_fft_kernel).  Accumulator register v = 4 q + r of the lane is frame
     //      8 q + 4 kgr + r of the block (component comp); the lane of the left channel takes r = 0, 1 with the right channel's values from its
@@ -314,9 +324,9 @@ __global__ __launch_bounds__(64 * am::WV) void audio_mfma_kernel(DeviceTables T,
     const int i_tile = (int)(mb - G.M0) + tile * C_TILE;
     float pv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float a0 = (ahh[4 * q] + (ahl[4 * q] + alh[4 * q])) * OSC, a1 = (ahh[4 * q + 1] + (ahl[4 * q + 1] + alh[4 * q + 1])) * OSC;
-        const float a2 = (ahh[4 * q + 2] + (ahl[4 * q + 2] + alh[4 * q + 2])) * OSC, a3 = (ahh[4 * q + 3] + (ahl[4 * q + 3] + alh[4 * q + 3])) * OSC;
+    for (int qq = 0; qq < 2; qq++) {
+        const int q = 2 * kh + qq;
+        const float a0 = acc[4 * qq], a1 = acc[4 * qq + 1], a2 = acc[4 * qq + 2], a3 = acc[4 * qq + 3];
         const float k0 = comp ? a2 : a0, k1 = comp ? a3 : a1;
         const float r0 = dpp_swap1(comp ? a0 : a2), r1 = dpp_swap1(comp ? a1 : a3);
         const float fl[2] = {comp ? r0 : k0, comp ? r1 : k1}, fr[2] = {comp ? k0 : r0, comp ? k1 : r1};
@@ -432,9 +442,9 @@ void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
                   int channels, hipStream_t s) {
     const int64_t frames = G.M1 - G.M0;
     if (frames <= 0) return;
-    // (FMX_AUDIO_MFMA=1: the Toeplitz form on the matrix pipe instead of the fast convolution -- parity-green, and measured SLOWER at 4096 channels,
-    // 0.58 ms against 0.42: this stage moves 0.63 GB of d ring and 0.16 GB of PCM per call, its floor is ~0.2 ms of memory time, and a workgroup's
-    // 42 KB of operand planes leave a CU six waves to hide its latencies with)
+    // (FMX_AUDIO_MFMA=1: the Toeplitz form on the matrix pipe instead of the fast convolution -- parity-green, and measured no faster at 4096 channels,
+    // 0.425 ms against 0.410 for the interval of this stage: it moves 0.8 GB of d ring and 0.16 GB of PCM per call through 20 480 workgroups whose
+    // operand planes (42 KB per 1024 frames) leave a CU twelve waves; neither form is bound by its arithmetic any more)
     static const bool mfma = getenv("FMX_AUDIO_MFMA") && atoi(getenv("FMX_AUDIO_MFMA")) != 0;
     if (mfma && T.audio_mtab) hipLaunchKernelGGL(audio_mfma_kernel, dim3((unsigned)((frames + am::FR - 1) / am::FR), channels), dim3(64 * am::WV), 0, s, T, B, G, pcm);
     else hipLaunchKernelGGL(audio_fft_kernel, dim3((unsigned)((frames + AF_VALID - 1) / AF_VALID), channels), dim3(fftc::T), 0, s, T, B, G, pcm);

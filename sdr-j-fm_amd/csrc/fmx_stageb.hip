@@ -1213,7 +1213,9 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 *reinterpret_cast<float2 *>(&park_cur[j0 + i]) = make_float2(cur[i], cur[i + 1]);
             }
             SB_FT(17); SB_FTW(18);
+#ifndef SB_NO_CONV      /* (diagnostic build: what the PSS low-pass costs -- the error it delivers is garbage) */
             fftc::convolve(tid, a, X, T.fft_w, T.pss_hs);
+#endif
             SB_FT(19);
             __syncthreads();                   // (er overlays the buffer the last stage was read from)
 #pragma unroll

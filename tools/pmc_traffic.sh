@@ -20,8 +20,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 line = [l for l in open("gpurun_out/pmc_FETCH_SIZE.log") if l.startswith("{")]
 cfg = json.loads(line[-1])["config"] if line else {}
 ch, n = cfg.get("channels_per_gpu"), cfg.get("block_samples_per_channel")
-f = sum(v for k, v in out["FETCH_SIZE_KB_per_launch"].items() if "front_kernel" in k)
-w = sum(v for k, v in out["WRITE_SIZE_KB_per_launch"].items() if "front_kernel" in k)
+import re
+isfront = lambda k: re.search(r"front\d?_kernel", k) is not None and "pre" not in k       # front_kernel / f3::front3_kernel / f4::front4_kernel: whichever ran
+f = sum(v for k, v in out["FETCH_SIZE_KB_per_launch"].items() if isfront(k))
+w = sum(v for k, v in out["WRITE_SIZE_KB_per_launch"].items() if isfront(k))
 res = {
     "note": "rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs) of `python bench.py %s` on MI355X; per launch of each fmx kernel. "
             "FETCH_SIZE is doubled for the front kernel per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced streaming reads); units are KB." % " ".join(sys.argv[2:]),
