@@ -4,6 +4,7 @@
 #include "../../include/fmx.h"
 #include "fmx_internal.h"
 #include "fmx_fftconv.h"
+#include "fmx_mfmaconv.h"
 #include "fmx_rdsgroups.h"
 #include "fmx_design.h"
 
@@ -72,7 +73,7 @@ struct fmx_handle_s {
     bool gain_pending = false;                                       // ... taken over by flush_mailbox together with the settings themselves (processing
                                                                      // thread only): gain_fix_kernel runs in the first call that produces frames
     float *d_audio_lp = nullptr, *d_rs_taps = nullptr;
-    uint16_t *d_audio_mtab = nullptr;
+    uint16_t *d_audio_mtab = nullptr, *d_pss_mtab = nullptr;
     float2 *d_audio_spec = nullptr;               // the audio low-pass and the resampler alone (gain_fix_kernel)
     // unique tap sets
     std::vector<int32_t> front_keys, audio_keys;
@@ -1106,6 +1107,14 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMemcpy(h->d_pss_hs, Hs.data(), sizeof(float2) * fftc::N, hipMemcpyHostToDevice));
         h->T.fft_w = h->d_fft_w;
         h->T.pss_hs = h->d_pss_hs;
+        // ... and its matrix-pipe form (fmx_mfmaconv.h; which of the two stage B runs is a compile-time choice: SB_PSS_MFMA in fmx_stageb.hip)
+        {
+            std::vector<uint16_t> mt(2 * 4 * mconv::TABN);
+            mconv::make_tables(h->h_pss_taps.data(), mt.data());
+            HIPCHK(hipMalloc(&h->d_pss_mtab, sizeof(uint16_t) * mt.size()));
+            HIPCHK(hipMemcpy(h->d_pss_mtab, mt.data(), sizeof(uint16_t) * mt.size(), hipMemcpyHostToDevice));
+            h->T.pss_mtab = h->d_pss_mtab;
+        }
     }
     h->T.sincos_C = fmRate / (2 * design::kPi);
     {   // fm_Demodulator ctor fm-demodulator.cpp:57-72
@@ -1211,7 +1220,7 @@ int fmx_destroy(fmx_handle h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &pr : h->prof) for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
-    void *ptrs[] = { h->d_audio_mtab, h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
+    void *ptrs[] = { h->d_pss_mtab, h->d_audio_mtab, h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
                      h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.dcv_hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
                      h->B.w_osc, h->B.w_diff, h->d_cv_taps, h->d_x48 };

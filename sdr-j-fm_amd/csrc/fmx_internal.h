@@ -184,6 +184,7 @@ struct DeviceTables {
     const float  *pss_taps;      // [PSS_TAPS]
     const float2 *fft_w;         // [fftc::W_COUNT] stage twiddles of fmx_fftconv.h
     const float2 *pss_hs;        // [2048] spectrum of the PSS taps in the forward transform's slot order, 1 / N included; null: direct FIR (FMX_PSS_FIR=direct)
+    const uint16_t *pss_mtab;    // [2][4][mconv::TABN] the PSS taps as fmx_mfmaconv.h wants them (f16 halves, reversed, four shifted copies); null: the fast convolution
     const float  *audio_taps;    // [sets][C_TAPS_STRIDE]
     const float  *audio_lp_taps; // [sets][AUDIO_TAPS] the audio low-pass alone (gain_fix_kernel), h[0] first
     const float  *rs_taps;       // [RS_TAPS] the resampler alone, h[0] first
