@@ -123,7 +123,8 @@ typedef enum {
                                   3 = fmx_front4.hip: the filter on the matrix pipe -- samples and taps split into two f16 halves each, their
                                   products exact in the f32 accumulator, the remainders' roundings at 2^-22 of a product: the fm-rate IQ
                                   agrees with kernel 1's to 5e-7 of its amplitude, PCM against the oracle is unchanged.  THE SAMPLES MUST
-                                  STAY BELOW 16 IN MAGNITUDE (the reference's devices deliver +-1); larger ones overflow f16.
+                                  STAY BELOW 16 IN MAGNITUDE (the reference's devices deliver +-1): larger ones are limited to +-15.99
+                                  there (f16's range behind the pre-scale), where kernel 1 and the reference are linear.
                                   2 and 3 take the whole 1536-sample tiles of the calls they can -- float32 samples, no local oscillator on
                                   any channel, the input filter on everywhere, a call that starts on a multiple of 12 samples -- and leave
                                   the rest to kernel 1.

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 v.y = (P.att_r != 0.f ? v.y / P.att_r : 0.f) + dc_now.y;
             }
             const int s = DECIM * c + r;                           // sample of the 288 in front of the call
-            const float xr = v.x * XSC, xi = v.y * XSC;
+            const float xr = __builtin_amdgcn_fmed3f(v.x * XSC, -65504.f, 65504.f), xi = __builtin_amdgcn_fmed3f(v.y * XSC, -65504.f, 65504.f);
             const h16 hr = (h16)xr, hi = (h16)xi;
             L.pl[0][s] = hr; L.pl[1][s] = hi;
             L.pl[2][s] = (h16)(xr - (float)hr); L.pl[3][s] = (h16)(xi - (float)hi);
@@ -254,8 +254,10 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #pragma unroll
             for (int k = 0; k < SPT / 2; k++) {
                 uint32_t hr, lr, hi, li;
-                split2(raw[k].x * XSC, raw[k].z * XSC, &hr, &lr);
-                split2(raw[k].y * XSC, raw[k].w * XSC, &hi, &li);
+                // (samples beyond f16's range behind the pre-scale, |x| >= 16, saturate there instead of becoming infinities that the filter
+                // would spread over 24 columns as NaNs: a limiter where the f32 kernel is linear -- include/fmx.h states the range)
+                split2(__builtin_amdgcn_fmed3f(raw[k].x * XSC, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(raw[k].z * XSC, -65504.f, 65504.f), &hr, &lr);
+                split2(__builtin_amdgcn_fmed3f(raw[k].y * XSC, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(raw[k].w * XSC, -65504.f, 65504.f), &hi, &li);
                 *reinterpret_cast<uint32_t *>(scW + 256 * k) = hr;
                 *reinterpret_cast<uint32_t *>(scW + 256 * k + PLB) = hi;
                 *reinterpret_cast<uint32_t *>(scW + 256 * k + 2 * PLB) = lr;

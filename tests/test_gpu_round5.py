@@ -230,3 +230,34 @@ def test_front4_raw_formats(fmx_amd, ol, fmt):
     assert float(np.abs(ta).max()) > 0.1 and float(np.abs(pa).max()) > 0.01
     _close(ta, tb, 3, "fm-rate IQ")
     _close(pa, pb, 3, "PCM")
+
+
+def test_front4_saturates_out_of_range_samples_and_keeps_them_to_their_channel(fmx_amd, ol):
+    """The matrix-pipe kernel works on f16 halves of the samples times 2^12: |x| >= 16 is beyond that range.  Such samples are limited to the
+    range's end (no infinities, no NaNs spreading through the filter), and what happens to one stream is no other stream's business: a burst of
+    samples of magnitude 100 and a NaN / Inf burst on stream 1 leave the PCM of the channels on stream 0 bit-identical, and the channels on
+    stream 1 finite where their input was."""
+    T = 1536
+    blocks = [100 * T, 100 * T]
+    n = sum(blocks)
+    iq = np.stack([ol.synth_iq(n, leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k) for k in range(2)])
+    bad = iq.copy()
+    bad[1, 50 * T:50 * T + 3000] *= 400.0                     # (magnitude ~100)
+    bad[1, 120 * T:120 * T + 100] = np.nan
+    bad[1, 121 * T:121 * T + 100, 0] = np.inf
+    outs = []
+    for x in (iq, bad):
+        f = fmx_amd.Fmx(6, streams=2, stream_of_channel=[0, 1, 0, 1, 0, 1], max_block=max(blocks))
+        for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FILTER_RESTARTS, 2), (M.P_FRONT_KERNEL, 3), (M.P_FRONT_PARTS, 1)):
+            f.set_param(pid, v)
+        pcm, pos = [], 0
+        for b in blocks:
+            pcm.append(f.process_host(x[:, pos:pos + b])); pos += b
+            assert f.last_front_kernel() == 3
+        outs.append(np.concatenate(pcm, axis=1))
+        del f
+    a, b = outs
+    for c in (0, 2, 4):
+        assert np.array_equal(a[c], b[c]), c
+    first_nan_frame = (120 * T) // 48
+    assert np.isfinite(b[1][:first_nan_frame - 200]).all()   # (the magnitude-100 burst: limited, finite)
