@@ -518,7 +518,10 @@ int ensure_ola(fmx_handle h) {
     HIPCHK(hipMalloc(&h->pre_look.maps, sizeof(float4) * C * h->pre_look.max_tiles));
     HIPCHK(hipMalloc(&h->pre_look.flags, sizeof(int32_t) * C * h->pre_look.max_tiles));
     HIPCHK(hipMemset(h->pre_look.flags, 0, sizeof(int32_t) * C * h->pre_look.max_tiles));
-    h->tail_ptrs.push_back(h->pre_look.maps); h->tail_ptrs.push_back(h->pre_look.flags);
+    HIPCHK(hipMalloc(&h->pre_look.tickets, sizeof(uint32_t) * C));
+    HIPCHK(hipMemset(h->pre_look.tickets, 0, sizeof(uint32_t) * C));
+    h->pre_look.ticket_base = 0;
+    h->tail_ptrs.push_back(h->pre_look.maps); h->tail_ptrs.push_back(h->pre_look.flags); h->tail_ptrs.push_back(h->pre_look.tickets);
     int rc = ola_alloc_side(h, h->ola_in, 2 * 32768 - 251, 251);          // inputFilter (2 * 32768, 251) fm-processor.cpp:77
     if (rc) return rc;
     return ola_alloc_side(h, h->ola_au, 2 * 4096 - AUDIO_TAPS, AUDIO_TAPS);   // fmAudioFilter (2 * 4096, 756) :76
@@ -816,10 +819,12 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
             ola_fill(h->ola_in, O);
             h->pre_look.epoch += 1;
             launch_pre(h->T, h->B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, &st1, &O, h->pre_look); FMX_LAUNCHED();
+            { const uint32_t nt = (uint32_t)((G.n + PRE_TILE_SAMPLES - 1) / PRE_TILE_SAMPLES); if (nt > 1) h->pre_look.ticket_base += nt; }
             ola_finish_single(h, h->ola_in, st1, O, s);
         } else {
             h->pre_look.epoch += 1;
             launch_pre(h->T, h->B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, nullptr, nullptr, h->pre_look); FMX_LAUNCHED();
+            { const uint32_t nt = (uint32_t)((G.n + PRE_TILE_SAMPLES - 1) / PRE_TILE_SAMPLES); if (nt > 1) h->pre_look.ticket_base += nt; }
             run_ola(h, h->ola_in, O, n, s);
         }
         CallGeom Gp = G; Gp.pre_processed = 1; Gp.iq_format = 0; Gp.iq_scale = 1.0f; Gp.stream_stride = h->cfg.max_block; Gp.streams_private = h->twins == 1 ? 1 : 0;

@@ -300,7 +300,9 @@ struct OlaBuffers {
 };
 // pre_kernel's look-back between the tiles of a channel: the tiles' RF DC maps and "published in launch `epoch`" flags (zeroed once; the
 // epoch counts the handle's launches, so nothing is ever reset)
-struct PreLook { float4 *maps; int32_t *flags; int32_t max_tiles, epoch; };
+// (tickets: a workgroup takes its tile index from its channel's counter -- a tile's workgroup only ever waits for tiles whose workgroups have
+// STARTED, whatever order the dispatcher starts them in; the counters run on from launch to launch, ticket_base = what earlier launches handed out)
+struct PreLook { float4 *maps; int32_t *flags; int32_t max_tiles, epoch; uint32_t *tickets; uint32_t ticket_base; };
 constexpr int PRE_TILE_SAMPLES = 8192;
 // (S, O given: the whole call is ONE run of every channel's filter, and the kernel does ola_io_kernel's work itself)
 void launch_pre(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, float2 *vbuf, int64_t vstride, int channels, hipStream_t s,

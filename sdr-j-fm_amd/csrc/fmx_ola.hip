@@ -67,8 +67,14 @@ __global__ __launch_bounds__(PRE_T) void pre_kernel(DeviceTables T, DeviceBuffer
     // first sample: every workgroup publishes its tile's map r -> r (1 - u) + a (it depends on the tile's samples only) and walks the maps of
     // the tiles in front of its own from the call's state, one after the other as a single workgroup walking the call would -- the same
     // values, without the call's tiles queueing up behind each other's round trips to memory (one channel, 0.1 s: 29 tiles, 0.28 -> 0.02 ms).
-    const int tile = blockIdx.x, ntiles = gridDim.x;
+    const int ntiles = gridDim.x;
     const int ch = blockIdx.y, t = threadIdx.x;
+    // the tile of this workgroup: the next one of its channel nobody has taken yet (NOT blockIdx.x: the look-back below spins on the tiles in front
+    // of its own, which is only safe when their workgroups are known to have started -- an order of dispatch HIP does not promise)
+    __shared__ int s_tile;
+    if (t == 0) s_tile = ntiles > 1 ? (int)(atomicAdd(&LB.tickets[ch], 1u) - LB.ticket_base) : 0;
+    __syncthreads();
+    const int tile = s_tile;
     const ChanParams P = B.params[ch];
     ChanState *st = B.state + ch;
     constexpr int BPS = (FMT == 0) ? 8 : (FMT == 3 ? 4 : 2);
