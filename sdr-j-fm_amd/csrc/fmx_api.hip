@@ -809,7 +809,9 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         // both sit at the packed-FMA power limit)
         if (h->front3_ok && fk == 2) { G.parts = 1; G.front3 = 1; }
         if (h->front4_ok && (fk == 3 || (fk == 0 && G.parts <= 1))) { G.parts = 1; G.front3 = 2; }
-        h->last_front_kernel = G.front3 == 2 ? 3 : (G.front3 == 1 ? 2 : 1);
+        // (what is reported is what runs: a call without a whole tile on the kernels' grid goes to front_kernel in launch_front)
+        const int tiles = G.front3 == 2 ? front4_tiles(G, d_iq) : (G.front3 == 1 ? front3_tiles(G, d_iq) : 0);
+        h->last_front_kernel = tiles > 0 ? G.front3 + 1 : 1;
     }
     if (h->ola_mode) {
         // few channels: RF DC removal / balance / LO mix per sample, the input filter as the reference's block machine, then the decimators

@@ -55,6 +55,9 @@ __device__ __forceinline__ void pss_errors(int tid, const float2 (&a)[8], char *
 #ifdef MCONV_ENTRY_BARRIER
     __syncthreads();
 #endif
+#ifndef MCONV_DRAIN
+#define MCONV_DRAIN "s_nop 7\n\ts_nop 4"    /* wait states between the last matrix instruction and the first VALU read of the sums */
+#endif
 #ifndef MCONV_TAIL
 #define MCONV_TAIL ""      /* (diagnostic builds: wait states behind a step's last matrix instruction, e.g. "\n\ts_nop 7") */
 #endif
@@ -119,7 +122,7 @@ __device__ __forceinline__ void pss_errors(int tid, const float2 (&a)[8], char *
             }
         }
         if (MCONV_SKIP & 4) { ahh = (v4f){0.f, 0.f, 0.f, 0.f}; ahl = ahh; alh = ahh; }
-        else asm volatile("s_nop 7\n\ts_nop 4" : "+v"(ahh), "+v"(ahl), "+v"(alh));
+        else asm volatile(MCONV_DRAIN : "+v"(ahh), "+v"(ahl), "+v"(alh));
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const float y = ahh[v] + (ahl[v] + alh[v]);

@@ -261,3 +261,30 @@ def test_front4_saturates_out_of_range_samples_and_keeps_them_to_their_channel(f
         assert np.array_equal(a[c], b[c]), c
     first_nan_frame = (120 * T) // 48
     assert np.isfinite(b[1][:first_nan_frame - 200]).all()   # (the magnitude-100 burst: limited, finite)
+
+
+def test_front_kernel_choice(fmx_amd, ol):
+    """The automatic choice of the input-filter kernel (fmx_last_front_kernel): the matrix-pipe kernel for a handle that fills the GPU without
+    splitting its channels in time, has no local oscillator and the input filter on everywhere, for calls on the 12-sample grid that hold a
+    whole tile; front_kernel otherwise."""
+    T = 1536
+    x = ol.synth_iq(64 * T + 5)
+    def run(nch, setup, n=4 * T, pre=0):
+        f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=64 * T)
+        for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_FILTER_RESTARTS, 2)):
+            f.set_param(pid, v)
+        setup(f)
+        if pre:
+            f.process_host(x[None, :pre])
+        f.process_host(x[None, pre:pre + n])
+        k = f.last_front_kernel()
+        del f
+        return k
+    assert run(600, lambda f: None) == 3
+    assert run(600, lambda f: None, n=T - 12) == 1                                   # (no whole tile)
+    assert run(600, lambda f: None, n=2 * T, pre=5) == 1                             # (off the 12-sample grid)
+    assert run(600, lambda f: f.set_param(M.P_LOCAL_OSCILLATOR, 200000, 7)) == 1     # (a local oscillator somewhere)
+    assert run(600, lambda f: f.set_param(M.P_BANDWIDTH, 0, 3)) == 1                 # (the input filter off somewhere)
+    assert run(600, lambda f: f.set_param(M.P_FRONT_KERNEL, 1)) == 1
+    assert run(40, lambda f: None, n=64 * T) == 1                                    # (too few channels: split in time on front_kernel)
+    assert run(40, lambda f: f.set_param(M.P_FRONT_KERNEL, 3), n=64 * T) == 3
