@@ -462,6 +462,8 @@ def main():
     stream = call_stream.cuda_stream
 
     calls = [0]
+    if os.environ.get("FMX_BENCH_PTRS"):         # (diagnostic: where the caller-side buffers landed)
+        print("ptrs iq %#x pcm %#x" % (iq.data_ptr(), pcm.data_ptr()), file=sys.stderr)
 
     def step():
         k = calls[0] % nblk
@@ -619,7 +621,10 @@ def main():
             L.fmx_debug_stream_bandwidth.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
             for mode, key in ((0, "copy_GBps"), (1, "read12_write1_GBps")):
                 g = C.c_double()
-                if L.fmx_debug_stream_bandwidth(local_rank, mode, 1 << 30, 10, C.byref(g)) == 0:
+                # (over 7.5 GiB, the size of a step's input: a 1 GiB probe, rounds 2-5, re-read a buffer of which the 256 MB memory-side cache
+                # keeps a quarter from one pass to the next and reported 6.3 TB/s for a traffic mix that streams at 5.4-5.5,
+                # tools/ubench/stream_shape.hip)
+                if L.fmx_debug_stream_bandwidth(local_rank, mode, 15 << 29, 3, C.byref(g)) == 0:
                     measured[key] = round(g.value, 1)
         except Exception as e:      # the probe is a diagnostic; the bench line does not depend on it
             measured = {"error": str(e)}

@@ -30,14 +30,24 @@
 // instead of 600 packed FMAs and ~370 others.
 // Six waves per channel, two channels per workgroup, one workgroup per CU, the waves of a channel staggered through its tiles as in
 // fmx_front3.hip (scatter, prefetch of the wave's next tile, filter, DC recurrence through a mailbox, output).
+// Where the time goes (tools/diag/f4_ablate.sh, 4096 channels, ms per launch on a box that runs the kernel in 1.50): no loads and no stores 0.97 --
+// no stores 1.25 -- no matrix instructions 1.50 -- everything 1.50.  The kernel runs at the rate this GPU streams its traffic mix at: twelve bytes
+// read for one written is 5.4-5.5 TB/s in a kernel that does nothing else, whatever the pattern (linear or 512 streams), the waves per CU (8 .. 64),
+// the form of the store (tools/ubench/stream_shape.hip: reads alone 6.8-7.0); bench.py's `frac_of_measured` is 1.0.  Tried on that evidence and
+// without effect, so not kept: the outputs in lane order through the LDS crossbar (whole 128-byte lines per quarter-wave), the store an iteration
+// late (in front of the next loads, so that no wait covers a fresh store), nontemporal stores (slower), a tile-major ring, twelve waves on one channel.
 #include "fmx_internal.h"
 #include "fmx_front_dc.h"
 
 namespace fmx {
 namespace f4 {
 
-constexpr int NW = 6;                          // waves (= ring slots) per channel
-constexpr int CPW = 2;                         // channels per workgroup
+#ifndef F4_NW
+#define F4_NW 6        /* (12 waves on ONE channel per workgroup, -DF4_NW=12 -DF4_CPW=1: the same time per launch) */
+#define F4_CPW 2
+#endif
+constexpr int NW = F4_NW;                      // waves (= ring slots) per channel
+constexpr int CPW = F4_CPW;                    // channels per workgroup
 constexpr int NTHR = 64 * NW * CPW;
 constexpr int WCOLS = 128;                     // columns (= outputs) per tile
 constexpr int WSAMP = WCOLS * DECIM;           // 1536 input samples per tile
@@ -78,7 +88,7 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t *hi, uint32_t 
 }
 
 #ifndef F4_ABL
-#define F4_ABL 0      /* diagnostic builds only: bit 0 no scatter, 1 no DC pass, 2 no matrix FIR, 3 no tile loads behind the first (garbage results) */
+#define F4_ABL 0      /* diagnostic builds only: bit 0 no scatter, 1 no DC pass, 2 no matrix FIR, 3 no tile loads behind the first, 4 no output stores (garbage results) */
 #endif
 
 // FMT: fmx_iq_format of the input (include/fmx.h).  Raw integer samples are converted while they are loaded -- (u8 - 127) / 128, s8 / 128,
@@ -395,7 +405,9 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
         const float4 o4 = comp ? make_float4(r0, k0, r1, k1) : make_float4(k0, r0, k1, r1);
         const int qc = qt + c0col + 2 * comp;         // the lane's first output column
         const int zi = (zr0 + qc) & G.ring_mask;
-        if ((zi & 1) == 0 && qc >= ja && qc + 1 < jb) {
+        if (F4_ABL & 16) {
+            if (o4.x == 1.2345e33f) zring[0] = make_float2(o4.y, o4.z);       // (diagnostic: the results stay alive, nothing is stored)
+        } else if ((zi & 1) == 0 && qc >= ja && qc + 1 < jb) {
             *reinterpret_cast<float4 *>(&zring[zi]) = o4;
         } else {
             if (qc >= ja && qc < jb) zring[(zr0 + qc) & G.ring_mask] = make_float2(o4.x, o4.y);
