@@ -642,6 +642,12 @@ int flush_mailbox(fmx_handle h) {
     }
     bool any_pll = false;
     for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0);     // pllC on the fm-rate IQ; |z| for the level squelch; the general AFC body for the noise squelch
+    {
+        int var = 0;
+        for (auto &p : h->params)          // (of the channels the pre-pass touches: fmx_demod.hip, afc_kernel's variants)
+            var |= (p.decoder == 2 ? 1 : 0) | (p.decoder == 1 ? 2 : 0) | (p.squelch_mode == 2 ? 4 : 0) | ((p.decoder > 2 && p.squelch_mode != 0) ? 8 : 0);
+        h->B.prepass_var = var;
+    }
     bool any_nsq = false;
     for (auto &p : h->params) any_nsq |= (p.squelch_mode == 1);
     if (any_nsq && !h->d_nsq) {

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void disc_kernel(DeviceTables T, DeviceBuffers
 }
 
 // =================================================================================================
-// afc_kernel: pllC (PLL / AM decoders), carrier level, AFC + scaling, squelches   [lane per channel, 64 channels per wave]
+// afc_kernel: pllC (PLL / AM decoders), carrier level, AFC + scaling, level squelch   [lane per channel, 64 channels per wave]
 //   fm-demodulator.cpp:130-131,145-148,197-198,215-241; pllC.cpp:67-90; squelchClass.cpp:47-113
 // A dependent chain per sample whose time is set by instruction latency; the work-array rows are read a batch ahead into registers
 // (global latency off the chain).
@@ -189,13 +189,58 @@ __device__ __forceinline__ void tile_pipeline(int nfull, LoadF load, BodyF body)
 }
 
 // ---- B2
-template <bool PLLDEC>
-__device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len, const int bid_x, const int bid_y, float *atan_lds) {
-    constexpr int PDA = PLLDEC ? 2 : 4;
+// n / d as the compiler's IEEE division computes it (v_div_scale, v_rcp, the Newton steps, v_div_fmas, v_div_fixup) WITHOUT the scaling and the
+// fix-up: the same eight operations on the same values, bit for bit, wherever v_div_scale leaves its operands alone -- d and n / d well inside the
+// normal range (tools/ubench/fdiv_check.hip compares the two over 4e9 operand pairs of the range used here).  Used on the PLL decoder's
+// LIMITED samples only: |conj (nco) sig| is 1 (or 0.0014 for a silent input), the larger component the denominator.
+__device__ __forceinline__ float fdiv_inrange(float n, float d) {
+    float y = __builtin_amdgcn_rcpf(d);
+    const float e = __fmaf_rn(-d, y, 1.0f);
+    y = __fmaf_rn(e, y, y);
+    float q = n * y;
+    float r = __fmaf_rn(-d, q, n);
+    q = __fmaf_rn(r, y, q);
+    r = __fmaf_rn(-d, q, n);
+    return __fmaf_rn(r, y, q);
+}
+// compAtan::atan2 (lut_atan2 of fmx_demod_math.h, the same operations) for the loop of pllC: the corner arguments Xtan2.cpp:56-68 answers
+// without its table -- a NaN, an infinity, x = 0 (and a denormal x, for the division's sake) -- are looked for with one v_cmp_class per
+// argument and sent to the general form for the WHOLE WAVE; everything else takes the arm without them.
+template <bool LIMITED>
+__device__ __forceinline__ float lut_atan2_chain(const float *__restrict__ ppy, float y, float x) {
+    const bool odd = __builtin_amdgcn_classf(x, 0x2f7) || __builtin_amdgcn_classf(y, 0x207);
+    if (__any(odd)) return lut_atan2(ppy, y, x);
+    asm volatile("" : "+v"(x), "+v"(y));          // (keeps the general form's comparisons, which it shares with this arm, out of the path in front of the test)
+    const float St = (float)3.14159265358979323846, Sh = St * 0.5f;
+    const bool xpos = x > 0.f, ypos = y >= 0.f;
+    const bool swap = !(fabsf(x) >= fabsf(y));
+    const bool same = xpos == ypos;
+    const float size = same ? (float)ATAN_N : -(float)ATAN_N;
+    const float num = swap ? x : y, den = swap ? y : x;
+    const float q = LIMITED ? fdiv_inrange(size * num, den) : size * num / den;
+    const int idx = (int)((double)q + 0.5);
+    const float tv = ppy[idx];
+    // (Sh * +-1, St * +-1 are exact; flat selects: a nested conditional becomes divergent branches here)
+    const float ah = ypos ? Sh : -Sh, at = ypos ? St : -St;
+    const float a0 = xpos ? 0.f : at;
+    const float A = swap ? ah : a0;
+    return A + ((same == swap) ? -tv : tv);
+}
+// What a handle's pre-pass channels use (DeviceBuffers::prepass_var, from the host's copy of the parameters): the kernel is compiled for the
+// combinations below and a handle runs the smallest one that covers it -- a lone wave pays four cycles for EVERY instruction, the scalar
+// bookkeeping of a feature nobody uses included.
+enum { AV_PLL = 1, AV_AM = 2, AV_LSQ = 4, AV_MIXED = 8, AV_ALL = 15 };     // AV_MIXED: some pre-pass channel is on neither decoder (a squelch behind another one)
+template <int VAR>
+__device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int chunk_len, const int bid_x, float *atan_lds) {
+    constexpr bool HAS_PLL = (VAR & AV_PLL) != 0, HAS_AM = (VAR & AV_AM) != 0, HAS_LSQ = (VAR & AV_LSQ) != 0;
+    constexpr bool HAS_CHAIN = HAS_PLL || HAS_AM;            // pllC runs (the PLL decoder on the limited sample, the AM decoder on the sample as it is)
+    constexpr bool HAS_IQ = HAS_CHAIN || HAS_LSQ;            // the second work array is read (the sample; |z| for the level squelch of the other decoders)
+    constexpr bool MIXED = (VAR & AV_MIXED) != 0 || (HAS_PLL && HAS_AM);     // (not MIXED: every lane that gets here is on the variant's one decoder)
+    constexpr int PDA = 2;
     const int CP = G.pitch;
     const int ch = bid_x * 64 + threadIdx.x;
     const int decoder0 = ch < C ? B.params[ch].decoder : 3;
-    if (PLLDEC) {
+    if (HAS_CHAIN) {
         // pllC's loop is one dependent chain per sample and a lone wave waits out every latency on it: the two table look-ups of a step must
         // not be trips to memory (they were 2 x ~350 ns of the step's 900).  The arc-tangent table (32 KB, Xtan2.cpp:28-31) is copied into LDS by
         // the wave that has a lane on the PLL or AM decoder; the NCO's table entry comes from the sine unit (sincos_idx_hw, as in stage B).
@@ -211,126 +256,128 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     if (ch >= C) return;
     ChanState *st = B.state + ch;
     const int decoder = decoder0;
-    if (B.prepass && !(decoder <= 2 || B.params[ch].squelch_mode != 0)) return;      // (the fused kernel does this channel's demodulator itself)
-    const bool use_pll = PLLDEC && (decoder == 2), use_am = PLLDEC && (decoder == 1);
-    // the sample behind which the reference takes its metaData snapshot (++myCount > fmRate / 2, fm-processor.cpp:662-684), row of this chunk
-    const int64_t snap_row = B.prepass ? (int64_t)(SINCOS_N >> 1) - st->my_count - rc0 : -1;
+    if (!(decoder <= 2 || B.params[ch].squelch_mode != 0)) return;      // (the fused kernel does this channel's demodulator itself)
+    const bool use_pll = HAS_PLL && (!MIXED || decoder == 2), use_am = HAS_AM && (!MIXED || decoder == 1);
+    // the sample behind which the reference takes its metaData snapshot (++myCount > fmRate / 2, fm-processor.cpp:662-684), row of this call
+    const int64_t snap_row = (int64_t)(SINCOS_N >> 1) - st->my_count;
     // level squelch (squelch::do_level_squelch squelchClass.cpp:89-113, fm-processor.cpp:504-506): the carrier amplitude IIR
     // of the demodulator (fm-demodulator.cpp:130-131) against a threshold, re-evaluated every fmRate / 20 samples
-    const bool lsq = PLLDEC && (B.params[ch].squelch_mode == 2);
+    const bool lsq = HAS_LSQ && (B.params[ch].squelch_mode == 2);
     const float sq_thr = B.params[ch].squelch_thr;
     int sq_cnt = st->sq_count; bool sq_sup = st->sq_suppress != 0;
+    bool sq_mute = lsq && sq_sup;
     float am = st->am_carr;
     // (the noise squelch, squelchClass.cpp:47-87, is a pass of its own behind this kernel: nsq_kernel below)
     const float fmDcAlpha = 0.0001f, c1 = 1 - fmDcAlpha, K = T.K_FM, rK = T.K_FM_rcp;
     const double SC = T.sincos_C;
     float afc = st->fm_afc, nco_phase = st->nco_phase, incr = st->phase_incr;
-    const size_t ro = widx(rc0, ch, CP);              // rc0 is a multiple of the tile height
+    const size_t ro = widx(0, ch, CP);
     float *wd = B.w_dem + ro;
-    const float2 *wiq = PLLDEC ? B.w_iq + ro : nullptr;
+    const float2 *wiq = HAS_IQ ? B.w_iq + ro : nullptr;
     // One sample.  A lone wave issues an instruction every 4-5 cycles whatever it is, and a divergent branch is half a dozen of them: the
-    // step is written with selects; what only some handles need (the AM decoder's division, the level squelch) sits behind wave-uniform flags,
-    // and what the loop never reaches in practice (an NCO phase outside [0, 2 pi]: the update below cannot leave one) behind a wave-uniform test.
-    const bool any_pll = PLLDEC && __any(use_pll || use_am), any_am = PLLDEC && __any(use_am), any_lsq = PLLDEC && __any(lsq);
-    const bool on_pll = use_pll || use_am;
+    // step is written with selects; what only some waves of a handle need sits behind wave-uniform flags, what the handle does not use at all
+    // is not compiled (VAR), and what the loop never reaches in practice (an NCO phase outside [0, 2 pi]: the update below cannot leave one;
+    // the arc-tangent's corner arguments) behind a wave-uniform test.
+    const bool any_pll = HAS_CHAIN && (!MIXED || __any(use_pll || use_am)), any_am = HAS_AM && (!MIXED || __any(use_am)), any_lsq = HAS_LSQ && __any(lsq);
+    const bool on_pll = !MIXED || use_pll || use_am;
     const float beta = T.pll_beta, omb = 1 - T.pll_beta, plo = T.pll_lo, phi = T.pll_hi, pce = T.pll_center;
-    auto step = [&](float res, float2 sig) -> float {
+    auto step = [&](float res, float2 sig) __attribute__((always_inline)) -> float {
         float r_am = 0.f;
-        if (PLLDEC) {
-            // |z| arrives in the demod array for the AM and PLL decoders, in the first half of the IQ array otherwise (disc_kernel)
-            if (any_am || any_lsq) {
-                const float am2 = (1.0f - 0.0010f) * am + 0.0010f * (decoder <= 2 ? res : sig.x);      // am_carr_ampl, carrierAlpha (fm-demodulator.cpp:117,130-131)
-                am = (use_am || lsq) ? am2 : am;
-            }
-            if (any_pll) {                               // pllC::do_pll pllC.cpp:67-90 (AM: on the unlimited sample, :222)
-                // The NCO phase is in [0, 2 pi] (as f32: the update below leaves nothing else, starting from the constructor's 0) and the
-                // loop's increment is limited to +-0.95 pi (NcoLLimit / NcoHLimit): SinCos::getComplex's table entry is one multiplication
-                // away, and the reference's wrap loops (pllC.cpp:84-89) are at most one turn either way.
-                int idx = (int)((double)nco_phase * SC);
-                idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
-                float2 nco;
-                sincos_idx_hw(idx, &nco.y, &nco.x);
-                const float dre = nco.x * sig.x - (-nco.y) * sig.y;      // conj(nco) * signal
-                const float dim = nco.x * sig.y + (-nco.y) * sig.x;
-                const float perr = lut_atan2(atan_lds, dim, dre);
-                float inc2 = omb * perr + beta * incr;
-                inc2 = (inc2 < plo || inc2 > phi) ? pce : inc2;
-                const float ph = nco_phase + inc2;
-                const bool over = ph >= 6.2831855f, under = ph < 0.f;                  // ((double) ph >= 2 pi  <=>  ph >= 6.2831855f)
-                const double turn = over ? -FMX_2PI : FMX_2PI;                         // (x - 2 pi is fmod (x, 2 pi) for 2 pi <= x < 4 pi)
-                const float moved = (float)((double)ph + turn);
-                const float phw = (over || under) ? moved : ph;
-                incr = on_pll ? inc2 : incr;
-                nco_phase = on_pll ? phw : nco_phase;
-                if (any_am) {                            // decodeAM fm-demodulator.cpp:215-241
-                    const float gainLimit = 0.01f;
-                    float r = (res - am) / (am < gainLimit ? gainLimit : am);
-                    r = (r > 1.0f) ? 1.0f : (r < -1.0f ? -1.0f : r);
-                    r_am = r;
-                }
-                res = use_pll ? incr : res;
-            }
+        // |z| arrives in the demod array for the AM and PLL decoders, in the first half of the IQ array otherwise (disc_kernel)
+        if ((HAS_AM || HAS_LSQ) && (any_am || any_lsq)) {
+            const float am2 = (1.0f - 0.0010f) * am + 0.0010f * (decoder <= 2 ? res : sig.x);      // am_carr_ampl, carrierAlpha (fm-demodulator.cpp:117,130-131)
+            am = (use_am || lsq) ? am2 : am;
         }
-        afc = c1 * afc + fmDcAlpha * ((PLLDEC && use_am) ? incr : res);     // fm-demodulator.cpp:197 (AM: of the loop's increment, :232)
+        if (HAS_CHAIN && any_pll) {                               // pllC::do_pll pllC.cpp:67-90 (AM: on the unlimited sample, :222)
+            // The NCO phase is in [0, 2 pi] (as f32: the update below leaves nothing else, starting from the constructor's 0) and the
+            // loop's increment is limited to +-0.95 pi (NcoLLimit / NcoHLimit): SinCos::getComplex's table entry is one multiplication
+            // away, and the reference's wrap loops (pllC.cpp:84-89) are at most one turn either way.
+            int idx = (int)((double)nco_phase * SC);
+            idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+            float2 nco;
+            sincos_idx_hw_bits(idx, &nco.y, &nco.x);
+            const float dre = nco.x * sig.x - (-nco.y) * sig.y;      // conj(nco) * signal
+            const float dim = nco.x * sig.y + (-nco.y) * sig.x;
+            const float perr = lut_atan2_chain<!HAS_AM>(atan_lds, dim, dre);
+            float inc2 = omb * perr + beta * incr;
+            inc2 = (inc2 < plo || inc2 > phi) ? pce : inc2;
+            const float ph = nco_phase + inc2;
+            const bool over = ph >= 6.2831855f, under = ph < 0.f;                  // ((double) ph >= 2 pi  <=>  ph >= 6.2831855f)
+            const double turn = over ? -FMX_2PI : FMX_2PI;                         // (x - 2 pi is fmod (x, 2 pi) for 2 pi <= x < 4 pi)
+            const float moved = (float)((double)ph + turn);
+            const float phw = (over || under) ? moved : ph;
+            incr = on_pll ? inc2 : incr;
+            nco_phase = on_pll ? phw : nco_phase;
+            if (HAS_AM && any_am) {                      // decodeAM fm-demodulator.cpp:215-241
+                const float gainLimit = 0.01f;
+                float r = (res - am) / (am < gainLimit ? gainLimit : am);
+                r = (r > 1.0f) ? 1.0f : (r < -1.0f ? -1.0f : r);
+                r_am = r;
+            }
+            if (HAS_PLL) res = use_pll ? incr : res;
+        }
+        afc = c1 * afc + fmDcAlpha * ((HAS_AM && use_am) ? incr : res);     // fm-demodulator.cpp:197 (AM: of the loop's increment, :232)
         float r = fdiv_const(20.0f * (res - afc) * 1.0f, K, rK);            // :198
-        r = (PLLDEC && use_am) ? r_am : r;
-        if (PLLDEC && any_lsq) {
-            // (squelch::do_level_squelch squelchClass.cpp:89-113)
-            const int c2 = sq_cnt + 1;
-            const bool hold = c2 >= SINCOS_N / 20;           // holdPeriod = fmRate / 20 (fm-processor.cpp:87)
-            const bool sup2 = hold ? (am < sq_thr - 0.000f ? true : (am >= sq_thr + 0.000f ? false : sq_sup)) : sq_sup;   // SQUELCH_HYSTERESIS_LSQ = 0
-            sq_cnt = lsq ? (hold ? 0 : c2) : sq_cnt;
-            sq_sup = lsq ? sup2 : sq_sup;
-            r = (lsq && sq_sup) ? r * 0.000f : r;            // LEVELREDUCTIONFACTOR = 0
+        if (HAS_AM) r = use_am ? r_am : r;
+        if (HAS_LSQ && any_lsq) {
+            // (squelch::do_level_squelch squelchClass.cpp:89-113; a lane's decision falls due once in fmRate / 20 samples: the wave looks for
+            // one with a single test per sample and takes the decisions behind it)
+            sq_cnt += lsq ? 1 : 0;
+            const bool hold = lsq && sq_cnt >= SINCOS_N / 20;      // holdPeriod = fmRate / 20 (fm-processor.cpp:87)
+            if (__any(hold)) {
+                const bool sup2 = am < sq_thr - 0.000f ? true : (am >= sq_thr + 0.000f ? false : sq_sup);   // SQUELCH_HYSTERESIS_LSQ = 0
+                sq_sup = hold ? sup2 : sq_sup;
+                sq_cnt = hold ? 0 : sq_cnt;
+                sq_mute = lsq && sq_sup;
+            }
+            r = sq_mute ? r * 0.000f : r;                    // LEVELREDUCTIONFACTOR = 0
         }
         return r;
+    };
+    // a run of samples straight from the work arrays, with the look-out for the metaData snapshot (get_demodDcComponent () behind sample
+    // snap_row): the ragged end of a call, and the one tile in 750 the snapshot falls into
+    auto slow_rows = [&](int k0, int k1) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (int k = k0; k < k1; k++) {
+            const float r = step(wd[(k / WT) * (WT * CP) + (k % WT)], HAS_IQ ? wiq[(k / WT) * (WT * CP) + (k % WT)] : make_float2(0.f, 0.f));
+            if ((int64_t)k == snap_row) st->meta_dc_if = afc;
+            wd[(k / WT) * (WT * CP) + (k % WT)] = r;
+        }
     };
     constexpr int UB = SEQ_UB;
     const int nfull = chunk_len / UB;
     const int TS = UB * CP;                                       // elements from one tile of this channel to the next
     // (prefetch registers as plain float arrays: loop-carried arrays of HIP's float2 struct end up in scratch memory)
-    float nx[2][PDA][UB]; float nqa[PLLDEC ? 2 : 1][PLLDEC ? PDA : 1][UB], nqb[PLLDEC ? 2 : 1][PLLDEC ? PDA : 1][UB];
+    float nx[2][PDA][UB]; float nqa[HAS_IQ ? 2 : 1][HAS_IQ ? PDA : 1][UB], nqb[HAS_IQ ? 2 : 1][HAS_IQ ? PDA : 1][UB];
     tile_pipeline<PDA>(nfull,
         [&](int s, int u, int tl) __attribute__((always_inline)) {
             wld(nx[s][u], wd + tl * TS);
-            if (PLLDEC) { const float *qp = reinterpret_cast<const float *>(wiq + tl * TS); wld(nqa[PLLDEC ? s : 0][PLLDEC ? u : 0], qp); wld(nqb[PLLDEC ? s : 0][PLLDEC ? u : 0], qp + UB); }
+            if (HAS_IQ) { const float *qp = reinterpret_cast<const float *>(wiq + tl * TS); wld(nqa[HAS_IQ ? s : 0][HAS_IQ ? u : 0], qp); wld(nqb[HAS_IQ ? s : 0][HAS_IQ ? u : 0], qp + UB); }
         },
         [&](int s, int u, int tb) __attribute__((always_inline)) {
-            float x[UB]; float2 xq[UB];
+            // (the metaData snapshot falls into one tile in 750: looked for once per tile, for the whole wave, and that tile walked row by row)
+            if (__any(snap_row >= (int64_t)tb * UB && snap_row < (int64_t)(tb + 1) * UB)) { slow_rows(tb * UB, (tb + 1) * UB); return; }
+            float x[UB];
 #pragma unroll
             for (int k = 0; k < UB; k++) {
-                x[k] = nx[s][u][k];
-                const int ss = PLLDEC ? s : 0, uu = PLLDEC ? u : 0;
-                xq[k] = !PLLDEC ? make_float2(0.f, 0.f)
-                        : (k < UB / 2 ? make_float2(nqa[ss][uu][2 * k], nqa[ss][uu][2 * k + 1])
-                                      : make_float2(nqb[ss][uu][(2 * k) % UB], nqb[ss][uu][(2 * k) % UB + 1]));
-            }
-            // (the metaData snapshot falls into one tile in 750: looked for once per tile, for the whole wave)
-            const bool snap_here = PLLDEC && __any(snap_row >= (int64_t)tb * UB && snap_row < (int64_t)(tb + 1) * UB);
-#pragma unroll
-            for (int k = 0; k < UB; k++) {
-                x[k] = step(x[k], xq[k]);
-                if (snap_here && (int64_t)tb * UB + k == snap_row) st->meta_dc_if = afc;       // get_demodDcComponent () at the snapshot
+                const int ss = HAS_IQ ? s : 0, uu = HAS_IQ ? u : 0;
+                const float2 xq = !HAS_IQ ? make_float2(0.f, 0.f)
+                                  : (k < UB / 2 ? make_float2(nqa[ss][uu][2 * k], nqa[ss][uu][2 * k + 1])
+                                                : make_float2(nqb[ss][uu][(2 * k) % UB], nqb[ss][uu][(2 * k) % UB + 1]));
+                x[k] = step(nx[s][u][k], xq);
             }
             wst(wd + tb * TS, x);
         });
-    {
-        float *wdt = wd + nfull * TS; const float2 *wiqt = PLLDEC ? wiq + nfull * TS : nullptr;
-        for (int k = 0; k < chunk_len - nfull * UB; k++)          // ragged end of a call: rows of the last, partial tile
-        {
-            float r = step(wdt[k], PLLDEC ? wiqt[k] : make_float2(0.f, 0.f));
-            if (PLLDEC && (int64_t)nfull * UB + k == snap_row) st->meta_dc_if = afc;
-            wdt[k] = r;
-        }
-    }
-    st->fm_afc = afc; st->nco_phase = nco_phase; st->phase_incr = incr; st->am_carr = am;
-    if (PLLDEC && lsq) { st->sq_count = sq_cnt; st->sq_suppress = sq_sup ? 1 : 0; }
+    slow_rows(nfull * UB, chunk_len);                             // ragged end of a call: rows of the last, partial tile
+    st->fm_afc = afc; st->am_carr = am;
+    if (HAS_CHAIN) { st->nco_phase = nco_phase; st->phase_incr = incr; }
+    if (HAS_LSQ && lsq) { st->sq_count = sq_cnt; st->sq_suppress = sq_sup ? 1 : 0; }
 }
-template <bool PLLDEC>
-__global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int64_t rc0, int chunk_len) {
+template <int VAR>
+__global__ __launch_bounds__(64) void afc_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int C, int chunk_len) {
     FMX_RECURRENCE_PRIO();
-    __shared__ __attribute__((aligned(16))) float atan_lds[PLLDEC ? ATAN_N + 4 : 4];
-    afc_body<PLLDEC>(T, B, G, C, rc0, chunk_len, (int)blockIdx.x, (int)blockIdx.y, atan_lds);
+    __shared__ __attribute__((aligned(16))) float atan_lds[(VAR & (AV_PLL | AV_AM)) ? ATAN_N + 4 : 4];
+    afc_body<VAR>(T, B, G, C, chunk_len, (int)blockIdx.x, atan_lds);
 }
 
 // =================================================================================================
@@ -428,7 +475,19 @@ void launch_demod_prepass(const DeviceTables &T, const DeviceBuffers &B, const C
     DeviceBuffers Bp = B;
     Bp.prepass = 1; Bp.lin_rows = 0; Bp.w_dem = B.w_osc;          // (the tiled work arrays of the two kernels: w_osc takes the demodulator output)
     hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((nj + DISC_ROWS - 1) / DISC_ROWS), (unsigned)((C + DISC_CH - 1) / DISC_CH)), dim3(256), 0, s, T, Bp, G, C, (int64_t)0, (int)nj); FMX_LAUNCHED();
-    hipLaunchKernelGGL(afc_kernel<true>, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, T, Bp, G, C, (int64_t)0, (int)nj); FMX_LAUNCHED();
+    {
+        const dim3 ga((unsigned)((C + 63) / 64));
+        switch (B.prepass_var) {          // (what the handle's channels use: fmx_api.hip)
+        case 0:      hipLaunchKernelGGL(afc_kernel<0>, ga, dim3(64), 0, s, T, Bp, G, C, (int)nj); break;
+        case AV_MIXED: hipLaunchKernelGGL(afc_kernel<0>, ga, dim3(64), 0, s, T, Bp, G, C, (int)nj); break;
+        case AV_PLL: hipLaunchKernelGGL(afc_kernel<AV_PLL>, ga, dim3(64), 0, s, T, Bp, G, C, (int)nj); break;
+        case AV_PLL | AV_MIXED: hipLaunchKernelGGL((afc_kernel<AV_PLL | AV_MIXED>), ga, dim3(64), 0, s, T, Bp, G, C, (int)nj); break;
+        case AV_AM:  hipLaunchKernelGGL(afc_kernel<AV_AM>, ga, dim3(64), 0, s, T, Bp, G, C, (int)nj); break;
+        case AV_LSQ: case AV_LSQ | AV_MIXED: hipLaunchKernelGGL(afc_kernel<AV_LSQ>, ga, dim3(64), 0, s, T, Bp, G, C, (int)nj); break;
+        default:     hipLaunchKernelGGL(afc_kernel<AV_ALL>, ga, dim3(64), 0, s, T, Bp, G, C, (int)nj); break;
+        }
+        FMX_LAUNCHED();
+    }
     if (T.nsq_coef) {        // (some channel has, or had, the noise squelch on: fmx_api.hip uploads the coefficients then)
         hipLaunchKernelGGL(nsq_kernel, dim3((unsigned)((C + NSQ_CH_PER_WAVE - 1) / NSQ_CH_PER_WAVE)), dim3(64), 0, s, T, Bp, G, C, (int)nj); FMX_LAUNCHED();
     }

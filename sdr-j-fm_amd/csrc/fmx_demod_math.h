@@ -237,5 +237,19 @@ __device__ __forceinline__ void sincos_idx_hw(int idx, float *sn, float *cs) {  
     *sn = (u >= HALF) ? -s : s;
     *cs = (u - QUAD < HALF) ? -c : c;                              // N/4 <= idx < 3N/4
 }
+// the same values with the signs put on as bits (one three-input bit operation each instead of a comparison and a select -- for the lone waves of
+// fmx_demod.hip, where every instruction is four cycles): u - HALF wraps (bit 31 set) exactly when u < HALF, h - QUAD exactly when h < QUAD;
+// the sine is negative for u >= HALF, the cosine for QUAD <= u < 3 QUAD, i.e. when exactly one of the two wraps
+__device__ __forceinline__ void sincos_idx_hw_bits(int idx, float *sn, float *cs) {      // 0 <= idx < 192000
+    constexpr unsigned HALF = SINCOS_N / 2, QUAD = SINCOS_N / 4;
+    const unsigned u = (unsigned)idx;
+    const unsigned uh = u - HALF;
+    const unsigned h = min(u, uh);
+    const unsigned rr = min(h, HALF - h);
+    const float t = (float)rr * (1.0f / (float)SINCOS_N);
+    const float s = __builtin_amdgcn_sinf(t), c = __builtin_amdgcn_cosf(t);
+    *sn = __uint_as_float(__float_as_uint(s) ^ (~uh & 0x80000000u));
+    *cs = __uint_as_float(__float_as_uint(c) ^ ((uh ^ (h - QUAD)) & 0x80000000u));
+}
 
 }  // namespace fmx
