@@ -235,25 +235,30 @@ __global__ void rds_collect(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, i
     Rb.phase_ring[(size_t)ch * RDS_PHASE_RING + (int)(n & (RDS_PHASE_RING - 1))] = c;
 }
 
-// ---- 57 kHz mix + decimate by 8: one thread per 24 kS/s output m (rds sample index 8m+7)
-__global__ void rds_mix_decim(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, int64_t m0, int nout) {
-    const int ch = blockIdx.y;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nout) return;                                   // (every channel: one that is off mixes zeros, see rds_collect)
-    const int64_t m = m0 + q;
-    float2 acc = make_float2(0.f, 0.f);
-    // block and position of the newest input (one 64-bit division per thread; the ten older inputs follow by counting down)
-    const int64_t n_hi = 8 * m + 7;
-    const int64_t blk_hi = n_hi / RBLK; const int inp_hi = (int)(n_hi - blk_hi * RBLK);
+// ---- 57 kHz mix + decimate by 8: one thread per 24 kS/s output m (rds sample index 8m+7).  A workgroup's 256 outputs read 2058 consecutive inputs:
+//      they are mixed ONCE each, from coalesced loads, into LDS (round 5; before, every output gathered and mixed its own eleven inputs -- 64-byte
+//      strides through the Hilbert block and 1.4 oscillator evaluations per input: the RDS path's largest kernel), and the decimator's eleven taps
+//      read them from there.  The same operations on the same values in the same order.
+constexpr int MD_OUT = 256, MD_IN = 8 * MD_OUT + 10;
+__device__ __forceinline__ int md_pos(int j) { return j + (j >> 3); }         // one entry of padding per eight: the outputs' reads, 64 bytes apart, spread over the banks
+__global__ __launch_bounds__(MD_OUT) void rds_mix_decim(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, int64_t m0, int nout) {
+    __shared__ float2 sx[MD_IN + MD_IN / 8 + 2];
+    const int ch = blockIdx.y;                               // (every channel: one that is off mixes zeros, see rds_collect)
+    const int tid = threadIdx.x;
+    const int64_t mb = m0 + (int64_t)blockIdx.x * MD_OUT;    // the workgroup's first output
+    const int64_t n_lo = 8 * mb + 7 - 10;                    // ... and the oldest input it reads (negative in front of the stream's start)
+    // block and position of that input (one 64-bit division per thread; the others follow by counting up, across at most one block boundary)
+    const int64_t nb = n_lo >= 0 ? n_lo : 0;
+    const int64_t blk_b = nb / RBLK; const int inp_b = (int)(nb - blk_b * RBLK);
     const float2 *hil = Rb.hil + (size_t)ch * 2 * RBLK;
     const float *pring = Rb.phase_ring + (size_t)ch * RDS_PHASE_RING;
-#pragma unroll
-    for (int i = 0; i < 11; i++) {                           // newest -> oldest, kernel[0] * newest (fir-filters.cpp:409-418)
-        const int64_t n = n_hi - i;
+    const int nin = (int)((nout - (int64_t)blockIdx.x * MD_OUT < MD_OUT ? nout - (int64_t)blockIdx.x * MD_OUT : MD_OUT) * 8 + 3);       // inputs 0 .. 8 (outputs - 1) + 10
+    for (int j = tid; j < nin; j += MD_OUT) {
+        const int64_t n = n_lo + j;
         float2 x = make_float2(0.f, 0.f);
         if (n >= 0) {
-            int inp = inp_hi - i; int64_t blk = blk_hi;
-            if (inp < 0) { inp += RBLK; blk -= 1; }
+            int inp = inp_b + (int)(n - nb); int64_t blk = blk_b;
+            if (inp >= RBLK) { inp -= RBLK; blk += 1; }
             // during block blk the Hilbert filter returns the result of block blk-1 (zeros for the first block)
             float2 hv = make_float2(0.f, 0.f);
             if (blk >= 1) hv = hil[(size_t)((blk - 1) & 1) * RBLK + inp];
@@ -266,6 +271,16 @@ __global__ void rds_mix_decim(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C,
             const float2 osc = make_float2(__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns));
             x = cmulf(osc, hv);                              // *rdsValueCmpl = oscValue * rdsBaseHilb  (:754)
         }
+        sx[md_pos(j)] = x;
+    }
+    __syncthreads();
+    const int q = blockIdx.x * MD_OUT + tid;
+    if (q >= nout) return;
+    const int64_t m = m0 + q;
+    float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 11; i++) {                           // newest -> oldest, kernel[0] * newest (fir-filters.cpp:409-418)
+        const float2 x = sx[md_pos(8 * tid + 10 - i)];
         const float2 k = Rb.dec_taps[i];
         const float2 p = cmulf(x, k);
         acc.x += p.x; acc.y += p.y;
