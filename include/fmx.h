@@ -129,6 +129,11 @@ typedef enum {
                                   any channel, the input filter on everywhere, a call that starts on a multiple of 12 samples -- and leave
                                   the rest to kernel 1.
                                   0 = automatic (default): 3 where a handle qualifies and has the channels to fill the GPU, else 1. */
+    FMX_P_LR_TAP = 26,         /* (handle-wide: the channel argument is ignored) whether the L-R difference in front of the matrix is kept for
+                                  FMX_TAP_LR_RAW (the reference's AF_SUM / AF_DIFF scopes, fm-processor.cpp:608-613) -- a display feed: 4 bytes
+                                  written per channel and fm sample that nothing else reads.  1 = kept, 0 = not kept (fmx_get_tap then answers
+                                  FMX_E_UNSUPPORTED for that tap), -1 = automatic (default): kept by handles of up to 64 channels -- the receiver
+                                  with a display --, not by larger batches.  Takes effect at the next call. */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */

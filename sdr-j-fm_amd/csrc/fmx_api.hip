@@ -116,6 +116,8 @@ struct fmx_handle_s {
     std::atomic<int> stageb_form{0};     // FMX_P_STAGEB_FORM
     std::atomic<int> front_parts{0};     // FMX_P_FRONT_PARTS
     std::atomic<int> front_kernel{0};    // FMX_P_FRONT_KERNEL
+    std::atomic<int> lr_tap{-1};         // FMX_P_LR_TAP
+    float *w_diff_mem = nullptr;         // the LR scope tap's rows (allocated when first wanted; DeviceBuffers::w_diff is null while the tap is off)
     bool front3_ok = false;              // every channel qualifies for front3_kernel (flush_mailbox)
     bool front4_ok = false;              // ... and for front4_kernel
     int last_front_kernel = 1;           // what the last call's stage A was given (FMX_P_FRONT_KERNEL numbering): fmx_last_front_kernel
@@ -642,6 +644,17 @@ int flush_mailbox(fmx_handle h) {
     }
     bool any_pll = false;
     for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0);     // pllC on the fm-rate IQ; |z| for the level squelch; the general AFC body for the noise squelch
+    {   // the LR scope tap (FMX_P_LR_TAP): a display feed, kept where there is a display
+        const int want = h->lr_tap.load();
+        const bool keep = want < 0 ? h->channels <= 64 : want != 0;
+        if (keep && !h->w_diff_mem) {
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMalloc(&h->w_diff_mem, sizeof(float) * (size_t)h->work_nj * h->pitch));
+            HIPCHK(hipMemset(h->w_diff_mem, 0, sizeof(float) * (size_t)h->work_nj * h->pitch));
+            h->tail_ptrs.push_back(h->w_diff_mem);
+        }
+        h->B.w_diff = keep ? h->w_diff_mem : nullptr;
+    }
     {
         int var = 0;
         for (auto &p : h->params)          // (of the channels the pre-pass touches: fmx_demod.hip, afc_kernel's variants)
@@ -1174,7 +1187,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         const size_t C = (size_t)h->pitch;   // rows are padded (see CallGeom.pitch)
         HIPCHK(hipMalloc(&h->B.w_dem, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_cur, sizeof(float) * NJ * C));
-        HIPCHK(hipMalloc(&h->B.w_diff, sizeof(float) * NJ * C));
+        h->B.w_diff = nullptr;      // (flush_mailbox: FMX_P_LR_TAP)
         h->B.lockm_stride = (int32_t)(NJ / 6 + 512);
         HIPCHK(hipMalloc(&h->B.w_lockm, (size_t)h->B.lockm_stride * C));
         HIPCHK(hipMemset(h->B.w_lockm, 0, (size_t)h->B.lockm_stride * C));
@@ -1185,7 +1198,6 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         // the recurrence kernels move whole 64-channel row blocks, pad columns included: keep those finite
         HIPCHK(hipMemset(h->B.w_dem, 0, sizeof(float) * NJ * C));
         HIPCHK(hipMemset(h->B.w_cur, 0, sizeof(float) * NJ * C));
-        HIPCHK(hipMemset(h->B.w_diff, 0, sizeof(float) * NJ * C));
     }
     HIPCHK(hipMalloc(&h->B.state, sizeof(ChanState) * C));
     HIPCHK(hipMalloc(&h->d_params, sizeof(ChanParams) * C));
@@ -1236,7 +1248,7 @@ int fmx_destroy(fmx_handle h) {
     void *ptrs[] = { h->d_pss_mtab, h->d_audio_mtab, h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
                      h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.dcv_hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
-                     h->B.w_osc, h->B.w_diff, h->d_cv_taps, h->d_x48 };
+                     h->B.w_osc, h->d_cv_taps, h->d_x48 };      // (the LR tap's rows are in tail_ptrs)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
     for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);
@@ -1273,6 +1285,9 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_FRONT_KERNEL:
         if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "front kernel must be 0 (automatic), 1 (four waves per channel), 2 (six waves per channel) or 3 (the filter on the matrix pipe)");
         h->front_kernel.store(iv); return FMX_OK;
+    case FMX_P_LR_TAP:
+        if (iv < -1 || iv > 1) return fail(FMX_E_INVALID, "LR tap must be -1 (automatic), 0 (not kept) or 1 (kept)");
+        h->lr_tap.store(iv); return FMX_OK;
     case FMX_P_FRONT_PARTS:
         if (iv < 0 || iv > 32) return fail(FMX_E_INVALID, "front parts must be 0 (automatic), 1 (one workgroup per channel) or 2..32");
         h->front_parts.store(iv); return FMX_OK;
@@ -1506,6 +1521,7 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
             std::vector<float> a((size_t)n), b;
             HIPCHK(hipMemcpy(a.data(), (tap == FMX_TAP_PILOT_PHASE ? h->B.w_cur : h->B.w_dem) + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
             if (tap == FMX_TAP_LR_RAW) {
+                if (!h->B.w_diff) return fail(FMX_E_UNSUPPORTED, "the LR scope tap is not kept by this handle (FMX_P_LR_TAP)");
                 b.resize((size_t)n);
                 HIPCHK(hipMemcpy(b.data(), h->B.w_diff + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
                 for (int64_t i = 0; i < n; i++) { dst[2 * i] = a[(size_t)i]; dst[2 * i + 1] = b[(size_t)i]; }

@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 sumv[i] = dem[i]; diffv[i] = dif;
             }
             SB_FT(27);
-            {   // scope tap (fmx_get_tap): channel-major rows of this call
+            if (B.w_diff) {   // scope tap (fmx_get_tap; FMX_P_LR_TAP: a display feed that large batches do not keep): channel-major rows of this call
                 float *wf = B.w_diff + (size_t)ch * B.lin_rows + seg0 + j0;
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) if (i < nv) wf[i] = diffv[i];

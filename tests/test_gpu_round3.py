@@ -194,7 +194,7 @@ def test_creeping_pilots_at_batch_scale(fmx_amd, ol):
             c = int(bad[0][0] * nst + bad[0][1])
             nt = f.last_fm_samples()
             where = []
-            for name, tap in (("fm IQ", M.TAP_FM_IQ), ("demod", M.TAP_DEMOD), ("pilot phase", M.TAP_PILOT_PHASE), ("LR raw", M.TAP_LR_RAW)):
+            for name, tap in (("fm IQ", M.TAP_FM_IQ), ("demod", M.TAP_DEMOD), ("pilot phase", M.TAP_PILOT_PHASE)):
                 ta, tb = f.tap(tap, nt, c), f.tap(tap, nt, c % nst)
                 wz = np.flatnonzero((ta != tb).reshape(nt, -1).any(axis=1))
                 where.append("%s %s" % (name, "same" if len(wz) == 0 else "first at fm sample %d of %d (%d differ, max %.2e)" % (wz[0], nt, len(wz), float(np.abs(ta - tb).max()))))

@@ -288,3 +288,31 @@ def test_front_kernel_choice(fmx_amd, ol):
     assert run(600, lambda f: f.set_param(M.P_FRONT_KERNEL, 1)) == 1
     assert run(40, lambda f: None, n=64 * T) == 1                                    # (too few channels: split in time on front_kernel)
     assert run(40, lambda f: f.set_param(M.P_FRONT_KERNEL, 3), n=64 * T) == 3
+
+
+def test_lr_scope_tap_switch(fmx_amd, ol):
+    """FMX_P_LR_TAP: the L-R difference in front of the matrix is a display feed (the reference's AF_SUM / AF_DIFF scopes) -- kept by a handle of up to 64
+    channels, not by a larger batch unless asked for; the PCM does not know the difference, and a batch that keeps it has the small handle's values."""
+    n = 16384 * 6
+    x = ol.synth_iq(n)
+    def run(nch, lr):
+        f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=n)
+        for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_FILTER_RESTARTS, 2), (M.P_PLL_SOLVER, 1)):
+            f.set_param(pid, v)
+        if lr is not None: f.set_param(M.P_LR_TAP, lr)
+        pcm = f.process_host(x[None])
+        try:
+            tap = f.tap(M.TAP_LR_RAW, 4096, nch - 1)
+        except Exception as e:
+            tap = str(e)
+        del f
+        return pcm, tap
+    p1, t1 = run(1, None)
+    assert isinstance(t1, np.ndarray) and np.abs(t1[:, 0]).max() > 0
+    p70, t70 = run(70, None)
+    assert isinstance(t70, str) and "LR" in t70                              # (not kept: the library says so)
+    p70k, t70k = run(70, 1)
+    assert np.array_equal(p70, p70k) and np.array_equal(p70[69], p1[0])
+    assert isinstance(t70k, np.ndarray) and np.array_equal(t70k, t1)
+    p1n, t1n = run(1, 0)
+    assert isinstance(t1n, str) and np.array_equal(p1n, p1)
