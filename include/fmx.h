@@ -76,7 +76,9 @@ typedef enum {
     FMX_P_ATTENUATION_L = 10,  /* setAttenuation (Lgain)                             (:351-359)  */
     FMX_P_ATTENUATION_R = 11,  /* setAttenuation (Rgain)                                         */
     FMX_P_RDS_MODE = 12,       /* setfmRdsSelector: 0 off, 1 = RDS_1 (rds-decoder-1.cpp), 2 = RDS_2 (rds-decoder-2.cpp),
-                                  3 = RDS_3 (rds-decoder-3.cpp)                      (:840-847)  */
+                                  3 = RDS_3 (rds-decoder-3.cpp)                      (:840-847).  Per channel, at any time: a channel's RDS path
+                                  (block filters, phase delay line, decimator, slicers) runs while its decoder is on and keeps what it holds while
+                                  it is off, as the reference's processor does (:733-754, :551-553) -- nothing is restarted by a switch */
     FMX_P_LOCAL_OSCILLATOR = 13,/* set_localOscillator, Hz                           (:866-868)  */
     FMX_P_AUTO_MONO = 14,      /* setAutoMonoMode                                    (:914-916)  */
     FMX_P_PSS = 15,            /* setPSSMode                                         (:918-920)  */
@@ -296,6 +298,11 @@ int64_t fmx_pll_exact_segments(fmx_handle h, int32_t channel);
 int32_t fmx_last_front_kernel(fmx_handle h);
 /* ... and 24 kS/s RDS samples (rdsDecimator outputs, fm-processor.cpp:553): the n that fmx_get_tap accepts for FMX_TAP_RDS_IQ */
 int64_t fmx_last_rds_samples(fmx_handle h);
+/* ... of one channel.  A channel's RDS path counts the fm samples IT has processed -- it runs while the channel's decoder is on and stands still
+ * otherwise, as a processor of the reference leaves its block filters, its phase delay line and its decimator alone while rdsModus is RDS_OFF
+ * (fm-processor.cpp:733-754, :551-553) -- so channels that switched their decoders on at different times divide by eight on different phases
+ * and a call may give one of them an output more than another.  fmx_last_rds_samples is this for channel 0. */
+int64_t fmx_last_rds_samples_of(fmx_handle h, int32_t channel);
 
 /* introspection used by the parity tests: the filter taps the kernels run with.
  * which: 0 front-end polyphase taps, 1 PSS low-pass, 2 audio+resampler FIR, 3 resampler alone,

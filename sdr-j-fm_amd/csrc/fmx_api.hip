@@ -63,7 +63,6 @@ struct fmx_handle_s {
     int n_cus = 256; size_t lds_per_block = 65536;     // device limits the stage-A layout choice looks at
     std::vector<int32_t> act_up;                                     // one-shot action bits uploaded with the last parameter upload
     std::vector<uint8_t> rds_reset_req;                              // resetRds / triggerFrequencyChange asked for the group decoder's reset
-    bool rds_rearm = false;                                          // every channel had RDS off: buffers and state restart at the next enable
     hipEvent_t ev_in = nullptr, ev_dummy = nullptr;
     std::mutex mtx;                          // guards the mailbox (set_param from any thread)
     std::vector<ChanUser> user;
@@ -101,17 +100,19 @@ struct fmx_handle_s {
     bool prof_on = false; std::vector<ProfRec> prof; fmx_profile prof_acc{};
     int64_t last_J0 = 0, last_J1 = 0;
     // RDS path (allocated when a channel first switches RDS on)
-    bool rds_alloc = false; RdsBuffers R{}; int64_t rds_start = -1;   // fm sample index at which RDS was switched on
+    bool rds_alloc = false; RdsBuffers R{};
+    // per channel: the fm samples its RDS path has processed (it stands still while the channel's decoder is off, as the reference's
+    // processor leaves its block filters, phase delay line and decimator alone then: fm-processor.cpp:733-754, :551-553), what RdsBuffers::nc0
+    // was in the last call, and the device copy of the latter
+    std::vector<int64_t> rds_nc, rds_nc0;
+    int64_t *d_rds_nc0 = nullptr;
     std::vector<int32_t> rds_read;          // per channel: bits already handed out by fmx_rds_bits
     std::vector<int32_t> rds_read_dec;      // ... and by fmx_rds_decode
     std::vector<int32_t> rds_read_sym;      // ... symbols handed out by fmx_rds_symbols
-    std::atomic<int32_t> rds_gen{0};        // counts rds_restart: a consumer that saw an older generation starts over (its own read position and,
-    std::vector<int32_t> rds_gen_ch;        // ... and per channel: counts the channel's own restarts (its decoder switched on while others were decoding)
-    std::vector<uint8_t> rds_was_on;        // per channel: the decoder was on in the last call
-    std::vector<int32_t> rds_fresh;         // channels whose slicer state the next call clears in front of its kernels
+    std::atomic<int32_t> rds_gen{0};        // (rounds 2-4 counted restarts of the RDS path here; nothing restarts it any more) a consumer that saw an older generation starts over (its own read position and,
     std::vector<int32_t> rds_gen_dec, rds_gen_sym;   // for fmx_rds_decode, the channel's block synchroniser / group decoder), however late it polls
     std::vector<fmx::RdsGroupDecoderHost> rds_dec;
-    int64_t last_m0 = 0, last_m1 = 0;       // 24 kS/s outputs of the last call
+    std::vector<int64_t> last_m0, last_m1;  // per channel: its 24 kS/s outputs of the last call
     std::vector<void *> rds_ptrs, tail_ptrs;
     std::atomic<int> stageb_form{0};     // FMX_P_STAGEB_FORM
     std::atomic<int> front_parts{0};     // FMX_P_FRONT_PARTS
@@ -462,36 +463,14 @@ int ensure_rds_body(fmx_handle h) {
         R.sincos24 = d24;
     }
     h->rds_read.assign(C, 0);
+    {
+        int *cl = nullptr;
+        if ((rc = dalloc((void **)&h->d_rds_nc0, sizeof(int64_t) * C, true))) return rc;
+        if ((rc = dalloc((void **)&cl, sizeof(int) * C, true))) return rc;
+        R.nc0 = h->d_rds_nc0; R.chlist = cl;
+        h->rds_nc.assign(C, 0); h->rds_nc0.assign(C, -1); h->last_m0.assign(C, 0); h->last_m1.assign(C, 0);
+    }
     h->rds_alloc = true;
-    return FMX_OK;
-}
-
-// RDS was off on every channel and is switched on again: zero the block buffers, overlaps, rings and bit rings and put the
-// slicer states back to their constructor values, so that nothing of the signal before the gap is decoded
-int rds_restart(fmx_handle h) {
-    const size_t C = (size_t)h->channels;
-    RdsBuffers &R = h->R;
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemset(R.in_blk, 0, sizeof(float) * C * RDS_BLK));
-    HIPCHK(hipMemset(R.bpreal, 0, sizeof(float) * C * 2 * RDS_BLK));
-    HIPCHK(hipMemset(R.bp_over, 0, sizeof(float2) * 2 * C * 768));
-    HIPCHK(hipMemset(R.hil, 0, sizeof(float2) * C * 2 * RDS_BLK));
-    HIPCHK(hipMemset(R.hil_over, 0, sizeof(float2) * 2 * C * 768));
-    HIPCHK(hipMemset(R.phase_ring, 0, sizeof(float) * C * RDS_PHASE_RING));
-    HIPCHK(hipMemset(R.rds24, 0, sizeof(float2) * C * RDS24_RING));
-    HIPCHK(hipMemset(R.bits, 0, C * RDS_BITS_CAP));
-    HIPCHK(hipMemset(R.c_ring, 0, sizeof(float) * C * RDS24_RING));
-    HIPCHK(hipMemset(R.f_ring, 0, sizeof(float) * C * RDS24_RING));
-    HIPCHK(hipMemset(R.state1, 0, sizeof(Rds1State) * C));
-    HIPCHK(hipMemset(R.state3, 0, sizeof(Rds3State) * C));
-    RdsState s0; std::memset(&s0, 0, sizeof(s0));
-    s0.gain = 9.0f; s0.mu = 0.f; s0.skip = 3; s0.sample_count = 0;
-    s0.c_limit = (float)(2 * design::kPi * (double)10.0f / (double)(float)24000);
-    std::vector<RdsState> init(C, s0);
-    HIPCHK(hipMemcpy(R.state, init.data(), sizeof(RdsState) * C, hipMemcpyHostToDevice));
-    h->rds_read.assign(C, 0);                       // the bit counters restart at 0
-    h->rds_fresh.clear();
-    h->rds_gen.fetch_add(1);                        // fmx_rds_decode / fmx_rds_symbols start over too (their own threads: they compare generations)
     return FMX_OK;
 }
 
@@ -597,6 +576,8 @@ void run_ola(fmx_handle h, fmx_handle_s::OlaSide &S, OlaBuffers O, int64_t len, 
     }
 }
 
+static bool any_rds_on(fmx_handle h) { for (auto &p : h->params) if (p.rds_mode != 0) return true; return false; }
+
 constexpr int PLL_SEQ_AUTO_MAX = 64;   // FMX_P_PLL_SOLVER = 0: handles up to this many channels evaluate the pilot PLL sequentially
 
 int flush_mailbox(fmx_handle h) {
@@ -621,27 +602,9 @@ int flush_mailbox(fmx_handle h) {
     }
     bool any_rds = false;
     for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
-    if (h->rds_was_on.size() != h->params.size()) { h->rds_was_on.assign(h->params.size(), 0); h->rds_gen_ch.assign(h->params.size(), 0); }
-    if (any_rds) {
-        int rc = ensure_rds(h); if (rc) return rc;
-        const bool first = h->rds_start < 0;
-        if (first) {
-            if (h->rds_rearm) { rc = rds_restart(h); if (rc) return rc; h->rds_rearm = false; }
-            h->rds_start = h->g_total / h->decim;    // the RDS filters start counting here (all channels)
-        }
-        // a channel that joins while others are decoding: its filters have been running on zeros (rds_collect), its slicer starts from the
-        // constructor's state in this call, its bit counters from 0
-        for (size_t c = 0; c < h->params.size(); c++) {
-            const bool on = h->params[c].rds_mode != 0;
-            if (on && !h->rds_was_on[c] && !first) { h->rds_fresh.push_back((int32_t)c); h->rds_read[c] = 0; h->rds_gen_ch[c] += 1; }
-            h->rds_was_on[c] = on ? 1 : 0;
-        }
-    } else if (h->rds_start >= 0) {
-        // nobody listens any more: the shared overlap-add block phase ends here; the next enable starts from fresh filters,
-        // rings and slicer states (calls in between are not seen by the RDS path at all)
-        h->rds_start = -1; h->rds_rearm = true;
-        std::fill(h->rds_was_on.begin(), h->rds_was_on.end(), 0);
-    }
+    // (a channel's RDS path runs while its decoder is on and stands still otherwise -- block filters, phase delay line, decimator and slicer
+    // keep what they hold, as the reference's processor's do: nothing restarts when a decoder is switched; run_call_one counts per channel)
+    if (any_rds) { const int rc = ensure_rds(h); if (rc) return rc; }
     bool any_pll = false;
     for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0);     // pllC on the fm-rate IQ; |z| for the level squelch; the general AFC body for the noise squelch
     {   // the LR scope tap (FMX_P_LR_TAP): a display feed, kept where there is a display
@@ -765,8 +728,8 @@ int front_parts_for(fmx_handle h, CallGeom &G) {
 
 int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
                  int64_t pcm_stride, int64_t *n_frames, hipStream_t s);
-// One call of the boundary.  The RDS front end works on blocks of RDS_BLK fm samples, one block phase for the handle, and one launch sequence covers
-// at most one block: while a channel decodes RDS, a longer call is made in pieces (the chain is invariant to how a stream is cut into calls).
+// One call of the boundary.  The RDS front end works on blocks of RDS_BLK fm samples, every channel on its own block phase, and one launch sequence covers
+// at most one block boundary per channel: while a channel decodes RDS, a longer call is made in pieces (the chain is invariant to how a stream is cut into calls).
 int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
              int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
     const int64_t PIECE = (int64_t)(RDS_BLK - 1) * h->decim;       // (J1 - J0 <= RDS_BLK whatever the call's phase in the fm-rate grid; decim: input samples per
@@ -808,7 +771,7 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     G.iq_format = fmt; G.iq_scale = (fmt == 3) ? 1.0f / s16_den : 1.0f / 128.0f; G.n_cus = h->n_cus;
     const int64_t frames = conv2_out(h, G.M1) - conv2_out(h, G.M0);
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
-    if (h->rds_alloc && h->rds_start >= 0 && G.J1 - G.J0 > RDS_BLK)
+    if (h->rds_alloc && any_rds_on(h) && G.J1 - G.J0 > RDS_BLK)
         return fail(FMX_E_TOO_LARGE, "with RDS on, a call may cover at most 32000 fm samples (384000 input samples)");
     ProfRec pr{}; const bool prof = h->prof_on;
     if (prof) {
@@ -860,31 +823,22 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
     G.stageb_form = h->stageb_form.load(); G.no_deemph = h->ola_mode ? 1 : 0;
     launch_demod_fused(h->T, h->B, G, h->channels, s);      // (with its pre-pass for the PLL / AM decoders and the squelches)
-    if (h->rds_alloc && h->rds_start >= 0) {
-        bool any_rds = false;
-        for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
-        if (any_rds) {
-            if (!h->rds_fresh.empty()) {
-                std::lock_guard<std::mutex> lk(h->mtx);
-                RdsState s0; std::memset(&s0, 0, sizeof(s0));
-                s0.gain = 9.0f; s0.mu = 0.f; s0.skip = 3; s0.sample_count = 0;
-                s0.c_limit = (float)(2 * design::kPi * (double)10.0f / (double)(float)24000);
-                for (int32_t c : h->rds_fresh) {
-                    HIPCHK(hipMemcpyAsync(h->R.state + c, &s0, sizeof(s0), hipMemcpyHostToDevice, s));
-                    HIPCHK(hipMemsetAsync(h->R.state1 + c, 0, sizeof(Rds1State), s));
-                    HIPCHK(hipMemsetAsync(h->R.state3 + c, 0, sizeof(Rds3State), s));
-                    HIPCHK(hipMemsetAsync(h->R.mfc + (size_t)c * h->R.mfc_stride, 0, 2 * sizeof(float2), s));
-                    HIPCHK(hipMemsetAsync(h->R.c_ring + (size_t)c * RDS24_RING, 0, sizeof(float) * RDS24_RING, s));
-                    HIPCHK(hipMemsetAsync(h->R.f_ring + (size_t)c * RDS24_RING, 0, sizeof(float) * RDS24_RING, s));
-                }
-                HIPCHK(hipStreamSynchronize(s));         // (s0 is on this stack; a join is a rare event)
-                h->rds_fresh.clear();
-            }
-            const int64_t n0 = G.J0 - h->rds_start;
-            int modes = 0;
-            for (auto &p : h->params) modes |= 1 << p.rds_mode;
-            launch_rds(h->B, h->R, G, h->channels, n0, modes, s);
-            h->last_m0 = n0 / 8; h->last_m1 = (n0 + (G.J1 - G.J0)) / 8;
+    if (h->rds_alloc && any_rds_on(h)) {
+        const int64_t nj = G.J1 - G.J0;
+        int modes = 0;
+        for (int c = 0; c < h->channels; c++) {
+            const int m = h->params[(size_t)c].rds_mode;
+            modes |= 1 << m;
+            h->rds_nc0[(size_t)c] = m != 0 ? h->rds_nc[(size_t)c] : -1;
+        }
+        // (pageable source: the copy is staged before the call returns, the vector is free again)
+        HIPCHK(hipMemcpyAsync(h->d_rds_nc0, h->rds_nc0.data(), sizeof(int64_t) * (size_t)h->channels, hipMemcpyHostToDevice, s));
+        launch_rds(h->B, h->R, G, h->channels, h->rds_nc0.data(), modes, s);
+        for (int c = 0; c < h->channels; c++) {
+            const int64_t a = h->rds_nc0[(size_t)c];
+            if (a < 0) continue;
+            h->last_m0[(size_t)c] = a / 8; h->last_m1[(size_t)c] = (a + nj) / 8;
+            h->rds_nc[(size_t)c] = a + nj;
         }
     }
     if (prof && prof_double) HIPCHK(hipEventRecord(pdummy, s));
@@ -1311,13 +1265,6 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     }
     std::lock_guard<std::mutex> lk(h->mtx);
     const int c0 = channel < 0 ? 0 : channel, c1 = channel < 0 ? h->channels : channel + 1;
-    if (id == FMX_P_RDS_MODE && iv != 0 && h->rds_start >= 0) {
-        // RDS already off everywhere (set since the last call, no call in between): that is "off everywhere first" -- the block phase
-        // ends now, this enable restarts the RDS path at the next call (what flush_mailbox would have done with a call in between)
-        bool any = false;
-        for (auto &p : h->params) any |= (p.rds_mode != 0);
-        if (!any) { h->rds_start = -1; h->rds_rearm = true; }
-    }
     if (id == FMX_A_RESET_RDS || id == FMX_A_TRIGGER_FREQUENCY_CHANGE) {
         if (h->rds_reset_req.size() != (size_t)h->channels) h->rds_reset_req.assign((size_t)h->channels, 0);
         for (int c = c0; c < c1; c++) h->rds_reset_req[(size_t)c] = 1;      // resetRds (:862-864); triggerFrequencyChange calls it (:852)
@@ -1531,11 +1478,12 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
     case FMX_TAP_PRE_RESAMPLER: base = (const char *)((h->ola_mode && h->d2ring ? h->d2ring : h->B.dring) + (size_t)channel * h->dring); cap = h->dring; elem = sizeof(float2); break;
     case 4: {   // FMX_TAP_RDS_IQ: complex @24 kS/s after rdsDecimator (:553): the last n outputs of the last call
         if (!h->rds_alloc) return fail(FMX_E_INVALID, "RDS is off");
-        if (n > h->last_m1 - h->last_m0) return fail(FMX_E_INVALID, "n exceeds the RDS samples produced by the last call");
+        const int64_t lm0 = h->last_m0[(size_t)channel], lm1 = h->last_m1[(size_t)channel];      // (the channel's own count: fmx_last_rds_samples_of)
+        if (n > lm1 - lm0) return fail(FMX_E_INVALID, "n exceeds the RDS samples the channel produced in the last call");
         char *o = (char *)dst;
-        for (int64_t m = h->last_m1 - n; m < h->last_m1;) {
+        for (int64_t m = lm1 - n; m < lm1;) {
             const int64_t pos = m & (RDS24_RING - 1);
-            const int64_t run = std::min<int64_t>(RDS24_RING - pos, h->last_m1 - m);
+            const int64_t run = std::min<int64_t>(RDS24_RING - pos, lm1 - m);
             HIPCHK(hipMemcpy(o, (const char *)(h->R.rds24 + (size_t)channel * RDS24_RING) + pos * sizeof(float2), (size_t)run * sizeof(float2), hipMemcpyDeviceToHost));
             o += run * sizeof(float2); m += run;
         }
@@ -1587,8 +1535,8 @@ int fmx_rds_symbols(fmx_handle h, int32_t channel, float *iq, int32_t capacity, 
     HIPCHK(hipMemcpy(&st, h->R.state + channel, sizeof(st), hipMemcpyDeviceToHost));
     int32_t &rd = h->rds_read_sym[(size_t)channel];
     if (h->rds_gen_sym.size() != (size_t)h->channels) h->rds_gen_sym.assign((size_t)h->channels, 0);
-    const int32_t gen = h->rds_gen.load() + (h->rds_gen_ch.size() == (size_t)h->channels ? h->rds_gen_ch[(size_t)channel] : 0);
-    if (h->rds_gen_sym[(size_t)channel] != gen) { h->rds_gen_sym[(size_t)channel] = gen; rd = 0; }   // the RDS path was restarted (rds_restart)
+    const int32_t gen = h->rds_gen.load();
+    if (h->rds_gen_sym[(size_t)channel] != gen) { h->rds_gen_sym[(size_t)channel] = gen; rd = 0; }   // (the generation moves with resetRds only)
     int32_t have = st.nbits - rd;
     if (have < 0) { rd = 0; have = st.nbits; }
     if (have > RDS_SYM_CAP) { rd = st.nbits - RDS_SYM_CAP; have = RDS_SYM_CAP; }        // ring overrun: oldest symbols lost
@@ -1625,7 +1573,11 @@ int64_t fmx_pll_exact_segments(fmx_handle h, int32_t channel) {
     return n;
 }
 int32_t fmx_last_front_kernel(fmx_handle h) { return h ? h->last_front_kernel : 0; }
-int64_t fmx_last_rds_samples(fmx_handle h) { return (h && h->rds_alloc) ? (int64_t)(h->last_m1 - h->last_m0) : 0; }
+int64_t fmx_last_rds_samples_of(fmx_handle h, int32_t channel) {
+    if (!h || !h->rds_alloc || channel < 0 || channel >= h->channels) return 0;
+    return h->last_m1[(size_t)channel] - h->last_m0[(size_t)channel];
+}
+int64_t fmx_last_rds_samples(fmx_handle h) { return fmx_last_rds_samples_of(h, 0); }
 
 int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {
     if (!h || channel < 0 || channel >= h->channels || !info) return fail(FMX_E_INVALID, "bad argument");
@@ -1643,8 +1595,8 @@ int fmx_rds_decode(fmx_handle h, int32_t channel, fmx_rds_info *info) {
         HIPCHK(hipMemcpy(&st, h->R.state + channel, sizeof(st), hipMemcpyDeviceToHost));
         int32_t &rd = h->rds_read_dec[(size_t)channel];
         if (h->rds_gen_dec.size() != (size_t)h->channels) h->rds_gen_dec.assign((size_t)h->channels, 0);
-        const int32_t gen = h->rds_gen.load() + (h->rds_gen_ch.size() == (size_t)h->channels ? h->rds_gen_ch[(size_t)channel] : 0);
-        if (h->rds_gen_dec[(size_t)channel] != gen) { h->rds_gen_dec[(size_t)channel] = gen; rd = 0; D.reset_all(); }   // the RDS path was restarted (rds_restart)
+        const int32_t gen = h->rds_gen.load();
+        if (h->rds_gen_dec[(size_t)channel] != gen) { h->rds_gen_dec[(size_t)channel] = gen; rd = 0; D.reset_all(); }   // (the generation moves with resetRds only)
         int32_t have = st.nbits - rd;
         if (have < 0) { rd = 0; have = st.nbits; D.reset_all(); }
         if (do_reset) {

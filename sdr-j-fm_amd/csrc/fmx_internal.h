@@ -365,9 +365,15 @@ struct RdsBuffers {
     Rds3State *state3;
     const float2 *sincos24;       // [24000] SinCos (rate) table of the bit-clock NCO (sincos.cpp:45-54)
     int32_t pitch;
+    // Every channel's RDS path counts the fm samples IT has processed (round 5): the reference's processor runs its block filters, its phase delay
+    // line and its decimator only while its decoder is on (fm-processor.cpp:733-754, :551-553), so a channel that switches on later than its
+    // neighbours -- or off and on again -- has block boundaries, a /8 phase and filter contents of its own.
+    const int64_t *nc0;           // [ch] samples the channel's path had processed in front of this call; < 0: the decoder is off in this call
+    int *chlist;                  // [ch] scratch: the channels of one block phase (launch_rds_block)
 };
 #define C_RDS_PITCH(Rb) ((Rb).pitch)
-void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, int64_t n0, int modes, hipStream_t s);   // modes: bit k = some channel runs RDS_k
+// modes: bit k = some channel runs RDS_k; h_nc0: the host's copy of RdsBuffers::nc0
+void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, const int64_t *h_nc0, int modes, hipStream_t s);
 
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s);

@@ -16,6 +16,8 @@
 // 11 inputs), the matched filter is time-parallel, and only AGC / M&M / Costas run as a lane-per-channel recurrence.
 #include "fmx_internal.h"
 #include "fmx_fftconv.h"
+#include <algorithm>
+#include <vector>
 
 namespace fmx {
 
@@ -211,20 +213,16 @@ __global__ void rds_save_tail(const float2 *__restrict__ U, float2 *__restrict__
 }
 
 // ---- append this call's demod samples to the block being filled and the pilot phases to the delay ring
-__global__ void rds_collect(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, int64_t row0, int nrows, int64_t n0 /* rds index of row0 */) {
+__global__ void rds_collect(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, int64_t row0, int nrows) {
     const int ch = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nrows) return;
-    const int64_t r = row0 + q, n = n0 + q;
-    // A channel whose RDS decoder is off takes ZEROS into the block filters and the phase delay (round 4): the filters of the batch run on
-    // one block phase, so a channel that switches its decoder on in a later call than the others cannot start machines of its own -- but a
-    // linear filter that has been fed zeros IS one that starts from cleared buffers (fftFilter's constructor, fft-filters.cpp:33-52), and the
-    // delayed pilot phase of the first 64000 samples is the cleared rdsPhaseBuffer's 0 (fm-processor.cpp:744).
-    const bool on = B.params[ch].rds_mode != 0;
-    const float demod = on ? B.w_dem[tap_idx(B, r, ch, G.pitch)] : 0.f;
-    const float cur = on ? B.w_cur[tap_idx(B, r, ch, G.pitch)] : 0.f;   // unconstrained pilot phase; PI_Constrain gives currentPilotPhase
-    // Channels 2p and 2p + 1 ride through the block transforms as the real and imaginary part of one row: a non-finite sample of one
-    // (the raw IQ formats cannot carry one, float32 input can) would turn the whole pair's spectrum into NaN and leave the
+    const int64_t nc0 = Rb.nc0[ch];
+    if (q >= nrows || nc0 < 0) return;              // (a channel whose decoder is off: its filters, its phase delay line and its decimator stand still, as the reference's do)
+    const int64_t r = row0 + q, n = nc0 + r;        // the channel's own sample count
+    const float demod = B.w_dem[tap_idx(B, r, ch, G.pitch)];
+    const float cur = B.w_cur[tap_idx(B, r, ch, G.pitch)];   // unconstrained pilot phase; PI_Constrain gives currentPilotPhase
+    // Channels of one block phase ride through the block transforms in pairs, as the real and imaginary part of one row: a non-finite sample of
+    // one (the raw IQ formats cannot carry one, float32 input can) would turn the whole pair's spectrum into NaN and leave the
     // neighbour's slicer state NaN for good.  It enters the block as zero instead.
     Rb.in_blk[(size_t)ch * RBLK + (int)(n % RBLK)] = (fabsf(demod) < __builtin_inff()) ? demod : 0.f;
     float c = (fabsf(cur) < __builtin_inff()) ? cur : 0.f;
@@ -241,10 +239,16 @@ __global__ void rds_collect(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, i
 //      read them from there.  The same operations on the same values in the same order.
 constexpr int MD_OUT = 256, MD_IN = 8 * MD_OUT + 10;
 __device__ __forceinline__ int md_pos(int j) { return j + (j >> 3); }         // one entry of padding per eight: the outputs' reads, 64 bytes apart, spread over the banks
-__global__ __launch_bounds__(MD_OUT) void rds_mix_decim(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, int64_t m0, int nout) {
+__global__ __launch_bounds__(MD_OUT) void rds_mix_decim(DeviceBuffers B, RdsBuffers Rb, CallGeom G, int C, int64_t row0, int nrows) {
     __shared__ float2 sx[MD_IN + MD_IN / 8 + 2];
-    const int ch = blockIdx.y;                               // (every channel: one that is off mixes zeros, see rds_collect)
+    const int ch = blockIdx.y;
     const int tid = threadIdx.x;
+    const int64_t nc0 = Rb.nc0[ch];
+    if (nc0 < 0) return;
+    // the channel's outputs whose newest input 8 m + 7 lies in rows [row0, row0 + nrows) of the call (its own count: nc0 + row)
+    const int64_t m0 = (nc0 + row0) / 8;
+    const int nout = (int)((nc0 + row0 + nrows) / 8 - m0);
+    if ((int64_t)blockIdx.x * MD_OUT >= nout) return;
     const int64_t mb = m0 + (int64_t)blockIdx.x * MD_OUT;    // the workgroup's first output
     const int64_t n_lo = 8 * mb + 7 - 10;                    // ... and the oldest input it reads (negative in front of the stream's start)
     // block and position of that input (one 64-bit division per thread; the others follow by counting up, across at most one block boundary)
@@ -290,9 +294,12 @@ __global__ __launch_bounds__(MD_OUT) void rds_mix_decim(DeviceBuffers B, RdsBuff
 
 // ---- RRC matched filter (rds-decoder-2.cpp:83-98), time-parallel; output channel-major: mfc[ch][2 + q] (entries 0, 1 are the last
 //      two AGC outputs of the previous call, put there by rds_agc)
-__global__ void rds_matched(DeviceBuffers B, RdsBuffers Rb, int64_t m0, int nout) {
+__global__ void rds_matched(DeviceBuffers B, RdsBuffers Rb, int nj) {
     const int ch = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
+    const int64_t nc0 = Rb.nc0[ch];
+    if (nc0 < 0) return;
+    const int64_t m0 = nc0 / 8; const int nout = (int)((nc0 + nj) / 8 - m0);          // the channel's own 24 kS/s outputs of this call
     if (q >= nout || B.params[ch].rds_mode != 2) return;
     const int64_t m = m0 + q;
     float2 acc = make_float2(0.f, 0.f);
@@ -317,7 +324,7 @@ __global__ void rds_matched(DeviceBuffers B, RdsBuffers Rb, int64_t m0, int nout
 //   rds_symbols  lane per channel over the SYMBOLS: the sample a symbol falls on follows from the skip count in closed form
 //                (`++sampleCount >= skipNrSamples`), so a lane jumps from symbol to symbol and every lane is in the branch together.
 constexpr int AGC_T = 256, AGC_K = 10;                         // threads per channel, samples per thread (2400 outputs per 0.1 s call)
-__global__ __launch_bounds__(AGC_T) void rds_agc(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
+__global__ __launch_bounds__(AGC_T) void rds_agc(DeviceBuffers B, RdsBuffers Rb, int C, int nj) {
     // AGC (2e-3, 0.38, start 9), agc.h:14-18: out = in * gain; gain += rate * (ref - |out|).  |out| = |in * gain| is taken as gain * |in|
     // with |in| from rds_matched (the same value to an ulp), which makes the gain an AFFINE recurrence, gain' = gain (1 - rate |in|) +
     // rate ref: one workgroup per channel, every thread composes the maps of its AGC_K adjacent samples in f64, a scan over the
@@ -326,6 +333,10 @@ __global__ __launch_bounds__(AGC_T) void rds_agc(DeviceBuffers B, RdsBuffers Rb,
     // 0.16-0.2 ms per call at 2048 channels, all of it address translation and load latency.)
     const int ch = blockIdx.x;
     if (ch >= C || B.params[ch].rds_mode != 2) return;
+    const int64_t nc0 = Rb.nc0[ch];
+    if (nc0 < 0) return;
+    const int64_t m0 = nc0 / 8; const int nout = (int)((nc0 + nj) / 8 - m0);          // the channel's own 24 kS/s outputs of this call
+    (void)m0;
     __shared__ double sA[4], sB[4];
     __shared__ float2 sLast[3];
     __shared__ float sGain;                                        // the gain behind a round of AGC_T * AGC_K samples
@@ -388,9 +399,13 @@ __global__ __launch_bounds__(AGC_T) void rds_agc(DeviceBuffers B, RdsBuffers Rb,
 
 // ---- Mueller & Mueller timing -> Costas -> slicer -> differential decode, one step per symbol   [lane per channel]
 //      rds-decoder-2.cpp:120-157, costas.h:21-33
-__global__ __launch_bounds__(64) void rds_symbols(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
+__global__ __launch_bounds__(64) void rds_symbols(DeviceBuffers B, RdsBuffers Rb, int C, int nj) {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= C || B.params[ch].rds_mode != 2) return;
+    const int64_t nc0 = Rb.nc0[ch];
+    if (nc0 < 0) return;
+    const int64_t m0 = nc0 / 8; const int nout = (int)((nc0 + nj) / 8 - m0);          // the channel's own 24 kS/s outputs of this call
+    (void)m0;
     RdsState st = Rb.state[ch];
     const float sps = 24000.0f / 1187.5f;                   // samplesPerSymbol = rate / (float)RDS_BITCLK_HZ
     const float mm_alpha = (float)0.01;
@@ -454,9 +469,13 @@ __device__ __forceinline__ float pi_constrain_generic(float ph) {               
     if (pv > -6.283185307179586) return (float)(pv + 6.283185307179586);
     return (float)(6.283185307179586 - fmod(-pv, 6.283185307179586));
 }
-__global__ __launch_bounds__(64) void rds1_costas(DeviceBuffers B, RdsBuffers Rb, int C, int64_t m0, int nout) {
+__global__ __launch_bounds__(64) void rds1_costas(DeviceBuffers B, RdsBuffers Rb, int C, int nj) {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= C || B.params[ch].rds_mode != 1) return;
+    const int64_t nc0 = Rb.nc0[ch];
+    if (nc0 < 0) return;
+    const int64_t m0 = nc0 / 8; const int nout = (int)((nc0 + nj) / 8 - m0);          // the channel's own 24 kS/s outputs of this call
+
     Rds1State *st = Rb.state1 + ch;
     float freq = st->c_freq, phase = st->c_phase;
     const float alpha = 1.0f / 16.0f, beta = 0.02f / 16.0f, lim = (float)(2 * 3.14159265358979323846 * (double)10.0f / (double)(float)24000);
@@ -478,9 +497,12 @@ __global__ __launch_bounds__(64) void rds1_costas(DeviceBuffers B, RdsBuffers Rb
 // out[m] = sum_i ring_in[m - i] * taps[i], i ascending from a zero accumulator (Basic_FIR::Pass fir-filters.h:96-108, Match :108-121)
 template <int NT>
 __global__ __launch_bounds__(256) void rds1_fir(DeviceBuffers B, const float *__restrict__ rin, float *__restrict__ rout,
-                                                const float *__restrict__ taps, int64_t m0, int nout, int to_mf, RdsBuffers Rb) {
+                                                const float *__restrict__ taps, int nj, int to_mf, RdsBuffers Rb) {
     const int ch = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
+    const int64_t nc0 = Rb.nc0[ch];
+    if (nc0 < 0) return;
+    const int64_t m0 = nc0 / 8; const int nout = (int)((nc0 + nj) / 8 - m0);          // the channel's own 24 kS/s outputs of this call
     if (q >= nout || B.params[ch].rds_mode != 1) return;
     const int64_t m = m0 + q;
     const float *in = rin + (size_t)ch * RDS24_RING;
@@ -494,9 +516,13 @@ __global__ __launch_bounds__(256) void rds1_fir(DeviceBuffers B, const float *__
     if (to_mf) Rb.mf[(size_t)q * C_RDS_PITCH(Rb) + ch] = make_float2(tmp, 0.f);   // sample-major for the lane-per-channel slicer
     else rout[(size_t)ch * RDS24_RING + (int)(m & (RDS24_RING - 1))] = tmp;
 }
-__global__ __launch_bounds__(64) void rds1_slicer(DeviceBuffers B, RdsBuffers Rb, int C, int nout) {
+__global__ __launch_bounds__(64) void rds1_slicer(DeviceBuffers B, RdsBuffers Rb, int C, int nj) {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= C || B.params[ch].rds_mode != 1) return;
+    const int64_t nc0 = Rb.nc0[ch];
+    if (nc0 < 0) return;
+    const int64_t m0 = nc0 / 8; const int nout = (int)((nc0 + nj) / 8 - m0);          // the channel's own 24 kS/s outputs of this call
+    (void)m0;
     Rds1State st = Rb.state1[ch];
     RdsState s2 = Rb.state[ch];                          // the bit ring's write counter is shared with the RDS_2 slicer
     const int pitch = C_RDS_PITCH(Rb);
@@ -581,9 +607,13 @@ __device__ __forceinline__ float sin24(const float2 *__restrict__ tab, float pha
     if (phase < 0) return -tab[((int)((double)(-phase) * C)) % 24000].y;
     return tab[((int)((double)phase * C)) % 24000].y;
 }
-__global__ __launch_bounds__(64) void rds3_slicer(DeviceBuffers B, RdsBuffers Rb, int C, int64_t m0, int nout) {
+__global__ __launch_bounds__(64) void rds3_slicer(DeviceBuffers B, RdsBuffers Rb, int C, int nj) {
     const int ch = blockIdx.x * 64 + threadIdx.x;
     if (ch >= C || B.params[ch].rds_mode != 3) return;
+    const int64_t nc0 = Rb.nc0[ch];
+    if (nc0 < 0) return;
+    const int64_t m0 = nc0 / 8; const int nout = (int)((nc0 + nj) / 8 - m0);          // the channel's own 24 kS/s outputs of this call
+
     Rds3State st = Rb.state3[ch];
     RdsState s2 = Rb.state[ch];
     if (!st.started) { st.started = 1; st.resync_pending = 1; }          // Resync = true (rds-decoder-3.cpp:81)
@@ -690,14 +720,15 @@ __global__ void rds_hil_split(const float2 *__restrict__ Z, const float2 *__rest
     if (b < C) { v = cmulf(xb, sk); U[(size_t)b * RN + k] = make_float2(v.x, -v.y); }
 }
 
-// one block boundary: BP filter of the demod block just completed (block index blk), Hilbert of the previous BP result
-void launch_rds_block(const RdsBuffers &Rb, int C, int64_t blk, hipStream_t s) {
-    const dim3 g(RN / 256, C);
+// one block boundary of the channels h_list[0 .. nlist) (one block phase and parity): BP filter of the demod block just completed (block index blk
+// of their own count), Hilbert of the previous BP result.  Every channel of the handle at once: pairs of channels per transform; a subset (channels
+// that joined at different times): one channel per transform, by list.  Both forms keep their overlap tails by block parity.
+void launch_rds_block(const RdsBuffers &Rb, int C, int64_t blk, const int *h_list, int nlist, hipStream_t s) {
     static const bool pair = !(getenv("FMX_RDS_PAIR") && atoi(getenv("FMX_RDS_PAIR")) == 0);
-    if (pair && C >= 2) {
+    const size_t ov = (size_t)C * RDEG;                           // one parity of an overlap buffer
+    if (pair && C >= 2 && nlist == C) {
         const int P = (C + 1) / 2;
         const dim3 gp(RN / 256, P);
-        const size_t ov = (size_t)C * RDEG;                       // one parity of an overlap buffer
         // Hilbert of the previous band-pass result: pairs forward straight from the real blocks (rows of V, U as scratch), apart into U,
         // backward per channel with the finishing pass in the transform
         fft_rows<0>(Rb.V, Rb.U, P, RdsEpi{}, s, Rb.bpreal + (size_t)((blk + 1) & 1) * RBLK, (size_t)2 * RBLK, C);
@@ -719,58 +750,76 @@ void launch_rds_block(const RdsBuffers &Rb, int C, int64_t blk, hipStream_t s) {
         }
         return;
     }
+    const int *chl = nullptr;
+    if (nlist != C) {
+        // (pageable source: the copy is staged before the call returns)
+        note_hip(hipMemcpyAsync(Rb.chlist, h_list, sizeof(int) * (size_t)nlist, hipMemcpyHostToDevice, s));
+        chl = Rb.chlist;
+    }
+    const dim3 g(RN / 256, nlist);
     // Hilbert first: its input is bpreal[(blk-1)&1] (zeros when blk == 0), output hil[blk & 1]
-    hipLaunchKernelGGL(rds_load_real, g, dim3(256), 0, s, Rb.bpreal + (size_t)((blk + 1) & 1) * RBLK, (size_t)2 * RBLK, Rb.U, nullptr);
-    fft_fwd(Rb, C, nullptr, s);
-    hipLaunchKernelGGL(rds_spectrum, g, dim3(256), 0, s, Rb.U, Rb.S_hil, 1.0f, nullptr);
-    fft_fwd(Rb, C, nullptr, s);
-    hipLaunchKernelGGL(rds_finish, g, dim3(256), 0, s, Rb.U, Rb.hil_over, (float *)nullptr, Rb.hil + (size_t)(blk & 1) * RBLK, (size_t)2 * RBLK, nullptr);
-    hipLaunchKernelGGL(rds_save_tail, dim3(3, C), dim3(256), 0, s, Rb.U, Rb.hil_over, nullptr);
+    hipLaunchKernelGGL(rds_load_real, g, dim3(256), 0, s, Rb.bpreal + (size_t)((blk + 1) & 1) * RBLK, (size_t)2 * RBLK, Rb.U, chl);
+    fft_fwd(Rb, nlist, chl, s);
+    hipLaunchKernelGGL(rds_spectrum, g, dim3(256), 0, s, Rb.U, Rb.S_hil, 1.0f, chl);
+    fft_fwd(Rb, nlist, chl, s);
+    hipLaunchKernelGGL(rds_finish, g, dim3(256), 0, s, Rb.U, Rb.hil_over + (size_t)((blk + 1) & 1) * ov, (float *)nullptr, Rb.hil + (size_t)(blk & 1) * RBLK, (size_t)2 * RBLK, chl);
+    hipLaunchKernelGGL(rds_save_tail, dim3(3, nlist), dim3(256), 0, s, Rb.U, Rb.hil_over + (size_t)(blk & 1) * ov, chl);
     // band-pass: input in_blk, output bpreal[blk & 1]
-    hipLaunchKernelGGL(rds_load_real, g, dim3(256), 0, s, Rb.in_blk, (size_t)RBLK, Rb.U, nullptr);
-    fft_fwd(Rb, C, nullptr, s);
-    hipLaunchKernelGGL(rds_spectrum, g, dim3(256), 0, s, Rb.U, Rb.S_bp, 3.0f, nullptr);
-    fft_fwd(Rb, C, nullptr, s);
-    hipLaunchKernelGGL(rds_finish, g, dim3(256), 0, s, Rb.U, Rb.bp_over, Rb.bpreal + (size_t)(blk & 1) * RBLK, (float2 *)nullptr, (size_t)2 * RBLK, nullptr);
-    hipLaunchKernelGGL(rds_save_tail, dim3(3, C), dim3(256), 0, s, Rb.U, Rb.bp_over, nullptr);
+    hipLaunchKernelGGL(rds_load_real, g, dim3(256), 0, s, Rb.in_blk, (size_t)RBLK, Rb.U, chl);
+    fft_fwd(Rb, nlist, chl, s);
+    hipLaunchKernelGGL(rds_spectrum, g, dim3(256), 0, s, Rb.U, Rb.S_bp, 3.0f, chl);
+    fft_fwd(Rb, nlist, chl, s);
+    hipLaunchKernelGGL(rds_finish, g, dim3(256), 0, s, Rb.U, Rb.bp_over + (size_t)((blk + 1) & 1) * ov, Rb.bpreal + (size_t)(blk & 1) * RBLK, (float2 *)nullptr, (size_t)2 * RBLK, chl);
+    hipLaunchKernelGGL(rds_save_tail, dim3(3, nlist), dim3(256), 0, s, Rb.U, Rb.bp_over + (size_t)(blk & 1) * ov, chl);
 }
 
-// the RDS work of one call: rows [0, nj) of the work arrays are rds samples [n0, n0 + nj)
-void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, int64_t n0, int modes, hipStream_t s) {
+// the RDS work of one call: rows [0, nj) of the work arrays; channel c's path has processed h_nc0[c] samples before (< 0: its decoder is off)
+void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G, int C, const int64_t *h_nc0, int modes, hipStream_t s) {
     const int64_t nj = G.J1 - G.J0;
     if (nj <= 0) return;
-    int64_t row = 0;
-    while (row < nj) {
-        const int64_t n = n0 + row;
-        const int64_t blk = n / RBLK;
-        const int64_t to_end = (blk + 1) * RBLK - n;              // samples until this block completes
-        const int64_t take = to_end < (nj - row) ? to_end : (nj - row);
-        hipLaunchKernelGGL(rds_collect, dim3((unsigned)((take + 255) / 256), C), dim3(256), 0, s, B, Rb, G, C, row, (int)take, n);
-        // the 24 kS/s outputs whose newest input 8m+7 lies in this segment: mixed BEFORE the block transform below
-        // replaces the Hilbert result of two blocks ago, which the 10-sample look-back may still need
-        const int64_t ma = n / 8, mb = (n + take) / 8;
-        if (mb > ma)
-            hipLaunchKernelGGL(rds_mix_decim, dim3((unsigned)((mb - ma + 255) / 256), C), dim3(256), 0, s, B, Rb, G, C, ma, (int)(mb - ma));
-        row += take;
-        if (take == to_end) launch_rds_block(Rb, C, blk, s);      // block `blk` is complete
+    // the block boundaries that fall into this call (a call holds at most one per channel: fmx_api.hip makes longer ones in pieces): the
+    // channels of one boundary row and block parity are one launch of the block filters
+    struct Cls { int64_t e; int64_t blk; std::vector<int> ch; };
+    std::vector<Cls> cls;
+    for (int c = 0; c < C; c++) {
+        if (h_nc0[c] < 0) continue;
+        const int64_t e = RBLK - (h_nc0[c] % RBLK);              // rows until the channel's block is complete (1 .. RBLK)
+        if (e > nj) continue;
+        const int64_t blk = (h_nc0[c] + e) / RBLK - 1;
+        size_t k = 0;
+        for (; k < cls.size(); k++) if (cls[k].e == e && ((cls[k].blk ^ blk) & 1) == 0) break;
+        if (k == cls.size()) cls.push_back(Cls{e, blk, {}});
+        cls[k].ch.push_back(c);
     }
-    const int64_t mfirst = n0 / 8;                 // smallest m with 8m+7 >= n0
-    const int64_t mend = (n0 + nj) / 8;            // one past the largest m with 8m+7 < n0+nj
-    const int nout = (int)(mend - mfirst);
-    if (nout <= 0) return;
+    std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.e < b.e; });
+    int64_t row = 0;
+    size_t k = 0;
+    while (row < nj) {
+        const int64_t end = k < cls.size() ? cls[k].e : nj;
+        const int64_t take = end - row;
+        if (take > 0) {
+            hipLaunchKernelGGL(rds_collect, dim3((unsigned)((take + 255) / 256), C), dim3(256), 0, s, B, Rb, G, C, row, (int)take);
+            // the 24 kS/s outputs whose newest input 8m+7 lies in this stretch: mixed BEFORE the block transform below
+            // replaces the Hilbert result of two blocks ago, which the 10-sample look-back may still need
+            hipLaunchKernelGGL(rds_mix_decim, dim3((unsigned)((take / 8 + 1 + MD_OUT - 1) / MD_OUT), C), dim3(MD_OUT), 0, s, B, Rb, G, C, row, (int)take);
+        }
+        row = end;
+        for (; k < cls.size() && cls[k].e == end; k++) launch_rds_block(Rb, C, cls[k].blk, cls[k].ch.data(), (int)cls[k].ch.size(), s);
+    }
+    const int nmax = (int)(nj / 8 + 1);            // most outputs any channel has in this call
     if (modes & (1 << 2)) {
-        hipLaunchKernelGGL(rds_matched, dim3((unsigned)((nout + 255) / 256), C), dim3(256), 0, s, B, Rb, mfirst, nout);
-        hipLaunchKernelGGL(rds_agc, dim3((unsigned)C), dim3(AGC_T), 0, s, B, Rb, C, nout);
-        hipLaunchKernelGGL(rds_symbols, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
+        hipLaunchKernelGGL(rds_matched, dim3((unsigned)((nmax + 255) / 256), C), dim3(256), 0, s, B, Rb, (int)nj);
+        hipLaunchKernelGGL(rds_agc, dim3((unsigned)C), dim3(AGC_T), 0, s, B, Rb, C, (int)nj);
+        hipLaunchKernelGGL(rds_symbols, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, (int)nj);
     }
     if (modes & (1 << 1)) {          // (the mf rows of an RDS_1 channel are its own: the two slicers never share a channel)
-        const dim3 gt((unsigned)((nout + 255) / 256), C);
-        hipLaunchKernelGGL(rds1_costas, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, mfirst, nout);
-        hipLaunchKernelGGL(rds1_fir<RDS1_FIR>, gt, dim3(256), 0, s, B, Rb.c_ring, Rb.f_ring, Rb.rds1_coef, mfirst, nout, 0, Rb);
-        hipLaunchKernelGGL(rds1_fir<RDS1_MATCH>, gt, dim3(256), 0, s, B, Rb.f_ring, (float *)nullptr, Rb.rds1_coef + RDS1_FIR, mfirst, nout, 1, Rb);
-        hipLaunchKernelGGL(rds1_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, nout);
+        const dim3 gt((unsigned)((nmax + 255) / 256), C);
+        hipLaunchKernelGGL(rds1_costas, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, (int)nj);
+        hipLaunchKernelGGL(rds1_fir<RDS1_FIR>, gt, dim3(256), 0, s, B, Rb.c_ring, Rb.f_ring, Rb.rds1_coef, (int)nj, 0, Rb);
+        hipLaunchKernelGGL(rds1_fir<RDS1_MATCH>, gt, dim3(256), 0, s, B, Rb.f_ring, (float *)nullptr, Rb.rds1_coef + RDS1_FIR, (int)nj, 1, Rb);
+        hipLaunchKernelGGL(rds1_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, (int)nj);
     }
-    if (modes & (1 << 3)) hipLaunchKernelGGL(rds3_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, mfirst, nout);
+    if (modes & (1 << 3)) hipLaunchKernelGGL(rds3_slicer, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, B, Rb, C, (int)nj);
 }
 
 }  // namespace fmx

@@ -36,7 +36,7 @@ EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
     "fmx_get_meta", "fmx_get_tap", "fmx_get_peaks",
-    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_pll_exact_segments", "fmx_last_front_kernel", "fmx_last_rds_samples", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
+    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_pll_exact_segments", "fmx_last_front_kernel", "fmx_last_rds_samples", "fmx_last_rds_samples_of", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
 
@@ -150,6 +150,8 @@ def load_library(path=None):
     L.fmx_pll_exact_segments.argtypes = [vp, C.c_int32]
     L.fmx_last_rds_samples.restype = C.c_int64
     L.fmx_last_rds_samples.argtypes = [vp]
+    L.fmx_last_rds_samples_of.restype = C.c_int64
+    L.fmx_last_rds_samples_of.argtypes = [vp, C.c_int32]
     L.fmx_get_taps.restype = C.c_int
     L.fmx_get_taps.argtypes = [vp, i32, i32, f32p, i32, C.POINTER(i32)]
     L.fmx_profile_enable.restype = C.c_int
@@ -292,9 +294,9 @@ class Fmx:
         """Which kernel ran the input-filter stage of the last call (fmx_last_front_kernel: FMX_P_FRONT_KERNEL's numbering)."""
         return int(self.L.fmx_last_front_kernel(self.h))
 
-    def last_rds_samples(self):
-        """24 kS/s RDS samples the last call produced (fmx_last_rds_samples): the n that tap(TAP_RDS_IQ, n) accepts."""
-        return int(self.L.fmx_last_rds_samples(self.h))
+    def last_rds_samples(self, channel=0):
+        """24 kS/s RDS samples the last call produced on `channel` (fmx_last_rds_samples_of): the n that tap(TAP_RDS_IQ, n, channel) accepts."""
+        return int(self.L.fmx_last_rds_samples_of(self.h, channel))
 
     def pll_replays(self, channel=-1):
         """Segments of the pilot PLL that were replayed sequentially (fmx_pll_replays)."""

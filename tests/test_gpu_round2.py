@@ -94,43 +94,52 @@ def test_pending_action_survives_introspection_and_tiny_calls(fmx_amd, ol):
     assert np.abs(pa - pb).max() <= 2e-7
 
 
-def test_rds_off_everywhere_then_on_again(fmx_amd, ol):
-    """When every channel switches RDS off, the shared block phase of the RDS front end ends; switching it on again later
-    (any decoder) starts from fresh filters and slicer states instead of decoding stale blocks across the gap."""
-    block = 16384 * 20
-    n = int(2.2 * 2304000) // block * block
+def test_rds_off_and_on_again_keeps_what_the_reference_keeps(fmx_amd, ol):
+    """setfmRdsSelector (RDS_OFF) and back (fm-processor.cpp:840-847): the reference's processor does not touch its RDS path while the decoder is off
+    (:733-754, :551-553) -- block filters, phase delay line, decimator and slicer keep what they hold and go on from there, in the middle of a
+    block and on whatever /8 phase they stopped at.  Two channels on one stream against two oracle chains taking the same switches: one goes off for
+    one call and comes back with another decoder, then both go off for three calls (a gap that is no multiple of a block) and
+    come back: the 24 kS/s baseband agrees throughout, the bit streams are the oracle's, and the programme decodes again.  (Rounds 2-4 restarted
+    the whole path from cleared buffers when every channel had been off: tidier, and not what the reference does.)"""
+    block = 16384 * 15                              # (the oracle applies a switch at its next 16384-sample block: 20480 fm samples per call; the gaps shift the block phase)
     p = dict(pi=0xD3A1, pty=10, ps="FMX-AMD ", text="HIP KERNELS ON MI355X - RDS OK")
-    iq = ol.synth_iq(2 * n, rds=1, rdsLevel=0.05, rds_payload=ol.rds_programme_bits(**p))
+    calls = 40
+    iq = ol.synth_iq(block * calls, rds=1, rdsLevel=0.05, rds_payload=ol.rds_programme_bits(**p))
     f = fmx_amd.Fmx(2, streams=1, stream_of_channel=[0, 0], max_block=block)
     gui_defaults(f)
-    f.set_param(M.P_RDS_MODE, 2)
-    for i in range(0, block * 4, block):
-        f.process_host(iq[i:i + block])
-    # one channel off while the other goes on decoding, and on again in the middle of a block (round 4: a channel that is off feeds
-    # zeros to the batch's block filters, tests/test_gpu_round4.py::test_rds_decoders_switched_on_channel_by_channel; refused before)
-    f.set_param(M.P_RDS_MODE, 0, 1); f.process_host(iq[4 * block:5 * block]); f.set_param(M.P_RDS_MODE, 1, 1)
-    f.set_param(M.P_RDS_MODE, 0)                    # RDS off everywhere
-    for i in range(5 * block, 8 * block, block):
-        f.process_host(iq[i:i + block])
-    f.set_param(M.P_RDS_MODE, 2, 0); f.set_param(M.P_RDS_MODE, 1, 1)      # any decoder may start again
-    k0 = 8 * block
-    for i in range(k0, k0 + n, block):
-        f.process_host(iq[i:i + block])
+    chains = [ol.OracleChain(inputFilterBw=165000, rdsMode=0, taps=[ol.TAP_RDS_IQ], tap_seconds=4.0) for _ in range(2)]
+    mode = {}
+    def sw(c, m):
+        f.set_param(M.P_RDS_MODE, m, c); chains[c].configure(rdsMode=m); mode[c] = m
+    sw(0, 2); sw(1, 2)
+    taps_g = [[], []]
+    for k in range(calls):
+        if k == 4: sw(1, 0)
+        if k == 5: sw(1, 1)                         # back with the other decoder, its own (fresh) state, the same filters
+        if k == 8: sw(0, 0); sw(1, 0)               # off everywhere
+        if k == 11: sw(0, 2); sw(1, 1)
+        x = iq[k * block:(k + 1) * block]
+        pg = f.process_host(x[None])
+        for c in range(2):
+            po = chains[c].process(x)
+            assert float(np.sqrt(np.mean((pg[c].astype(np.float64) - po) ** 2))) <= 1e-5
+            if mode[c]: taps_g[c].append(f.tap(M.TAP_RDS_IQ, f.last_rds_samples(c), c))
+            else: assert f.last_rds_samples(c) == 0 or k > 0      # (the count of the channel's last call with its decoder on stays readable)
     for c in range(2):
+        g = np.concatenate(taps_g[c]); o = chains[c].tap(ol.TAP_RDS_IQ)
+        assert len(g) == len(o), (c, len(g), len(o))
+        sig = float(np.sqrt(np.mean(o[len(o) // 2:].astype(np.float64) ** 2)))
+        e = float(np.sqrt(np.mean((g.astype(np.float64) - o) ** 2)))
+        b_g, b_o = f.rds_bits(c, 16384), chains[c].rds_bits()
+        m = min(len(b_g), len(b_o))
+        where = np.nonzero(b_g[-m:] != b_o[-m:])[0]
+        print("\n[RDS off and on, channel %d] baseband rms err %.2e (signal %.2e); bits %d / %d, %d differ behind the pull-in" % (c, e, sig, len(b_g), len(b_o), int(np.count_nonzero(where >= 460))))
+        assert sig > 1e-3 and e <= 1e-4 * sig
+        # (the first ~460 bits are decided on the filters' numerical dust and on the slicer's pull-in, as in
+        # tests/test_gpu_round4.py::test_rds_decoders_switched_on_channel_by_channel)
+        assert len(b_g) == len(b_o) and np.count_nonzero(where >= 460) <= 2
         info = f.rds_decode(c)
         assert info.synchronized == 1 and info.pi_code == p["pi"] and info.station_label.decode() == p["ps"], c
-        assert info.crc_errors <= 2
-    # off everywhere and on again with NO call in between (a paused device, a programmatic reconfiguration): the same restart, no
-    # error; a consumer that polls only at the very end still gets a fresh synchroniser / decoder picture (ADVICE r2)
-    g_before = [f.rds_decode(c).groups_decoded for c in range(2)]
-    f.set_param(M.P_RDS_MODE, 0)
-    f.set_param(M.P_RDS_MODE, 2)
-    for i in range(0, n, block):
-        f.process_host(iq[i:i + block])
-    for c in range(2):
-        info = f.rds_decode(c)
-        assert info.synchronized == 1 and info.pi_code == p["pi"] and info.station_label.decode() == p["ps"], c
-        assert 8 <= info.groups_decoded < g_before[c] + 8 and info.crc_errors <= 2      # counted from the restart, not on top of the old run
 
 
 def test_meta_snapshot_is_taken_at_the_reference_sample(fmx_amd, ol):

@@ -100,15 +100,13 @@ def test_long_calls_with_rds_on_are_made_in_pieces(fmx_amd, ol):
 
 
 def test_rds_decoders_switched_on_channel_by_channel(fmx_amd, ol):
-    """setfmRdsSelector per processor and at any time (fm-processor.cpp:840-847; VERDICT r3 missing #4): three channels on one stream,
-    channel 0 decodes RDS from the start, channel 1 switches its decoder on 0.3 s later, channel 2 at 0.5 s, and channel 0 goes off at 0.6 s
-    while the others go on -- each against an oracle chain that takes the same calls and the same switch.  The late channels' block
-    filters have been running on zeros (the batch has one block phase), which is what the reference's filters start from: PCM within the
-    tolerance and the bit streams equal once the slicer has pulled in.  The 24 kS/s baseband of a late channel agrees with its oracle to
-    1.3e-3 of the sub-carrier (channel 0: 3e-5): the reference's Hilbert filter is a frequency-domain mask (fft-filters.cpp:166-190) whose
-    impulse response wraps around the 32768-point block, so its output depends on where the block boundaries fall -- a late channel of the
-    batch takes the batch's boundaries, a late processor of the reference its own.  (The calls start a multiple of 8 fm samples after the
-    first enable, so the late channels' /8 decimators sit on the reference's phase.)"""
+    """setfmRdsSelector per processor and at any time (fm-processor.cpp:840-847; VERDICT r3 missing #4, r4 missing #2): three channels on one
+    stream, channel 0 decodes RDS from the start, channel 1 switches its decoder on 0.3 s later, channel 2 at 0.5 s, and channel 0 goes off at
+    0.6 s while the others go on -- each against an oracle chain that takes the same calls and the same switch.  Round 5: a channel's RDS path
+    counts its OWN samples -- block boundaries, the phase delay line and the /8 phase are the processor's own in the reference, where all of it
+    runs only while the decoder is on (:733-754, :551-553) -- so the late channels' 24 kS/s baseband agrees with their oracles as channel 0's
+    does (3e-5 of the sub-carrier; 1.3e-3 while the batch had one block phase: the Hilbert filter is a frequency-domain mask whose impulse
+    response wraps around the block, fft-filters.cpp:166-190), PCM within the tolerance, the bit streams equal once the slicer has pulled in."""
     block, calls = 16384 * 15, 15            # (the oracle takes whole 16384-sample blocks; 20480 fm samples per call)
     join = {0: 0, 1: 3, 2: 5}
     off0 = 6
@@ -131,7 +129,7 @@ def test_rds_decoders_switched_on_channel_by_channel(fmx_amd, ol):
             assert pg[c].shape == po.shape
             worst[c] = max(worst[c], float(np.sqrt(np.mean((pg[c].astype(np.float64) - po) ** 2))))
             if k >= join[c] and not (c == 0 and k >= off0):
-                taps_g[c].append(f.tap(M.TAP_RDS_IQ, f.last_rds_samples(), c))
+                taps_g[c].append(f.tap(M.TAP_RDS_IQ, f.last_rds_samples(c), c))
     print("\n[RDS channel by channel] worst PCM rms per channel:", " ".join("%.1e" % w for w in worst))
     assert max(worst) <= 1e-5
     for c in (1, 2):
@@ -141,7 +139,7 @@ def test_rds_decoders_switched_on_channel_by_channel(fmx_amd, ol):
         b_g, b_o = f.rds_bits(c, 8192), chains[c].rds_bits()
         where = np.nonzero(b_g[:min(len(b_g), len(b_o))] != b_o[:min(len(b_g), len(b_o))])[0]
         print("[RDS channel %d, on from call %d] baseband rms err %.2e (signal %.2e); bits %d / %d, differ at %s" % (c, join[c], e, sig, len(b_g), len(b_o), where.tolist()[:12]))
-        assert len(g) == len(o) and sig > 1e-3 and e <= 3e-3 * sig
+        assert len(g) == len(o) and sig > 1e-3 and e <= 1e-4 * sig
         assert len(b_g) == len(b_o) and len(b_o) > 900
         # (the first ~400 bits are decided on the filters' numerical dust -- 1e-9 here, where channel 0's spectrum leaks into its pair
         # partner's row; exact zeros in the oracle -- and on the slicer's pull-in)

@@ -24,7 +24,7 @@ for k in range(calls):
     for c in range(3):
         chains[c].process(x)
         if k >= join[c]:
-            n = f.last_rds_samples()
+            n = f.last_rds_samples(c)
             g = f.tap(M.TAP_RDS_IQ, n, c)
             o = chains[c].tap(ol.TAP_RDS_IQ)[pos[c]:pos[c] + n]; pos[c] += n
             msg.append("ch%d err %.2e (sig %.2e)" % (c, np.sqrt(np.mean((g - o).astype(np.float64) ** 2)), np.sqrt(np.mean(o.astype(np.float64) ** 2))))
