@@ -316,3 +316,46 @@ def test_lr_scope_tap_switch(fmx_amd, ol):
     assert isinstance(t70k, np.ndarray) and np.array_equal(t70k, t1)
     p1n, t1n = run(1, 0)
     assert isinstance(t1n, str) and np.array_equal(p1n, p1)
+
+
+def test_rds_block_phases_per_channel_in_a_batch(fmx_amd, ol):
+    """A batch whose channels switch their RDS decoders on at different times (and one off and on again): three block phases in one handle, the
+    block filters by channel list for the groups that are not the whole handle.  A representative of every group against an oracle chain that
+    takes the same switches (24 kS/s baseband, bits); the channels of a group are bit-identical to each other."""
+    block, calls, nch = 16384 * 15, 9, 70
+    iq = ol.synth_iq(block * calls, rds=1, rdsLevel=0.05, rdsBitsSeed=777)
+    f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block)
+    for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_FILTER_RESTARTS, 2), (M.P_PLL_SOLVER, 1)):
+        f.set_param(pid, v)
+    group = lambda c: 0 if c < 40 else (1 if c < 60 else 2)
+    join = {0: 0, 1: 2, 2: 3}
+    reps = {0: 0, 1: 40, 2: 60, 3: 5}                                 # (3: channel 5, which pauses from call 4 to call 6)
+    chains = {g: ol.OracleChain(inputFilterBw=165000, rdsMode=0, taps=[ol.TAP_RDS_IQ], tap_seconds=1.2) for g in reps}
+    taps = {g: [] for g in reps}
+    on = [False] * nch
+    for k in range(calls):
+        for c in range(nch):
+            if join[group(c)] == k: f.set_param(M.P_RDS_MODE, 2, c); on[c] = True
+        for g in reps:
+            if join[group(reps[g])] == k: chains[g].configure(rdsMode=2)
+        if k == 4: f.set_param(M.P_RDS_MODE, 0, 5); chains[3].configure(rdsMode=0); on[5] = False
+        if k == 6: f.set_param(M.P_RDS_MODE, 2, 5); chains[3].configure(rdsMode=2); on[5] = True
+        x = iq[k * block:(k + 1) * block]
+        f.process_host(x[None])
+        for g in reps: chains[g].process(x)
+        for g, c in reps.items():
+            if on[c]: taps[g].append(f.tap(M.TAP_RDS_IQ, f.last_rds_samples(c), c))
+        for c in (1, 39, 41, 59, 61, 69):                               # twins of the representatives 0, 40, 60
+            r = reps[group(c)]
+            if on[c]:
+                assert f.last_rds_samples(c) == f.last_rds_samples(r)
+                assert np.array_equal(f.tap(M.TAP_RDS_IQ, f.last_rds_samples(c), c), f.tap(M.TAP_RDS_IQ, f.last_rds_samples(r), r)), (k, c)
+    for g, c in reps.items():
+        gt = np.concatenate(taps[g]); o = chains[g].tap(ol.TAP_RDS_IQ)
+        assert len(gt) == len(o), (g, len(gt), len(o))
+        sig = float(np.sqrt(np.mean(o[len(o) // 2:].astype(np.float64) ** 2)))
+        e = float(np.sqrt(np.mean((gt.astype(np.float64) - o) ** 2)))
+        b_g, b_o = f.rds_bits(c, 8192), chains[g].rds_bits()
+        print("\n[RDS batch, channel %d] baseband rms err %.2e (signal %.2e); bits %d / %d" % (c, e, sig, len(b_g), len(b_o)))
+        assert sig > 1e-3 and e <= 1e-4 * sig and len(b_g) == len(b_o)
+        assert np.count_nonzero(np.nonzero(b_g != b_o)[0] >= 460) <= 2
