@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Randomised soak of the batch path against the oracle (GPU box; not collected by pytest: run by hand, `python tests/soak_random.py [first seed] [seeds] [channels] [plain 0|1]`).
+Per seed: a handle of `channels` channels on five streams with settings drawn at random -- input filter width / off, IQ balance, local oscillator, DC
+removal, all six decoders, the three squelch modes with random thresholds, fm mode, selector, panorama, de-emphasis, volume, audio filter, auto-mono, and an
+RDS decoder (0 .. 3) switched on at a random call (some switched off again later) -- fed in calls of uneven length; every channel's PCM, and its RDS bit count
+where a decoder ran, against an oracle chain taking the same settings and switches."""
+import importlib, os, sys
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import oracle_lib as ol
+pkg = importlib.import_module("sdr-j-fm_amd"); M = pkg.fmx
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+nseeds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+nch = int(sys.argv[3]) if len(sys.argv) > 3 else 70
+plain = int(sys.argv[4]) if len(sys.argv) > 4 else 0        # 1: no local oscillator, the input filter on everywhere (what the matrix-pipe input filter takes)
+TOL = 1e-5
+nstreams = 5
+blocks = [16384 * 3 * k for k in (5, 4, 6, 5, 3, 5)]                    # (the oracle applies a switch at its next 16384-sample block: calls are whole blocks, their fm counts multiples of 8)
+n = sum(blocks)
+bad = 0
+for seed in range(seed0, seed0 + nseeds):
+    rng = np.random.default_rng(seed)
+    streams = []
+    for sidx in range(nstreams):
+        x = ol.synth_iq(n, stereo=1 if sidx != 1 else 0, noiseSeed=100 * seed + sidx, noiseSigma=0.002 * sidx, rds=1, rdsLevel=0.05, rdsBitsSeed=seed * 10 + sidx,
+                        pilotLevel=float(rng.choice([0.10, 0.10, 0.05])))
+        x[:, 0] += float(rng.choice([0.0, 0.007, -0.02])); x[:, 1] += float(rng.choice([0.0, -0.004, 0.015]))
+        streams.append(x)
+    iq = np.stack(streams, axis=0)
+    cfgs, rdsplan = [], []
+    for c in range(nch):
+        kw = dict(inputFilterBw=int(rng.choice([0, 165000, 165000, 130000, 200000])), attL=float(rng.choice([1.0, 0.9, 1.15])), attR=float(rng.choice([1.0, 1.1, 0.85])),
+                  loFrequency=int(rng.choice([0, 0, 0, 2500, -4000])), dcRemove=int(rng.choice([1, 1, 1, 0])), decoder=int(rng.choice([1, 2, 3, 3, 4, 5, 6])),
+                  fmMode=int(rng.choice([0, 0, 1, 2])), soundSelector=int(rng.choice([0, 1, 4])), panorama=int(rng.choice([100, 60, 140])),
+                  deemphasis=int(rng.choice([50, 75])), volumeDb=float(rng.choice([-6.0, -10.5, 0.0])), lfCutoff=int(rng.choice([15000, 12000, 0])),
+                  autoMono=int(rng.choice([1, 0])), squelchMode=int(rng.choice([0, 0, 0, 1, 2])), squelchValue=int(rng.integers(20, 80)))
+        if plain: kw["loFrequency"] = 0; kw["inputFilterBw"] = int(rng.choice([165000, 130000, 200000]))
+        cfgs.append(kw)
+        mode = int(rng.choice([0, 0, 1, 2, 2, 3]))
+        rdsplan.append((mode, int(rng.integers(0, 4)), int(rng.choice([99, 99, 4, 5]))))            # (mode, on at call, off at call)
+    f = pkg.Fmx(nch, streams=nstreams, stream_of_channel=[c % nstreams for c in range(nch)], max_block=max(blocks))
+    pid = dict(inputFilterBw=M.P_BANDWIDTH, attL=M.P_ATTENUATION_L, attR=M.P_ATTENUATION_R, loFrequency=M.P_LOCAL_OSCILLATOR, dcRemove=M.P_DC_REMOVE,
+               decoder=M.P_FM_DECODER, fmMode=M.P_FM_MODE, soundSelector=M.P_SOUND_MODE, panorama=M.P_STEREO_PANORAMA, deemphasis=M.P_DEEMPHASIS,
+               volumeDb=M.P_VOLUME_DB, lfCutoff=M.P_LF_CUTOFF, autoMono=M.P_AUTO_MONO, squelchMode=M.P_SQUELCH_MODE, squelchValue=M.P_SQUELCH_VALUE)
+    for c, kw in enumerate(cfgs):
+        for k, v in kw.items(): f.set_param(pid[k], v, c)
+    chains = [ol.OracleChain(rdsMode=0, **kw) for kw in cfgs]
+    outs, ref, pos = [], [[] for _ in range(nch)], 0
+    for k, b in enumerate(blocks):
+        for c, (mode, on_at, off_at) in enumerate(rdsplan):
+            if mode and on_at == k: f.set_param(M.P_RDS_MODE, mode, c); chains[c].configure(rdsMode=mode)
+            if mode and off_at == k: f.set_param(M.P_RDS_MODE, 0, c); chains[c].configure(rdsMode=0)
+        outs.append(f.process_host(np.ascontiguousarray(iq[:, pos:pos + b])))
+        for c in range(nch): ref[c].append(chains[c].process(iq[c % nstreams, pos:pos + b]))
+        pos += b
+    pcm = np.concatenate(outs, axis=1)
+    worst, wc = 0.0, -1
+    for c in range(nch):
+        po = np.concatenate(ref[c])
+        m = min(pcm.shape[1], po.shape[0])
+        # (behind the first call.  Where the input filter's latency ends -- 28 ms into the stream -- the limiter decides "|z| <= 0.001" on the filter's
+        # start-up transient, sample by sample: one of them on the knife's edge, on a difference in the last bit between the reference's "balance, then
+        # filter" and the library's "filter, then balance", is one demodulator sample of a different kind -- a click of 1e-4 .. 5e-3 in that call's PCM
+        # (seed 22: the four channels with attL 0.9 on one stream).  Reported, not counted.)
+        f0 = outs[0].shape[1]
+        e0 = float(np.sqrt(np.mean((pcm[c][:f0].astype(np.float64) - po[:f0]) ** 2)))
+        e = float(np.sqrt(np.mean((pcm[c][f0:m].astype(np.float64) - po[f0:m]) ** 2)))
+        if e0 > TOL: print("   seed %d channel %d: first call %.3e (start-up)" % (seed, c, e0))
+        if e > worst: worst, wc = e, c
+        # (the PLL decoder, decoder 2: pllC senses its phase through two quantised tables, so two runs a last bit apart somewhere walk through
+        # different table entries at sporadic samples -- single quanta of 1e-4 in the demodulator output; behind a start-up click like the one
+        # above the two stay a fraction of a quantum apart for good: 9e-5 in the PCM of seed 22's channel 597.  The reference against itself,
+        # built with another compiler, does the same.)
+        tol = 2e-4 if cfgs[c]["decoder"] == 2 else TOL
+        ok = m > 0.95 * pcm.shape[1] and e <= tol and e0 <= 2e-2 and np.isfinite(pcm[c]).all()
+        if rdsplan[c][0]:
+            nb_g, nb_o = len(f.rds_bits(c, 8192)), len(chains[c].rds_bits())
+            # (RDS_1 takes a bit at every top of its recovered clock, rds-decoder-1.cpp:124-142: while that clock pulls in, a top more or less is rounding)
+            ok = ok and abs(nb_g - nb_o) <= (3 if rdsplan[c][0] == 1 else 0)
+            if nb_g != nb_o: print("   seed %d channel %d: RDS bits %d against %d, plan %s" % (seed, c, nb_g, nb_o, rdsplan[c]))
+        if not ok:
+            bad += 1
+            print("   seed %d channel %d: PCM rms %.3e settings %s rds %s" % (seed, c, e, cfgs[c], rdsplan[c]))
+    print("seed %d: %d channels, worst PCM rms %.3e (channel %d), front kernel %d" % (seed, nch, worst, wc, f.last_front_kernel()), flush=True)
+    del f
+print("channels out of tolerance:", bad)
+sys.exit(1 if bad else 0)
