@@ -117,7 +117,8 @@ struct fmx_handle_s {
     std::atomic<int> stageb_form{0};     // FMX_P_STAGEB_FORM
     std::atomic<int> front_parts{0};     // FMX_P_FRONT_PARTS
     std::atomic<int> front_kernel{0};    // FMX_P_FRONT_KERNEL
-    std::atomic<int> lr_tap{-1};         // FMX_P_LR_TAP
+    std::atomic<int> scope_taps{-1};     // FMX_P_SCOPE_TAPS
+    bool taps_kept = true;               // the last call kept the scope-tap rows (fmx_get_tap)
     float *w_diff_mem = nullptr;         // the LR scope tap's rows (allocated when first wanted; DeviceBuffers::w_diff is null while the tap is off)
     bool front3_ok = false;              // every channel qualifies for front3_kernel (flush_mailbox)
     bool front4_ok = false;              // ... and for front4_kernel
@@ -607,8 +608,8 @@ int flush_mailbox(fmx_handle h) {
     if (any_rds) { const int rc = ensure_rds(h); if (rc) return rc; }
     bool any_pll = false;
     for (auto &p : h->params) any_pll |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0);     // pllC on the fm-rate IQ; |z| for the level squelch; the general AFC body for the noise squelch
-    {   // the LR scope tap (FMX_P_LR_TAP): a display feed, kept where there is a display
-        const int want = h->lr_tap.load();
+    {   // the scope taps that are rows of stage B's work arrays (FMX_P_SCOPE_TAPS): display feeds, kept where there is a display; the RDS path reads two of them
+        const int want = h->scope_taps.load();
         const bool keep = want < 0 ? h->channels <= 64 : want != 0;
         if (keep && !h->w_diff_mem) {
             HIPCHK(hipDeviceSynchronize());
@@ -617,6 +618,8 @@ int flush_mailbox(fmx_handle h) {
             h->tail_ptrs.push_back(h->w_diff_mem);
         }
         h->B.w_diff = keep ? h->w_diff_mem : nullptr;
+        h->taps_kept = keep;
+        h->B.rows_on = (keep || any_rds) ? 1 : 0;
     }
     {
         int var = 0;
@@ -1141,7 +1144,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         const size_t C = (size_t)h->pitch;   // rows are padded (see CallGeom.pitch)
         HIPCHK(hipMalloc(&h->B.w_dem, sizeof(float) * NJ * C));
         HIPCHK(hipMalloc(&h->B.w_cur, sizeof(float) * NJ * C));
-        h->B.w_diff = nullptr;      // (flush_mailbox: FMX_P_LR_TAP)
+        h->B.w_diff = nullptr;      // (flush_mailbox: FMX_P_SCOPE_TAPS)
         h->B.lockm_stride = (int32_t)(NJ / 6 + 512);
         HIPCHK(hipMalloc(&h->B.w_lockm, (size_t)h->B.lockm_stride * C));
         HIPCHK(hipMemset(h->B.w_lockm, 0, (size_t)h->B.lockm_stride * C));
@@ -1239,9 +1242,9 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_FRONT_KERNEL:
         if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "front kernel must be 0 (automatic), 1 (four waves per channel), 2 (six waves per channel) or 3 (the filter on the matrix pipe)");
         h->front_kernel.store(iv); return FMX_OK;
-    case FMX_P_LR_TAP:
-        if (iv < -1 || iv > 1) return fail(FMX_E_INVALID, "LR tap must be -1 (automatic), 0 (not kept) or 1 (kept)");
-        h->lr_tap.store(iv); return FMX_OK;
+    case FMX_P_SCOPE_TAPS:
+        if (iv < -1 || iv > 1) return fail(FMX_E_INVALID, "scope taps must be -1 (automatic), 0 (not kept) or 1 (kept)");
+        h->scope_taps.store(iv); return FMX_OK;
     case FMX_P_FRONT_PARTS:
         if (iv < 0 || iv > 32) return fail(FMX_E_INVALID, "front parts must be 0 (automatic), 1 (one workgroup per channel) or 2..32");
         h->front_parts.store(iv); return FMX_OK;
@@ -1462,13 +1465,13 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
     case FMX_TAP_DEMOD: case FMX_TAP_LR_RAW: case FMX_TAP_PILOT_PHASE: {
         // these taps are read back from the last call's work arrays (channel-major rows of the call), rows [nj - n, nj)
         const int64_t nj = h->last_J1 - h->last_J0, r0 = nj - n;
+        if (!h->taps_kept) return fail(FMX_E_UNSUPPORTED, "this handle does not keep the demodulator / LR / pilot-phase scope taps (FMX_P_SCOPE_TAPS)");
         if (n == 0) return FMX_OK;
         {                            // this call's rows are contiguous per channel
             const size_t off = (size_t)channel * (size_t)h->work_nj + (size_t)r0;
             std::vector<float> a((size_t)n), b;
             HIPCHK(hipMemcpy(a.data(), (tap == FMX_TAP_PILOT_PHASE ? h->B.w_cur : h->B.w_dem) + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
             if (tap == FMX_TAP_LR_RAW) {
-                if (!h->B.w_diff) return fail(FMX_E_UNSUPPORTED, "the LR scope tap is not kept by this handle (FMX_P_LR_TAP)");
                 b.resize((size_t)n);
                 HIPCHK(hipMemcpy(b.data(), h->B.w_diff + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
                 for (int64_t i = 0; i < n; i++) { dst[2 * i] = a[(size_t)i]; dst[2 * i + 1] = b[(size_t)i]; }

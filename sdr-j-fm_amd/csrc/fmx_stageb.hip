@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             if (lock_exact && owner) cy.lock = lock_end;             // (the chain's own end value: read again behind the next segment's barriers)
         }
         SB_FT(15);
-        {   // scope taps and the inputs of the RDS path: channel-major rows of this call
+        if (PART == 1 || B.rows_on) {   // the second kernel's input; scope taps and the inputs of the RDS path (the whole kernel: where somebody wants them): channel-major rows of this call
             const size_t lrow = (size_t)ch * B.lin_rows + seg0 + j0;
             float *wd = B.w_dem + lrow, *wc = B.w_cur + lrow;
 #pragma unroll
@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 sumv[i] = dem[i]; diffv[i] = dif;
             }
             SB_FT(27);
-            if (B.w_diff) {   // scope tap (fmx_get_tap; FMX_P_LR_TAP: a display feed that large batches do not keep): channel-major rows of this call
+            if (B.w_diff) {   // scope tap (fmx_get_tap; FMX_P_SCOPE_TAPS: a display feed that large batches do not keep): channel-major rows of this call
                 float *wf = B.w_diff + (size_t)ch * B.lin_rows + seg0 + j0;
 #pragma unroll
                 for (int i = 0; i < FB_K; i++) if (i < nv) wf[i] = diffv[i];
@@ -1627,7 +1627,9 @@ void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const Cal
     const int cus = G.n_cus > 0 ? G.n_cus : 256;
     const long whole = (long)((C + SB_WG_PER_SIMD * cus - 1) / (SB_WG_PER_SIMD * cus)) * SB_WG_PER_SIMD * 100;
     const long halves = (long)((C + 4 * cus - 1) / (4 * cus)) * 4 * 102;          // (two launches, the hand-over through HBM: 2 %)
-    const bool split = force >= 0 ? force != 0 : halves < whole;
+    // (a batch that keeps no scope taps and decodes no RDS: the whole kernel leaves the rows unwritten -- 0.63 GB per call at 4096 channels, and writes
+    // are the expensive direction on this GPU -- and is then the faster form where the halves were: 1.60 against 1.69 ms)
+    const bool split = force >= 0 ? force != 0 : (B.rows_on ? halves < whole : (getenv("FMX_ROWS_OFF_SPLIT") ? halves < whole : false));
     if (split) {
         hipLaunchKernelGGL(stageb_kernel<1>, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
         hipLaunchKernelGGL(stageb_kernel<2>, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();

@@ -194,7 +194,7 @@ def test_creeping_pilots_at_batch_scale(fmx_amd, ol):
             c = int(bad[0][0] * nst + bad[0][1])
             nt = f.last_fm_samples()
             where = []
-            for name, tap in (("fm IQ", M.TAP_FM_IQ), ("demod", M.TAP_DEMOD), ("pilot phase", M.TAP_PILOT_PHASE)):
+            for name, tap in (("fm IQ", M.TAP_FM_IQ), ("pre-resampler", M.TAP_PRE_RESAMPLER)):
                 ta, tb = f.tap(tap, nt, c), f.tap(tap, nt, c % nst)
                 wz = np.flatnonzero((ta != tb).reshape(nt, -1).any(axis=1))
                 where.append("%s %s" % (name, "same" if len(wz) == 0 else "first at fm sample %d of %d (%d differ, max %.2e)" % (wz[0], nt, len(wz), float(np.abs(ta - tb).max()))))
@@ -258,6 +258,7 @@ def test_newton_solver_batch_equals_single_and_reports_rounds(fmx_amd, ol):
     out = {}
     for nch in (4, 65):
         f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block)
+        f.set_param(M.P_SCOPE_TAPS, 1)                  # (the pilot-phase tap of a batch: a display feed it does not keep by default)
         gui_defaults(f)
         pcm = np.concatenate([f.process_host(iq[i:i + block]) for i in range(0, n, block)], axis=1)
         d = f.tap(M.TAP_PILOT_PHASE, nt, nch - 1).astype(np.float64) - pil_o
@@ -503,6 +504,7 @@ def test_discriminator_corner_arguments_of_the_atan_table(fmx_amd, ol, variant):
     nch = 65 if variant == "batch65" else 1
     for dec in (3, 4):
         f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block, inputRate=192000)
+        f.set_param(M.P_SCOPE_TAPS, 1)                  # (the demodulator tap of a batch: a display feed it does not keep by default)
         gui_defaults(f, 0)
         f.set_param(M.P_DC_REMOVE, 0); f.set_param(M.P_FM_DECODER, dec)
         if variant == "solver2":

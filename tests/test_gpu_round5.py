@@ -290,32 +290,44 @@ def test_front_kernel_choice(fmx_amd, ol):
     assert run(40, lambda f: f.set_param(M.P_FRONT_KERNEL, 3), n=64 * T) == 3
 
 
-def test_lr_scope_tap_switch(fmx_amd, ol):
-    """FMX_P_LR_TAP: the L-R difference in front of the matrix is a display feed (the reference's AF_SUM / AF_DIFF scopes) -- kept by a handle of up to 64
-    channels, not by a larger batch unless asked for; the PCM does not know the difference, and a batch that keeps it has the small handle's values."""
+def test_scope_taps_switch(fmx_amd, ol):
+    """FMX_P_SCOPE_TAPS: the demodulator output, the L-R difference in front of the matrix and the pilot phase are display feeds (the reference's scopes) --
+    rows of stage B's work arrays, kept by a handle of up to 64 channels, not by a larger batch unless asked for (a batch without them runs stage B as
+    one kernel that leaves the rows unwritten); the PCM does not know the difference, and a batch that keeps them has the small handle's values.  A channel
+    that decodes RDS has its rows regardless of the taps: the RDS path reads them."""
     n = 16384 * 6
-    x = ol.synth_iq(n)
-    def run(nch, lr):
+    x = ol.synth_iq(n, rds=1, rdsLevel=0.05)
+    def run(nch, taps, rds=False):
         f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=n)
         for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_FILTER_RESTARTS, 2), (M.P_PLL_SOLVER, 1)):
             f.set_param(pid, v)
-        if lr is not None: f.set_param(M.P_LR_TAP, lr)
+        if taps is not None: f.set_param(M.P_SCOPE_TAPS, taps)
+        if rds: f.set_param(M.P_RDS_MODE, 2, nch - 1)
         pcm = f.process_host(x[None])
-        try:
-            tap = f.tap(M.TAP_LR_RAW, 4096, nch - 1)
-        except Exception as e:
-            tap = str(e)
+        out = []
+        for t in (M.TAP_DEMOD, M.TAP_LR_RAW, M.TAP_PILOT_PHASE):
+            try:
+                out.append(f.tap(t, 4096, nch - 1))
+            except Exception as e:
+                out.append(str(e))
+        ring = f.tap(M.TAP_FM_IQ, 4096, nch - 1)
+        iq24 = f.tap(M.TAP_RDS_IQ, f.last_rds_samples(nch - 1), nch - 1) if rds else None
         del f
-        return pcm, tap
-    p1, t1 = run(1, None)
-    assert isinstance(t1, np.ndarray) and np.abs(t1[:, 0]).max() > 0
-    p70, t70 = run(70, None)
-    assert isinstance(t70, str) and "LR" in t70                              # (not kept: the library says so)
-    p70k, t70k = run(70, 1)
+        return pcm, out, ring, iq24
+    p1, t1, r1, _ = run(1, None)
+    assert all(isinstance(t, np.ndarray) for t in t1) and np.abs(t1[0]).max() > 0 and np.abs(t1[1][:, 0]).max() > 0
+    p70, t70, r70, _ = run(70, None)
+    assert all(isinstance(t, str) and "SCOPE_TAPS" in t for t in t70)      # (not kept: the library says so)
+    assert np.array_equal(r70, r1)                                            # (the ring taps are always there)
+    p70k, t70k, _, _ = run(70, 1)
     assert np.array_equal(p70, p70k) and np.array_equal(p70[69], p1[0])
-    assert isinstance(t70k, np.ndarray) and np.array_equal(t70k, t1)
-    p1n, t1n = run(1, 0)
-    assert isinstance(t1n, str) and np.array_equal(p1n, p1)
+    assert all(np.array_equal(a, b) for a, b in zip(t70k, t1))
+    p1n, t1n, _, _ = run(1, 0)
+    assert all(isinstance(t, str) for t in t1n) and np.array_equal(p1n, p1)
+    # RDS in a batch without taps: the rows are written for the RDS path, the 24 kS/s baseband is the small handle's
+    _, _, _, q1 = run(1, None, rds=True)
+    p70r, _, _, q70 = run(70, None, rds=True)
+    assert np.array_equal(q70, q1) and np.array_equal(p70r, p70)
 
 
 def test_rds_block_phases_per_channel_in_a_batch(fmx_amd, ol):

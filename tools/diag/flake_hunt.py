@@ -63,7 +63,7 @@ for r in range(runs):
             c = chans[0]
             nt = f.last_fm_samples()
             msg = []
-            for name, tap in (("fm IQ", M.TAP_FM_IQ), ("demod", M.TAP_DEMOD), ("pilot phase", M.TAP_PILOT_PHASE), ("pre-resampler", M.TAP_PRE_RESAMPLER)):
+            for name, tap in (("fm IQ", M.TAP_FM_IQ), ("pre-resampler", M.TAP_PRE_RESAMPLER)):
                 a, b2 = f.tap(tap, nt, c), f.tap(tap, nt, c % 4)
                 w = np.flatnonzero((a != b2).reshape(nt, -1).any(axis=1))
                 msg.append("%s: %s" % (name, "same" if len(w) == 0 else "first at %d (segment %d, thread %d), last %d, %d samples, max %.2e" % (w[0], w[0] // 1536, (w[0] % 1536) // 6, w[-1], len(w), float(np.abs(a - b2).max()))))

@@ -17,7 +17,7 @@ cap = block // 48 + 96
 d_pcm = torch.zeros((C, cap, 2), dtype=torch.float32, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
 f = pkg.Fmx(C, max_block=block, device=0)
-f.set_param(M.P_LR_TAP, 1)          # (the LR scope tap, which a batch does not keep by default, is one of the taps compared)
+f.set_param(M.P_SCOPE_TAPS, 1)      # (the scope taps, which a batch does not keep by default, are among the taps compared)
 for p, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FM_MODE, 0), (M.P_FM_DECODER, 3)):
     f.set_param(p, v, -1)
 if rds: f.set_param(M.P_RDS_MODE, 2)
