@@ -13,7 +13,7 @@ bash tools/pmc_traffic.sh r05 --quick --steps 4 --warmup 44 2>&1 | tail -1
 {
   echo "# rocprofv3 --pmc passes of python bench.py --quick (4096 channels, established population), averages per launch and per collection unit"
   for set in "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAVES SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY"; do
-    for kn in "front4_kernel" "stageb_kernel<1>" "stageb_kernel<2>" "audio_fft"; do
+    for kn in "front4_kernel" "stageb_kernel<0>" "audio_fft"; do
       bash tools/pmc_kernel.sh "$set" "$kn" --quick --steps 4 --warmup 44 2>&1 | tail -1
     done
   done
