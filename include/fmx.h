@@ -131,13 +131,14 @@ typedef enum {
                                   any channel, the input filter on everywhere, a call that starts on a multiple of 12 samples -- and leave
                                   the rest to kernel 1.
                                   0 = automatic (default): 3 where a handle qualifies and has the channels to fill the GPU, else 1. */
-    FMX_P_SCOPE_TAPS = 26,     /* (handle-wide: the channel argument is ignored) whether the three scope taps that are rows of stage B's work arrays are
-                                  kept: FMX_TAP_DEMOD, FMX_TAP_LR_RAW, FMX_TAP_PILOT_PHASE -- the reference's display feeds (fm-processor.cpp:608-613 and
-                                  the demodulator / pilot scopes), 12 bytes written per channel and fm sample that nothing else reads (a channel that
-                                  decodes RDS keeps its demodulator and pilot rows regardless: the RDS path reads them).  1 = kept, 0 = not kept
-                                  (fmx_get_tap then answers FMX_E_UNSUPPORTED for those taps; FMX_TAP_FM_IQ, FMX_TAP_PRE_RESAMPLER and FMX_TAP_RDS_IQ
-                                  are read from rings and always there), -1 = automatic (default): kept by handles of up to 64 channels -- the
-                                  receiver with a display --, not by larger batches.  Takes effect at the next call. */
+    FMX_P_SCOPE_TAPS = 26,     /* (handle-wide: the channel argument is ignored) whether the DISPLAY FEEDS are produced: the three scope taps that are rows
+                                  of stage B's work arrays -- FMX_TAP_DEMOD, FMX_TAP_LR_RAW, FMX_TAP_PILOT_PHASE (fm-processor.cpp:608-613 and the
+                                  demodulator / pilot scopes): 12 bytes written per channel and fm sample that nothing else reads (a channel that
+                                  decodes RDS keeps its demodulator and pilot rows regardless: the RDS path reads them) -- and the peak-level
+                                  meter's maxima (showPeakLevel: fmx_get_peaks).  1 = produced, 0 = not (fmx_get_tap answers FMX_E_UNSUPPORTED for
+                                  those taps, fmx_get_peaks likewise; FMX_TAP_FM_IQ, FMX_TAP_PRE_RESAMPLER and FMX_TAP_RDS_IQ are read from rings
+                                  and always there), -1 = automatic (default): produced by handles of up to 64 channels -- the receiver with a
+                                  display --, not by larger batches.  The PCM does not depend on it.  Takes effect at the next call. */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */

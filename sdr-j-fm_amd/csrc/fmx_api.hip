@@ -620,6 +620,7 @@ int flush_mailbox(fmx_handle h) {
         h->B.w_diff = keep ? h->w_diff_mem : nullptr;
         h->taps_kept = keep;
         h->B.rows_on = (keep || any_rds) ? 1 : 0;
+        h->B.peaks_on = keep ? 1 : 0;
     }
     {
         int var = 0;
@@ -1425,6 +1426,7 @@ int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
 int fmx_get_peaks(fmx_handle h, int32_t channel, float *lr_db, int32_t capacity, int32_t *n_events) {
     if (!h || !n_events || channel < 0 || channel >= h->channels || capacity < 0 || (capacity > 0 && !lr_db))
         return fail(FMX_E_INVALID, "bad argument");
+    if (!h->taps_kept) return fail(FMX_E_UNSUPPORTED, "this handle does not run the peak-level meter (FMX_P_SCOPE_TAPS)");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
     ChanState st;

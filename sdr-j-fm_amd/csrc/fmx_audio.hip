@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64) void pcm_tail_kernel(DeviceBuffers B, CallGeom 
     const int cnt0 = st->pk_cnt;
     float L = st->pk_l, R = st->pk_r;
     int ev = st->pk_events;
-    const int tiles = (frames + C_TILE - 1) / C_TILE;
+    const int tiles = B.peaks_on ? (frames + C_TILE - 1) / C_TILE : 0;      // (the meter off: the window grid goes on counting, nothing is folded or handed out)
     for (int tile = 0; tile < tiles; tile++) {
         const int i0 = tile * C_TILE, nfr = min(C_TILE, frames - i0);
         const float4 p = B.pk_part[(size_t)ch * B.pk_tiles + tile];
@@ -63,6 +63,7 @@ static_assert(AUDIO_DELAY % 4 == 0, "the four phases of a frame are one aligned 
 #ifndef AF_WAVES_PER_SIMD
 #define AF_WAVES_PER_SIMD 3
 #endif
+template <bool PEAKS>      // (the peak meter's maxima: a display feed that a batch does not take, FMX_P_SCOPE_TAPS -- 7 % of the kernel)
 __global__ __launch_bounds__(fftc::T, AF_WAVES_PER_SIMD) void audio_fft_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, float2 *__restrict__ pcm) {
     __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];
     __shared__ int pkt[7][4];
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(fftc::T, AF_WAVES_PER_SIMD) void audio_fft_kernel(D
     const AudioSet AS = T.audio_sets[P.audio_set];
     const float2 *__restrict__ dring = B.dring + (size_t)ch * (G.dring_mask + 1);
     const float2 *__restrict__ Gs = T.audio_spec + (size_t)P.audio_set * 4 * fftc::N;
-    if (t < 28) pkt[t >> 2][t & 3] = 0;
+    if (PEAKS && t < 28) pkt[t >> 2][t & 3] = 0;
     // window entry n' <-> frame mb - 220 + n': its four phases are d[4 (mb - 220 + n') - delay + 0 .. 3], phase p = entry 3 - p.
     // A phase's eight entries are loaded in front of its transform (the four phases share their cache lines; holding all four
     // windows in registers costs 48 VGPRs and a third of the occupancy)
@@ -139,11 +140,12 @@ __global__ __launch_bounds__(fftc::T, AF_WAVES_PER_SIMD) void audio_fft_kernel(D
             }
             const int i_tile = (int)(mb - G.M0) + tile * C_TILE;
             const bool second = (cnt0 + i) / PK_WIN != (cnt0 + i_tile) / PK_WIN;
-            pv[second ? 2 : 0] = fabsf(al); pv[second ? 3 : 1] = fabsf(ar);
+            if (PEAKS) { pv[second ? 2 : 0] = fabsf(al); pv[second ? 3 : 1] = fabsf(ar); }
             pcm[(size_t)ch * G.pcm_stride + (m - G.M0)] = make_float2(al, ar);
         }
         // peak maxima per 256-frame tile: for a given k a wave's frames lie in one tile except the wave that holds t = 220
-        if (t < 192) {
+        if (!PEAKS) {
+        } else if (t < 192) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 // (the wave's maximum of four non-negative values per step k: 32 reductions per thread -- as DPP moves on the vector pipe, not
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(fftc::T, AF_WAVES_PER_SIMD) void audio_fft_kernel(D
             for (int q = 0; q < 4; q++) atomicMax(&pkt[tile][q], __float_as_int(pv[q]));
         }
     }
+    if (!PEAKS) return;
     __syncthreads();
     const int tiles = (int)(((G.M1 - mb) < AF_VALID ? (G.M1 - mb) : AF_VALID) + C_TILE - 1) / C_TILE;
     if (t < tiles) B.pk_part[(size_t)ch * B.pk_tiles + 7 * blockIdx.x + t] = make_float4(__int_as_float(pkt[t][0]), __int_as_float(pkt[t][1]), __int_as_float(pkt[t][2]), __int_as_float(pkt[t][3]));
@@ -447,7 +450,8 @@ void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
     // operand planes (42 KB per 1024 frames) leave a CU twelve waves; neither form is bound by its arithmetic any more)
     static const bool mfma = getenv("FMX_AUDIO_MFMA") && atoi(getenv("FMX_AUDIO_MFMA")) != 0;
     if (mfma && T.audio_mtab) hipLaunchKernelGGL(audio_mfma_kernel, dim3((unsigned)((frames + am::FR - 1) / am::FR), channels), dim3(64 * am::WV), 0, s, T, B, G, pcm);
-    else hipLaunchKernelGGL(audio_fft_kernel, dim3((unsigned)((frames + AF_VALID - 1) / AF_VALID), channels), dim3(fftc::T), 0, s, T, B, G, pcm);
+    else if (B.peaks_on) hipLaunchKernelGGL(audio_fft_kernel<true>, dim3((unsigned)((frames + AF_VALID - 1) / AF_VALID), channels), dim3(fftc::T), 0, s, T, B, G, pcm);
+    else hipLaunchKernelGGL(audio_fft_kernel<false>, dim3((unsigned)((frames + AF_VALID - 1) / AF_VALID), channels), dim3(fftc::T), 0, s, T, B, G, pcm);
     hipLaunchKernelGGL(pcm_tail_kernel, dim3((channels + 63) / 64), dim3(64), 0, s, B, G, channels);
 }
 

@@ -266,6 +266,7 @@ struct DeviceBuffers {
     int32_t prepass;     // != 0: disc_kernel / afc_kernel<true> run as the pre-pass of the fused stage B (launch_demod_fused): only the channels
                          // with a recurrence of their own in the demodulator (PLL / AM decoder, a squelch) are touched, their demodulator output
                          // goes to the 16-row tiles of w_osc (given to them as w_dem), the metaData snapshot of the AFC value is taken there
+    int32_t peaks_on;    // != 0: the peak-level meter's maxima are taken (showPeakLevel: a display feed, FMX_P_SCOPE_TAPS)
     int32_t rows_on;     // != 0: the per-call rows w_dem / w_cur are wanted beyond stage B's own hand-over -- a scope tap is kept (FMX_P_SCOPE_TAPS) or a channel decodes RDS
     int32_t prepass_var; // what the pre-pass channels of the handle use: bit 0 the PLL decoder, 1 the AM decoder, 2 the level squelch, 3 a squelch behind another decoder (afc_kernel's variants)
     // PCM tail (fmx_audio.hip)

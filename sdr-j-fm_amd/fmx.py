@@ -23,7 +23,7 @@ P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE
 P_DISP_DELAY = 20
 P_STAGEB_FORM = 22            # handle-wide: 0 automatic, 1 stage B as one kernel per call, 2 as two (bit-identical results)
 P_FRONT_KERNEL = 25           # handle-wide: 0 automatic, 1 fmx_front.hip (packed f32 FMAs), 2 fmx_front3.hip (the same on six waves), 3 fmx_front4.hip (f16-split matrix FIR)
-P_SCOPE_TAPS = 26             # handle-wide: -1 automatic (kept up to 64 channels), 0 the demodulator / LR / pilot-phase scope taps are not kept, 1 kept
+P_SCOPE_TAPS = 26             # handle-wide: -1 automatic (up to 64 channels), 0 the display feeds (demodulator / LR / pilot-phase scope taps, peak meter) are not produced, 1 produced
 P_FRONT_PARTS = 24            # handle-wide: 0 automatic, 1 one workgroup per channel, 2..32 parts in time per channel (bit-identical results)
 P_FILTER_RESTARTS = 23        # handle-wide, before the first call: 0 automatic, 1 the reference's block filters (<= 64 channels), 2 folded FIRs
 P_PLL_SOLVER = 21             # 0 automatic, 1 sequential (the reference's trajectory), 2 Newton while in lock + sequential around lock decisions, 3 Newton always

@@ -292,7 +292,7 @@ def test_front_kernel_choice(fmx_amd, ol):
 
 def test_scope_taps_switch(fmx_amd, ol):
     """FMX_P_SCOPE_TAPS: the demodulator output, the L-R difference in front of the matrix and the pilot phase are display feeds (the reference's scopes) --
-    rows of stage B's work arrays, kept by a handle of up to 64 channels, not by a larger batch unless asked for (a batch without them runs stage B as
+    rows of stage B's work arrays --, and so is the peak-level meter: produced by a handle of up to 64 channels, not by a larger batch unless asked for (a batch without them runs stage B as
     one kernel that leaves the rows unwritten); the PCM does not know the difference, and a batch that keeps them has the small handle's values.  A channel
     that decodes RDS has its rows regardless of the taps: the RDS path reads them."""
     n = 16384 * 6
@@ -310,12 +310,16 @@ def test_scope_taps_switch(fmx_amd, ol):
                 out.append(f.tap(t, 4096, nch - 1))
             except Exception as e:
                 out.append(str(e))
+        try:
+            out.append(f.peaks(nch - 1))
+        except Exception as e:
+            out.append(str(e))
         ring = f.tap(M.TAP_FM_IQ, 4096, nch - 1)
         iq24 = f.tap(M.TAP_RDS_IQ, f.last_rds_samples(nch - 1), nch - 1) if rds else None
         del f
         return pcm, out, ring, iq24
     p1, t1, r1, _ = run(1, None)
-    assert all(isinstance(t, np.ndarray) for t in t1) and np.abs(t1[0]).max() > 0 and np.abs(t1[1][:, 0]).max() > 0
+    assert all(isinstance(t, np.ndarray) for t in t1) and np.abs(t1[0]).max() > 0 and np.abs(t1[1][:, 0]).max() > 0 and len(t1[3]) >= 1
     p70, t70, r70, _ = run(70, None)
     assert all(isinstance(t, str) and "SCOPE_TAPS" in t for t in t70)      # (not kept: the library says so)
     assert np.array_equal(r70, r1)                                            # (the ring taps are always there)
