@@ -266,6 +266,7 @@ def sub_bench(extra):
         return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "channels_per_gpu": j["config"]["channels_per_gpu"],
                 "kernels_ms_per_step": {x: k[x] for x in ("front_fir", "demod_pilot_pss", "audio_fir_resample")},
                 "stage_b_min_median_max": j["kernels_ms_per_step_raw"]["stage_b_min_median_max"], "pilot_pll": j["pilot_pll"],
+                **({"call_pieces": j["call_pieces"]["pieces_per_call"]} if "call_pieces" in j else {}),
                 "front_fir_frac_of_8TBps": j["roofline"]["frac"], **({"front_fir_bytes": j["roofline"]["front_fir_bytes"]} if "front_fir_bytes" in j["roofline"] else {}),
                 **({"rds_check": j["rds_check"]} if "rds_check" in j else {})}
     except Exception as e:          # an extra leg must not take the headline line down
@@ -519,9 +520,11 @@ def main():
         step()
         torch.cuda.synchronize()
         one = f.profile_read(reset=True)
+        # (a call made in overlapping pieces -- FMX_P_CALL_PIECES: pre-pass batches -- records one set of events per piece: a step's stage time is their sum)
+        pieces = f.last_call_pieces()
         for k in range(3):
-            prof["launches"][k] += one["launches"][k]; prof["ms"][k] += one["ms"][k]
-            per_step[k].append(one["ms"][k] / max(one["launches"][k], 1))
+            prof["launches"][k] += one["launches"][k] if pieces <= 1 else 1; prof["ms"][k] += one["ms"][k]
+            per_step[k].append(one["ms"][k] / (max(one["launches"][k], 1) if pieces <= 1 else 1))
     torch.cuda.synchronize()
     pll_counts = {"steps": nprof, "fail_safe_replays_per_step": round((f.pll_replays() - rep0) / nprof, 2),
                   "guard_sequential_segments_per_step": round((f.pll_exact_segments() - ex0) / nprof, 1),
@@ -666,6 +669,9 @@ def main():
                                         "note": "HIP-event intervals of a separate untimed pass of %d steps, each enqueued behind a spin kernel; their sum "
                                                 "exceeds the timed step by the events' own cost" % launches},
             "pilot_pll": pll_counts,
+            **({"call_pieces": {"pieces_per_call": pieces, "note": "FMX_P_CALL_PIECES: the call is made in pieces whose stages overlap on three streams (stage A of piece k + 1, the "
+                                "demodulator's lone-wave recurrences of piece k, stage B / C of piece k - 1); the stage intervals are sums over the pieces and overlap in time"}}
+               if pieces > 1 else {}),
             "per_rank_value": [round(rank_channels[r] * n * args.steps / t / 1e6, 3) for r, t in enumerate(per_rank)],
         }
         if rds_check: out["rds_check"] = rds_check
@@ -698,7 +704,8 @@ def main():
                                       "configs[3], mixed population": sub_bench(["--population", "mixed"]),
                                       "configs[3], no channel locked": sub_bench(["--population", "unlocked"]),
                                       "configs[3], PLL decoder on every channel": sub_bench(["--decoder", "2"]),
-                                      "configs[3], noise squelch on every channel": sub_bench(["--squelch", "1"])}
+                                      "configs[3], noise squelch on every channel": sub_bench(["--squelch", "1"]),
+                                      "configs[3], level squelch on every channel": sub_bench(["--squelch", "2"])}
             proj = {"1": {"channels_per_gpu": channels, "per_gpu_value": out["value"], "efficiency": 1.0}}
             for g in (2, 4, 8):
                 r = sub_bench(["--channels", str(channels // g)])

@@ -139,6 +139,14 @@ typedef enum {
                                   those taps, fmx_get_peaks likewise; FMX_TAP_FM_IQ, FMX_TAP_PRE_RESAMPLER and FMX_TAP_RDS_IQ are read from rings
                                   and always there), -1 = automatic (default): produced by handles of up to 64 channels -- the receiver with a
                                   display --, not by larger batches.  The PCM does not depend on it.  Takes effect at the next call. */
+    FMX_P_CALL_PIECES = 27,    /* (handle-wide: the channel argument is ignored) fm samples per PIECE of a call that is made in overlapping pieces.  A batch
+                                  whose channels run the PLL / AM decoder or a squelch (pllC.cpp:67-90, squelchClass.cpp:47-113: recurrences that walk a
+                                  channel's samples one after the other, one wave per 64 channels) would leave the GPU idle for most of such a call:
+                                  the library cuts the call into pieces -- the chain does not depend on how a stream is cut into calls -- and runs the
+                                  input filter of piece k + 1 and the stereo / audio stages of piece k - 1 while the recurrences walk piece k.
+                                  -1 = automatic (default): 3072 (PLL / AM decoder) or 4608 (squelches only) for handles of 1024 channels and more, calls of two pieces
+                                  and more, no RDS decoder on, no second converter;
+                                  0 = never; n > 0: pieces of n fm samples (rounded up to 16) for any handle above 64 channels.  Takes effect at the next call. */
     /* actions (value ignored) */
     FMX_A_TRIGGER_FREQUENCY_CHANGE = 100, /* triggerFrequencyChange (:849-855) */
     FMX_A_RESTART_PSS = 101,              /* restartPssAnalyzer     (:857-860) */
@@ -299,6 +307,8 @@ int64_t fmx_pll_exact_segments(fmx_handle h, int32_t channel);
 /* Which kernel the last fmx_process_* call gave its input-filter stage to (FMX_P_FRONT_KERNEL's numbering: 1, 2 or 3; the remainder of a call
  * that is not whole 1536-sample tiles always goes to kernel 1): what a benchmark names beside its number. */
 int32_t fmx_last_front_kernel(fmx_handle h);
+/* ... and the number of overlapping pieces it was made in (FMX_P_CALL_PIECES; 1: the call was made whole). */
+int32_t fmx_last_call_pieces(fmx_handle h);
 /* ... and 24 kS/s RDS samples (rdsDecimator outputs, fm-processor.cpp:553): the n that fmx_get_tap accepts for FMX_TAP_RDS_IQ */
 int64_t fmx_last_rds_samples(fmx_handle h);
 /* ... of one channel.  A channel's RDS path counts the fm samples IT has processed -- it runs while the channel's decoder is on and stands still

@@ -123,6 +123,13 @@ struct fmx_handle_s {
     bool front3_ok = false;              // every channel qualifies for front3_kernel (flush_mailbox)
     bool front4_ok = false;              // ... and for front4_kernel
     int last_front_kernel = 1;           // what the last call's stage A was given (FMX_P_FRONT_KERNEL numbering): fmx_last_front_kernel
+    // a batch call whose channels need the demodulator pre-pass (a lone wave per 64 channels walking the call sample by sample: 6 % of the chip for
+    // most of the call's time) is made in pieces whose stages overlap: run_call
+    hipStream_t pipe_sA = nullptr, pipe_sP = nullptr, pipe_sB = nullptr;   // stage A (and the parallel part of the pre-pass) of piece k + 1, the recurrences of piece k, stage B / C of piece k - 1
+    hipEvent_t pipe_ev0 = nullptr, pipe_evA = nullptr, pipe_evD = nullptr, pipe_evP = nullptr, pipe_evE = nullptr, pipe_evB[2] = {nullptr, nullptr};
+    std::atomic<int> pipe_rows{-1};      // FMX_P_CALL_PIECES: fm samples per piece (-1 automatic, 0 never)
+    int last_pieces = 1;                 // overlapping pieces the last call was made in (fmx_last_call_pieces)
+    int my_count_host = 0;               // the reference's myCount (fm-processor.cpp:662-684) as stage B keeps it in every channel's state: the same in all of them
     PreLook pre_look{};                  // pre_kernel's look-back buffers (ensure_ola)
     void *hp_iq = nullptr; float2 *hp_pcm = nullptr; size_t hp_iq_bytes = 0; int64_t hp_pcm_cap = 0;   // fmx_process_host: pinned, device-visible staging of small calls
     // the reference's two overlap-add filters as the block machines they are (fmx_ola.hip): handles of up to OLA_MAX_CH channels
@@ -579,6 +586,10 @@ void run_ola(fmx_handle h, fmx_handle_s::OlaSide &S, OlaBuffers O, int64_t len, 
 
 static bool any_rds_on(fmx_handle h) { for (auto &p : h->params) if (p.rds_mode != 0) return true; return false; }
 
+constexpr int PIPE_ROWS_AUTO = 3072;      // fm samples per piece of an overlapping call where pllC runs (two of stage B's segments; measured at 4096 channels:
+                                          // 2048 / 3072 / 4608 / 6400 fm samples per piece give 6.37 / 6.18 / 6.46 / 6.79 ms per step, the call made whole 8.24)
+constexpr int PIPE_ROWS_AUTO_SQ = 4608;   // ... where only squelches do (noise squelch 6.61 / 5.73 / 5.46 / 5.54 against 5.90 whole, level squelch 5.43 / 4.73 / 4.59 / 4.72 against 5.23)
+constexpr int PIPE_MIN_CHANNELS = 1024;   // automatic: batches that fill the chip
 constexpr int PLL_SEQ_AUTO_MAX = 64;   // FMX_P_PLL_SOLVER = 0: handles up to this many channels evaluate the pilot PLL sequentially
 
 int flush_mailbox(fmx_handle h) {
@@ -730,8 +741,9 @@ int front_parts_for(fmx_handle h, CallGeom &G) {
     return FMX_OK;
 }
 
+struct PipePiece { int k; };       // a piece of a call made in overlapping pieces (its number)
 int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
-                 int64_t pcm_stride, int64_t *n_frames, hipStream_t s);
+                 int64_t pcm_stride, int64_t *n_frames, hipStream_t s, const PipePiece *pp = nullptr);
 // One call of the boundary.  The RDS front end works on blocks of RDS_BLK fm samples, every channel on its own block phase, and one launch sequence covers
 // at most one block boundary per channel: while a channel decodes RDS, a longer call is made in pieces (the chain is invariant to how a stream is cut into calls).
 int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
@@ -740,6 +752,61 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
                                                                    // fm sample at this handle's rate -- 12, 6 or 1 as the reference decimates)
     bool any_rds = false;
     { std::lock_guard<std::mutex> lk(h->mtx); for (auto &p : h->params) any_rds |= (p.rds_mode != 0); }
+    h->last_pieces = 1;
+    if (!any_rds && fmt >= 0 && fmt <= 3 && n <= h->cfg.max_block) {
+        // A batch whose channels need the demodulator pre-pass (PLL / AM decoder, a squelch: fmx_demod.hip).  Its recurrences are one wave per 64 channels
+        // walking the call's fm samples one after the other -- 64 waves on 1024 SIMDs at 4096 channels, for longer than stages A, B and C together take --
+        // and nothing else can run meanwhile: stage B waits for its output, it waits for stage A.  Such a call is made in PIECES (the chain is invariant
+        // to how a stream is cut into calls) on three streams: stage A of piece k + 1 and stage B / C of piece k - 1 fill the chip while the pre-pass
+        // walks piece k.  The pre-pass's work arrays alternate between two halves of their allocation; an event per stage boundary orders the rest.
+        // What the stages share beyond their hand-over arrays: the myCount of the metaData snapshot (kept by stage B, read by the pre-pass: handed over by
+        // the host, CallGeom::host_count) and the RF DC level stage B's snapshot reads from stage A's state (a display value that moves by 1e-7 of its
+        // distance per sample: it may be the next piece's).
+        static const int env_rows = getenv("FMX_CALL_PIECES") ? atoi(getenv("FMX_CALL_PIECES")) : -1;
+        const int want = h->pipe_rows.load() >= 0 ? h->pipe_rows.load() : env_rows;
+        bool special = false, chain = false;
+        { std::lock_guard<std::mutex> lk(h->mtx); for (auto &p : h->params) { special |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0); chain |= (p.decoder == 2 || p.decoder == 1); } }
+        const int64_t rows = want > 0 ? ((want + 15) / 16) * 16 : (chain ? PIPE_ROWS_AUTO : PIPE_ROWS_AUTO_SQ);
+        const int64_t half = (h->work_nj / 2) & ~(int64_t)15;
+        const int64_t piece = rows * h->decim;
+        if (special && want != 0 && h->B.w_iq && !h->ola_mode && !h->cv_nt && (want > 0 || h->channels >= PIPE_MIN_CHANNELS) && rows + 2 <= half && n >= 2 * piece) {
+            {
+                CallGeom G{}; frames_geom(h, n, &G);
+                if (conv2_out(h, G.M1) - conv2_out(h, G.M0) > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
+            }
+            if (!h->pipe_sA) {
+                // (plain streams, the recurrences' with priority.  Measured and not kept: compute units of their own for the recurrences -- masked streams,
+                // 16 CUs for 64 waves: the dispatcher does not put one wave on each SIMD of a CU, and two lone waves on one SIMD are slower than a lone wave
+                // among stage A's or B's: 300 ns per sample against 270, and 216 with the chip to itself; 6.7 against 6.0 ms per step)
+                int lo = 0, hi = 0;
+                HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIPCHK(hipStreamCreateWithPriority(&h->pipe_sA, hipStreamNonBlocking, lo));
+                HIPCHK(hipStreamCreateWithPriority(&h->pipe_sB, hipStreamNonBlocking, lo));
+                HIPCHK(hipStreamCreateWithPriority(&h->pipe_sP, hipStreamNonBlocking, hi));     // (the chain everything waits for)
+                for (hipEvent_t *e : {&h->pipe_ev0, &h->pipe_evA, &h->pipe_evD, &h->pipe_evP, &h->pipe_evE, &h->pipe_evB[0], &h->pipe_evB[1]}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            }
+            // the pieces run on the handle's three streams, behind what the caller's stream held when the call began; the caller's stream goes on behind the last of them
+            HIPCHK(hipEventRecord(h->pipe_ev0, s));
+            HIPCHK(hipStreamWaitEvent(h->pipe_sA, h->pipe_ev0, 0)); HIPCHK(hipStreamWaitEvent(h->pipe_sB, h->pipe_ev0, 0));
+            const int64_t bps = (fmt == 0) ? 8 : (fmt == 3 ? 4 : 2);
+            int64_t total = 0; int k = 0;
+            for (int64_t pos = 0; pos < n; pos += piece, k++) {
+                int64_t got = 0;
+                const PipePiece pp{k};
+                // (a last piece shorter than half a piece rides with the one before it: the arrays' halves hold a piece and a half)
+                int64_t len = (n - pos < piece) ? n - pos : piece;
+                if (n - pos - len > 0 && n - pos - len < piece / 2 && (rows * 3) / 2 + 2 <= half) len = n - pos;
+                const int rc = run_call_one(h, reinterpret_cast<const char *>(d_iq) + pos * bps, fmt, s16_den, stream_stride, len, d_pcm + total, pcm_stride, &got, h->pipe_sB, &pp);
+                if (rc) { (void)hipDeviceSynchronize(); return rc; }
+                total += got;
+                if (len > piece) pos += len - piece;
+            }
+            HIPCHK(hipEventRecord(h->pipe_evE, h->pipe_sB)); HIPCHK(hipStreamWaitEvent(s, h->pipe_evE, 0));
+            h->last_pieces = k;
+            if (n_frames) *n_frames = total;
+            return FMX_OK;
+        }
+    }
     if (!any_rds || n <= PIECE || fmt < 0 || fmt > 3 || n > h->cfg.max_block) return run_call_one(h, d_iq, fmt, s16_den, stream_stride, n, d_pcm, pcm_stride, n_frames, s);
     {
         CallGeom G{}; frames_geom(h, n, &G);
@@ -759,7 +826,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
 }
 
 int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
-                 int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
+                 int64_t pcm_stride, int64_t *n_frames, hipStream_t s, const PipePiece *pp) {
     if (fmt < 0 || fmt > 3) return fail(FMX_E_INVALID, "unknown IQ format");
     if (fmt == 3) {
         int ex = 0; const float m = std::frexp(s16_den, &ex);
@@ -777,11 +844,16 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     if (frames > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
     if (h->rds_alloc && any_rds_on(h) && G.J1 - G.J0 > RDS_BLK)
         return fail(FMX_E_TOO_LARGE, "with RDS on, a call may cover at most 32000 fm samples (384000 input samples)");
+    // (a piece of an overlapping call: stage A on its own stream, behind what the caller's stream held when the call began)
+    // (FMX_CALL_PIECES_SERIAL=1, a diagnostic read per call: the same pieces one after the other on the caller's stream -- what the overlapping run must equal bit for bit)
+    const bool piped = pp != nullptr && !h->ola_mode && !(getenv("FMX_CALL_PIECES_SERIAL") && atoi(getenv("FMX_CALL_PIECES_SERIAL")) != 0);
+    hipStream_t sa = piped ? h->pipe_sA : s;
+    G.host_count1 = piped ? h->my_count_host + 1 : 0;
     ProfRec pr{}; const bool prof = h->prof_on;
     if (prof) {
         for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&pr.e[i]));
         pr.in_samples = n * h->streams; pr.ch_samples = n * h->channels;
-        HIPCHK(hipEventRecord(pr.e[0], s));
+        HIPCHK(hipEventRecord(pr.e[0], sa));
     }
     g_launch_err = hipSuccess;
     h->B.lin_rows = (int32_t)h->work_nj;
@@ -818,15 +890,30 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         CallGeom Gp = G; Gp.pre_processed = 1; Gp.iq_format = 0; Gp.iq_scale = 1.0f; Gp.stream_stride = h->cfg.max_block; Gp.streams_private = h->twins == 1 ? 1 : 0;
         launch_front(h->T, h->B, Gp, h->d_u, h->channels, s);
     } else
-    launch_front(h->T, h->B, G, d_iq, h->channels, s);   // stage A: four waves per channel, packed-FMA FIR (fmx_front.hip)
+    launch_front(h->T, h->B, G, d_iq, h->channels, sa);   // stage A: four waves per channel, packed-FMA FIR (fmx_front.hip)
     FMX_LAUNCHED();
     static const bool prof_double = getenv("FMX_PROF_DOUBLE") != nullptr;    // (diagnostic: a throw-away event in front of each boundary event)
     if (prof && prof_double && !h->ev_dummy) HIPCHK(hipEventCreate(&h->ev_dummy));      // (one per handle, destroyed with it)
     hipEvent_t pdummy = h->ev_dummy;
-    if (prof && prof_double) HIPCHK(hipEventRecord(pdummy, s));
-    if (prof) HIPCHK(hipEventRecord(pr.e[1], s));
+    if (prof && prof_double) HIPCHK(hipEventRecord(pdummy, sa));
+    if (prof) HIPCHK(hipEventRecord(pr.e[1], sa));
     G.stageb_form = h->stageb_form.load(); G.no_deemph = h->ola_mode ? 1 : 0;
+    if (piped) {
+        // the pre-pass of this piece: its parallel part (disc_kernel) behind the piece's stage A on that stream -- and behind the stage B that read the half
+        // of the work arrays it is about to overwrite --, the recurrences on theirs, the noise squelch's pipeline and stage B on `s`
+        if (pp->k >= 2) HIPCHK(hipStreamWaitEvent(sa, h->pipe_evB[pp->k & 1], 0));
+        DeviceBuffers Bk = h->B;
+        if (pp->k & 1) { const size_t off = (size_t)((h->work_nj / 2) & ~(int64_t)15) * (size_t)h->pitch; Bk.w_iq += off; Bk.w_osc += off; }
+        const PrepassStreams ps{sa, h->pipe_sP, h->pipe_evD, h->pipe_evP};
+        launch_demod_fused(h->T, Bk, G, h->channels, s, &ps);
+        HIPCHK(hipEventRecord(h->pipe_evB[pp->k & 1], s));
+    } else
     launch_demod_fused(h->T, h->B, G, h->channels, s);      // (with its pre-pass for the PLL / AM decoders and the squelches)
+    if (G.J1 > G.J0) {       // (stage B's bookkeeping behind the call, fmx_stageb.hip)
+        int cnt = h->my_count_host + (int)(G.J1 - G.J0);
+        if (cnt > (SINCOS_N >> 1)) cnt -= (SINCOS_N >> 1) + 1;
+        h->my_count_host = cnt;
+    }
     if (h->rds_alloc && any_rds_on(h)) {
         const int64_t nj = G.J1 - G.J0;
         int modes = 0;
@@ -1212,6 +1299,8 @@ int fmx_destroy(fmx_handle h) {
     for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);
     if (h->hp_iq) (void)hipHostFree(h->hp_iq);
     if (h->hp_pcm) (void)hipHostFree(h->hp_pcm);
+    for (hipStream_t st : {h->pipe_sA, h->pipe_sP, h->pipe_sB}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : {h->pipe_ev0, h->pipe_evA, h->pipe_evD, h->pipe_evP, h->pipe_evE, h->pipe_evB[0], h->pipe_evB[1]}) if (e) (void)hipEventDestroy(e);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_dummy) (void)hipEventDestroy(h->ev_dummy);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1246,6 +1335,9 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_SCOPE_TAPS:
         if (iv < -1 || iv > 1) return fail(FMX_E_INVALID, "scope taps must be -1 (automatic), 0 (not kept) or 1 (kept)");
         h->scope_taps.store(iv); return FMX_OK;
+    case FMX_P_CALL_PIECES:
+        if (iv < -1 || iv > (1 << 20)) return fail(FMX_E_INVALID, "call pieces must be -1 (automatic), 0 (never) or the fm samples per piece");
+        h->pipe_rows.store(iv); return FMX_OK;
     case FMX_P_FRONT_PARTS:
         if (iv < 0 || iv > 32) return fail(FMX_E_INVALID, "front parts must be 0 (automatic), 1 (one workgroup per channel) or 2..32");
         h->front_parts.store(iv); return FMX_OK;
@@ -1578,6 +1670,7 @@ int64_t fmx_pll_exact_segments(fmx_handle h, int32_t channel) {
     return n;
 }
 int32_t fmx_last_front_kernel(fmx_handle h) { return h ? h->last_front_kernel : 0; }
+int32_t fmx_last_call_pieces(fmx_handle h) { return h ? h->last_pieces : 0; }
 int64_t fmx_last_rds_samples_of(fmx_handle h, int32_t channel) {
     if (!h || !h->rds_alloc || channel < 0 || channel >= h->channels) return 0;
     return h->last_m1[(size_t)channel] - h->last_m0[(size_t)channel];

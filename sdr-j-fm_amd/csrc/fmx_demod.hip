@@ -16,6 +16,7 @@
 // Round 1 / 2 ran ALL of stage B on kernels of this kind (a five-stream chunk pipeline, then one persistent recurrence kernel with
 // progress words): removed in round 3 -- the fused kernel is 2.5x faster and has no co-residency assumption.
 #include "fmx_internal.h"
+#include <type_traits>
 #include "fmx_demod_math.h"
 
 namespace fmx {
@@ -259,7 +260,7 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     if (!(decoder <= 2 || B.params[ch].squelch_mode != 0)) return;      // (the fused kernel does this channel's demodulator itself)
     const bool use_pll = HAS_PLL && (!MIXED || decoder == 2), use_am = HAS_AM && (!MIXED || decoder == 1);
     // the sample behind which the reference takes its metaData snapshot (++myCount > fmRate / 2, fm-processor.cpp:662-684), row of this call
-    const int64_t snap_row = (int64_t)(SINCOS_N >> 1) - st->my_count;
+    const int64_t snap_row = (int64_t)(SINCOS_N >> 1) - (G.host_count1 ? G.host_count1 - 1 : st->my_count);
     // level squelch (squelch::do_level_squelch squelchClass.cpp:89-113, fm-processor.cpp:504-506): the carrier amplitude IIR
     // of the demodulator (fm-demodulator.cpp:130-131) against a threshold, re-evaluated every fmRate / 20 samples
     const bool lsq = HAS_LSQ && (B.params[ch].squelch_mode == 2);
@@ -281,7 +282,8 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     const bool any_pll = HAS_CHAIN && (!MIXED || __any(use_pll || use_am)), any_am = HAS_AM && (!MIXED || __any(use_am)), any_lsq = HAS_LSQ && __any(lsq);
     const bool on_pll = !MIXED || use_pll || use_am;
     const float beta = T.pll_beta, omb = 1 - T.pll_beta, plo = T.pll_lo, phi = T.pll_hi, pce = T.pll_center;
-    auto step = [&](float res, float2 sig) __attribute__((always_inline)) -> float {
+    // (decide: a level-squelch decision may fall due at this sample -- one tile in 600 has one; the others are walked without the look-out)
+    auto step = [&](float res, float2 sig, auto decide) __attribute__((always_inline)) -> float {
         float r_am = 0.f;
         // |z| arrives in the demod array for the AM and PLL decoders, in the first half of the IQ array otherwise (disc_kernel)
         if ((HAS_AM || HAS_LSQ) && (any_am || any_lsq)) {
@@ -323,12 +325,14 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
             // (squelch::do_level_squelch squelchClass.cpp:89-113; a lane's decision falls due once in fmRate / 20 samples: the wave looks for
             // one with a single test per sample and takes the decisions behind it)
             sq_cnt += lsq ? 1 : 0;
-            const bool hold = lsq && sq_cnt >= SINCOS_N / 20;      // holdPeriod = fmRate / 20 (fm-processor.cpp:87)
-            if (__any(hold)) {
-                const bool sup2 = am < sq_thr - 0.000f ? true : (am >= sq_thr + 0.000f ? false : sq_sup);   // SQUELCH_HYSTERESIS_LSQ = 0
-                sq_sup = hold ? sup2 : sq_sup;
-                sq_cnt = hold ? 0 : sq_cnt;
-                sq_mute = lsq && sq_sup;
+            if (decltype(decide)::value) {
+                const bool hold = lsq && sq_cnt >= SINCOS_N / 20;      // holdPeriod = fmRate / 20 (fm-processor.cpp:87)
+                if (__any(hold)) {
+                    const bool sup2 = am < sq_thr - 0.000f ? true : (am >= sq_thr + 0.000f ? false : sq_sup);   // SQUELCH_HYSTERESIS_LSQ = 0
+                    sq_sup = hold ? sup2 : sq_sup;
+                    sq_cnt = hold ? 0 : sq_cnt;
+                    sq_mute = lsq && sq_sup;
+                }
             }
             r = sq_mute ? r * 0.000f : r;                    // LEVELREDUCTIONFACTOR = 0
         }
@@ -339,7 +343,7 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     auto slow_rows = [&](int k0, int k1) __attribute__((always_inline)) {
 #pragma unroll 1
         for (int k = k0; k < k1; k++) {
-            const float r = step(wd[(k / WT) * (WT * CP) + (k % WT)], HAS_IQ ? wiq[(k / WT) * (WT * CP) + (k % WT)] : make_float2(0.f, 0.f));
+            const float r = step(wd[(k / WT) * (WT * CP) + (k % WT)], HAS_IQ ? wiq[(k / WT) * (WT * CP) + (k % WT)] : make_float2(0.f, 0.f), std::true_type{});
             if ((int64_t)k == snap_row) st->meta_dc_if = afc;
             wd[(k / WT) * (WT * CP) + (k % WT)] = r;
         }
@@ -358,14 +362,19 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
             // (the metaData snapshot falls into one tile in 750: looked for once per tile, for the whole wave, and that tile walked row by row)
             if (__any(snap_row >= (int64_t)tb * UB && snap_row < (int64_t)(tb + 1) * UB)) { slow_rows(tb * UB, (tb + 1) * UB); return; }
             float x[UB];
+            auto samples = [&](auto decide) __attribute__((always_inline)) {
 #pragma unroll
-            for (int k = 0; k < UB; k++) {
-                const int ss = HAS_IQ ? s : 0, uu = HAS_IQ ? u : 0;
-                const float2 xq = !HAS_IQ ? make_float2(0.f, 0.f)
-                                  : (k < UB / 2 ? make_float2(nqa[ss][uu][2 * k], nqa[ss][uu][2 * k + 1])
-                                                : make_float2(nqb[ss][uu][(2 * k) % UB], nqb[ss][uu][(2 * k) % UB + 1]));
-                x[k] = step(nx[s][u][k], xq);
-            }
+                for (int k = 0; k < UB; k++) {
+                    const int ss = HAS_IQ ? s : 0, uu = HAS_IQ ? u : 0;
+                    const float2 xq = !HAS_IQ ? make_float2(0.f, 0.f)
+                                      : (k < UB / 2 ? make_float2(nqa[ss][uu][2 * k], nqa[ss][uu][2 * k + 1])
+                                                    : make_float2(nqb[ss][uu][(2 * k) % UB], nqb[ss][uu][(2 * k) % UB + 1]));
+                    x[k] = step(nx[s][u][k], xq, decide);
+                }
+            };
+            // (the variant with everything in it keeps one form of the tile: its loop is 120 KB of code as it is)
+            if (HAS_LSQ && (VAR == AV_ALL || (any_lsq && __any(lsq && sq_cnt + UB >= SINCOS_N / 20)))) samples(std::true_type{});
+            else samples(std::false_type{});
             wst(wd + tb * TS, x);
         });
     slow_rows(nfull * UB, chunk_len);                             // ragged end of a call: rows of the last, partial tile
@@ -414,14 +423,45 @@ __global__ __launch_bounds__(64) void nsq_kernel(DeviceTables T, DeviceBuffers B
     float *wd = B.w_dem + widx(0, chs, CP);                                 // (prepass: w_dem = w_osc, 16-row tiles; tile t of this channel at + t * 16 * CP)
     const int TS = WT * CP;
     const double k1 = 1.0 / (double)(float)(SINCOS_N / 100), k2 = 1.0 - k1;   // decayingAverage squelchClass.cpp:40-45, weight = sampleRate / 100, in double
-    float xin[WT], xout[WT], xtail[WT];                                      // the tile the first lanes feed from; the tile the last lane is muting
+    // The tiles come from HBM / Infinity Cache with ~1.4 us of latency and a pipeline wave has nothing else to run meanwhile: every lane that reads a
+    // tile at all (the cascades' first lanes: the input; the low-pass's last lane: the values it mutes, nine samples behind) takes tile t + 2 while
+    // the wave steps through tile t -- four register slots in rotation, the loop unrolled by four so that the slots are compile-time names.
+    float xs[4][WT], xout[WT];
 #pragma unroll
-    for (int i = 0; i < WT; i++) { xin[i] = 0.f; xout[i] = 0.f; xtail[i] = 0.f; }
+    for (int i = 0; i < WT; i++) { xs[0][i] = 0.f; xs[1][i] = 0.f; xs[2][i] = 0.f; xs[3][i] = 0.f; xout[i] = 0.f; }
     float o = 0.f;                                                         // this lane's output of the previous step
     const int nsteps = nrows + NSQ_QUADS - 1;
-    for (int s0 = 0; s0 < nsteps + WT; s0 += WT) {
-        // the first lanes take tile s0 / 16 of the input; the last low-pass lane takes the tile whose samples it will mute in these steps
-        if (mine && first && s0 < nrows) wld(xin, wd + (s0 / WT) * TS);
+    const int ntiles = (nrows + WT - 1) / WT;
+    // (clamped, never conditional -- a load behind a branch makes the compiler wait for every load in flight at the next use; the lanes that read
+    // nothing load their channel's tile as well, into registers nobody looks at)
+    auto take = [&](float *dst, int t) __attribute__((always_inline)) { wld(dst, wd + (t < ntiles ? t : ntiles - 1) * TS); };
+    take(xs[0], 0); take(xs[1], 1);
+    constexpr int LAG = NSQ_QUADS - 1;
+    constexpr int HOLD = SINCOS_N / 20;
+    // A tile in the steady state -- every lane of a cascade on a sample of the call, no decision due in any of the wave's channels (one in 600 tiles
+    // has one) -- is walked without a test: the operations of the general form below, on every lane, the results of the lanes they do not concern
+    // never looked at.  (The general form costs 115 instructions per step, most of them the exec-mask bookkeeping of its conditions, and a lone wave
+    // issues one every four to five cycles: 3.9 ms per call; this form has 25.)
+    auto fast_tile = [&](int t, const float *cur, const float *prev) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WT; i++) {
+            const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o), 0x138, 0xf, 0xf, false));
+            const float in = first ? cur[i] * gain : up;
+            const float w = in - m1 * c2 - m2 * c3;
+            o = w + m1 * c0 + m2 * c1;
+            m2 = m1; m1 = w;
+            avg = (float)((double)fabsf(o) * k1 + (double)avg * k2);
+            const int ti = (i + WT - LAG) & (WT - 1);
+            const float xv = i >= LAG ? cur[ti] : prev[ti];
+            xout[ti] = sq_sup ? xv * 0.000f : xv;
+            if (ti == WT - 1 && mine && last && f == 1) wst(wd + (t - 1) * TS, xout);      // (i = 8: sample t * 16 - 1, the previous tile's last)
+        }
+        sq_cnt += WT;
+    };
+    // the general form: the pipeline's fill and drain, the tiles with a decision point.  Every lane of a channel counts the samples its cascades' last lanes
+    // have taken and takes the channel's decisions with them.
+    auto tile = [&](int t, const float *cur, const float *prev) __attribute__((always_inline)) {
+        const int s0 = t * WT;
 #pragma unroll
         for (int i = 0; i < WT; i++) {
             const int s = s0 + i;
@@ -429,21 +469,21 @@ __global__ __launch_bounds__(64) void nsq_kernel(DeviceTables T, DeviceBuffers B
             const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o), 0x138, 0xf, 0xf, false));     // the lane below, previous step
             const bool act = mine && n >= 0 && n < nrows;
             if (act) {
-                const float in = first ? xin[i] * gain : up;                // Basic_IIR::Pass: o = in * gain, then the quads
+                const float in = first ? cur[i] * gain : up;                // Basic_IIR::Pass: o = in * gain, then the quads
                 const float w = in - m1 * c2 - m2 * c3;
                 o = w + m1 * c0 + m2 * c1;
                 m2 = m1; m1 = w;
             }
             const bool tail = act && last;
             if (tail) avg = (float)((double)fabsf(o) * k1 + (double)avg * k2);
-            // the two cascades' last lanes work on the same sample in the same step and count it; at a decision point (squelchClass.cpp:60-75:
-            // every fmRate / 20 samples) they exchange their averages -- only then -- and both take the decision
+            // the two cascades' last lanes work on the same sample in the same step; at a decision point (squelchClass.cpp:60-75: every fmRate / 20
+            // samples) the channel's lanes fetch the two averages -- only then -- and take the decision
+            const bool counted = mine && s - LAG >= 0 && s - LAG < nrows;
             bool hit = false;
-            if (tail) { hit = ++sq_cnt >= SINCOS_N / 20; sq_cnt = hit ? 0 : sq_cnt; }
+            if (counted) { hit = ++sq_cnt >= HOLD; sq_cnt = hit ? 0 : sq_cnt; }
             if (__any(hit)) {
-                const float other = __shfl(avg, lane + (f ? -NSQ_QUADS : NSQ_QUADS), 64);
+                const float avg_hi = __shfl(avg, k * NSQ_LANES + NSQ_QUADS - 1, 64), avg_lo = __shfl(avg, k * NSQ_LANES + 2 * NSQ_QUADS - 1, 64);
                 if (hit) {
-                    const float avg_hi = f ? other : avg, avg_lo = f ? avg : other;
                     if (thr < 0.001f) sq_sup = true;                       // SQUELCH_HYSTERESIS_NSQ = 0.001
                     else if (avg_hi < avg_lo * thr - 0.001f) sq_sup = false;
                     else if (avg_hi >= avg_lo * thr + 0.001f) sq_sup = true;
@@ -451,17 +491,25 @@ __global__ __launch_bounds__(64) void nsq_kernel(DeviceTables T, DeviceBuffers B
             }
             if (tail) {
                 if (f == 1) {
-                    // (sample n = s - 9 sits at place (i + 7) mod 16 of tile n / 16 -- a constant of the unrolled step: xtail holds that tile's
-                    // input, xout collects the muted values; rows of the last tile behind the call's last sample are nobody's)
-                    constexpr int LAG = NSQ_QUADS - 1;
+                    // (sample n = s - 9 sits at place (i + 7) mod 16 of tile n / 16 -- a constant of the unrolled step: the first nine steps of a
+                    // tile mute the previous tile's last nine values, xout collects the muted values; rows of the last tile behind the call's last
+                    // sample are nobody's)
                     const int ti = (i + WT - LAG) & (WT - 1);
-                    if (ti == 0) wld(xtail, wd + (n / WT) * TS);
-                    const float r = sq_sup ? xtail[ti] * 0.000f : xtail[ti];
+                    const float xv = i >= LAG ? cur[ti] : prev[ti];
+                    const float r = sq_sup ? xv * 0.000f : xv;
                     xout[ti] = r;
                     if (ti == WT - 1 || n == nrows - 1) wst(wd + (n / WT) * TS, xout);
                 }
             }
         }
+    };
+    auto walk = [&](int t, const float *cur, const float *prev, float *ahead) __attribute__((always_inline)) {
+        take(ahead, t + 2);
+        const bool steady = t >= 1 && (t + 1) * WT <= nrows && !__any(mine && sq_cnt + WT >= HOLD);
+        if (steady) fast_tile(t, cur, prev); else tile(t, cur, prev);
+    };
+    for (int t = 0; t * WT < nsteps + WT; t += 4) {
+        walk(t, xs[0], xs[3], xs[2]); walk(t + 1, xs[1], xs[0], xs[3]); walk(t + 2, xs[2], xs[1], xs[0]); walk(t + 3, xs[3], xs[2], xs[1]);
     }
     if (mine) { st->sq_m[f][q][0] = m1; st->sq_m[f][q][1] = m2; }
     if (mine && last) {
@@ -469,12 +517,15 @@ __global__ __launch_bounds__(64) void nsq_kernel(DeviceTables T, DeviceBuffers B
     }
 }
 
-void launch_demod_prepass(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s) {
+void launch_demod_prepass(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s_main, const PrepassStreams *ps) {
     const int64_t nj = G.J1 - G.J0;
     if (nj <= 0) return;
     DeviceBuffers Bp = B;
     Bp.prepass = 1; Bp.lin_rows = 0; Bp.w_dem = B.w_osc;          // (the tiled work arrays of the two kernels: w_osc takes the demodulator output)
+    // (whole calls: everything on the caller's stream.  Pieces of an overlapping call: see PrepassStreams)
+    hipStream_t s = ps ? ps->s_disc : s_main;
     hipLaunchKernelGGL(disc_kernel, dim3((unsigned)((nj + DISC_ROWS - 1) / DISC_ROWS), (unsigned)((C + DISC_CH - 1) / DISC_CH)), dim3(256), 0, s, T, Bp, G, C, (int64_t)0, (int)nj); FMX_LAUNCHED();
+    if (ps) { note_hip(hipEventRecord(ps->ev_disc, ps->s_disc)); note_hip(hipStreamWaitEvent(ps->s_afc, ps->ev_disc, 0)); s = ps->s_afc; }
     {
         const dim3 ga((unsigned)((C + 63) / 64));
         switch (B.prepass_var) {          // (what the handle's channels use: fmx_api.hip)
@@ -488,6 +539,7 @@ void launch_demod_prepass(const DeviceTables &T, const DeviceBuffers &B, const C
         }
         FMX_LAUNCHED();
     }
+    if (ps) { note_hip(hipEventRecord(ps->ev_afc, ps->s_afc)); note_hip(hipStreamWaitEvent(s_main, ps->ev_afc, 0)); s = s_main; }
     if (T.nsq_coef) {        // (some channel has, or had, the noise squelch on: fmx_api.hip uploads the coefficients then)
         hipLaunchKernelGGL(nsq_kernel, dim3((unsigned)((C + NSQ_CH_PER_WAVE - 1) / NSQ_CH_PER_WAVE)), dim3(64), 0, s, T, Bp, G, C, (int)nj); FMX_LAUNCHED();
     }

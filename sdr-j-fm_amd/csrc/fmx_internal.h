@@ -233,6 +233,9 @@ struct CallGeom {
                              // (fmx_front4.hip: the filter on the matrix pipe; RfDC taken 12 columns back in every tap set as well); launch_front
                              // gives it the whole tiles of a call that starts on a column boundary, front_kernel the remainder and everything else
     int32_t cont;            // front_kernel: this launch continues a call whose head another launch has made (the one-shot actions are done)
+    int32_t host_count1;     // != 0: the demodulator pre-pass takes the reference's myCount (fm-processor.cpp:662) in front of this call from here (the count
+                             // + 1) instead of the channel state -- a call made in overlapping pieces (fmx_api.hip: run_call), where the previous piece's
+                             // stage B, which keeps the count, may still be running
     int32_t parts, part_tiles;   // stage A, handles that leave the chip empty (one workgroup per channel, few channels): a channel's tiles are
                              // split in time over `parts` workgroups of `part_tiles` tiles each (FMX_P_FRONT_PARTS); parts <= 1: one per channel
 };
@@ -392,9 +395,12 @@ inline void note_hip(hipError_t e) { if (e != hipSuccess && g_launch_err == hipS
 #define FMX_LAUNCHED() ::fmx::note_hip(hipGetLastError())
 // the demodulators with a recurrence of their own (PLL / AM decoder, squelches), one lane per channel over the whole call, in front of
 // the fused kernel and on the same stream (fmx_demod.hip: disc_kernel + afc_kernel<true> with DeviceBuffers::prepass set)
-void launch_demod_prepass(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
+// A call made in overlapping pieces (fmx_api.hip run_call) spreads the pre-pass over streams: disc_kernel (a parallel kernel) behind the piece's stage A,
+// the lone-wave recurrences of afc_kernel on a stream of their own (with compute units of their own), nsq_kernel and stage B on `s`.
+struct PrepassStreams { hipStream_t s_disc, s_afc; hipEvent_t ev_disc, ev_afc; };
+void launch_demod_prepass(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s, const PrepassStreams *ps = nullptr);
 // stage B as one time-parallel workgroup per channel and segment (fmx_stageb.hip): everything on the caller's stream
-void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s);
+void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s, const PrepassStreams *ps = nullptr);
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,
                   int channels, hipStream_t s);
 // second converter workingRate -> audioRate (fm-processor.cpp:825-838): x48 = [channels][x_stride] with nt history frames in front of

@@ -1610,9 +1610,9 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
 #undef B
 #undef G
 
-void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s) {
+void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int C, hipStream_t s, const PrepassStreams *ps) {
     if (G.J1 - G.J0 <= 0) return;
-    if (B.w_iq) launch_demod_prepass(T, B, G, C, s);     // some channel has (had) a PLL / AM decoder or a squelch: fmx_demod.hip
+    if (B.w_iq) launch_demod_prepass(T, B, G, C, s, ps);     // some channel has (had) a PLL / AM decoder or a squelch: fmx_demod.hip
     StageBArgs A; A.T = T; A.B = B; A.G = G; A.C = C;
     // One kernel or two?  Per channel both forms cost the same (measured, 256 ... 4096 channels: the kernel is bound by instruction
     // issue, a fourth workgroup per CU adds nothing), what differs is the tail: the whole kernel runs 3 workgroups per CU, its halves 4,

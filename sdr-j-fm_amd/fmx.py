@@ -24,6 +24,7 @@ P_DISP_DELAY = 20
 P_STAGEB_FORM = 22            # handle-wide: 0 automatic, 1 stage B as one kernel per call, 2 as two (bit-identical results)
 P_FRONT_KERNEL = 25           # handle-wide: 0 automatic, 1 fmx_front.hip (packed f32 FMAs), 2 fmx_front3.hip (the same on six waves), 3 fmx_front4.hip (f16-split matrix FIR)
 P_SCOPE_TAPS = 26             # handle-wide: -1 automatic (up to 64 channels), 0 the display feeds (demodulator / LR / pilot-phase scope taps, peak meter) are not produced, 1 produced
+P_CALL_PIECES = 27            # handle-wide: -1 automatic, 0 never, n > 0 fm samples per piece of a call made in overlapping pieces (pre-pass batches)
 P_FRONT_PARTS = 24            # handle-wide: 0 automatic, 1 one workgroup per channel, 2..32 parts in time per channel (bit-identical results)
 P_FILTER_RESTARTS = 23        # handle-wide, before the first call: 0 automatic, 1 the reference's block filters (<= 64 channels), 2 folded FIRs
 P_PLL_SOLVER = 21             # 0 automatic, 1 sequential (the reference's trajectory), 2 Newton while in lock + sequential around lock decisions, 3 Newton always
@@ -36,7 +37,7 @@ EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
     "fmx_get_meta", "fmx_get_tap", "fmx_get_peaks",
-    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_pll_exact_segments", "fmx_last_front_kernel", "fmx_last_rds_samples", "fmx_last_rds_samples_of", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
+    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_pll_exact_segments", "fmx_last_front_kernel", "fmx_last_call_pieces", "fmx_last_rds_samples", "fmx_last_rds_samples_of", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
 
@@ -147,6 +148,8 @@ def load_library(path=None):
     L.fmx_pll_exact_segments.restype = C.c_int64
     L.fmx_last_front_kernel.restype = C.c_int32
     L.fmx_last_front_kernel.argtypes = [vp]
+    L.fmx_last_call_pieces.restype = C.c_int32
+    L.fmx_last_call_pieces.argtypes = [vp]
     L.fmx_pll_exact_segments.argtypes = [vp, C.c_int32]
     L.fmx_last_rds_samples.restype = C.c_int64
     L.fmx_last_rds_samples.argtypes = [vp]
@@ -293,6 +296,10 @@ class Fmx:
     def last_front_kernel(self):
         """Which kernel ran the input-filter stage of the last call (fmx_last_front_kernel: FMX_P_FRONT_KERNEL's numbering)."""
         return int(self.L.fmx_last_front_kernel(self.h))
+
+    def last_call_pieces(self):
+        """Overlapping pieces the last call was made in (fmx_last_call_pieces, P_CALL_PIECES; 1: whole)."""
+        return int(self.L.fmx_last_call_pieces(self.h))
 
     def last_rds_samples(self, channel=0):
         """24 kS/s RDS samples the last call produced on `channel` (fmx_last_rds_samples_of): the n that tap(TAP_RDS_IQ, n, channel) accepts."""
