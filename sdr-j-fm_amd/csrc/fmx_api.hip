@@ -769,15 +769,18 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         const int64_t rows = want > 0 ? ((want + 15) / 16) * 16 : (chain ? PIPE_ROWS_AUTO : PIPE_ROWS_AUTO_SQ);
         const int64_t half = (h->work_nj / 2) & ~(int64_t)15;
         const int64_t piece = rows * h->decim;
-        if (special && want != 0 && h->B.w_iq && !h->ola_mode && !h->cv_nt && (want > 0 || h->channels >= PIPE_MIN_CHANNELS) && rows + 2 <= half && n >= 2 * piece) {
+        // (only these batches.  Measured: the headline's batch -- no pre-pass; stage A bound by HBM, stage B by instruction issue -- made in 13 / 6 / 4 / 3 overlapping
+        // pieces takes 4.97 / 3.89 / 3.60 / 3.60 ms per step against 3.46 whole: stage B's workgroups fill the register files, the stages do not share a CU)
+        if (special && h->B.w_iq && want != 0 && !h->ola_mode && !h->cv_nt && (want > 0 || h->channels >= PIPE_MIN_CHANNELS) && rows + 2 <= half && n >= 2 * piece) {
             {
                 CallGeom G{}; frames_geom(h, n, &G);
                 if (conv2_out(h, G.M1) - conv2_out(h, G.M0) > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
             }
             if (!h->pipe_sA) {
-                // (plain streams, the recurrences' with priority.  Measured and not kept: compute units of their own for the recurrences -- masked streams,
-                // 16 CUs for 64 waves: the dispatcher does not put one wave on each SIMD of a CU, and two lone waves on one SIMD are slower than a lone wave
-                // among stage A's or B's: 300 ns per sample against 270, and 216 with the chip to itself; 6.7 against 6.0 ms per step)
+                // (plain streams, the recurrences' with priority.  Measured and not kept: compute units of their own for the recurrences -- CU-masked streams,
+                // 16 / 32 / 64 CUs for the 64 waves, the rest for the other streams: 6.7 / 6.3 / 6.0 ms per step against 6.2 without masks.  A lone wave walks a
+                // sample in 216 ns with the chip to itself and in 270-300 ns while the other stages run, on CUs of its own or not: what it loses is the
+                // chip's clock under load, not its SIMD.)
                 int lo = 0, hi = 0;
                 HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
                 HIPCHK(hipStreamCreateWithPriority(&h->pipe_sA, hipStreamNonBlocking, lo));
@@ -898,6 +901,7 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     if (prof && prof_double) HIPCHK(hipEventRecord(pdummy, sa));
     if (prof) HIPCHK(hipEventRecord(pr.e[1], sa));
     G.stageb_form = h->stageb_form.load(); G.no_deemph = h->ola_mode ? 1 : 0;
+    if (piped) { HIPCHK(hipEventRecord(h->pipe_evA, sa)); HIPCHK(hipStreamWaitEvent(s, h->pipe_evA, 0)); }      // (stage B of this piece behind its stage A)
     if (piped) {
         // the pre-pass of this piece: its parallel part (disc_kernel) behind the piece's stage A on that stream -- and behind the stage B that read the half
         // of the work arrays it is about to overwrite --, the recurrences on theirs, the noise squelch's pipeline and stage B on `s`
