@@ -391,11 +391,16 @@ __global__ __launch_bounds__(64 * am::WV) void audio_mfma_kernel(DeviceTables T,
 // the resampler, so PCM frame m = sum_k h_rs[k] g(4 m + 3 - k) a[4 m + 3 - k] with a = audio low-pass output; for the frames
 // whose window reaches behind the call's first fm sample J0 the old gain still weighs in.  audio_kernel computes
 // g_new * (folded FIR); this kernel computes the rest, (g_old - g_new) * sum over the window entries older than J0, for the
-// call's first 32 frames: A[q] = a[J0 - q] (q = 1 .. 127, one thread each, 756 taps of the d ring), then
+// call's first frames: A[q] = a[J0 - q] (one thread each, 756 taps of the d ring), then
 // corr[r] = sum_q h_rs[e_r + q] A[q], e_r = 4 (M0 + r) + 3 - J0.  One workgroup per channel; channels whose gain did not change
 // write zeros.  Also records the gains for the next change.
-__global__ __launch_bounds__(128) void gain_fix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int channels) {
-    __shared__ float2 A[RS_TAPS];
+// The call's frames begin at the 192-sample block J0 falls into: e_0 is 3 when J0 is a multiple of 192 and as low as -188 otherwise -- a frame
+// whose whole window lies in front of J0 reaches q = 127 - e_r <= 315 samples back, and frames up to r = 78 still straddle J0.  (Rounds 2-5 kept 128
+// entries and 32 frames: right for calls of whole 192-sample blocks, the bench's and most tests'; otherwise the first -e_0 / 4 frames summed LDS
+// beyond A[] -- whatever the CU's previous workgroup had left there: 1e-4 on five frames of a channel, differently from channel to channel -- and
+// frames 32 ... 78 went without their part.  Found by test_call_made_in_overlapping_pieces_against_the_oracle's twins.)
+__global__ __launch_bounds__(GAIN_FIX_BACK) void gain_fix_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, int channels) {
+    __shared__ float2 A[GAIN_FIX_BACK];
     const int ch = blockIdx.x, t = threadIdx.x;
     const ChanParams &P = B.params[ch];
     ChanState *st = &B.state[ch];
@@ -428,8 +433,7 @@ __global__ __launch_bounds__(128) void gain_fix_kernel(DeviceTables T, DeviceBuf
     if (t < GAIN_FIX_FRAMES) {
         const int e = (int)(4 * (G.M0 + t) + 3 - G.J0);           // newest window entry of frame M0 + t, relative to J0
         float2 c = make_float2(0.f, 0.f);
-        for (int q = 1; e + q < RS_TAPS; q++) {
-            if (e + q < 0) continue;
+        for (int q = (e < -1 ? -e : 1); q < GAIN_FIX_BACK && e + q < RS_TAPS; q++) {
             const float h = T.rs_taps[e + q];
             c.x = fmaf(h, A[q].x, c.x); c.y = fmaf(h, A[q].y, c.y);
         }
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(128) void gain_fix_kernel(DeviceTables T, DeviceBuf
 }
 
 void launch_gain_fix(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, int channels, hipStream_t s) {
-    hipLaunchKernelGGL(gain_fix_kernel, dim3(channels), dim3(128), 0, s, T, B, G, channels);
+    hipLaunchKernelGGL(gain_fix_kernel, dim3(channels), dim3(GAIN_FIX_BACK), 0, s, T, B, G, channels);
 }
 
 void launch_audio(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, float2 *pcm,

@@ -22,7 +22,9 @@ constexpr int C_MAX_TAPS = AUDIO_TAPS + RS_TAPS - 1;   // 883
 constexpr int C_TAPS_STRIDE = 896;     // padded
 constexpr int C_TILE = 256;            // PCM frames per audio-FIR tile
 constexpr int AM_TAB = 1152;           // entries of a tap table of audio_mfma_kernel (fmx_audio.hip)
-constexpr int GAIN_FIX_FRAMES = RS_TAPS / 4;   // PCM frames whose resampler memory straddles a gain change (32)
+constexpr int GAIN_FIX_BACK = RS_TAPS + 192;   // fm samples in front of a call's first that its first frames' resampler windows can reach: a call's frames begin at the
+                                               // 192-sample block its first fm sample falls into (frames_geom: M0 = 48 (J0 / 192)), up to 191 samples before J0
+constexpr int GAIN_FIX_FRAMES = GAIN_FIX_BACK / 4;   // PCM frames whose resampler memory straddles a gain change (80; 32 when J0 is a multiple of 192)
 constexpr int NSQ_QUADS = 10;          // ((20 + 1) & 0176) / 2 biquads per filter (iir-filters.cpp:454)
 constexpr int TT_SILENT = 96001;       // ++TimePeriodCounter > workingRate * 2.0f fires on the 96001st silent frame (fm-processor.cpp:816-817)
 constexpr int TT_BURST = 1200;         // workingRate * 0.025f (:819)
