@@ -464,3 +464,16 @@ def test_volume_change_on_a_call_that_starts_inside_a_resampler_block(fmx_amd, o
     e = float(np.abs(pcm[0][:128].astype(np.float64) - po[:128]).max())
     print("\n[volume change inside a resampler block] first 128 frames: max |err| %.2e (full scale %.2f)" % (e, float(np.abs(po[:128]).max())))
     assert e <= 1e-5 and float(np.abs(po[:128]).max()) > 0.02
+
+
+@pytest.mark.parametrize("seed,channels,kinds,pieces", [(1, 130, 5, -1), (2, 70, 5, 2048)])
+def test_twins_under_runtime_changes(seed, channels, kinds, pieces):
+    """tools/diag/twins_setters.py, bounded: a batch in kinds of equal settings on one stream, calls of uneven length (most of them not whole resampler
+    blocks), random setters and actions applied to whole kinds between calls; every call every channel's PCM and metaData equal its twin's, the RDS bits at
+    the end.  The class of defect it looks for: memory a channel should not have read (gain_fix_kernel's stale LDS, rounds 2-5) and races (round 4)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "diag", "twins_setters.py"), str(seed), "5", str(channels), str(kinds), "10", str(pieces)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert r.stdout.strip().splitlines()[-1].endswith("mismatch: 0"), r.stdout[-3000:]
