@@ -741,6 +741,22 @@ int front_parts_for(fmx_handle h, CallGeom &G) {
     return FMX_OK;
 }
 
+// the handle's side streams (a call made in overlapping pieces: run_call; stage B's last round of workgroups beside stage C: run_call_one), created when first wanted
+int ensure_pipe_streams(fmx_handle h) {
+    if (h->pipe_sA) return FMX_OK;
+    // (plain streams, the recurrences' with priority.  Measured and not kept: compute units of their own for the recurrences -- CU-masked streams,
+    // 16 / 32 / 64 CUs for the 64 waves, the rest for the other streams: 6.7 / 6.3 / 6.0 ms per step against 6.2 without masks.  A lone wave walks a
+    // sample in 216 ns with the chip to itself and in 270-300 ns while the other stages run, on CUs of its own or not: what it loses is the
+    // chip's clock under load, not its SIMD.)
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(hipStreamCreateWithPriority(&h->pipe_sA, hipStreamNonBlocking, lo));
+    HIPCHK(hipStreamCreateWithPriority(&h->pipe_sB, hipStreamNonBlocking, lo));
+    HIPCHK(hipStreamCreateWithPriority(&h->pipe_sP, hipStreamNonBlocking, hi));     // (the chain everything waits for)
+    for (hipEvent_t *e : {&h->pipe_ev0, &h->pipe_evA, &h->pipe_evD, &h->pipe_evP, &h->pipe_evE, &h->pipe_evB[0], &h->pipe_evB[1]}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return FMX_OK;
+}
+
 struct PipePiece { int k; };       // a piece of a call made in overlapping pieces (its number)
 int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
                  int64_t pcm_stride, int64_t *n_frames, hipStream_t s, const PipePiece *pp = nullptr);
@@ -776,18 +792,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
                 CallGeom G{}; frames_geom(h, n, &G);
                 if (conv2_out(h, G.M1) - conv2_out(h, G.M0) > pcm_stride) return fail(FMX_E_TOO_LARGE, "pcm_stride smaller than the frames this call produces");
             }
-            if (!h->pipe_sA) {
-                // (plain streams, the recurrences' with priority.  Measured and not kept: compute units of their own for the recurrences -- CU-masked streams,
-                // 16 / 32 / 64 CUs for the 64 waves, the rest for the other streams: 6.7 / 6.3 / 6.0 ms per step against 6.2 without masks.  A lone wave walks a
-                // sample in 216 ns with the chip to itself and in 270-300 ns while the other stages run, on CUs of its own or not: what it loses is the
-                // chip's clock under load, not its SIMD.)
-                int lo = 0, hi = 0;
-                HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-                HIPCHK(hipStreamCreateWithPriority(&h->pipe_sA, hipStreamNonBlocking, lo));
-                HIPCHK(hipStreamCreateWithPriority(&h->pipe_sB, hipStreamNonBlocking, lo));
-                HIPCHK(hipStreamCreateWithPriority(&h->pipe_sP, hipStreamNonBlocking, hi));     // (the chain everything waits for)
-                for (hipEvent_t *e : {&h->pipe_ev0, &h->pipe_evA, &h->pipe_evD, &h->pipe_evP, &h->pipe_evE, &h->pipe_evB[0], &h->pipe_evB[1]}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-            }
+            { const int rc = ensure_pipe_streams(h); if (rc) return rc; }
             // the pieces run on the handle's three streams, behind what the caller's stream held when the call began; the caller's stream goes on behind the last of them
             HIPCHK(hipEventRecord(h->pipe_ev0, s));
             HIPCHK(hipStreamWaitEvent(h->pipe_sA, h->pipe_ev0, 0)); HIPCHK(hipStreamWaitEvent(h->pipe_sB, h->pipe_ev0, 0));
@@ -901,6 +906,31 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     if (prof && prof_double) HIPCHK(hipEventRecord(pdummy, sa));
     if (prof) HIPCHK(hipEventRecord(pr.e[1], sa));
     G.stageb_form = h->stageb_form.load(); G.no_deemph = h->ola_mode ? 1 : 0;
+    // A plain batch (no pre-pass, no RDS, no scope-tap rows: stage B as the whole kernel, three workgroups per CU) of more channels than one round of stage-B
+    // workgroups: stages B and C run as TWO CHANNEL GROUPS on two streams.  Stage B is bound by instruction issue and leaves its last round of workgroups partly
+    // filled (4096 channels are 5.33 rounds of 768); stage C moves the d ring and the PCM.  With the second group's stage B finished while the first group's still
+    // runs, its stage C fills what stage B leaves free: 3.48 -> 3.32 ms per step at 4096 channels.  Stage A stays one launch with the chip to itself -- the stage the
+    // roofline line is measured on.  The groups touch disjoint channels (CallGeom::ch0 / ch_count); the caller's stream goes on behind both.  FMX_TAIL_SPLIT=0: off.
+    int tail_ch = 0;
+    {
+        static const bool tail_on = !(getenv("FMX_TAIL_SPLIT") && atoi(getenv("FMX_TAIL_SPLIT")) == 0);
+        const int slots = 3 * (h->n_cus > 0 ? h->n_cus : 256);
+        const bool plain = !piped && !h->ola_mode && !h->B.w_iq && !h->cv_nt && !h->B.rows_on && !(h->rds_alloc && any_rds_on(h)) && !h->gain_pending && G.stageb_form == 0 &&
+                           !getenv("FMX_STAGEB_SPLIT") && G.J1 > G.J0 && G.M1 > G.M0;
+        if (tail_on && plain && h->channels > slots) {
+            // (the first group: 2304 of 4096 channels on 256 CUs -- three whole rounds.  Measured there, second group of 256 / 512 / 1024 /
+            // 1792 / 2048 / 3072 channels: 3.47 / 3.45 / 3.35 / 3.32 / 3.39 / 3.43 ms per step against 3.47-3.55 with one group.  FMX_TAIL_CH=n: a diagnostic)
+            // other counts, one group -> two, ms per step: 3840 (2304 + 1536) 3.20 -> 3.12, 3000 (2304 + 696) 2.51 -> 2.43 (1536 + 1464: 2.51), 2048 (1536 + 512)
+            // 1.68 -> 1.63, 1536 (768 + 768) 1.30 -> 1.27, 1024 (768 + 256) 0.915 -> 0.910: the first group is two thirds of the rounds, in whole rounds
+            int first_rounds = (int)(0.65 * (double)h->channels / (double)slots + 0.5);
+            if (first_rounds < 1) first_rounds = 1;
+            tail_ch = h->channels - first_rounds * slots;
+            static const int force = getenv("FMX_TAIL_CH") ? atoi(getenv("FMX_TAIL_CH")) : 0;
+            if (force > 0 && force < h->channels) tail_ch = force;
+            if (tail_ch <= 0) tail_ch = 0;
+            if (tail_ch > 0) { const int rc2 = ensure_pipe_streams(h); if (rc2) return rc2; }
+        }
+    }
     if (piped) { HIPCHK(hipEventRecord(h->pipe_evA, sa)); HIPCHK(hipStreamWaitEvent(s, h->pipe_evA, 0)); }      // (stage B of this piece behind its stage A)
     if (piped) {
         // the pre-pass of this piece: its parallel part (disc_kernel) behind the piece's stage A on that stream -- and behind the stage B that read the half
@@ -911,6 +941,13 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         const PrepassStreams ps{sa, h->pipe_sP, h->pipe_evD, h->pipe_evP};
         launch_demod_fused(h->T, Bk, G, h->channels, s, &ps);
         HIPCHK(hipEventRecord(h->pipe_evB[pp->k & 1], s));
+    } else if (tail_ch > 0) {
+        // (the second group on the handle's side stream, behind stage A)
+        HIPCHK(hipEventRecord(h->pipe_evA, s)); HIPCHK(hipStreamWaitEvent(h->pipe_sA, h->pipe_evA, 0));
+        CallGeom G1 = G, G2 = G;
+        G1.ch0 = 0; G1.ch_count = h->channels - tail_ch; G2.ch0 = h->channels - tail_ch; G2.ch_count = tail_ch;
+        launch_demod_fused(h->T, h->B, G1, h->channels, s);
+        launch_demod_fused(h->T, h->B, G2, h->channels, h->pipe_sA);
     } else
     launch_demod_fused(h->T, h->B, G, h->channels, s);      // (with its pre-pass for the PLL / AM decoders and the squelches)
     if (G.J1 > G.J0) {       // (stage B's bookkeeping behind the call, fmx_stageb.hip)
@@ -956,7 +993,13 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     }
     if (h->ola_mode) Bq.dring = h->d2ring;
     if (h->gain_pending && G.M1 > G.M0) { G.gain_fix = 1; launch_gain_fix(h->T, Bq, G, h->channels, s); FMX_LAUNCHED(); h->gain_pending = false; }
-    if (!h->cv_nt) launch_audio(h->T, Bq, G, d_pcm, h->channels, s);
+    if (tail_ch > 0) {
+        CallGeom G1 = G, G2 = G;
+        G1.ch0 = 0; G2.ch0 = h->channels - tail_ch;
+        launch_audio(h->T, Bq, G1, d_pcm, h->channels - tail_ch, s);
+        launch_audio(h->T, Bq, G2, d_pcm, tail_ch, h->pipe_sA);
+        HIPCHK(hipEventRecord(h->pipe_evE, h->pipe_sA)); HIPCHK(hipStreamWaitEvent(s, h->pipe_evE, 0));
+    } else if (!h->cv_nt) launch_audio(h->T, Bq, G, d_pcm, h->channels, s);
     else {
         // the audio stage writes its 48 kHz frames behind the converter's history; theConverter's output goes to the caller
         CallGeom G48 = G; G48.pcm_stride = h->x48_stride;

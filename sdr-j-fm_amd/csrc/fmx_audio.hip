@@ -25,8 +25,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // the maxima of every window that closed in this call to the channel's ring (the host turns them into dB and runs the
 // display delay line: fmx_get_peaks), advances the test-tone cycle position.
 __global__ __launch_bounds__(64) void pcm_tail_kernel(DeviceBuffers B, CallGeom G, int channels) {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= channels) return;
+    const int ch = blockIdx.x * 64 + threadIdx.x + G.ch0;
+    if (ch >= G.ch0 + channels) return;
     ChanState *st = &B.state[ch];
     const int frames = (int)(G.M1 - G.M0);
     const int cnt0 = st->pk_cnt;
@@ -67,7 +67,7 @@ template <bool PEAKS>      // (the peak meter's maxima: a display feed that a ba
 __global__ __launch_bounds__(fftc::T, AF_WAVES_PER_SIMD) void audio_fft_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, float2 *__restrict__ pcm) {
     __shared__ __attribute__((aligned(16))) float2 X[fftc::LDS_N];
     __shared__ int pkt[7][4];
-    const int ch = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const int ch = blockIdx.y + G.ch0, t = threadIdx.x, lane = t & 63;
     const int64_t mb = G.M0 + (int64_t)blockIdx.x * AF_VALID;
     if (mb >= G.M1) return;
     const ChanParams P = B.params[ch];

@@ -235,6 +235,9 @@ struct CallGeom {
                              // (fmx_front4.hip: the filter on the matrix pipe; RfDC taken 12 columns back in every tap set as well); launch_front
                              // gives it the whole tiles of a call that starts on a column boundary, front_kernel the remainder and everything else
     int32_t cont;            // front_kernel: this launch continues a call whose head another launch has made (the one-shot actions are done)
+    int32_t ch_count;        // stage B: workgroups of the launch (0: one per channel of the handle); with ch0:
+    int32_t ch0;             // stage B / C: the launch covers the channels ch0 ... ch0 + ch_count - 1 (stage C: + its channel argument - 1) (a batch whose last round of stage-B workgroups
+                             // would leave the chip two thirds empty gives that round to a second stream: fmx_api.hip run_call_one); 0 everywhere else
     int32_t host_count1;     // != 0: the demodulator pre-pass takes the reference's myCount (fm-processor.cpp:662) in front of this call from here (the count
                              // + 1) instead of the channel state -- a call made in overlapping pieces (fmx_api.hip: run_call), where the previous piece's
                              // stage B, which keeps the count, may still be running

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     static_assert(4 * mconv::PLB + mconv::TABB <= XF * 4 && mconv::OUT == FB_W && mconv::TAPS == PSS_TAPS, "the f16 planes and the hi tap table fit the convolution buffer");
     __shared__ __attribute__((aligned(16))) uint32_t mlo[(PART == 1 || !SB_PSS_MFMA) ? 4 : mconv::TABB / 4 + MCONV_EXTRA_LDS];      // the lo halves of the PSS taps (fmx_mfmaconv.h)
     __shared__ __attribute__((aligned(16))) DecayTab<(PART == 0 ? 4 : 2)> dtab;
-    const int ch = blockIdx.x;
+    const int ch = blockIdx.x + G.ch0;
     if (ch >= C) return;
 #ifdef SB_POISON_LDS
     // (diagnostic build: every LDS word a NaN pattern before anything is written -- a read of a word nobody wrote shows in the results)
@@ -1630,11 +1630,12 @@ void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const Cal
     // (a batch that keeps no scope taps and decodes no RDS: the whole kernel leaves the rows unwritten -- 0.63 GB per call at 4096 channels, and writes
     // are the expensive direction on this GPU -- and is then the faster form where the halves were: 1.60 against 1.69 ms)
     const bool split = force >= 0 ? force != 0 : (B.rows_on ? halves < whole : (getenv("FMX_ROWS_OFF_SPLIT") ? halves < whole : false));
+    const unsigned grid = (unsigned)(G.ch_count > 0 ? G.ch_count : C);       // (a launch for some of the channels: CallGeom::ch0)
     if (split) {
-        hipLaunchKernelGGL(stageb_kernel<1>, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
-        hipLaunchKernelGGL(stageb_kernel<2>, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
+        hipLaunchKernelGGL(stageb_kernel<1>, dim3(grid), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
+        hipLaunchKernelGGL(stageb_kernel<2>, dim3(grid), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
     } else {
-        hipLaunchKernelGGL(stageb_kernel<0>, dim3((unsigned)C), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
+        hipLaunchKernelGGL(stageb_kernel<0>, dim3(grid), dim3(FB_T), 0, s, A); FMX_LAUNCHED();
     }
 }
 
