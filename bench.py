@@ -669,6 +669,10 @@ def main():
                                         "note": "HIP-event intervals of a separate untimed pass of %d steps, each enqueued behind a spin kernel; their sum "
                                                 "exceeds the timed step by the events' own cost" % launches},
             "pilot_pll": pll_counts,
+            **({"stage_groups": {"channels": [channels - f.last_second_group(), f.last_second_group()],
+                                 "note": "stages B and C run as two channel groups on two streams (the audio stage of one beside the stereo stage of the other); stage A, "
+                                         "the roofline's kernel, is one launch with the chip to itself; the demod_pilot_pss interval ends with the first group's stage B"}}
+               if f.last_second_group() > 0 else {}),
             **({"call_pieces": {"pieces_per_call": pieces, "note": "FMX_P_CALL_PIECES: the call is made in pieces whose stages overlap on three streams (stage A of piece k + 1, the "
                                 "demodulator's lone-wave recurrences of piece k, stage B / C of piece k - 1); the stage intervals are sums over the pieces and overlap in time"}}
                if pieces > 1 else {}),

@@ -309,6 +309,11 @@ int64_t fmx_pll_exact_segments(fmx_handle h, int32_t channel);
 int32_t fmx_last_front_kernel(fmx_handle h);
 /* ... and the number of overlapping pieces it was made in (FMX_P_CALL_PIECES; 1: the call was made whole). */
 int32_t fmx_last_call_pieces(fmx_handle h);
+/* ... and the channels of the SECOND of the two channel groups its stereo / audio stages ran as (0: one group).  A batch of more channels than one round of
+ * the stereo stage's workgroups, without RDS, scope taps or demodulator pre-pass, runs those stages for the channels 0 .. C - n - 1 on the caller's stream and
+ * for the last n on a side stream of the handle, so that the audio stage of one group fills what the stereo stage of the other leaves free; the input
+ * filter stage stays one launch.  The results do not depend on it (every channel's arithmetic is its own); FMX_TAIL_SPLIT=0 in the environment switches it off. */
+int32_t fmx_last_second_group(fmx_handle h);
 /* ... and 24 kS/s RDS samples (rdsDecimator outputs, fm-processor.cpp:553): the n that fmx_get_tap accepts for FMX_TAP_RDS_IQ */
 int64_t fmx_last_rds_samples(fmx_handle h);
 /* ... of one channel.  A channel's RDS path counts the fm samples IT has processed -- it runs while the channel's decoder is on and stands still

@@ -129,6 +129,7 @@ struct fmx_handle_s {
     hipEvent_t pipe_ev0 = nullptr, pipe_evA = nullptr, pipe_evD = nullptr, pipe_evP = nullptr, pipe_evE = nullptr, pipe_evB[2] = {nullptr, nullptr};
     std::atomic<int> pipe_rows{-1};      // FMX_P_CALL_PIECES: fm samples per piece (-1 automatic, 0 never)
     int last_pieces = 1;                 // overlapping pieces the last call was made in (fmx_last_call_pieces)
+    int last_second_group = 0;           // channels of the second stage-B / C group of the last call (fmx_last_second_group)
     int my_count_host = 0;               // the reference's myCount (fm-processor.cpp:662-684) as stage B keeps it in every channel's state: the same in all of them
     PreLook pre_look{};                  // pre_kernel's look-back buffers (ensure_ola)
     void *hp_iq = nullptr; float2 *hp_pcm = nullptr; size_t hp_iq_bytes = 0; int64_t hp_pcm_cap = 0;   // fmx_process_host: pinned, device-visible staging of small calls
@@ -930,6 +931,7 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
             if (tail_ch <= 0) tail_ch = 0;
             if (tail_ch > 0) { const int rc2 = ensure_pipe_streams(h); if (rc2) return rc2; }
         }
+        h->last_second_group = tail_ch;
     }
     if (piped) { HIPCHK(hipEventRecord(h->pipe_evA, sa)); HIPCHK(hipStreamWaitEvent(s, h->pipe_evA, 0)); }      // (stage B of this piece behind its stage A)
     if (piped) {
@@ -1718,6 +1720,7 @@ int64_t fmx_pll_exact_segments(fmx_handle h, int32_t channel) {
 }
 int32_t fmx_last_front_kernel(fmx_handle h) { return h ? h->last_front_kernel : 0; }
 int32_t fmx_last_call_pieces(fmx_handle h) { return h ? h->last_pieces : 0; }
+int32_t fmx_last_second_group(fmx_handle h) { return h ? h->last_second_group : 0; }
 int64_t fmx_last_rds_samples_of(fmx_handle h, int32_t channel) {
     if (!h || !h->rds_alloc || channel < 0 || channel >= h->channels) return 0;
     return h->last_m1[(size_t)channel] - h->last_m0[(size_t)channel];

@@ -37,7 +37,7 @@ EXPORTS = [
     "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
     "fmx_get_meta", "fmx_get_tap", "fmx_get_peaks",
-    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_pll_exact_segments", "fmx_last_front_kernel", "fmx_last_call_pieces", "fmx_last_rds_samples", "fmx_last_rds_samples_of", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
+    "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_pll_exact_segments", "fmx_last_front_kernel", "fmx_last_call_pieces", "fmx_last_second_group", "fmx_last_rds_samples", "fmx_last_rds_samples_of", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
 ]
 
 
@@ -150,6 +150,8 @@ def load_library(path=None):
     L.fmx_last_front_kernel.argtypes = [vp]
     L.fmx_last_call_pieces.restype = C.c_int32
     L.fmx_last_call_pieces.argtypes = [vp]
+    L.fmx_last_second_group.restype = C.c_int32
+    L.fmx_last_second_group.argtypes = [vp]
     L.fmx_pll_exact_segments.argtypes = [vp, C.c_int32]
     L.fmx_last_rds_samples.restype = C.c_int64
     L.fmx_last_rds_samples.argtypes = [vp]
@@ -300,6 +302,10 @@ class Fmx:
     def last_call_pieces(self):
         """Overlapping pieces the last call was made in (fmx_last_call_pieces, P_CALL_PIECES; 1: whole)."""
         return int(self.L.fmx_last_call_pieces(self.h))
+
+    def last_second_group(self):
+        """Channels of the second of the two groups the last call's stereo / audio stages ran as (fmx_last_second_group; 0: one group)."""
+        return int(self.L.fmx_last_second_group(self.h))
 
     def last_rds_samples(self, channel=0):
         """24 kS/s RDS samples the last call produced on `channel` (fmx_last_rds_samples_of): the n that tap(TAP_RDS_IQ, n, channel) accepts."""

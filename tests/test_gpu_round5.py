@@ -477,3 +477,23 @@ def test_twins_under_runtime_changes(seed, channels, kinds, pieces):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert r.stdout.strip().splitlines()[-1].endswith("mismatch: 0"), r.stdout[-3000:]
+
+
+def test_stages_b_and_c_as_two_channel_groups_equal_one_group():
+    """A plain batch of more channels than one round of stage-B workgroups runs stages B and C as two channel groups on two streams (fmx_api.hip run_call_one,
+    fmx_last_second_group): 1100 channels on four programmes (768 + 332), four calls of uneven length, the first and the one behind a volume change made as one group (the gain correction runs) --
+    against the same calls with FMX_TAIL_SPLIT=0, bit for bit; twins equal inside each run."""
+    import os, subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("0", "1"):
+            path = os.path.join(td, "g%s.npz" % flag)
+            r = subprocess.run([sys.executable, os.path.join(root, "tools", "diag", "groups_check.py"), path, "1100", "4", "100000"],
+                               env=dict(os.environ, FMX_TAIL_SPLIT=flag), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+            res.append(np.load(path))
+    one, two = res
+    assert list(one["groups"]) == [0, 0, 0, 0] and list(two["groups"]) == [0, 332, 0, 332], (one["groups"], two["groups"])
+    assert one["pcm"].shape == two["pcm"].shape and float(np.abs(one["pcm"]).max()) > 0.01
+    assert np.array_equal(one["pcm"], two["pcm"])
