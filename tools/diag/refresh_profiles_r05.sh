@@ -9,6 +9,7 @@ bash tools/prof.sh r05_mixed --population mixed > /dev/null 2>&1
 bash tools/prof.sh r05_config5 --workload config5 > /dev/null 2>&1
 bash tools/prof.sh r05_pll_decoder --decoder 2 > /dev/null 2>&1
 bash tools/prof.sh r05_noise_squelch --squelch 1 > /dev/null 2>&1
+bash tools/prof.sh r05_level_squelch --squelch 2 > /dev/null 2>&1
 bash tools/pmc_traffic.sh r05 --quick --steps 4 --warmup 44 2>&1 | tail -1
 {
   echo "# rocprofv3 --pmc passes of python bench.py --quick (4096 channels, established population), averages per launch and per collection unit"
