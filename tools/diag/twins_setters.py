@@ -3,7 +3,8 @@
 uneven length (most of them not whole resampler blocks) while random setters and actions are applied to whole kinds between calls.  Whatever a kind's settings
 are, its channels run the same arithmetic on the same data: a channel that differs from its twin in PCM, RDS bits or metaData has read memory it should
 not have (stale LDS, a neighbour's rows) or raced.  No oracle involved: thousands of setter / call combinations per minute.
-usage: twins_setters.py [seed] [rounds] [channels] [kinds] [calls per round] [pieces -1|0|n]"""
+usage: twins_setters.py [seed] [rounds] [channels] [kinds] [calls per round] [pieces -1|0|n] [streams] [format f32|s16|u8]
+streams > 1: the kinds listen to different streams (kind k to stream k % streams; twins share their stream).  A raw format goes through fmx_process_host_raw."""
 import importlib, os, sys
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +17,8 @@ nch = int(sys.argv[3]) if len(sys.argv) > 3 else 130
 nk = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 calls = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 pieces = int(sys.argv[6]) if len(sys.argv) > 6 else -1
+nst = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+fmtname = sys.argv[8] if len(sys.argv) > 8 else "f32"
 MAXB = 16384 * 16
 SETTERS = [
     (M.P_FM_MODE, [0, 1, 2]), (M.P_FM_DECODER, [1, 2, 3, 4, 5, 6]), (M.P_SOUND_MODE, [0, 1, 2, 3, 4, 5, 6]), (M.P_STEREO_PANORAMA, [0, 60, 100, 140, 200]),
@@ -34,8 +37,14 @@ for rnd in range(rounds):
     a, b = sorted(int(v) for v in rng.integers(0, n, 2))
     env[a:b] = 0.004                                               # (a fade: the squelches get something to decide)
     iq = (iq * env[:, None]).astype(np.float32)
+    streams = [iq] + [ol.synth_iq(n, stereo=1, noiseSeed=seed * 100 + rnd + 7 * k, noiseSigma=0.002 * k, leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k, rds=1, rdsLevel=0.05,
+                                  rdsBitsSeed=seed + rnd + k, dcI=0.004 * (k % 2), dcQ=-0.003 * k) for k in range(1, nst)]
+    iqs = np.stack(streams, axis=0)
+    if fmtname == "s16": raw, code = np.clip(np.round(iqs * 1500.0 + 9.0), -32768, 32767).astype(np.int16), M.IQ_S16
+    elif fmtname == "u8": raw, code = np.clip(np.round(iqs * 100.0 + 127.4), 0, 255).astype(np.uint8), M.IQ_U8
+    else: raw, code = iqs, M.IQ_F32
     kind = [c % nk for c in range(nch)]
-    f = pkg.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=MAXB)
+    f = pkg.Fmx(nch, streams=nst, stream_of_channel=[(c % nk) % nst for c in range(nch)], max_block=MAXB)
     for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0)): f.set_param(pid, v)
     f.set_param(M.P_CALL_PIECES, pieces)
     if rng.integers(0, 2): f.set_param(M.P_STAGEB_FORM, int(rng.integers(0, 3)))
@@ -52,7 +61,7 @@ for rnd in range(rounds):
         for _ in range(int(rng.integers(0, 4))):
             pid, vals = SETTERS[int(rng.integers(0, len(SETTERS)))]
             apply(int(rng.integers(0, nk)), pid, vals[int(rng.integers(0, len(vals)))])
-        pcm = f.process_host(iq[None, pos:pos + ln]); pos += ln
+        pcm = f.process_host(raw[:, pos:pos + ln]) if code == M.IQ_F32 else f.process_host_raw(raw[:, pos:pos + ln], code); pos += ln
         assert np.isfinite(pcm).all()
         diff = [c for c in range(nk, nch) if not np.array_equal(pcm[c], pcm[kind[c]])]
         metas = [f.meta(c) for c in range(nch)]
