@@ -1,6 +1,8 @@
+"""A volume change on a call that starts inside a resampler block: every channel against channel 0 and the oracle, frame by frame (the diagnostic that
+located gain_fix_kernel's read beyond its LDS array).  usage: dbg_gainfix.py CHANNELS"""
 import importlib, os, sys
 import numpy as np
-R="/root/repo"
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import oracle_lib as ol
 pkg = importlib.import_module("sdr-j-fm_amd"); M = pkg.fmx

@@ -1,6 +1,8 @@
+"""Twins of a 70-channel handle (PLL / AM decoder, squelches) with a frequency change (t), a volume change (v), a squelch slider (s) between calls, made whole or
+in overlapping pieces.  usage: dbg_twins_pieces.py PIECES {t|v|s}+"""
 import importlib, os, sys
 import numpy as np
-R="/root/repo"
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import oracle_lib as ol
 pkg = importlib.import_module("sdr-j-fm_amd"); M = pkg.fmx
