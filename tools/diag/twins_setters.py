@@ -3,7 +3,7 @@
 uneven length (most of them not whole resampler blocks) while random setters and actions are applied to whole kinds between calls.  Whatever a kind's settings
 are, its channels run the same arithmetic on the same data: a channel that differs from its twin in PCM, RDS bits or metaData has read memory it should
 not have (stale LDS, a neighbour's rows) or raced.  No oracle involved: thousands of setter / call combinations per minute.
-usage: twins_setters.py [seed] [rounds] [channels] [kinds] [calls per round] [pieces -1|0|n] [streams] [format f32|s16|u8]
+usage: twins_setters.py [seed] [rounds] [channels] [kinds] [calls per round] [pieces -1|0|n] [streams] [format f32|s16|u8] [input rate]
 streams > 1: the kinds listen to different streams (kind k to stream k % streams; twins share their stream).  A raw format goes through fmx_process_host_raw."""
 import importlib, os, sys
 import numpy as np
@@ -19,6 +19,7 @@ calls = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 pieces = int(sys.argv[6]) if len(sys.argv) > 6 else -1
 nst = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 fmtname = sys.argv[8] if len(sys.argv) > 8 else "f32"
+rate = int(sys.argv[9]) if len(sys.argv) > 9 else 2304000      # (1152000: the reference decimates by 6; 192000: not at all)
 MAXB = 16384 * 16
 SETTERS = [
     (M.P_FM_MODE, [0, 1, 2]), (M.P_FM_DECODER, [1, 2, 3, 4, 5, 6]), (M.P_SOUND_MODE, [0, 1, 2, 3, 4, 5, 6]), (M.P_STEREO_PANORAMA, [0, 60, 100, 140, 200]),
@@ -32,19 +33,19 @@ for rnd in range(rounds):
     rng = np.random.default_rng(1000 * seed + rnd)
     lens = [int(rng.choice([16384 * 14, 16384 * 3, 230400, 100001, 16384 * 16, 57600, 7777, 192 * 12 * 50 + 12 * int(rng.integers(0, 192))])) for _ in range(calls)]
     n = sum(lens)
-    iq = ol.synth_iq(n, stereo=1, noiseSeed=seed * 100 + rnd, noiseSigma=0.003, rds=1, rdsLevel=0.05, rdsBitsSeed=seed + rnd)
+    iq = ol.synth_iq(n, stereo=1, noiseSeed=seed * 100 + rnd, noiseSigma=0.003, rds=1, rdsLevel=0.05, rdsBitsSeed=seed + rnd, inputRate=rate)
     env = np.ones(n, np.float32)
     a, b = sorted(int(v) for v in rng.integers(0, n, 2))
     env[a:b] = 0.004                                               # (a fade: the squelches get something to decide)
     iq = (iq * env[:, None]).astype(np.float32)
     streams = [iq] + [ol.synth_iq(n, stereo=1, noiseSeed=seed * 100 + rnd + 7 * k, noiseSigma=0.002 * k, leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k, rds=1, rdsLevel=0.05,
-                                  rdsBitsSeed=seed + rnd + k, dcI=0.004 * (k % 2), dcQ=-0.003 * k) for k in range(1, nst)]
+                                  rdsBitsSeed=seed + rnd + k, dcI=0.004 * (k % 2), dcQ=-0.003 * k, inputRate=rate) for k in range(1, nst)]
     iqs = np.stack(streams, axis=0)
     if fmtname == "s16": raw, code = np.clip(np.round(iqs * 1500.0 + 9.0), -32768, 32767).astype(np.int16), M.IQ_S16
     elif fmtname == "u8": raw, code = np.clip(np.round(iqs * 100.0 + 127.4), 0, 255).astype(np.uint8), M.IQ_U8
     else: raw, code = iqs, M.IQ_F32
     kind = [c % nk for c in range(nch)]
-    f = pkg.Fmx(nch, streams=nst, stream_of_channel=[(c % nk) % nst for c in range(nch)], max_block=MAXB)
+    f = pkg.Fmx(nch, streams=nst, stream_of_channel=[(c % nk) % nst for c in range(nch)], max_block=MAXB, inputRate=rate)
     for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0)): f.set_param(pid, v)
     f.set_param(M.P_CALL_PIECES, pieces)
     if rng.integers(0, 2): f.set_param(M.P_STAGEB_FORM, int(rng.integers(0, 3)))
