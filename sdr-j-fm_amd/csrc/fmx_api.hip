@@ -590,6 +590,7 @@ static bool any_rds_on(fmx_handle h) { for (auto &p : h->params) if (p.rds_mode 
 constexpr int PIPE_ROWS_AUTO = 3072;      // fm samples per piece of an overlapping call where pllC runs (two of stage B's segments; measured at 4096 channels:
                                           // 2048 / 3072 / 4608 / 6400 fm samples per piece give 6.37 / 6.18 / 6.46 / 6.79 ms per step, the call made whole 8.24)
 constexpr int PIPE_ROWS_AUTO_SQ = 4608;   // ... where only squelches do (noise squelch 6.61 / 5.73 / 5.46 / 5.54 against 5.90 whole, level squelch 5.43 / 4.73 / 4.59 / 4.72 against 5.23)
+constexpr int TAIL_MIN_CHANNELS = 128;    // the second stage-B / C channel group: at least this many channels
 constexpr int PIPE_MIN_CHANNELS = 1024;   // automatic: batches that fill the chip
 constexpr int PLL_SEQ_AUTO_MAX = 64;   // FMX_P_PLL_SOLVER = 0: handles up to this many channels evaluate the pilot PLL sequentially
 
@@ -928,7 +929,7 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
             tail_ch = h->channels - first_rounds * slots;
             static const int force = getenv("FMX_TAIL_CH") ? atoi(getenv("FMX_TAIL_CH")) : 0;
             if (force > 0 && force < h->channels) tail_ch = force;
-            if (tail_ch <= 0) tail_ch = 0;
+            if (tail_ch < TAIL_MIN_CHANNELS) tail_ch = 0;             // (a second group of a few dozen channels is three launches for nothing)
             if (tail_ch > 0) { const int rc2 = ensure_pipe_streams(h); if (rc2) return rc2; }
         }
         h->last_second_group = tail_ch;
