@@ -466,14 +466,15 @@ def test_volume_change_on_a_call_that_starts_inside_a_resampler_block(fmx_amd, o
     assert e <= 1e-5 and float(np.abs(po[:128]).max()) > 0.02
 
 
-@pytest.mark.parametrize("seed,channels,kinds,pieces", [(1, 130, 5, -1), (2, 70, 5, 2048)])
-def test_twins_under_runtime_changes(seed, channels, kinds, pieces):
+@pytest.mark.parametrize("seed,channels,kinds,pieces,extra", [(1, 130, 5, -1, ()), (2, 70, 5, 2048, ()), (3, 130, 5, -1, ("3", "s16")), (4, 1040, 4, -1, ("2", "f32", "1152000"))])
+def test_twins_under_runtime_changes(seed, channels, kinds, pieces, extra):
     """tools/diag/twins_setters.py, bounded: a batch in kinds of equal settings on one stream, calls of uneven length (most of them not whole resampler
     blocks), random setters and actions applied to whole kinds between calls; every call every channel's PCM and metaData equal its twin's, the RDS bits at
-    the end.  The class of defect it looks for: memory a channel should not have read (gain_fix_kernel's stale LDS, rounds 2-5) and races (round 4)."""
+    the end.  The class of defect it looks for: memory a channel should not have read (gain_fix_kernel's stale LDS, rounds 2-5) and races (round 4).
+    Variants: pieces forced on a 70-channel handle; three streams of raw int16 samples; 1040 channels (two stage-B / C channel groups) on two streams at 1.152 MS/s."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "diag", "twins_setters.py"), str(seed), "5", str(channels), str(kinds), "10", str(pieces)],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "diag", "twins_setters.py"), str(seed), "5" if channels < 1000 else "3", str(channels), str(kinds), "10", str(pieces)] + list(extra),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert r.stdout.strip().splitlines()[-1].endswith("mismatch: 0"), r.stdout[-3000:]
