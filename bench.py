@@ -22,7 +22,7 @@ Extra legs on rank 0 at N = 1 (reported as extra keys; the headline `value` stay
   host_call      latency of the single-receiver drop-in call: 1 channel, 16384 samples, fmx_process_host (in a process of its own)
   cpu_baseline   the oracle (a port) on the host cores; with oracle/_ref present also the reference's own leaf classes
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config4|shard512|config2|config3|config5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config4|shard512|config1|config2|config3|config5]
 """
 import argparse
 import importlib
@@ -50,6 +50,8 @@ WORKLOADS = {
     "config4": (4096, 0, "configs[3] whole on each GPU: 4096 independent 2.304 MS/s channels, configs[1] settings "
                          "(stereo + PSS + de-emphasis 50us + input FIR 165 kHz + audio LPF 15 kHz)"),
     "shard512": (512, 0, "configs[3] split over 8 GPUs, one GPU's shard: 512 independent channels, configs[1] settings"),
+    "config1": (4096, 0, "configs[0] at batch scale: 4096 channels, each with configs[0]'s settings (mono FM, input filter OFF, de-emphasis 50 us, "
+                         "audio LPF 15 kHz): stage A then runs the 37-tap fold of the two decimators alone (front_kernel, packed f32 FMAs)"),
     "config2": (1, 0, "configs[1]: 1 channel, stereo + PSS + de-emphasis + input FIR ON"),
     "config3": (256, 24, "configs[2]: 256 carriers in 24 wide-band IQ streams (11 per stream, 200 kHz raster)"),
     "config5": (2048, 0, "configs[4] per-GPU shard: 2048 channels (16384 over 8 GPUs), full chain incl. the RDS front end and "
@@ -201,7 +203,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(seconds_budget=12.0, ref_budget=6.0):
+def cpu_baseline(seconds_budget=12.0, ref_budget=6.0, config0_budget=5.0):
     """The oracle (a port of the reference chain, oracle/fm_oracle.c) timed on this box's host cores:
     one channel per core, all usable cores busy, configs[1] settings -- the reference is single-threaded per
     channel.  Bounded sample: every worker demodulates 0.1 s blocks until the time budget is spent.
@@ -241,6 +243,14 @@ def cpu_baseline(seconds_budget=12.0, ref_budget=6.0):
                      "configs[1] settings, oracle/fm_oracle.c -O2" % (cores, blocks, n, seconds_budget),
            "per_core_MSps": round(total / dt / 1e6 / cores, 3)}
     del chains
+    # SURVEY 8d asks for both CPU-runnable configs: configs[0] (mono FM, input filter OFF) beside configs[1]
+    blocks0, dt0, chains = timed(lambda: ol.OracleChain(inputFilterBw=0, fmMode=2),
+                                 lambda c, i: L.fmo_chain_process(c.h, ol.fptr(iq), n, ol.fptr(pcm[i]), pcm[i].shape[0]),
+                                 config0_budget)
+    out["configs0"] = {"value": round(blocks0 * n / dt0 / 1e6, 3), "unit": "MS/s", "cores": cores, "kind": "port",
+                       "sample": "%d channels (one per usable core), %d blocks of %d samples in all within a %.0f s budget, configs[0] settings "
+                                 "(mono FM, input filter OFF)" % (cores, blocks0, n, config0_budget)}
+    del chains
     R = ol.ref()
     if R is not None and R.ref_has_qt():
         nf = n // 12 + 8
@@ -264,6 +274,7 @@ def sub_bench(extra):
         j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         k = j["kernels_ms_per_step"]
         return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "channels_per_gpu": j["config"]["channels_per_gpu"],
+                "front_kernel_used": j.get("front_kernel_used"),
                 "kernels_ms_per_step": {x: k[x] for x in ("front_fir", "demod_pilot_pss", "audio_fir_resample")},
                 "stage_b_min_median_max": j["kernels_ms_per_step_raw"]["stage_b_min_median_max"], "pilot_pll": j["pilot_pll"],
                 **({"call_pieces": j["call_pieces"]["pieces_per_call"]} if "call_pieces" in j else {}),
@@ -399,11 +410,11 @@ def main():
     nblk = 1                  # blocks of n samples per stream in the IQ buffer (the calls walk through them cyclically)
 
     def configure(f, nch):
-        f.set_param(m.P_BANDWIDTH, 165000)
+        f.set_param(m.P_BANDWIDTH, 0 if args.workload == "config1" else 165000)
         f.set_param(m.P_LF_CUTOFF, 15000)
         f.set_param(m.P_DEEMPHASIS, 50)
         f.set_param(m.P_VOLUME_DB, -6.0)
-        f.set_param(m.P_FM_MODE, 0)
+        f.set_param(m.P_FM_MODE, 2 if args.workload == "config1" else 0)
         if args.workload == "config5":
             f.set_param(m.P_RDS_MODE, 2)
         if args.pll_solver:
@@ -645,13 +656,17 @@ def main():
             "rccl_ranks": dist.get_world_size() if world > 1 else 1, "rccl_backend": dist.get_backend() if world > 1 else None,
             "untimed_calls": untimed,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            # the arithmetic the path computes in: f32 throughout -- except that front4_kernel multiplies 3-term split-f16 operands on the matrix pipe
+            # (22-bit operands behind a per-tile power-of-two scale, products exact, f32 accumulate: DESIGN 3.1); `roofline.control` holds the f32 kernel beside it
+            "dtype": "f32 (stage A: 3-term split-f16 MFMA with a per-tile block exponent, f32 accumulate)" if front_kernel_used == 3 else "f32",
+            "front_kernel_used": front_kernel_used, "data": "synthetic",
             "config": {"workload": args.workload, "description": desc, "population": args.population, "population_description": POPULATIONS[args.population][0],
                        "channels_per_gpu": channels, "channels_total": total_channels,
                        "streams_per_gpu": nstreams, "block_samples_per_channel": n,
                        "realtime_channels_equiv": round(value / 2.304, 1),
                        "pcm_frames_per_channel_per_step": frames // max(args.steps, 1), "parallelism": "channels sharded, 1 rank/GPU"},
-            "roofline": {"bound": "hbm", "kernel": {1: "fmx::front_kernel", 2: "fmx::f3::front3_kernel", 3: "fmx::f4::front4_kernel"}.get(front_kernel_used, "?") + " (input FIR stage)",
+            "roofline": {"bound": "hbm", "kernel": {1: "fmx::front_kernel", 3: "fmx::f4::front4_kernel"}.get(front_kernel_used, "?") + " (input FIR stage)",
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_read_only": round(achieved * (8.0 / ALG_BYTES_STAGE_A) / HBM_PEAK_GBPS, 4),
@@ -683,9 +698,48 @@ def main():
         if bcast: out["broadcast"] = bcast
         if sustained: out["sustained"] = sustained
 
+    # ---- the f32 control of the headline's stage A: one extra untimed pass, rank 0 at N = 1 only ----------------------
+    # Two fresh handles on the same input -- the automatic kernel choice (the matrix-pipe filter) and front_kernel forced (plain f32 packed FMAs) -- walk
+    # the same calls from the stream's start through pilot lock; the last call's PCM of every channel is compared sample by sample, and front_kernel's
+    # mean launch time is taken from the library's events as the headline's is.
+    if rank == 0 and world == 1 and not args.quick and front_kernel_used == 3:
+        del f
+        f = None
+        torch.cuda.empty_cache()
+        try:
+            ncalls = 12
+            res = []
+            for kern in (0, 1):
+                fc = fmx_amd.Fmx(channels, streams=streams, stream_of_channel=smap, device=local_rank, max_block=n)
+                configure(fc, channels)
+                fc.set_param(m.P_FRONT_KERNEL, kern)
+                pc = torch.zeros((channels, frames_cap, 2), dtype=torch.float32, device=device)
+                fr = 0
+                for k in range(ncalls):
+                    if k == ncalls - 4:
+                        torch.cuda.synchronize(); fc.profile_enable(True); fc.profile_read(reset=True)
+                    fr = fc.process_device(iq.data_ptr() + (k % nblk) * n * 8, stride, n, pc.data_ptr(), frames_cap, hip_stream=stream)
+                torch.cuda.synchronize()
+                pr = fc.profile_read(reset=True)
+                res.append((pc[:, :fr].clone(), pr["ms"][0] / max(pr["launches"][0], 1), fc.last_front_kernel()))
+                del fc, pc
+                torch.cuda.empty_cache()
+            (pa, ms3, k3), (pb, ms1, k1) = res
+            out["roofline"]["control"] = {"kernel": "fmx::front_kernel (f32 packed FMAs)" if k1 == 1 else "?", "avg_launch_ms": round(ms1, 4),
+                                          "frac": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms1 > 0 else None,
+                                          "headline_kernel_avg_launch_ms_same_pass": round(ms3, 4), "headline_kernel": k3,
+                                          "pcm_max_abs_diff": float((pa - pb).abs().max().item()), "pcm_full_scale": float(pb.abs().max().item()),
+                                          "what": "two fresh handles, the same %d calls from the stream's start (through pilot lock); PCM of the last call, every channel, "
+                                                  "max |matrix-pipe stage A - f32 stage A|; launch times: mean of the last 4 calls" % ncalls}
+            del pa, pb, res
+        except Exception as e:      # the control is a report; the headline does not depend on it
+            out["roofline"]["control"] = {"error": str(e)[:200]}
+        torch.cuda.empty_cache()
+
     # ---- host-side legs, rank 0 at N = 1 only ---------------------------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_ingest:
-        del f
+        if f is not None:
+            del f
         torch.cuda.empty_cache()
         out["host_ingest"] = host_ingest_legs(torch, fmx_amd, configure, args, device, local_rank, n, streams, smap)
         out["host_call"] = host_call_leg(fmx_amd, local_rank)
@@ -700,7 +754,8 @@ def main():
             # the other BASELINE configs as one-liners (so that the driver's record carries every config), and the shard sizes of
             # configs[3] split 2 / 4 / 8 ways: what strong scaling of 4096 channels comes to per GPU, before any RCCL cost (there is
             # no collective on the data path; `python bench.py --gpus N --scaling strong --total-channels 4096` measures it for real)
-            out["other_workloads"] = {"configs[1] (1 channel)": sub_bench(["--workload", "config2"]),
+            out["other_workloads"] = {"configs[0] at batch scale (4096 channels, mono, input filter off)": sub_bench(["--workload", "config1"]),
+                                      "configs[1] (1 channel)": sub_bench(["--workload", "config2"]),
                                       "configs[2] (256 carriers on 24 shared streams)": sub_bench(["--workload", "config3"]),
                                       "configs[4] shard (2048 channels, RDS on)": sub_bench(["--workload", "config5"]),
                                       # the path where it is slow: populations that are not all established, and the decoders /

@@ -23,10 +23,12 @@
 extern "C" {
 #endif
 
-/* 2: fmx_meta and fmx_rds_info grew (live_rf_dc_*, radio_text_ucs2*), FMX_P_PLL_SOLVER 3, fmx_pll_exact_segments.  The output
+/* 2: fmx_meta and fmx_rds_info grew (live_rf_dc_*, radio_text_ucs2*), FMX_P_PLL_SOLVER 3, fmx_pll_exact_segments.
+ * 3 (round 6): handles above 64 channels keep no display feeds unless asked (FMX_P_SCOPE_TAPS: fmx_get_tap / fmx_get_peaks answer FMX_E_UNSUPPORTED there), round 5's
+ * exports (fmx_last_front_kernel, fmx_last_call_pieces, fmx_last_second_group, fmx_last_rds_samples_of ...), FMX_P_FRONT_KERNEL without its value 2.  The output
  * structs are caller-allocated and carry no size field: a caller built against another version must not call in -- the adapters
  * compare fmx_abi_version () with the FMX_ABI_VERSION they were compiled with when they load the library. */
-#define FMX_ABI_VERSION 2
+#define FMX_ABI_VERSION 3
 
 typedef struct fmx_handle_s *fmx_handle;
 
@@ -121,15 +123,18 @@ typedef enum {
     FMX_P_FRONT_KERNEL = 25,   /* (handle-wide: the channel argument is ignored) which kernel runs the input-filter stage.
                                   1 = fmx_front.hip: four waves per channel, the folded filter as packed f32 FMAs; every input format, local
                                   oscillators, any call.
-                                  2 = fmx_front3.hip: the same arithmetic on six waves per channel (bit-identical results; measured slower).
                                   3 = fmx_front4.hip: the filter on the matrix pipe -- samples and taps split into two f16 halves each, their
                                   products exact in the f32 accumulator, the remainders' roundings at 2^-22 of a product: the fm-rate IQ
-                                  agrees with kernel 1's to 5e-7 of its amplitude, PCM against the oracle is unchanged.  THE SAMPLES MUST
-                                  STAY BELOW 16 IN MAGNITUDE (the reference's devices deliver +-1): larger ones are limited to +-15.99
-                                  there (f16's range behind the pre-scale), where kernel 1 and the reference are linear.
-                                  2 and 3 take the whole 1536-sample tiles of the calls they can -- float32 samples, no local oscillator on
-                                  any channel, the input filter on everywhere, a call that starts on a multiple of 12 samples -- and leave
-                                  the rest to kernel 1.
+                                  agrees with kernel 1's to 5e-7 of its amplitude, PCM against the oracle is unchanged.  BLOCK FLOATING
+                                  POINT: every 1536-sample tile of a channel is split behind a power-of-two scale of its own (its largest
+                                  balanced sample goes to [2^14, 2^15)), so the stage is linear at any level, as the reference's f32 filter
+                                  is -- nothing is clamped, weak signals keep 22 bits.  (Limit: two adjacent tiles of one channel whose
+                                  largest samples differ by more than 2^126.)  The IQ balance is applied in front of the filter, where the
+                                  reference has it (fm-processor.cpp:462-464).
+                                  3 takes the whole 1536-sample tiles of the calls it can -- any sample format, no local oscillator on
+                                  any channel, the input filter on everywhere, a balance between 1e-6 and 1e6 in magnitude, a call that
+                                  starts on a multiple of 12 samples -- and leaves the rest to kernel 1.  (2 was round 5's six-wave VALU
+                                  kernel: measured slower, now tools/experiments/fmx_front3.hip; the value is refused.)
                                   0 = automatic (default): 3 where a handle qualifies and has the channels to fill the GPU, else 1. */
     FMX_P_SCOPE_TAPS = 26,     /* (handle-wide: the channel argument is ignored) whether the DISPLAY FEEDS are produced: the three scope taps that are rows
                                   of stage B's work arrays -- FMX_TAP_DEMOD, FMX_TAP_LR_RAW, FMX_TAP_PILOT_PHASE (fm-processor.cpp:608-613 and the
@@ -294,7 +299,8 @@ int  fmx_rds_bits(fmx_handle h, int32_t channel, uint8_t *bits, int32_t capacity
  * first, own read position.  RDS_2 only; the library keeps the last 1024. */
 int  fmx_rds_symbols(fmx_handle h, int32_t channel, float *iq, int32_t capacity, int32_t *n_symbols);
 /* fm-rate samples (inputRate / the reference's decimation: 12, 6 or 1) the last fmx_process_* call produced per channel: the n that fmx_get_tap accepts for the
- * fm-rate taps, and the number of entries the reference's run() pushed into its LF scope vector for the same block */
+ * fm-rate taps, and the number of entries the reference's run() pushed into its LF scope vector for the same block.  A call the library made in pieces -- with a
+ * channel decoding RDS (pieces of 31999 fm samples) or as overlapping pieces (FMX_P_CALL_PIECES) -- reports its LAST piece here, and the row taps hold that piece. */
 int64_t fmx_last_fm_samples(fmx_handle h);
 /* Health counter of the pilot PLL (no counterpart in the reference, whose loop is sequential): stage B finds the loop's
  * trajectory of a 1536-sample segment by Newton's method on the whole segment; a segment that does not settle within the

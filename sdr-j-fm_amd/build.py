@@ -14,7 +14,6 @@ LIB = os.path.join(LIBDIR, "libfmx.so")
 # expressions reproduce the reference's unfused arithmetic (SURVEY A.14 ii).
 SOURCES = [
     ("fmx_front.hip", []),
-    ("fmx_front3.hip", []),
     ("fmx_front4.hip", []),
     ("fmx_demod.hip", ["-ffp-contract=off"]),
     ("fmx_stageb.hip", ["-ffp-contract=off"]),

@@ -2,9 +2,9 @@
 // design + upload, per-call geometry and the three kernel launches.  No CPU fallback exists:
 // every entry point fails when HIP is unavailable.
 #include "../../include/fmx.h"
+#include "../../include/fmx_debug.h"
 #include "fmx_internal.h"
 #include "fmx_fftconv.h"
-#include "fmx_mfmaconv.h"
 #include "fmx_rdsgroups.h"
 #include "fmx_design.h"
 
@@ -23,6 +23,7 @@ using namespace fmx;
 namespace {
 
 thread_local std::string g_err;
+int env_int(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 #define HIPCHK(expr)                                                                       \
@@ -72,7 +73,6 @@ struct fmx_handle_s {
     bool gain_pending = false;                                       // ... taken over by flush_mailbox together with the settings themselves (processing
                                                                      // thread only): gain_fix_kernel runs in the first call that produces frames
     float *d_audio_lp = nullptr, *d_rs_taps = nullptr;
-    uint16_t *d_audio_mtab = nullptr, *d_pss_mtab = nullptr;
     float2 *d_audio_spec = nullptr;               // the audio low-pass and the resampler alone (gain_fix_kernel)
     // unique tap sets
     std::vector<int32_t> front_keys, audio_keys;
@@ -114,14 +114,16 @@ struct fmx_handle_s {
     std::vector<fmx::RdsGroupDecoderHost> rds_dec;
     std::vector<int64_t> last_m0, last_m1;  // per channel: its 24 kS/s outputs of the last call
     std::vector<void *> rds_ptrs, tail_ptrs;
+    // what a call needs of `params` beyond the device copy, taken under `mtx` by flush_mailbox: fmx_set_param may write `params` from another thread
+    // while the processing thread enqueues the call
+    std::vector<int8_t> call_rds_mode; bool call_any_rds = false;
     std::atomic<int> stageb_form{0};     // FMX_P_STAGEB_FORM
     std::atomic<int> front_parts{0};     // FMX_P_FRONT_PARTS
     std::atomic<int> front_kernel{0};    // FMX_P_FRONT_KERNEL
     std::atomic<int> scope_taps{-1};     // FMX_P_SCOPE_TAPS
     bool taps_kept = true;               // the last call kept the scope-tap rows (fmx_get_tap)
     float *w_diff_mem = nullptr;         // the LR scope tap's rows (allocated when first wanted; DeviceBuffers::w_diff is null while the tap is off)
-    bool front3_ok = false;              // every channel qualifies for front3_kernel (flush_mailbox)
-    bool front4_ok = false;              // ... and for front4_kernel
+    bool front4_ok = false;              // every channel qualifies for front4_kernel (flush_mailbox)
     int last_front_kernel = 1;           // what the last call's stage A was given (FMX_P_FRONT_KERNEL numbering): fmx_last_front_kernel
     // a batch call whose channels need the demodulator pre-pass (a lone wave per 64 channels walking the call sample by sample: 6 % of the chip for
     // most of the call's time) is made in pieces whose stages overlap: run_call
@@ -302,24 +304,6 @@ int ensure_sets(fmx_handle h) {
             HIPCHK(hipMalloc(&h->d_audio_spec, sizeof(float2) * spec.size()));
             HIPCHK(hipMemcpy(h->d_audio_spec, spec.data(), sizeof(float2) * spec.size(), hipMemcpyHostToDevice));
             h->T.audio_spec = h->d_audio_spec;
-            // ... and the same taps as audio_mfma_kernel wants them: two f16 halves of g * 2^14, reversed, shifted by the window's parity
-            std::vector<uint16_t> mt(ak.size() * 4 * AM_TAB, 0);
-            for (size_t i = 0; i < ak.size(); i++) {
-                const int nt = h->h_audio_sets[i].ntaps;
-                const float *rev = &h->h_audio_taps[i * C_TAPS_STRIDE];
-                for (int sh = 0; sh < 2; sh++)
-                    for (int u = 0; u < AM_TAB; u++) {
-                        const int kk = u - 124 - sh;
-                        const float gs = (kk >= 0 && kk < nt) ? rev[kk] * 16384.0f : 0.f;
-                        const _Float16 gh = (_Float16)gs, gl = (_Float16)(gs - (float)gh);
-                        std::memcpy(&mt[((i * 2 + sh) * 2 + 0) * AM_TAB + u], &gh, 2);
-                        std::memcpy(&mt[((i * 2 + sh) * 2 + 1) * AM_TAB + u], &gl, 2);
-                    }
-            }
-            if (h->d_audio_mtab) (void)hipFree(h->d_audio_mtab);
-            HIPCHK(hipMalloc(&h->d_audio_mtab, sizeof(uint16_t) * mt.size()));
-            HIPCHK(hipMemcpy(h->d_audio_mtab, mt.data(), sizeof(uint16_t) * mt.size(), hipMemcpyHostToDevice));
-            h->T.audio_mtab = h->d_audio_mtab;
         }
     }
     h->sets_dirty = false;
@@ -585,7 +569,7 @@ void run_ola(fmx_handle h, fmx_handle_s::OlaSide &S, OlaBuffers O, int64_t len, 
     }
 }
 
-static bool any_rds_on(fmx_handle h) { for (auto &p : h->params) if (p.rds_mode != 0) return true; return false; }
+static bool any_rds_on(fmx_handle h) { return h->call_any_rds; }     // (as of the call's flush_mailbox)
 
 constexpr int PIPE_ROWS_AUTO = 3072;      // fm samples per piece of an overlapping call where pllC runs (two of stage B's segments; measured at 4096 channels:
                                           // 2048 / 3072 / 4608 / 6400 fm samples per piece give 6.37 / 6.18 / 6.46 / 6.79 ms per step, the call made whole 8.24)
@@ -603,19 +587,22 @@ int flush_mailbox(fmx_handle h) {
     for (auto &p : h->params) any_lo |= (p.lo_freq != 0);
     if (any_lo) { int rc = ensure_lo_table(h); if (rc) return rc; }
     {
-        // stage A on three waves per SIMD (fmx_front3.hip): no LO on any channel, every tap set the long fold (RfDC taken 1 .. 13 columns back)
+        // stage A on the matrix pipe (fmx_front4.hip): no LO on any channel, every tap set the long fold with its RfDC taken 12 columns back
         bool ok = !any_lo && h->twins == 1 && !h->ola_mode;
+        for (auto &p : h->params) { if (!ok) break; ok = h->h_front_sets[(size_t)p.front_set].nd > 4; }
+        // front4_kernel applies the IQ balance in front of its filter together with the tile's scale and takes the RF DC recurrence's column sums back
+        // through 1 / balance: a balance of 0 (the slider's end, radio.cpp:989-995) or one no slider produces goes to front_kernel's per-sample pass
         for (auto &p : h->params) {
             if (!ok) break;
-            const FrontSet &fs = h->h_front_sets[(size_t)p.front_set];
-            ok = fs.nd > 4 && fs.dc_k >= 1 && fs.dc_k <= 13;
+            const float al = std::fabs(p.att_l), ar = std::fabs(p.att_r);
+            ok = h->h_front_sets[(size_t)p.front_set].dc_k == 12 && al >= 1e-6f && al <= 1e6f && ar >= 1e-6f && ar <= 1e6f;
         }
-        h->front3_ok = ok;
-        for (auto &p : h->params) { if (!ok) break; ok = h->h_front_sets[(size_t)p.front_set].dc_k == 12; }
         h->front4_ok = ok;
     }
     bool any_rds = false;
-    for (auto &p : h->params) any_rds |= (p.rds_mode != 0);
+    h->call_rds_mode.resize((size_t)h->channels);
+    for (int c = 0; c < h->channels; c++) { h->call_rds_mode[(size_t)c] = (int8_t)h->params[(size_t)c].rds_mode; any_rds |= (h->params[(size_t)c].rds_mode != 0); }
+    h->call_any_rds = any_rds;
     // (a channel's RDS path runs while its decoder is on and stands still otherwise -- block filters, phase delay line, decimator and slicer
     // keep what they hold, as the reference's processor's do: nothing restarts when a decoder is switched; run_call_one counts per channel)
     if (any_rds) { const int rc = ensure_rds(h); if (rc) return rc; }
@@ -780,8 +767,7 @@ int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t
         // What the stages share beyond their hand-over arrays: the myCount of the metaData snapshot (kept by stage B, read by the pre-pass: handed over by
         // the host, CallGeom::host_count) and the RF DC level stage B's snapshot reads from stage A's state (a display value that moves by 1e-7 of its
         // distance per sample: it may be the next piece's).
-        static const int env_rows = getenv("FMX_CALL_PIECES") ? atoi(getenv("FMX_CALL_PIECES")) : -1;
-        const int want = h->pipe_rows.load() >= 0 ? h->pipe_rows.load() : env_rows;
+        const int want = h->pipe_rows.load() >= 0 ? h->pipe_rows.load() : env_switches().call_pieces;
         bool special = false, chain = false;
         { std::lock_guard<std::mutex> lk(h->mtx); for (auto &p : h->params) { special |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0); chain |= (p.decoder == 2 || p.decoder == 1); } }
         const int64_t rows = want > 0 ? ((want + 15) / 16) * 16 : (chain ? PIPE_ROWS_AUTO : PIPE_ROWS_AUTO_SQ);
@@ -855,8 +841,8 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     if (h->rds_alloc && any_rds_on(h) && G.J1 - G.J0 > RDS_BLK)
         return fail(FMX_E_TOO_LARGE, "with RDS on, a call may cover at most 32000 fm samples (384000 input samples)");
     // (a piece of an overlapping call: stage A on its own stream, behind what the caller's stream held when the call began)
-    // (FMX_CALL_PIECES_SERIAL=1, a diagnostic read per call: the same pieces one after the other on the caller's stream -- what the overlapping run must equal bit for bit)
-    const bool piped = pp != nullptr && !h->ola_mode && !(getenv("FMX_CALL_PIECES_SERIAL") && atoi(getenv("FMX_CALL_PIECES_SERIAL")) != 0);
+    // (FMX_CALL_PIECES_SERIAL=1, a diagnostic: the same pieces one after the other on the caller's stream -- what the overlapping run must equal bit for bit)
+    const bool piped = pp != nullptr && !h->ola_mode && !env_switches().pieces_serial;
     hipStream_t sa = piped ? h->pipe_sA : s;
     G.host_count1 = piped ? h->my_count_host + 1 : 0;
     ProfRec pr{}; const bool prof = h->prof_on;
@@ -870,16 +856,13 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     rc = front_parts_for(h, G);
     if (rc) return rc;
     {
-        static const int fk_env = getenv("FMX_FRONT_KERNEL") ? atoi(getenv("FMX_FRONT_KERNEL")) : 0;     // (diagnostic: A/B runs of one build)
-        const int fk = h->front_kernel.load() ? h->front_kernel.load() : fk_env;
+        const int fk = h->front_kernel.load() ? h->front_kernel.load() : env_switches().front_kernel;     // (the environment: A/B runs of one build)
         // automatic: the filter on the matrix pipe wherever a handle qualifies and has the channels to fill the chip without splitting them in time
         // (measured at 4096 channels on one box: 1.52 ms per launch against 1.75 for the four-wave kernel and 1.84 for the six-wave VALU kernel, which
         // both sit at the packed-FMA power limit)
-        if (h->front3_ok && fk == 2) { G.parts = 1; G.front3 = 1; }
-        if (h->front4_ok && (fk == 3 || (fk == 0 && G.parts <= 1))) { G.parts = 1; G.front3 = 2; }
-        // (what is reported is what runs: a call without a whole tile on the kernels' grid goes to front_kernel in launch_front)
-        const int tiles = G.front3 == 2 ? front4_tiles(G, d_iq) : (G.front3 == 1 ? front3_tiles(G, d_iq) : 0);
-        h->last_front_kernel = tiles > 0 ? G.front3 + 1 : 1;
+        if (h->front4_ok && (fk == 3 || (fk == 0 && G.parts <= 1))) { G.parts = 1; G.front4 = 1; }
+        // (what is reported is what runs: a call without a whole tile on the kernel's grid goes to front_kernel in launch_front)
+        h->last_front_kernel = (G.front4 && front4_tiles(G, d_iq) > 0) ? 3 : 1;
     }
     if (h->ola_mode) {
         // few channels: RF DC removal / balance / LO mix per sample, the input filter as the reference's block machine, then the decimators
@@ -902,7 +885,7 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     } else
     launch_front(h->T, h->B, G, d_iq, h->channels, sa);   // stage A: four waves per channel, packed-FMA FIR (fmx_front.hip)
     FMX_LAUNCHED();
-    static const bool prof_double = getenv("FMX_PROF_DOUBLE") != nullptr;    // (diagnostic: a throw-away event in front of each boundary event)
+    const bool prof_double = env_switches().prof_double != 0;    // (diagnostic: a throw-away event in front of each boundary event)
     if (prof && prof_double && !h->ev_dummy) HIPCHK(hipEventCreate(&h->ev_dummy));      // (one per handle, destroyed with it)
     hipEvent_t pdummy = h->ev_dummy;
     if (prof && prof_double) HIPCHK(hipEventRecord(pdummy, sa));
@@ -915,10 +898,10 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     // roofline line is measured on.  The groups touch disjoint channels (CallGeom::ch0 / ch_count); the caller's stream goes on behind both.  FMX_TAIL_SPLIT=0: off.
     int tail_ch = 0;
     {
-        static const bool tail_on = !(getenv("FMX_TAIL_SPLIT") && atoi(getenv("FMX_TAIL_SPLIT")) == 0);
+        const bool tail_on = env_switches().tail_split != 0;
         const int slots = 3 * (h->n_cus > 0 ? h->n_cus : 256);
         const bool plain = !piped && !h->ola_mode && !h->B.w_iq && !h->cv_nt && !h->B.rows_on && !(h->rds_alloc && any_rds_on(h)) && !h->gain_pending && G.stageb_form == 0 &&
-                           !getenv("FMX_STAGEB_SPLIT") && G.J1 > G.J0 && G.M1 > G.M0;
+                           env_switches().stageb_split < 0 && G.J1 > G.J0 && G.M1 > G.M0;
         if (tail_on && plain && h->channels > slots) {
             // (the first group: 2304 of 4096 channels on 256 CUs -- three whole rounds.  Measured there, second group of 256 / 512 / 1024 /
             // 1792 / 2048 / 3072 channels: 3.47 / 3.45 / 3.35 / 3.32 / 3.39 / 3.43 ms per step against 3.47-3.55 with one group.  FMX_TAIL_CH=n: a diagnostic)
@@ -927,7 +910,7 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
             int first_rounds = (int)(0.65 * (double)h->channels / (double)slots + 0.5);
             if (first_rounds < 1) first_rounds = 1;
             tail_ch = h->channels - first_rounds * slots;
-            static const int force = getenv("FMX_TAIL_CH") ? atoi(getenv("FMX_TAIL_CH")) : 0;
+            const int force = env_switches().tail_ch;
             if (force > 0 && force < h->channels) tail_ch = force;
             if (tail_ch < TAIL_MIN_CHANNELS) tail_ch = 0;             // (a second group of a few dozen channels is three launches for nothing)
             if (tail_ch > 0) { const int rc2 = ensure_pipe_streams(h); if (rc2) return rc2; }
@@ -962,7 +945,7 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         const int64_t nj = G.J1 - G.J0;
         int modes = 0;
         for (int c = 0; c < h->channels; c++) {
-            const int m = h->params[(size_t)c].rds_mode;
+            const int m = h->call_rds_mode[(size_t)c];
             modes |= 1 << m;
             h->rds_nc0[(size_t)c] = m != 0 ? h->rds_nc[(size_t)c] : -1;
         }
@@ -971,7 +954,7 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         launch_rds(h->B, h->R, G, h->channels, h->rds_nc0.data(), modes, s);
         for (int c = 0; c < h->channels; c++) {
             const int64_t a = h->rds_nc0[(size_t)c];
-            if (a < 0) continue;
+            if (a < 0) { h->last_m0[(size_t)c] = h->last_m1[(size_t)c]; continue; }       // (decoder off in this call: no outputs, not the last on-call's)
             h->last_m0[(size_t)c] = a / 8; h->last_m1[(size_t)c] = (a + nj) / 8;
             h->rds_nc[(size_t)c] = a + nj;
         }
@@ -1037,6 +1020,20 @@ int prof_drain(fmx_handle h) {
 
 }  // namespace
 
+namespace fmx {
+const EnvSwitches &env_switches() {
+    static const EnvSwitches sw = [] {
+        EnvSwitches e{};
+        e.call_pieces = env_int("FMX_CALL_PIECES", -1); e.pieces_serial = env_int("FMX_CALL_PIECES_SERIAL", 0) != 0; e.front_kernel = env_int("FMX_FRONT_KERNEL", 0);
+        e.prof_double = getenv("FMX_PROF_DOUBLE") != nullptr; e.tail_split = env_int("FMX_TAIL_SPLIT", 1) != 0; e.tail_ch = env_int("FMX_TAIL_CH", 0);
+        e.stageb_split = env_int("FMX_STAGEB_SPLIT", -1); e.rows_off_split = getenv("FMX_ROWS_OFF_SPLIT") != nullptr; e.no_sinpoly = getenv("FMX_DEBUG_NO_SINPOLY") != nullptr;
+        e.host_zerocopy = env_int("FMX_HOST_ZEROCOPY", 1) != 0; e.rds_pair = env_int("FMX_RDS_PAIR", 1) != 0;
+        return e;
+    }();
+    return sw;
+}
+}  // namespace fmx
+
 // ---- diagnostics: the practical HBM ceiling (SURVEY 8d asks for the measured device-copy bandwidth next to the nominal 8 TB/s)
 namespace fmx {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -1068,6 +1065,7 @@ const char *fmx_last_error(void) { return g_err.c_str(); }
 
 int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     if (!cfg || !out) return fail(FMX_E_INVALID, "null argument");
+    (void)env_switches();                       // (the FMX_* environment switches: read here, once per process)
     if (cfg->struct_size != (int32_t)sizeof(fmx_config)) return fail(FMX_E_INVALID, "fmx_config.struct_size mismatch");
     if (cfg->channels < 1) return fail(FMX_E_INVALID, "channels must be >= 1");
     if (cfg->fmRate != 192000 || cfg->workingRate != 48000)
@@ -1167,7 +1165,7 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
                 if (std::memcmp(&sn, &sc[i].y, 4) != 0) { if (sp.ns < 4) { sp.s_idx[sp.ns] = i; sp.s_val[sp.ns] = sc[i].y; sp.ns++; } else fits = false; }
                 if (std::memcmp(&cs, &sc[i].x, 4) != 0) { if (sp.nc < 4) { sp.c_idx[sp.nc] = i; sp.c_val[sp.nc] = sc[i].x; sp.nc++; } else fits = false; }
             }
-            sp.ok = (fits && !getenv("FMX_DEBUG_NO_SINPOLY")) ? 1 : 0;
+            sp.ok = (fits && !env_switches().no_sinpoly) ? 1 : 0;
             h->T.sp = sp;
         }
         {   // 2-level factorisation of the sine column for the sequential pilot PLL (LDS resident):
@@ -1228,14 +1226,6 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
         HIPCHK(hipMemcpy(h->d_pss_hs, Hs.data(), sizeof(float2) * fftc::N, hipMemcpyHostToDevice));
         h->T.fft_w = h->d_fft_w;
         h->T.pss_hs = h->d_pss_hs;
-        // ... and its matrix-pipe form (fmx_mfmaconv.h; which of the two stage B runs is a compile-time choice: SB_PSS_MFMA in fmx_stageb.hip)
-        {
-            std::vector<uint16_t> mt(2 * 4 * mconv::TABN);
-            mconv::make_tables(h->h_pss_taps.data(), mt.data());
-            HIPCHK(hipMalloc(&h->d_pss_mtab, sizeof(uint16_t) * mt.size()));
-            HIPCHK(hipMemcpy(h->d_pss_mtab, mt.data(), sizeof(uint16_t) * mt.size(), hipMemcpyHostToDevice));
-            h->T.pss_mtab = h->d_pss_mtab;
-        }
     }
     h->T.sincos_C = fmRate / (2 * design::kPi);
     {   // fm_Demodulator ctor fm-demodulator.cpp:57-72
@@ -1340,7 +1330,7 @@ int fmx_destroy(fmx_handle h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &pr : h->prof) for (int i = 0; i < 4; i++) (void)hipEventDestroy(pr.e[i]);
-    void *ptrs[] = { h->d_pss_mtab, h->d_audio_mtab, h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
+    void *ptrs[] = { h->d_audio_spec, h->d_audio_lp, h->d_rs_taps, h->B.gfix, h->d_fft_w, h->d_pss_hs, h->d_front_taps, h->d_audio_taps, h->d_pss_taps, h->d_front_sets, h->d_audio_sets, h->d_sincos,
                      h->d_lo, h->d_atan, h->d_arcsine, h->d_trig3, h->d_params, h->B.hist, h->B.dcv_hist, h->B.zring,
                      h->B.sring, h->B.dring, h->B.state, h->d_iq, h->d_pcm, h->B.w_dem, h->B.w_iq, h->B.w_cur,
                      h->B.w_osc, h->d_cv_taps, h->d_x48 };      // (the LR tap's rows are in tail_ptrs)
@@ -1380,7 +1370,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     case FMX_P_SQUELCH_VALUE: if (iv < 0 || iv > 100) return fail(FMX_E_INVALID, "squelch value must be 0..100"); break;
     case FMX_P_PLL_SOLVER: if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "PLL solver must be 0 (automatic), 1 (sequential), 2 (Newton, sequential around lock decisions) or 3 (Newton always)"); break;
     case FMX_P_FRONT_KERNEL:
-        if (iv < 0 || iv > 3) return fail(FMX_E_INVALID, "front kernel must be 0 (automatic), 1 (four waves per channel), 2 (six waves per channel) or 3 (the filter on the matrix pipe)");
+        if (iv < 0 || iv > 3 || iv == 2) return fail(FMX_E_INVALID, "front kernel must be 0 (automatic), 1 (four waves per channel, packed f32 FMAs) or 3 (the filter on the matrix pipe); 2 was round 5's six-wave kernel, now tools/experiments/fmx_front3.hip");
         h->front_kernel.store(iv); return FMX_OK;
     case FMX_P_SCOPE_TAPS:
         if (iv < -1 || iv > 1) return fail(FMX_E_INVALID, "scope taps must be -1 (automatic), 0 (not kept) or 1 (kept)");
@@ -1505,7 +1495,7 @@ int fmx_process_host_raw(fmx_handle h, const void *iq, int32_t format, float s16
     // The single receiver's call (one stream, 16384 samples: 128 KB in, 2.7 KB out) spends a third of its time in the two copies' fixed costs
     // (a pageable buffer is staged by the runtime, each copy is a submission of its own).  Small calls go through pinned, device-visible
     // memory instead: the samples are copied there by the CPU and READ BY STAGE A over the bus, the PCM is written there by stage C.
-    static const bool zc_env = !(getenv("FMX_HOST_ZEROCOPY") && atoi(getenv("FMX_HOST_ZEROCOPY")) == 0);
+    const bool zc_env = env_switches().host_zerocopy != 0;
     constexpr size_t ZC_MAX_IN = (size_t)1 << 20;
     const size_t in_bytes = bps * (size_t)n * (size_t)h->streams;
     if (zc_env && in_bytes <= ZC_MAX_IN && (size_t)h->channels * (size_t)cap * sizeof(float2) <= ZC_MAX_IN) {
@@ -1568,7 +1558,7 @@ int fmx_get_meta(fmx_handle h, int32_t channel, fmx_meta *m) {
 int fmx_get_peaks(fmx_handle h, int32_t channel, float *lr_db, int32_t capacity, int32_t *n_events) {
     if (!h || !n_events || channel < 0 || channel >= h->channels || capacity < 0 || (capacity > 0 && !lr_db))
         return fail(FMX_E_INVALID, "bad argument");
-    if (!h->taps_kept) return fail(FMX_E_UNSUPPORTED, "this handle does not run the peak-level meter (FMX_P_SCOPE_TAPS)");
+    if (!h->taps_kept) return fail(FMX_E_UNSUPPORTED, "this handle does not run the peak-level meter: a display feed, automatic only up to 64 channels -- fmx_set_param (h, -1, FMX_P_SCOPE_TAPS, 1) and one call switch it on");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipDeviceSynchronize());
     ChanState st;
@@ -1609,7 +1599,7 @@ int fmx_get_tap(fmx_handle h, int32_t channel, int32_t tap, float *dst, int64_t 
     case FMX_TAP_DEMOD: case FMX_TAP_LR_RAW: case FMX_TAP_PILOT_PHASE: {
         // these taps are read back from the last call's work arrays (channel-major rows of the call), rows [nj - n, nj)
         const int64_t nj = h->last_J1 - h->last_J0, r0 = nj - n;
-        if (!h->taps_kept) return fail(FMX_E_UNSUPPORTED, "this handle does not keep the demodulator / LR / pilot-phase scope taps (FMX_P_SCOPE_TAPS)");
+        if (!h->taps_kept) return fail(FMX_E_UNSUPPORTED, "this handle does not keep the demodulator / LR / pilot-phase scope taps: display feeds, automatic only up to 64 channels -- fmx_set_param (h, -1, FMX_P_SCOPE_TAPS, 1) and one call switch them on");
         if (n == 0) return FMX_OK;
         {                            // this call's rows are contiguous per channel
             const size_t off = (size_t)channel * (size_t)h->work_nj + (size_t)r0;
@@ -1836,7 +1826,7 @@ int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32
     return FMX_OK;
 }
 
-// diagnostics (not part of include/fmx.h): streaming bandwidth of this GPU in GB/s over `bytes` of float2 data, the mean of
+// diagnostics (include/fmx_debug.h): streaming bandwidth of this GPU in GB/s over `bytes` of float2 data, the mean of
 // `iters` launches timed with HIP events.  mode 0: copy (counts bytes read + written); mode 1: read 12, write 1 (stage A's shape).
 int fmx_debug_stream_bandwidth(int32_t device, int32_t mode, int64_t bytes, int32_t iters, double *gbps) {
     if (!gbps || bytes < (1 << 20) || iters < 1 || (mode != 0 && mode != 1)) return fail(FMX_E_INVALID, "bad argument");
@@ -1864,7 +1854,7 @@ int fmx_debug_stream_bandwidth(int32_t device, int32_t mode, int64_t bytes, int3
     return FMX_OK;
 }
 
-// diagnostics (not part of include/fmx.h): per-phase shader-cycle counters of front_kernel, summed over channels
+// diagnostics (include/fmx_debug.h): per-phase shader-cycle counters of front_kernel, summed over channels
 int fmx_debug_phase_cycles(fmx_handle h, int32_t enable, unsigned long long *out /*[DBG_SLOTS = 96], may be null*/) {
     if (!h) return fail(FMX_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));

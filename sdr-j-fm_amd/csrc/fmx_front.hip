@@ -260,10 +260,17 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     // R0: an oscillator set back to 0 Hz keeps its phase (Oscillator::nextValue oscillator.cpp:49-58 goes on reading the table entry it
     // stopped at), so the reference multiplies every sample by that constant -- which commutes with the real-tap filters and rides with
     // the complex output gain here.
-    const bool lo_on = (P.lo_freq != 0) && (T.lo_table != nullptr);
-    const float2 R0 = (!pp && !lo_on && T.lo_table != nullptr && sn.lo_phase != 0) ? T.lo_table[sn.lo_phase] : make_float2(1.f, 0.f);
+    // (round 6: a channel whose IQ balance is not 1 takes the per-sample pass as well -- RfDC, balance, mix in the reference's order in front of the
+    // filter, :423-466 -- so that the filter sees the reference's own products x att.  `lo_on` reads "the channel's samples are processed in front of
+    // the filter", `lo_real` "its oscillator runs")
+    const bool lo_real = (P.lo_freq != 0) && (T.lo_table != nullptr);
+    const bool lo_on = lo_real || P.att_l != 1.0f || P.att_r != 1.0f;
+    const float2 R0 = (!pp && !lo_real && T.lo_table != nullptr && sn.lo_phase != 0) ? T.lo_table[sn.lo_phase] : make_float2(1.f, 0.f);
     const bool dc_rst0 = (P.actions & ACT_DC_RESET) != 0;
-    const float2 R0h = (lo_on && sn.hist_fmt == 0 && sn.lo_phase != 0) ? T.lo_table[sn.lo_phase] : make_float2(1.f, 0.f);   // (what the raw history was read with)
+    const float2 R0h = (lo_real && sn.hist_fmt == 0 && sn.lo_phase != 0) ? T.lo_table[sn.lo_phase] : make_float2(1.f, 0.f);   // (what the raw history was read with)
+    // processed history of a channel whose oscillator has just been set back to 0 Hz and whose balance keeps it on the per-sample pass: the constant the
+    // oscillator stopped at rides with the output gain from here on, the history's samples carry the oscillator's own values already
+    const bool hist_derot = !pp && lo_on && !lo_real && sn.hist_fmt == 1 && T.lo_table != nullptr && sn.lo_phase != 0;
     const bool hist_convert = lo_on && (sn.hist_fmt == 0) && (P.dc_remove != 0 || P.att_l != 1.0f || P.att_r != 1.0f || dc_rst0 || sn.lo_phase != 0);
     const bool hist_to_raw = !pp && !lo_on && (sn.hist_fmt == 1);
     const bool hist_rst = !lo_on && (sn.hist_fmt == 0) && dc_rst0;
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
                 v = make_float2(v.x * R0.x + v.y * R0.y, v.y * R0.x - v.x * R0.y);
                 v.x = (P.att_l != 0.f ? v.x / P.att_l : 0.f) + dc_now.x;
                 v.y = (P.att_r != 0.f ? v.y / P.att_r : 0.f) + dc_now.y;
-            }
+            } else if (hist_derot) v = make_float2(v.x * R0.x + v.y * R0.y, v.y * R0.x - v.x * R0.y);
             X2[xidx(r, c)] = v;
         }
     }
@@ -336,9 +343,9 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
     // subtraction -- and the IQ balance, a gain per component -- happens on the 128 outputs of a tile instead of its 1536 inputs.
     // The DC pass then only SUMS the lane's samples (first order in alpha: the terms dropped are alpha^2 k^2 |x| < 5e-7 |RfDC| over
     // a tile; the decay between tiles stays exact), scans, and leaves the RfDC value at every column boundary in `dcv`.
-    const bool fast = !mix;
+    const bool fast = !mix && Lg == 1.0f && Rg == 1.0f;
     const bool fastdc = fast && dcr;
-    const bool dc_phase = mix ? touch : dcr;
+    const bool dc_phase = !fast ? touch : dcr;
     const float hsum = FS.hsum, dcw = FS.dc_w;
     const int dck = FS.dc_k;
     // a lane's sample PAIR is one 16 / 4 / 8 byte load when the buffer is aligned that far
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
                     hist[i] = v;
                 }
                 if (lane == 0 && (dcr || dc_rst)) { st->dc_re = dcr ? c_out_r : dc0r; st->dc_im = dcr ? c_out_i : dc0i; }
-                if (lane == 0 && !pp) st->hist_fmt = mix ? 1 : 0;
+                if (lane == 0 && !pp) st->hist_fmt = !fast ? 1 : 0;
                 if (fast) {
                     // RfDC in front of the 13 columns before the next call's first column qn and of qn itself (the state behind the
                     // call when the call ends on a column boundary; zero history when DC removal is off)
@@ -664,7 +671,6 @@ __global__ __launch_bounds__(NTHR, FMX_WG_PER_CU) FMX_WAVES_ATTR void front_kern
                 aA.x = fmaf(-hsum, __builtin_amdgcn_fmed3f(dAr, -0.01f, 0.01f), aA.x); aA.y = fmaf(-hsum, __builtin_amdgcn_fmed3f(dAi, -0.01f, 0.01f), aA.y);
                 aB.x = fmaf(-hsum, __builtin_amdgcn_fmed3f(dBr, -0.01f, 0.01f), aB.x); aB.y = fmaf(-hsum, __builtin_amdgcn_fmed3f(dBi, -0.01f, 0.01f), aB.y);
             }
-            if (fast && (Lg != 1.0f || Rg != 1.0f)) { aA.x *= Lg; aA.y *= Rg; aB.x *= Lg; aB.y *= Rg; }      // IQ balance :462-464
             const float2 zA = make_float2(aA.x * cg_re - aA.y * cg_im, aA.x * cg_im + aA.y * cg_re);
             const float2 zB = make_float2(aB.x * cg_re - aB.y * cg_im, aB.x * cg_im + aB.y * cg_re);
             const int zi = (zr0 + q) & G.ring_mask;
@@ -754,15 +760,15 @@ __global__ __launch_bounds__(64) void front_pre_kernel(DeviceBuffers B, CallGeom
 
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s) {
-    if (G.front3) {
-        // batches that fill the chip: the call's whole tiles on three waves per SIMD, what is left of it (less than a tile) behind them as a
+    if (G.front4) {
+        // batches that fill the chip: the call's whole tiles on the matrix pipe, what is left of it (less than a tile) behind them as a
         // call of its own -- the chain is invariant to how a stream is cut into calls
-        const int k = G.front3 == 2 ? front4_tiles(G, iq) : front3_tiles(G, iq);
+        const int k = front4_tiles(G, iq);
         if (k > 0) {
             CallGeom G3 = G; G3.n = (int64_t)k * WSAMP; G3.parts = 1;
-            if (G.front3 == 2) launch_front4(T, B, G3, iq, channels, s); else launch_front3(T, B, G3, iq, channels, s);
+            launch_front4(T, B, G3, iq, channels, s);
             if (G3.n == G.n) return;
-            CallGeom G2 = G; G2.front3 = 0; G2.cont = 1; G2.parts = 1; G2.g0 = G.g0 + G3.n; G2.n = G.n - G3.n;
+            CallGeom G2 = G; G2.front4 = 0; G2.cont = 1; G2.parts = 1; G2.g0 = G.g0 + G3.n; G2.n = G.n - G3.n;
             const size_t bps = (G.iq_format == 0) ? 8 : (G.iq_format == 3 ? 4 : 2);
             launch_front(T, B, G2, reinterpret_cast<const char *>(iq) + (size_t)G3.n * bps, channels, s);
             return;

@@ -7,18 +7,23 @@
 //   fmBand_1 (25 taps, /6)   fm-processor.cpp:472,  fir-filters.cpp:397-424
 //   fmBand_2 (3 taps, /2)    fm-processor.cpp:474
 //
-// Why.  front_kernel (and its six-wave sibling fmx_front3.hip) spend 600 v_pk_fma_f32 per 1536-sample tile on the folded 287-tap filter, and a
+// Why.  front_kernel (and its six-wave sibling, tools/experiments/fmx_front3.hip) spend 600 v_pk_fma_f32 per 1536-sample tile on the folded 287-tap filter, and a
 // kernel of packed FMAs runs this GPU into its power limit: 93 TFLOP/s sustained of the nominal 157 (tools/ubench/pkfma_clock.hip).  With
 // every load compiled out front3_kernel takes 1.67 ms per launch at 4096 channels, with everything BUT the loads compiled out 1.49 ms
 // (tools/diag/f3_ablate.sh): the stage sits at the vector ALU's power limit, not at the HBM stream's.  The f32 matrix instruction is no way
 // out (round 2, fmx_front2.hip: the Toeplitz form wastes 38 % of its multiplies, and it runs on the same f32 data path).  The f16 matrix
 // instruction is: sixteen times the rate, so the filter can afford both the Toeplitz zeros and a SPLIT of every operand into two halves --
-//     x * 2^12 = xh + xl,   t * 2^14 = th + tl      (xh, th: the value rounded to f16; xl, tl: the remainder rounded to f16)
-//     sum t x  ~  2^-26 sum (th xh + th xl + tl xh)  (+ tl xl with FMX_F4_TERMS = 4)
+//     x * 2^e = xh + xl,   t * 2^14 = th + tl       (xh, th: the value rounded to f16; xl, tl: the remainder rounded to f16)
+//     sum t x  ~  2^-(e + 14) sum (th xh + th xl + tl xh)  (+ tl xl with FMX_F4_TERMS = 4)
 // -- products of f16 values are exact in the f32 accumulator, so what is lost is the rounding of the remainders and the dropped tl xl: 2^-21
-// of a product, the same order as the f32 filter's own rounding (measured against front_kernel: tests/test_gpu_round5.py).  The pre-scales keep
-// the remainders of every sample above 1e-8 and of every tap above 4e-9 out of f16's subnormals.  |x| must stay below 16 (the reference's
-// devices deliver +-1).
+// of a product, the same order as the f32 filter's own rounding (measured against front_kernel: tests/test_gpu_round5.py).
+// BLOCK FLOATING POINT (round 6): e is the TILE's -- 2^e max |x| in [2^14, 2^15) over the tile's 1536 balanced samples, found by the wave that
+// holds them (24 v_max3, one DPP reduction) -- so the filter is as linear as the reference's f32 one at any level a device or a file delivers:
+// nothing is clamped, a sample keeps 22 bits whatever the stream's amplitude, and a remainder that falls into f16's subnormals is below
+// 2^-39 of the tile's largest sample.  A window that begins in the previous tile (the first two column blocks: K-steps 0 .. 8 / 0 .. 2) sums
+// that part in the previous tile's unit and is rescaled by the exact power of two where the tiles' exponents differ (wave-uniform test; the
+// exponents ride with the scatter's sequence counters).  The IQ balance (fm-processor.cpp:462-464) is applied IN FRONT of the split, where the
+// reference has it: x (att 2^e) = RN (x att) 2^e, the reference's own product.
 //
 // Layout.  K of the matrix product is TIME: the Toeplitz matrix A[i][k] = G[12 i + off + 288 - k] of the folded taps G (16 adjacent outputs i
 // against the 480 samples k of their 40-column window) times B[k][n] = the window of column block b, component comp, n = 2 b + comp.  So the
@@ -29,7 +34,7 @@
 //   per tile and wave: 45 + 12 v_mfma_f32_16x16x32_f16, 66 LDS operand reads, ~300 plain VALU instructions (conversion, DC scan, epilogue)
 // instead of 600 packed FMAs and ~370 others.
 // Six waves per channel, two channels per workgroup, one workgroup per CU, the waves of a channel staggered through its tiles as in
-// fmx_front3.hip (scatter, prefetch of the wave's next tile, filter, DC recurrence through a mailbox, output).
+// tools/experiments/fmx_front3.hip (scatter, prefetch of the wave's next tile, filter, DC recurrence through a mailbox, output).
 // Where the time goes (tools/diag/f4_ablate.sh, 4096 channels, ms per launch on a box that runs the kernel in 1.50): no loads and no stores 0.97 --
 // no stores 1.25 -- no matrix instructions 1.50 -- everything 1.50.  The kernel runs at the rate this GPU streams its traffic mix at: twelve bytes
 // read for one written is 5.4-5.5 TB/s in a kernel that does nothing else, whatever the pattern (linear or 512 streams), the waves per CU (8 .. 64),
@@ -63,8 +68,22 @@ constexpr int MB_N = 16;                       // mailbox slot: [0..12] RfDC in 
 #ifndef FMX_F4_TERMS
 #define FMX_F4_TERMS 3
 #endif
-constexpr float XSC = 4096.f, TSC = 16384.f;   // pre-scales of the samples and of the taps
-constexpr float OSC = 1.0f / (4096.f * 16384.f);
+constexpr float TSC = 16384.f;                 // pre-scale of the taps (2^14); the samples' is the tile's own 2^e (block floating point)
+// a tile's scale from the biased exponent E of its largest balanced sample (clamped to [29, 254]: every factor below stays a normal float):
+// 2^e with e = 141 - E puts that sample into [2^14, 2^15); 2^-e; 2^-(e + 14) takes the accumulator back
+__device__ __forceinline__ int   bfp_E(float m) { const int E = (int)((__float_as_uint(m) >> 23) & 255u); return E < 29 ? 29 : (E > 254 ? 254 : E); }
+__device__ __forceinline__ float bfp_scale(int E) { return __uint_as_float((uint32_t)(268 - E) << 23); }
+__device__ __forceinline__ float bfp_inv(int E) { return __uint_as_float((uint32_t)(E - 14) << 23); }
+__device__ __forceinline__ float bfp_out(int E) { return __uint_as_float((uint32_t)(E - 28) << 23); }
+// 2^(e_cur - e_prev) = 2^(E_prev - E_cur): what takes a sum in the previous tile's unit into this tile's (the exponent limited to a float's)
+__device__ __forceinline__ float bfp_ratio(int E_prev, int E_cur) { int d = E_prev - E_cur; d = d < -126 ? -126 : (d > 127 ? 127 : d); return __uint_as_float((uint32_t)(127 + d) << 23); }
+// largest |.| of a wave's values, in every lane's SGPR copy
+__device__ __forceinline__ float wave_max(float v) {
+#define F4_MAX_STEP(ctrl, rmask) v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false)));
+    F4_MAX_STEP(0x111, 0xf) F4_MAX_STEP(0x112, 0xf) F4_MAX_STEP(0x114, 0xf) F4_MAX_STEP(0x118, 0xf) F4_MAX_STEP(0x142, 0xa) F4_MAX_STEP(0x143, 0xc)
+#undef F4_MAX_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 static_assert(HS % 32 == 0 && KSTEPS == 15 && PLB % 16 == 0 && (TA_N * 2) % 16 == 0, "geometry");
 
 typedef _Float16 h16;
@@ -79,8 +98,15 @@ __device__ __forceinline__ float dpp_swap1(float v) { return __int_as_float(__bu
 template <int SH> __device__ __forceinline__ float dpp_row_shr(float v) {        // lanes shifted right by SH within their row of 16, zeros shifted in
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + SH, 0xf, 0xf, true));
 }
-// a sample pair of one component, scaled: the two f16 roundings and the two f16 remainders, packed
-__device__ __forceinline__ void split2(float a, float b, uint32_t *hi, uint32_t *lo) {
+// a sample pair of one component times the tile's factor (balance x 2^e): the two f16 roundings and the two f16 remainders, packed.
+// The product is OPAQUE to the compiler behind its f32 rounding: with a factor that is not a power of two it is inexact, and hipcc (ROCm 7.2) otherwise
+// folds it into one of the two conversions -- the stored half RN16 (RN32 (x s)) by v_cvt_pk_f16_f32, the half it subtracts RN16 (x s) by
+// v_fma_mixlo_f16 -- one f16 ulp apart at every double-rounding tie: one sample in 2^13 lost its low half, 1e-4 of an output (found by
+// tools/diag/f4_bal.py; `#pragma clang fp contract(off)` does not stop the fold).  So: rounded to f32 once -- the reference's own x * Lgain
+// (fm-processor.cpp:462-464) -- and both halves taken from that value.
+__device__ __forceinline__ void split2(float x0, float x1, float sc, uint32_t *hi, uint32_t *lo) {
+    float a = x0 * sc, b = x1 * sc;
+    asm volatile("" : "+v"(a), "+v"(b));
     const h16 ha = (h16)a, hb = (h16)b;
     const h16 la = (h16)(a - (float)ha), lb = (h16)(b - (float)hb);
     *hi = __builtin_bit_cast(uint32_t, (v2h){ha, hb});
@@ -103,6 +129,8 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
         float2 mb[8][MB_N];                // RfDC boundaries behind tile ti, slot = ti & 7
         int carry_seq;                     // tiles whose mailbox slot is published
         int scat_seq[NW], fir_seq[NW];     // per wave: tiles scattered / tiles whose filter has read everything, + 1
+        int texp[8];                       // biased exponent (bfp_E) of the scale of the tile in ring slot w (written with the slot, read by the next tile's filter
+                                           // like the slot's last 288 samples: the same counters order both); [NW]: of the call's history
         int pad_[3];
     };
     __shared__ __attribute__((aligned(16))) ChanLds Lall[CPW];
@@ -166,26 +194,46 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
                                            : make_float2(__builtin_amdgcn_fmed3f(st_dc_re, -0.01f, 0.01f), __builtin_amdgcn_fmed3f(st_dc_im, -0.01f, 0.01f));
     const float2 *dcvR = B.dcv_hist + (size_t)ch * DCV_SAVE;
     if (wave == 0) {
-        for (int i = lane; i < DECIM * A_HIST_COLS; i += 64) {
+        constexpr int HQ = (DECIM * A_HIST_COLS + 63) / 64;
+        float2 hv[HQ];
+        float hm = 0.f;
+#pragma unroll
+        for (int q = 0; q < HQ; q++) {
+            const int i = lane + 64 * q;
             const int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;
-            if (c == HL) continue;                                 // (the partial column of a call that starts inside one: never here)
-            float2 v = hist[i];
-            if (hist_rst) {
-                const int tb = c - HL + 13;
-                const float2 d = dcvR[tb < 0 ? 0 : tb];
-                v.x -= __builtin_amdgcn_fmed3f(d.x, -0.01f, 0.01f);
-                v.y -= __builtin_amdgcn_fmed3f(d.y, -0.01f, 0.01f);
-            } else if (hist_to_raw) {
-                v = make_float2(v.x * R0.x + v.y * R0.y, v.y * R0.x - v.x * R0.y);
-                v.x = (P.att_l != 0.f ? v.x / P.att_l : 0.f) + dc_now.x;
-                v.y = (P.att_r != 0.f ? v.y / P.att_r : 0.f) + dc_now.y;
+            float2 v = make_float2(0.f, 0.f);
+            if (i < DECIM * A_HIST_COLS && c != HL) {              // (c == HL: the partial column of a call that starts inside one: never here)
+                v = hist[i];
+                if (hist_rst) {
+                    const int tb = c - HL + 13;
+                    const float2 d = dcvR[tb < 0 ? 0 : tb];
+                    v.x -= __builtin_amdgcn_fmed3f(d.x, -0.01f, 0.01f);
+                    v.y -= __builtin_amdgcn_fmed3f(d.y, -0.01f, 0.01f);
+                } else if (hist_to_raw) {
+                    v = make_float2(v.x * R0.x + v.y * R0.y, v.y * R0.x - v.x * R0.y);
+                    v.x = v.x / P.att_l + dc_now.x;                // (the balance is never 0 here: fmx_api.hip, front4_ok)
+                    v.y = v.y / P.att_r + dc_now.y;
+                }
             }
-            const int s = DECIM * c + r;                           // sample of the 288 in front of the call
-            const float xr = __builtin_amdgcn_fmed3f(v.x * XSC, -65504.f, 65504.f), xi = __builtin_amdgcn_fmed3f(v.y * XSC, -65504.f, 65504.f);
-            const h16 hr = (h16)xr, hi = (h16)xi;
-            L.pl[0][s] = hr; L.pl[1][s] = hi;
-            L.pl[2][s] = (h16)(xr - (float)hr); L.pl[3][s] = (h16)(xi - (float)hi);
+            hv[q] = v;
+            hm = __builtin_fmaxf(hm, __builtin_fmaxf(__builtin_fabsf(v.x * P.att_l), __builtin_fabsf(v.y * P.att_r)));
         }
+        const int Eh = bfp_E(wave_max(hm));
+        const float hsl = P.att_l * bfp_scale(Eh), hsr = P.att_r * bfp_scale(Eh);     // IQ balance :462-464 and the block's scale, one exact factor
+#pragma unroll
+        for (int q = 0; q < HQ; q++) {
+            const int i = lane + 64 * q;
+            const int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;
+            if (i < DECIM * A_HIST_COLS && c != HL) {
+                const int s = DECIM * c + r;                       // sample of the 288 in front of the call
+                uint32_t hr2, lr2, hi2, li2;
+                split2(hv[q].x, 0.f, hsl, &hr2, &lr2);
+                split2(hv[q].y, 0.f, hsr, &hi2, &li2);
+                reinterpret_cast<uint16_t *>(&L.pl[0][0])[s] = (uint16_t)(hr2 & 0xffffu); reinterpret_cast<uint16_t *>(&L.pl[1][0])[s] = (uint16_t)(hi2 & 0xffffu);
+                reinterpret_cast<uint16_t *>(&L.pl[2][0])[s] = (uint16_t)(lr2 & 0xffffu); reinterpret_cast<uint16_t *>(&L.pl[3][0])[s] = (uint16_t)(li2 & 0xffffu);
+            }
+        }
+        if (lane == 0) L.texp[NW] = Eh;
     }
     // RfDC in front of the 13 columns before this call's first column and of that column itself
     if (t < 14) mb[7][t] = (hist_to_raw || hist_rst) ? make_float2(dc_rst ? 0.f : st_dc_re, dc_rst ? 0.f : st_dc_im) : dcvR[t];
@@ -198,8 +246,9 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const float alpha = 1.0f / (float)G.input_rate;   // rfDcAlpha fm-processor.cpp:379
     const float cg_re = (FS.gain_re * R0.x - FS.gain_im * R0.y), cg_im = (FS.gain_re * R0.y + FS.gain_im * R0.x);     // complex output gain x R0
     const float kown = cg_re, kpar = comp ? cg_im : -cg_im;       // z = a_own kown + a_partner kpar
-    const float bal = comp ? P.att_r : P.att_l;                   // IQ balance :462-464
-    const float hsum = FS.hsum, dcw = FS.dc_w;
+    const float bal = comp ? P.att_r : P.att_l;                   // IQ balance :462-464: applied with the tile's scale, in front of the filter
+    const float ibal = 1.0f / bal;                                // (the column sums of the RF DC recurrence are wanted without it)
+    const float hsum = FS.hsum * bal, dcw = FS.dc_w;              // what the filter makes of a constant that is balanced like the samples
     // the RF DC recurrence over a tile (first order in alpha inside it, as front_kernel's fast path; the decay of the state over the tile and of
     // the samples' weights towards its end to third / second order: relative errors below 1e-10)
     const float ut = 1536.0f * alpha, u_tile = ut - 0.5f * ut * ut + (1.0f / 6.0f) * ut * ut * ut;       // 1 - (1 - alpha)^1536
@@ -259,15 +308,26 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
         const int qt = ti * WCOLS;                    // first column of the tile
         // ---- split the samples and put them into the ring, once the next tile's filter (the wave behind this one) has read its history from
         //      what the slot held
+        // the tile's scale: its largest balanced sample goes to [2^14, 2^15) (an infinite or NaN sample spreads over the filter's length as it does
+        // in the reference: nothing limits)
+        int Et;
+        {
+            float mr = 0.f, mi = 0.f;
+#pragma unroll
+            for (int k = 0; k < SPT / 2; k++) {
+                mr = __builtin_fmaxf(mr, __builtin_fmaxf(__builtin_fabsf(raw[k].x), __builtin_fabsf(raw[k].z)));
+                mi = __builtin_fmaxf(mi, __builtin_fmaxf(__builtin_fabsf(raw[k].y), __builtin_fabsf(raw[k].w)));
+            }
+            Et = bfp_E(wave_max(__builtin_fmaxf(mr * __builtin_fabsf(P.att_l), mi * __builtin_fabsf(P.att_r))));
+        }
+        const float sc_l = P.att_l * bfp_scale(Et), sc_r = P.att_r * bfp_scale(Et);      // x (att 2^e) = RN (x att) 2^e: the reference's product :462-464
         if (ti - NW + 1 >= 0) seq_wait(&fir_seq[nw], ti - NW + 2);
         if (!(F4_ABL & 1)) {
 #pragma unroll
             for (int k = 0; k < SPT / 2; k++) {
                 uint32_t hr, lr, hi, li;
-                // (samples beyond f16's range behind the pre-scale, |x| >= 16, saturate there instead of becoming infinities that the filter
-                // would spread over 24 columns as NaNs: a limiter where the f32 kernel is linear -- include/fmx.h states the range)
-                split2(__builtin_amdgcn_fmed3f(raw[k].x * XSC, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(raw[k].z * XSC, -65504.f, 65504.f), &hr, &lr);
-                split2(__builtin_amdgcn_fmed3f(raw[k].y * XSC, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(raw[k].w * XSC, -65504.f, 65504.f), &hi, &li);
+                split2(raw[k].x, raw[k].z, sc_l, &hr, &lr);
+                split2(raw[k].y, raw[k].w, sc_r, &hi, &li);
                 *reinterpret_cast<uint32_t *>(scW + 256 * k) = hr;
                 *reinterpret_cast<uint32_t *>(scW + 256 * k + PLB) = hi;
                 *reinterpret_cast<uint32_t *>(scW + 256 * k + 2 * PLB) = lr;
@@ -294,12 +354,19 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
             }
             if (lane < DECIM) hist[lane * A_HIST_COLS + HL] = make_float2(0.f, 0.f);
         }
+        if (lane == 0) L.texp[wave] = Et;
         __builtin_amdgcn_wave_barrier();              // LDS operations of one wave complete in order
         if (lane == 0) seq_post(&scat_seq[wave], ti + 1);
         // ---- prefetch this wave's next tile as soon as the registers are free: the loads are in flight for the whole iteration
         if (ti + NW < NT && !(F4_ABL & 8)) load_tile(ti + NW);
         // ---- the previous tile's newest 288 samples are this tile's history (tile 0: the call's, put there in front of the barrier)
         if (ti > 0) seq_wait(&scat_seq[pw], ti);
+        // the first two column blocks' windows begin in the previous tile (K-steps 0 .. 8 of block 0, 0 .. 2 of block 1): where its scale is
+        // another one, their sums change unit behind those steps
+        const int Ep = __builtin_amdgcn_readfirstlane(L.texp[ti == 0 ? NW : pw]);
+        const bool rescale = Ep != Et;
+        const float rt = bfp_ratio(Ep, Et);
+        const float rt2 = (blk == 1) ? rt : 1.0f, rt8 = (blk == 0) ? rt : 1.0f;
 
         // ---- the filter: D[i][n] += A[i][k] B[k][n] over the 480 samples of the window, three (four) f16 terms; the column sums beside it
         v4f ahh = (v4f){0.f, 0.f, 0.f, 0.f}, ahl = ahh, alh = ahh, asum = ahh;
@@ -323,20 +390,24 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
                     asum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ao, Bh, asum, 0, 0, 0);
                     asum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ao, Bl, asum, 0, 0, 0);
                 }
+                if (rescale && j == 2) { ahh *= rt2; ahl *= rt2; alh *= rt2; }
+                if (rescale && j == 8) { ahh *= rt8; ahl *= rt8; alh *= rt8; }
             }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) seq_post(&fir_seq[wave], ti + 1);           // this slot's predecessor may take its owner's next tile
         float a[4];
+        const float osc = bfp_out(Et);
 #pragma unroll
-        for (int v = 0; v < 4; v++) a[v] = (ahh[v] + (ahl[v] + alh[v])) * OSC;
+        for (int v = 0; v < 4; v++) a[v] = (ahh[v] + (ahl[v] + alh[v])) * osc;
 
         // ---- RF DC removal (fm-processor.cpp:423-446) behind the filter, as front_kernel does it for channels without an LO -- here in the
         //      accumulator layout: the lane has the sums of its four columns (of its component), the exclusive prefix over the tile's 128 columns
         //      comes from two cross-row exchanges and a three-step row scan, the state in front of the tile from the previous tile's mailbox slot
         float c_out_r = dc0r, c_out_i = dc0i;
         if (dcr && !(F4_ABL & 2)) {
-            const float S0 = asum[0] * (1.0f / XSC), S1 = asum[1] * (1.0f / XSC), S2 = asum[2] * (1.0f / XSC), S3 = asum[3] * (1.0f / XSC);
+            const float isc = bfp_inv(Et) * ibal;                 // (the sums of the raw samples: RfDC runs in front of the balance)
+            const float S0 = asum[0] * isc, S1 = asum[1] * isc, S2 = asum[2] * isc, S3 = asum[3] * isc;
             const float e2 = S0 + S1, e3 = e2 + S2, tot = e3 + S3;
             const float p16 = bperm(lane ^ 16, tot), x1 = tot + p16;
             const float p32 = bperm(lane ^ 32, x1), bt = x1 + p32;                                  // the block's 16 columns
@@ -392,11 +463,9 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 a[v] = fmaf(-hsum, __builtin_amdgcn_fmed3f(d, -0.01f, 0.01f), a[v]);
             }
         }
-        // ---- IQ balance (:462-464), the decimators' complex gain, the fm-rate ring: the lane of the real part stores the quad's first two outputs,
+        // ---- the decimators' complex gain, the fm-rate ring: the lane of the real part stores the quad's first two outputs,
         //      the lane of the imaginary part the other two
         float z[4];
-#pragma unroll
-        for (int v = 0; v < 4; v++) a[v] *= bal;
 #pragma unroll
         for (int v = 0; v < 4; v++) z[v] = fmaf(dpp_swap1(a[v]), kpar, a[v] * kown);
         const float k0 = comp ? z[2] : z[0], k1 = comp ? z[3] : z[1];       // what the lane keeps ...

@@ -1,4 +1,4 @@
-// fmx_front_dc.h -- pieces the two input-FIR kernels (fmx_front.hip, fmx_front3.hip) and front_pre_kernel share: the RF DC recurrence of
+// fmx_front_dc.h -- pieces the input-FIR kernels (fmx_front.hip, fmx_front4.hip) and front_pre_kernel share: the RF DC recurrence of
 // fm-processor.cpp:423-446 over one tile as an affine map (per-lane run, DPP wave scan), and the mailbox counters between the waves of a
 // workgroup.  One definition, so that every kernel that walks a stream's tiles gets the same values bit for bit.
 #pragma once

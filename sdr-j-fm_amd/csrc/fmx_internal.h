@@ -21,7 +21,6 @@ constexpr int AUDIO_DELAY = 8192 - 756;
 constexpr int C_MAX_TAPS = AUDIO_TAPS + RS_TAPS - 1;   // 883
 constexpr int C_TAPS_STRIDE = 896;     // padded
 constexpr int C_TILE = 256;            // PCM frames per audio-FIR tile
-constexpr int AM_TAB = 1152;           // entries of a tap table of audio_mfma_kernel (fmx_audio.hip)
 constexpr int GAIN_FIX_BACK = RS_TAPS + 192;   // fm samples in front of a call's first that its first frames' resampler windows can reach: a call's frames begin at the
                                                // 192-sample block its first fm sample falls into (frames_geom: M0 = 48 (J0 / 192)), up to 191 samples before J0
 constexpr int GAIN_FIX_FRAMES = GAIN_FIX_BACK / 4;   // PCM frames whose resampler memory straddles a gain change (80; 32 when J0 is a multiple of 192)
@@ -186,15 +185,12 @@ struct DeviceTables {
     const float  *pss_taps;      // [PSS_TAPS]
     const float2 *fft_w;         // [fftc::W_COUNT] stage twiddles of fmx_fftconv.h
     const float2 *pss_hs;        // [2048] spectrum of the PSS taps in the forward transform's slot order, 1 / N included; null: direct FIR (FMX_PSS_FIR=direct)
-    const uint16_t *pss_mtab;    // [2][4][mconv::TABN] the PSS taps as fmx_mfmaconv.h wants them (f16 halves, reversed, four shifted copies); null: the fast convolution
     const float  *audio_taps;    // [sets][C_TAPS_STRIDE]
     const float  *audio_lp_taps; // [sets][AUDIO_TAPS] the audio low-pass alone (gain_fix_kernel), h[0] first
     const float  *rs_taps;       // [RS_TAPS] the resampler alone, h[0] first
     const float2 *audio_spec;    // [sets][4][2048] spectra of the folded FIR's four decimation phases, slot order of fmx_fftconv.h, 1 / N
                                  // included; null: the direct form (FMX_AUDIO_FIR=direct)
     const AudioSet *audio_sets;
-    const uint16_t *audio_mtab;  // [sets][2][2][AM_TAB] audio_mfma_kernel's tap tables as f16 bit patterns: window parity sh, (hi, lo) half, entry u = the folded
-                                 // FIR's reversed tap u - 124 - sh times 2^14 (zero outside the filter); null: the fast convolution
     double  sincos_C;            // Rate / (2*M_PI)  (sincos.cpp:42)
     float   K_FM, K_FM_rcp, pil_omega_rcp;   // rcp = RN(1/c) for fdiv_const
     float   pil_omega, pil_gain, pss_alpha, pss_lock_alpha;
@@ -231,9 +227,9 @@ struct CallGeom {
     int32_t no_deemph;       // channel, no RF DC removal, balance or LO mix here, history always raw, no front-end state written.  no_deemph: stage B
                              // writes the stereo pair to the d ring as it is: the audio low-pass (a block machine then) comes first, deemph_kernel behind it
     int32_t streams;         // IQ streams of the handle
-    int32_t front3;          // stage A: 1 the handle runs front3_kernel (fmx_front3.hip: no LO anywhere, every tap set the long fold), 2 front4_kernel
-                             // (fmx_front4.hip: the filter on the matrix pipe; RfDC taken 12 columns back in every tap set as well); launch_front
-                             // gives it the whole tiles of a call that starts on a column boundary, front_kernel the remainder and everything else
+    int32_t front4;          // stage A: != 0 the handle runs front4_kernel (fmx_front4.hip: the filter on the matrix pipe; no LO anywhere, every tap set the
+                             // long fold with RfDC taken 12 columns back); launch_front gives it the whole tiles of a call that starts on a column
+                             // boundary, front_kernel the remainder and everything else
     int32_t cont;            // front_kernel: this launch continues a call whose head another launch has made (the one-shot actions are done)
     int32_t ch_count;        // stage B: workgroups of the launch (0: one per channel of the handle); with ch0:
     int32_t ch0;             // stage B / C: the launch covers the channels ch0 ... ch0 + ch_count - 1 (stage C: + its channel argument - 1) (a batch whose last round of stage-B workgroups
@@ -387,12 +383,25 @@ void launch_rds(const DeviceBuffers &B, const RdsBuffers &Rb, const CallGeom &G,
 
 void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq,
                   int channels, hipStream_t s);
-// fmx_front3.hip: whole tiles of the call front3_kernel can take (0: none), and its launch over that many
-int front3_tiles(const CallGeom &G, const void *iq);
-void launch_front3(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels, hipStream_t s);
-// fmx_front4.hip: the same for front4_kernel (the filter on the matrix pipe; CallGeom::front3 == 2)
+// fmx_front4.hip: whole tiles of the call front4_kernel can take (0: none), and its launch over that many
 int front4_tiles(const CallGeom &G, const void *iq);
 void launch_front4(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels, hipStream_t s);
+// The FMX_* environment switches (diagnostics and A/B runs of one build; none is needed by a user): read ONCE, by the first fmx_create of the process --
+// nothing on the per-call path asks the environment.
+struct EnvSwitches {
+    int call_pieces;      // FMX_CALL_PIECES: fm samples per piece of an overlapping call (-1: the handle's setting)
+    int pieces_serial;    // FMX_CALL_PIECES_SERIAL=1: the same pieces one after the other on the caller's stream
+    int front_kernel;     // FMX_FRONT_KERNEL: stage-A kernel where the handle says automatic
+    int prof_double;      // FMX_PROF_DOUBLE: a throw-away event in front of each profiling event
+    int tail_split;       // FMX_TAIL_SPLIT=0: stages B and C as one channel group
+    int tail_ch;          // FMX_TAIL_CH=n: channels of the second group
+    int stageb_split;     // FMX_STAGEB_SPLIT=0 / 1: stage B as one kernel / two (-1: the round arithmetic)
+    int rows_off_split;   // FMX_ROWS_OFF_SPLIT: the round arithmetic also for batches that keep no scope-tap rows
+    int no_sinpoly;       // FMX_DEBUG_NO_SINPOLY: the SinCos table from memory
+    int host_zerocopy;    // FMX_HOST_ZEROCOPY=0: fmx_process_host through staged copies
+    int rds_pair;         // FMX_RDS_PAIR=0: one channel per RDS block transform
+};
+const EnvSwitches &env_switches();
 // first HIP error of the launches / event calls of the current fmx_process_* call (they are enqueued by void helpers);
 // run_call clears it before the launches and turns it into FMX_E_HIP behind them
 extern thread_local hipError_t g_launch_err;

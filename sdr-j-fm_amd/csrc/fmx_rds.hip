@@ -724,7 +724,7 @@ __global__ void rds_hil_split(const float2 *__restrict__ Z, const float2 *__rest
 // of their own count), Hilbert of the previous BP result.  Every channel of the handle at once: pairs of channels per transform; a subset (channels
 // that joined at different times): one channel per transform, by list.  Both forms keep their overlap tails by block parity.
 void launch_rds_block(const RdsBuffers &Rb, int C, int64_t blk, const int *h_list, int nlist, hipStream_t s) {
-    static const bool pair = !(getenv("FMX_RDS_PAIR") && atoi(getenv("FMX_RDS_PAIR")) == 0);
+    const bool pair = env_switches().rds_pair != 0;
     const size_t ov = (size_t)C * RDEG;                           // one parity of an overlap buffer
     if (pair && C >= 2 && nlist == C) {
         const int P = (C + 1) / 2;

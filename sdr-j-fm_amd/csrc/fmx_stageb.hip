@@ -37,16 +37,6 @@
 #include "fmx_internal.h"
 #include "fmx_demod_math.h"
 #include "fmx_fftconv.h"
-#include "fmx_mfmaconv.h"
-#ifndef MCONV_EXTRA_LDS
-#define MCONV_EXTRA_LDS 0   /* (diagnostic builds: words of LDS on top, to lower the kernel's occupancy) */
-#endif
-#ifndef SB_PSS_MFMA
-#define SB_PSS_MFMA 0     /* 1: the PSS low-pass on the matrix pipe (fmx_mfmaconv.h) instead of the fast convolution of fmx_fftconv.h.  NOT ADOPTED (round 5):
-                             worth 2-4 % of stage B (1.63 against 1.68 ms at 4096 channels), and in the second kernel of the two-kernel form 0.4 % of the
-                             (channel, call) pairs still differ from their twins (tools/diag/flake_hunt.py) after the matrix instructions' partly overlapping
-                             addends were taken out (see the header): a single window entry wrong now and then, cause not found.  The one-kernel form is clean. */
-#endif
 #include <type_traits>
 
 namespace fmx {
@@ -384,8 +374,6 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
     float *const sq_lo = big, *const sq_hi = big + FB_W, *const sq_b = big + 2 * FB_W, *const sq_wa = big + 3 * FB_W, *const sq_wb = big + 4 * FB_W;
     float *const pout = sq_lo;
     static_assert(5 * FB_W <= XF + 2 * FB_W && (FB_W % 4) == 0, "the rows fit the block");
-    static_assert(4 * mconv::PLB + mconv::TABB <= XF * 4 && mconv::OUT == FB_W && mconv::TAPS == PSS_TAPS, "the f16 planes and the hi tap table fit the convolution buffer");
-    __shared__ __attribute__((aligned(16))) uint32_t mlo[(PART == 1 || !SB_PSS_MFMA) ? 4 : mconv::TABB / 4 + MCONV_EXTRA_LDS];      // the lo halves of the PSS taps (fmx_mfmaconv.h)
     __shared__ __attribute__((aligned(16))) DecayTab<(PART == 0 ? 4 : 2)> dtab;
     const int ch = blockIdx.x + G.ch0;
     if (ch >= C) return;
@@ -1233,21 +1221,6 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 *reinterpret_cast<float2 *>(&park_cur[j0 + i]) = make_float2(cur[i], cur[i + 1]);
             }
             SB_FT(17); SB_FTW(18);
-#if SB_PSS_MFMA
-            // the low-pass on the matrix pipe (fmx_mfmaconv.h): the window into f16 planes in the convolution buffer, er behind its last barrier
-            mconv::pss_errors(tid, a, reinterpret_cast<char *>(big), reinterpret_cast<char *>(mlo), T.pss_mtab, er);
-            SB_FT(19);
-#ifdef MCONV_DEBUG_BOTH      /* (diagnostic: the fast convolution behind it, whose errors replace the matrix pipe's) */
-            __syncthreads();
-            fftc::convolve(tid, a, X, T.fft_w, T.pss_hs);
-            __syncthreads();
-#pragma unroll
-            for (int p = 0; p < 8; p++) {
-                const int m = tid + FB_T * p - (PSS_TAPS - 1);
-                if (m >= 0 && m < FB_W) er[m] = a[p].x * a[p].y;
-            }
-#endif
-#else
             fftc::convolve(tid, a, X, T.fft_w, T.pss_hs);
             SB_FT(19);
             __syncthreads();                   // (er overlays the buffer the last stage was read from)
@@ -1256,7 +1229,6 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 const int m = tid + FB_T * p - (PSS_TAPS - 1);
                 if (m >= 0 && m < FB_W) er[m] = a[p].x * a[p].y;
             }
-#endif
 #pragma unroll
             for (int i = 0; i < FB_K; i += 2) {
                 const float2 d2 = *reinterpret_cast<const float2 *>(&park_dem[j0 + i]), c2 = *reinterpret_cast<const float2 *>(&park_cur[j0 + i]);
@@ -1629,15 +1601,14 @@ void launch_demod_fused(const DeviceTables &T, const DeviceBuffers &B, const Cal
     // FMX_P_STAGEB_FORM (tests) or the environment (FMX_STAGEB_SPLIT=0 / 1: A/B runs of the bench) force either form.
     // (the handle's own CU count rides in CallGeom: handles on different devices -- another SKU, another partition mode -- each do their own
     // round arithmetic)
-    const char *envs = getenv("FMX_STAGEB_SPLIT");
-    const int env = envs ? atoi(envs) : -1;
+    const int env = env_switches().stageb_split;
     const int force = G.stageb_form ? G.stageb_form - 1 : env;
     const int cus = G.n_cus > 0 ? G.n_cus : 256;
     const long whole = (long)((C + SB_WG_PER_SIMD * cus - 1) / (SB_WG_PER_SIMD * cus)) * SB_WG_PER_SIMD * 100;
     const long halves = (long)((C + 4 * cus - 1) / (4 * cus)) * 4 * 102;          // (two launches, the hand-over through HBM: 2 %)
     // (a batch that keeps no scope taps and decodes no RDS: the whole kernel leaves the rows unwritten -- 0.63 GB per call at 4096 channels, and writes
     // are the expensive direction on this GPU -- and is then the faster form where the halves were: 1.60 against 1.69 ms)
-    const bool split = force >= 0 ? force != 0 : (B.rows_on ? halves < whole : (getenv("FMX_ROWS_OFF_SPLIT") ? halves < whole : false));
+    const bool split = force >= 0 ? force != 0 : (B.rows_on ? halves < whole : (env_switches().rows_off_split ? halves < whole : false));
     const unsigned grid = (unsigned)(G.ch_count > 0 ? G.ch_count : C);       // (a launch for some of the channels: CallGeom::ch0)
     if (split) {
         hipLaunchKernelGGL(stageb_kernel<1>, dim3(grid), dim3(FB_T), 0, s, A); FMX_LAUNCHED();

@@ -16,13 +16,13 @@ LIB_PATH = os.environ.get("FMX_LIB") or os.path.join(HERE, "lib", "libfmx.so")  
 FMX_OK, FMX_E_INVALID, FMX_E_UNSUPPORTED, FMX_E_NO_DEVICE, FMX_E_HIP, FMX_E_NOMEM, FMX_E_TOO_LARGE = 0, -1, -2, -3, -4, -5, -6
 
 # parameter ids (include/fmx.h fmx_param_id)
-ABI_VERSION = 2               # FMX_ABI_VERSION of include/fmx.h this mirror follows
+ABI_VERSION = 3               # FMX_ABI_VERSION of include/fmx.h this mirror follows
 P_FM_MODE, P_FM_DECODER, P_SOUND_MODE, P_STEREO_PANORAMA, P_SOUND_BALANCE, P_DEEMPHASIS = 1, 2, 3, 4, 5, 6
 P_VOLUME_DB, P_LF_CUTOFF, P_BANDWIDTH, P_ATTENUATION_L, P_ATTENUATION_R, P_RDS_MODE = 7, 8, 9, 10, 11, 12
 P_LOCAL_OSCILLATOR, P_AUTO_MONO, P_PSS, P_DC_REMOVE, P_SQUELCH_MODE, P_TEST_TONE, P_SQUELCH_VALUE = 13, 14, 15, 16, 17, 18, 19
 P_DISP_DELAY = 20
 P_STAGEB_FORM = 22            # handle-wide: 0 automatic, 1 stage B as one kernel per call, 2 as two (bit-identical results)
-P_FRONT_KERNEL = 25           # handle-wide: 0 automatic, 1 fmx_front.hip (packed f32 FMAs), 2 fmx_front3.hip (the same on six waves), 3 fmx_front4.hip (f16-split matrix FIR)
+P_FRONT_KERNEL = 25           # handle-wide: 0 automatic, 1 fmx_front.hip (packed f32 FMAs), 3 fmx_front4.hip (f16-split matrix FIR; 2 was the six-wave kernel now in tools/experiments)
 P_SCOPE_TAPS = 26             # handle-wide: -1 automatic (up to 64 channels), 0 the display feeds (demodulator / LR / pilot-phase scope taps, peak meter) are not produced, 1 produced
 P_CALL_PIECES = 27            # handle-wide: -1 automatic, 0 never, n > 0 fm samples per piece of a call made in overlapping pieces (pre-pass batches)
 P_FRONT_PARTS = 24            # handle-wide: 0 automatic, 1 one workgroup per channel, 2..32 parts in time per channel (bit-identical results)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised soak of the batch path against the oracle (GPU box; not collected by pytest: run by hand, `python tests/soak_random.py [first seed] [seeds] [channels] [plain 0|1]`).
+"""Randomised soak of the batch path against the oracle (GPU box: `python tests/soak_random.py [first seed] [seeds] [channels] [plain 0|1]`; a bounded run is in the suite,
+tests/test_gpu_round6.py::test_randomised_soak_against_the_oracle).
 Per seed: a handle of `channels` channels on five streams with settings drawn at random -- input filter width / off, IQ balance, local oscillator, DC
 removal, all six decoders, the three squelch modes with random thresholds, fm mode, selector, panorama, de-emphasis, volume, audio filter, auto-mono, and an
 RDS decoder (0 .. 3) switched on at a random call (some switched off again later) -- fed in calls of uneven length; every channel's PCM, and its RDS bit count
@@ -59,21 +60,21 @@ for seed in range(seed0, seed0 + nseeds):
     for c in range(nch):
         po = np.concatenate(ref[c])
         m = min(pcm.shape[1], po.shape[0])
-        # (behind the first call.  Where the input filter's latency ends -- 28 ms into the stream -- the limiter decides "|z| <= 0.001" on the filter's
-        # start-up transient, sample by sample: one of them on the knife's edge, on a difference in the last bit between the reference's "balance, then
-        # filter" and the library's "filter, then balance", is one demodulator sample of a different kind -- a click of 1e-4 .. 5e-3 in that call's PCM
-        # (seed 22: the four channels with attL 0.9 on one stream).  Reported, not counted.)
+        # (the first call on its own: the input filter's latency ends 28 ms into the stream and the limiter decides "|z| <= 0.001" on the filter's start-up
+        # transient, sample by sample.  Round 5 exempted it -- the library filtered first and balanced afterwards, one last bit away from the reference's
+        # "balance, then filter" (fm-processor.cpp:462-470), and a sample on the knife's edge became a click.  Since round 6 every stage-A kernel
+        # multiplies by the balance in front of its filter, as the reference does: the first call counts like every other.)
         f0 = outs[0].shape[1]
         e0 = float(np.sqrt(np.mean((pcm[c][:f0].astype(np.float64) - po[:f0]) ** 2)))
         e = float(np.sqrt(np.mean((pcm[c][f0:m].astype(np.float64) - po[f0:m]) ** 2)))
-        if e0 > TOL: print("   seed %d channel %d: first call %.3e (start-up)" % (seed, c, e0))
+        if e0 > TOL: print("   seed %d channel %d: first call %.3e" % (seed, c, e0))
         if e > worst: worst, wc = e, c
         # (the PLL decoder, decoder 2: pllC senses its phase through two quantised tables, so two runs a last bit apart somewhere walk through
         # different table entries at sporadic samples -- single quanta of 1e-4 in the demodulator output; behind a start-up click like the one
         # above the two stay a fraction of a quantum apart for good: 9e-5 in the PCM of seed 22's channel 597.  The reference against itself,
         # built with another compiler, does the same.)
         tol = 2e-4 if cfgs[c]["decoder"] == 2 else TOL
-        ok = m > 0.95 * pcm.shape[1] and e <= tol and e0 <= 2e-2 and np.isfinite(pcm[c]).all()
+        ok = m > 0.95 * pcm.shape[1] and e <= tol and e0 <= tol and np.isfinite(pcm[c]).all()
         if rdsplan[c][0]:
             nb_g, nb_o = len(f.rds_bits(c, 8192)), len(chains[c].rds_bits())
             # (RDS_1 takes a bit at every top of its recovered clock, rds-decoder-1.cpp:124-142: while that clock pulls in, a top more or less is rounding)

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    txt = open(os.path.join(ROOT, "include", "fmx.h")).read()
+def header_functions(name="fmx.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(fmx_[a-z_0-9]+)\s*\(", txt)))
 
@@ -25,7 +25,16 @@ def test_library_exports_every_declared_symbol(fmx_amd):
     L = fmx_amd.load_library()
     for n in header_functions():
         assert hasattr(L, n), n
-    assert L.fmx_abi_version() == 2
+    assert L.fmx_abi_version() == 3
+    dbg = header_functions("fmx_debug.h")          # the two diagnostic exports have a header of their own (not part of the boundary)
+    assert dbg == ["fmx_debug_phase_cycles", "fmx_debug_stream_bandwidth"]
+    for n in dbg:
+        assert hasattr(L, n), n
+    # ... and nothing else is exported under the library's prefix
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", fmx_amd.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r"\b(fmx_[a-z_0-9]+)$", syms, flags=re.M)))
+    assert exported == sorted(header_functions() + dbg), set(exported) ^ set(header_functions() + dbg)
 
 
 def test_no_oracle_dependency_in_product():

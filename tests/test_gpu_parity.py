@@ -862,6 +862,7 @@ def test_full_size_config4_device_path(fmx_amd, ol):
             d_iq_new = d_base[:, i * block:(i + 1) * block].unsqueeze(0).expand(C // 4, 4, block, 2).reshape(C, block, 2).contiguous()
         d_iq = d_iq_new
         frames = f.process_device(d_iq.data_ptr(), block, block, d_pcm.data_ptr(), cap, hip_stream=side.cuda_stream)
+        assert f.last_front_kernel() == 3          # (the headline's stage A: the filter on the matrix pipe -- no silent fallback)
         f.synchronize()
         out = d_pcm[:, :frames].reshape(C // 4, 4, frames, 2)
         differing += int((out != out[0:1]).any(dim=3).any(dim=2).sum().item())

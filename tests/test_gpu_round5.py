@@ -1,5 +1,6 @@
-"""Round-5 GPU tests.  Stage A on three waves per SIMD (FMX_P_FRONT_KERNEL, csrc/fmx_front3.hip): the kernel takes the whole 1536-sample tiles of
-a call, front_kernel the rest -- the results must be front_kernel's bit for bit."""
+"""Round-5 GPU tests.  Stage A on the matrix pipe (FMX_P_FRONT_KERNEL = 3, csrc/fmx_front4.hip): the kernel takes the whole 1536-sample tiles of
+a call, front_kernel the rest -- the results must be front_kernel's to the bounds of _close.  (The tests were written for two kernels: round 5's
+six-wave VALU kernel, `kernel == 2`, bit-identical and slower, left the product in round 6: tools/experiments/fmx_front3.hip.)"""
 import importlib
 
 import numpy as np
@@ -61,7 +62,7 @@ def _close(a, b, kernel, what):
     assert err <= tol, (what, err, tol)
 
 
-@pytest.mark.parametrize("kernel", [2, 3])
+@pytest.mark.parametrize("kernel", [3])
 def test_front3_whole_tiles_bit_identical(fmx_amd, ol, kernel):
     """Calls of whole tiles (1 .. 150 of them: fewer tiles than the workgroup has waves, more, a multiple, not a multiple): six waves per channel
     against four -- PCM, the fm-rate IQ and the RF DC state bit for bit; a setDCRemove in mid-stream (its reset of RfDC) on the way.  And the
@@ -81,7 +82,7 @@ def test_front3_whole_tiles_bit_identical(fmx_amd, ol, kernel):
     _close(a[0], b[0], kernel, "PCM")
 
 
-@pytest.mark.parametrize("kernel", [2, 3])
+@pytest.mark.parametrize("kernel", [3])
 def test_front3_remainders_and_fallbacks(fmx_amd, ol, kernel):
     """Calls that are not whole tiles: the six-wave kernel takes the tiles, front_kernel the remainder as a call of its own -- so a handle on
     front_kernel alone that is given the same stretches in two calls (tiles, remainder) must agree bit for bit in the fm-rate IQ.  Calls shorter
@@ -106,7 +107,7 @@ def test_front3_remainders_and_fallbacks(fmx_amd, ol, kernel):
     assert float(np.abs(a[0] - b[0]).max()) < 2e-6
 
 
-@pytest.mark.parametrize("kernel", [2, 3])
+@pytest.mark.parametrize("kernel", [3])
 def test_front3_against_oracle_in_a_batch(fmx_amd, ol, kernel):
     """600 channels on 4 streams, six waves per channel (two channels per workgroup, an even count), three calls -- whole tiles,
     tiles and a remainder twice --, every 152nd channel against the oracle chain on its stream."""
@@ -170,38 +171,6 @@ def test_twins_at_batch_scale_flake_hunt(rds, form, hard):
     assert last.endswith("mismatch: 0"), r.stdout[-3000:]
 
 
-def test_audio_fir_on_the_matrix_pipe_matches_the_fast_convolution(fmx_amd, ol):
-    """Stage C's folded 883-tap FIR as a Toeplitz product of f16 halves on the matrix pipe (FMX_AUDIO_MFMA=1, csrc/fmx_audio.hip audio_mfma_kernel;
-    an opt-in: measured slower than the fast convolution) against the default: the same PCM to 2e-7 (two processes: the switch is read once)."""
-    import os, subprocess, sys, textwrap, tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    prog = textwrap.dedent('''
-        import sys, importlib, numpy as np
-        sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
-        import oracle_lib as ol
-        pkg = importlib.import_module("sdr-j-fm_amd"); M = pkg.fmx
-        blocks = [230400, 100001, 16384, 230400]
-        iq = np.stack([ol.synth_iq(sum(blocks), leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k) for k in range(2)])
-        f = pkg.Fmx(70, streams=2, stream_of_channel=[c %% 2 for c in range(70)], max_block=max(blocks))
-        for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0)): f.set_param(pid, v)
-        f.set_param(M.P_LF_CUTOFF, 0, 3); f.set_param(M.P_TEST_TONE, 1, 5)
-        out, pos = [], 0
-        for b in blocks:
-            out.append(f.process_host(iq[:, pos:pos + b])); pos += b
-        np.save(sys.argv[1], np.concatenate(out, axis=1))
-    ''' % (root, root))
-    res = []
-    with tempfile.TemporaryDirectory() as td:
-        for flag in ("0", "1"):
-            path = os.path.join(td, "pcm%s.npy" % flag)
-            r = subprocess.run([sys.executable, "-c", prog, path], env=dict(os.environ, FMX_AUDIO_MFMA=flag), capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-3000:]
-            res.append(np.load(path))
-    a, b = res
-    assert a.shape == b.shape and float(np.abs(a).max()) > 0.01
-    assert float(np.abs(a - b).max()) <= 2e-7, float(np.abs(a - b).max())
-
-
 @pytest.mark.parametrize("fmt", ["u8", "s8", "s16"])
 def test_front4_raw_formats(fmx_amd, ol, fmt):
     """Raw integer samples through the matrix-pipe kernel (converted while they are loaded, as the reference's device handlers convert them):
@@ -228,39 +197,51 @@ def test_front4_raw_formats(fmx_amd, ol, fmt):
         del f
     (pa, ta), (pb, tb) = outs
     assert float(np.abs(ta).max()) > 0.1 and float(np.abs(pa).max()) > 0.01
-    _close(ta, tb, 3, "fm-rate IQ")
+    # (channel 2 has an IQ balance and the stream a DC offset: front_kernel takes such a channel through its per-sample pass since round 6 -- the reference's own
+    # RfDC recurrence in front of the balance --, the matrix-pipe kernel removes RfDC behind the filter: 2.5e-6 of the scale between the two)
+    rest = [c for c in range(NCH) if c != 2]
+    _close(ta[rest], tb[rest], 3, "fm-rate IQ")
+    assert float(np.abs(ta[2].astype(np.float64) - tb[2]).max()) <= 4e-6 * float(np.abs(ta[2]).max())
     _close(pa, pb, 3, "PCM")
 
 
-def test_front4_saturates_out_of_range_samples_and_keeps_them_to_their_channel(fmx_amd, ol):
-    """The matrix-pipe kernel works on f16 halves of the samples times 2^12: |x| >= 16 is beyond that range.  Such samples are limited to the
-    range's end (no infinities, no NaNs spreading through the filter), and what happens to one stream is no other stream's business: a burst of
-    samples of magnitude 100 and a NaN / Inf burst on stream 1 leave the PCM of the channels on stream 0 bit-identical, and the channels on
-    stream 1 finite where their input was."""
+def test_front4_large_samples_are_linear_and_bad_ones_stay_in_their_channel(fmx_amd, ol):
+    """Round 5's matrix-pipe kernel worked on f16 halves of the samples times a FIXED 2^12 and limited |x| >= 16.  Since round 6 every tile has a
+    scale of its own (block floating point): a burst of samples of magnitude 100 in the middle of a stream goes through the filter as it goes
+    through front_kernel's f32 one (the fm-rate IQ of both kernels agree to 8e-7 of the burst's scale), nothing is limited; and what happens to
+    one stream is no other stream's business: the burst and a NaN / Inf burst on stream 1 leave the PCM of the channels on stream 0
+    bit-identical, the channels on stream 1 finite where their input was (the reference's filter spreads a NaN over its own length too)."""
     T = 1536
     blocks = [100 * T, 100 * T]
     n = sum(blocks)
     iq = np.stack([ol.synth_iq(n, leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k) for k in range(2)])
     bad = iq.copy()
     bad[1, 50 * T:50 * T + 3000] *= 400.0                     # (magnitude ~100)
+    big = bad.copy()
     bad[1, 120 * T:120 * T + 100] = np.nan
     bad[1, 121 * T:121 * T + 100, 0] = np.inf
-    outs = []
-    for x in (iq, bad):
+    def run(x, kernel):
         f = fmx_amd.Fmx(6, streams=2, stream_of_channel=[0, 1, 0, 1, 0, 1], max_block=max(blocks))
-        for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FILTER_RESTARTS, 2), (M.P_FRONT_KERNEL, 3), (M.P_FRONT_PARTS, 1)):
+        for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FILTER_RESTARTS, 2), (M.P_FRONT_KERNEL, kernel), (M.P_FRONT_PARTS, 1)):
             f.set_param(pid, v)
-        pcm, pos = [], 0
+        pcm, taps, pos = [], [], 0
         for b in blocks:
             pcm.append(f.process_host(x[:, pos:pos + b])); pos += b
-            assert f.last_front_kernel() == 3
-        outs.append(np.concatenate(pcm, axis=1))
-        del f
-    a, b = outs
+            assert f.last_front_kernel() == kernel
+            taps.append(np.stack([f.tap(M.TAP_FM_IQ, f.last_fm_samples(), c) for c in range(2)]))
+        return np.concatenate(pcm, axis=1), np.concatenate(taps, axis=1)
+    a, _ = run(iq, 3)
+    b, _ = run(bad, 3)
     for c in (0, 2, 4):
         assert np.array_equal(a[c], b[c]), c
     first_nan_frame = (120 * T) // 48
-    assert np.isfinite(b[1][:first_nan_frame - 200]).all()   # (the magnitude-100 burst: limited, finite)
+    assert np.isfinite(b[1][:first_nan_frame - 200]).all()
+    # the burst through both kernels: the same fm-rate IQ (the burst arrives one filter latency later: the second call's ring)
+    (_, t3), (_, t1) = run(big, 3), run(big, 1)
+    scale = float(np.abs(t1[1]).max())
+    err = float(np.abs(t3[1].astype(np.float64) - t1[1]).max())
+    print("\n[a burst of magnitude 100 through kernels 3 and 1] fm-rate IQ max |diff| %.2e of a scale of %.1f" % (err, scale))
+    assert scale > 100.0 and err <= 8e-7 * scale
 
 
 def test_front_kernel_choice(fmx_amd, ol):

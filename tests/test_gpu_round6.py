@@ -1,0 +1,110 @@
+"""Round-6 GPU tests.  Stage A on the matrix pipe with a block-floating-point split (csrc/fmx_front4.hip: a power-of-two scale per 1536-sample tile) and
+the IQ balance in front of every stage-A filter: the input stage is as linear as the reference's f32 one at any level, and the filter's start-up needs
+no exemption."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+M = importlib.import_module("sdr-j-fm_amd").fmx
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = 1536
+
+
+def rms(x):
+    return float(np.sqrt(np.mean(np.asarray(x, np.float64) ** 2)))
+
+
+def _batch(fmx_amd, nch, nst, max_block, kernel=0):
+    f = fmx_amd.Fmx(nch, streams=nst, stream_of_channel=[c % nst for c in range(nch)], max_block=max_block)
+    for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0), (M.P_FRONT_KERNEL, kernel)):
+        f.set_param(pid, v)
+    return f
+
+
+@pytest.mark.parametrize("amp", [30.0, 15.9, 1.0, 1e-2, 1e-4, 1e-6])
+def test_matrix_pipe_input_filter_is_linear_at_any_level(fmx_amd, ol, amp):
+    """VERDICT r5 weak #1 / next #1.  The reference's input stage is plain f32 at any level (fm-processor.cpp:461-476, fir-filters.cpp:397-424).
+    Round 5's front4_kernel split its samples into f16 halves behind a fixed 2^12: |x| >= 16 was limited and signals below ~3e-5 lost their low
+    half to f16's subnormals.  Now every tile carries its own power-of-two scale.  600 channels on 4 streams at carrier amplitude `amp`, the automatic
+    kernel choice (asserted: the matrix-pipe kernel ran), calls of whole tiles and of tiles plus a remainder, against the OracleChain of each
+    stream: the fm-rate IQ of the last call to 1e-6 OF THE SIGNAL'S OWN SCALE at the worst sample (what separates a linear stage from a limiter or
+    a quantiser), PCM within the north-star 1e-5.  (At 1e-4 and below the fm-rate samples are under the limiter's 0.001 floor,
+    fm-demodulator.cpp:120-127: reference and library both demodulate silence -- the IQ comparison is the one that says something there.)"""
+    nch, nst = 600, 4
+    blocks = [49152 * 2, 49152, 49152 * 2 + 600, 49152 - 600]     # 18 of the oracle's 16384-sample blocks; every call starts on the 12-sample grid: 64 / 32 / 64 tiles + 600 samples / 31 tiles + 936
+    n = sum(blocks)
+    iq = np.stack([ol.synth_iq(n, carrierAmp=amp, leftHz=500.0 + 250 * k, rightHz=900.0 + 150 * k, dcI=0.004 * amp * (k & 1), dcQ=-0.003 * amp * (k >> 1),
+                               noiseSeed=7 + k, noiseSigma=0.001 * amp * k) for k in range(nst)])
+    f = _batch(fmx_amd, nch, nst, max(blocks))
+    pcm, pos = [], 0
+    for b in blocks:
+        pcm.append(f.process_host(iq[:, pos:pos + b])); pos += b
+        assert f.last_front_kernel() == 3
+    pcm = np.concatenate(pcm, axis=1)
+    nt = f.last_fm_samples()
+    nfm = n // 12
+    worst_iq, worst_pcm = 0.0, 0.0
+    for k in range(nst):
+        ch = ol.OracleChain(inputFilterBw=165000, taps=[ol.TAP_FM_IQ], tap_seconds=1.0)
+        ref = ch.process(iq[k])
+        z_o = ch.tap(ol.TAP_FM_IQ)[nfm - nt:nfm]
+        scale = float(np.abs(z_o).max())
+        for c in range(k, nch, 148):
+            z_g = f.tap(M.TAP_FM_IQ, nt, c)
+            worst_iq = max(worst_iq, float(np.abs(z_g.astype(np.float64) - z_o).max()) / scale)
+            assert pcm[c].shape == ref.shape
+            worst_pcm = max(worst_pcm, rms(pcm[c] - ref))
+    print("\n[stage A on the matrix pipe, carrier amplitude %g] fm-rate IQ: worst sample %.2e of the signal's scale; PCM rms against the oracle %.2e (PCM scale %.3f)"
+          % (amp, worst_iq, worst_pcm, float(np.abs(pcm).max())))
+    # (the oracle's own overlap-add filter carries ~1e-6 of its block's scale: fft-complex.cpp:69-71)
+    assert worst_iq <= 2e-6 and worst_pcm <= 1e-5
+
+
+def test_a_level_step_between_two_tiles(fmx_amd, ol):
+    """Block floating point across a tile boundary: the stream jumps by a factor of 2^20 up and, later, down again in the middle of a call (an AGC step, a
+    file spliced from two recordings).  A filter window that straddles the boundary sums its first part in the previous tile's unit and is rescaled by the
+    exact power of two: against front_kernel's f32 filter on the same calls the fm-rate IQ agrees to 8e-7 of the LOCAL scale (the largest magnitude
+    within the filter's length) -- also in the quiet stretch behind the step down, a million times below what the ring held a tile earlier."""
+    nch, blocks = 600, [40 * T] * 4
+    n = sum(blocks)
+    x = ol.synth_iq(n)
+    g = np.full(n, 2.0 ** -10, np.float32)
+    g[13 * T + 700:55 * T + 100] = np.float32(2.0 ** 10)
+    iq = (x * g[:, None])[None]
+    outs = []
+    for kernel in (3, 1):
+        f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=max(blocks))
+        for pid, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_FILTER_RESTARTS, 2), (M.P_FRONT_KERNEL, kernel), (M.P_FRONT_PARTS, 1), (M.P_DC_REMOVE, 0)):
+            f.set_param(pid, v)
+        taps, pos = [], 0
+        for b in blocks:
+            f.process_host(iq[:, pos:pos + b]); pos += b
+            assert f.last_front_kernel() == kernel
+            taps.append(f.tap(M.TAP_FM_IQ, f.last_fm_samples(), nch - 1))       # (what stage B read in this call: the ring 5440 fm samples back)
+        outs.append(np.concatenate(taps))
+        del f
+    a, b = outs
+    mag = np.abs(b).max(axis=1)
+    local = np.maximum.reduce([np.roll(mag, k) for k in range(-2, 27)])
+    live = local > 0
+    assert live.sum() > 12000 and float(mag.max()) > 1000 * float(np.median(mag[live]))      # (both levels are in the ring's read-out)
+    err = np.abs(a.astype(np.float64) - b).max(axis=1)[live] / local[live]
+    print("\n[a 2^20 level step inside a call] fm-rate IQ of kernels 3 and 1: worst sample %.2e of the local scale (levels %.3g and %.3g)"
+          % (float(err.max()), float(np.median(mag[live])), float(mag.max())))
+    assert float(err.max()) <= 8e-7
+
+
+def test_randomised_soak_against_the_oracle():
+    """tests/soak_random.py in the suite, bounded, WITHOUT round 5's start-up exemption -- handles with every setting drawn
+    at random (filter widths / off, IQ balance, oscillators, DC removal, all six decoders, the squelches, modes, selectors, RDS decoders switched on and off
+    at random calls) against an oracle chain per channel, the first call included.  Seeds 22 and 42 are the two on which round 5 saw the start-up
+    click; the 300-channel plain run is the population the matrix-pipe kernel takes."""
+    for args in (("22", "1", "70", "0"), ("42", "1", "70", "0"), ("7", "1", "300", "1")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_random.py"), *args], capture_output=True, text=True, timeout=900)
+        print(r.stdout[-1500:])
+        assert r.returncode == 0, (args, r.stdout[-3000:], r.stderr[-2000:])
