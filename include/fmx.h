@@ -112,10 +112,12 @@ typedef enum {
     FMX_P_FILTER_RESTARTS = 23,/* (handle-wide, before the first call) how the two overlap-add filters of the reference -- inputFilter (65536 points, 251
                                   taps, :469-470) and fmAudioFilter (8192 points, 756 taps, :589-591) -- are built: 1 = as the block machines they
                                   are (fft-filters.cpp:33-163): a setBandwidth / setlfcutoff in the middle of a stream then replays the last output
-                                  block, drops the block in progress and carries the old tail over, sample for sample as the reference does
-                                  (handles of up to 64 channels); 2 = folded into stage A's / stage C's polyphase FIRs -- the same filters
-                                  wherever the settings were made before the first call, a different glitch of one filter latency behind a
-                                  change in mid-stream (what large batches run); 0 = automatic (default): 1 up to 64 channels, 2 above */
+                                  block, drops the block in progress and carries the old tail over, sample for sample as the reference does (any
+                                  channel count; about seven times the cost of 2 on a batch); 2 = folded into stage A's / stage C's polyphase FIRs
+                                  for good -- the same filters wherever the settings were made before the first call, a different glitch of one
+                                  filter latency behind a change in mid-stream; 0 = automatic (default): 1 up to 64 channels; above, folded UNTIL a
+                                  filter setter arrives in mid-stream -- the handle then becomes a block-machine handle before the setter takes
+                                  effect (fmx_filter_change_due), and the change is the reference's, sample for sample */
     FMX_P_FRONT_PARTS = 24,    /* (handle-wide: the channel argument is ignored) the input-filter stage runs one workgroup per channel; a handle with
                                   fewer channels than the GPU has workgroup slots splits every channel's call in time over several workgroups
                                   (each later one recomputes one 1536-sample tile to get its filter history): 0 = automatic (default), 1 = never,
@@ -206,6 +208,13 @@ int  fmx_set_param(fmx_handle h, int32_t channel, int32_t param_id, double value
 
 /* number of PCM frames the next call with n complex samples will produce per channel */
 int64_t fmx_frames_for(fmx_handle h, int64_t n_complex);
+/* replaces the moment at which the reference's loop takes a setBandwidth / setlfcutoff over (fm-processor.cpp:396-408: the next block start).  A handle
+ * that runs its filters as the reference's block machines takes it with its next call: -1.  A BATCH (above 64 channels, FMX_P_FILTER_RESTARTS
+ * automatic) runs the filters folded into its polyphase FIRs until a filter setter arrives in mid-stream; it then keeps what its streams deliver for
+ * three blocks of the input filter (196 879 samples, 85 ms) and becomes a block-machine handle at the first call boundary behind that, where the setter
+ * restarts its filter exactly as the reference's setLowPass does (fft-filters.cpp:84-95).  Returns the input samples per stream still to come before
+ * that call (0: the next call applies the change at its first sample), -1 when nothing is pending. */
+int64_t fmx_filter_change_due(fmx_handle h);
 
 /* Replaces one iteration of the loop in fmProcessor::run() (fm-processor.cpp:387-686) for every
  * channel: `iq` = what deviceHandler::getSamples (device-handler.h:71-74) delivered, interleaved

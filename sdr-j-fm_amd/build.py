@@ -20,6 +20,7 @@ SOURCES = [
     ("fmx_audio.hip", []),
     ("fmx_rds.hip", ["-ffp-contract=off"]),
     ("fmx_ola.hip", ["-ffp-contract=off"]),
+    ("fmx_promote.hip", ["-ffp-contract=off"]),
     ("fmx_api.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -39,6 +39,8 @@ int next_pow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return (int)p; 
 struct ChanUser {
     int32_t bandwidth = 0;       // 0 = Off.  NB ctor default: inputFilterOn=false (fm-processor.cpp:149)
     int32_t lf_cutoff = 0;       // <=0 = off. ctor default fmAudioFilterActive=false (:164)
+    int32_t bw_applied = 0, lf_applied = 0;    // what a FOLDED handle's tap sets are built from: the setter's value -- except while a mid-stream change of a batch
+                                 // is pending (fmx_handle_s::promo_pending): then the values in force when the setter arrived
     bool bw_event = false, lf_event = false;   // setBandwidth / setlfcutoff CALLED with a value since the last call: the reference sets newInputFilter /
                                  // newAudioFilter whatever the value (:232-239, :762-770), and its loop restarts the filter's block (:396-408)
     int32_t deemph_us = 0;       // 0 = ctor default alpha (:174)
@@ -143,6 +145,19 @@ struct fmx_handle_s {
         std::vector<int32_t> inp, on, key;   // per channel: block position, Pass () in use, the setting the kernel was designed for (-1: none yet)
     } ola_in, ola_au;
     float2 *d_v = nullptr, *d_u = nullptr, *d2ring = nullptr;   // pre_kernel's output, the input filter's output ([channels][max_block]), the audio filter's output ring
+    // A batch (folded filters) whose filters are changed in mid-stream: the setter stays pending while the library keeps the streams' samples (fmx_promote.hip),
+    // then the handle switches to the block machines (promote).  FMX_P_FILTER_RESTARTS = 2 pins the folded filters (the change then applies at once, as
+    // rounds 1-5 applied it: a different glitch of one filter latency).
+    bool folded_pinned = false;          // FMX_P_FILTER_RESTARTS = 2 was asked for
+    bool promo_pending = false;          // a filter setter arrived behind the first call
+    bool promo_recapture = false;        // ... and a setter of what pre_kernel applies (RF DC removal, balance, oscillator) behind it: the kept samples start over
+    int64_t promo_have = 0, promo_g0 = 0;   // samples kept per stream, and the stream position of the first
+    float2 *tail_iq = nullptr; int64_t tail_cap = 0; FrontSnap *tail_snap = nullptr;
+    ChanParams *d_params_replay = nullptr; FrontSet *d_old_sets = nullptr; int32_t *d_old_set_of = nullptr; float2 *d_au_tail = nullptr;
+    // the block machines' steps of a handle above OLA_MAX_CH channels: tables in device memory (the launchers take a step by value up to 64 channels),
+    // a ring of STEP_SLOTS tables, each copied from pinned host memory on the call's stream in front of the kernels that read it
+    static constexpr int STEP_SLOTS = 32;
+    OlaChan *step_dev = nullptr, *step_host = nullptr; hipEvent_t step_ev[STEP_SLOTS] = {}; bool step_used[STEP_SLOTS] = {}; int step_next = 0;
 };
 
 namespace {
@@ -224,7 +239,7 @@ int ensure_sets(fmx_handle h) {
     // deduplicate bandwidth / lf-cutoff values into tap sets, upload when changed
     std::vector<int32_t> fk, ak;
     for (int c = 0; c < h->channels; c++) {
-        int32_t b = h->user[c].bandwidth, l = h->user[c].lf_cutoff > 0 ? h->user[c].lf_cutoff : 0;
+        int32_t b = h->user[c].bw_applied, l = h->user[c].lf_applied > 0 ? h->user[c].lf_applied : 0;      // (folded handles: see ChanUser)
         if (h->ola_mode) { b = 0; l = 0; }      // (the two filters run as block machines in front of stage A's decimators / stage C's resampler)
         auto it = std::find(fk.begin(), fk.end(), b);
         if (it == fk.end()) { fk.push_back(b); it = fk.end() - 1; }
@@ -523,50 +538,170 @@ int ola_take_settings(fmx_handle h) {
     }
     return FMX_OK;
 }
+// one step of every channel's block machine, as the host works it out; step_ref hands it to the launchers
+struct HStep { std::vector<OlaChan> ch; };
+int step_ref(fmx_handle h, const HStep &st, hipStream_t s, OlaStepRef *out) {
+    *out = OlaStepRef{};
+    if (h->channels <= OLA_MAX_CH) { for (int c = 0; c < h->channels; c++) out->val.ch[c] = st.ch[(size_t)c]; return FMX_OK; }
+    const size_t C = (size_t)h->channels;
+    if (!h->step_dev) {
+        HIPCHK(hipMalloc(&h->step_dev, sizeof(OlaChan) * C * fmx_handle_s::STEP_SLOTS));
+        HIPCHK(hipHostMalloc((void **)&h->step_host, sizeof(OlaChan) * C * fmx_handle_s::STEP_SLOTS, hipHostMallocDefault));
+        for (auto &e : h->step_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->tail_ptrs.push_back(h->step_dev);
+    }
+    const int k = h->step_next; h->step_next = (k + 1) % fmx_handle_s::STEP_SLOTS;
+    if (h->step_used[k]) HIPCHK(hipEventSynchronize(h->step_ev[k]));          // (the copy that last used this slot's host side has run)
+    h->step_used[k] = true;
+    std::memcpy(h->step_host + (size_t)k * C, st.ch.data(), sizeof(OlaChan) * C);
+    HIPCHK(hipMemcpyAsync(h->step_dev + (size_t)k * C, h->step_host + (size_t)k * C, sizeof(OlaChan) * C, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(h->step_ev[k], s));
+    out->tab = h->step_dev + (size_t)k * C;
+    return FMX_OK;
+}
 void ola_fill(const fmx_handle_s::OlaSide &S, OlaBuffers &O) { O.A = S.A; O.C = S.C; O.over = S.over; O.over_new = S.over_new; O.taps = S.taps; O.L = S.L; O.degree = S.degree; }
 // does every channel's filter take the whole call as one run (no block boundary before its last sample)?  Then the step is returned and
 // the caller's own kernel (pre_kernel / deemph_kernel) does the copy; ola_finish_single runs the block transforms that fall due behind it.
-bool ola_single_step(fmx_handle h, const fmx_handle_s::OlaSide &S, int64_t len, OlaStep *st) {
-    *st = OlaStep{};
+bool ola_single_step(fmx_handle h, const fmx_handle_s::OlaSide &S, int64_t len, HStep *st) {
+    st->ch.assign((size_t)h->channels, OlaChan{});
     for (int c = 0; c < h->channels; c++) {
         const bool on = S.on[(size_t)c] != 0;
         if (on && S.inp[(size_t)c] + len > S.L) return false;
-        OlaChan &d = st->ch[c];
+        OlaChan &d = st->ch[(size_t)c];
         d.off = 0; d.len = (int32_t)len; d.inp = S.inp[(size_t)c]; d.on = on ? 1 : 0; d.conv = (on && len > 0 && S.inp[(size_t)c] + len == S.L) ? 1 : 0;
     }
     return true;
 }
-void ola_finish_single(fmx_handle h, fmx_handle_s::OlaSide &S, const OlaStep &st, const OlaBuffers &O, hipStream_t s) {
+void ola_finish_single(fmx_handle h, fmx_handle_s::OlaSide &S, const HStep &st, const OlaStepRef &ref, const OlaBuffers &O, hipStream_t s) {
     bool any_conv = false;
-    for (int c = 0; c < h->channels; c++) any_conv |= st.ch[c].conv != 0;
-    if (any_conv) { launch_ola_conv(st, O, h->channels, s); FMX_LAUNCHED(); }
-    for (int c = 0; c < h->channels; c++) if (st.ch[c].on) S.inp[(size_t)c] = st.ch[c].conv ? 0 : S.inp[(size_t)c] + st.ch[c].len;
+    for (int c = 0; c < h->channels; c++) any_conv |= st.ch[(size_t)c].conv != 0;
+    if (any_conv) { launch_ola_conv(ref, O, h->channels, s); FMX_LAUNCHED(); }
+    for (int c = 0; c < h->channels; c++) if (st.ch[(size_t)c].on) S.inp[(size_t)c] = st.ch[(size_t)c].conv ? 0 : S.inp[(size_t)c] + st.ch[(size_t)c].len;
 }
 // Pass () of every channel over `len` samples: runs up to the block boundary, the block transform where a block completes, and on
-void run_ola(fmx_handle h, fmx_handle_s::OlaSide &S, OlaBuffers O, int64_t len, hipStream_t s) {
+int run_ola(fmx_handle h, fmx_handle_s::OlaSide &S, OlaBuffers O, int64_t len, hipStream_t s) {
     ola_fill(S, O);
     std::vector<int64_t> off((size_t)h->channels, 0);
     for (;;) {
-        OlaStep st{};
+        HStep st; st.ch.assign((size_t)h->channels, OlaChan{});
         int maxlen = 0; bool any_conv = false;
         for (int c = 0; c < h->channels; c++) {
             const int64_t rem = len - off[(size_t)c];
             const bool on = S.on[(size_t)c] != 0;
             const int64_t run = on ? std::min<int64_t>(rem, S.L - S.inp[(size_t)c]) : rem;
-            OlaChan &d = st.ch[c];
+            OlaChan &d = st.ch[(size_t)c];
             d.off = (int32_t)off[(size_t)c]; d.len = (int32_t)run; d.inp = S.inp[(size_t)c]; d.on = on ? 1 : 0;
             d.conv = (on && run > 0 && S.inp[(size_t)c] + run == S.L) ? 1 : 0;
             maxlen = std::max<int>(maxlen, (int)run); any_conv |= d.conv != 0;
         }
         if (maxlen <= 0) break;
-        launch_ola_io(st, O, h->channels, maxlen, s); FMX_LAUNCHED();
-        if (any_conv) { launch_ola_conv(st, O, h->channels, s); FMX_LAUNCHED(); }
+        OlaStepRef ref; { const int rc = step_ref(h, st, s, &ref); if (rc) return rc; }
+        launch_ola_io(ref, O, h->channels, maxlen, s); FMX_LAUNCHED();
+        if (any_conv) { launch_ola_conv(ref, O, h->channels, s); FMX_LAUNCHED(); }
         for (int c = 0; c < h->channels; c++) {
-            const OlaChan &d = st.ch[c];
+            const OlaChan &d = st.ch[(size_t)c];
             off[(size_t)c] += d.len;
             if (d.on) S.inp[(size_t)c] = d.conv ? 0 : S.inp[(size_t)c] + d.len;
         }
     }
+    return FMX_OK;
+}
+
+// the input side of a block-machine handle's call: pre_kernel (RF DC removal, balance, oscillator per sample) and the input filter's machine over the call's
+// G.n samples; the machines' output stream is h->d_u
+int ola_input_side(fmx_handle h, const CallGeom &G, const DeviceBuffers &B, const void *d_iq, hipStream_t s) {
+    OlaBuffers O{}; O.src = h->d_v; O.dst = h->d_u; O.src_stride = O.dst_stride = h->cfg.max_block; O.src_mask = O.dst_mask = -1;
+    HStep st1;
+    int rc;
+    if (ola_single_step(h, h->ola_in, G.n, &st1)) {
+        OlaStepRef ref; rc = step_ref(h, st1, s, &ref); if (rc) return rc;
+        ola_fill(h->ola_in, O);
+        h->pre_look.epoch += 1;
+        launch_pre(h->T, B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, &ref, &O, h->pre_look); FMX_LAUNCHED();
+        { const uint32_t nt = (uint32_t)((G.n + PRE_TILE_SAMPLES - 1) / PRE_TILE_SAMPLES); if (nt > 1) h->pre_look.ticket_base += nt; }
+        ola_finish_single(h, h->ola_in, st1, ref, O, s);
+    } else {
+        h->pre_look.epoch += 1;
+        launch_pre(h->T, B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, nullptr, nullptr, h->pre_look); FMX_LAUNCHED();
+        { const uint32_t nt = (uint32_t)((G.n + PRE_TILE_SAMPLES - 1) / PRE_TILE_SAMPLES); if (nt > 1) h->pre_look.ticket_base += nt; }
+        rc = run_ola(h, h->ola_in, O, G.n, s); if (rc) return rc;
+    }
+    return FMX_OK;
+}
+
+// PROMOTION of a folded batch to the block machines at the stream position g_total (fmx_promote.hip has the story).  Rare and heavy: the device is idle around it.
+int promote(fmx_handle h, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(h->mtx);
+    const size_t C = (size_t)h->channels;
+    HIPCHK(hipDeviceSynchronize());
+    int rc = ensure_ola(h); if (rc) return rc;
+    if (!h->d_old_sets) {
+        HIPCHK(hipMalloc(&h->d_old_sets, sizeof(FrontSet) * std::max<size_t>(h->h_front_sets.size(), 1)));
+        HIPCHK(hipMalloc(&h->d_old_set_of, sizeof(int32_t) * C));
+        HIPCHK(hipMalloc(&h->d_params_replay, sizeof(ChanParams) * C));
+        HIPCHK(hipMalloc(&h->d_au_tail, sizeof(float2) * C * PROMO_TAIL_AU));
+        for (void *p : {(void *)h->d_old_sets, (void *)h->d_old_set_of, (void *)h->d_params_replay, (void *)h->d_au_tail}) h->tail_ptrs.push_back(p);
+    }
+    {   // what the folded stage A used: its tap sets' delays (the ring's newest entries move by them), and the parameters the kept samples were taken under
+        std::vector<int32_t> set_of(C);
+        std::vector<ChanParams> pr(h->params);
+        for (size_t c = 0; c < C; c++) { set_of[c] = h->params[c].front_set; pr[c].actions = 0; }
+        HIPCHK(hipMemcpy(h->d_old_sets, h->h_front_sets.data(), sizeof(FrontSet) * h->h_front_sets.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_old_set_of, set_of.data(), sizeof(int32_t) * C, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_params_replay, pr.data(), sizeof(ChanParams) * C, hipMemcpyHostToDevice));
+    }
+    const int64_t t0 = h->g_total, have = h->promo_have;
+    const int64_t J0 = t0 / h->decim;
+    // the machines as the settings in force leave them at the first kept sample / at the d ring's tail: kernels designed, block positions as the reference's
+    // (both filters count from the stream's first sample: a folded handle has had no restart), buffers empty
+    for (int side = 0; side < 2; side++) {
+        fmx_handle_s::OlaSide &S = side ? h->ola_au : h->ola_in;
+        const int64_t start = side ? J0 - PROMO_TAIL_AU : h->promo_g0;
+        HIPCHK(hipMemset(S.A, 0, sizeof(float2) * C * S.L)); HIPCHK(hipMemset(S.C, 0, sizeof(float2) * C * S.L));
+        HIPCHK(hipMemset(S.over, 0, sizeof(float2) * C * OLA_MAX_TAPS));
+        for (size_t c = 0; c < C; c++) {
+            const int32_t want = side ? (h->user[c].lf_applied > 0 ? h->user[c].lf_applied : 0) : (h->user[c].bw_applied > 0 ? h->user[c].bw_applied : 0);
+            S.key[c] = want; S.on[c] = want != 0 ? 1 : 0;
+            S.inp[c] = want != 0 ? (int32_t)(((start % S.L) + S.L) % S.L) : 0;
+            if (want == 0) continue;
+            const std::vector<float> k = side ? design::lowpass(AUDIO_TAPS, want, h->cfg.fmRate) : design::lowpass(251, want / 2, h->cfg.inputRate);
+            HIPCHK(hipMemcpy(S.taps + c * OLA_MAX_TAPS, k.data(), sizeof(float) * k.size(), hipMemcpyHostToDevice));
+        }
+    }
+    g_launch_err = hipSuccess;
+    // ---- the input side: the channels' state back to where it was at the first kept sample, then pre_kernel and the machine over the kept samples
+    launch_promo_state(h->B.state, h->tail_snap, h->channels, 1, s); FMX_LAUNCHED();
+    DeviceBuffers Bc = h->B; Bc.params = h->d_params_replay;
+    int64_t pos = 0, last_len = 0;
+    while (pos < have) {
+        int64_t len = (pos == 0 && have % h->cfg.max_block) ? have % h->cfg.max_block : h->cfg.max_block;
+        if (len > have - pos) len = have - pos;
+        CallGeom Gc{};
+        Gc.g0 = h->promo_g0 + pos; Gc.n = len; Gc.input_rate = h->cfg.inputRate; Gc.iq_format = 0; Gc.iq_scale = 1.0f; Gc.stream_stride = h->tail_cap;
+        Gc.channels = h->channels; Gc.streams = h->streams; Gc.twins = h->twins; Gc.n_cus = h->n_cus;
+        rc = ola_input_side(h, Gc, Bc, h->tail_iq + pos, s); if (rc) return rc;
+        pos += len; last_len = len;
+    }
+    if (last_len < 12 * A_HIST_COLS + 12) return fail(FMX_E_HIP, "promotion: the last kept piece is shorter than the decimators' history");
+    // ---- the decimators' history and the ring's newest entries
+    launch_promo_hist(h->B.hist, h->d_u, h->cfg.max_block, last_len, (int)(t0 % DECIM), h->twins, h->B.zring, h->ring - 1, J0, h->d_params, h->d_old_sets, h->d_old_set_of,
+                      h->channels, s); FMX_LAUNCHED();
+    // ---- the audio side: the d ring's tail with the de-emphasis taken out, the audio machine over it, the de-emphasis behind the machine into the ring stage C reads
+    launch_promo_inv_deemph(h->B.dring, h->dring - 1, J0, PROMO_TAIL_AU, h->d_params_replay, h->d_au_tail, h->channels, s); FMX_LAUNCHED();
+    {
+        OlaBuffers O{}; O.src = h->d_au_tail; O.src_stride = PROMO_TAIL_AU; O.src_mask = -1; O.src_pos = 0;
+        O.dst = h->d2ring; O.dst_stride = h->dring; O.dst_mask = h->dring - 1; O.dst_pos = J0 - PROMO_TAIL_AU;
+        rc = run_ola(h, h->ola_au, O, PROMO_TAIL_AU, s); if (rc) return rc;
+        CallGeom Gx{}; Gx.J0 = J0 - PROMO_TAIL_AU; Gx.J1 = J0; Gx.dring_mask = h->dring - 1;
+        launch_deemph(Bc, Gx, h->d2ring, h->channels, s, nullptr, nullptr); FMX_LAUNCHED();
+    }
+    HIPCHK(g_launch_err);
+    HIPCHK(hipDeviceSynchronize());
+    // ---- a block-machine handle from here on: the pending setters reach their filters through ola_take_settings, as a small handle's do
+    h->ola_mode = true; h->sets_dirty = true; h->params_dirty = true;
+    h->promo_pending = false; h->promo_have = 0;
+    for (auto &u : h->user) { u.bw_applied = u.bandwidth; u.lf_applied = u.lf_cutoff; }
+    return FMX_OK;
 }
 
 static bool any_rds_on(fmx_handle h) { return h->call_any_rds; }     // (as of the call's flush_mailbox)
@@ -582,6 +717,7 @@ int flush_mailbox(fmx_handle h) {
     std::lock_guard<std::mutex> lk(h->mtx);
     if (h->gain_dirty) { h->gain_pending = true; h->gain_dirty = false; }   // (a change arriving behind this point belongs to the next call, flag and value)
     if (h->ola_mode) { int rc = ensure_ola(h); if (rc) return rc; rc = ola_take_settings(h); if (rc) return rc; }
+    else if (!h->promo_pending) for (auto &u : h->user) { u.bw_event = false; u.lf_event = false; }     // (a folded handle applies a filter value, not the setter's call)
     if (h->sets_dirty) { int rc = ensure_sets(h); if (rc) return rc; h->params_dirty = true; }
     bool any_lo = false;
     for (auto &p : h->params) any_lo |= (p.lo_freq != 0);
@@ -829,7 +965,20 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         if (!(s16_den >= 1.0f) || m != 0.5f) return fail(FMX_E_INVALID, "s16_denominator must be a power of two >= 1");
     }
     if (n <= 0 || n > h->cfg.max_block) return fail(FMX_E_TOO_LARGE, "n_complex must be in [1, max_block]");
-    int rc = flush_mailbox(h);
+    int rc;
+    bool capture = false;
+    {   // a folded batch with a filter change pending (fmx_promote.hip): promoted once enough of its streams is kept, else this call's samples are kept too
+        bool do_promote = false;
+        {
+            std::lock_guard<std::mutex> lk(h->mtx);
+            if (!h->promo_pending || h->ola_mode) h->promo_recapture = false;
+            else if (h->promo_recapture) { h->promo_recapture = false; h->promo_have = 0; }      // (what pre_kernel applies changed: the kept samples start over, behind this call)
+            else if (h->promo_have >= PROMO_TAIL_IN) do_promote = true;
+            else capture = true;
+        }
+        if (do_promote) { rc = promote(h, s); if (rc) return rc; }
+    }
+    rc = flush_mailbox(h);
     if (rc) return rc;
     CallGeom G{};
     frames_geom(h, n, &G);
@@ -853,6 +1002,17 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     }
     g_launch_err = hipSuccess;
     h->B.lin_rows = (int32_t)h->work_nj;
+    if (capture) {
+        if (!h->tail_iq) {
+            h->tail_cap = PROMO_TAIL_IN + h->cfg.max_block;
+            HIPCHK(hipMalloc(&h->tail_iq, sizeof(float2) * (size_t)h->streams * h->tail_cap));
+            HIPCHK(hipMalloc(&h->tail_snap, sizeof(FrontSnap) * (size_t)h->channels));
+            h->tail_ptrs.push_back(h->tail_iq); h->tail_ptrs.push_back(h->tail_snap);
+        }
+        if (h->promo_have == 0) { h->promo_g0 = h->g_total; launch_promo_state(h->B.state, h->tail_snap, h->channels, 0, sa); FMX_LAUNCHED(); }
+        launch_capture(d_iq, fmt, G.iq_scale, stream_stride, n, h->streams, h->tail_iq, h->tail_cap, h->promo_have, sa); FMX_LAUNCHED();
+        h->promo_have += n;
+    }
     rc = front_parts_for(h, G);
     if (rc) return rc;
     {
@@ -865,21 +1025,8 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         h->last_front_kernel = (G.front4 && front4_tiles(G, d_iq) > 0) ? 3 : 1;
     }
     if (h->ola_mode) {
-        // few channels: RF DC removal / balance / LO mix per sample, the input filter as the reference's block machine, then the decimators
-        OlaBuffers O{}; O.src = h->d_v; O.dst = h->d_u; O.src_stride = O.dst_stride = h->cfg.max_block; O.src_mask = O.dst_mask = -1;
-        OlaStep st1;
-        if (ola_single_step(h, h->ola_in, n, &st1)) {
-            ola_fill(h->ola_in, O);
-            h->pre_look.epoch += 1;
-            launch_pre(h->T, h->B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, &st1, &O, h->pre_look); FMX_LAUNCHED();
-            { const uint32_t nt = (uint32_t)((G.n + PRE_TILE_SAMPLES - 1) / PRE_TILE_SAMPLES); if (nt > 1) h->pre_look.ticket_base += nt; }
-            ola_finish_single(h, h->ola_in, st1, O, s);
-        } else {
-            h->pre_look.epoch += 1;
-            launch_pre(h->T, h->B, G, d_iq, h->d_v, h->cfg.max_block, h->channels, s, nullptr, nullptr, h->pre_look); FMX_LAUNCHED();
-            { const uint32_t nt = (uint32_t)((G.n + PRE_TILE_SAMPLES - 1) / PRE_TILE_SAMPLES); if (nt > 1) h->pre_look.ticket_base += nt; }
-            run_ola(h, h->ola_in, O, n, s);
-        }
+        // RF DC removal / balance / LO mix per sample, the input filter as the reference's block machine, then the decimators
+        rc = ola_input_side(h, G, h->B, d_iq, s); if (rc) return rc;
         CallGeom Gp = G; Gp.pre_processed = 1; Gp.iq_format = 0; Gp.iq_scale = 1.0f; Gp.stream_stride = h->cfg.max_block; Gp.streams_private = h->twins == 1 ? 1 : 0;
         launch_front(h->T, h->B, Gp, h->d_u, h->channels, s);
     } else
@@ -966,14 +1113,15 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         // the audio low-pass as the reference's block machine on the de-emphasised stream; the resampler reads its output
         OlaBuffers O{}; O.src = h->B.dring; O.dst = h->d2ring; O.src_stride = O.dst_stride = h->dring; O.src_mask = O.dst_mask = h->dring - 1;
         O.src_pos = O.dst_pos = G.J0;
-        OlaStep st1;
+        HStep st1;
         // de-emphasis behind the filter, as the reference orders them (:589-595)
         if (ola_single_step(h, h->ola_au, G.J1 - G.J0, &st1)) {
+            OlaStepRef ref; rc = step_ref(h, st1, s, &ref); if (rc) return rc;
             ola_fill(h->ola_au, O);
-            launch_deemph(h->B, G, h->d2ring, h->channels, s, &st1, &O); FMX_LAUNCHED();
-            ola_finish_single(h, h->ola_au, st1, O, s);
+            launch_deemph(h->B, G, h->d2ring, h->channels, s, &ref, &O); FMX_LAUNCHED();
+            ola_finish_single(h, h->ola_au, st1, ref, O, s);
         } else {
-            run_ola(h, h->ola_au, O, G.J1 - G.J0, s);
+            rc = run_ola(h, h->ola_au, O, G.J1 - G.J0, s); if (rc) return rc;
             launch_deemph(h->B, G, h->d2ring, h->channels, s, nullptr, nullptr); FMX_LAUNCHED();
         }
     }
@@ -1250,7 +1398,8 @@ int fmx_create(const fmx_config *cfg, fmx_handle *out) {
     // ---- per-channel buffers ------------------------------------------------------------
     const int64_t fm_per_call = cfg->max_block / h->decim + 2;
     h->ring = next_pow2((2 * 32768 - 251) / h->decim + 1 + fm_per_call + 512);      // the input filter's latency in fm samples + a call
-    h->dring = next_pow2(AUDIO_DELAY + C_MAX_TAPS + fm_per_call + 192 + 4 * C_TILE);
+    // (a batch keeps three blocks of the audio filter in its d ring: what its promotion to the block machines runs the audio machine over, fmx_promote.hip)
+    h->dring = next_pow2(std::max<int64_t>(AUDIO_DELAY + C_MAX_TAPS, h->channels > OLA_MAX_CH ? PROMO_TAIL_AU + 8 : 0) + fm_per_call + 192 + 4 * C_TILE);
     h->sring = 4096;
     const size_t C = (size_t)h->channels;
     const size_t CT = C * (size_t)h->twins;                    // stage-A workgroups: `twins` per channel
@@ -1337,6 +1486,8 @@ int fmx_destroy(fmx_handle h) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
     for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);
+    if (h->step_host) (void)hipHostFree(h->step_host);
+    for (hipEvent_t e : h->step_ev) if (e) (void)hipEventDestroy(e);
     if (h->hp_iq) (void)hipHostFree(h->hp_iq);
     if (h->hp_pcm) (void)hipHostFree(h->hp_pcm);
     for (hipStream_t st : {h->pipe_sA, h->pipe_sP, h->pipe_sB}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
@@ -1388,9 +1539,9 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         if (iv < 0 || iv > 2) return fail(FMX_E_INVALID, "filter restarts must be 0 (automatic), 1 (the reference's block filters) or 2 (folded FIRs)");
         std::lock_guard<std::mutex> lk(h->mtx);
         if (h->g_total != 0) return fail(FMX_E_UNSUPPORTED, "the filter structure of a handle is fixed by its first call");
-        if (iv == 1 && h->channels > OLA_MAX_CH) return fail(FMX_E_UNSUPPORTED, "the block filters are built for handles of up to 64 channels");
         const bool want = iv == 1 || (iv == 0 && h->channels <= OLA_MAX_CH);
         if (want != h->ola_mode) { h->ola_mode = want; h->sets_dirty = true; }
+        h->folded_pinned = iv == 2;
         return FMX_OK; }
     case FMX_P_DISP_DELAY: if (iv < 0 || iv > 100000) return fail(FMX_E_INVALID, "display delay must be 0..100000 steps"); break;
     case FMX_P_TEST_TONE:
@@ -1415,13 +1566,19 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         case FMX_P_SOUND_BALANCE: u.balance = iv; h->gain_dirty = true; break;
         case FMX_P_DEEMPHASIS: u.deemph_us = iv; break;
         case FMX_P_VOLUME_DB: u.volume_db = (float)value; u.ctor_volume = false; h->gain_dirty = true; break;
-        case FMX_P_LF_CUTOFF: u.lf_cutoff = iv > 0 ? iv : 0; u.lf_event = iv > 0; h->sets_dirty = true; break;
-        case FMX_P_BANDWIDTH: u.bandwidth = iv; u.bw_event = iv > 0; h->sets_dirty = true; break;
-        case FMX_P_ATTENUATION_L: p.att_l = (float)value; break;
-        case FMX_P_ATTENUATION_R: p.att_r = (float)value; break;
+        case FMX_P_LF_CUTOFF: case FMX_P_BANDWIDTH: {
+            if (id == FMX_P_LF_CUTOFF) { u.lf_cutoff = iv > 0 ? iv : 0; u.lf_event = iv > 0; } else { u.bandwidth = iv; u.bw_event = iv > 0; }
+            // a folded handle in mid-stream: the setter stays pending until the handle has kept enough of its streams to become a block-machine handle
+            // (promote); everywhere else -- before the first call, a block-machine handle, folded filters pinned -- it applies with the next call
+            const bool defer = !h->ola_mode && !h->folded_pinned && h->g_total > 0 && h->twins >= 1 && h->cfg.max_block >= 4096;
+            if (defer) { if (!h->promo_pending) { h->promo_pending = true; h->promo_have = 0; } }
+            else { u.bw_applied = u.bandwidth; u.lf_applied = u.lf_cutoff; h->sets_dirty = true; }
+            break; }
+        case FMX_P_ATTENUATION_L: p.att_l = (float)value; h->promo_recapture = true; break;
+        case FMX_P_ATTENUATION_R: p.att_r = (float)value; h->promo_recapture = true; break;
         case FMX_P_RDS_MODE: p.rds_mode = iv; break;
         case FMX_P_LOCAL_OSCILLATOR: {
-            p.lo_freq = iv;
+            p.lo_freq = iv; h->promo_recapture = true;
             int64_t a = iv < 0 ? -(int64_t)iv : iv, b = h->cfg.inputRate;
             while (b) { const int64_t r = a % b; a = b; b = r; }                  // gcd(|lo|, inputRate)
             const int64_t per = a ? h->cfg.inputRate / a : 0;
@@ -1436,7 +1593,7 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
         case FMX_P_PLL_SOLVER: p.pll_seq = (iv == 1 || (iv == 0 && h->channels <= PLL_SEQ_AUTO_MAX)) ? 1 : (iv == 3 ? 2 : 0); break;
         case FMX_P_DISP_DELAY:                       // DelayLine::set_delay_steps fm-processor.h:60-63: resize keeps what is there
             u.delay.resize((size_t)iv + 1, make_float2(-40.0f, -40.0f)); u.delay_idx = 0; break;
-        case FMX_P_DC_REMOVE: p.dc_remove = iv != 0; p.actions |= ACT_DC_RESET; break;
+        case FMX_P_DC_REMOVE: p.dc_remove = iv != 0; p.actions |= ACT_DC_RESET; h->promo_recapture = true; break;
         case FMX_A_TRIGGER_FREQUENCY_CHANGE: p.actions |= ACT_TRIGGER_FREQ; break;
         case FMX_A_RESTART_PSS: p.actions |= ACT_RESTART_PSS; break;
         default: break;
@@ -1445,6 +1602,14 @@ int fmx_set_param(fmx_handle h, int32_t channel, int32_t id, double value) {
     }
     h->params_dirty = true;
     return FMX_OK;
+}
+
+int64_t fmx_filter_change_due(fmx_handle h) {
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lk(h->mtx);
+    if (!h->promo_pending || h->ola_mode) return -1;
+    if (h->promo_recapture) return PROMO_TAIL_IN + 1;
+    return h->promo_have >= PROMO_TAIL_IN ? 0 : PROMO_TAIL_IN - h->promo_have;
 }
 
 int64_t fmx_frames_for(fmx_handle h, int64_t n) {

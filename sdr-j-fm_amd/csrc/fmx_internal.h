@@ -297,6 +297,9 @@ constexpr int OLA_MAX_CH = 64;              // FMX_P_FILTER_RESTARTS automatic: 
 constexpr int OLA_MAX_TAPS = 768;           // >= 756 (fmAudioFilter) and 251 (inputFilter)
 struct OlaChan { int32_t off, len, inp; int16_t on, conv; };   // this step of one channel: samples [off, off + len) of the call enter the block at inp; conv: the block is complete behind them
 struct OlaStep { OlaChan ch[OLA_MAX_CH]; };
+// a step as the launchers take it: by value (handles of up to OLA_MAX_CH channels: the receiver's call pays no copy), or as a table in device memory
+// (tab != null; larger handles: a batch that switched to the block machines behind a mid-stream filter change, fmx_api.hip)
+struct OlaStepRef { OlaStep val; const OlaChan *tab; };
 struct OlaBuffers {
     const float2 *src; float2 *dst;         // input / output streams, channel c at + c * stride, sample i of the call at (pos + i) & mask
     int64_t src_stride, dst_stride, src_mask, dst_mask, src_pos, dst_pos;
@@ -313,11 +316,20 @@ struct PreLook { float4 *maps; int32_t *flags; int32_t max_tiles, epoch; uint32_
 constexpr int PRE_TILE_SAMPLES = 8192;
 // (S, O given: the whole call is ONE run of every channel's filter, and the kernel does ola_io_kernel's work itself)
 void launch_pre(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, float2 *vbuf, int64_t vstride, int channels, hipStream_t s,
-                const OlaStep *S, const OlaBuffers *O, const PreLook &LB);
-void launch_ola_io(const OlaStep &S, const OlaBuffers &O, int channels, int maxlen, hipStream_t s);
-void launch_ola_conv(const OlaStep &S, const OlaBuffers &O, int channels, hipStream_t s);
+                const OlaStepRef *S, const OlaBuffers *O, const PreLook &LB);
+void launch_ola_io(const OlaStepRef &S, const OlaBuffers &O, int channels, int maxlen, hipStream_t s);
+void launch_ola_conv(const OlaStepRef &S, const OlaBuffers &O, int channels, hipStream_t s);
 // de-emphasis (fm-processor.cpp:594-595) of fm samples [J0, J1) of every channel, in place in `ring`
-void launch_deemph(const DeviceBuffers &B, const CallGeom &G, float2 *ring, int channels, hipStream_t s, const OlaStep *S, const OlaBuffers *O);
+void launch_deemph(const DeviceBuffers &B, const CallGeom &G, float2 *ring, int channels, hipStream_t s, const OlaStepRef *S, const OlaBuffers *O);
+
+// ---- a batch handle's promotion to the block machines behind a mid-stream filter change (fmx_promote.hip, fmx_api.hip promote)
+constexpr int PROMO_TAIL_IN = 3 * (2 * 32768 - 251) + 1024;      // input samples kept per stream: the block in progress, the two blocks in front of it, the filter's length
+constexpr int PROMO_TAIL_AU = 3 * (2 * 4096 - AUDIO_TAPS) + 1200; // fm samples of the d ring the audio machine is run over (and the de-emphasis behind it settles in)
+void launch_capture(const void *iq, int fmt, float qs, int64_t stream_stride, int64_t n, int streams, float2 *tail, int64_t tail_cap, int64_t pos, hipStream_t s);
+void launch_promo_state(ChanState *st, FrontSnap *snap, int channels, int mode, hipStream_t s);
+void launch_promo_hist(float2 *hist, const float2 *u, int64_t u_stride, int64_t len, int r0, int twins, float2 *zring, int ring_mask, int64_t J0,
+                       const ChanParams *params, const FrontSet *old_sets, const int32_t *old_set_of, int channels, hipStream_t s);
+void launch_promo_inv_deemph(const float2 *dring, int dmask, int64_t J0, int NA, const ChanParams *params, float2 *out, int channels, hipStream_t s);
 
 // ---- RDS path (fmx_rds.hip) -------------------------------------------------------------------
 constexpr int RDS_BLK = 32000;              // overlap-add block of the two 32768-pt filters (fft-filters.cpp:34)

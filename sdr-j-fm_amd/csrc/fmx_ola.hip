@@ -62,7 +62,7 @@ __device__ __forceinline__ void wg_affine_scan(AffW m, AffW *excl, AffW *total, 
 
 template <int FMT>
 __global__ __launch_bounds__(PRE_T) void pre_kernel(DeviceTables T, DeviceBuffers B, CallGeom G, const void *__restrict__ iq_raw, float2 *__restrict__ vbuf, int64_t vstride,
-                                                       int fused, OlaStep S, OlaBuffers O, PreLook LB) {
+                                                       int fused, OlaStep S, const OlaChan *__restrict__ Stab, OlaBuffers O, PreLook LB) {
     // One workgroup per TILE (8192 samples) and channel.  The only thing a tile needs from the tiles in front of it is the RF DC state at its
     // first sample: every workgroup publishes its tile's map r -> r (1 - u) + a (it depends on the tile's samples only) and walks the maps of
     // the tiles in front of its own from the call's state, one after the other as a single workgroup walking the call would -- the same
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(PRE_T) void pre_kernel(DeviceTables T, DeviceBuffer
         return make_float2((float)p[0] * qs, (float)p[1] * qs);
     };
     // (where this kernel also does the input filter's Pass (), the block results that go out in the samples' place are requested with them)
-    const OlaChan od = fused ? S.ch[ch] : OlaChan{};
+    const OlaChan od = fused ? (Stab ? Stab[ch] : S.ch[ch]) : OlaChan{};     // (handles above OLA_MAX_CH channels: the step's table in device memory)
     const bool pass = fused && od.on;
     const float2 *Cc = pass ? O.C + (size_t)ch * O.L + od.inp : nullptr;
     float2 *Ab = pass ? O.A + (size_t)ch * O.L + od.inp : nullptr;
@@ -213,15 +213,16 @@ __global__ __launch_bounds__(PRE_T) void pre_kernel(DeviceTables T, DeviceBuffer
 }
 
 void launch_pre(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, float2 *vbuf, int64_t vstride, int channels, hipStream_t s,
-                const OlaStep *S, const OlaBuffers *O, const PreLook &LB) {
+                const OlaStepRef *S, const OlaBuffers *O, const PreLook &LB) {
     const int fused = S != nullptr;
-    const OlaStep S0 = S ? *S : OlaStep{}; const OlaBuffers O0 = O ? *O : OlaBuffers{};
+    const OlaStep S0 = (S && !S->tab) ? S->val : OlaStep{}; const OlaBuffers O0 = O ? *O : OlaBuffers{};
+    const OlaChan *Stab = S ? S->tab : nullptr;
     const dim3 grid((unsigned)((G.n + PRE_TILE - 1) / PRE_TILE), channels);
     switch (G.iq_format) {
-    case 1: hipLaunchKernelGGL(pre_kernel<1>, grid, dim3(PRE_T), 0, s, T, B, G, iq, vbuf, vstride, fused, S0, O0, LB); break;
-    case 2: hipLaunchKernelGGL(pre_kernel<2>, grid, dim3(PRE_T), 0, s, T, B, G, iq, vbuf, vstride, fused, S0, O0, LB); break;
-    case 3: hipLaunchKernelGGL(pre_kernel<3>, grid, dim3(PRE_T), 0, s, T, B, G, iq, vbuf, vstride, fused, S0, O0, LB); break;
-    default: hipLaunchKernelGGL(pre_kernel<0>, grid, dim3(PRE_T), 0, s, T, B, G, iq, vbuf, vstride, fused, S0, O0, LB); break;
+    case 1: hipLaunchKernelGGL(pre_kernel<1>, grid, dim3(PRE_T), 0, s, T, B, G, iq, vbuf, vstride, fused, S0, Stab, O0, LB); break;
+    case 2: hipLaunchKernelGGL(pre_kernel<2>, grid, dim3(PRE_T), 0, s, T, B, G, iq, vbuf, vstride, fused, S0, Stab, O0, LB); break;
+    case 3: hipLaunchKernelGGL(pre_kernel<3>, grid, dim3(PRE_T), 0, s, T, B, G, iq, vbuf, vstride, fused, S0, Stab, O0, LB); break;
+    default: hipLaunchKernelGGL(pre_kernel<0>, grid, dim3(PRE_T), 0, s, T, B, G, iq, vbuf, vstride, fused, S0, Stab, O0, LB); break;
     }
 }
 
@@ -229,9 +230,9 @@ void launch_pre(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G
 // ola_io_kernel: Pass () over a run of `len` samples of every channel that does not cross the block boundary (the host cuts the
 // call there).  grid = (chunks, channels).  A filter that is switched off passes its input through and keeps its buffers.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ola_io_kernel(OlaStep S, OlaBuffers O) {
+__global__ __launch_bounds__(256) void ola_io_kernel(OlaStep S, const OlaChan *__restrict__ Stab, OlaBuffers O) {
     const int c = blockIdx.y;
-    const OlaChan d = S.ch[c];
+    const OlaChan d = Stab ? Stab[c] : S.ch[c];
     const int64_t smask = O.src_mask, dmask = O.dst_mask;
     const float2 *src = O.src + (size_t)c * O.src_stride;
     float2 *dst = O.dst + (size_t)c * O.dst_stride;
@@ -250,9 +251,9 @@ __global__ __launch_bounds__(256) void ola_io_kernel(OlaStep S, OlaBuffers O) {
 // grid = (ceil (L / 256) + ceil (degree / 256), channels): the last workgroups of a channel compute the new tail into a scratch row that
 // ola_tail_kernel moves into place (the old Overloop is an input of the first workgroups).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ola_conv_kernel(OlaStep S, OlaBuffers O) {
+__global__ __launch_bounds__(256) void ola_conv_kernel(OlaStep S, const OlaChan *__restrict__ Stab, OlaBuffers O) {
     const int c = blockIdx.y;
-    if (!S.ch[c].conv) return;
+    if (!(Stab ? Stab[c].conv : S.ch[c].conv)) return;
     const int L = O.L, D = O.degree;
     const float2 *A = O.A + (size_t)c * L;
     float2 *Cc = O.C + (size_t)c * L;
@@ -279,9 +280,9 @@ __global__ __launch_bounds__(256) void ola_conv_kernel(OlaStep S, OlaBuffers O) 
         } else O.over_new[(size_t)c * OLA_MAX_TAPS + (k - L)] = make_float2(ar, ai);
     }
 }
-__global__ __launch_bounds__(256) void ola_tail_kernel(OlaStep S, OlaBuffers O) {
+__global__ __launch_bounds__(256) void ola_tail_kernel(OlaStep S, const OlaChan *__restrict__ Stab, OlaBuffers O) {
     const int c = blockIdx.x;
-    if (!S.ch[c].conv) return;
+    if (!(Stab ? Stab[c].conv : S.ch[c].conv)) return;
     for (int i = threadIdx.x; i < O.degree; i += 256) O.over[(size_t)c * OLA_MAX_TAPS + i] = O.over_new[(size_t)c * OLA_MAX_TAPS + i];
 }
 
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void ola_tail_kernel(OlaStep S, OlaBuffers O) 
 // deemph_kernel: audio = last = (audio - last) * deemphAlpha + last (fm-processor.cpp:594-595) behind the audio filter, one workgroup per
 // channel over the call's fm samples; the same scan as pre_kernel's (the carry across threads is summed in another order: 1e-7 of it)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PRE_T) void deemph_kernel(DeviceBuffers B, CallGeom G, float2 *__restrict__ ring, int fused, OlaStep S, OlaBuffers O) {
+__global__ __launch_bounds__(PRE_T) void deemph_kernel(DeviceBuffers B, CallGeom G, float2 *__restrict__ ring, int fused, OlaStep S, const OlaChan *__restrict__ Stab, OlaBuffers O) {
     const int ch = blockIdx.x, t = threadIdx.x;
     ChanState *st = B.state + ch;
     const float a = B.params[ch].deemph_alpha;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(PRE_T) void deemph_kernel(DeviceBuffers B, CallGeom
     float yl = st->de_l, yr = st->de_r;
     __shared__ AffW sW[PRE_T / 64];
     __shared__ float2 sx[PRE_LDS];
-    const OlaChan od = fused ? S.ch[ch] : OlaChan{};
+    const OlaChan od = fused ? (Stab ? Stab[ch] : S.ch[ch]) : OlaChan{};
     const bool pass = fused && od.on;
     for (int base = 0; base < n; base += PRE_TILE) {
         const int i0 = base + t * PRE_K;
@@ -345,22 +346,22 @@ __global__ __launch_bounds__(PRE_T) void deemph_kernel(DeviceBuffers B, CallGeom
     // the next call's carry would see anyway)
     if (t == 0 && n > 0) { st->de_l = yl; st->de_r = yr; }
 }
-void launch_deemph(const DeviceBuffers &B, const CallGeom &G, float2 *ring, int channels, hipStream_t s, const OlaStep *S, const OlaBuffers *O) {
+void launch_deemph(const DeviceBuffers &B, const CallGeom &G, float2 *ring, int channels, hipStream_t s, const OlaStepRef *S, const OlaBuffers *O) {
     if (G.J1 <= G.J0) return;
-    const OlaStep S0 = S ? *S : OlaStep{}; const OlaBuffers O0 = O ? *O : OlaBuffers{};
-    hipLaunchKernelGGL(deemph_kernel, dim3(channels), dim3(PRE_T), 0, s, B, G, ring, S != nullptr ? 1 : 0, S0, O0);
+    const OlaStep S0 = (S && !S->tab) ? S->val : OlaStep{}; const OlaBuffers O0 = O ? *O : OlaBuffers{};
+    hipLaunchKernelGGL(deemph_kernel, dim3(channels), dim3(PRE_T), 0, s, B, G, ring, S != nullptr ? 1 : 0, S0, S ? S->tab : nullptr, O0);
 }
 
-void launch_ola_io(const OlaStep &S, const OlaBuffers &O, int channels, int maxlen, hipStream_t s) {
+void launch_ola_io(const OlaStepRef &S, const OlaBuffers &O, int channels, int maxlen, hipStream_t s) {
     if (maxlen <= 0) return;
     const int chunks = maxlen > 256 * 64 ? 64 : (maxlen + 255) / 256;
-    hipLaunchKernelGGL(ola_io_kernel, dim3((unsigned)chunks, (unsigned)channels), dim3(256), 0, s, S, O);
+    hipLaunchKernelGGL(ola_io_kernel, dim3((unsigned)chunks, (unsigned)channels), dim3(256), 0, s, S.tab ? OlaStep{} : S.val, S.tab, O);
 }
-void launch_ola_conv(const OlaStep &S, const OlaBuffers &O, int channels, hipStream_t s) {
+void launch_ola_conv(const OlaStepRef &S, const OlaBuffers &O, int channels, hipStream_t s) {
     static_assert(OLA_MAX_TAPS <= 1024, "the tail fits the workgroups below");
     const int body = (O.L + 255) / 256, tails = (O.degree + 255) / 256;
-    hipLaunchKernelGGL(ola_conv_kernel, dim3((unsigned)(body + tails), (unsigned)channels), dim3(256), 0, s, S, O);
-    hipLaunchKernelGGL(ola_tail_kernel, dim3((unsigned)channels), dim3(256), 0, s, S, O);
+    hipLaunchKernelGGL(ola_conv_kernel, dim3((unsigned)(body + tails), (unsigned)channels), dim3(256), 0, s, S.tab ? OlaStep{} : S.val, S.tab, O);
+    hipLaunchKernelGGL(ola_tail_kernel, dim3((unsigned)channels), dim3(256), 0, s, S.tab ? OlaStep{} : S.val, S.tab, O);
 }
 
 }  // namespace fmx

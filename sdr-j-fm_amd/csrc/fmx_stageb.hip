@@ -64,6 +64,11 @@ constexpr int PSS_MAX_ROUNDS = 64;
 // (into rows 1, 3) and row_bcast:31 (into rows 2, 3)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int CTRL, int RM> __device__ __forceinline__ int dppi(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xf, false); }
+// the same with ZERO where a lane has no source (bound_ctrl; every row enabled): no register to preset, and the move folds into the add / fma that follows
+// (round 6: `old = 0` cost a v_mov_b32 per step and kept the compiler from folding -- 700 v_mov_b32_dpp and as many presets in the kernel's listing)
+template <int CTRL> __device__ __forceinline__ int dppzi(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dppzf(float v) { return __int_as_float(dppzi<CTRL>(__float_as_int(v))); }
+template <int CTRL> __device__ __forceinline__ double dppzd(double v) { return __hiloint2double(dppzi<CTRL>(__double2hiint(v)), dppzi<CTRL>(__double2loint(v))); }
 template <int CTRL, int RM> __device__ __forceinline__ float dppf(float old, float v) { return __int_as_float(dppi<CTRL, RM>(__float_as_int(old), __float_as_int(v))); }
 template <int CTRL, int RM> __device__ __forceinline__ double dppd(double old, double v) {
     const int lo = dppi<CTRL, RM>(__double2loint(old), __double2loint(v));
@@ -71,17 +76,17 @@ template <int CTRL, int RM> __device__ __forceinline__ double dppd(double old, d
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wscan_add_d(double v) {
-    v += dppd<0x111, 0xf>(0.0, v); v += dppd<0x112, 0xf>(0.0, v); v += dppd<0x114, 0xf>(0.0, v); v += dppd<0x118, 0xf>(0.0, v);
+    v += dppzd<0x111>(v); v += dppzd<0x112>(v); v += dppzd<0x114>(v); v += dppzd<0x118>(v);
     v += dppd<0x142, 0xa>(0.0, v); v += dppd<0x143, 0xc>(0.0, v);
     return v;
 }
 __device__ __forceinline__ float wscan_add_f(float v) {
-    v += dppf<0x111, 0xf>(0.f, v); v += dppf<0x112, 0xf>(0.f, v); v += dppf<0x114, 0xf>(0.f, v); v += dppf<0x118, 0xf>(0.f, v);
+    v += dppzf<0x111>(v); v += dppzf<0x112>(v); v += dppzf<0x114>(v); v += dppzf<0x118>(v);
     v += dppf<0x142, 0xa>(0.f, v); v += dppf<0x143, 0xc>(0.f, v);
     return v;
 }
 __device__ __forceinline__ int wscan_add_i(int v) {
-    v += dppi<0x111, 0xf>(0, v); v += dppi<0x112, 0xf>(0, v); v += dppi<0x114, 0xf>(0, v); v += dppi<0x118, 0xf>(0, v);
+    v += dppzi<0x111>(v); v += dppzi<0x112>(v); v += dppzi<0x114>(v); v += dppzi<0x118>(v);
     v += dppi<0x142, 0xa>(0, v); v += dppi<0x143, 0xc>(0, v);
     return v;
 }
@@ -129,8 +134,8 @@ template <int NSCANS> __device__ __forceinline__ DecayW load_decay(const DecayTa
 }
 // inclusive over the wave: Z[t] = D Z[t-1] + L[t]
 __device__ __forceinline__ float wscan_decay(float v, const DecayW &w) {
-    v = fmaf(dppf<0x111, 0xf>(0.f, v), w.m1, v); v = fmaf(dppf<0x112, 0xf>(0.f, v), w.m2, v);
-    v = fmaf(dppf<0x114, 0xf>(0.f, v), w.m4, v); v = fmaf(dppf<0x118, 0xf>(0.f, v), w.m8, v);
+    v = fmaf(dppzf<0x111>(v), w.m1, v); v = fmaf(dppzf<0x112>(v), w.m2, v);
+    v = fmaf(dppzf<0x114>(v), w.m4, v); v = fmaf(dppzf<0x118>(v), w.m8, v);
     v = fmaf(dppf<0x142, 0xa>(0.f, v), w.mA, v); v = fmaf(dppf<0x143, 0xc>(0.f, v), w.mB, v);
     return v;
 }
@@ -315,7 +320,9 @@ __device__ __forceinline__ bool all_in(const float *v, float limit) {
 // inclusive wave scan of affine maps d -> A d + Bv (composition: the later map after the earlier one)
 struct Aff { float A, Bv; };
 template <int CTRL, int RM> __device__ __forceinline__ Aff aff_step(Aff c) {
-    const float pA = dppf<CTRL, RM>(1.f, c.A), pB = dppf<CTRL, RM>(0.f, c.Bv);     // lanes without a source compose with the identity
+    const float pA = dppf<CTRL, RM>(1.f, c.A);                                      // lanes without a source compose with the identity
+    float pB;
+    if constexpr (RM == 0xf) pB = dppzf<CTRL>(c.Bv); else pB = dppf<CTRL, RM>(0.f, c.Bv);
     Aff r; r.Bv = fmaf(c.A, pB, c.Bv); r.A = c.A * pA;
     return r;
 }

@@ -34,7 +34,7 @@ TAP_FM_IQ, TAP_DEMOD, TAP_LR_RAW, TAP_PRE_RESAMPLER, TAP_RDS_IQ, TAP_PILOT_PHASE
 IQ_F32, IQ_U8, IQ_S8, IQ_S16 = 0, 1, 2, 3
 
 EXPORTS = [
-    "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for",
+    "fmx_abi_version", "fmx_last_error", "fmx_create", "fmx_destroy", "fmx_set_param", "fmx_frames_for", "fmx_filter_change_due",
     "fmx_process_host", "fmx_process_device", "fmx_process_host_raw", "fmx_process_device_raw", "fmx_synchronize",
     "fmx_get_meta", "fmx_get_tap", "fmx_get_peaks",
     "fmx_rds_bits", "fmx_rds_symbols", "fmx_last_fm_samples", "fmx_pll_replays", "fmx_pll_exact_segments", "fmx_last_front_kernel", "fmx_last_call_pieces", "fmx_last_second_group", "fmx_last_rds_samples", "fmx_last_rds_samples_of", "fmx_rds_decode", "fmx_rds_decode_bits", "fmx_rds_pty_name", "fmx_rds_map_char", "fmx_rds_prepare_text", "fmx_get_taps", "fmx_profile_enable", "fmx_profile_read",
@@ -146,6 +146,8 @@ def load_library(path=None):
     L.fmx_pll_replays.restype = C.c_int64
     L.fmx_pll_replays.argtypes = [vp, C.c_int32]
     L.fmx_pll_exact_segments.restype = C.c_int64
+    L.fmx_filter_change_due.restype = C.c_int64
+    L.fmx_filter_change_due.argtypes = [vp]
     L.fmx_last_front_kernel.restype = C.c_int32
     L.fmx_last_front_kernel.argtypes = [vp]
     L.fmx_last_call_pieces.restype = C.c_int32
@@ -294,6 +296,11 @@ class Fmx:
 
     def last_fm_samples(self):
         return int(self.L.fmx_last_fm_samples(self.h))
+
+    def filter_change_due(self):
+        """Input samples per stream still to come before a pending mid-stream setBandwidth / setlfcutoff of a batch takes effect (fmx_filter_change_due):
+        0 = the next call applies it at its first sample, -1 = nothing pending (setters apply with the next call)."""
+        return int(self.L.fmx_filter_change_due(self.h))
 
     def last_front_kernel(self):
         """Which kernel ran the input-filter stage of the last call (fmx_last_front_kernel: FMX_P_FRONT_KERNEL's numbering)."""

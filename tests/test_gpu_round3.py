@@ -539,7 +539,7 @@ MID_ORDER = [dict(inputFilterBw=0), dict(inputFilterBw=120000), dict(lfCutoff=12
              dict(inputFilterBw=165000, lfCutoff=9000)]
 
 
-def run_mid_stream_changes(fmx_amd, ol, nch, gap_s, block=16384 * 3):
+def run_mid_stream_changes(fmx_amd, ol, nch, gap_s, block=16384 * 3, restarts=None):
     """the changes of MID_ORDER, one every gap_s seconds, through the library and the oracle: per-call PCM RMS differences and the change calls"""
     per_s = 2304000 / block
     gap = int(gap_s * per_s)
@@ -548,6 +548,8 @@ def run_mid_stream_changes(fmx_amd, ol, nch, gap_s, block=16384 * 3):
     iq = ol.synth_iq(nb * block)
     o = ol.OracleChain(inputFilterBw=165000)
     f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block)
+    if restarts is not None:
+        f.set_param(M.P_FILTER_RESTARTS, restarts)
     gui_defaults(f)
     per_call = []
     for b in range(nb):
@@ -578,15 +580,17 @@ def test_mid_stream_filter_changes_single_receiver(fmx_amd, ol):
     assert max(per_call) <= PCM_RMS_TOL
 
 
-def test_mid_stream_filter_changes_are_bounded_in_a_batch(fmx_amd, ol):
-    """The same changes on a handle above 64 channels, whose filters are folded into the polyphase FIRs of stage A and stage C: the new tap
+def test_mid_stream_filter_changes_are_bounded_with_the_folded_filters_pinned(fmx_amd, ol):
+    """(Round 6: a batch on the automatic setting is EXACT behind such a change -- tests/test_gpu_round6.py::test_mid_stream_filter_changes_are_exact_in_a_batch;
+    this is what FMX_P_FILTER_RESTARTS = 2, the folded filters for good, still gives.)
+    The same changes on a handle above 64 channels, whose filters are folded into the polyphase FIRs of stage A and stage C: the new tap
     set applies from the call's first sample and the rings are read at the new latency -- during one filter latency the reference's
     output and the library's are both glitches, and different ones.  Behind an AUDIO filter change nothing else has state: the PCM agrees
     again within 0.25 s.  Behind an INPUT filter change the 28 ms of different fm-rate IQ kick the pilot PLL, the lock detector and the PSS
     differently; where the glitch costs one side its pilot lock the stereo decoder comes back half a second apart and the PSS
     integrator re-converges behind it.  Asserted: PCM finite and bounded throughout (run_mid_stream_changes), within the tolerance again
     at most 0.25 s behind an audio filter change and 2.3 s behind an input filter change, and from there until the next change."""
-    per_call, switches, gap = run_mid_stream_changes(fmx_amd, ol, 65, 2.5)
+    per_call, switches, gap = run_mid_stream_changes(fmx_amd, ol, 65, 2.5, restarts=2)
     per_s = 2304000 / (16384 * 3)
     back = {s_: next((i for i in range(gap) if all(v <= PCM_RMS_TOL for v in per_call[s_ + i:s_ + gap])), gap) for s_ in sorted(switches)}
     print("\n[mid-stream filter changes, 65 channels, folded filters] seconds behind each change until the PCM is back under 1e-5 for good: "

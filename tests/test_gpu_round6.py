@@ -108,3 +108,57 @@ def test_randomised_soak_against_the_oracle():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_random.py"), *args], capture_output=True, text=True, timeout=900)
         print(r.stdout[-1500:])
         assert r.returncode == 0, (args, r.stdout[-3000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("nch", [65, 1100])
+def test_block_machines_on_a_batch(fmx_amd, ol, nch):
+    """The reference's two overlap-add filters as the block machines they are (fmx_ola.hip) were built for handles of up to 64 channels -- a step of every
+    channel's machine rode in the kernel arguments.  Since round 6 the steps of a larger handle are tables in device memory: FMX_P_FILTER_RESTARTS = 1 on 65
+    and on 1100 channels, the seven mid-stream filter changes of test_mid_stream_filter_changes_single_receiver every 0.5 s -- "165kHz" -> "Off" -> "120kHz",
+    three changes of the audio cut-off, back, both at once --: the PCM of EVERY call within the tolerance, glitches included, every channel its twins' equal."""
+    from test_gpu_round3 import run_mid_stream_changes
+    per_call, switches, gap = run_mid_stream_changes(fmx_amd, ol, nch, 0.5, restarts=1)
+    print("\n[mid-stream filter changes, %d channels on the block machines] worst call behind each change: " % nch
+          + ", ".join("%s: %.1e" % (switches[s_], max(per_call[s_:s_ + gap])) for s_ in sorted(switches)))
+    assert max(per_call) <= 1e-5
+
+
+@pytest.mark.parametrize("nch", [65, 1100])
+def test_mid_stream_filter_changes_are_exact_in_a_batch(fmx_amd, ol, nch):
+    """VERDICT r3 / r4 / r5 missing #1.  setBandwidth (radio.cpp:1706-1712 -> fm-processor.cpp:232-239,396-408) and setlfcutoff (:762-770) while the stream
+    runs, on a BATCH with the automatic settings.  The reference's overlap-add filters restart their block position at every setLowPass
+    (fft-filters.cpp:84-95: inp = 0, buffers kept): the last completed output block is played again, the block in progress is dropped, the old block's tail is
+    added to the first block of the new kernel; "Off" lets the undelayed samples through at once.  A batch runs its filters folded into the polyphase FIRs --
+    until the first such setter arrives: the change stays pending while the library keeps three blocks of its streams (fmx_filter_change_due counts them
+    down: 85 ms), then the handle becomes a block-machine handle (fmx_promote.hip) and the setter restarts its filter as the reference's does.  The test hands
+    the oracle each setter at the call the library says it applies it at.  "165kHz" -> "Off" -> "120kHz", three changes of the audio cut-off, back to "165kHz",
+    both filters at once, every 0.5 s: the PCM of EVERY call within the tolerance, the glitches included, every channel equal to its twins."""
+    from test_gpu_round3 import MID_ORDER, gui_defaults
+    block = 16384 * 3
+    per_s = 2304000 / block
+    gap = int(0.5 * per_s)
+    switches = {(i + 1) * gap: d for i, d in enumerate(MID_ORDER)}
+    nb = (len(MID_ORDER) + 1) * gap
+    iq = ol.synth_iq(nb * block)
+    o = ol.OracleChain(inputFilterBw=165000)
+    f = fmx_amd.Fmx(nch, streams=1, stream_of_channel=[0] * nch, max_block=block)
+    gui_defaults(f)
+    per_call, waiting, applied_at = [], None, {}
+    for b in range(nb):
+        if b in switches:
+            assert waiting is None
+            for k, v in switches[b].items():
+                f.set_param(M.P_BANDWIDTH if k == "inputFilterBw" else M.P_LF_CUTOFF, v)
+            waiting = (b, switches[b])
+        if waiting is not None and f.filter_change_due() <= 0:           # (0: this call applies it at its first sample; -1: a block-machine handle, likewise)
+            o.configure(**waiting[1]); applied_at[waiting[0]] = b; waiting = None
+        x = iq[b * block:(b + 1) * block]
+        po, pg = o.process(x), f.process_host(x)
+        assert pg[0].shape == po.shape and np.isfinite(pg).all()
+        for c in range(1, nch):
+            assert np.array_equal(pg[c], pg[0])
+        per_call.append(rms(pg[0] - po))
+    print("\n[mid-stream filter changes, %d channels, automatic settings] setter at call -> applied at call: %s; worst call behind each change: " % (nch, applied_at)
+          + ", ".join("%s: %.1e" % (switches[s_], max(per_call[s_:s_ + gap])) for s_ in sorted(switches)))
+    assert max(applied_at[s_] - s_ for s_ in applied_at) <= 5 and len(applied_at) == len(switches)
+    assert max(per_call) <= 1e-5
