@@ -728,9 +728,11 @@ def main():
             out["roofline"]["control"] = {"kernel": "fmx::front_kernel (f32 packed FMAs)" if k1 == 1 else "?", "avg_launch_ms": round(ms1, 4),
                                           "frac": round(alg_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms1 > 0 else None,
                                           "headline_kernel_avg_launch_ms_same_pass": round(ms3, 4), "headline_kernel": k3,
-                                          "pcm_max_abs_diff": float((pa - pb).abs().max().item()), "pcm_full_scale": float(pb.abs().max().item()),
+                                          "pcm_max_abs_diff": float((pa - pb).abs().max().item()), "pcm_rms_diff": float((pa - pb).double().pow(2).mean().sqrt().item()),
+                                          "pcm_full_scale": float(pb.abs().max().item()),
                                           "what": "two fresh handles, the same %d calls from the stream's start (through pilot lock); PCM of the last call, every channel, "
-                                                  "max |matrix-pipe stage A - f32 stage A|; launch times: mean of the last 4 calls" % ncalls}
+                                                  "max and rms of |matrix-pipe stage A - f32 stage A| (call 12 sits behind the pilot's lock-in, where the stereo decoder has just switched on: the largest "
+                                                  "differences are single samples there); launch times: mean of the last 4 calls" % ncalls}
             del pa, pb, res
         except Exception as e:      # the control is a report; the headline does not depend on it
             out["roofline"]["control"] = {"error": str(e)[:200]}

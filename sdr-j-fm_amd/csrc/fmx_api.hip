@@ -149,10 +149,16 @@ struct fmx_handle_s {
     // then the handle switches to the block machines (promote).  FMX_P_FILTER_RESTARTS = 2 pins the folded filters (the change then applies at once, as
     // rounds 1-5 applied it: a different glitch of one filter latency).
     bool folded_pinned = false;          // FMX_P_FILTER_RESTARTS = 2 was asked for
+    bool promoted = false;               // a block-machine handle by promotion: goes back to the folded filters once its machines have been quiet (demote)
+    bool demo_capture = false;           // ... and is keeping its streams for that
+    int64_t last_filter_event_g = 0;     // stream position at which a filter setter was last applied (ola_take_settings)
+    std::vector<int64_t> origin_in, origin_au;   // per channel: the stream position (input samples / fm samples) at which the filter's block counter was last 0, as far as a
+                                         // FOLDED handle knows it (0 from fmx_create; the machines' own counters at a demotion)
     bool promo_pending = false;          // a filter setter arrived behind the first call
     bool promo_recapture = false;        // ... and a setter of what pre_kernel applies (RF DC removal, balance, oscillator) behind it: the kept samples start over
     int64_t promo_have = 0, promo_g0 = 0;   // samples kept per stream, and the stream position of the first
     float2 *tail_iq = nullptr; int64_t tail_cap = 0; FrontSnap *tail_snap = nullptr;
+    size_t old_sets_cap = 0;
     ChanParams *d_params_replay = nullptr; FrontSet *d_old_sets = nullptr; int32_t *d_old_set_of = nullptr; float2 *d_au_tail = nullptr;
     // the block machines' steps of a handle above OLA_MAX_CH channels: tables in device memory (the launchers take a step by value up to 64 channels),
     // a ring of STEP_SLOTS tables, each copied from pinned host memory on the call's stream in front of the kernels that read it
@@ -527,8 +533,9 @@ int ola_take_settings(fmx_handle h) {
             bool &ev = side ? h->user[c].lf_event : h->user[c].bw_event;
             const bool again = ev && want != 0 && S.key[(size_t)c] >= 0;        // (the value in use selected again: the block restarts, the kernel stays)
             ev = false;
-            if (want == S.key[(size_t)c]) { if (again) { S.on[(size_t)c] = 1; S.inp[(size_t)c] = 0; } continue; }
+            if (want == S.key[(size_t)c]) { if (again) { S.on[(size_t)c] = 1; S.inp[(size_t)c] = 0; h->last_filter_event_g = h->g_total; } continue; }
             S.key[(size_t)c] = want;
+            h->last_filter_event_g = h->g_total;
             if (want == 0) { S.on[(size_t)c] = 0; continue; }
             const std::vector<float> k = side ? design::lowpass(AUDIO_TAPS, want, h->cfg.fmRate) : design::lowpass(251, want / 2, h->cfg.inputRate);
             if (!synced) { HIPCHK(hipDeviceSynchronize()); synced = true; }      // (an earlier call may still be reading the kernels)
@@ -635,12 +642,16 @@ int promote(fmx_handle h, hipStream_t s) {
     const size_t C = (size_t)h->channels;
     HIPCHK(hipDeviceSynchronize());
     int rc = ensure_ola(h); if (rc) return rc;
-    if (!h->d_old_sets) {
-        HIPCHK(hipMalloc(&h->d_old_sets, sizeof(FrontSet) * std::max<size_t>(h->h_front_sets.size(), 1)));
+    if (h->h_front_sets.size() > h->old_sets_cap) {
+        if (h->d_old_sets) (void)hipFree(h->d_old_sets);
+        h->d_old_sets = nullptr; h->old_sets_cap = h->h_front_sets.size() + 8;
+        HIPCHK(hipMalloc(&h->d_old_sets, sizeof(FrontSet) * h->old_sets_cap));
+    }
+    if (!h->d_old_set_of) {
         HIPCHK(hipMalloc(&h->d_old_set_of, sizeof(int32_t) * C));
         HIPCHK(hipMalloc(&h->d_params_replay, sizeof(ChanParams) * C));
         HIPCHK(hipMalloc(&h->d_au_tail, sizeof(float2) * C * PROMO_TAIL_AU));
-        for (void *p : {(void *)h->d_old_sets, (void *)h->d_old_set_of, (void *)h->d_params_replay, (void *)h->d_au_tail}) h->tail_ptrs.push_back(p);
+        for (void *p : {(void *)h->d_old_set_of, (void *)h->d_params_replay, (void *)h->d_au_tail}) h->tail_ptrs.push_back(p);
     }
     {   // what the folded stage A used: its tap sets' delays (the ring's newest entries move by them), and the parameters the kept samples were taken under
         std::vector<int32_t> set_of(C);
@@ -662,7 +673,8 @@ int promote(fmx_handle h, hipStream_t s) {
         for (size_t c = 0; c < C; c++) {
             const int32_t want = side ? (h->user[c].lf_applied > 0 ? h->user[c].lf_applied : 0) : (h->user[c].bw_applied > 0 ? h->user[c].bw_applied : 0);
             S.key[c] = want; S.on[c] = want != 0 ? 1 : 0;
-            S.inp[c] = want != 0 ? (int32_t)(((start % S.L) + S.L) % S.L) : 0;
+            const int64_t org = (side ? h->origin_au : h->origin_in).size() == C ? (side ? h->origin_au : h->origin_in)[c] : 0;
+            S.inp[c] = want != 0 ? (int32_t)((((start - org) % S.L) + S.L) % S.L) : 0;
             if (want == 0) continue;
             const std::vector<float> k = side ? design::lowpass(AUDIO_TAPS, want, h->cfg.fmRate) : design::lowpass(251, want / 2, h->cfg.inputRate);
             HIPCHK(hipMemcpy(S.taps + c * OLA_MAX_TAPS, k.data(), sizeof(float) * k.size(), hipMemcpyHostToDevice));
@@ -699,8 +711,74 @@ int promote(fmx_handle h, hipStream_t s) {
     HIPCHK(hipDeviceSynchronize());
     // ---- a block-machine handle from here on: the pending setters reach their filters through ola_take_settings, as a small handle's do
     h->ola_mode = true; h->sets_dirty = true; h->params_dirty = true;
-    h->promo_pending = false; h->promo_have = 0;
+    h->promo_pending = false; h->promo_have = 0; h->promoted = true; h->demo_capture = false; h->last_filter_event_g = t0;
     for (auto &u : h->user) { u.bw_applied = u.bandwidth; u.lf_applied = u.lf_cutoff; }
+    return FMX_OK;
+}
+
+// may a promoted handle go back?  Every filter that has ever run is running and has been undisturbed for three blocks (a filter that is switched off keeps
+// buffers the reference would replay when it is switched on again: such a handle stays on the machines), nothing is pending
+bool demotable(fmx_handle h) {
+    if (!h->promoted || !h->ola_mode || h->folded_pinned || h->twins != 1) return false;
+    if (h->g_total - h->last_filter_event_g < DEMO_QUIET) return false;
+    for (int side = 0; side < 2; side++) {
+        const fmx_handle_s::OlaSide &S = side ? h->ola_au : h->ola_in;
+        for (int c = 0; c < h->channels; c++) {
+            const ChanUser &u = h->user[(size_t)c];
+            if ((side ? u.lf_event : u.bw_event)) return false;
+            const int32_t want = side ? (u.lf_cutoff > 0 ? u.lf_cutoff : 0) : (u.bandwidth > 0 ? u.bandwidth : 0);
+            if (want != S.key[(size_t)c] && !(want == 0 && S.key[(size_t)c] <= 0)) return false;      // (a setter on its way)
+            if (S.key[(size_t)c] > 0 && !S.on[(size_t)c]) return false;
+            if (S.key[(size_t)c] == 0 && want == 0 && S.inp[(size_t)c] != 0) return false;             // (switched off in mid-block: stale buffers)
+        }
+    }
+    return true;
+}
+// DEMOTION: the folded filters again at the stream position g_total (see DEMO_QUIET in fmx_internal.h)
+int demote(fmx_handle h, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(h->mtx);
+    const size_t C = (size_t)h->channels;
+    HIPCHK(hipDeviceSynchronize());
+    const int64_t t1 = h->g_total, have = h->promo_have, J1 = t1 / h->decim;
+    h->origin_in.assign(C, 0); h->origin_au.assign(C, 0);
+    for (size_t c = 0; c < C; c++) {
+        if (h->ola_in.on[c]) h->origin_in[c] = t1 - h->ola_in.inp[c];
+        if (h->ola_au.on[c]) h->origin_au[c] = J1 - h->ola_au.inp[c];
+    }
+    h->ola_mode = false; h->promoted = false; h->demo_capture = false; h->promo_have = 0;
+    for (auto &u : h->user) { u.bw_applied = u.bandwidth; u.lf_applied = u.lf_cutoff; }
+    h->sets_dirty = true;
+    int rc = ensure_sets(h); if (rc) return rc;                   // (the folded tap sets of the settings in force; the channels' set indices with them)
+    {
+        std::vector<ChanParams> pr(h->params);
+        for (auto &p : pr) p.actions = 0;
+        HIPCHK(hipMemcpy(h->d_params_replay, pr.data(), sizeof(ChanParams) * C, hipMemcpyHostToDevice));
+    }
+    g_launch_err = hipSuccess;
+    // the channels' stage-A state back to the first kept sample, an empty filter history (the run's first 24 outputs land in ring entries nobody reads any more)
+    launch_promo_state(h->B.state, h->tail_snap, h->channels, 1, s); FMX_LAUNCHED();
+    HIPCHK(hipMemsetAsync(h->B.hist, 0, sizeof(float2) * C * DECIM * A_HIST_COLS, s));
+    HIPCHK(hipMemsetAsync(h->B.dcv_hist, 0, sizeof(float2) * C * DCV_SAVE, s));
+    DeviceBuffers Bc = h->B; Bc.params = h->d_params_replay;
+    int64_t pos = 0;
+    while (pos < have) {
+        const int64_t len = std::min<int64_t>(h->cfg.max_block, have - pos);
+        CallGeom Gc{};
+        Gc.g0 = h->promo_g0 + pos; Gc.n = len; Gc.J0 = Gc.g0 / h->decim; Gc.J1 = (Gc.g0 + len) / h->decim;
+        Gc.ring_mask = h->ring - 1; Gc.dring_mask = h->dring - 1; Gc.sring_mask = h->sring - 1; Gc.input_rate = h->cfg.inputRate; Gc.pitch = h->pitch;
+        Gc.iq_format = 0; Gc.iq_scale = 1.0f; Gc.stream_stride = h->tail_cap; Gc.channels = h->channels; Gc.streams = h->streams; Gc.twins = h->twins; Gc.n_cus = h->n_cus;
+        Gc.parts = 1;
+        launch_front(h->T, Bc, Gc, h->tail_iq + pos, h->channels, s); FMX_LAUNCHED();
+        pos += len;
+    }
+    // the d ring as the folded stage B leaves it: de-emphasised (its last entries, from a standing start 2048 entries in front of what stage C reads)
+    {
+        CallGeom Gx{}; Gx.J0 = J1 - DEMO_TAIL_AU; Gx.J1 = J1; Gx.dring_mask = h->dring - 1;
+        launch_deemph(Bc, Gx, h->B.dring, h->channels, s, nullptr, nullptr); FMX_LAUNCHED();
+    }
+    HIPCHK(g_launch_err);
+    HIPCHK(hipDeviceSynchronize());
+    h->params_dirty = true;
     return FMX_OK;
 }
 
@@ -968,15 +1046,25 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     int rc;
     bool capture = false;
     {   // a folded batch with a filter change pending (fmx_promote.hip): promoted once enough of its streams is kept, else this call's samples are kept too
-        bool do_promote = false;
+        bool do_promote = false, do_demote = false;
         {
             std::lock_guard<std::mutex> lk(h->mtx);
-            if (!h->promo_pending || h->ola_mode) h->promo_recapture = false;
+            if (h->ola_mode) {
+                // (a promoted handle whose machines have been quiet goes back to the folded filters: it keeps a block of its streams first)
+                const bool ok = demotable(h);
+                if (!ok || h->promo_recapture) { h->demo_capture = false; h->promo_have = 0; }
+                else if (!h->demo_capture) { h->demo_capture = true; h->promo_have = 0; capture = true; }
+                else if (h->promo_have >= DEMO_TAIL_IN) do_demote = true;
+                else capture = true;
+                h->promo_recapture = false;
+            }
+            else if (!h->promo_pending) h->promo_recapture = false;
             else if (h->promo_recapture) { h->promo_recapture = false; h->promo_have = 0; }      // (what pre_kernel applies changed: the kept samples start over, behind this call)
             else if (h->promo_have >= PROMO_TAIL_IN) do_promote = true;
             else capture = true;
         }
         if (do_promote) { rc = promote(h, s); if (rc) return rc; }
+        if (do_demote) { rc = demote(h, s); if (rc) return rc; }
     }
     rc = flush_mailbox(h);
     if (rc) return rc;
@@ -1486,6 +1574,7 @@ int fmx_destroy(fmx_handle h) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : h->rds_ptrs) if (p) (void)hipFree(p);
     for (void *p : h->tail_ptrs) if (p) (void)hipFree(p);
+    if (h->d_old_sets) (void)hipFree(h->d_old_sets);
     if (h->step_host) (void)hipHostFree(h->step_host);
     for (hipEvent_t e : h->step_ev) if (e) (void)hipEventDestroy(e);
     if (h->hp_iq) (void)hipHostFree(h->hp_iq);

@@ -325,6 +325,12 @@ void launch_deemph(const DeviceBuffers &B, const CallGeom &G, float2 *ring, int 
 // ---- a batch handle's promotion to the block machines behind a mid-stream filter change (fmx_promote.hip, fmx_api.hip promote)
 constexpr int PROMO_TAIL_IN = 3 * (2 * 32768 - 251) + 1024;      // input samples kept per stream: the block in progress, the two blocks in front of it, the filter's length
 constexpr int PROMO_TAIL_AU = 3 * (2 * 4096 - AUDIO_TAPS) + 1200; // fm samples of the d ring the audio machine is run over (and the de-emphasis behind it settles in)
+// ... and back (demote): once its machines have been quiet for DEMO_QUIET input samples (three blocks: they are the LTI filters again, which the folded FIRs
+// reproduce), a promoted batch keeps DEMO_TAIL_IN samples of its streams and runs the folded stage A over them -- the fm-rate ring's entries in flight and
+// the filter history a folded call finds --, and takes the d ring's last DEMO_TAIL_AU entries through the de-emphasis the folded stage B applies
+constexpr int64_t DEMO_QUIET = 3 * (2 * 32768 - 251) + 4096;
+constexpr int DEMO_TAIL_IN = (2 * 32768 - 251) + 4096;
+constexpr int DEMO_TAIL_AU = AUDIO_DELAY + C_MAX_TAPS + 2048;
 void launch_capture(const void *iq, int fmt, float qs, int64_t stream_stride, int64_t n, int streams, float2 *tail, int64_t tail_cap, int64_t pos, hipStream_t s);
 void launch_promo_state(ChanState *st, FrontSnap *snap, int channels, int mode, hipStream_t s);
 void launch_promo_hist(float2 *hist, const float2 *u, int64_t u_stride, int64_t len, int r0, int twins, float2 *zring, int ring_mask, int64_t J0,

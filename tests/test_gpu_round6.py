@@ -123,8 +123,8 @@ def test_block_machines_on_a_batch(fmx_amd, ol, nch):
     assert max(per_call) <= 1e-5
 
 
-@pytest.mark.parametrize("nch", [65, 1100])
-def test_mid_stream_filter_changes_are_exact_in_a_batch(fmx_amd, ol, nch):
+@pytest.mark.parametrize("nch,first", [(65, 0), (1100, 0), (65, 1), (1100, 2), (65, 5)])
+def test_mid_stream_filter_changes_are_exact_in_a_batch(fmx_amd, ol, nch, first):
     """VERDICT r3 / r4 / r5 missing #1.  setBandwidth (radio.cpp:1706-1712 -> fm-processor.cpp:232-239,396-408) and setlfcutoff (:762-770) while the stream
     runs, on a BATCH with the automatic settings.  The reference's overlap-add filters restart their block position at every setLowPass
     (fft-filters.cpp:84-95: inp = 0, buffers kept): the last completed output block is played again, the block in progress is dropped, the old block's tail is
@@ -132,8 +132,11 @@ def test_mid_stream_filter_changes_are_exact_in_a_batch(fmx_amd, ol, nch):
     until the first such setter arrives: the change stays pending while the library keeps three blocks of its streams (fmx_filter_change_due counts them
     down: 85 ms), then the handle becomes a block-machine handle (fmx_promote.hip) and the setter restarts its filter as the reference's does.  The test hands
     the oracle each setter at the call the library says it applies it at.  "165kHz" -> "Off" -> "120kHz", three changes of the audio cut-off, back to "165kHz",
-    both filters at once, every 0.5 s: the PCM of EVERY call within the tolerance, the glitches included, every channel equal to its twins."""
+    both filters at once, every 0.5 s: the PCM of EVERY call within the tolerance, the glitches included, every channel equal to its twins.
+    `first`: the list of changes rotated, so that the change the promotion meets is "Off" (0), a new width (1: a restart with another kernel), a new audio
+    cut-off (2), the width in use selected again (5: the block restarts, the kernel stays)."""
     from test_gpu_round3 import MID_ORDER, gui_defaults
+    MID_ORDER = MID_ORDER[first:] + MID_ORDER[:first]
     block = 16384 * 3
     per_s = 2304000 / block
     gap = int(0.5 * per_s)
@@ -162,3 +165,101 @@ def test_mid_stream_filter_changes_are_exact_in_a_batch(fmx_amd, ol, nch):
           + ", ".join("%s: %.1e" % (switches[s_], max(per_call[s_:s_ + gap])) for s_ in sorted(switches)))
     assert max(applied_at[s_] - s_ for s_ in applied_at) <= 5 and len(applied_at) == len(switches)
     assert max(per_call) <= 1e-5
+
+
+@pytest.mark.parametrize("rate,fmt", [(2304000, "f32"), (2304000, "s16"), (2048000, "f32")])
+def test_promotion_with_oscillators_offsets_and_per_channel_setters(fmx_amd, ol, rate, fmt):
+    """The promotion's run over the kept samples starts from the channels' own state -- RfDC, the oscillator's phase -- and applies every channel's own
+    settings: 70 channels on three streams with DC offsets (one beyond the limiter), kinds of channels with an oscillator, an IQ balance, RF DC removal off,
+    other widths and a filter that is off; raw int16 samples; the rate the reference decimates by six.  Setters on SOME channels only (the rest of the handle is promoted with them and must not notice): a new width for kind 1, "Off" for kind 2, an audio
+    cut-off for kind 3, the filter switched ON for kind 5.  Every channel against an oracle chain of its kind taking the setter when the library says so;
+    every call within the tolerance."""
+    nch, nst = 70, 3
+    kinds = [dict(), dict(loFrequency=2500), dict(attL=0.9, attR=1.1), dict(dcRemove=0, inputFilterBw=130000), dict(loFrequency=-4000, attL=1.15), dict(inputFilterBw=0)]
+    events = {1: dict(inputFilterBw=120000), 2: dict(inputFilterBw=0), 3: dict(lfCutoff=9000), 5: dict(inputFilterBw=165000)}
+    blocks = [16384 * 3] * 42
+    n = sum(blocks)
+    iq = np.stack([ol.synth_iq(n, inputRate=2304000, leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k, dcI=(0.0, 0.006, -0.02)[k], dcQ=(0.0, -0.004, 0.015)[k],
+                               noiseSeed=5 + k, noiseSigma=0.001 * k) for k in range(nst)])
+    raw, code = iq, None
+    if fmt == "s16":
+        raw = np.clip(np.round(iq * 16384.0), -32768, 32767).astype(np.int16); code = M.IQ_S16
+        iq = (raw.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    f = fmx_amd.Fmx(nch, streams=nst, stream_of_channel=[c % nst for c in range(nch)], max_block=max(blocks), inputRate=rate)
+    pid = dict(inputFilterBw=M.P_BANDWIDTH, lfCutoff=M.P_LF_CUTOFF, attL=M.P_ATTENUATION_L, attR=M.P_ATTENUATION_R, loFrequency=M.P_LOCAL_OSCILLATOR, dcRemove=M.P_DC_REMOVE)
+    for p_, v in ((M.P_BANDWIDTH, 165000), (M.P_LF_CUTOFF, 15000), (M.P_DEEMPHASIS, 50), (M.P_VOLUME_DB, -6.0)):
+        f.set_param(p_, v)
+    kind_of = [(c // nst) % len(kinds) for c in range(nch)]
+    for c in range(nch):
+        for k, v in kinds[kind_of[c]].items():
+            f.set_param(pid[k], v, c)
+    chains = {}
+    for c in range(nch):
+        key = (c % nst, kind_of[c])
+        if key not in chains:
+            chains[key] = (ol.OracleChain(inputRate=rate, **dict(dict(inputFilterBw=165000), **kinds[kind_of[c]])), c)
+    at_call, waiting, applied = 20, False, None
+    worst, pos = 0.0, 0
+    for b, nb_ in enumerate(blocks):
+        if b == at_call:
+            for c in range(nch):
+                for k, v in events.get(kind_of[c], {}).items():
+                    f.set_param(pid[k], v, c)
+            waiting = True
+        if waiting and f.filter_change_due() <= 0:
+            for (sidx, kd), (ch, c) in chains.items():
+                if kd in events:
+                    ch.configure(**events[kd])
+            waiting, applied = False, b
+        x = raw[:, pos:pos + nb_]
+        pg = f.process_host(x) if code is None else f.process_host_raw(x, code, s16_denominator=32768.0)
+        for (sidx, kd), (ch, c) in chains.items():
+            po = ch.process(iq[sidx, pos:pos + nb_])
+            assert pg[c].shape == po.shape, (b, c, pg[c].shape, po.shape)
+            e = rms(pg[c] - po)
+            worst = max(worst, e)
+            assert e <= 1e-5, (b, c, kinds[kd], e)
+        for c in range(nch):
+            assert np.array_equal(pg[c], pg[chains[(c % nst, kind_of[c])][1]]), (b, c)
+        pos += nb_
+    print("\n[promotion, %d channels of %d kinds on %d streams, rate %d, %s] setters at call %d, applied at call %s; worst call of any channel %.2e" % (nch, len(kinds), nst, rate, fmt, at_call, applied, worst))
+    assert applied is not None and applied - at_call <= 5
+
+
+def test_a_promoted_batch_goes_back_to_the_folded_filters(fmx_amd, ol):
+    """A batch that was promoted to the block machines (about seven times the folded filters' cost) goes back once its machines have been quiet for three
+    blocks of the input filter -- they are the LTI filters again, which the folded FIRs reproduce --: it keeps a block of its streams, runs the folded stage A
+    over it (the fm-rate ring's entries in flight, the filter history) and takes the d ring's tail through the de-emphasis (fmx_api.hip demote).  600 channels
+    on two streams, a new width for half of them; the handle is promoted within five calls, demoted within a dozen more (fmx_last_front_kernel says the
+    matrix-pipe kernel runs again), a second change is taken the same way -- with the block counters where the machines left them -- and EVERY call's PCM of both
+    halves stays within the tolerance of oracle chains taking the setters when the library says so."""
+    nch, block = 600, 16384 * 3
+    nb = 70
+    iq = np.stack([ol.synth_iq(nb * block, leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k) for k in range(2)])
+    f = _batch(fmx_amd, nch, 2, block)
+    chains = [ol.OracleChain(inputFilterBw=165000) for _ in range(2)]
+    plan = {8: (M.P_BANDWIDTH, "inputFilterBw", 130000), 38: (M.P_LF_CUTOFF, "lfCutoff", 12000)}
+    waiting, applied, kern, worst = None, {}, [], 0.0
+    for b in range(nb):
+        if b in plan:
+            pid_, key, v = plan[b]
+            for c in range(1, nch, 2):
+                f.set_param(pid_, v, c)
+            waiting = (b, {key: v})
+        if waiting is not None and f.filter_change_due() <= 0:
+            chains[1].configure(**waiting[1]); applied[waiting[0]] = b; waiting = None
+        x = iq[:, b * block:(b + 1) * block]
+        pg = f.process_host(x)
+        kern.append(f.last_front_kernel())
+        for k in range(2):
+            po = chains[k].process(x[k])
+            e = rms(pg[k] - po)
+            worst = max(worst, e)
+            assert e <= 1e-5, (b, k, e, kern)
+        assert all(np.array_equal(pg[c], pg[c % 2]) for c in range(2, nch))
+    print("\n[promotion and demotion, %d channels] setters at calls %s applied at %s; stage-A kernel per call: %s; worst call %.2e" % (nch, sorted(plan), applied, "".join(str(k) for k in kern), worst))
+    # folded (3) -> machines (1) -> folded (3) -> machines (1) -> folded (3)
+    runs = "".join(str(k) for k in kern)
+    import re as _re
+    assert _re.fullmatch(r"3+1+3+1+3+", runs), runs
+    assert all(applied[b_] - b_ <= 5 for b_ in applied) and len(applied) == 2
