@@ -106,11 +106,22 @@ template <int SH> __device__ __forceinline__ float dpp_row_shr(float v) {       
 // (fm-processor.cpp:462-464) -- and both halves taken from that value.
 __device__ __forceinline__ void split2(float x0, float x1, float sc, uint32_t *hi, uint32_t *lo) {
     float a = x0 * sc, b = x1 * sc;
+#ifndef F4_SPLIT_PLAIN
+    // five instructions per pair: the two products, ONE packed conversion for the stored halves, and the remainders straight from the f32 products and the
+    // packed halves by the mixed-precision fma (a * 1.0 - (f32) half, rounded to f16: the difference itself is exact in f32)
+    uint32_t h, l;
+    asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+                 "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+                 "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                 : "=&v"(h), "=&v"(l) : "v"(a), "v"(b));
+    *hi = h; *lo = l;
+#else
     asm volatile("" : "+v"(a), "+v"(b));
     const h16 ha = (h16)a, hb = (h16)b;
     const h16 la = (h16)(a - (float)ha), lb = (h16)(b - (float)hb);
     *hi = __builtin_bit_cast(uint32_t, (v2h){ha, hb});
     *lo = __builtin_bit_cast(uint32_t, (v2h){la, lb});
+#endif
 }
 
 #ifndef F4_ABL
