@@ -133,9 +133,11 @@ typedef enum {
                                   is -- nothing is clamped, weak signals keep 22 bits.  (Limit: two adjacent tiles of one channel whose
                                   largest samples differ by more than 2^126.)  The IQ balance is applied in front of the filter, where the
                                   reference has it (fm-processor.cpp:462-464).
-                                  3 takes the whole 1536-sample tiles of the calls it can -- any sample format, no local oscillator on
-                                  any channel, the input filter on everywhere, a balance between 1e-6 and 1e6 in magnitude, a call that
-                                  starts on a multiple of 12 samples -- and leaves the rest to kernel 1.  (2 was round 5's six-wave VALU
+                                  3 takes the whole 1536-sample tiles of the calls it can -- any sample format, the input filter on
+                                  everywhere, a balance between 1e-6 and 1e6 in magnitude, a call that starts on a multiple of 12 samples --
+                                  and leaves the rest to kernel 1.  A handle with LOCAL OSCILLATORS runs the kernel's complex-tap variant
+                                  (the mix folded into a tap set per channel built from the reference's own oscillator table; one channel
+                                  per workgroup: automatic for handles with at least one channel per compute unit).  (2 was round 5's six-wave VALU
                                   kernel: measured slower, now tools/experiments/fmx_front3.hip; the value is refused.)
                                   0 = automatic (default): 3 where a handle qualifies and has the channels to fill the GPU, else 1. */
     FMX_P_SCOPE_TAPS = 26,     /* (handle-wide: the channel argument is ignored) whether the DISPLAY FEEDS are produced: the three scope taps that are rows

@@ -15,6 +15,7 @@ LIB = os.path.join(LIBDIR, "libfmx.so")
 SOURCES = [
     ("fmx_front.hip", []),
     ("fmx_front4.hip", []),
+    ("fmx_front4lo.hip", []),
     ("fmx_demod.hip", ["-ffp-contract=off"]),
     ("fmx_stageb.hip", ["-ffp-contract=off"]),
     ("fmx_audio.hip", []),
@@ -43,6 +44,7 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(CSRC, "fmx_front4.hip"))          # (fmx_front4lo.hip is this source compiled a second time)
     headers.append(os.path.join(os.path.dirname(HERE), "include", "fmx.h"))
     objs = []
     cc = hipcc()

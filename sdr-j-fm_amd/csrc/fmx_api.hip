@@ -126,6 +126,8 @@ struct fmx_handle_s {
     bool taps_kept = true;               // the last call kept the scope-tap rows (fmx_get_tap)
     float *w_diff_mem = nullptr;         // the LR scope tap's rows (allocated when first wanted; DeviceBuffers::w_diff is null while the tap is off)
     bool front4_ok = false;              // every channel qualifies for front4_kernel (flush_mailbox)
+    bool front4_lo = false;              // ... and some channel has a local oscillator: the complex-tap variant (fmx_front4lo.hip)
+    std::vector<std::pair<int32_t, int32_t>> hlo_key;   // per channel: the (bandwidth, oscillator) its ChanParams::hlo_* were computed for
     int last_front_kernel = 1;           // what the last call's stage A was given (FMX_P_FRONT_KERNEL numbering): fmx_last_front_kernel
     // a batch call whose channels need the demodulator pre-pass (a lone wave per 64 channels walking the call sample by sample: 6 % of the chip for
     // most of the call's time) is made in pieces whose stages overlap: run_call
@@ -801,8 +803,9 @@ int flush_mailbox(fmx_handle h) {
     for (auto &p : h->params) any_lo |= (p.lo_freq != 0);
     if (any_lo) { int rc = ensure_lo_table(h); if (rc) return rc; }
     {
-        // stage A on the matrix pipe (fmx_front4.hip): no LO on any channel, every tap set the long fold with its RfDC taken 12 columns back
-        bool ok = !any_lo && h->twins == 1 && !h->ola_mode;
+        // stage A on the matrix pipe (fmx_front4.hip): every tap set the long fold with its RfDC taken 12 columns back; a handle with a local oscillator somewhere
+        // runs the complex-tap variant (fmx_front4lo.hip)
+        bool ok = h->twins == 1 && !h->ola_mode;
         for (auto &p : h->params) { if (!ok) break; ok = h->h_front_sets[(size_t)p.front_set].nd > 4; }
         // front4_kernel applies the IQ balance in front of its filter together with the tile's scale and takes the RF DC recurrence's column sums back
         // through 1 / balance: a balance of 0 (the slider's end, radio.cpp:989-995) or one no slider produces goes to front_kernel's per-sample pass
@@ -811,7 +814,32 @@ int flush_mailbox(fmx_handle h) {
             const float al = std::fabs(p.att_l), ar = std::fabs(p.att_r);
             ok = h->h_front_sets[(size_t)p.front_set].dc_k == 12 && al >= 1e-6f && al <= 1e6f && ar >= 1e-6f && ar <= 1e6f;
         }
-        h->front4_ok = ok;
+        h->front4_ok = ok; h->front4_lo = any_lo;
+        if (ok && any_lo) {
+            // the sum of a channel's complex taps, Hlo = sum_m G [m] e^(j 2 pi ((m lo) mod R) / R): what the filter makes of the RF DC value (fmx_front4.hip)
+            // (computed when a channel's tap set or oscillator changes, not per call: 300 sine / cosine pairs per channel)
+            const int R = h->cfg.inputRate;
+            h->hlo_key.resize(h->params.size(), std::make_pair(-1, 0x7fffffff));
+            for (size_t ci = 0; ci < h->params.size(); ci++) {
+                ChanParams &p = h->params[ci];
+                const std::pair<int32_t, int32_t> key(h->front_keys[(size_t)p.front_set / (size_t)h->twins], p.lo_freq);
+                if (h->hlo_key[ci] == key) continue;
+                h->hlo_key[ci] = key;
+                const FrontSet &fs = h->h_front_sets[(size_t)p.front_set];
+                const float *tz = &h->h_front_taps[(size_t)p.front_set * A_TAPS_STRIDE];
+                double hr = 0, hi = 0;
+                for (int d = 0; d < A_MAX_ND; d++)
+                    for (int r = 0; r < DECIM; r++) {
+                        const int m = 12 * d + fs.off - r;
+                        if (m < 0) continue;
+                        const int64_t ph = (((int64_t)m * p.lo_freq) % R + R) % R;
+                        const double g = (double)tz[(d + 1) * DECIM + r], a = 2.0 * design::kPi * (double)ph / (double)R;
+                        hr += g * std::cos(a); hi += g * std::sin(a);
+                    }
+                const float fr = (float)hr, fi = (float)hi;
+                if (fr != p.hlo_re || fi != p.hlo_im) { p.hlo_re = fr; p.hlo_im = fi; h->params_dirty = true; }
+            }
+        }
     }
     bool any_rds = false;
     h->call_rds_mode.resize((size_t)h->channels);
@@ -1108,7 +1136,9 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
         // automatic: the filter on the matrix pipe wherever a handle qualifies and has the channels to fill the chip without splitting them in time
         // (measured at 4096 channels on one box: 1.52 ms per launch against 1.75 for the four-wave kernel and 1.84 for the six-wave VALU kernel, which
         // both sit at the packed-FMA power limit)
-        if (h->front4_ok && (fk == 3 || (fk == 0 && G.parts <= 1))) { G.parts = 1; G.front4 = 1; }
+        // (the complex-tap variant runs one channel per workgroup: a handle of one channel per compute unit fills the chip)
+        if (h->front4_ok && !h->front4_lo && (fk == 3 || (fk == 0 && G.parts <= 1))) { G.parts = 1; G.front4 = 1; }
+        if (h->front4_ok && h->front4_lo && (fk == 3 || (fk == 0 && h->channels >= h->n_cus))) { G.parts = 1; G.front4 = 2; }
         // (what is reported is what runs: a call without a whole tile on the kernel's grid goes to front_kernel in launch_front)
         h->last_front_kernel = (G.front4 && front4_tiles(G, d_iq) > 0) ? 3 : 1;
     }

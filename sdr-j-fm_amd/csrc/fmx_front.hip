@@ -766,7 +766,7 @@ void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
         const int k = front4_tiles(G, iq);
         if (k > 0) {
             CallGeom G3 = G; G3.n = (int64_t)k * WSAMP; G3.parts = 1;
-            launch_front4(T, B, G3, iq, channels, s);
+            if (G.front4 == 2) launch_front4_lo(T, B, G3, iq, channels, s); else launch_front4(T, B, G3, iq, channels, s);
             if (G3.n == G.n) return;
             CallGeom G2 = G; G2.front4 = 0; G2.cont = 1; G2.parts = 1; G2.g0 = G.g0 + G3.n; G2.n = G.n - G3.n;
             const size_t bps = (G.iq_format == 0) ? 8 : (G.iq_format == 3 ? 4 : 2);

@@ -44,13 +44,27 @@
 #include "fmx_internal.h"
 #include "fmx_front_dc.h"
 
-namespace fmx {
-namespace f4 {
-
-#ifndef F4_NW
-#define F4_NW 6        /* (12 waves on ONE channel per workgroup, -DF4_NW=12 -DF4_CPW=1: the same time per launch) */
+// This source is compiled TWICE (round 6): as it stands -- namespace f4, six waves per channel and two channels per workgroup, real taps: the headline's
+// kernel -- and from fmx_front4lo.hip with F4_LO = 1 -- namespace f4lo, TWELVE waves on ONE channel per workgroup (the same LDS, room for two more tap
+// tables; 256 channels are one workgroup per CU), for handles with LOCAL OSCILLATORS: BASELINE configs[2], 256 carriers in 24 wide-band streams.  There the mix
+// v[n] = x'[n] LO[n] (fm-processor.cpp:466, oscillator.cpp:49-58: LO[n] = table[(P0 - (n + 1) lo) mod R], so LO[n - m] = LO[n] table[(m lo) mod R]) leaves
+// the samples alone and goes into the TAPS:
+//     z[q] = cg sum_m G[m] v[n - m]  =  cg LO[n] sum_m (G[m] table[(m lo) mod R]) x'[n - m],     n = 12 q + off,
+// a complex tap set per channel (built here, once per launch, from the real one and the reference's own oscillator table) against the UNROTATED
+// samples -- twice the matrix instructions, which the stage has to spare, and nothing per sample: the scatter, the f16 split, the RF DC column sums are the
+// real-tap kernel's.  The output takes the oscillator's value at its newest sample (four table entries per lane and tile); the RF DC term the reference
+// subtracts in front of the mix becomes (c att) sum_m Gc[m] = (c att) Hlo, Hlo a complex constant of the channel (ChanParams::hlo_*, host side).
+#ifndef F4_NS
+#define F4_NS f4
+#define F4_NW 6        /* (12 waves on ONE channel per workgroup, F4_NW = 12, F4_CPW = 1: the same time per launch) */
 #define F4_CPW 2
+#define F4_LO 0
+#define F4_FN(name) name
 #endif
+namespace fmx {
+namespace F4_NS {
+
+constexpr bool LO = F4_LO != 0;                // complex taps for channels with a local oscillator
 constexpr int NW = F4_NW;                      // waves (= ring slots) per channel
 constexpr int CPW = F4_CPW;                    // channels per workgroup
 constexpr int NTHR = 64 * NW * CPW;
@@ -136,11 +150,12 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
     constexpr int BPS = (FMT == 0) ? 8 : (FMT == 3 ? 4 : 2);          // bytes per complex sample
     struct ChanLds {
         h16 pl[4][PL];                     // hi re, hi im, lo re, lo im of the channel's newest six tiles (and the mirror)
-        h16 ta[3][TA_N];                   // reversed tap table: hi, lo, and the boxcar of ones that sums a column
+        h16 ta[LO ? 5 : 3][TA_N];          // reversed tap table: hi, lo, and the boxcar of ones that sums a column; LO: the taps' imaginary parts, hi and lo
+        float2 hb[LO ? 28 : 1];            // LO, a call's last tile: RfDC in front of its columns 103 .. 128 (the processed history the next call finds)
         float2 mb[8][MB_N];                // RfDC boundaries behind tile ti, slot = ti & 7
         int carry_seq;                     // tiles whose mailbox slot is published
         int scat_seq[NW], fir_seq[NW];     // per wave: tiles scattered / tiles whose filter has read everything, + 1
-        int texp[8];                       // biased exponent (bfp_E) of the scale of the tile in ring slot w (written with the slot, read by the next tile's filter
+        int texp[NW + 2];                     // biased exponent (bfp_E) of the scale of the tile in ring slot w (written with the slot, read by the next tile's filter
                                            // like the slot's last 288 samples: the same counters order both); [NW]: of the call's history
         int pad_[3];
     };
@@ -185,20 +200,42 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 const int r = ((off - m) % DECIM + DECIM) % DECIM, d = (m - off + r) / DECIM;
                 if (d < A_MAX_ND) g = T.front_taps[(size_t)P.front_set * A_TAPS_DEV + r * A_TAPS_ROW + d];
             }
-            const float gs = g * TSC;
+            float gs = g * TSC;
+            if constexpr (LO) {
+                // Gc[m] = G[m] table[(m lo) mod R]: the oscillator's value m samples back, relative to its value at the newest sample
+                float gi = 0.f;
+                if (P.lo_freq != 0 && T.lo_table != nullptr && m >= 0) {
+                    long long ph = ((long long)m * (long long)P.lo_freq) % (long long)G.input_rate;
+                    if (ph < 0) ph += G.input_rate;
+                    const float2 w = T.lo_table[ph];
+                    gi = gs * w.y; gs = gs * w.x;
+                }
+                const h16 ih = (h16)gi;
+                L.ta[3][u] = ih;
+                L.ta[4][u] = (h16)(gi - (float)ih);
+            }
             const h16 gh = (h16)gs;
             L.ta[0][u] = gh;
             L.ta[1][u] = (h16)(gs - (float)gh);
             L.ta[2][u] = (m >= off - (DECIM - 1) && m <= off) ? (h16)1.0f : (h16)0.0f;      // the 12 samples of the output's own column
         }
     }
+    const int lo = LO ? P.lo_freq : 0;
+    const bool mix = LO && lo != 0 && T.lo_table != nullptr;       // this channel's oscillator runs (the same for the whole workgroup half)
+    const int Rr = G.input_rate;
+    // oscillator table index at call-relative sample s: (P0 - (s + 1) lo) mod R
+    auto lo_idx = [&](long long s_rel, int P0) -> int {
+        long long ph = ((long long)P0 - (s_rel + 1) * (long long)lo) % (long long)Rr;
+        if (ph < 0) ph += Rr;
+        return (int)ph;
+    };
     if (t == 0) { carry_seq = 0; for (int i = 0; i < NW; i++) { scat_seq[i] = 0; fir_seq[i] = 0; } }
     // ---- the call's history (raw samples, or what front_kernel's conversions make of them: see there) -> the mirror in front of ring slot 0
     const bool dc_rst = (P.actions & ACT_DC_RESET) != 0;           // setDCRemove zeroes RfDC (:922-925)
     const int hist_fmt0 = st->hist_fmt, lo_phase0 = st->lo_phase;
     const float st_dc_re = st->dc_re, st_dc_im = st->dc_im;
     const float2 R0 = (T.lo_table != nullptr && lo_phase0 != 0) ? T.lo_table[lo_phase0] : make_float2(1.f, 0.f);   // an oscillator set back to 0 Hz keeps its phase
-    const bool hist_to_raw = (hist_fmt0 == 1);                     // the LO was switched off in front of this call
+    const bool hist_to_raw = (hist_fmt0 == 1) && !mix;             // the LO was switched off in front of this call
     const bool hist_rst = (hist_fmt0 == 0) && dc_rst;
     const bool dcr = P.dc_remove != 0;
     const float2 dc_now = (dc_rst || !dcr) ? make_float2(0.f, 0.f)
@@ -215,6 +252,23 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
             float2 v = make_float2(0.f, 0.f);
             if (i < DECIM * A_HIST_COLS && c != HL) {              // (c == HL: the partial column of a call that starts inside one: never here)
                 v = hist[i];
+                if (mix) {
+                    // A running oscillator: the reference's filter memory holds p = ((x - RfDC) att) LO [s] of every history sample -- what front_kernel keeps for
+                    // such a channel (hist_fmt 1), and what a history of raw samples (hist_fmt 0: the oscillator stood at R0 while they came) amounts to with
+                    // R0 in LO's place.  The complex taps turn every sample of the window by the oscillator's own steps, so the sample that stands for p here is
+                    // x_eq = (p conj (LO [s])) / att + RfDC now.
+                    float2 p = v;
+                    if (hist_fmt0 != 1) {
+                        const int tb = c - HL + 13;
+                        const float2 d = dcvR[tb < 0 ? 0 : tb];
+                        const bool sub = dcr || dc_rst;           // (as front_kernel's conversion: the boundaries saved with the history)
+                        const float qx = (v.x - (sub ? __builtin_amdgcn_fmed3f(d.x, -0.01f, 0.01f) : 0.f)) * P.att_l;
+                        const float qy = (v.y - (sub ? __builtin_amdgcn_fmed3f(d.y, -0.01f, 0.01f) : 0.f)) * P.att_r;
+                        p = make_float2(qx * R0.x - qy * R0.y, qx * R0.y + qy * R0.x);
+                    }
+                    const float2 w = T.lo_table[lo_idx((long long)(DECIM * (c - HL) + r), lo_phase0)];
+                    v = make_float2((p.x * w.x + p.y * w.y) / P.att_l + dc_now.x, (p.y * w.x - p.x * w.y) / P.att_r + dc_now.y);
+                } else
                 if (hist_rst) {
                     const int tb = c - HL + 13;
                     const float2 d = dcvR[tb < 0 ? 0 : tb];
@@ -247,7 +301,7 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
         if (lane == 0) L.texp[NW] = Eh;
     }
     // RfDC in front of the 13 columns before this call's first column and of that column itself
-    if (t < 14) mb[7][t] = (hist_to_raw || hist_rst) ? make_float2(dc_rst ? 0.f : st_dc_re, dc_rst ? 0.f : st_dc_im) : dcvR[t];
+    if (t < 14) mb[7][t] = (hist_to_raw || hist_rst || mix) ? make_float2(dc_rst ? 0.f : st_dc_re, dc_rst ? 0.f : st_dc_im) : dcvR[t];
     const float dc0r = dc_rst ? 0.f : st_dc_re, dc0i = dc_rst ? 0.f : st_dc_im;
     __syncthreads();                                  // the only workgroup barrier: tables, history and counters are set up
 
@@ -255,10 +309,20 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const int kg = lane >> 4, n = lane & 15, blk = n >> 1, comp = n & 1;
     const int c0col = 16 * blk + 4 * kg;              // the lane's first output column in the tile
     const float alpha = 1.0f / (float)G.input_rate;   // rfDcAlpha fm-processor.cpp:379
-    const float cg_re = (FS.gain_re * R0.x - FS.gain_im * R0.y), cg_im = (FS.gain_re * R0.y + FS.gain_im * R0.x);     // complex output gain x R0
+    const float2 R0g = mix ? make_float2(1.f, 0.f) : R0;          // (a running oscillator's value rides with every output, below)
+    const float cg_re = (FS.gain_re * R0g.x - FS.gain_im * R0g.y), cg_im = (FS.gain_re * R0g.y + FS.gain_im * R0g.x);     // complex output gain x R0
     const float kown = cg_re, kpar = comp ? cg_im : -cg_im;       // z = a_own kown + a_partner kpar
+    const float sgn = comp ? 1.0f : -1.0f;
+    // the oscillator's table index at the newest sample of the lane's first output of the wave's first tile, and its steps per column and per round of tiles
+    int ph_q0 = 0, ph_step12 = 0, ph_stepT = 0;
+    if (LO && mix) {
+        ph_q0 = lo_idx((long long)(DECIM * (wave * WCOLS + c0col) + off), lo_phase0);
+        ph_step12 = (int)((((long long)DECIM * lo) % Rr + Rr) % Rr);
+        ph_stepT = (int)((((long long)NW * WSAMP * lo) % Rr + Rr) % Rr);
+    }
     const float bal = comp ? P.att_r : P.att_l;                   // IQ balance :462-464: applied with the tile's scale, in front of the filter
     const float ibal = 1.0f / bal;                                // (the column sums of the RF DC recurrence are wanted without it)
+    const float hlo_re = (LO && mix) ? P.hlo_re * bal : 0.f, hlo_im = (LO && mix) ? P.hlo_im : 0.f;      // (sum of the complex taps; the own component's balance folded in)
     const float hsum = FS.hsum * bal, dcw = FS.dc_w;              // what the filter makes of a constant that is balanced like the samples
     // the RF DC recurrence over a tile (first order in alpha inside it, as front_kernel's fast path; the decay of the state over the tile and of
     // the samples' weights towards its end to third / second order: relative errors below 1e-10)
@@ -369,7 +433,7 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
         __builtin_amdgcn_wave_barrier();              // LDS operations of one wave complete in order
         if (lane == 0) seq_post(&scat_seq[wave], ti + 1);
         // ---- prefetch this wave's next tile as soon as the registers are free: the loads are in flight for the whole iteration
-        if (ti + NW < NT && !(F4_ABL & 8)) load_tile(ti + NW);
+        if (!LO && ti + NW < NT && !(F4_ABL & 8)) load_tile(ti + NW);        // (LO: behind the filter, whose second set of accumulators needs the registers)
         // ---- the previous tile's newest 288 samples are this tile's history (tile 0: the call's, put there in front of the barrier)
         if (ti > 0) seq_wait(&scat_seq[pw], ti);
         // the first two column blocks' windows begin in the previous tile (K-steps 0 .. 8 of block 0, 0 .. 2 of block 1): where its scale is
@@ -381,6 +445,8 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
 
         // ---- the filter: D[i][n] += A[i][k] B[k][n] over the 480 samples of the window, three (four) f16 terms; the column sums beside it
         v4f ahh = (v4f){0.f, 0.f, 0.f, 0.f}, ahl = ahh, alh = ahh, asum = ahh;
+        v4f bhh = ahh, bhl = ahh, blh = ahh;          // LO: the same against the taps' imaginary parts
+
         if (!(F4_ABL & 4)) {
 #pragma unroll
             for (int j = 0; j < KSTEPS; j++) {
@@ -401,21 +467,51 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
                     asum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ao, Bh, asum, 0, 0, 0);
                     asum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ao, Bl, asum, 0, 0, 0);
                 }
-                if (rescale && j == 2) { ahh *= rt2; ahl *= rt2; alh *= rt2; }
-                if (rescale && j == 8) { ahh *= rt8; ahl *= rt8; alh *= rt8; }
+                if constexpr (LO) {
+                    if (mix) {
+                        const u32x2 i0 = *reinterpret_cast<const u32x2 *>(aB + 64 * j + 6 * TA_N), i1 = *reinterpret_cast<const u32x2 *>(aB + 64 * j + 6 * TA_N + 8);
+                        const u32x2 m0 = *reinterpret_cast<const u32x2 *>(aB + 64 * j + 8 * TA_N), m1 = *reinterpret_cast<const u32x2 *>(aB + 64 * j + 8 * TA_N + 8);
+                        const v8h Ih = __builtin_bit_cast(v8h, (u32x4){i0.x, i0.y, i1.x, i1.y}), Il = __builtin_bit_cast(v8h, (u32x4){m0.x, m0.y, m1.x, m1.y});
+                        bhh = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ih, Bh, bhh, 0, 0, 0);
+                        bhl = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ih, Bl, bhl, 0, 0, 0);
+                        blh = __builtin_amdgcn_mfma_f32_16x16x32_f16(Il, Bh, blh, 0, 0, 0);
+                    }
+                }
+                if (rescale && j == 2) { ahh *= rt2; ahl *= rt2; alh *= rt2; if (LO) { bhh *= rt2; bhl *= rt2; blh *= rt2; } }
+                if (rescale && j == 8) { ahh *= rt8; ahl *= rt8; alh *= rt8; if (LO) { bhh *= rt8; bhl *= rt8; blh *= rt8; } }
             }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) seq_post(&fir_seq[wave], ti + 1);           // this slot's predecessor may take its owner's next tile
+        if (LO && ti + NW < NT && !(F4_ABL & 8)) load_tile(ti + NW);
+        // LO: the oscillator's values at the newest samples of the lane's four outputs (requested behind the filter, whose registers they would crowd;
+        // wanted behind the RF DC recurrence)
+        float2 Wq[4];
+        if constexpr (LO) {
+            if (mix) {
+                int ph = ph_q0;
+#pragma unroll
+                for (int v = 0; v < 4; v++) { Wq[v] = T.lo_table[ph]; ph -= ph_step12; ph += ph < 0 ? Rr : 0; }
+                ph_q0 -= ph_stepT; ph_q0 += ph_q0 < 0 ? Rr : 0;
+            }
+        }
         float a[4];
         const float osc = bfp_out(Et);
 #pragma unroll
         for (int v = 0; v < 4; v++) a[v] = (ahh[v] + (ahl[v] + alh[v])) * osc;
+        if constexpr (LO) {
+            if (mix) {
+                // complex taps: the real part's lane has Gr * xr and Gi * xr, its partner Gr * xi and Gi * xi:  S.re = Gr xr - Gi xi,  S.im = Gr xi + Gi xr
+#pragma unroll
+                for (int v = 0; v < 4; v++) a[v] = fmaf(sgn, dpp_swap1((bhh[v] + (bhl[v] + blh[v])) * osc), a[v]);
+            }
+        }
 
         // ---- RF DC removal (fm-processor.cpp:423-446) behind the filter, as front_kernel does it for channels without an LO -- here in the
         //      accumulator layout: the lane has the sums of its four columns (of its component), the exclusive prefix over the tile's 128 columns
         //      comes from two cross-row exchanges and a three-step row scan, the state in front of the tile from the previous tile's mailbox slot
         float c_out_r = dc0r, c_out_i = dc0i;
+        float rr[4] = {0.f, 0.f, 0.f, 0.f};           // RfDC in front of the lane's four columns
         if (dcr && !(F4_ABL & 2)) {
             const float isc = bfp_inv(Et) * ibal;                 // (the sums of the raw samples: RfDC runs in front of the balance)
             const float S0 = asum[0] * isc, S1 = asum[1] * isc, S2 = asum[2] * isc, S3 = asum[3] * isc;
@@ -443,8 +539,6 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
             if (ti > 0) { const float2 cc = mp[13]; c0r = cc.x; c0i = cc.y; }
             c_out_r = dc_chain(c0r, u_tile, alpha * W_re); c_out_i = dc_chain(c0i, u_tile, alpha * W_im);
             const float c0 = comp ? c0i : c0r;
-            // RfDC in front of the lane's four columns
-            float rr[4];
             {
                 const float P0 = pre0, P1 = pre0 + S0, P2 = pre0 + e2, P3 = pre0 + e3;
                 const float base = (float)(DECIM * c0col) * alpha;
@@ -471,14 +565,25 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const float d = fmaf(dcw, E[v + 1] - E[v], E[v]);
-                a[v] = fmaf(-hsum, __builtin_amdgcn_fmed3f(d, -0.01f, 0.01f), a[v]);
+                const float dl = __builtin_amdgcn_fmed3f(d, -0.01f, 0.01f);
+                if (LO && mix) {
+                    // (c att) Hlo, complex: own component D Hr -+ partner's D Hi (hlo_re carries the own component's balance; the partner's its own)
+                    const float dp = dpp_swap1(dl * bal);
+                    a[v] = a[v] - (dl * hlo_re + sgn * (dp * hlo_im));
+                } else a[v] = fmaf(-hsum, dl, a[v]);
             }
         }
         // ---- the decimators' complex gain, the fm-rate ring: the lane of the real part stores the quad's first two outputs,
         //      the lane of the imaginary part the other two
         float z[4];
 #pragma unroll
-        for (int v = 0; v < 4; v++) z[v] = fmaf(dpp_swap1(a[v]), kpar, a[v] * kown);
+        for (int v = 0; v < 4; v++) {
+            if (LO && mix) {
+                // z = (cg LO [n]) S: the output gain turned by the oscillator's value at the output's newest sample
+                const float wr = cg_re * Wq[v].x - cg_im * Wq[v].y, wi = cg_re * Wq[v].y + cg_im * Wq[v].x;
+                z[v] = fmaf(dpp_swap1(a[v]), sgn * wi, a[v] * wr);
+            } else z[v] = fmaf(dpp_swap1(a[v]), kpar, a[v] * kown);
+        }
         const float k0 = comp ? z[2] : z[0], k1 = comp ? z[3] : z[1];       // what the lane keeps ...
         const float g0 = comp ? z[0] : z[2], g1 = comp ? z[1] : z[3];       // ... and what its partner stores
         const float r0 = dpp_swap1(g0), r1 = dpp_swap1(g1);
@@ -496,17 +601,51 @@ __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3)))
         // ---- last tile: the state the next call finds (front_kernel's format)
         if (ti == NT - 1) {
             if (lane == 0 && (dcr || dc_rst)) { st->dc_re = c_out_r; st->dc_im = c_out_i; }
-            if (lane == 0) st->hist_fmt = 0;
+            if (lane == 0) st->hist_fmt = mix ? 1 : 0;
             __builtin_amdgcn_wave_barrier();
             if (lane < 14) B.dcv_hist[(size_t)ch * DCV_SAVE + lane] = dcr ? mb[ti & 7][lane] : make_float2(dc0r, dc0i);
+            if constexpr (LO) {
+                if (mix) {
+                    // A running oscillator: the next call finds the history PROCESSED, p = ((x - RfDC) att) LO [s] per sample, as front_kernel keeps it for such a
+                    // channel (hist_fmt 1) -- whichever kernel takes the next call reads the same thing.  RfDC behind sample 12 c + r from the boundaries of
+                    // columns c and c + 1 (it moves by 1e-6 of |x| within a column: linear to 1e-9); the samples are the raw ones this wave stored behind
+                    // its scatter, converted in place.
+                    float *hbf = reinterpret_cast<float *>(&L.hb[0]);
+                    if (blk >= 6) {
+#pragma unroll
+                        for (int v = 0; v < 4; v++) { const int c = c0col + v; if (c >= 103) hbf[2 * (c - 103) + comp] = rr[v]; }
+                    }
+                    if (lane == 0) L.hb[25] = make_float2(c_out_r, c_out_i);
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();            // (the raw history this wave stored behind its scatter is read back here, converted in place)
+                    constexpr int HQ2 = (DECIM * A_HIST_COLS + 63) / 64;
+#pragma unroll
+                    for (int q = 0; q < HQ2; q++) {
+                        const int i = lane + 64 * q;
+                        const int r = i / A_HIST_COLS, c = i - r * A_HIST_COLS;          // history column c = the tile's column 104 + c
+                        if (i < DECIM * A_HIST_COLS && c != HL) {
+                            const float2 x = hist[i];
+                            const float2 b0 = L.hb[c + 1], b1 = L.hb[c + 2];
+                            const float fr = (float)(r + 1) * (1.0f / 12.0f);
+                            const float cr_ = dcr ? __builtin_amdgcn_fmed3f(fmaf(fr, b1.x - b0.x, b0.x), -0.01f, 0.01f) : 0.f;
+                            const float ci_ = dcr ? __builtin_amdgcn_fmed3f(fmaf(fr, b1.y - b0.y, b0.y), -0.01f, 0.01f) : 0.f;
+                            const float xr = (x.x - cr_) * P.att_l, xi = (x.y - ci_) * P.att_r;
+                            const float2 w = T.lo_table[lo_idx((long long)G.n - HS + DECIM * c + r, lo_phase0)];
+                            hist[i] = make_float2(xr * w.x - xi * w.y, xr * w.y + xi * w.x);
+                        }
+                    }
+                    if (lane == 0) st->lo_phase = lo_idx((long long)G.n - 1, lo_phase0);       // LOPhase behind the call's last sample: (P0 - n lo) mod R
+                }
+            }
         }
     }
 }
 
-}  // namespace f4
+}  // namespace F4_NS
 
 // The calls front4_kernel takes (launch_front asks): whole tiles, on a column boundary, float32 samples 16-byte aligned.  The per-channel
 // conditions -- no LO anywhere, every tap set the long fold with its RfDC taken 12 columns back, one twin -- are the handle's (fmx_api.hip).
+#if !F4_LO
 int front4_tiles(const CallGeom &G, const void *iq) {
     if (G.iq_format < 0 || G.iq_format > 3 || G.twins != 1 || G.pre_processed || G.parts > 1) return 0;
     const int bps = (G.iq_format == 0) ? 8 : (G.iq_format == 3 ? 4 : 2);
@@ -514,7 +653,9 @@ int front4_tiles(const CallGeom &G, const void *iq) {
     if ((G.g0 % DECIM) != 0 || (G.stream_stride & 1) != 0 || (reinterpret_cast<uintptr_t>(iq) & (uintptr_t)(2 * bps - 1)) != 0) return 0;
     return (int)(G.n / f4::WSAMP);
 }
-void launch_front4(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels, hipStream_t s) {
+#endif
+void F4_FN(launch_front4)(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels, hipStream_t s) {
+    namespace f4 = F4_NS;
     const dim3 grid((channels + f4::CPW - 1) / f4::CPW);
     switch (G.iq_format) {
     case 1: hipLaunchKernelGGL((f4::front4_kernel<1, false>), grid, dim3(f4::NTHR), 0, s, T, B, G, iq); break;

@@ -71,6 +71,8 @@ struct ChanParams {
     int32_t test_tone;      // setTestTone fm-processor.cpp:931-933
     float   squelch_nthr;   // noiseSquelchThreshold squelchClass.cpp:36
     float   deemph_l2;      // log2 (1.0f - deemph_alpha) (fused stage B: scan weights)
+    float   hlo_re, hlo_im; // a channel with a local oscillator on the matrix-pipe input filter (fmx_front4lo.hip): the sum of its complex taps, sum_m G [m] table [(m lo) mod R]
+                            // -- what the filter makes of the RF DC value the reference subtracts in front of the mix; (hsum, 0) without an oscillator
     int32_t pll_seq;        // FMX_P_PLL_SOLVER resolved on the host: 1 the pilot PLL of this channel is evaluated sample by sample in every segment;
                             // 0 Newton's method on the segment while the pilot is comfortably in lock, sample by sample otherwise (PLL_GUARD in
                             // fmx_stageb.hip: the lock decisions are then taken on the reference's own trajectory); 2 Newton's method always (diagnostic)
@@ -227,7 +229,8 @@ struct CallGeom {
     int32_t no_deemph;       // channel, no RF DC removal, balance or LO mix here, history always raw, no front-end state written.  no_deemph: stage B
                              // writes the stereo pair to the d ring as it is: the audio low-pass (a block machine then) comes first, deemph_kernel behind it
     int32_t streams;         // IQ streams of the handle
-    int32_t front4;          // stage A: != 0 the handle runs front4_kernel (fmx_front4.hip: the filter on the matrix pipe; no LO anywhere, every tap set the
+    int32_t front4;          // stage A: != 0 the handle runs front4_kernel (fmx_front4.hip: the filter on the matrix pipe; 2: its complex-tap variant for handles with
+                             // local oscillators, fmx_front4lo.hip; every tap set the
                              // long fold with RfDC taken 12 columns back); launch_front gives it the whole tiles of a call that starts on a column
                              // boundary, front_kernel the remainder and everything else
     int32_t cont;            // front_kernel: this launch continues a call whose head another launch has made (the one-shot actions are done)
@@ -404,6 +407,8 @@ void launch_front(const DeviceTables &T, const DeviceBuffers &B, const CallGeom 
 // fmx_front4.hip: whole tiles of the call front4_kernel can take (0: none), and its launch over that many
 int front4_tiles(const CallGeom &G, const void *iq);
 void launch_front4(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels, hipStream_t s);
+// fmx_front4lo.hip: the same kernel with complex taps, one channel per workgroup (CallGeom::front4 == 2: some channel of the handle has a local oscillator)
+void launch_front4_lo(const DeviceTables &T, const DeviceBuffers &B, const CallGeom &G, const void *iq, int channels, hipStream_t s);
 // The FMX_* environment switches (diagnostics and A/B runs of one build; none is needed by a user): read ONCE, by the first fmx_create of the process --
 // nothing on the per-call path asks the environment.
 struct EnvSwitches {

@@ -197,6 +197,7 @@ def test_full_size_config3_shared_wideband_streams(fmx_amd, ol):
     iq = np.stack([contents[s % 3] for s in range(S)])          # [24, n, 2]
     pcm = np.concatenate([f.process_host(iq[:, i * block:(i + 1) * block]) for i in range(calls)], axis=1)
     assert pcm.shape[0] == C
+    assert f.last_front_kernel() == 3          # (round 6: the input filter on the matrix pipe with complex taps, fmx_front4lo.hip: one channel per compute unit)
     # (i) duplicates: channel c against the channel of stream (s % 3) with the same carrier index
     ref_of = {}
     for c in range(C):

@@ -247,7 +247,8 @@ def test_front4_large_samples_are_linear_and_bad_ones_stay_in_their_channel(fmx_
 def test_front_kernel_choice(fmx_amd, ol):
     """The automatic choice of the input-filter kernel (fmx_last_front_kernel): the matrix-pipe kernel for a handle that fills the GPU without
     splitting its channels in time, has no local oscillator and the input filter on everywhere, for calls on the 12-sample grid that hold a
-    whole tile; front_kernel otherwise."""
+    whole tile; front_kernel otherwise.  (Round 6: a handle with local oscillators runs the kernel's complex-tap variant, one channel per workgroup, when it has
+    a channel per compute unit.)"""
     T = 1536
     x = ol.synth_iq(64 * T + 5)
     def run(nch, setup, n=4 * T, pre=0):
@@ -264,7 +265,8 @@ def test_front_kernel_choice(fmx_amd, ol):
     assert run(600, lambda f: None) == 3
     assert run(600, lambda f: None, n=T - 12) == 1                                   # (no whole tile)
     assert run(600, lambda f: None, n=2 * T, pre=5) == 1                             # (off the 12-sample grid)
-    assert run(600, lambda f: f.set_param(M.P_LOCAL_OSCILLATOR, 200000, 7)) == 1     # (a local oscillator somewhere)
+    assert run(600, lambda f: f.set_param(M.P_LOCAL_OSCILLATOR, 200000, 7)) == 3     # (a local oscillator somewhere: since round 6 the complex-tap variant, fmx_front4lo.hip)
+    assert run(200, lambda f: f.set_param(M.P_LOCAL_OSCILLATOR, 200000, 7), n=64 * T) == 1     # (... which wants a channel per compute unit)
     assert run(600, lambda f: f.set_param(M.P_BANDWIDTH, 0, 3)) == 1                 # (the input filter off somewhere)
     assert run(600, lambda f: f.set_param(M.P_FRONT_KERNEL, 1)) == 1
     assert run(40, lambda f: None, n=64 * T) == 1                                    # (too few channels: split in time on front_kernel)

@@ -263,3 +263,74 @@ def test_a_promoted_batch_goes_back_to_the_folded_filters(fmx_amd, ol):
     import re as _re
     assert _re.fullmatch(r"3+1+3+1+3+", runs), runs
     assert all(applied[b_] - b_ <= 5 for b_ in applied) and len(applied) == 2
+
+
+def test_matrix_pipe_input_filter_with_local_oscillators(fmx_amd, ol):
+    """the matrix-pipe stage A for channels with a local oscillator (BASELINE configs[2]).  fmx_front4lo.hip puts the mix into the TAPS --
+    sum_m (G[m] table[(m lo) mod R]) x[n - m], a complex tap set per channel built from the reference's own oscillator table, times the oscillator's value at
+    the output's newest sample -- and leaves the samples alone.  300 channels on three wide-band streams (carriers at 0, +200 kHz, -400 kHz, +2.5 kHz off tune), DC
+    offsets (one beyond the limiter), oscillators on the 200 kHz raster and off it (2500 Hz: a period of 4608 samples; -4000), none, an IQ balance, RF DC removal
+    off; calls of whole tiles, of tiles and a remainder (front_kernel takes it: the history goes back and forth between the kernels), an oscillator
+    switched off and another switched on in mid-stream.  The fm-rate IQ against front_kernel on the same calls to 1.5e-6 of its scale, PCM to 3e-6; every kind
+    against an oracle chain with the same oscillator: PCM <= 1e-5."""
+    nch, nst = 300, 3
+    blocks = [T * 40, T * 33 + 480, T * 27 - 480, T * 40, T * 32, T * 32]          # (204 tiles = 19.125 of the oracle's blocks: the last 2048 samples stay pending there)
+    n = sum(blocks)
+    carriers = [0.0, 200000.0, -400000.0, 2500.0]
+    iq = np.zeros((nst, n, 2), np.float32)
+    for sidx in range(nst):
+        acc = np.zeros((n, 2), np.float64)
+        for k, o in enumerate(carriers):
+            acc += ol.synth_iq(n, offsetHz=o, leftHz=300.0 + 170 * k + 40 * sidx, rightHz=800.0 + 90 * k + 25 * sidx, carrierAmp=0.2)
+        acc[:, 0] += (0.0, 0.006, -0.02)[sidx]; acc[:, 1] += (0.0, -0.004, 0.015)[sidx]
+        iq[sidx] = acc.astype(np.float32)
+    kinds = [dict(loFrequency=0), dict(loFrequency=200000), dict(loFrequency=-400000), dict(loFrequency=2500), dict(loFrequency=200000, attL=0.9, attR=1.1),
+             dict(loFrequency=-400000, dcRemove=0), dict(loFrequency=2500, inputFilterBw=130000)]
+    pid = dict(inputFilterBw=M.P_BANDWIDTH, attL=M.P_ATTENUATION_L, attR=M.P_ATTENUATION_R, loFrequency=M.P_LOCAL_OSCILLATOR, dcRemove=M.P_DC_REMOVE)
+    kind_of = [(c // nst) % len(kinds) for c in range(nch)]
+    events = {3: [(1, dict(loFrequency=0))], 4: [(0, dict(loFrequency=2500))]}     # call -> [(kind, setters)]
+    outs = []
+    for kernel in (0, 1):
+        f = _batch(fmx_amd, nch, nst, max(blocks), kernel=kernel)
+        for c in range(nch):
+            for k, v in kinds[kind_of[c]].items():
+                f.set_param(pid[k], v, c)
+        pcm, taps, pos = [], [], 0
+        for b, nb_ in enumerate(blocks):
+            for kd, ev in events.get(b, []):
+                for c in range(nch):
+                    if kind_of[c] == kd:
+                        for k, v in ev.items():
+                            f.set_param(pid[k], v, c)
+            pcm.append(f.process_host(iq[:, pos:pos + nb_])); pos += nb_
+            assert f.last_front_kernel() == (3 if kernel == 0 else 1), (b, f.last_front_kernel())
+            taps.append(np.stack([f.tap(M.TAP_FM_IQ, f.last_fm_samples(), c) for c in range(3 * len(kinds))]))
+        outs.append((np.concatenate(pcm, axis=1), np.concatenate(taps, axis=1)))
+        del f
+    (pa, ta), (pb, tb) = outs
+    scale = float(np.abs(tb).max())
+    ez = float(np.abs(ta.astype(np.float64) - tb).max())
+    ep = float(np.abs(pa.astype(np.float64) - pb).max())
+    print("\n[matrix-pipe stage A with oscillators, %d channels] against front_kernel: fm-rate IQ max |diff| %.2e of a scale of %.2f, PCM max |diff| %.2e" % (nch, ez, scale, ep))
+    assert ez <= 1.5e-6 * scale and ep <= 3e-6
+    for c in range(nst, nch):
+        assert np.array_equal(pa[c], pa[c % (nst * len(kinds))]) or c < nst * len(kinds)
+    worst = 0.0
+    for c in range(nst * len(kinds)):
+        kd, sidx = kind_of[c], c % nst
+        if sidx != 1 and kd not in (0, 1):
+            continue                                                            # (every kind on the stream with the DC offsets, the two that change on all three)
+        kw = dict(dict(inputFilterBw=165000), **kinds[kd])
+        ch = ol.OracleChain(**kw)
+        ref, pos = [], 0
+        for b, nb_ in enumerate(blocks):
+            pass
+        # (the oracle takes a setter at its next 16384-sample block: the library's calls end off that grid here, so the oracle is fed in its own blocks with the
+        # setters at the library's call boundaries rounded UP to a block -- the kinds that change are compared up to the change only)
+        stop = sum(blocks[:min([b for b in events if any(k_ == kd for k_, _ in events[b])] + [len(blocks)])])
+        m = (stop // 16384) * 16384
+        po = ch.process(iq[sidx, :m])
+        e = rms(pa[c][:po.shape[0]] - po)
+        worst = max(worst, e)
+        assert e <= 1e-5, (c, kinds[kd], e)
+    print("[matrix-pipe stage A with oscillators] worst PCM rms against the oracle %.2e" % worst)
