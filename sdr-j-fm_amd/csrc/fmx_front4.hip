@@ -148,18 +148,20 @@ template <int FMT, bool NTL>
 __global__ __launch_bounds__(NTHR, 3) __attribute__((amdgpu_waves_per_eu(3, 3))) void front4_kernel(DeviceTables T, DeviceBuffers B, CallGeom G,
                                                                                                        const void *__restrict__ iq_raw) {
     constexpr int BPS = (FMT == 0) ? 8 : (FMT == 3 ? 4 : 2);          // bytes per complex sample
-    struct ChanLds {
+    struct __attribute__((aligned(16))) ChanLds {      // (a multiple of 16 bytes: the second channel's planes are read 16 bytes at a time -- an 8-byte
+                                                       // member added in round 6 cost the stage 25 % until this said so)
         h16 pl[4][PL];                     // hi re, hi im, lo re, lo im of the channel's newest six tiles (and the mirror)
         h16 ta[LO ? 5 : 3][TA_N];          // reversed tap table: hi, lo, and the boxcar of ones that sums a column; LO: the taps' imaginary parts, hi and lo
-        float2 hb[LO ? 28 : 1];            // LO, a call's last tile: RfDC in front of its columns 103 .. 128 (the processed history the next call finds)
         float2 mb[8][MB_N];                // RfDC boundaries behind tile ti, slot = ti & 7
         int carry_seq;                     // tiles whose mailbox slot is published
         int scat_seq[NW], fir_seq[NW];     // per wave: tiles scattered / tiles whose filter has read everything, + 1
         int texp[NW + 2];                     // biased exponent (bfp_E) of the scale of the tile in ring slot w (written with the slot, read by the next tile's filter
                                            // like the slot's last 288 samples: the same counters order both); [NW]: of the call's history
         int pad_[3];
+        float2 hb[LO ? 28 : 2];            // LO, a call's last tile: RfDC in front of its columns 103 .. 128 (the processed history the next call finds)
     };
     __shared__ __attribute__((aligned(16))) ChanLds Lall[CPW];
+    static_assert(sizeof(ChanLds) % 16 == 0, "every channel's planes on a 16-byte boundary");
 
     const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (64 * NW));
     const int ch_raw = (int)blockIdx.x * CPW + half;

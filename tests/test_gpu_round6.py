@@ -334,3 +334,42 @@ def test_matrix_pipe_input_filter_with_local_oscillators(fmx_amd, ol):
         worst = max(worst, e)
         assert e <= 1e-5, (c, kinds[kd], e)
     print("[matrix-pipe stage A with oscillators] worst PCM rms against the oracle %.2e" % worst)
+
+
+@pytest.mark.parametrize("variant", ["pieces", "rds"])
+def test_promotion_beside_the_other_forms_of_a_call(fmx_amd, ol, variant):
+    """The promotion of a batch to the block machines where a call is not one plain launch sequence: "pieces" -- 1100 channels on the PLL decoder, whose calls are made
+    in overlapping pieces on three streams (FMX_P_CALL_PIECES; the promotion falls into a call's first piece, the rest of the call runs on the machines) --
+    and "rds" -- 70 channels decoding RDS_2 (the RDS path reads stage B's rows and has block phases of its own).  A new input-filter width in mid-stream; PCM of every
+    call against the oracle taking the setter when the library says so, the RDS bits at the end."""
+    if variant == "pieces":
+        nch, block, nb, kw, at = 1100, 16384 * 6, 24, dict(decoder=2), 8
+    else:
+        nch, block, nb, kw, at = 70, 16384 * 3, 44, dict(rdsMode=2), 14
+    iq = ol.synth_iq(nb * block, rds=1, rdsLevel=0.05, rdsBitsSeed=3)
+    f = _batch(fmx_amd, nch, 1, block)
+    if variant == "pieces":
+        f.set_param(M.P_FM_DECODER, 2)
+    else:
+        f.set_param(M.P_RDS_MODE, 2)
+    o = ol.OracleChain(inputFilterBw=165000, **kw)
+    waiting, applied, worst, pieces = False, None, 0.0, []
+    for b in range(nb):
+        if b == at:
+            f.set_param(M.P_BANDWIDTH, 130000); waiting = True
+        if waiting and f.filter_change_due() <= 0:
+            o.configure(inputFilterBw=130000); waiting, applied = False, b
+        x = iq[b * block:(b + 1) * block]
+        pg, po = f.process_host(x[None]), o.process(x)
+        pieces.append(f.last_call_pieces())
+        e = rms(pg[nch - 1] - po)
+        worst = max(worst, e)
+        assert e <= 1e-5, (b, e, pieces)
+        assert np.array_equal(pg[0], pg[nch - 1])
+    print("\n[promotion, %s: %d channels] setter at call %d applied at %s, pieces per call %s, worst call %.2e" % (variant, nch, at, applied, pieces, worst))
+    assert applied is not None
+    if variant == "pieces":
+        assert max(pieces[:at]) >= 2
+    else:
+        bg, bo = f.rds_bits(nch - 1, 8192), o.rds_bits()
+        assert len(bg) == len(bo) and len(bg) > 1500 and np.array_equal(bg[-1200:], bo[-1200:])
