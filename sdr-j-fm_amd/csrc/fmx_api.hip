@@ -156,6 +156,8 @@ struct fmx_handle_s {
     int64_t last_filter_event_g = 0;     // stream position at which a filter setter was last applied (ola_take_settings)
     std::vector<int64_t> origin_in, origin_au;   // per channel: the stream position (input samples / fm samples) at which the filter's block counter was last 0, as far as a
                                          // FOLDED handle knows it (0 from fmx_create; the machines' own counters at a demotion)
+    bool call_head = true;               // the launch sequence being enqueued is the first of its fmx_process_* call (a call may be made in pieces, run_call): a handle
+                                         // changes its filter structure there only -- fmx_filter_change_due speaks of CALLS
     bool promo_pending = false;          // a filter setter arrived behind the first call
     bool promo_recapture = false;        // ... and a setter of what pre_kernel applies (RF DC removal, balance, oscillator) behind it: the kept samples start over
     int64_t promo_have = 0, promo_g0 = 0;   // samples kept per stream, and the stream position of the first
@@ -993,8 +995,17 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
                  int64_t pcm_stride, int64_t *n_frames, hipStream_t s, const PipePiece *pp = nullptr);
 // One call of the boundary.  The RDS front end works on blocks of RDS_BLK fm samples, every channel on its own block phase, and one launch sequence covers
 // at most one block boundary per channel: while a channel decodes RDS, a longer call is made in pieces (the chain is invariant to how a stream is cut into calls).
+int run_call_pieces(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
+                    int64_t pcm_stride, int64_t *n_frames, hipStream_t s);
 int run_call(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
              int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
+    h->call_head = true;
+    const int rc = run_call_pieces(h, d_iq, fmt, s16_den, stream_stride, n, d_pcm, pcm_stride, n_frames, s);
+    h->call_head = true;
+    return rc;
+}
+int run_call_pieces(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int64_t stream_stride, int64_t n, float2 *d_pcm,
+                    int64_t pcm_stride, int64_t *n_frames, hipStream_t s) {
     const int64_t PIECE = (int64_t)(RDS_BLK - 1) * h->decim;       // (J1 - J0 <= RDS_BLK whatever the call's phase in the fm-rate grid; decim: input samples per
                                                                    // fm sample at this handle's rate -- 12, 6 or 1 as the reference decimates)
     bool any_rds = false;
@@ -1082,13 +1093,13 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
                 const bool ok = demotable(h);
                 if (!ok || h->promo_recapture) { h->demo_capture = false; h->promo_have = 0; }
                 else if (!h->demo_capture) { h->demo_capture = true; h->promo_have = 0; capture = true; }
-                else if (h->promo_have >= DEMO_TAIL_IN) do_demote = true;
+                else if (h->promo_have >= DEMO_TAIL_IN && h->call_head) do_demote = true;
                 else capture = true;
                 h->promo_recapture = false;
             }
             else if (!h->promo_pending) h->promo_recapture = false;
             else if (h->promo_recapture) { h->promo_recapture = false; h->promo_have = 0; }      // (what pre_kernel applies changed: the kept samples start over, behind this call)
-            else if (h->promo_have >= PROMO_TAIL_IN) do_promote = true;
+            else if (h->promo_have >= PROMO_TAIL_IN && h->call_head) do_promote = true;
             else capture = true;
         }
         if (do_promote) { rc = promote(h, s); if (rc) return rc; }
@@ -1118,6 +1129,7 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     }
     g_launch_err = hipSuccess;
     h->B.lin_rows = (int32_t)h->work_nj;
+    if (capture && h->tail_iq && h->promo_have + n > h->tail_cap) capture = false;      // (cannot happen: a change is applied at the first call boundary behind PROMO_TAIL_IN samples)
     if (capture) {
         if (!h->tail_iq) {
             h->tail_cap = PROMO_TAIL_IN + h->cfg.max_block;
@@ -1265,6 +1277,7 @@ int run_call_one(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, int
     actions_consumed(h, G.J1 > G.J0);
     h->last_J0 = G.J0; h->last_J1 = G.J1;
     h->g_total += n;
+    h->call_head = false;
     if (n_frames) *n_frames = frames;
     return FMX_OK;
 }
