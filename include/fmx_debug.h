@@ -7,7 +7,7 @@
 extern "C" {
 #endif
 /* Streaming bandwidth of GPU `device` in GB/s over `bytes` (>= 1 MiB) of float2 data, the mean of `iters` launches timed with HIP events.
- * mode 0: copy (bytes read + written are counted); mode 1: read 12, write 1 -- the input-filter stage's traffic shape (SURVEY 8d asks for the
+ * mode 0: copy (bytes read + written are counted); mode 1: read 12, write 1 -- the input-filter stage's traffic shape; mode 2: the same reads, nothing written (SURVEY 8d asks for the
  * measured device bandwidth beside the nominal 8 TB/s: bench.py `roofline.measured_stream_bandwidth`). */
 int fmx_debug_stream_bandwidth(int32_t device, int32_t mode, int64_t bytes, int32_t iters, double *gbps);
 /* Per-phase shader-cycle counters of front_kernel (and, in -DSB_FINE_TICKS builds, of stage B), summed over the handle's channels into out[96]

@@ -1316,7 +1316,8 @@ const EnvSwitches &env_switches() {
 // ---- diagnostics: the practical HBM ceiling (SURVEY 8d asks for the measured device-copy bandwidth next to the nominal 8 TB/s)
 namespace fmx {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-// mode 0: dst[i] = src[i] (float2 copy, 16 B per lane per access);  mode 1: stage A's traffic shape: read 12 float2, write 1.
+// mode 0: dst[i] = src[i] (float2 copy, 16 B per lane per access);  mode 1: stage A's traffic shape: read 12 float2, write 1;  mode 2: the same reads and NO
+// write (a sum that is never the sentinel): what this GPU reads at when nothing is written -- the ceiling of `roofline.frac_read_only`.
 template <int MODE>
 __global__ __launch_bounds__(256) void stream_probe_kernel(const f32x4_t *__restrict__ src, f32x4_t *__restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * 256;
@@ -1331,7 +1332,8 @@ __global__ __launch_bounds__(256) void stream_probe_kernel(const f32x4_t *__rest
             f32x4_t a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 6; k++) a += __builtin_nontemporal_load(src + (g * 6 + k) * 64 + lane);
-            reinterpret_cast<float2 *>(dst)[g * 64 + lane] = make_float2(a.x + a.z, a.y + a.w);
+            if (MODE == 2) { if (a.x + a.z == 1.2345e33f) reinterpret_cast<float2 *>(dst)[lane] = make_float2(a.y, a.w); }
+            else reinterpret_cast<float2 *>(dst)[g * 64 + lane] = make_float2(a.x + a.z, a.y + a.w);
         }
     }
 }
@@ -2126,7 +2128,7 @@ int fmx_get_taps(fmx_handle h, int32_t channel, int32_t which, float *dst, int32
 // diagnostics (include/fmx_debug.h): streaming bandwidth of this GPU in GB/s over `bytes` of float2 data, the mean of
 // `iters` launches timed with HIP events.  mode 0: copy (counts bytes read + written); mode 1: read 12, write 1 (stage A's shape).
 int fmx_debug_stream_bandwidth(int32_t device, int32_t mode, int64_t bytes, int32_t iters, double *gbps) {
-    if (!gbps || bytes < (1 << 20) || iters < 1 || (mode != 0 && mode != 1)) return fail(FMX_E_INVALID, "bad argument");
+    if (!gbps || bytes < (1 << 20) || iters < 1 || mode < 0 || mode > 2) return fail(FMX_E_INVALID, "bad argument");
     HIPCHK(hipSetDevice(device));
     const size_t n16 = (size_t)bytes / 16 / (6 * 64) * (6 * 64);
     fmx::f32x4_t *src = nullptr, *dst = nullptr;
@@ -2139,13 +2141,14 @@ int fmx_debug_stream_bandwidth(int32_t device, int32_t mode, int64_t bytes, int3
     for (int it = -2; it < iters; it++) {
         if (it == 0) HIPCHK(hipEventRecord(e0, 0));
         if (mode == 0) hipLaunchKernelGGL(fmx::stream_probe_kernel<0>, dim3(grid), dim3(256), 0, 0, src, dst, n16);
-        else hipLaunchKernelGGL(fmx::stream_probe_kernel<1>, dim3(grid), dim3(256), 0, 0, src, dst, n16);
+        else if (mode == 1) hipLaunchKernelGGL(fmx::stream_probe_kernel<1>, dim3(grid), dim3(256), 0, 0, src, dst, n16);
+        else hipLaunchKernelGGL(fmx::stream_probe_kernel<2>, dim3(grid), dim3(256), 0, 0, src, dst, n16);
     }
     HIPCHK(hipEventRecord(e1, 0));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    const double moved = mode == 0 ? 2.0 * n16 * 16 : n16 * 16 * (1.0 + 1.0 / 12);
+    const double moved = mode == 0 ? 2.0 * n16 * 16 : (mode == 1 ? n16 * 16 * (1.0 + 1.0 / 12) : (double)n16 * 16);
     *gbps = moved * iters / (ms * 1e-3) * 1e-9;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(src); (void)hipFree(dst);
     return FMX_OK;
