@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised soak of the batch path against the oracle (GPU box: `python tests/soak_random.py [first seed] [seeds] [channels] [plain 0|1|2] [setters 0|1]`; a bounded run is in the suite,
+"""Randomised soak of the batch path against the oracle (GPU box: `python tests/soak_random.py [first seed] [seeds] [channels] [plain 0|1|2] [setters 0|1] [ragged 0|1]`; a bounded run is in the suite,
 tests/test_gpu_round6.py::test_randomised_soak_against_the_oracle).
 Per seed: a handle of `channels` channels on five streams with settings drawn at random -- input filter width / off, IQ balance, local oscillator, DC
 removal, all six decoders, the three squelch modes with random thresholds, fm mode, selector, panorama, de-emphasis, volume, audio filter, auto-mono, and an
@@ -7,7 +7,8 @@ RDS decoder (0 .. 3) switched on at a random call (some switched off again later
 where a decoder ran, against an oracle chain taking the same settings and switches.
 plain 1: no oscillator and the input filter on everywhere (the matrix-pipe kernel's population); 2: oscillators, the filter on everywhere (its complex-tap
 variant's, from 256 channels).  setters 1: at the second or third call one channel in seven takes a setBandwidth or a setlfcutoff -- the handle is promoted to the
-block machines (fmx_promote.hip) and the oracle chains take the setter at the call fmx_filter_change_due () names."""
+block machines (fmx_promote.hip) and the oracle chains take the setter at the call fmx_filter_change_due () names.  ragged 1: calls of any length (not
+multiples of the decimation: the f32 kernel takes what the matrix-pipe kernels leave, history handed back and forth); RDS decoders on from the first call."""
 import importlib, os, sys
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,6 +20,7 @@ nseeds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 nch = int(sys.argv[3]) if len(sys.argv) > 3 else 70
 plain = int(sys.argv[4]) if len(sys.argv) > 4 else 0        # 1: no local oscillator, the input filter on everywhere (what the matrix-pipe input filter takes)
 setters = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+ragged = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 TOL = 1e-5
 nstreams = 5
 blocks = [16384 * 3 * k for k in (5, 4, 6, 5, 3, 5)]                    # (the oracle applies a switch at its next 16384-sample block: calls are whole blocks, their fm counts multiples of 8)
@@ -26,6 +28,10 @@ n = sum(blocks)
 bad = edge = 0
 for seed in range(seed0, seed0 + nseeds):
     rng = np.random.default_rng(seed)
+    if ragged:
+        # (a switch is applied by the oracle at its next 16384-sample block and by the library at the call: ragged calls take none)
+        cuts = np.sort(np.random.default_rng(9000 + seed).integers(20000, n - 20000, size=6))
+        blocks = [int(v) for v in np.diff(np.concatenate([[0], cuts, [n]])) if v > 0]
     streams = []
     for sidx in range(nstreams):
         x = ol.synth_iq(n, stereo=1 if sidx != 1 else 0, noiseSeed=100 * seed + sidx, noiseSigma=0.002 * sidx, rds=1, rdsLevel=0.05, rdsBitsSeed=seed * 10 + sidx,
@@ -44,6 +50,7 @@ for seed in range(seed0, seed0 + nseeds):
         cfgs.append(kw)
         mode = int(rng.choice([0, 0, 1, 2, 2, 3]))
         rdsplan.append((mode, int(rng.integers(0, 4)), int(rng.choice([99, 99, 4, 5]))))            # (mode, on at call, off at call)
+        if ragged: rdsplan[-1] = (mode, 0, 99)
     # (drawn from a generator of its own: the draws above stay what they were without setters)
     rng2 = np.random.default_rng(7000 + seed)
     ev_call = int(rng2.integers(1, 3))
@@ -129,7 +136,7 @@ for seed in range(seed0, seed0 + nseeds):
             # of seed 2 channel 58 at 1.26e-5 -- 2 draws in 40 move the oracle further, the median draw 2.7e-6 (six draws, as first written, saw 4.4e-6).
             xs = iq[chan_stream[c]]
             self_e = self_e0 = 0.0
-            first_only = e <= tol          # (the first call alone is out: the draws need not go further)
+            first_only = e <= tol and not ragged         # (the first call alone is out: the draws need not go further; a ragged call's frame count is the library's own)
             for trial in range(48):
                 if (e <= tol or self_e > tol) and (e0 <= tol or self_e0 > tol): break
                 filt = cfgs[c]["inputFilterBw"] > 0

@@ -106,7 +106,8 @@ def test_randomised_soak_against_the_oracle():
     click; the 300-channel plain run is the population the matrix-pipe kernel takes, the 300 channels with oscillators its complex-tap variant's; the last
     run hands one channel in seven a setBandwidth / setlfcutoff in mid-stream (the batch is promoted to the block machines, fmx_promote.hip).  A channel out
     of tolerance counts unless the oracle leaves the tolerance against ITSELF under another draw of its own input filter's rounding noise (soak_random.py)."""
-    for args in (("22", "1", "70", "0"), ("42", "1", "70", "0"), ("7", "1", "300", "1"), ("1", "1", "300", "2"), ("10", "1", "70", "0", "1")):
+    for args in (("22", "1", "70", "0"), ("42", "1", "70", "0"), ("7", "1", "300", "1"), ("1", "1", "300", "2"), ("10", "1", "70", "0", "1"),
+                 ("30", "1", "300", "1", "0", "1")):          # (the last: calls of ragged lengths)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_random.py"), *args], capture_output=True, text=True, timeout=900)
         print(r.stdout[-1500:])
         assert r.returncode == 0, (args, r.stdout[-3000:], r.stderr[-2000:])
