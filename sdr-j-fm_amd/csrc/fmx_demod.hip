@@ -209,8 +209,10 @@ __device__ __forceinline__ float fdiv_inrange(float n, float d) {
 // argument and sent to the general form for the WHOLE WAVE; everything else takes the arm without them.
 template <bool LIMITED>
 __device__ __forceinline__ float lut_atan2_chain(const float *__restrict__ ppy, float y, float x) {
-    const bool odd = __builtin_amdgcn_classf(x, 0x2f7) || __builtin_amdgcn_classf(y, 0x207);
-    if (__any(odd)) return lut_atan2(ppy, y, x);
+    // (x and y are the two components of conj (nco) * sample with a finite nco: an infinity or a NaN in y comes from one in the sample, and then x -- a sum
+    // of products with BOTH of the sample's components -- is not finite either: x's class answers for y's)
+    const bool odd = __builtin_amdgcn_classf(x, 0x2f7);
+    if (__builtin_expect(__any(odd), 0)) return lut_atan2(ppy, y, x);
     asm volatile("" : "+v"(x), "+v"(y));          // (keeps the general form's comparisons, which it shares with this arm, out of the path in front of the test)
     const float St = (float)3.14159265358979323846, Sh = St * 0.5f;
     const bool xpos = x > 0.f, ypos = y >= 0.f;
@@ -218,8 +220,12 @@ __device__ __forceinline__ float lut_atan2_chain(const float *__restrict__ ppy, 
     const bool same = xpos == ypos;
     const float size = same ? (float)ATAN_N : -(float)ATAN_N;
     const float num = swap ? x : y, den = swap ? y : x;
-    const float q = LIMITED ? fdiv_inrange(size * num, den) : size * num / den;
-    const int idx = (int)((double)q + 0.5);
+    // (LIMITED: the quotient with ONE correction step, fdiv_fast -- the IEEE quotient but for rare half-way cases, and what is used is its integer part:
+    // over 4.3e9 operand pairs of this range 3 quotients and NO index differ, tools/ubench/fdiv_check.hip)
+    const float q = LIMITED ? fdiv_fast(size * num, den) : size * num / den;
+    // (int)((double) q + 0.5), Xtan2.cpp:70-90, in two f32 operations: q + (0.5 - 2^-25) rounds into the same integer interval for EVERY f32 q in
+    // [-0, 8192] -- all 1 174 405 121 of them compared, tools/ubench/atan_round_check.py (0.5 itself fails at q = 0.5 - 2^-25: the sum is a tie that rounds to 1)
+    const int idx = (int)(q + 0.49999997f);
     const float tv = ppy[idx];
     // (Sh * +-1, St * +-1 are exact; flat selects: a nested conditional becomes divergent branches here)
     const float ah = ypos ? Sh : -Sh, at = ypos ? St : -St;
@@ -281,7 +287,9 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     // the arc-tangent's corner arguments) behind a wave-uniform test.
     const bool any_pll = HAS_CHAIN && (!MIXED || __any(use_pll || use_am)), any_am = HAS_AM && (!MIXED || __any(use_am)), any_lsq = HAS_LSQ && __any(lsq);
     const bool on_pll = !MIXED || use_pll || use_am;
-    const float beta = T.pll_beta, omb = 1 - T.pll_beta, plo = T.pll_lo, phi = T.pll_hi, pce = T.pll_center;
+    const float beta = T.pll_beta, omb = 1 - T.pll_beta, plo = T.pll_lo, phi = T.pll_hi;
+    float pce = T.pll_center;
+    asm volatile("" : "+v"(pce));       // (kept in a vector register: the compiler moved it there from its scalar one at every sample)
     // (decide: a level-squelch decision may fall due at this sample -- one tile in 600 has one; the others are walked without the look-out)
     auto step = [&](float res, float2 sig, auto decide) __attribute__((always_inline)) -> float {
         float r_am = 0.f;
@@ -294,8 +302,10 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
             // The NCO phase is in [0, 2 pi] (as f32: the update below leaves nothing else, starting from the constructor's 0) and the
             // loop's increment is limited to +-0.95 pi (NcoLLimit / NcoHLimit): SinCos::getComplex's table entry is one multiplication
             // away, and the reference's wrap loops (pllC.cpp:84-89) are at most one turn either way.
-            int idx = (int)((double)nco_phase * SC);
-            idx = idx >= SINCOS_N ? idx - SINCOS_N : idx;
+            // (idx = SINCOS_N -- a phase of exactly 6.2831855f, what a tiny negative phase wraps to -- needs no wrap of its own: sincos_idx_hw_bits folds it
+            // to the first entry, (1, -0.0) for the table's (1, +0.0); the products of a zero differ in the sign of a zero at most, and a zero argument of
+            // the arc-tangent goes to the general form, which does not look at its sign)
+            const int idx = (int)((double)nco_phase * SC);
             float2 nco;
             sincos_idx_hw_bits(idx, &nco.y, &nco.x);
             const float dre = nco.x * sig.x - (-nco.y) * sig.y;      // conj(nco) * signal
@@ -304,10 +314,18 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
             float inc2 = omb * perr + beta * incr;
             inc2 = (inc2 < plo || inc2 > phi) ? pce : inc2;
             const float ph = nco_phase + inc2;
-            const bool over = ph >= 6.2831855f, under = ph < 0.f;                  // ((double) ph >= 2 pi  <=>  ph >= 6.2831855f)
-            const double turn = over ? -FMX_2PI : FMX_2PI;                         // (x - 2 pi is fmod (x, 2 pi) for 2 pi <= x < 4 pi)
-            const float moved = (float)((double)ph + turn);
-            const float phw = (over || under) ? moved : ph;
+            // pllC.cpp:84-89: ph >= 2 pi ((double) ph >= 2 pi  <=>  ph >= 6.2831855f) goes down a turn (x - 2 pi is fmod (x, 2 pi) for 2 pi <= x < 4 pi), ph < 0
+            // up.  One unsigned comparison finds both -- a negative float's bits lie above every positive one's; ph is never -0.0: the phase never is -- and the
+            // turn takes ph's sign: ph - copysign (2 pi, ph).
+            const unsigned phb = __float_as_uint(ph);
+            const bool wrapped = phb >= 0x40c90fdbu;                               // (the bits of 6.2831855f)
+            // (the comparison here, in front of the conversions: its mask is read by the select behind them, and a select straight behind its comparison waits
+            // two issue slots for the mask)
+            asm volatile("" :: "s"(__builtin_amdgcn_ballot_w64(wrapped)));
+            __builtin_amdgcn_sched_barrier(0);
+            const double turn = __hiloint2double((int)(((unsigned)__double2hiint(FMX_2PI) & 0x7fffffffu) | (phb & ~0x7fffffffu)), __double2loint(FMX_2PI));
+            const float moved = (float)((double)ph - turn);
+            const float phw = wrapped ? moved : ph;
             incr = on_pll ? inc2 : incr;
             nco_phase = on_pll ? phw : nco_phase;
             if (HAS_AM && any_am) {                      // decodeAM fm-demodulator.cpp:215-241

@@ -8,6 +8,7 @@ use_null = (len(sys.argv) > 2 and sys.argv[2] == "null")
 n = 230400
 f = pkg.Fmx(ch, max_block=n)
 for p, v in ((m.P_BANDWIDTH, 165000), (m.P_LF_CUTOFF, 15000), (m.P_DEEMPHASIS, 50), (m.P_VOLUME_DB, -6.0)): f.set_param(p, v)
+if len(sys.argv) > 3: f.set_param(m.P_FM_DECODER, int(sys.argv[3]))
 dev = torch.device('cuda', 0)
 iq = bench.synth_device(torch, ch, n, dev)
 pcm = torch.zeros((ch, n // 48 + 96, 2), dtype=torch.float32, device=dev)
