@@ -222,10 +222,11 @@ __host__ __device__ __forceinline__ void sincos_idx_f32(int idx, float *sn, floa
 __device__ __forceinline__ float sin_idx_hw(int idx) {            // 0 <= idx < 192000
     constexpr unsigned HALF = SINCOS_N / 2;
     const unsigned u = (unsigned)idx;
-    const unsigned h = min(u, u - HALF);                           // (u - HALF wraps to a huge value when u < HALF)
+    const unsigned uh = u - HALF;                                  // (wraps to a huge value -- bit 31 set -- exactly when u < HALF)
+    const unsigned h = min(u, uh);
     const unsigned rr = min(h, HALF - h);
     const float s = __builtin_amdgcn_sinf((float)rr * (1.0f / (float)SINCOS_N));
-    return (u >= HALF) ? -s : s;
+    return __uint_as_float(__float_as_uint(s) ^ (~uh & 0x80000000u));      // -s for u >= HALF: the sign put on as a bit (one operation, no comparison and select)
 }
 __device__ __forceinline__ void sincos_idx_hw(int idx, float *sn, float *cs) {      // 0 <= idx < 192000
     constexpr unsigned HALF = SINCOS_N / 2, QUAD = SINCOS_N / 4;

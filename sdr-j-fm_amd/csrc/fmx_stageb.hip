@@ -1464,10 +1464,11 @@ __global__ __launch_bounds__(FB_T, PART == 0 ? SB_WG_PER_SIMD : 4) void stageb_k
                 if (wide) cc = pi_constrain(cur[i]);
                 const float p = (float)(2 * ((double)cc + FMX_PI_4) - (double)used[i]);      // (+ PILOTTESTDELAY = 0, fm-processor.cpp:42: x + 0 = x for x > 0)
                 const double u = __builtin_amdgcn_fract((double)p * INV2PI);
-                int idx = (int)(u * (double)SINCOS_N);               // SinCos::getComplex sincos.cpp:93-97
-                idx = idx >= SINCOS_N ? SINCOS_N - 1 : idx;
+                // SinCos::getComplex sincos.cpp:93-97 (the fraction of a turn is at most 1 - 2^-53, v_fract_f64's own bound: its product with 192000 rounds
+                // below 192000, the index needs no clamp)
+                const int idx = (int)(u * (double)SINCOS_N);
                 float2 e;
-                sincos_idx_hw(idx, &e.y, &e.x);
+                sincos_idx_hw_bits(idx, &e.y, &e.x);
                 float dif = 0.f;
                 if (tag[i] != -2) {
                     if (tag[i] >= 0 && i < nv) sring[(icl + tag[i]) & smask] = make_float2(e.x * dem[i], e.y * dem[i]);
