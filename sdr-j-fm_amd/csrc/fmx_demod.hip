@@ -207,12 +207,15 @@ __device__ __forceinline__ float fdiv_inrange(float n, float d) {
 // compAtan::atan2 (lut_atan2 of fmx_demod_math.h, the same operations) for the loop of pllC: the corner arguments Xtan2.cpp:56-68 answers
 // without its table -- a NaN, an infinity, x = 0 (and a denormal x, for the division's sake) -- are looked for with one v_cmp_class per
 // argument and sent to the general form for the WHOLE WAVE; everything else takes the arm without them.
-template <bool LIMITED>
-__device__ __forceinline__ float lut_atan2_chain(const float *__restrict__ ppy, float y, float x) {
+// `shadow`: work of the caller's that does not depend on this arc-tangent, issued right behind the table read -- a lone wave waits ~64 cycles for the LDS
+// and has nothing else to fill them with (called exactly once, on either path).
+struct NoShadow { __device__ __forceinline__ void operator()() const {} };
+template <bool LIMITED, typename ShadowF = NoShadow>
+__device__ __forceinline__ float lut_atan2_chain(const float *__restrict__ ppy, float y, float x, ShadowF shadow = ShadowF()) {
     // (x and y are the two components of conj (nco) * sample with a finite nco: an infinity or a NaN in y comes from one in the sample, and then x -- a sum
     // of products with BOTH of the sample's components -- is not finite either: x's class answers for y's)
     const bool odd = __builtin_amdgcn_classf(x, 0x2f7);
-    if (__builtin_expect(__any(odd), 0)) return lut_atan2(ppy, y, x);
+    if (__builtin_expect(__any(odd), 0)) { shadow(); return lut_atan2(ppy, y, x); }
     asm volatile("" : "+v"(x), "+v"(y));          // (keeps the general form's comparisons, which it shares with this arm, out of the path in front of the test)
     const float St = (float)3.14159265358979323846, Sh = St * 0.5f;
     const bool xpos = x > 0.f, ypos = y >= 0.f;
@@ -227,6 +230,11 @@ __device__ __forceinline__ float lut_atan2_chain(const float *__restrict__ ppy, 
     // [-0, 8192] -- all 1 174 405 121 of them compared, tools/ubench/atan_round_check.py (0.5 itself fails at q = 0.5 - 2^-25: the sum is a tie that rounds to 1)
     const int idx = (int)(q + 0.49999997f);
     const float tv = ppy[idx];
+    if (!std::is_same<ShadowF, NoShadow>::value) {      // (the caller's work BETWEEN the read and its use: left to itself the compiler packs it behind the wait)
+        __builtin_amdgcn_sched_barrier(0);
+        shadow();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // (Sh * +-1, St * +-1 are exact; flat selects: a nested conditional becomes divergent branches here)
     const float ah = ypos ? Sh : -Sh, at = ypos ? St : -St;
     const float a0 = xpos ? 0.f : at;
@@ -356,6 +364,45 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
         }
         return r;
     };
+    // The PLL decoder, or the AM decoder, alone on every lane (VAR == AV_PLL, AV_AM: the headlines of the pre-pass populations) as a software pipeline: the step above in two parts --
+    // `chain`, pllC's loop (the next sample waits for it), and `tail`, AFC and scaling of the loop's increment (nothing waits for it) -- with the tail of
+    // sample k - 1 issued in the shadow of sample k's table read, and beta * incr in front of the sine unit's latency instead of behind the arc-tangent.  The
+    // same operations on the same values in the same order per variable: bit-identical to `step`.
+    auto tail_am = [&](float res, float inc) __attribute__((always_inline)) -> float {      // decodeAM fm-demodulator.cpp:215-241, as in `step`
+        am = (1.0f - 0.0010f) * am + 0.0010f * res;
+        const float gainLimit = 0.01f;
+        float r = (res - am) / (am < gainLimit ? gainLimit : am);
+        r = (r > 1.0f) ? 1.0f : (r < -1.0f ? -1.0f : r);
+        { const float t1 = c1 * afc, t2 = fmDcAlpha * inc; asm("v_add_f32 %0, %1, %2" : "=v"(afc) : "v"(t1), "v"(t2)); }      // :232
+        return r;
+    };
+    auto tail = [&](float res) __attribute__((always_inline)) -> float {
+        // fm-demodulator.cpp:197.  (the addition as an instruction of its own: left to the compiler it is packed with the arc-tangent's last one into a
+        // v_pk_add_f32 -- behind the wait for the table -- and the whole tail follows it there)
+        { const float t1 = c1 * afc, t2 = fmDcAlpha * res; asm("v_add_f32 %0, %1, %2" : "=v"(afc) : "v"(t1), "v"(t2)); }
+        return fdiv_const(20.0f * (res - afc) * 1.0f, K, rK);               // :198
+    };
+    auto chain = [&](float2 sig, auto shadow) __attribute__((always_inline)) -> float {      // pllC::do_pll pllC.cpp:67-90, as in `step`
+        const float bi = beta * incr;
+        const int idx = (int)((double)nco_phase * SC);
+        float2 nco;
+        sincos_idx_hw_bits(idx, &nco.y, &nco.x);
+        const float dre = nco.x * sig.x - (-nco.y) * sig.y;
+        const float dim = nco.x * sig.y + (-nco.y) * sig.x;
+        const float perr = lut_atan2_chain<!HAS_AM>(atan_lds, dim, dre, shadow);
+        float inc2 = omb * perr + bi;
+        inc2 = (inc2 < plo || inc2 > phi) ? pce : inc2;
+        const float ph = nco_phase + inc2;
+        const unsigned phb = __float_as_uint(ph);
+        const bool wrapped = phb >= 0x40c90fdbu;
+        asm volatile("" :: "s"(__builtin_amdgcn_ballot_w64(wrapped)));
+        __builtin_amdgcn_sched_barrier(0);
+        const double turn = __hiloint2double((int)(((unsigned)__double2hiint(FMX_2PI) & 0x7fffffffu) | (phb & ~0x7fffffffu)), __double2loint(FMX_2PI));
+        const float moved = (float)((double)ph - turn);
+        incr = inc2;
+        nco_phase = wrapped ? moved : ph;
+        return inc2;
+    };
     // a run of samples straight from the work arrays, with the look-out for the metaData snapshot (get_demodDcComponent () behind sample
     // snap_row): the ragged end of a call, and the one tile in 750 the snapshot falls into
     auto slow_rows = [&](int k0, int k1) __attribute__((always_inline)) {
@@ -390,6 +437,19 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
                     x[k] = step(nx[s][u][k], xq, decide);
                 }
             };
+            if constexpr (VAR == AV_PLL || VAR == AV_AM) {
+                float pend = 0.f;
+                auto tail_k = [&](int k) __attribute__((always_inline)) { x[k] = (VAR == AV_AM) ? tail_am(nx[s][u][k], pend) : tail(pend); };
+#pragma unroll
+                for (int k = 0; k < UB; k++) {
+                    const float2 xq = k < UB / 2 ? make_float2(nqa[s][u][2 * k], nqa[s][u][2 * k + 1]) : make_float2(nqb[s][u][(2 * k) % UB], nqb[s][u][(2 * k) % UB + 1]);
+                    const float inc = (k == 0) ? chain(xq, NoShadow()) : chain(xq, [&]() __attribute__((always_inline)) { tail_k(k - 1); });
+                    pend = inc;
+                }
+                tail_k(UB - 1);
+                wst(wd + tb * TS, x);
+                return;
+            }
             // (the variant with everything in it keeps one form of the tile: its loop is 120 KB of code as it is)
             if (HAS_LSQ && (VAR == AV_ALL || (any_lsq && __any(lsq && sq_cnt + UB >= SINCOS_N / 20)))) samples(std::true_type{});
             else samples(std::false_type{});

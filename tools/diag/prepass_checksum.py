@@ -8,9 +8,10 @@ pkg = importlib.import_module("sdr-j-fm_amd"); M = pkg.fmx
 nch, nst, n = 200, 4, 16384 * 3 * 4
 iq = np.stack([ol.synth_iq(3 * n, leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k, noiseSeed=3 + k, noiseSigma=0.01 * k, offsetHz=(0.0, 30000.0, -55000.0, 1200.0)[k]) for k in range(nst)])
 f = pkg.Fmx(nch, streams=nst, stream_of_channel=[c % nst for c in range(nch)], max_block=n)
+mode = os.environ.get("MODE", "mixed")          # mixed | pll | am: one decoder on every channel runs the kernel's variant for that decoder alone
 for c in range(nch):
-    f.set_param(M.P_FM_DECODER, (2, 1, 2, 3, 2)[c % 5], c)
-    f.set_param(M.P_SQUELCH_MODE, (0, 0, 2, 1)[(c // 5) % 4], c)
+    f.set_param(M.P_FM_DECODER, (2, 1, 2, 3, 2)[c % 5] if mode == "mixed" else (2 if mode == "pll" else 1), c)
+    if mode == "mixed": f.set_param(M.P_SQUELCH_MODE, (0, 0, 2, 1)[(c // 5) % 4], c)
 h = hashlib.md5()
 for k in range(3):
     p = f.process_host(np.ascontiguousarray(iq[:, k * n:(k + 1) * n]))
