@@ -790,6 +790,8 @@ static bool any_rds_on(fmx_handle h) { return h->call_any_rds; }     // (as of t
 
 constexpr int PIPE_ROWS_AUTO = 3072;      // fm samples per piece of an overlapping call where pllC runs (two of stage B's segments; measured at 4096 channels:
                                           // 2048 / 3072 / 4608 / 6400 fm samples per piece give 6.37 / 6.18 / 6.46 / 6.79 ms per step, the call made whole 8.24)
+constexpr int PIPE_ROWS_AUTO_PLL = 4608;  // ... where pllC runs for the PLL decoder only (round 6: its chain is 66 issue slots per sample instead of 80 and the launches' own cost counts more:
+                                          // pieces of 3072 x 6 / 4608 x 4 / 5376 x 3 + 3072 / 4608 x 3 + 3072 + 2304 give 5.29 / 5.21 / 4.92 / 4.82 ms per step; the AM decoder stays at 3072: 6.0 against 6.2-6.4)
 constexpr int PIPE_ROWS_AUTO_SQ = 4608;   // ... where only squelches do (noise squelch 6.61 / 5.73 / 5.46 / 5.54 against 5.90 whole, level squelch 5.43 / 4.73 / 4.59 / 4.72 against 5.23)
 constexpr int TAIL_MIN_CHANNELS = 128;    // the second stage-B / C channel group: at least this many channels
 constexpr int PIPE_MIN_CHANNELS = 1024;   // automatic: batches that fill the chip
@@ -1021,9 +1023,14 @@ int run_call_pieces(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, 
         // the host, CallGeom::host_count) and the RF DC level stage B's snapshot reads from stage A's state (a display value that moves by 1e-7 of its
         // distance per sample: it may be the next piece's).
         const int want = h->pipe_rows.load() >= 0 ? h->pipe_rows.load() : env_switches().call_pieces;
-        bool special = false, chain = false;
-        { std::lock_guard<std::mutex> lk(h->mtx); for (auto &p : h->params) { special |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0); chain |= (p.decoder == 2 || p.decoder == 1); } }
-        const int64_t rows = want > 0 ? ((want + 15) / 16) * 16 : (chain ? PIPE_ROWS_AUTO : PIPE_ROWS_AUTO_SQ);
+        bool special = false, chain = false, am_chain = false;
+        { std::lock_guard<std::mutex> lk(h->mtx); for (auto &p : h->params) { special |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0); chain |= (p.decoder == 2 || p.decoder == 1); am_chain |= (p.decoder == 1); } }
+        // (the PLL decoder's chain without the AM decoder's: longer pieces with a short last one, PIPE_ROWS_AUTO_PLL)
+        const bool taper = want < 0 && chain && !am_chain;
+        // (a call too short for two of the PLL decoder's longer pieces is cut into the shorter ones)
+        const int64_t rows = want > 0 ? ((want + 15) / 16) * 16
+                                      : (chain ? ((am_chain || n < 2 * (int64_t)PIPE_ROWS_AUTO_PLL * h->decim) ? PIPE_ROWS_AUTO : PIPE_ROWS_AUTO_PLL) : PIPE_ROWS_AUTO_SQ);
+        const int64_t ends_rows = env_switches().call_pieces_ends >= 0 ? ((env_switches().call_pieces_ends + 15) / 16) * 16 : 0;
         const int64_t half = (h->work_nj / 2) & ~(int64_t)15;
         const int64_t piece = rows * h->decim;
         // (only these batches.  Measured: the headline's batch -- no pre-pass; stage A bound by HBM, stage B by instruction issue -- made in 13 / 6 / 4 / 3 overlapping
@@ -1038,17 +1045,57 @@ int run_call_pieces(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, 
             HIPCHK(hipEventRecord(h->pipe_ev0, s));
             HIPCHK(hipStreamWaitEvent(h->pipe_sA, h->pipe_ev0, 0)); HIPCHK(hipStreamWaitEvent(h->pipe_sB, h->pipe_ev0, 0));
             const int64_t bps = (fmt == 0) ? 8 : (fmt == 3 ? 4 : 2);
-            int64_t total = 0; int k = 0;
-            for (int64_t pos = 0; pos < n; pos += piece, k++) {
+            // the pieces' lengths.  What the call pays beyond the chain of the lone waves is its FIRST piece's stage A (nothing to overlap it with yet) and its
+            // LAST piece's stages B and C (the chain has ended): short end pieces of `ends` fm samples, equal ones in between.
+            std::vector<int64_t> lens;
+            const int64_t ends = ends_rows * h->decim;
+            if (ends > 0 && n >= 2 * ends + piece) {
+                const int64_t inner = n - 2 * ends;
+                int64_t m = (inner + piece / 2) / piece; if (m < 1) m = 1;
+                const int64_t grid = 16 * h->decim;
+                int64_t mid = ((inner / m) / grid) * grid;
+                if (mid / h->decim + 2 > half) { m++; mid = ((inner / m) / grid) * grid; }
+                lens.push_back(ends);
+                for (int64_t i = 0; i < m; i++) lens.push_back(mid);
+                lens.push_back(n - ends - m * mid);
+            }
+            if (!env_switches().call_pieces_list.empty()) {      // (a diagnostic: the pieces' fm samples spelt out; the last one takes what is left)
+                lens.clear(); int64_t used = 0;
+                for (int r : env_switches().call_pieces_list) { const int64_t l = (int64_t)r * h->decim; if (used + l < n) { lens.push_back(l); used += l; } }
+                lens.push_back(n - used);
+            }
+            bool fits = !lens.empty();
+            for (int64_t l : lens) fits = fits && l > 0 && l / h->decim + 2 <= half;
+            if (!fits && taper) {
+                // whole pieces, then the rest (between one and two pieces) as a multiple of stage B's segment and a SHORT last piece of one and a half to two and a
+                // half segments: what follows the chain's end is the last piece's stages B and C (19200 fm samples: 4608 4608 4608 3072 2304)
+                lens.clear();
+                const int64_t seg = (int64_t)1536 * h->decim;           // (stage B's segment, fmx_stageb.hip FB_W)
+                int64_t pos = 0;
+                while (n - pos >= 2 * piece) { lens.push_back(piece); pos += piece; }
+                const int64_t R = n - pos;
+                int64_t a = ((R - 3 * seg / 2) / seg) * seg;
+                if (a > piece) a = piece;
+                if (a >= seg) { lens.push_back(a); lens.push_back(R - a); } else lens.push_back(R);
+                fits = true;
+                for (int64_t l : lens) fits = fits && l > 0 && l / h->decim + 2 <= half;
+            }
+            if (!fits) {
+                lens.clear();
+                for (int64_t pos = 0; pos < n;) {
+                    // (a last piece shorter than half a piece rides with the one before it: the arrays' halves hold a piece and a half)
+                    int64_t len = (n - pos < piece) ? n - pos : piece;
+                    if (n - pos - len > 0 && n - pos - len < piece / 2 && (rows * 3) / 2 + 2 <= half) len = n - pos;
+                    lens.push_back(len); pos += len;
+                }
+            }
+            int64_t total = 0, pos = 0; int k = 0;
+            for (int64_t len : lens) {
                 int64_t got = 0;
                 const PipePiece pp{k};
-                // (a last piece shorter than half a piece rides with the one before it: the arrays' halves hold a piece and a half)
-                int64_t len = (n - pos < piece) ? n - pos : piece;
-                if (n - pos - len > 0 && n - pos - len < piece / 2 && (rows * 3) / 2 + 2 <= half) len = n - pos;
                 const int rc = run_call_one(h, reinterpret_cast<const char *>(d_iq) + pos * bps, fmt, s16_den, stream_stride, len, d_pcm + total, pcm_stride, &got, h->pipe_sB, &pp);
                 if (rc) { (void)hipDeviceSynchronize(); return rc; }
-                total += got;
-                if (len > piece) pos += len - piece;
+                total += got; pos += len; k++;
             }
             HIPCHK(hipEventRecord(h->pipe_evE, h->pipe_sB)); HIPCHK(hipStreamWaitEvent(s, h->pipe_evE, 0));
             h->last_pieces = k;
@@ -1303,7 +1350,8 @@ namespace fmx {
 const EnvSwitches &env_switches() {
     static const EnvSwitches sw = [] {
         EnvSwitches e{};
-        e.call_pieces = env_int("FMX_CALL_PIECES", -1); e.pieces_serial = env_int("FMX_CALL_PIECES_SERIAL", 0) != 0; e.front_kernel = env_int("FMX_FRONT_KERNEL", 0);
+        e.call_pieces = env_int("FMX_CALL_PIECES", -1); e.call_pieces_ends = env_int("FMX_CALL_PIECES_ENDS", -1);
+        if (const char *v = getenv("FMX_CALL_PIECES_LIST")) { for (const char *q = v; *q;) { e.call_pieces_list.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; } } e.pieces_serial = env_int("FMX_CALL_PIECES_SERIAL", 0) != 0; e.front_kernel = env_int("FMX_FRONT_KERNEL", 0);
         e.prof_double = getenv("FMX_PROF_DOUBLE") != nullptr; e.tail_split = env_int("FMX_TAIL_SPLIT", 1) != 0; e.tail_ch = env_int("FMX_TAIL_CH", 0);
         e.stageb_split = env_int("FMX_STAGEB_SPLIT", -1); e.rows_off_split = getenv("FMX_ROWS_OFF_SPLIT") != nullptr; e.no_sinpoly = getenv("FMX_DEBUG_NO_SINPOLY") != nullptr;
         e.host_zerocopy = env_int("FMX_HOST_ZEROCOPY", 1) != 0; e.rds_pair = env_int("FMX_RDS_PAIR", 1) != 0;

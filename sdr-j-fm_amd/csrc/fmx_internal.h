@@ -413,6 +413,8 @@ void launch_front4_lo(const DeviceTables &T, const DeviceBuffers &B, const CallG
 // nothing on the per-call path asks the environment.
 struct EnvSwitches {
     int call_pieces;      // FMX_CALL_PIECES: fm samples per piece of an overlapping call (-1: the handle's setting)
+    int call_pieces_ends; // FMX_CALL_PIECES_ENDS: fm samples of such a call's first and last piece (-1: the library's choice)
+    std::vector<int> call_pieces_list;   // FMX_CALL_PIECES_LIST=a,b,c: the pieces' fm samples spelt out (a diagnostic)
     int pieces_serial;    // FMX_CALL_PIECES_SERIAL=1: the same pieces one after the other on the caller's stream
     int front_kernel;     // FMX_FRONT_KERNEL: stage-A kernel where the handle says automatic
     int prof_double;      // FMX_PROF_DOUBLE: a throw-away event in front of each profiling event
