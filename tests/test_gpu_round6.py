@@ -409,3 +409,35 @@ def test_odd_channel_counts_on_the_matrix_pipe(fmx_amd, ol, nch, lo):
         po = ol.OracleChain(inputFilterBw=165000, loFrequency=lo).process(iq[k, :m])
         e = rms(pa[k][:po.shape[0]] - po)
         assert e <= 1e-5, (k, e)
+
+
+@pytest.mark.parametrize("decoder,pieces", [(2, 5), (1, 6)])
+def test_piece_schedule_of_a_prepass_batch(fmx_amd, ol, decoder, pieces):
+    """A batch whose channels run pllC is cut into overlapping pieces (fmx_api.hip run_call_pieces).  Since round 6 the PLL decoder's are 4608 fm samples long with a
+    SHORT last one -- 19200 fm samples: 4608 4608 4608 3072 2304 --, the AM decoder's stay at 3072 (the last 768 ride with the piece before them).  1024 channels
+    on two streams, three calls of 230400 samples: the count of pieces, every channel bit for bit its twin, the two streams within the tolerance of oracle chains
+    fed the calls whole (the chain is invariant to how a stream is cut)."""
+    nch, n = 1024, 230400
+    iq = np.stack([ol.synth_iq(3 * n, leftHz=400.0 + 300 * k, rightHz=700.0 + 200 * k, offsetHz=(0.0, 1500.0)[k]) for k in range(2)])
+    f = _batch(fmx_amd, nch, 2, n)
+    f.set_param(M.P_FM_DECODER, decoder)
+    chains = [ol.OracleChain(inputFilterBw=165000, decoder=decoder) for _ in range(2)]
+    outs, refs = [], [[], []]
+    for b in range(3):
+        x = iq[:, b * n:(b + 1) * n]
+        pg = f.process_host(x)
+        assert f.last_call_pieces() == (pieces if b else 1), (b, f.last_call_pieces())      # (the first call allocates the pre-pass's arrays and runs whole)
+        for c in range(2, nch):
+            assert np.array_equal(pg[c], pg[c % 2]), (b, c)
+        outs.append(pg[:2].copy())
+        for k in range(2):
+            refs[k].append(chains[k].process(x[k]))        # (the oracle works in blocks of 16384 samples: the calls' frame counts differ, the streams do not)
+    pcm = np.concatenate(outs, axis=1)
+    worst = 0.0
+    for k in range(2):
+        po = np.concatenate(refs[k])
+        m = min(pcm.shape[1], po.shape[0])
+        assert m > 0.95 * pcm.shape[1]
+        worst = max(worst, rms(pcm[k][:m] - po[:m]))
+    print("\n[pre-pass batch, decoder %d, %d channels] %d pieces per call; worst call against the oracle %.2e" % (decoder, nch, pieces, worst))
+    assert worst <= 1e-5
