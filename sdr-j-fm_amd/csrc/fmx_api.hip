@@ -797,6 +797,17 @@ constexpr int TAIL_MIN_CHANNELS = 128;    // the second stage-B / C channel grou
 constexpr int PIPE_MIN_CHANNELS = 1024;   // automatic: batches that fill the chip
 constexpr int PLL_SEQ_AUTO_MAX = 64;   // FMX_P_PLL_SOLVER = 0: handles up to this many channels evaluate the pilot PLL sequentially
 
+// the tiled work arrays of the demodulator pre-pass (fmx_demod.hip): limited / unlimited samples in, demodulator output out.  (Allocated by the first call
+// that needs them -- before run_call decides how the call is made: a call in pieces needs them too.)
+int ensure_prepass_arrays(fmx_handle h) {
+    if (h->B.w_iq) return FMX_OK;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMalloc(&h->B.w_iq, sizeof(float2) * (size_t)h->work_nj * h->pitch));
+    HIPCHK(hipMemset(h->B.w_iq, 0, sizeof(float2) * (size_t)h->work_nj * h->pitch));
+    HIPCHK(hipMalloc(&h->B.w_osc, sizeof(float) * (size_t)h->work_nj * h->pitch));
+    HIPCHK(hipMemset(h->B.w_osc, 0, sizeof(float) * (size_t)h->work_nj * h->pitch));
+    return FMX_OK;
+}
 int flush_mailbox(fmx_handle h) {
     std::lock_guard<std::mutex> lk(h->mtx);
     if (h->gain_dirty) { h->gain_pending = true; h->gain_dirty = false; }   // (a change arriving behind this point belongs to the next call, flag and value)
@@ -895,14 +906,7 @@ int flush_mailbox(fmx_handle h) {
         HIPCHK(hipMemcpy(h->d_nsq, h->h_nsq.data(), sizeof(float) * h->h_nsq.size(), hipMemcpyHostToDevice));
         h->T.nsq_coef = h->d_nsq; h->tail_ptrs.push_back(h->d_nsq);
     }
-    if (any_pll && !h->B.w_iq) {
-        // the tiled work arrays of the demodulator pre-pass (fmx_demod.hip): limited / unlimited samples in, demodulator output out
-        HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipMalloc(&h->B.w_iq, sizeof(float2) * (size_t)h->work_nj * h->pitch));
-        HIPCHK(hipMemset(h->B.w_iq, 0, sizeof(float2) * (size_t)h->work_nj * h->pitch));
-        HIPCHK(hipMalloc(&h->B.w_osc, sizeof(float) * (size_t)h->work_nj * h->pitch));
-        HIPCHK(hipMemset(h->B.w_osc, 0, sizeof(float) * (size_t)h->work_nj * h->pitch));
-    }
+    if (any_pll) { const int rc = ensure_prepass_arrays(h); if (rc) return rc; }
     for (int c = 0; c < h->channels; c++) {            // set_squelchValue takes effect at a block start, when it differs (fm-processor.cpp:410-413)
         ChanUser &u = h->user[c];
         if (u.squelch_value != u.squelch_old) {
@@ -1026,6 +1030,7 @@ int run_call_pieces(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, 
         bool special = false, chain = false, am_chain = false;
         { std::lock_guard<std::mutex> lk(h->mtx); for (auto &p : h->params) { special |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0); chain |= (p.decoder == 2 || p.decoder == 1); am_chain |= (p.decoder == 1); } }
         // (the PLL decoder's chain without the AM decoder's: longer pieces with a short last one, PIPE_ROWS_AUTO_PLL)
+        if (special && !h->ola_mode) { const int rc = ensure_prepass_arrays(h); if (rc) return rc; }
         const bool taper = want < 0 && chain && !am_chain;
         // (a call too short for two of the PLL decoder's longer pieces is cut into the shorter ones)
         const int64_t rows = want > 0 ? ((want + 15) / 16) * 16

@@ -426,7 +426,7 @@ def test_piece_schedule_of_a_prepass_batch(fmx_amd, ol, decoder, pieces):
     for b in range(3):
         x = iq[:, b * n:(b + 1) * n]
         pg = f.process_host(x)
-        assert f.last_call_pieces() == (pieces if b else 1), (b, f.last_call_pieces())      # (the first call allocates the pre-pass's arrays and runs whole)
+        assert f.last_call_pieces() == pieces, (b, f.last_call_pieces())
         for c in range(2, nch):
             assert np.array_equal(pg[c], pg[c % 2]), (b, c)
         outs.append(pg[:2].copy())
