@@ -153,7 +153,9 @@ struct AtanArmF { int idx; float A; bool neg; };
 __device__ __forceinline__ AtanArmF atan_arm_plain(float y, float x, bool *odd) {
     const float St = (float)3.14159265358979323846, Sh = St * 0.5f;
     // v_cmp_class masks: 0x001 sNaN 0x002 qNaN 0x004 -inf 0x010 -denormal 0x020 -0 0x040 +0 0x080 +denormal 0x200 +inf (denormal x: to the general form, whatever the denormal mode makes of it)
-    *odd = *odd || __builtin_amdgcn_classf(x, 0x2f7) || __builtin_amdgcn_classf(y, 0x207);
+    // (the caller's x = I I1 + Q Q1 and y = Q I1 - I Q1 are sums of products that hold all four of its inputs: an infinity or a NaN in y comes from one of them,
+    // and then x is not finite either -- x's class answers for y's)
+    *odd = *odd || __builtin_amdgcn_classf(x, 0x2f7);
     const bool xpos = x > 0.f, ypos = y >= 0.f;
     const bool swap = !(fabsf(x) >= fabsf(y));
     const bool same = xpos == ypos;
@@ -162,7 +164,11 @@ __device__ __forceinline__ AtanArmF atan_arm_plain(float y, float x, bool *odd) 
     int idx = (int)(fdiv_fast(size * num, den) + 0.5f);
     AtanArmF a;
     a.idx = idx < 0 ? 0 : (idx > ATAN_N ? ATAN_N : idx);
-    a.A = swap ? (ypos ? Sh : -Sh) : (xpos ? 0.f : (ypos ? St : -St));
+    // (Sh * +-1, St * +-1 are exact; FLAT selects: the nested conditional  swap ? (ypos ? Sh : -Sh) : (xpos ? 0 : (ypos ? St : -St))  became divergent branches --
+    // a dozen exec-mask instructions per sample in stage B's discriminator)
+    const float ah = ypos ? Sh : -Sh, at = ypos ? St : -St;
+    const float a0 = xpos ? 0.f : at;
+    a.A = swap ? ah : a0;
     a.neg = same == swap;
     return a;
 }
