@@ -369,7 +369,8 @@ __device__ __forceinline__ void afc_body(DeviceTables T, DeviceBuffers B, CallGe
     // sample k - 1 issued in the shadow of sample k's table read, and beta * incr in front of the sine unit's latency instead of behind the arc-tangent.  The
     // same operations on the same values in the same order per variable: bit-identical to `step`.
     auto tail_am = [&](float res, float inc) __attribute__((always_inline)) -> float {      // decodeAM fm-demodulator.cpp:215-241, as in `step`
-        am = (1.0f - 0.0010f) * am + 0.0010f * res;
+        // (the additions as instructions of their own, as in `tail`: packed with the arc-tangent's last one they take the divisions behind the wait with them)
+        { const float t1 = (1.0f - 0.0010f) * am, t2 = 0.0010f * res; asm("v_add_f32 %0, %1, %2" : "=v"(am) : "v"(t1), "v"(t2)); }
         const float gainLimit = 0.01f;
         float r = (res - am) / (am < gainLimit ? gainLimit : am);
         r = (r > 1.0f) ? 1.0f : (r < -1.0f ? -1.0f : r);
