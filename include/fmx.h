@@ -153,7 +153,7 @@ typedef enum {
                                   channel's samples one after the other, one wave per 64 channels) would leave the GPU idle for most of such a call:
                                   the library cuts the call into pieces -- the chain does not depend on how a stream is cut into calls -- and runs the
                                   input filter of piece k + 1 and the stereo / audio stages of piece k - 1 while the recurrences walk piece k.
-                                  -1 = automatic (default): 3072 (AM decoder), 4608 with a short last piece (PLL decoder alone: 19200 fm samples are cut 4608 4608 4608 3072 2304)
+                                  -1 = automatic (default): 3840 (AM decoder) or 4608 (PLL decoder alone) with a short last piece (19200 fm samples are cut 4608 4608 4608 3840 1536)
                                   or 4608 (squelches only) for handles of 1024 channels and more, calls of two pieces and more, no RDS decoder on, no second converter;
                                   0 = never; n > 0: pieces of n fm samples (rounded up to 16) for any handle above 64 channels.  Takes effect at the next call. */
     /* actions (value ignored) */

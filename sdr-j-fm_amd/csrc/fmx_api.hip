@@ -791,7 +791,8 @@ static bool any_rds_on(fmx_handle h) { return h->call_any_rds; }     // (as of t
 constexpr int PIPE_ROWS_AUTO = 3072;      // fm samples per piece of an overlapping call where pllC runs (two of stage B's segments; measured at 4096 channels:
                                           // 2048 / 3072 / 4608 / 6400 fm samples per piece give 6.37 / 6.18 / 6.46 / 6.79 ms per step, the call made whole 8.24)
 constexpr int PIPE_ROWS_AUTO_PLL = 4608;  // ... where pllC runs for the PLL decoder only (round 6: its chain is 66 issue slots per sample instead of 80 and the launches' own cost counts more:
-                                          // pieces of 3072 x 6 / 4608 x 4 / 5376 x 3 + 3072 / 4608 x 3 + 3072 + 2304 give 5.29 / 5.21 / 4.92 / 4.82 ms per step; the AM decoder stays at 3072: 6.0 against 6.2-6.4)
+                                          // pieces of 3072 x 6 / 4608 x 4 / 5376 x 3 + 3072 / 4608 x 3 + 3072 + 2304 / 4608 x 3 + 3840 + 1536 give 5.29 / 5.21 / 4.92 / 4.82 / 4.83 ms per step)
+constexpr int PIPE_ROWS_AUTO_AM = 3840;   // ... where the AM decoder runs (its chain is longer per sample): 3072 x 6 / 3840 x 4 + 2304 + 1536 / 3840 x 4 + 1536 + 2304 / 3072 x 5 + 2304 + 1536 give 6.0-6.1 / 5.72 / 5.93 / 5.77 ms per step
 constexpr int PIPE_ROWS_AUTO_SQ = 4608;   // ... where only squelches do (noise squelch 6.61 / 5.73 / 5.46 / 5.54 against 5.90 whole, level squelch 5.43 / 4.73 / 4.59 / 4.72 against 5.23)
 constexpr int TAIL_MIN_CHANNELS = 128;    // the second stage-B / C channel group: at least this many channels
 constexpr int PIPE_MIN_CHANNELS = 1024;   // automatic: batches that fill the chip
@@ -1029,12 +1030,13 @@ int run_call_pieces(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, 
         const int want = h->pipe_rows.load() >= 0 ? h->pipe_rows.load() : env_switches().call_pieces;
         bool special = false, chain = false, am_chain = false;
         { std::lock_guard<std::mutex> lk(h->mtx); for (auto &p : h->params) { special |= (p.decoder == 2 || p.decoder == 1 || p.squelch_mode != 0); chain |= (p.decoder == 2 || p.decoder == 1); am_chain |= (p.decoder == 1); } }
-        // (the PLL decoder's chain without the AM decoder's: longer pieces with a short last one, PIPE_ROWS_AUTO_PLL)
         if (special && !h->ola_mode) { const int rc = ensure_prepass_arrays(h); if (rc) return rc; }
-        const bool taper = want < 0 && chain && !am_chain;
+        // (pllC's chain: longer pieces with a short last one, PIPE_ROWS_AUTO_PLL / _AM)
+        const bool taper = want < 0 && chain;
         // (a call too short for two of the PLL decoder's longer pieces is cut into the shorter ones)
         const int64_t rows = want > 0 ? ((want + 15) / 16) * 16
-                                      : (chain ? ((am_chain || n < 2 * (int64_t)PIPE_ROWS_AUTO_PLL * h->decim) ? PIPE_ROWS_AUTO : PIPE_ROWS_AUTO_PLL) : PIPE_ROWS_AUTO_SQ);
+                                      : (chain ? (n < 2 * (int64_t)(am_chain ? PIPE_ROWS_AUTO_AM : PIPE_ROWS_AUTO_PLL) * h->decim ? PIPE_ROWS_AUTO : (am_chain ? PIPE_ROWS_AUTO_AM : PIPE_ROWS_AUTO_PLL))
+                                               : PIPE_ROWS_AUTO_SQ);
         const int64_t ends_rows = env_switches().call_pieces_ends >= 0 ? ((env_switches().call_pieces_ends + 15) / 16) * 16 : 0;
         const int64_t half = (h->work_nj / 2) & ~(int64_t)15;
         const int64_t piece = rows * h->decim;
@@ -1072,14 +1074,14 @@ int run_call_pieces(fmx_handle h, const void *d_iq, int32_t fmt, float s16_den, 
             bool fits = !lens.empty();
             for (int64_t l : lens) fits = fits && l > 0 && l / h->decim + 2 <= half;
             if (!fits && taper) {
-                // whole pieces, then the rest (between one and two pieces) as a multiple of stage B's segment and a SHORT last piece of one and a half to two and a
-                // half segments: what follows the chain's end is the last piece's stages B and C (19200 fm samples: 4608 4608 4608 3072 2304)
+                // whole pieces, then the rest (between one and two pieces) as a multiple of half a segment of stage B's and a SHORT last piece of one segment to one
+                // and a half: what follows the chain's end is the last piece's stages B and C (19200 fm samples: 4608 4608 4608 3840 1536; AM decoder: 3840 x 4, 2304, 1536)
                 lens.clear();
                 const int64_t seg = (int64_t)1536 * h->decim;           // (stage B's segment, fmx_stageb.hip FB_W)
                 int64_t pos = 0;
                 while (n - pos >= 2 * piece) { lens.push_back(piece); pos += piece; }
                 const int64_t R = n - pos;
-                int64_t a = ((R - 3 * seg / 2) / seg) * seg;
+                int64_t a = ((R - seg) / (seg / 2)) * (seg / 2);
                 if (a > piece) a = piece;
                 if (a >= seg) { lens.push_back(a); lens.push_back(R - a); } else lens.push_back(R);
                 fits = true;

@@ -414,7 +414,7 @@ def test_odd_channel_counts_on_the_matrix_pipe(fmx_amd, ol, nch, lo):
 @pytest.mark.parametrize("decoder,pieces", [(2, 5), (1, 6)])
 def test_piece_schedule_of_a_prepass_batch(fmx_amd, ol, decoder, pieces):
     """A batch whose channels run pllC is cut into overlapping pieces (fmx_api.hip run_call_pieces).  Since round 6 the PLL decoder's are 4608 fm samples long with a
-    SHORT last one -- 19200 fm samples: 4608 4608 4608 3072 2304 --, the AM decoder's stay at 3072 (the last 768 ride with the piece before them).  1024 channels
+    SHORT last one -- 19200 fm samples: 4608 4608 4608 3840 1536 --, the AM decoder's 3840 (3840 x 4, 2304, 1536).  1024 channels
     on two streams, three calls of 230400 samples: the count of pieces, every channel bit for bit its twin, the two streams within the tolerance of oracle chains
     fed the calls whole (the chain is invariant to how a stream is cut)."""
     nch, n = 1024, 230400
